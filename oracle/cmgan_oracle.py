@@ -1,0 +1,283 @@
+"""CPU restatement of the CMGAN generator forward path (torch, fp32, functional).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Parity status: PINNED against the
+reference's own modules run in the build container (tests/golden/*.npz, made by
+tests/golden/make_golden.py from /root/reference/src; checked by
+tests/test_oracle_golden.py).  The reference ships no golden vectors or tests of
+its own for this path.
+
+Every function takes the reference ``state_dict`` (``sd``) plus a key prefix and
+cites the reference lines it restates.  Paths are relative to /root/reference/.
+The code is written functionally (no nn.Module tree), with the layout flips,
+concatenations and the rel-pos gather re-expressed, so it doubles as the
+executable specification the HIP kernels are written against.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+EPS = 1e-5  # LayerNorm / InstanceNorm2d / BatchNorm1d default eps
+
+
+# --------------------------------------------------------------------------- #
+# front / back end: src/evaluation.py:21-53, src/utils.py:20-39
+# --------------------------------------------------------------------------- #
+def rms_scale(wav: torch.Tensor) -> torch.Tensor:
+    """c = sqrt(L / sum(x^2)) per row (src/evaluation.py:21, src/train.py:75-79)."""
+    return torch.sqrt(wav.size(-1) / torch.sum(wav ** 2.0, dim=-1))
+
+
+def stft(wav: torch.Tensor, n_fft: int = 400, hop: int = 100) -> torch.Tensor:
+    """[B, L] -> [B, F, T, 2] with the reference's torch.stft settings
+    (src/evaluation.py:36-38): periodic Hamming window, center/reflect pad,
+    one-sided, un-normalised.  torch 2.x needs return_complex=True; the legacy
+    real view is restored with view_as_real."""
+    win = torch.hamming_window(n_fft, dtype=wav.dtype)
+    spec = torch.stft(wav, n_fft, hop, window=win, onesided=True, return_complex=True)
+    return torch.view_as_real(spec)
+
+
+def power_compress(spec: torch.Tensor) -> torch.Tensor:
+    """[B, F, T, 2] -> [B, 2, F, T]; mag**0.3 with the phase kept (src/utils.py:20-29)."""
+    re, im = spec[..., 0], spec[..., 1]
+    mag = torch.sqrt(re * re + im * im)
+    phase = torch.atan2(im, re)
+    m = mag ** 0.3
+    return torch.stack([m * torch.cos(phase), m * torch.sin(phase)], dim=1)
+
+
+def power_uncompress(real: torch.Tensor, imag: torch.Tensor) -> torch.Tensor:
+    """[B, 1, F, T] x2 -> [B, 1, F, T, 2]; mag**(1/0.3) (src/utils.py:32-39)."""
+    mag = torch.sqrt(real * real + imag * imag)
+    phase = torch.atan2(imag, real)
+    m = mag ** (1.0 / 0.3)
+    return torch.stack([m * torch.cos(phase), m * torch.sin(phase)], dim=-1)
+
+
+def istft(spec: torch.Tensor, n_fft: int = 400, hop: int = 100) -> torch.Tensor:
+    """[B, F, T, 2] -> [B, hop*(T-1)] (src/evaluation.py:44-50)."""
+    win = torch.hamming_window(n_fft, dtype=spec.dtype)
+    return torch.istft(torch.view_as_complex(spec.contiguous()), n_fft, hop,
+                       window=win, onesided=True)
+
+
+def stft_compress(wav: torch.Tensor, n_fft: int = 400, hop: int = 100) -> torch.Tensor:
+    """[B, L] -> model input [B, 2, T, F] (src/evaluation.py:36-39)."""
+    return power_compress(stft(wav, n_fft, hop)).permute(0, 1, 3, 2).contiguous()
+
+
+def uncompress_istft(est_real: torch.Tensor, est_imag: torch.Tensor,
+                     n_fft: int = 400, hop: int = 100) -> torch.Tensor:
+    """model outputs 2x[B, 1, T, F] -> [B, hop*(T-1)] (src/evaluation.py:41-50)."""
+    r, i = est_real.permute(0, 1, 3, 2), est_imag.permute(0, 1, 3, 2)
+    return istft(power_uncompress(r, i).squeeze(1), n_fft, hop)
+
+
+# --------------------------------------------------------------------------- #
+# conformer: src/models/conformer.py
+# --------------------------------------------------------------------------- #
+def layer_norm(sd, p, x):
+    """nn.LayerNorm(64) (conformer.py:68,161,214)."""
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], EPS)
+
+
+def feed_forward(sd, p, x):
+    """Scale(0.5, PreNorm(FeedForward)) (conformer.py:136-148, 54-72, 211-212).
+    ``p`` is e.g. 'TSCB_1.time_conformer.ff1'."""
+    h = layer_norm(sd, p + ".fn.norm", x)
+    h = F.linear(h, sd[p + ".fn.fn.net.0.weight"], sd[p + ".fn.fn.net.0.bias"])
+    h = h * torch.sigmoid(h)                                  # Swish, conformer.py:25-27
+    h = F.linear(h, sd[p + ".fn.fn.net.3.weight"], sd[p + ".fn.fn.net.3.bias"])
+    return 0.5 * h
+
+
+def attention(sd, p, x, heads: int = 4, max_pos: int = 512):
+    """PreNorm(Attention) with Shaw relative positions (conformer.py:75-133).
+    bias[i,j] = q_i . E[clamp(i-j, +-512) + 512]; the reference materialises
+    E[dist] as [n, n, d]; here q E^T is formed once ([.., n, 1025]) and gathered
+    along the relative index - the same sums, a Toeplitz read."""
+    n = x.shape[-2]
+    h = layer_norm(sd, p + ".norm", x)
+    q = F.linear(h, sd[p + ".fn.to_q.weight"])
+    kv = F.linear(h, sd[p + ".fn.to_kv.weight"])
+    k, v = kv[..., : kv.shape[-1] // 2], kv[..., kv.shape[-1] // 2:]
+    d = q.shape[-1] // heads
+    split = lambda t: t.reshape(t.shape[0], n, heads, d).transpose(1, 2)   # b h n d
+    q, k, v = split(q), split(k), split(v)
+    scale = d ** -0.5
+    dots = torch.matmul(q, k.transpose(-1, -2)) * scale
+    emb = sd[p + ".fn.rel_pos_emb.weight"]                                  # [1025, d]
+    idx = torch.arange(n)
+    rel = (idx[:, None] - idx[None, :]).clamp(-max_pos, max_pos) + max_pos   # [n, n]
+    qe = torch.matmul(q, emb.t())                                           # b h n 1025
+    pos = torch.gather(qe, -1, rel.expand(q.shape[0], heads, n, n)) * scale
+    attn = torch.softmax(dots + pos, dim=-1)
+    out = torch.matmul(attn, v).transpose(1, 2).reshape(x.shape[0], n, heads * d)
+    return F.linear(out, sd[p + ".fn.to_out.weight"], sd[p + ".fn.to_out.bias"])
+
+
+def conv_module(sd, p, x, kernel: int = 31):
+    """ConformerConvModule, eval mode (conformer.py:151-176, 30-48)."""
+    h = layer_norm(sd, p + ".net.0", x).transpose(1, 2)                    # b c n
+    h = F.conv1d(h, sd[p + ".net.2.weight"], sd[p + ".net.2.bias"])
+    a, g = h.chunk(2, dim=1)
+    h = a * torch.sigmoid(g)                                               # GLU
+    pad = kernel // 2
+    h = F.pad(h, (pad, pad - (kernel + 1) % 2))
+    h = F.conv1d(h, sd[p + ".net.4.conv.weight"], sd[p + ".net.4.conv.bias"],
+                 groups=h.shape[1])
+    h = F.batch_norm(h, sd[p + ".net.5.running_mean"], sd[p + ".net.5.running_var"],
+                     sd[p + ".net.5.weight"], sd[p + ".net.5.bias"], False, 0.1, EPS)
+    h = h * torch.sigmoid(h)
+    h = F.conv1d(h, sd[p + ".net.7.weight"], sd[p + ".net.7.bias"])
+    return h.transpose(1, 2)
+
+
+def conformer_block(sd, p, x, stages: dict | None = None):
+    """ConformerBlock.forward (conformer.py:216-222).  x: [N, L, 64].
+    ``stages`` (optional dict) receives the residual stream after each sub-module."""
+    pre = (p + ".") if p else ""
+    x = feed_forward(sd, pre + "ff1", x) + x
+    if stages is not None: stages["ff1"] = x
+    x = attention(sd, pre + "attn", x) + x
+    if stages is not None: stages["attn"] = x
+    x = conv_module(sd, pre + "conv", x) + x
+    if stages is not None: stages["conv"] = x
+    x = feed_forward(sd, pre + "ff2", x) + x
+    if stages is not None: stages["ff2"] = x
+    return layer_norm(sd, pre + "post_norm", x)
+
+
+# --------------------------------------------------------------------------- #
+# generator: src/models/generator.py
+# --------------------------------------------------------------------------- #
+def _in_prelu(sd, norm, prelu, x):
+    x = F.instance_norm(x, weight=sd[norm + ".weight"], bias=sd[norm + ".bias"], eps=EPS)
+    return F.prelu(x, sd[prelu + ".weight"])
+
+
+def dense_block(sd, p, x):
+    """DilatedDenseNet.forward (generator.py:39-47): 4 x {pad(top=dil, l/r=1),
+    conv(2x3, dilation (dil,1)), InstanceNorm, PReLU, cat newest-first}."""
+    skip = x
+    out = x
+    for i in range(1, 5):
+        dil = 2 ** (i - 1)
+        out = F.pad(skip, (1, 1, dil, 0))
+        out = F.conv2d(out, sd[f"{p}.conv{i}.weight"], sd[f"{p}.conv{i}.bias"], dilation=(dil, 1))
+        out = _in_prelu(sd, f"{p}.norm{i}", f"{p}.prelu{i}", out)
+        skip = torch.cat([out, skip], dim=1)
+    return out
+
+
+def dense_encoder(sd, x_in):
+    """DenseEncoder.forward (generator.py:65-69).  [B,3,T,F] -> [B,64,T,F']."""
+    p = "dense_encoder"
+    x = F.conv2d(x_in, sd[p + ".conv_1.0.weight"], sd[p + ".conv_1.0.bias"])
+    x = _in_prelu(sd, p + ".conv_1.1", p + ".conv_1.2", x)
+    x = dense_block(sd, p + ".dilated_dense", x)
+    x = F.conv2d(x, sd[p + ".conv_2.0.weight"], sd[p + ".conv_2.0.bias"], stride=(1, 2), padding=(0, 1))
+    return _in_prelu(sd, p + ".conv_2.1", p + ".conv_2.2", x)
+
+
+def tscb(sd, p, x):
+    """TSCB.forward (generator.py:92-99): time conformer over T for every (b,f),
+    then frequency conformer over F' for every (b,t), each with an outer residual."""
+    b, c, t, f = x.shape
+    xt = x.permute(0, 3, 2, 1).reshape(b * f, t, c)
+    xt = conformer_block(sd, p + ".time_conformer", xt) + xt
+    xf = xt.reshape(b, f, t, c).permute(0, 2, 1, 3).reshape(b * t, f, c)
+    xf = conformer_block(sd, p + ".freq_conformer", xf) + xf
+    return xf.reshape(b, t, f, c).permute(0, 3, 1, 2)
+
+
+def sub_pixel(sd, p, x, r: int = 2):
+    """SPConvTranspose2d (generator.py:112-119): out[b,c,t,2f+k] = conv[b,64k+c,t,f]."""
+    y = F.conv2d(F.pad(x, (1, 1, 0, 0)), sd[p + ".conv.weight"], sd[p + ".conv.bias"])
+    b, ch, t, w = y.shape
+    return y.reshape(b, r, ch // r, t, w).permute(0, 2, 3, 4, 1).reshape(b, ch // r, t, w * r)
+
+
+def mask_decoder(sd, x):
+    """MaskDecoder.forward (generator.py:133-139).  [B,64,T,F'] -> [B,1,T,F]."""
+    p = "mask_decoder"
+    x = dense_block(sd, p + ".dense_block", x)
+    x = sub_pixel(sd, p + ".sub_pixel", x)
+    x = F.conv2d(x, sd[p + ".conv_1.weight"], sd[p + ".conv_1.bias"])
+    x = _in_prelu(sd, p + ".norm", p + ".prelu", x)
+    x = F.conv2d(x, sd[p + ".final_conv.weight"], sd[p + ".final_conv.bias"])
+    a = sd[p + ".prelu_out.weight"].view(1, 1, 1, -1)          # slope per frequency bin
+    return torch.where(x >= 0, x, a * x)
+
+
+def complex_decoder(sd, x):
+    """ComplexDecoder.forward (generator.py:151-156).  [B,64,T,F'] -> [B,2,T,F]."""
+    p = "complex_decoder"
+    x = dense_block(sd, p + ".dense_block", x)
+    x = sub_pixel(sd, p + ".sub_pixel", x)
+    x = _in_prelu(sd, p + ".norm", p + ".prelu", x)
+    return F.conv2d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"])
+
+
+def tscnet_forward(sd, x, stages: dict | None = None):
+    """TSCNet.forward (generator.py:174-196).  x: [B,2,T,F] -> 2 x [B,1,T,F]."""
+    re, im = x[:, 0:1], x[:, 1:2]
+    mag = torch.sqrt(re * re + im * im)
+    phase = torch.atan2(im, re)
+    h = dense_encoder(sd, torch.cat([mag, x], dim=1))
+    if stages is not None: stages["encoder"] = h
+    for b in range(1, 5):
+        h = tscb(sd, f"TSCB_{b}", h)
+        if stages is not None: stages[f"tscb{b}"] = h
+    mask = mask_decoder(sd, h)
+    cplx = complex_decoder(sd, h)
+    if stages is not None:
+        stages["mask"] = mask
+        stages["complex"] = cplx
+    out_mag = mask * mag
+    real = out_mag * torch.cos(phase) + cplx[:, 0:1]
+    imag = out_mag * torch.sin(phase) + cplx[:, 1:2]
+    return real, imag
+
+
+# --------------------------------------------------------------------------- #
+# whole pipeline: src/evaluation.py:12-58 (enhance_one_track, minus file I/O)
+# --------------------------------------------------------------------------- #
+def chunk_rows(padded_len: int, cut_len: int) -> int:
+    """Batch rows for long audio (evaluation.py:30-34)."""
+    if padded_len <= cut_len:
+        return 1
+    rows = int(math.ceil(padded_len / cut_len))
+    while 100 % rows != 0:
+        rows += 1
+    return rows
+
+
+@torch.no_grad()
+def enhance(sd, noisy: torch.Tensor, cut_len: int = 16000 * 16, n_fft: int = 400, hop: int = 100):
+    """noisy: [1, L] float32 in [-1, 1] -> enhanced [L] (evaluation.py:21-53)."""
+    c = rms_scale(noisy)
+    noisy = noisy * c[:, None]
+    length = noisy.size(-1)
+    padded = int(math.ceil(length / 100)) * 100
+    noisy = torch.cat([noisy, noisy[:, : padded - length]], dim=-1)
+    rows = chunk_rows(padded, cut_len)
+    if rows > 1:
+        noisy = noisy.reshape(rows, -1)
+    spec = stft_compress(noisy, n_fft, hop)
+    real, imag = tscnet_forward(sd, spec)
+    audio = uncompress_istft(real, imag, n_fft, hop) / c
+    return audio.flatten()[:length]
+
+
+@torch.no_grad()
+def enhance_batch(sd, wav: torch.Tensor, n_fft: int = 400, hop: int = 100):
+    """Batched fixed-length form used by the benchmark: per-row RMS scale
+    (train.py:75-79), STFT, generator, ISTFT, un-scale.  wav: [B, L], L % hop == 0."""
+    c = rms_scale(wav)
+    spec = stft_compress(wav * c[:, None], n_fft, hop)
+    real, imag = tscnet_forward(sd, spec)
+    return uncompress_istft(real, imag, n_fft, hop) / c[:, None]

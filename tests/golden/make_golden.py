@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory from the REFERENCE implementation.
+
+Run in the build container only (needs /root/reference, which does not exist on
+the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports the reference's own ``models.generator`` / ``models.conformer`` /
+``utils`` from /root/reference/src, loads the deterministic weights from
+``oracle/weights.py`` into them (strict), runs them on small seeded inputs on
+CPU and stores inputs + outputs as ``*.npz``.  ``evaluation.py`` itself cannot
+be imported (torchaudio/natsort/soundfile/pesq are absent and it parses
+sys.argv), so its 20-line glue (src/evaluation.py:21-53) is driven here through
+the reference's ``power_compress`` / ``power_uncompress`` / ``TSCNet`` with the
+torch>=2 adapters for ``torch.stft`` / ``torch.istft``.
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/src")
+sys.dont_write_bytecode = True
+
+from models.conformer import ConformerBlock            # noqa: E402  (reference)
+from models.generator import TSCNet                    # noqa: E402  (reference)
+import utils as ref_utils                              # noqa: E402  (reference)
+
+from oracle.weights import conformer_state_dict, make_state_dict, synthetic_clips  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def rnd(shape, seed, scale=1.0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((scale * rng.standard_normal(shape)).astype(np.float32))
+
+
+def save(name, **arrs):
+    out = {k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()}
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print(f"{name}: " + ", ".join(f"{k}{tuple(v.shape)}" for k, v in out.items()))
+
+
+def ref_stft(x, n_fft=400, hop=100):
+    return torch.view_as_real(torch.stft(x, n_fft, hop, window=torch.hamming_window(n_fft),
+                                         onesided=True, return_complex=True))
+
+
+def ref_istft(spec, n_fft=400, hop=100):
+    return torch.istft(torch.view_as_complex(spec.contiguous()), n_fft, hop,
+                       window=torch.hamming_window(n_fft), onesided=True)
+
+
+def ref_enhance(model, noisy, cut_len, n_fft=400, hop=100):
+    """src/evaluation.py:21-53 driven through the reference's own functions."""
+    c = torch.sqrt(noisy.size(-1) / torch.sum((noisy ** 2.0), dim=-1))
+    noisy = torch.transpose(noisy, 0, 1)
+    noisy = torch.transpose(noisy * c, 0, 1)
+    length = noisy.size(-1)
+    frame_num = int(np.ceil(length / 100))
+    padded_len = frame_num * 100
+    padding_len = padded_len - length
+    noisy = torch.cat([noisy, noisy[:, :padding_len]], dim=-1)
+    if padded_len > cut_len:
+        batch_size = int(np.ceil(padded_len / cut_len))
+        while 100 % batch_size != 0:
+            batch_size += 1
+        noisy = torch.reshape(noisy, (batch_size, -1))
+    noisy_spec = ref_stft(noisy, n_fft, hop)
+    noisy_spec = ref_utils.power_compress(noisy_spec).permute(0, 1, 3, 2)
+    est_real, est_imag = model(noisy_spec)
+    est_real, est_imag = est_real.permute(0, 1, 3, 2), est_imag.permute(0, 1, 3, 2)
+    est_spec_uncompress = ref_utils.power_uncompress(est_real, est_imag).squeeze(1)
+    est_audio = ref_istft(est_spec_uncompress, n_fft, hop)
+    est_audio = est_audio / c
+    return torch.flatten(est_audio)[:length]
+
+
+def main():
+    # -- key/shape manifest of the reference state_dict ------------------------
+    model = TSCNet(num_channel=64, num_features=201).eval()
+    manifest = {k: list(v.shape) for k, v in model.state_dict().items()}
+    with open(os.path.join(HERE, "state_dict_manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=True)
+    sd = make_state_dict(seed=0, num_features=201)
+    model.load_state_dict(sd, strict=True)
+
+    # -- 1. front/back end ------------------------------------------------------
+    wav = synthetic_clips(2, 800, seed=1)
+    spec = ref_stft(wav)                                   # [2,201,9,2]
+    comp = ref_utils.power_compress(spec)                  # [2,2,201,9]
+    unc = ref_utils.power_uncompress(comp[:, 0:1], comp[:, 1:2])   # [2,1,201,9,2]
+    back = ref_istft(unc.squeeze(1))
+    save("stft.npz", wav=wav, spec=spec, compressed=comp, uncompressed=unc, istft=back)
+
+    # -- 2. one conformer block, sub-module by sub-module ----------------------
+    csd = conformer_state_dict(seed=3)
+    blk = ConformerBlock(dim=64, dim_head=16, heads=4, conv_kernel_size=31,
+                         attn_dropout=0.2, ff_dropout=0.2).eval()
+    blk.load_state_dict(csd, strict=True)
+    x = rnd((3, 37, 64), 11)
+    s1 = blk.ff1(x) + x
+    s2 = blk.attn(s1) + s1
+    s3 = blk.conv(s2) + s2
+    s4 = blk.ff2(s3) + s3
+    out = blk.post_norm(s4)
+    assert torch.equal(out, blk(x))
+    save("conformer.npz", x=x, ff1=s1, attn=s2, conv=s3, ff2=s4, out=out)
+
+    # -- 3. attention beyond max_pos_emb (clamp active, n = 600) ---------------
+    xl = rnd((1, 600, 64), 12)
+    save("attention_long.npz", x=xl, out=blk.attn(xl))
+
+    # -- 4. TSCNet on a short spectrogram, with stage taps ---------------------
+    xin = rnd((2, 2, 9, 201), 13, 0.5)
+    mag = torch.sqrt(xin[:, 0:1] ** 2 + xin[:, 1:2] ** 2)
+    enc = model.dense_encoder(torch.cat([mag, xin], dim=1))
+    t1 = model.TSCB_1(enc)
+    t4 = model.TSCB_4(model.TSCB_3(model.TSCB_2(t1)))
+    mask = model.mask_decoder(t4)
+    cplx = model.complex_decoder(t4)
+    real, imag = model(xin)
+    save("tscnet.npz", x=xin, encoder=enc, tscb1=t1.contiguous(), tscb4=t4.contiguous(),
+         mask=mask, complex=cplx, real=real, imag=imag)
+
+    # -- 5. whole pipeline: ragged length, and the >cut_len chunking rule ------
+    noisy = synthetic_clips(1, 2350, seed=2)
+    save("pipeline.npz", noisy=noisy, enhanced=ref_enhance(model, noisy, 16000 * 16),
+         enhanced_chunked=ref_enhance(model, noisy, 1000), cut_len_chunked=np.int64(1000))
+
+    # -- 6. 48 kHz variant: n_fft 1200 / hop 300, F = 601 ----------------------
+    m48 = TSCNet(num_channel=64, num_features=601).eval()
+    sd48 = make_state_dict(seed=5, num_features=601)
+    m48.load_state_dict(sd48, strict=True)
+    x48 = rnd((1, 2, 5, 601), 14, 0.5)
+    r48, i48 = m48(x48)
+    save("tscnet48.npz", x=x48, real=r48, imag=i48)
+
+
+if __name__ == "__main__":
+    main()

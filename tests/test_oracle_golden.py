@@ -1,0 +1,107 @@
+"""Pins the oracle (oracle/cmgan_oracle.py) against fixtures produced by the
+reference's own modules (tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, rel_err
+from oracle import cmgan_oracle as O
+from oracle.weights import conformer_state_dict, make_state_dict
+
+TOL = 2e-5   # fp32 re-association noise between two CPU formulations of the same sums
+
+
+@pytest.fixture(scope="module")
+def sd():
+    return make_state_dict(seed=0, num_features=201)
+
+
+def test_state_dict_manifest_matches_reference():
+    with open(os.path.join(GOLDEN, "state_dict_manifest.json")) as f:
+        manifest = json.load(f)
+    sd = make_state_dict(0, 201)
+    assert len(manifest) == 359
+    assert set(manifest) == set(sd)
+    for k, shape in manifest.items():
+        assert list(sd[k].shape) == shape, k
+
+
+def test_weights_are_deterministic():
+    a, b = make_state_dict(7), make_state_dict(7)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = make_state_dict(8)
+    assert not torch.equal(a["dense_encoder.conv_1.0.weight"], c["dense_encoder.conv_1.0.weight"])
+
+
+def test_stft_compress_uncompress_istft():
+    g = load_golden("stft.npz")
+    spec = O.stft(g["wav"])
+    assert rel_err(spec, g["spec"]) < 1e-6
+    comp = O.power_compress(spec)
+    assert rel_err(comp, g["compressed"]) < 1e-6
+    unc = O.power_uncompress(comp[:, 0:1], comp[:, 1:2])
+    assert rel_err(unc, g["uncompressed"]) < 1e-6
+    assert rel_err(O.istft(unc.squeeze(1)), g["istft"]) < 1e-6
+    # round trip through the model-layout helpers
+    x = O.stft_compress(g["wav"])
+    assert x.shape == (2, 2, 9, 201)
+    back = O.uncompress_istft(x[:, 0:1], x[:, 1:2])
+    assert rel_err(back, g["wav"]) < 1e-5
+
+
+def test_conformer_block_stages():
+    g = load_golden("conformer.npz")
+    csd = conformer_state_dict(seed=3)
+    stages = {}
+    out = O.conformer_block(csd, "", g["x"], stages)
+    for name in ("ff1", "attn", "conv", "ff2"):
+        assert rel_err(stages[name], g[name]) < TOL, name
+    assert rel_err(out, g["out"]) < TOL
+
+
+def test_attention_rel_pos_clamp_beyond_512():
+    g = load_golden("attention_long.npz")
+    csd = conformer_state_dict(seed=3)
+    out = O.attention(csd, "attn", g["x"])
+    assert rel_err(out, g["out"]) < TOL
+
+
+def test_tscnet_stages_and_output(sd):
+    g = load_golden("tscnet.npz")
+    stages = {}
+    real, imag = O.tscnet_forward(sd, g["x"], stages)
+    assert rel_err(stages["encoder"], g["encoder"]) < TOL
+    assert rel_err(stages["tscb1"], g["tscb1"]) < TOL
+    assert rel_err(stages["tscb4"], g["tscb4"]) < TOL
+    assert rel_err(stages["mask"], g["mask"]) < TOL
+    assert rel_err(stages["complex"], g["complex"]) < TOL
+    assert rel_err(real, g["real"]) < TOL
+    assert rel_err(imag, g["imag"]) < TOL
+
+
+def test_tscnet_48k_variant():
+    g = load_golden("tscnet48.npz")
+    sd48 = make_state_dict(seed=5, num_features=601)
+    real, imag = O.tscnet_forward(sd48, g["x"])
+    assert rel_err(real, g["real"]) < TOL
+    assert rel_err(imag, g["imag"]) < TOL
+
+
+def test_pipeline_ragged_and_chunked(sd):
+    g = load_golden("pipeline.npz")
+    out = O.enhance(sd, g["noisy"])
+    assert out.shape == (2350,)
+    assert rel_err(out, g["enhanced"]) < 5e-5
+    out_c = O.enhance(sd, g["noisy"], cut_len=int(g["cut_len_chunked"]))
+    assert rel_err(out_c, g["enhanced_chunked"]) < 5e-5
+
+
+def test_chunk_rows_rule():
+    # evaluation.py:30-34: smallest divisor of 100 that is >= ceil(len / cut_len)
+    assert O.chunk_rows(2400, 1000) == 4
+    assert O.chunk_rows(256000, 256000) == 1
+    assert O.chunk_rows(256100, 256000) == 2
+    assert O.chunk_rows(3 * 256000, 256000) == 4      # 3 does not divide 100
+    assert O.chunk_rows(6 * 256000 + 100, 256000) == 10
