@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the CMGAN generator forward path on MI355X (BASELINE.json metric:
+enhanced audio frames/sec, 16 kHz, 2 s clips, batch 32 per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" = one pass of the whole device pipeline (RMS scale -> STFT -> power compress ->
+TSCNet -> power uncompress -> ISTFT) over one batch of 32 synthetic 2 s clips per GPU that
+are already resident in HBM.  For N > 1 the driver launches one rank per GPU with
+torch.distributed.run; utterances are sharded by rank (weak scaling: 32 clips per GPU), the
+forward needs no collective, and each step ends with ONE all-reduce of two scalars
+(RCCL over xGMI), as north_star specifies.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+CLIP_LEN = 32000          # 2 s @ 16 kHz                       (src/train.py:22)
+BATCH_PER_GPU = 32        # BASELINE.json configs[1]
+N_FFT, HOP = 400, 100
+T_FRAMES = CLIP_LEN // HOP + 1                                 # 321 (src/train.py:53)
+F_BINS, F2 = 201, 101
+FP32_MFMA_PEAK_TF = 157.3                                      # MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def flops_per_clip():
+    """Algorithmic FLOPs (2 x MAC) per 2 s clip by kernel family."""
+    P, P2, T = T_FRAMES * F_BINS, T_FRAMES * F2, T_FRAMES
+    per_tok_ffn = 2 * (64 * 256 + 256 * 64)
+    fl = {
+        "conv_in": 2 * 3 * 64 * P,
+        "conv_dense": 491520 * P + 2 * 491520 * P2,
+        "conv_1x3": 2 * 3 * 64 * 64 * P2,
+        "conv_subpixel": 2 * 2 * 3 * 64 * 128 * P2,
+        "tail_proj": 2 * (64 * 2 + 64 * 4) * T * 2 * F2,
+        "ffn": 8 * per_tok_ffn * P2,            # ff1 of the 8 conformers
+        "ffn_post": 8 * per_tok_ffn * P2,       # ff2 (+ post-norm) of the 8 conformers
+        "qkv": 8 * 2 * 64 * 192 * P2,
+        "outproj": 8 * 2 * 64 * 64 * P2,
+        "attn": 4 * 384 * (F2 * T * T + T * F2 * F2),
+        "pw1glu": 8 * 2 * 64 * 256 * P2,
+        "dwconv": 8 * 2 * 31 * 128 * P2,
+        "pw2": 8 * 2 * 128 * 64 * P2,
+    }
+    return fl
+
+
+def cpu_baseline(sd, seconds_budget=20.0):
+    """The oracle (CPU restatement of the reference path, torch fp32 on the host cores) timed on a
+    bounded sample of the same workload: B=1 clips of the same shape, repeated."""
+    from oracle import cmgan_oracle as O
+    from oracle.weights import synthetic_clips
+    torch.set_num_threads(os.cpu_count() or 1)
+    wav = synthetic_clips(1, CLIP_LEN, seed=0)
+    O.enhance_batch(sd, wav)                                   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.enhance_batch(sd, wav)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds_budget or n >= 12:
+            break
+    return {"value": n * T_FRAMES / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} x (B=1, 2 s clip, full pipeline) after 1 warm-up, {dt:.1f} s of CPU time"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from cmgan_amd import TSCNet, dist as cdist
+    from oracle.weights import make_state_dict, synthetic_clips
+
+    rank, local, world = cdist.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    sd = make_state_dict(seed=0)                               # random-init weights of the architecture
+    model = TSCNet(64, F_BINS, device=dev).load_state_dict(sd).eval()
+    eng = model.engine
+    wav = synthetic_clips(BATCH_PER_GPU, CLIP_LEN, seed=rank).to(dev)    # resident in HBM before timing
+    scal = torch.zeros(2, device=dev)
+
+    def step():
+        out = eng.enhance(wav)
+        # two per-step "loss" scalars (time-domain L1 / L2 against the input) and their single all-reduce
+        d = out - wav
+        scal[0] = d.abs().mean()
+        scal[1] = (d * d).mean()
+        cdist.allreduce_scalars(scal)
+        return out
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(et, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(et.item())
+
+    # ---- per-kernel durations, measured live with HIP events on the launch stream ----------
+    eng.set_profiling(True)
+    agg = {}
+    reps = 3
+    for _ in range(reps):
+        eng.enhance(wav)
+        torch.cuda.synchronize()
+        for name, ms in eng.profile():
+            a = agg.setdefault(name, [0.0, 0])
+            a[0] += ms
+            a[1] += 1
+    eng.set_profiling(False)
+
+    if rank == 0:
+        frames_per_step = world * BATCH_PER_GPU * T_FRAMES
+        ms_per_step = 1e3 * elapsed / args.steps
+        fl = flops_per_clip()
+        total_flop = sum(fl.values()) * BATCH_PER_GPU
+        kern = {k: {"ms_per_step": v[0] / reps, "launches_per_step": v[1] // reps} for k, v in agg.items()}
+        dom = max((k for k in kern if k in fl), key=lambda k: kern[k]["ms_per_step"])
+        dom_tf = fl[dom] * BATCH_PER_GPU / (kern[dom]["ms_per_step"] * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(dom_tf, 2), "peak": FP32_MFMA_PEAK_TF,
+                "unit": "TFLOP/s", "frac": round(dom_tf / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                "launches_per_step": kern[dom]["launches_per_step"],
+                "avg_launch_ms": round(kern[dom]["ms_per_step"] / max(1, kern[dom]["launches_per_step"]), 4)}
+        stft_bytes = BATCH_PER_GPU * (4 * CLIP_LEN + 8 * F_BINS * T_FRAMES)
+        extra = {}
+        if "stft_compress" in kern:
+            gbs = stft_bytes / (kern["stft_compress"]["ms_per_step"] * 1e-3) / 1e9
+            extra["stft_hbm"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        line = {
+            "metric": "enhanced audio frames/sec (16 kHz, 2 s clips, batch 32 per GPU)",
+            "value": frames_per_step * args.steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: batch=32 x 2 s synthetic 16 kHz noisy clips per GPU, n_fft=400 "
+                                   "hop=100, TSCNet(64,201) random-init, full pipeline wav->wav, fp32",
+                       "batch_per_gpu": BATCH_PER_GPU, "global_batch": world * BATCH_PER_GPU,
+                       "frames_per_clip": T_FRAMES, "parallelism": f"dp{world}"},
+            "path_tflops": round(total_flop / (ms_per_step * 1e-3) / 1e12, 2),
+            "path_frac_of_fp32_mfma_peak": round(total_flop / (ms_per_step * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, 4),
+            "roofline": roof,
+            "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(),
+                                                                                   key=lambda kv: -kv[1]["ms_per_step"])},
+        }
+        line.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,97 @@
+"""ctypes binding of libcmgan_hip.so (C ABI: include/cmgan_hip.h).
+
+There is no fallback: if the shared library is missing or does not export a
+declared symbol, importing the binding raises - the HIP kernels ARE the product.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libcmgan_hip.so")
+
+OK = 0
+ABI_VERSION = 1
+
+
+class CmganError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libcmgan_hip error {code}: {msg}")
+        self.code = code
+
+
+class Config(Structure):
+    _fields_ = [(n, c_int32) for n in ("n_fft", "hop", "num_features", "num_channel", "num_tscb",
+                                       "heads", "dim_head", "conv_kernel", "max_pos_emb")]
+
+
+class Taps(Structure):
+    _fields_ = [("encoder_dev", c_void_p), ("tscb_dev", c_void_p * 4), ("mask_dev", c_void_p),
+                ("complex_dev", c_void_p)]
+
+
+class KernelTime(Structure):
+    _fields_ = [("name", c_char_p), ("ms", c_float)]
+
+
+# name -> (restype, argtypes); must list every symbol include/cmgan_hip.h declares
+SIGNATURES = {
+    "cmgan_default_config": (None, [POINTER(Config)]),
+    "cmgan_abi_version": (c_int, []),
+    "cmgan_create": (c_int, [POINTER(c_void_p), POINTER(Config)]),
+    "cmgan_destroy": (None, [c_void_p]),
+    "cmgan_last_error": (c_char_p, [c_void_p]),
+    "cmgan_load_weights": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "cmgan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "cmgan_rms_scale": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "cmgan_num_frames": (c_int, [c_void_p, c_int]),
+    "cmgan_stft_compress": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "cmgan_tscnet_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cmgan_uncompress_istft": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cmgan_enhance": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cmgan_power_compress": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "cmgan_power_uncompress": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "cmgan_conformer_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "cmgan_conformer_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cmgan_tscnet_forward_taps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(Taps), c_void_p, c_size_t, c_void_p]),
+    "cmgan_selftest_mfma": (c_int, [c_void_p, POINTER(c_float)]),
+    "cmgan_set_profiling": (c_int, [c_void_p, c_int]),
+    "cmgan_profile_read": (c_int, [c_void_p, POINTER(KernelTime), c_int]),
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raise loudly if it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -m cmgan_amd.build). "
+            "cmgan_amd has no CPU / eager fallback by design.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.cmgan_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libcmgan_hip ABI version {got}, binding expects {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def default_config() -> Config:
+    cfg = Config()
+    load().cmgan_default_config(ctypes.byref(cfg))
+    return cfg
+
+
+def check(handle, rc: int):
+    if rc != OK:
+        msg = load().cmgan_last_error(handle)
+        raise CmganError(rc, msg.decode() if msg else "?")

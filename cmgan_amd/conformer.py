@@ -1,0 +1,40 @@
+"""Drop-in for ``models.conformer.ConformerBlock`` (reference: src/models/conformer.py:182-222)
+in eval mode: ``forward(x[N,L,64]) -> [N,L,64]`` on the HIP kernels.  Only the configuration
+CMGAN instantiates (generator.py:75-90) is supported."""
+from __future__ import annotations
+
+import torch
+
+from . import packer
+from .engine import Engine
+
+
+class ConformerBlock:
+    def __init__(self, *, dim=64, dim_head=16, heads=4, ff_mult=4, conv_expansion_factor=2,
+                 conv_kernel_size=31, attn_dropout=0.0, ff_dropout=0.0, conv_dropout=0.0, device=None):
+        if (dim, dim_head, heads, ff_mult, conv_expansion_factor, conv_kernel_size) != (64, 16, 4, 4, 2, 31):
+            raise ValueError("HIP kernels are specialised for dim=64, dim_head=16, heads=4, ff_mult=4, "
+                             "conv_expansion_factor=2, conv_kernel_size=31")
+        self.engine = Engine(device=device)     # dropouts are identity in eval mode
+
+    def eval(self):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    def load_state_dict(self, state_dict: dict, strict: bool = True):
+        self.engine.load_blob(packer.pack_conformer_state_dict(state_dict, slot=0))
+        return self
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, mask=None):
+        if mask is not None:
+            raise NotImplementedError("CMGAN never passes an attention mask (generator.py:95,97)")
+        return self.engine.conformer_forward(0, x)
+
+    __call__ = forward
+
+    def forward_with_taps(self, x: torch.Tensor):
+        """(out, taps[4,N,L,64]) - residual stream after ff1 / attn / conv / ff2."""
+        return self.engine.conformer_forward(0, x, taps=True)

@@ -1,0 +1,631 @@
+// api.hip - C ABI of libcmgan_hip.so (see include/cmgan_hip.h): handle, weight upload,
+// workspace plan and the launch sequences of the generator forward path.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cmgan_hip.h"
+#include "kernels.h"
+#include "weights.h"
+
+static thread_local std::string g_create_error;
+
+struct WEntry { size_t off; size_t count; };
+
+struct cmgan_handle {
+    cmgan_config cfg;
+    int device = 0;
+    std::string err;
+    // tables
+    float* d_tables = nullptr;
+    SpectralTables st{};
+    // weights
+    float* d_weights = nullptr;
+    size_t weight_floats = 0;
+    std::map<uint32_t, WEntry> dir;
+    Profiler prof;
+    std::vector<std::string> prof_names;
+};
+
+static int fail(cmgan_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t _e = (call);                                                                  \
+        if (_e != hipSuccess) return fail(h, CMGAN_E_HIP, "%s: %s", #call, hipGetErrorString(_e)); \
+    } while (0)
+
+static int check_launch(cmgan_handle* h, const char* where) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, CMGAN_E_HIP, "%s: %s", where, hipGetErrorString(e));
+    return CMGAN_OK;
+}
+
+extern "C" void cmgan_default_config(cmgan_config* c) {
+    if (!c) return;
+    c->n_fft = 400; c->hop = 100; c->num_features = 201; c->num_channel = 64; c->num_tscb = 4;
+    c->heads = 4; c->dim_head = 16; c->conv_kernel = 31; c->max_pos_emb = 512;
+}
+
+extern "C" int cmgan_abi_version(void) { return CMGAN_ABI_VERSION; }
+
+extern "C" const char* cmgan_last_error(const cmgan_handle* h) {
+    return h ? h->err.c_str() : g_create_error.c_str();
+}
+
+// fm[rb][kb][lane][r] = M[16*rb + (lane&15)][16*kb + 4*(lane>>4) + r]   (weights.h)
+static void pack_fm(const std::vector<double>& M, int R, int K, float* out) {
+    const int RB = R / 16, KB = K / 16;
+    for (int rb = 0; rb < RB; ++rb)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * rb + (lane & 15), col = 16 * kb + 4 * (lane >> 4) + r;
+                    out[(((size_t)rb * KB + kb) * 64 + lane) * 4 + r] = (float)M[(size_t)row * K + col];
+                }
+}
+
+extern "C" int cmgan_create(cmgan_handle** out, const cmgan_config* cfg) {
+    if (!out || !cfg) return fail(nullptr, CMGAN_E_BADARG, "cmgan_create: null argument");
+    *out = nullptr;
+    if (cfg->num_channel != 64 || cfg->heads != 4 || cfg->dim_head != 16 || cfg->conv_kernel != 31)
+        return fail(nullptr, CMGAN_E_UNSUPPORTED,
+                    "kernels are specialised for num_channel=64, heads=4, dim_head=16, conv_kernel=31");
+    if (cfg->n_fft <= 0 || cfg->n_fft % 16 || cfg->hop <= 0 || cfg->hop % 4 || cfg->n_fft % cfg->hop ||
+        cfg->num_features != cfg->n_fft / 2 + 1 || (cfg->num_features & 1) == 0)
+        return fail(nullptr, CMGAN_E_UNSUPPORTED,
+                    "need n_fft %% 16 == 0, hop %% 4 == 0, hop | n_fft, num_features == n_fft/2+1 (odd)");
+    if (cfg->num_tscb < 1 || cfg->num_tscb > 4 || cfg->max_pos_emb < 1)
+        return fail(nullptr, CMGAN_E_UNSUPPORTED, "num_tscb must be 1..4, max_pos_emb >= 1");
+    cmgan_handle* h = new cmgan_handle();
+    h->cfg = *cfg;
+    hipError_t e = hipGetDevice(&h->device);
+    if (e != hipSuccess) {
+        fail(nullptr, CMGAN_E_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+        delete h;
+        return CMGAN_E_HIP;
+    }
+    // ---- window + forward / inverse DFT matrices (host fp64 -> fp32, fragment-major) ----
+    const int N = cfg->n_fft, F = cfg->num_features, FB = (F + 15) / 16;
+    const double PI2 = 6.283185307179586476925286766559;
+    std::vector<double> win(N);
+    for (int n = 0; n < N; ++n) win[n] = 0.54 - 0.46 * cos(PI2 * n / N);   // torch.hamming_window(periodic)
+    const int RF = 2 * FB * 16;                                             // rows: re bins | im bins
+    std::vector<double> fwd((size_t)RF * N, 0.0), inv((size_t)N * RF, 0.0);
+    for (int k = 0; k < F; ++k)
+        for (int n = 0; n < N; ++n) {
+            const long m = ((long)k * n) % N;
+            const double cs = cos(PI2 * m / N), sn = sin(PI2 * m / N);
+            fwd[(size_t)k * N + n] = win[n] * cs;
+            fwd[(size_t)(FB * 16 + k) * N + n] = -win[n] * sn;
+            const double wk = (k == 0 || k == N / 2) ? 1.0 : 2.0;
+            inv[(size_t)n * RF + k] = win[n] * wk * cs / N;
+            inv[(size_t)n * RF + FB * 16 + k] = (k == 0 || k == N / 2) ? 0.0 : -win[n] * wk * sn / N;
+        }
+    const size_t n_fwd = (size_t)RF * N, n_inv = (size_t)N * RF;
+    std::vector<float> host(n_fwd + n_inv + N);
+    pack_fm(fwd, RF, N, host.data());
+    pack_fm(inv, N, RF, host.data() + n_fwd);
+    for (int n = 0; n < N; ++n) host[n_fwd + n_inv + n] = (float)win[n];
+    e = hipMalloc(&h->d_tables, host.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(h->d_tables, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        fail(nullptr, CMGAN_E_HIP, "table upload: %s", hipGetErrorString(e));
+        if (h->d_tables) hipFree(h->d_tables);
+        delete h;
+        return CMGAN_E_HIP;
+    }
+    h->st.n_fft = N; h->st.hop = cfg->hop; h->st.F = F; h->st.FB = FB;
+    h->st.fwd_fm = h->d_tables; h->st.inv_fm = h->d_tables + n_fwd; h->st.window = h->d_tables + n_fwd + n_inv;
+    *out = h;
+    return CMGAN_OK;
+}
+
+extern "C" void cmgan_destroy(cmgan_handle* h) {
+    if (!h) return;
+    if (h->d_tables) hipFree(h->d_tables);
+    if (h->d_weights) hipFree(h->d_weights);
+    for (auto ev : h->prof.pool) hipEventDestroy(ev);
+    delete h;
+}
+
+// ------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------
+static size_t expected_count(const cmgan_config& c, uint32_t id) {
+    const uint32_t grp = id / 64, item = id % 64;
+    const size_t F = c.num_features;
+    if (grp == G_ENC) {
+        switch (item) {
+            case ENC_C1_W: return 256; case ENC_C1_GB: return 128; case ENC_C1_PRELU: return 64;
+            case ENC_C2_W: return 4 * 3 * 4 * 256; case ENC_C2_BIAS: return 64; case ENC_C2_GB: return 128;
+            case ENC_C2_PRELU: return 64;
+        }
+    } else if (grp == G_DB_E || grp == G_DB_M || grp == G_DB_C) {
+        const uint32_t i = item / 4, k = item % 4;
+        if (i < 4) {
+            if (k == 0) return (size_t)4 * (i + 1) * 6 * 4 * 256;
+            if (k == 1) return 64; if (k == 2) return 128; return 64;
+        }
+    } else if (grp == G_MASK) {
+        switch (item) {
+            case MK_SP_W: return 4 * 3 * 8 * 256; case MK_SP_BIAS: return 128; case MK_TAIL_W: return 4 * 256;
+            case MK_SCALARS: return 8; case MK_PRELU_OUT: return F;
+        }
+    } else if (grp == G_CPLX) {
+        switch (item) {
+            case CX_SP_W: return 4 * 3 * 8 * 256; case CX_SP_BIAS: return 128; case CX_GB: return 128;
+            case CX_PRELU: return 64; case CX_TAIL_W: return 4 * 256; case CX_BIAS: return 2;
+        }
+    } else if (grp >= G_CONF0 && grp < G_CONF0 + 8) {
+        switch (item) {
+            case CF_FF1_W1: case CF_FF2_W1: return 16 * 4 * 256;
+            case CF_FF1_B1: case CF_FF2_B1: return 256;
+            case CF_FF1_W2: case CF_FF2_W2: return 4 * 16 * 256;
+            case CF_FF1_B2: case CF_FF2_B2: return 64;
+            case CF_QKV_W: return 12 * 4 * 256; case CF_QKV_B: return 192;
+            case CF_WO: return 4 * 4 * 256; case CF_BO: return 64;
+            case CF_REL: return (size_t)(2 * c.max_pos_emb + 1) * 16;
+            case CF_PW1_W: return 16 * 4 * 256; case CF_PW1_B: return 256;
+            case CF_DW_W: return 31 * 128; case CF_DW_B: return 128;
+            case CF_PW2_W: return 4 * 8 * 256; case CF_PW2_B: return 64;
+            case CF_POST_GB: return 128;
+        }
+    }
+    return 0;
+}
+
+extern "C" int cmgan_load_weights(cmgan_handle* h, const void* blob, size_t bytes) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!blob || bytes < 16) return fail(h, CMGAN_E_BADARG, "cmgan_load_weights: null / short blob");
+    const uint32_t* u = (const uint32_t*)blob;
+    if (u[0] != CMGAN_BLOB_MAGIC || u[1] != CMGAN_BLOB_VERSION)
+        return fail(h, CMGAN_E_WEIGHTS, "bad blob magic/version (%08x, %u)", u[0], u[1]);
+    const uint32_t n = u[2], payload = u[3];
+    const size_t head = 16 + (size_t)n * 16;
+    if (bytes != head + (size_t)payload * 4) return fail(h, CMGAN_E_WEIGHTS, "blob size mismatch");
+    std::map<uint32_t, WEntry> dir;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t* e = u + 4 + 4 * i;
+        const uint32_t id = e[0], off = e[1], cnt = e[2];
+        if ((size_t)off + cnt > payload || (off % 4) != 0)
+            return fail(h, CMGAN_E_WEIGHTS, "entry %u (id %u) out of range / misaligned", i, id);
+        const size_t want = expected_count(h->cfg, id);
+        if (want == 0) return fail(h, CMGAN_E_WEIGHTS, "unknown weight id %u", id);
+        if (want != cnt) return fail(h, CMGAN_E_WEIGHTS, "weight id %u has %u floats, expected %zu", id, cnt, want);
+        dir[id] = {off, cnt};
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    if (h->d_weights) { hipFree(h->d_weights); h->d_weights = nullptr; }
+    HIPCHK(h, hipMalloc(&h->d_weights, (size_t)payload * 4 + 256));
+    HIPCHK(h, hipMemcpy(h->d_weights, (const char*)blob + head, (size_t)payload * 4, hipMemcpyHostToDevice));
+    h->weight_floats = payload;
+    h->dir.swap(dir);
+    return CMGAN_OK;
+}
+
+static const float* W(cmgan_handle* h, uint32_t id, bool& okflag) {
+    auto it = h->dir.find(id);
+    if (it == h->dir.end()) {
+        if (okflag) fail(h, CMGAN_E_WEIGHTS, "weight id %u (group %u item %u) not loaded", id, id / 64, id % 64);
+        okflag = false;
+        return nullptr;
+    }
+    return h->d_weights + it->second.off;
+}
+
+static bool conf_weights(cmgan_handle* h, int index, ConfWeights& w) {
+    bool ok = true;
+    const int g = G_CONF0 + index;
+    w.ff1_w1 = W(h, WID(g, CF_FF1_W1), ok); w.ff1_b1 = W(h, WID(g, CF_FF1_B1), ok);
+    w.ff1_w2 = W(h, WID(g, CF_FF1_W2), ok); w.ff1_b2 = W(h, WID(g, CF_FF1_B2), ok);
+    w.qkv_w = W(h, WID(g, CF_QKV_W), ok);   w.qkv_b = W(h, WID(g, CF_QKV_B), ok);
+    w.wo = W(h, WID(g, CF_WO), ok);         w.bo = W(h, WID(g, CF_BO), ok);
+    w.rel = W(h, WID(g, CF_REL), ok);
+    w.pw1_w = W(h, WID(g, CF_PW1_W), ok);   w.pw1_b = W(h, WID(g, CF_PW1_B), ok);
+    w.dw_w = W(h, WID(g, CF_DW_W), ok);     w.dw_b = W(h, WID(g, CF_DW_B), ok);
+    w.pw2_w = W(h, WID(g, CF_PW2_W), ok);   w.pw2_b = W(h, WID(g, CF_PW2_B), ok);
+    w.ff2_w1 = W(h, WID(g, CF_FF2_W1), ok); w.ff2_b1 = W(h, WID(g, CF_FF2_B1), ok);
+    w.ff2_w2 = W(h, WID(g, CF_FF2_W2), ok); w.ff2_b2 = W(h, WID(g, CF_FF2_B2), ok);
+    w.post_gb = W(h, WID(g, CF_POST_GB), ok);
+    w.max_pos = h->cfg.max_pos_emb;
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------
+// workspace plan (all offsets in floats, 64-float aligned)
+// ------------------------------------------------------------------------------------
+struct WsPlan {
+    size_t total = 0;
+    size_t e[5];          // encoder dense slots [B,P,64]; e[1..4] double as decoder slots, e[0] as SP
+    size_t xa, xb, q, k, v, o, u, w;
+    size_t dm, dc;        // tail projections [B, T*W, 4]
+    size_t partials;
+    size_t ns;            // 16 x {scale[B][64], shift[B][64]}
+    size_t mstat;         // [B][2]
+    size_t scale;         // [B] rms scale (enhance)
+    size_t spec;          // [B,2,T,F] (enhance)
+    size_t est;           // 2 x [B,T,F] (enhance)
+    size_t frames;        // [B,T,n_fft] (istft)
+};
+
+static size_t take(size_t& cur, size_t n) {
+    const size_t o = cur;
+    cur += (n + 63) & ~(size_t)63;
+    return o;
+}
+
+static WsPlan plan_ws(const cmgan_config& c, int B, int T) {
+    WsPlan p;
+    const size_t F = c.num_features, F2 = (F + 1) / 2, W2 = 2 * F2;
+    const size_t P = (size_t)T * F, P2 = (size_t)T * F2, M = (size_t)B * P2;
+    size_t cur = 0;
+    p.e[0] = take(cur, (size_t)B * T * std::max(F, W2) * 64);
+    for (int i = 1; i < 5; ++i) p.e[i] = take(cur, (size_t)B * P * 64);
+    p.xa = take(cur, M * 64);
+    p.xb = take(cur, M * 64);
+    const size_t qf = std::max(conf_qkv_floats((int)(B * F2), T), conf_qkv_floats(B * T, (int)F2));
+    p.q = take(cur, qf); p.k = take(cur, qf); p.v = take(cur, qf); p.o = take(cur, qf);
+    p.u = take(cur, M * 128);
+    p.w = take(cur, M * 128);
+    p.dm = take(cur, (size_t)B * T * W2 * 4 + 64);
+    p.dc = take(cur, (size_t)B * T * W2 * 4 + 64);
+    const size_t nt = std::max((size_t)conv3_ntiles(T, (int)F), (size_t)conv_in_ntiles((int)P));
+    p.partials = take(cur, (size_t)B * nt * 128 * 2);
+    p.ns = take(cur, (size_t)16 * 2 * B * 64);
+    p.mstat = take(cur, (size_t)B * 2);
+    p.scale = take(cur, (size_t)B);
+    p.spec = take(cur, (size_t)B * 2 * P);
+    p.est = take(cur, (size_t)B * 2 * P);
+    p.frames = take(cur, (size_t)B * T * c.n_fft);
+    p.total = cur;
+    return p;
+}
+
+extern "C" size_t cmgan_workspace_bytes(const cmgan_handle* h, int B, int T) {
+    if (!h || B <= 0 || T <= 0) return 0;
+    return plan_ws(h->cfg, B, T).total * sizeof(float);
+}
+
+static int check_ws(cmgan_handle* h, void* ws, size_t bytes, size_t need) {
+    if (!ws) return fail(h, CMGAN_E_BADARG, "workspace is null");
+    if (((uintptr_t)ws & 255) != 0) return fail(h, CMGAN_E_WORKSPACE, "workspace must be 256-byte aligned");
+    if (bytes < need) return fail(h, CMGAN_E_WORKSPACE, "workspace too small: %zu < %zu bytes", bytes, need);
+    return CMGAN_OK;
+}
+
+static LaunchCtx begin(cmgan_handle* h, void* stream) {
+    return LaunchCtx{(hipStream_t)stream, &h->prof};
+}
+
+// ------------------------------------------------------------------------------------
+// front / back end
+// ------------------------------------------------------------------------------------
+extern "C" int cmgan_num_frames(const cmgan_handle* h, int L) { return h ? L / h->cfg.hop + 1 : 0; }
+
+static int check_wave_len(cmgan_handle* h, int L) {
+    if (L <= 0 || L % h->cfg.hop != 0) return fail(h, CMGAN_E_BADSHAPE, "L=%d must be a positive multiple of hop=%d", L, h->cfg.hop);
+    if (L <= h->cfg.n_fft / 2) return fail(h, CMGAN_E_BADSHAPE, "L=%d must exceed n_fft/2=%d (reflect padding)", L, h->cfg.n_fft / 2);
+    return CMGAN_OK;
+}
+
+extern "C" int cmgan_rms_scale(cmgan_handle* h, const float* wav, int B, int L, float* scale, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!wav || !scale || B <= 0 || L <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_rms_scale: bad argument");
+    launch_rms_scale(begin(h, stream), wav, B, L, scale);
+    return check_launch(h, "rms_scale");
+}
+
+extern "C" int cmgan_stft_compress(cmgan_handle* h, const float* wav, const float* scale, int B, int L,
+                                   float* spec, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!wav || !spec || B <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_stft_compress: bad argument");
+    if (int rc = check_wave_len(h, L)) return rc;
+    launch_stft_compress(begin(h, stream), h->st, wav, scale, B, L, L / h->cfg.hop + 1, spec);
+    return check_launch(h, "stft_compress");
+}
+
+extern "C" int cmgan_uncompress_istft(cmgan_handle* h, const float* re, const float* im, const float* scale, int B,
+                                      int T, float* wav_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!re || !im || !wav_out || B <= 0 || T < 2) return fail(h, CMGAN_E_BADARG, "cmgan_uncompress_istft: bad argument");
+    const WsPlan p = plan_ws(h->cfg, B, T);
+    if (int rc = check_ws(h, ws, ws_bytes, p.total * sizeof(float))) return rc;
+    launch_uncompress_istft(begin(h, stream), h->st, re, im, scale, B, T, (float*)ws + p.frames, wav_out);
+    return check_launch(h, "uncompress_istft");
+}
+
+extern "C" int cmgan_power_compress(cmgan_handle* h, const float* x, int B, int F, int T, float* y, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !y || B <= 0 || F <= 0 || T <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_power_compress: bad argument");
+    launch_power_compress(begin(h, stream), x, B, F, T, y);
+    return check_launch(h, "power_compress");
+}
+
+extern "C" int cmgan_power_uncompress(cmgan_handle* h, const float* re, const float* im, int B, int F, int T,
+                                      float* y, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!re || !im || !y || B <= 0 || F <= 0 || T <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_power_uncompress: bad argument");
+    launch_power_uncompress(begin(h, stream), re, im, B, F, T, y);
+    return check_launch(h, "power_uncompress");
+}
+
+// ------------------------------------------------------------------------------------
+// conformer (stand-alone entry)
+// ------------------------------------------------------------------------------------
+struct ConfPlan { size_t total, xa, xb, q, k, v, o, u, w; };
+static ConfPlan plan_conf(int N, int L) {
+    ConfPlan p;
+    size_t cur = 0;
+    const size_t M = (size_t)N * L, qf = conf_qkv_floats(N, L);
+    p.xa = take(cur, M * 64); p.xb = take(cur, M * 64);
+    p.q = take(cur, qf); p.k = take(cur, qf); p.v = take(cur, qf); p.o = take(cur, qf);
+    p.u = take(cur, M * 128); p.w = take(cur, M * 128);
+    p.total = cur;
+    return p;
+}
+
+extern "C" size_t cmgan_conformer_workspace_bytes(const cmgan_handle* h, int N, int L) {
+    if (!h || N <= 0 || L <= 0) return 0;
+    return plan_conf(N, L).total * sizeof(float);
+}
+
+extern "C" int cmgan_conformer_forward(cmgan_handle* h, int index, const float* x, int N, int L, float* y,
+                                       float* taps, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !y || N <= 0 || L <= 0 || index < 0 || index >= 8) return fail(h, CMGAN_E_BADARG, "cmgan_conformer_forward: bad argument");
+    const ConfPlan p = plan_conf(N, L);
+    if (int rc = check_ws(h, ws, ws_bytes, p.total * sizeof(float))) return rc;
+    ConfWeights w;
+    if (!conf_weights(h, index, w)) return CMGAN_E_WEIGHTS;
+    float* f = (float*)ws;
+    ConfBuffers b{f + p.xa, f + p.xb, f + p.q, f + p.k, f + p.v, f + p.o, f + p.u, f + p.w};
+    hipStream_t s = (hipStream_t)stream;
+    const size_t M = (size_t)N * L;
+    HIPCHK(h, hipMemcpyAsync(b.xa, x, M * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const TokMap seq = make_seq_map(N, L, 1, L, 0, 1);
+    conformer_forward(begin(h, stream), w, b, seq, (long)M, taps);
+    HIPCHK(h, hipMemcpyAsync(y, b.xa, M * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return check_launch(h, "conformer_forward");
+}
+
+// ------------------------------------------------------------------------------------
+// TSCNet.forward
+// ------------------------------------------------------------------------------------
+struct DenseW { const float *w[4], *bias[4], *gb[4], *prelu[4]; };
+static bool dense_weights(cmgan_handle* h, int grp, DenseW& d) {
+    bool ok = true;
+    for (int i = 0; i < 4; ++i) {
+        d.w[i] = W(h, WID(grp, DB_W(i)), ok); d.bias[i] = W(h, WID(grp, DB_BIAS(i)), ok);
+        d.gb[i] = W(h, WID(grp, DB_GB(i)), ok); d.prelu[i] = W(h, WID(grp, DB_PRELU(i)), ok);
+    }
+    return ok;
+}
+
+// DilatedDenseNet (generator.py:39-47): slot 0 = x0 (with optional norm-on-load), layer i writes slot i+1.
+// ns(j) -> {scale, shift} storage for norm instance j; returns the instance index used by the last layer.
+static void run_dense_block(LaunchCtx ctx, const DenseW& d, const float* x0, const float* x0_scale,
+                            const float* x0_shift, const float* x0_alpha, float* const slots[4], float* partials,
+                            float* const nsc[4], float* const nsh[4], int B, int T, int F) {
+    const int nt = conv3_ntiles(T, F);
+    for (int i = 0; i < 4; ++i) {
+        ConvArgs a{};
+        a.in[0] = x0; a.nscale[0] = x0_scale; a.nshift[0] = x0_shift; a.nalpha[0] = x0_alpha;
+        for (int s = 1; s <= i; ++s) {
+            a.in[s] = slots[s - 1]; a.nscale[s] = nsc[s - 1]; a.nshift[s] = nsh[s - 1]; a.nalpha[s] = d.prelu[s - 1];
+        }
+        a.nslots = i + 1;
+        a.w = d.w[i]; a.bias = d.bias[i];
+        a.out = slots[i]; a.partials = partials;
+        a.T = T; a.F = F; a.dil = 1 << i; a.mode = 0; a.ntiles = nt;
+        launch_conv3(ctx, a, B, 2, 64);
+        launch_in_finalize(ctx, partials, B, nt, 64, 0, (double)T * F, d.gb[i], nsc[i], nsh[i]);
+    }
+}
+
+static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* out_re, float* out_im,
+                       const cmgan_taps* taps, void* ws, size_t ws_bytes, void* stream, bool reset_prof) {
+    if (!spec || !out_re || !out_im || B <= 0 || T <= 0) return fail(h, CMGAN_E_BADARG, "tscnet_forward: bad argument");
+    const WsPlan p = plan_ws(h->cfg, B, T);
+    if (int rc = check_ws(h, ws, ws_bytes, p.total * sizeof(float))) return rc;
+    const int F = h->cfg.num_features, F2 = (F + 1) / 2, W2 = 2 * F2;
+    const long P = (long)T * F, P2 = (long)T * F2, M = (long)B * P2;
+    float* f = (float*)ws;
+    LaunchCtx ctx = begin(h, stream);
+    if (h->prof.enabled && reset_prof) h->prof.reset();
+
+    bool ok = true;
+    const float* c1w = W(h, WID(G_ENC, ENC_C1_W), ok);
+    const float* c1gb = W(h, WID(G_ENC, ENC_C1_GB), ok);
+    const float* c1pr = W(h, WID(G_ENC, ENC_C1_PRELU), ok);
+    const float* c2w = W(h, WID(G_ENC, ENC_C2_W), ok);
+    const float* c2b = W(h, WID(G_ENC, ENC_C2_BIAS), ok);
+    const float* c2gb = W(h, WID(G_ENC, ENC_C2_GB), ok);
+    const float* c2pr = W(h, WID(G_ENC, ENC_C2_PRELU), ok);
+    DenseW dbe, dbm, dbc;
+    ok = dense_weights(h, G_DB_E, dbe) && ok;
+    ok = dense_weights(h, G_DB_M, dbm) && ok;
+    ok = dense_weights(h, G_DB_C, dbc) && ok;
+    const float* mk_spw = W(h, WID(G_MASK, MK_SP_W), ok);
+    const float* mk_spb = W(h, WID(G_MASK, MK_SP_BIAS), ok);
+    const float* mk_tail = W(h, WID(G_MASK, MK_TAIL_W), ok);
+    const float* mk_sca = W(h, WID(G_MASK, MK_SCALARS), ok);
+    const float* mk_pout = W(h, WID(G_MASK, MK_PRELU_OUT), ok);
+    const float* cx_spw = W(h, WID(G_CPLX, CX_SP_W), ok);
+    const float* cx_spb = W(h, WID(G_CPLX, CX_SP_BIAS), ok);
+    const float* cx_gb = W(h, WID(G_CPLX, CX_GB), ok);
+    const float* cx_pr = W(h, WID(G_CPLX, CX_PRELU), ok);
+    const float* cx_tail = W(h, WID(G_CPLX, CX_TAIL_W), ok);
+    const float* cx_bias = W(h, WID(G_CPLX, CX_BIAS), ok);
+    ConfWeights cw[8];
+    for (int i = 0; i < 2 * h->cfg.num_tscb; ++i) ok = conf_weights(h, i, cw[i]) && ok;
+    if (!ok) return CMGAN_E_WEIGHTS;
+
+    auto nsc = [&](int j) { return f + p.ns + (size_t)j * 2 * B * 64; };
+    auto nsh = [&](int j) { return f + p.ns + (size_t)j * 2 * B * 64 + (size_t)B * 64; };
+    float* partials = f + p.partials;
+
+    // ---- dense encoder (generator.py:65-69) --------------------------------------------
+    launch_conv_in(ctx, spec, c1w, f + p.e[0], partials, B, (int)P);
+    launch_in_finalize(ctx, partials, B, conv_in_ntiles((int)P), 64, 0, (double)P, c1gb, nsc(0), nsh(0));
+    {
+        float* slots[4] = {f + p.e[1], f + p.e[2], f + p.e[3], f + p.e[4]};
+        float* sc[4] = {nsc(1), nsc(2), nsc(3), nsc(4)};
+        float* sh[4] = {nsh(1), nsh(2), nsh(3), nsh(4)};
+        run_dense_block(ctx, dbe, f + p.e[0], nsc(0), nsh(0), c1pr, slots, partials, sc, sh, B, T, F);
+    }
+    {   // conv_2: (1,3) stride (1,2) pad (0,1) == stride-1 conv keeping the even columns
+        ConvArgs a{};
+        a.in[0] = f + p.e[4]; a.nscale[0] = nsc(4); a.nshift[0] = nsh(4); a.nalpha[0] = dbe.prelu[3];
+        a.nslots = 1; a.w = c2w; a.bias = c2b; a.out = f + p.xb; a.partials = partials;
+        a.T = T; a.F = F; a.dil = 1; a.mode = 1; a.ntiles = conv3_ntiles(T, F);
+        launch_conv3(ctx, a, B, 1, 64);
+        launch_in_finalize(ctx, partials, B, a.ntiles, 64, 0, (double)P2, c2gb, nsc(5), nsh(5));
+        launch_in_apply(ctx, f + p.xb, nsc(5), nsh(5), c2pr, f + p.xa, B, P2);
+    }
+    if (taps && taps->encoder_dev) launch_cl_to_nchw(ctx, f + p.xa, taps->encoder_dev, B, P2);
+
+    // ---- TSCBs (generator.py:92-99) -----------------------------------------------------
+    ConfBuffers cb{f + p.xa, f + p.xb, f + p.q, f + p.k, f + p.v, f + p.o, f + p.u, f + p.w};
+    const TokMap tmap = make_seq_map(B * F2, T, F2, (long)T * F2, 1, F2);
+    const TokMap fmap = make_seq_map(B * T, F2, 1, F2, 0, 1);
+    for (int k = 0; k < h->cfg.num_tscb; ++k) {
+        conformer_forward(ctx, cw[2 * k], cb, tmap, M, nullptr);
+        conformer_forward(ctx, cw[2 * k + 1], cb, fmap, M, nullptr);
+        if (taps && taps->tscb_dev[k]) launch_cl_to_nchw(ctx, f + p.xa, taps->tscb_dev[k], B, P2);
+    }
+
+    // ---- decoders (generator.py:133-139, 151-156) ------------------------------------
+    float* dslots[4] = {f + p.e[1], f + p.e[2], f + p.e[3], f + p.e[4]};
+    float* sp = f + p.e[0];
+    const int nt2 = conv3_ntiles(T, F2);
+    for (int dec = 0; dec < 2; ++dec) {
+        const DenseW& d = dec == 0 ? dbm : dbc;
+        const int j0 = dec == 0 ? 6 : 10;
+        float* sc[4] = {nsc(j0), nsc(j0 + 1), nsc(j0 + 2), nsc(j0 + 3)};
+        float* sh[4] = {nsh(j0), nsh(j0 + 1), nsh(j0 + 2), nsh(j0 + 3)};
+        run_dense_block(ctx, d, f + p.xa, nullptr, nullptr, nullptr, dslots, partials, sc, sh, B, T, F2);
+        ConvArgs a{};
+        a.in[0] = dslots[3]; a.nscale[0] = sc[3]; a.nshift[0] = sh[3]; a.nalpha[0] = d.prelu[3];
+        a.nslots = 1; a.w = dec == 0 ? mk_spw : cx_spw; a.bias = dec == 0 ? mk_spb : cx_spb;
+        a.out = sp; a.partials = dec == 0 ? nullptr : partials;
+        a.T = T; a.F = F2; a.dil = 1; a.mode = 2; a.ntiles = nt2;
+        launch_conv3(ctx, a, B, 1, 128);
+        if (dec == 0) {
+            launch_tail_proj(ctx, sp, nullptr, nullptr, nullptr, mk_tail, f + p.dm, B, (long)T * W2);
+        } else {
+            launch_in_finalize(ctx, partials, B, nt2, 128, 1, (double)T * W2, cx_gb, nsc(14), nsh(14));
+            launch_tail_proj(ctx, sp, nsc(14), nsh(14), cx_pr, cx_tail, f + p.dc, B, (long)T * W2);
+        }
+    }
+    launch_mask_stats(ctx, f + p.dm, mk_sca, B, T, F, f + p.mstat);
+    launch_final_combine(ctx, spec, f + p.dm, f + p.dc, f + p.mstat, mk_sca, mk_pout, cx_bias, B, T, F, out_re,
+                         out_im, taps ? taps->mask_dev : nullptr, taps ? taps->complex_dev : nullptr);
+    return check_launch(h, "tscnet_forward");
+}
+
+extern "C" int cmgan_tscnet_forward(cmgan_handle* h, const float* spec, int B, int T, float* out_re, float* out_im,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    return tscnet_impl(h, spec, B, T, out_re, out_im, nullptr, ws, ws_bytes, stream, true);
+}
+
+extern "C" int cmgan_tscnet_forward_taps(cmgan_handle* h, const float* spec, int B, int T, float* out_re,
+                                         float* out_im, const cmgan_taps* taps, void* ws, size_t ws_bytes,
+                                         void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    return tscnet_impl(h, spec, B, T, out_re, out_im, taps, ws, ws_bytes, stream, true);
+}
+
+extern "C" int cmgan_enhance(cmgan_handle* h, const float* wav, int B, int L, float* wav_out, void* ws,
+                             size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!wav || !wav_out || B <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_enhance: bad argument");
+    if (int rc = check_wave_len(h, L)) return rc;
+    const int T = L / h->cfg.hop + 1;
+    const WsPlan p = plan_ws(h->cfg, B, T);
+    if (int rc = check_ws(h, ws, ws_bytes, p.total * sizeof(float))) return rc;
+    float* f = (float*)ws;
+    const long P = (long)T * h->cfg.num_features;
+    if (h->prof.enabled) h->prof.reset();
+    LaunchCtx ctx = begin(h, stream);
+    launch_rms_scale(ctx, wav, B, L, f + p.scale);
+    launch_stft_compress(ctx, h->st, wav, f + p.scale, B, L, T, f + p.spec);
+    if (int rc = check_launch(h, "stft_compress")) return rc;
+    if (int rc = tscnet_impl(h, f + p.spec, B, T, f + p.est, f + p.est + (size_t)B * P, nullptr, ws, ws_bytes, stream,
+                             false))
+        return rc;
+    launch_uncompress_istft(ctx, h->st, f + p.est, f + p.est + (size_t)B * P, f + p.scale, B, T, f + p.frames, wav_out);
+    return check_launch(h, "enhance");
+}
+
+// ------------------------------------------------------------------------------------
+// diagnostics
+// ------------------------------------------------------------------------------------
+extern "C" int cmgan_selftest_mfma(cmgan_handle* h, float* max_err_host) {
+    if (!h || !max_err_host) return CMGAN_E_BADARG;
+    const int KB = 3, K = 16 * KB;
+    std::vector<double> A(16 * K), Bt(16 * K);     // A[i][k], Bt[j][k] = B[k][j]; asymmetric on purpose
+    for (int i = 0; i < 16; ++i)
+        for (int k = 0; k < K; ++k) {
+            A[i * K + k] = 0.25 * ((i * 7 + k * 3) % 11) - 1.0;
+            Bt[i * K + k] = 0.125 * ((i * 5 + k * 13) % 17) - 0.5 + 0.01 * i;
+        }
+    std::vector<float> af(16 * K), bf(16 * K), d(256);
+    pack_fm(A, 16, K, af.data());
+    pack_fm(Bt, 16, K, bf.data());
+    float *da, *db, *dd;
+    HIPCHK(h, hipMalloc(&da, af.size() * 4)); HIPCHK(h, hipMalloc(&db, bf.size() * 4)); HIPCHK(h, hipMalloc(&dd, 1024));
+    HIPCHK(h, hipMemcpy(da, af.data(), af.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(db, bf.data(), bf.size() * 4, hipMemcpyHostToDevice));
+    launch_selftest_mfma(nullptr, da, db, dd, KB);
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(d.data(), dd, 1024, hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dd);
+    double worst = 0.0;
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            double ref = 0.0;
+            for (int k = 0; k < K; ++k) ref += (double)(float)A[i * K + k] * (double)(float)Bt[j * K + k];
+            worst = std::max(worst, fabs(ref - (double)d[i * 16 + j]));
+        }
+    *max_err_host = (float)worst;
+    return CMGAN_OK;
+}
+
+extern "C" int cmgan_set_profiling(cmgan_handle* h, int enabled) {
+    if (!h) return CMGAN_E_BADARG;
+    h->prof.enabled = enabled != 0;
+    h->prof.reset();
+    return CMGAN_OK;
+}
+
+extern "C" int cmgan_profile_read(cmgan_handle* h, cmgan_kernel_time* out, int cap) {
+    if (!h || !out || cap <= 0) return 0;
+    int n = 0;
+    for (auto& r : h->prof.recs) {
+        if (n >= cap) break;
+        hipEventSynchronize(r.b);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        out[n].name = r.name;
+        out[n].ms = ms;
+        ++n;
+    }
+    return n;
+}

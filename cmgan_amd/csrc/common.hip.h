@@ -1,0 +1,129 @@
+// common.hip.h - device helpers shared by all kernels (gfx950 only, wave64).
+//
+// MFMA convention used everywhere (v_mfma_f32_16x16x4_f32, exact fp32):
+//   lane l: c = l & 15, g = l >> 4
+//   A[i = c][k = g]   one f32 per lane        B[k = g][j = c]   one f32 per lane
+//   D[row = 4*g + reg][col = c], reg = 0..3   (f32x4 per lane)
+// A "fragment" is the float4 a lane feeds over four consecutive k-steps; k-step r of
+// block kb consumes k = 16*kb + 4*g + r (the contraction order is ours to choose, so
+// operands are fetched as one float4 per lane instead of four strided scalars).
+//
+// Per-token linear layers are evaluated TRANSPOSED: out^T = W * x^T, with W as the A
+// operand (rows = output features) and the activations as B (columns = 16 tokens).
+// Then lane (token c, group g) of the result holds out[token][16*ob + 4*g + reg] -
+// exactly the B-fragment layout the next layer needs for k-block ob - so chains of
+// layers (LN -> W1 -> Swish -> W2, attention S -> softmax -> PV) never leave registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CMGAN_EPS 1e-5f
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void stg4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 splat4(float v) { f32x4 r = {v, v, v, v}; return r; }
+
+// reduce over the 4 lane groups (lanes c, c+16, c+32, c+48)
+__device__ __forceinline__ float red_g_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float red_g_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+// reduce over the 16 lanes of one lane group (same g, c = 0..15)
+__device__ __forceinline__ float red_c_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return red_g_sum(red_c_sum(v)); }
+
+__device__ __forceinline__ float sigmoidf_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float swishf(float x) { return x * sigmoidf_fast(x); }
+
+// orders a wave's LDS writes before its later LDS reads (cross-lane, same wave)
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------
+// Token maps: which activation row each of the 16 tokens of a token block is.
+// flat : block b covers tokens 16b .. 16b+15 of [M]
+// seq  : block b = (n, ib) covers positions 16ib .. 16ib+15 of sequence n;
+//        row(n, l) = (n / inner) * outer + (n % inner) * istride + l * lstride
+//        time axis (n = (b,f'), l = t): inner = F', outer = T*F', istride = 1, lstride = F'
+//        freq axis (n = (b,t),  l = f'): inner = 1,  outer = F',   istride = 0, lstride = 1
+// ---------------------------------------------------------------------------------
+struct TokMap {
+    int seq;
+    int nblocks;
+    long M;
+    int L, Lb;
+    int inner;
+    long outer, istride, lstride;
+};
+
+// returns validity; `row` is always a readable row (clamped) so loads need no predicate
+__device__ __forceinline__ bool tok_row(const TokMap& m, int blk, int c, long& row) {
+    if (!m.seq) {
+        long t = (long)blk * 16 + c;
+        bool ok = t < m.M;
+        row = ok ? t : m.M - 1;
+        return ok;
+    }
+    int n = blk / m.Lb, ib = blk - n * m.Lb;
+    int l = ib * 16 + c;
+    bool ok = l < m.L;
+    if (!ok) l = m.L - 1;
+    row = (long)(n / m.inner) * m.outer + (long)(n % m.inner) * m.istride + (long)l * m.lstride;
+    return ok;
+}
+
+// acc[tb] += Wfm[ob][0..KB) (A operand) x xf[tb][0..KB) (B operand)
+// wp = W_fm + ob*KB*256 + lane*4
+template <int KB, int NTB>
+__device__ __forceinline__ void lin_acc(const float* __restrict__ wp, const f32x4 (&xf)[NTB][KB],
+                                        f32x4 (&acc)[NTB]) {
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        const f32x4 a = ldg4(wp + kb * 256);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int tb = 0; tb < NTB; ++tb) acc[tb] = mfma16(a[r], xf[tb][kb][r], acc[tb]);
+        }
+    }
+}
+
+// LayerNorm statistics of a 64-channel row held as 4 fragments (16 values per lane,
+// the 4 lanes c, c+16, c+32, c+48 together hold the row).  Biased variance, eps 1e-5
+// (nn.LayerNorm, conformer.py:68).
+__device__ __forceinline__ void ln_stats(const f32x4 (&x)[4], float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) s += (x[kb][0] + x[kb][1]) + (x[kb][2] + x[kb][3]);
+    mean = red_g_sum(s) * (1.0f / 64.0f);
+    float v = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = x[kb][r] - mean;
+            v = fmaf(d, d, v);
+        }
+    }
+    rstd = rsqrtf(red_g_sum(v) * (1.0f / 64.0f) + CMGAN_EPS);
+}

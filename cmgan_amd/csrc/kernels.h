@@ -1,0 +1,106 @@
+// kernels.h - internal launcher interface between api.hip and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "common.hip.h"
+
+// Optional per-launch timing with HIP events on the caller's stream (bench.py's
+// live roofline figure).  Disabled by default: then LAUNCH() is a plain launch.
+struct Profiler {
+    bool enabled = false;
+    struct Rec { const char* name; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    hipEvent_t get() {
+        if (used == pool.size()) { hipEvent_t e; hipEventCreate(&e); pool.push_back(e); }
+        return pool[used++];
+    }
+    void reset() { recs.clear(); used = 0; }
+};
+
+struct LaunchCtx {
+    hipStream_t stream;
+    Profiler* prof;
+};
+
+#define LAUNCH(ctx, name, ...)                                         \
+    do {                                                               \
+        if ((ctx).prof && (ctx).prof->enabled) {                       \
+            hipEvent_t _a = (ctx).prof->get(), _b = (ctx).prof->get(); \
+            hipEventRecord(_a, (ctx).stream);                          \
+            __VA_ARGS__;                                               \
+            hipEventRecord(_b, (ctx).stream);                          \
+            (ctx).prof->recs.push_back({name, _a, _b});                \
+        } else {                                                       \
+            __VA_ARGS__;                                               \
+        }                                                              \
+    } while (0)
+
+// ------------------------------- stft.hip ---------------------------------------
+struct SpectralTables {
+    int n_fft, hop, F, FB;          // FB = ceil(F/16) bin blocks
+    const float* fwd_fm;            // fm [2*FB][n_fft/16][64][4]: rows = re bins | im bins, window folded
+    const float* inv_fm;            // fm [n_fft/16][2*FB][64][4]: rows = output sample n, cols = re|im bins, window/N folded
+    const float* window;            // [n_fft]
+};
+void launch_rms_scale(LaunchCtx, const float* wav, int B, int L, float* scale);
+void launch_stft_compress(LaunchCtx, const SpectralTables&, const float* wav, const float* scale,
+                          int B, int L, int T, float* spec);
+void launch_uncompress_istft(LaunchCtx, const SpectralTables&, const float* re, const float* im,
+                             const float* scale, int B, int T, float* frames_ws, float* wav_out);
+void launch_power_compress(LaunchCtx, const float* x, int B, int F, int T, float* y);
+void launch_power_uncompress(LaunchCtx, const float* re, const float* im, int B, int F, int T, float* y);
+
+// ------------------------------- conv.hip ---------------------------------------
+struct ConvArgs {
+    const float* in[4];        // channels-last [B, T*F, 64] slots, slot order = concat order (oldest first)
+    const float* nscale[4];    // per slot [B][64] InstanceNorm scale (NULL = identity)
+    const float* nshift[4];    // per slot [B][64]
+    const float* nalpha[4];    // per slot [64] PReLU slopes (NULL = none)
+    int nslots;
+    const float* w;            // fm chunks [4*nslots][taps][COUT/16][64][4]
+    const float* bias;         // [COUT]
+    float* out;
+    float* partials;           // [B][ntiles][COUT][2] (sum, sum of squares) or NULL
+    int T, F, dil;
+    int mode;                  // 0 plain, 1 keep even f only (stride-2 conv), 2 pixel shuffle (COUT = 128)
+    int ntiles;
+};
+int  conv3_ntiles(int T, int F);
+void launch_conv3(LaunchCtx, const ConvArgs&, int B, int time_taps, int cout);
+int  conv_in_ntiles(int P);
+void launch_conv_in(LaunchCtx, const float* spec, const float* w, float* out, float* partials, int B, int P);
+void launch_in_finalize(LaunchCtx, const float* partials, int B, int ntiles, int cstride, int fold2,
+                        double count, const float* gb, float* nscale, float* nshift);
+void launch_in_apply(LaunchCtx, const float* in, const float* nscale, const float* nshift,
+                     const float* alpha, float* out, int B, long P);
+void launch_tail_proj(LaunchCtx, const float* sp, const float* nscale, const float* nshift,
+                      const float* alpha, const float* tailw, float* d, int B, long P2);
+void launch_mask_stats(LaunchCtx, const float* dm, const float* scalars, int B, int T, int F, float* mstat);
+void launch_final_combine(LaunchCtx, const float* spec, const float* dm, const float* dc, const float* mstat,
+                          const float* mk_scalars, const float* prelu_out, const float* cx_bias,
+                          int B, int T, int F, float* out_re, float* out_im, float* tap_mask, float* tap_cplx);
+void launch_cl_to_nchw(LaunchCtx, const float* in, float* out, int B, long P);
+
+// ----------------------------- conformer.hip ------------------------------------
+struct ConfWeights {
+    const float *ff1_w1, *ff1_b1, *ff1_w2, *ff1_b2;
+    const float *qkv_w, *qkv_b, *wo, *bo, *rel;
+    const float *pw1_w, *pw1_b, *dw_w, *dw_b, *pw2_w, *pw2_b;
+    const float *ff2_w1, *ff2_b1, *ff2_w2, *ff2_b2, *post_gb;
+    int max_pos;
+};
+struct ConfBuffers {
+    float *xa, *xb;        // residual stream ping/pong [M,64]
+    float *q, *k, *v, *o;  // fragment-major per (sequence, head)
+    float *u, *w;          // conv module [M,128]
+};
+TokMap make_flat_map(long M);
+TokMap make_seq_map(int N, int L, int inner, long outer, long istride, long lstride);
+size_t conf_qkv_floats(int N, int L);   // floats of one of q/k/v/o for N sequences of length L
+// one ConformerBlock on the residual stream in bufs.xa (in place); taps (may be NULL) -> 4 x [M,64]
+void conformer_forward(LaunchCtx, const ConfWeights&, const ConfBuffers&, const TokMap& seq, long M, float* taps);
+
+// ------------------------------- selftest ---------------------------------------
+void launch_selftest_mfma(hipStream_t, const float* a_fm, const float* b_fm, float* d, int KB);

@@ -1,0 +1,235 @@
+// stft.hip - waveform <-> power-compressed spectrogram front/back end (reference:
+// src/evaluation.py:21-23,36-39,41-51 and src/utils.py:20-39; torch.stft/istft with
+// n_fft=400, hop=100, periodic Hamming window, center=True/reflect, onesided).
+//
+// n_fft = 400 = 2^4 * 5^2 is not a power of two; at these sizes the transform is a tiny
+// fraction of the path, so it is evaluated as a dense (windowed) DFT-matrix product on the
+// fp32 MFMA pipe with the power-law compression fused into the epilogue: one kernel reads
+// the waveform once and writes the model input [B,2,T,F] once.  The inverse is the
+// mirror image (uncompress fused into the operand staging, synthesis window folded into
+// the inverse DFT matrix) followed by a small overlap-add / envelope / un-scale kernel.
+#include "kernels.h"
+
+// ---------------------------------------------------------------------------------
+// c[b] = sqrt(L / sum x^2)                    evaluation.py:21, train.py:75-79
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void rms_scale_kernel(const float* __restrict__ wav, int L,
+                                                         float* __restrict__ scale) {
+    __shared__ double red[1024];
+    const float* x = wav + (long)blockIdx.x * L;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < L; i += 1024) s += (double)x[i] * (double)x[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scale[blockIdx.x] = (float)sqrt((double)L / red[0]);
+}
+
+void launch_rms_scale(LaunchCtx ctx, const float* wav, int B, int L, float* scale) {
+    LAUNCH(ctx, "rms_scale", (rms_scale_kernel<<<B, 1024, 0, ctx.stream>>>(wav, L, scale)));
+}
+
+// ---------------------------------------------------------------------------------
+// STFT + power compression.  block = (16 frames of one clip), 4 waves; the 16 frames'
+// samples (15*hop + n_fft, reflect-padded, times the RMS scale) are staged in LDS once.
+// Orientation out[frame][bin]: A = frames (LDS), B = windowed DFT matrix (fragment-major,
+// global/L2), so for a fixed accumulator register 16 lanes hold 16 consecutive bins of
+// one frame and the store is contiguous.  Each wave owns bin blocks wv, wv+4, ... and
+// accumulates the re and im rows of a bin block together, so the compression
+// X * (re^2+im^2)^-0.35  (== mag^0.3 * (cos, sin)(phase), utils.py:20-29) is lane-local.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stft_compress_kernel(SpectralTables tb, const float* __restrict__ wav,
+                                                            const float* __restrict__ scale, int L, int T,
+                                                            float* __restrict__ spec) {
+    extern __shared__ __attribute__((aligned(16))) float seg[];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y, fb = blockIdx.x;
+    const int seglen = 15 * tb.hop + tb.n_fft;
+    const int start = fb * 16 * tb.hop - tb.n_fft / 2;
+    const float sc = scale ? scale[b] : 1.0f;
+    const float* x = wav + (long)b * L;
+    for (int i = threadIdx.x; i < seglen; i += 256) {
+        int s = start + i;
+        if (s < 0) s = -s;
+        if (s >= L) s = 2 * (L - 1) - s;
+        s = s < 0 ? 0 : (s >= L ? L - 1 : s);      // frames past T in the last block: any finite value
+        seg[i] = x[s] * sc;
+    }
+    __syncthreads();
+    const int KB = tb.n_fft / 16;
+    const long P = (long)T * tb.F;
+    for (int bb = wv; bb < tb.FB; bb += 4) {
+        f32x4 are = splat4(0.f), aim = splat4(0.f);
+        const float* wre = tb.fwd_fm + (long)bb * KB * 256 + lane * 4;
+        const float* wim = tb.fwd_fm + (long)(tb.FB + bb) * KB * 256 + lane * 4;
+#pragma unroll 5
+        for (int kb = 0; kb < KB; ++kb) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&seg[c * tb.hop + 16 * kb + 4 * g]);
+            const f32x4 br = ldg4(wre + kb * 256), bi = ldg4(wim + kb * 256);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                are = mfma16(a[r], br[r], are);
+                aim = mfma16(a[r], bi[r], aim);
+            }
+        }
+        const int bin = bb * 16 + c;
+        if (bin < tb.F) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = fb * 16 + 4 * g + r;
+                if (t < T) {
+                    const float m2 = are[r] * are[r] + aim[r] * aim[r];
+                    const float s = m2 > 0.f ? __powf(m2, -0.35f) : 0.f;
+                    spec[((long)b * 2 + 0) * P + (long)t * tb.F + bin] = are[r] * s;
+                    spec[((long)b * 2 + 1) * P + (long)t * tb.F + bin] = aim[r] * s;
+                }
+            }
+        }
+    }
+}
+
+void launch_stft_compress(LaunchCtx ctx, const SpectralTables& tb, const float* wav, const float* scale, int B,
+                          int L, int T, float* spec) {
+    dim3 grid((T + 15) / 16, B);
+    const size_t shm = (size_t)(15 * tb.hop + tb.n_fft) * sizeof(float);
+    LAUNCH(ctx, "stft_compress",
+           (stft_compress_kernel<<<grid, 256, shm, ctx.stream>>>(tb, wav, scale, L, T, spec)));
+}
+
+// ---------------------------------------------------------------------------------
+// power uncompress + inverse real DFT + synthesis window, per 16 frames.
+// est[B,1,T,F] (re, im) -> frames[B,T,n_fft].  The uncompressed spectrum
+// Y * (re^2+im^2)^(7/6)  (== mag^(1/0.3) with phase kept, utils.py:32-39) of 16 frames is
+// staged in LDS as [16][2*FB*16] (re bins | im bins, zero padded); the inverse matrix has
+// irfft's Hermitian weights (1, 2, ..., 2, 1; imag of DC/Nyquist ignored), 1/N and the
+// Hamming window folded in (evaluation.py:44-50).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void uncompress_irfft_kernel(SpectralTables tb, const float* __restrict__ re,
+                                                               const float* __restrict__ im, int T,
+                                                               float* __restrict__ frames) {
+    extern __shared__ __attribute__((aligned(16))) float ysp[];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y, fb = blockIdx.x;
+    const int K = 2 * tb.FB * 16;              // padded contraction length
+    const int ld = K + 4;                      // row pitch (floats), keeps 16 B alignment
+    const long P = (long)T * tb.F;
+    for (int i = threadIdx.x; i < 16 * tb.FB * 16; i += 256) {
+        const int fr = i / (tb.FB * 16), bin = i - fr * (tb.FB * 16);
+        const int t = fb * 16 + fr;
+        float yr = 0.f, yi = 0.f;
+        if (t < T && bin < tb.F) {
+            const float a = re[(long)b * P + (long)t * tb.F + bin], bq = im[(long)b * P + (long)t * tb.F + bin];
+            const float m2 = a * a + bq * bq;
+            const float s = m2 > 0.f ? __powf(m2, 7.0f / 6.0f) : 0.f;
+            yr = a * s;
+            yi = bq * s;
+        }
+        ysp[fr * ld + bin] = yr;
+        ysp[fr * ld + tb.FB * 16 + bin] = yi;
+    }
+    __syncthreads();
+    const int KB = K / 16;
+    const int NB = tb.n_fft / 16;
+    for (int nb = wv; nb < NB; nb += 4) {
+        f32x4 acc0 = splat4(0.f), acc1 = splat4(0.f);
+        const float* wp = tb.inv_fm + (long)nb * KB * 256 + lane * 4;
+        for (int kb = 0; kb < KB; kb += 2) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&ysp[c * ld + 16 * kb + 4 * g]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&ysp[c * ld + 16 * (kb + 1) + 4 * g]);
+            const f32x4 b0 = ldg4(wp + kb * 256), b1 = ldg4(wp + (kb + 1) * 256);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc0 = mfma16(a0[r], b0[r], acc0);
+                acc1 = mfma16(a1[r], b1[r], acc1);
+            }
+        }
+        const int n = nb * 16 + c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = fb * 16 + 4 * g + r;
+            if (t < T) frames[((long)b * T + t) * tb.n_fft + n] = acc0[r] + acc1[r];
+        }
+    }
+}
+
+// overlap-add, window-envelope division, centre trim, '/ c'   (torch.istft; evaluation.py:51)
+__global__ __launch_bounds__(256) void ola_kernel(const float* __restrict__ frames, const float* __restrict__ window,
+                                                  const float* __restrict__ scale, int n_fft, int hop, int T,
+                                                  int Lout, float* __restrict__ wav) {
+    const int b = blockIdx.y;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= Lout) return;
+    const int p = s + n_fft / 2;
+    int t1 = p / hop;
+    if (t1 > T - 1) t1 = T - 1;
+    int t0 = (p - n_fft + hop) / hop;          // ceil((p - n_fft + 1) / hop) for p >= n_fft - 1
+    if (p - n_fft + 1 <= 0) t0 = 0;
+    float acc = 0.f, env = 0.f;
+    for (int t = t0; t <= t1; ++t) {
+        const int n = p - t * hop;
+        if (n >= 0 && n < n_fft) {
+            acc += frames[((long)b * T + t) * n_fft + n];
+            env = fmaf(window[n], window[n], env);
+        }
+    }
+    float v = acc / env;
+    if (scale) v /= scale[b];
+    wav[(long)b * Lout + s] = v;
+}
+
+void launch_uncompress_istft(LaunchCtx ctx, const SpectralTables& tb, const float* re, const float* im,
+                             const float* scale, int B, int T, float* frames_ws, float* wav_out) {
+    dim3 grid((T + 15) / 16, B);
+    const size_t shm = (size_t)16 * (2 * tb.FB * 16 + 4) * sizeof(float);
+    LAUNCH(ctx, "uncompress_irfft",
+           (uncompress_irfft_kernel<<<grid, 256, shm, ctx.stream>>>(tb, re, im, T, frames_ws)));
+    const int Lout = tb.hop * (T - 1);
+    dim3 g2((Lout + 255) / 256, B);
+    LAUNCH(ctx, "ola", (ola_kernel<<<g2, 256, 0, ctx.stream>>>(frames_ws, tb.window, scale, tb.n_fft, tb.hop, T, Lout,
+                                                              wav_out)));
+}
+
+// ---------------------------------------------------------------------------------
+// stand-alone utils.power_compress / power_uncompress (src/utils.py:20-39) in the
+// reference's own layouts, for drop-in use outside the fused pipeline.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void power_compress_kernel(const float* __restrict__ x, long FT, long total,
+                                                             float* __restrict__ y) {
+    // x[B,F,T,2] -> y[B,2,F,T]
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / FT, p = i - b * FT;
+        const float re = x[i * 2], im = x[i * 2 + 1];
+        const float m2 = re * re + im * im;
+        const float s = m2 > 0.f ? __powf(m2, -0.35f) : 0.f;
+        y[(b * 2 + 0) * FT + p] = re * s;
+        y[(b * 2 + 1) * FT + p] = im * s;
+    }
+}
+
+__global__ __launch_bounds__(256) void power_uncompress_kernel(const float* __restrict__ re,
+                                                               const float* __restrict__ im, long total,
+                                                               float* __restrict__ y) {
+    // real, imag [B,1,F,T] -> y[B,1,F,T,2]
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const float a = re[i], b = im[i];
+        const float m2 = a * a + b * b;
+        const float s = m2 > 0.f ? __powf(m2, 7.0f / 6.0f) : 0.f;
+        y[i * 2] = a * s;
+        y[i * 2 + 1] = b * s;
+    }
+}
+
+void launch_power_compress(LaunchCtx ctx, const float* x, int B, int F, int T, float* y) {
+    const long FT = (long)F * T, total = (long)B * FT;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    LAUNCH(ctx, "power_compress", (power_compress_kernel<<<grid, 256, 0, ctx.stream>>>(x, FT, total, y)));
+}
+
+void launch_power_uncompress(LaunchCtx ctx, const float* re, const float* im, int B, int F, int T, float* y) {
+    const long total = (long)B * F * T;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    LAUNCH(ctx, "power_uncompress", (power_uncompress_kernel<<<grid, 256, 0, ctx.stream>>>(re, im, total, y)));
+}

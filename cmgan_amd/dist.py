@@ -1,0 +1,62 @@
+"""Data-parallel launcher glue: one process per GPU, utterance batches sharded by rank,
+weights replicated, NO data-path collective (the forward has no cross-sample coupling in
+eval mode: InstanceNorm is per sample, BatchNorm1d uses running stats - SURVEY.md 8e).
+The only collective is the reduction of per-step scalars (north_star: "a single RCCL
+all-reduce over xGMI on the loss scalars"): backend "nccl" on ROCm is RCCL; tests use gloo.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world).  Single-process when WORLD_SIZE is unset/1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced [lo, hi) slice of n_items for `rank` (first n%world ranks get one more)."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batch(batch: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    lo, hi = shard_bounds(batch.size(0), rank, world)
+    return batch[lo:hi]
+
+
+def allreduce_scalars(values: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
+    """One small all-reduce (RCCL over xGMI on the GPU box); identity in a single process."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(values, op=op)
+    return values
+
+
+def gather_shards(local: torch.Tensor, n_items: int) -> torch.Tensor:
+    """Reassemble rank-ordered shards of a [n_items, ...] batch on every rank (test helper)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    sizes = [shard_bounds(n_items, r, world) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((mx,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.size(0)] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)

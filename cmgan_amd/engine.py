@@ -1,0 +1,214 @@
+"""Thin host wrapper over one libcmgan_hip handle.
+
+PyTorch is used only for device memory and streams: every method takes CUDA (ROCm)
+``torch.Tensor``s, passes their ``data_ptr()`` through the C ABI, and enqueues on
+``torch.cuda.current_stream()``.  No arithmetic happens in Python.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Config, KernelTime, Taps, check
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor must live on the GPU (cmgan_amd has no CPU path)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Engine:
+    """One handle = one device = one set of weights."""
+
+    def __init__(self, n_fft: int = 400, hop: int = 100, num_features: Optional[int] = None,
+                 num_tscb: int = 4, max_pos_emb: int = 512, device: Optional[torch.device] = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("cmgan_amd needs a ROCm GPU: torch.cuda.is_available() is False")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        cfg = _lib.default_config()
+        cfg.n_fft, cfg.hop = n_fft, hop
+        cfg.num_features = num_features if num_features is not None else n_fft // 2 + 1
+        cfg.num_tscb, cfg.max_pos_emb = num_tscb, max_pos_emb
+        self.cfg = cfg
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.lib.cmgan_create(ctypes.byref(self._h), ctypes.byref(cfg))
+        if rc != 0:
+            msg = self.lib.cmgan_last_error(None)
+            raise _lib.CmganError(rc, msg.decode() if msg else "?")
+        self._ws: Optional[torch.Tensor] = None
+        self._cws: Optional[torch.Tensor] = None
+        self.weights_loaded = False
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            try:
+                self.lib.cmgan_destroy(h)
+            except Exception:
+                pass
+            self._h = ctypes.c_void_p()
+
+    # ---- weights -------------------------------------------------------------------
+    def load_blob(self, blob: np.ndarray):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        with torch.cuda.device(self.device):
+            check(self._h, self.lib.cmgan_load_weights(self._h, blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes))
+        self.weights_loaded = True
+
+    # ---- workspace -----------------------------------------------------------------
+    def _workspace(self, B: int, T: int) -> torch.Tensor:
+        need = self.lib.cmgan_workspace_bytes(self._h, B, T)
+        if need == 0:
+            raise ValueError(f"bad batch/frames ({B}, {T})")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _conf_workspace(self, N: int, L: int) -> torch.Tensor:
+        need = self.lib.cmgan_conformer_workspace_bytes(self._h, N, L)
+        if self._cws is None or self._cws.numel() < need:
+            self._cws = None
+            self._cws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._cws
+
+    @property
+    def F(self) -> int:
+        return self.cfg.num_features
+
+    def num_frames(self, L: int) -> int:
+        return L // self.cfg.hop + 1
+
+    # ---- front / back end ----------------------------------------------------------
+    def rms_scale(self, wav: torch.Tensor) -> torch.Tensor:
+        wav = _f32c(wav, "wav")
+        B, L = wav.shape
+        out = torch.empty(B, dtype=torch.float32, device=wav.device)
+        check(self._h, self.lib.cmgan_rms_scale(self._h, wav.data_ptr(), B, L, out.data_ptr(), _stream()))
+        return out
+
+    def stft_compress(self, wav: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+        wav = _f32c(wav, "wav")
+        B, L = wav.shape
+        sp = _f32c(scale, "scale").data_ptr() if scale is not None else None
+        out = torch.empty(B, 2, self.num_frames(L), self.F, dtype=torch.float32, device=wav.device)
+        check(self._h, self.lib.cmgan_stft_compress(self._h, wav.data_ptr(), sp, B, L, out.data_ptr(), _stream()))
+        return out
+
+    def uncompress_istft(self, real: torch.Tensor, imag: torch.Tensor,
+                         scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+        real, imag = _f32c(real, "real"), _f32c(imag, "imag")
+        B, _, T, F = real.shape
+        if F != self.F or imag.shape != real.shape:
+            raise ValueError(f"expected 2 x [B,1,T,{self.F}], got {tuple(real.shape)} / {tuple(imag.shape)}")
+        ws = self._workspace(B, T)
+        sp = _f32c(scale, "scale").data_ptr() if scale is not None else None
+        out = torch.empty(B, self.cfg.hop * (T - 1), dtype=torch.float32, device=real.device)
+        check(self._h, self.lib.cmgan_uncompress_istft(self._h, real.data_ptr(), imag.data_ptr(), sp, B, T,
+                                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+        return out
+
+    def power_compress(self, x: torch.Tensor) -> torch.Tensor:
+        x = _f32c(x, "x")
+        B, F, T, two = x.shape
+        assert two == 2
+        y = torch.empty(B, 2, F, T, dtype=torch.float32, device=x.device)
+        check(self._h, self.lib.cmgan_power_compress(self._h, x.data_ptr(), B, F, T, y.data_ptr(), _stream()))
+        return y
+
+    def power_uncompress(self, real: torch.Tensor, imag: torch.Tensor) -> torch.Tensor:
+        real, imag = _f32c(real, "real"), _f32c(imag, "imag")
+        B, one, F, T = real.shape
+        y = torch.empty(B, 1, F, T, 2, dtype=torch.float32, device=real.device)
+        check(self._h, self.lib.cmgan_power_uncompress(self._h, real.data_ptr(), imag.data_ptr(), B, F, T,
+                                                       y.data_ptr(), _stream()))
+        return y
+
+    # ---- model ---------------------------------------------------------------------
+    def _need_weights(self):
+        if not self.weights_loaded:
+            raise RuntimeError("no weights loaded: call load_state_dict() first")
+
+    def tscnet_forward(self, x: torch.Tensor, taps: bool = False):
+        self._need_weights()
+        x = _f32c(x, "x")
+        B, two, T, F = x.shape
+        if two != 2 or F != self.F:
+            raise ValueError(f"expected [B,2,T,{self.F}], got {tuple(x.shape)}")
+        ws = self._workspace(B, T)
+        real = torch.empty(B, 1, T, F, dtype=torch.float32, device=x.device)
+        imag = torch.empty_like(real)
+        if not taps:
+            check(self._h, self.lib.cmgan_tscnet_forward(self._h, x.data_ptr(), B, T, real.data_ptr(),
+                                                         imag.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+            return real, imag
+        F2 = (F + 1) // 2
+        st = {"encoder": torch.empty(B, 64, T, F2, dtype=torch.float32, device=x.device),
+              "mask": torch.empty(B, 1, T, F, dtype=torch.float32, device=x.device),
+              "complex": torch.empty(B, 2, T, F, dtype=torch.float32, device=x.device)}
+        tp = Taps()
+        tp.encoder_dev = st["encoder"].data_ptr()
+        for k in range(self.cfg.num_tscb):
+            st[f"tscb{k + 1}"] = torch.empty(B, 64, T, F2, dtype=torch.float32, device=x.device)
+            tp.tscb_dev[k] = st[f"tscb{k + 1}"].data_ptr()
+        tp.mask_dev, tp.complex_dev = st["mask"].data_ptr(), st["complex"].data_ptr()
+        check(self._h, self.lib.cmgan_tscnet_forward_taps(self._h, x.data_ptr(), B, T, real.data_ptr(),
+                                                          imag.data_ptr(), ctypes.byref(tp), ws.data_ptr(),
+                                                          ws.numel(), _stream()))
+        return real, imag, st
+
+    def conformer_forward(self, index: int, x: torch.Tensor, taps: bool = False):
+        self._need_weights()
+        x = _f32c(x, "x")
+        N, L, C = x.shape
+        if C != 64:
+            raise ValueError("conformer dim must be 64")
+        ws = self._conf_workspace(N, L)
+        y = torch.empty_like(x)
+        tp = torch.empty(4, N, L, 64, dtype=torch.float32, device=x.device) if taps else None
+        check(self._h, self.lib.cmgan_conformer_forward(self._h, index, x.data_ptr(), N, L, y.data_ptr(),
+                                                        tp.data_ptr() if taps else None, ws.data_ptr(),
+                                                        ws.numel(), _stream()))
+        return (y, tp) if taps else y
+
+    def enhance(self, wav: torch.Tensor) -> torch.Tensor:
+        """wav[B,L] -> enhanced[B,L]: the whole device pipeline in one ABI call."""
+        self._need_weights()
+        wav = _f32c(wav, "wav")
+        B, L = wav.shape
+        ws = self._workspace(B, self.num_frames(L))
+        out = torch.empty_like(wav)
+        check(self._h, self.lib.cmgan_enhance(self._h, wav.data_ptr(), B, L, out.data_ptr(), ws.data_ptr(),
+                                              ws.numel(), _stream()))
+        return out
+
+    # ---- diagnostics ---------------------------------------------------------------
+    def selftest_mfma(self) -> float:
+        err = ctypes.c_float()
+        check(self._h, self.lib.cmgan_selftest_mfma(self._h, ctypes.byref(err)))
+        return float(err.value)
+
+    def set_profiling(self, on: bool):
+        check(self._h, self.lib.cmgan_set_profiling(self._h, 1 if on else 0))
+
+    def profile(self):
+        """[(kernel name, ms)] of the most recent forward (profiling must be on)."""
+        cap = 1024
+        buf = (KernelTime * cap)()
+        n = self.lib.cmgan_profile_read(self._h, buf, cap)
+        return [(buf[i].name.decode(), float(buf[i].ms)) for i in range(n)]

@@ -1,0 +1,170 @@
+/*
+ * cmgan_hip.h - C ABI of libcmgan_hip.so: the CMGAN generator forward path
+ * (waveform -> STFT -> power-compress -> TSCNet -> power-uncompress -> ISTFT)
+ * as hand-written HIP kernels for MI355X (gfx950 / CDNA4).
+ *
+ * The reference (ruizhecao96/CMGAN) is pure Python and has no operator / FFI
+ * boundary; the seam this library sits behind is the Python module boundary
+ * (SURVEY.md section 8b).  Each entry point cites the reference code it replaces
+ * (paths relative to the reference tree).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C types only; every pointer named *_dev is a device pointer owned by
+ *    the caller (e.g. torch.Tensor.data_ptr()); fp32 everywhere.
+ *  - every call returns 0 (CMGAN_OK) or a negative CMGAN_E_* code; the message is
+ *    available from cmgan_last_error().  Nothing throws across the ABI.
+ *  - all kernels are enqueued on the caller's `stream` (a hipStream_t passed as
+ *    void*; NULL = the legacy default stream) and return without synchronising.
+ *    No allocation, free or synchronisation happens inside forward calls, so they
+ *    can be captured into a hipGraph.
+ *  - a handle is bound to the device that was current at cmgan_create() and is
+ *    not re-entrant; use one handle per GPU / per process.
+ */
+#ifndef CMGAN_HIP_H
+#define CMGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CMGAN_OK             0
+#define CMGAN_E_BADARG      -1   /* null pointer / non-positive size               */
+#define CMGAN_E_BADSHAPE    -2   /* shape incompatible with the handle's config    */
+#define CMGAN_E_UNSUPPORTED -3   /* config outside what the kernels are built for  */
+#define CMGAN_E_WEIGHTS     -4   /* blob malformed / tensor missing / wrong size   */
+#define CMGAN_E_WORKSPACE   -5   /* workspace too small or misaligned              */
+#define CMGAN_E_HIP         -6   /* a HIP runtime call failed (see last_error)     */
+
+#define CMGAN_ABI_VERSION 1
+
+typedef struct cmgan_handle cmgan_handle;
+
+/* Hyper-parameters that are constructor arguments or literals in the reference:
+ * TSCNet(num_channel=64, num_features=n_fft/2+1)  src/models/generator.py:160-172
+ * n_fft=400, hop=100                               src/evaluation.py:62,78
+ * heads=4, dim_head=16, conv kernel 31             src/models/generator.py:75-90
+ * max_pos_emb=512                                  src/models/conformer.py:76      */
+typedef struct cmgan_config {
+    int32_t n_fft;         /* 400 (16 kHz) or 1200 (48 kHz); multiple of 16, even  */
+    int32_t hop;           /* 100 / 300; must divide n_fft                          */
+    int32_t num_features;  /* F = n_fft/2 + 1                                       */
+    int32_t num_channel;   /* 64 (the only value the kernels are specialised for)   */
+    int32_t num_tscb;      /* 4                                                     */
+    int32_t heads;         /* 4                                                     */
+    int32_t dim_head;      /* 16                                                    */
+    int32_t conv_kernel;   /* 31                                                    */
+    int32_t max_pos_emb;   /* 512                                                   */
+} cmgan_config;
+
+/* Fills *cfg with the reference's 16 kHz defaults (above). */
+void cmgan_default_config(cmgan_config* cfg);
+
+int  cmgan_abi_version(void);
+
+/* Creates a handle on the current device; builds the window / DFT tables
+ * (replaces the torch.hamming_window + cuFFT plan of src/evaluation.py:36-38,44-50). */
+int  cmgan_create(cmgan_handle** out, const cmgan_config* cfg);
+void cmgan_destroy(cmgan_handle* h);
+
+/* Last error message for this handle (or for a failed cmgan_create when h == NULL). */
+const char* cmgan_last_error(const cmgan_handle* h);
+
+/* Uploads packed weights.  `blob` is the host buffer produced by
+ * cmgan_amd.packer.pack_state_dict() from the reference generator state_dict
+ * (the 359-entry dict loaded at src/evaluation.py:63-64).  Layout: see
+ * cmgan_amd/csrc/weights.h.  May be called again to swap weights (synchronises). */
+int  cmgan_load_weights(cmgan_handle* h, const void* blob, size_t bytes);
+
+/* Bytes of scratch the forward calls need for a batch of B spectrograms of T
+ * frames (0 on bad arguments).  The caller allocates it once (256-byte aligned). */
+size_t cmgan_workspace_bytes(const cmgan_handle* h, int B, int T);
+
+/* c[b] = sqrt(L / sum_l wav[b,l]^2)            src/evaluation.py:21, src/train.py:75-79 */
+int cmgan_rms_scale(cmgan_handle* h, const float* wav_dev, int B, int L,
+                    float* scale_dev, void* stream);
+
+/* Frames of an L-sample row: L / hop + 1 (torch.stft, center=True). */
+int cmgan_num_frames(const cmgan_handle* h, int L);
+
+/* wav[B,L] (optionally scaled by scale_dev[B]; NULL = 1) -> power-compressed
+ * spectrogram spec[B,2,T,F] = the tensor fed to TSCNet.forward.
+ * Replaces torch.stft + utils.power_compress + permute
+ * (src/evaluation.py:36-39, src/utils.py:20-29).  L % hop == 0, L > n_fft/2.  */
+int cmgan_stft_compress(cmgan_handle* h, const float* wav_dev, const float* scale_dev,
+                        int B, int L, float* spec_dev, void* stream);
+
+/* TSCNet.forward (src/models/generator.py:174-196):
+ * spec[B,2,T,F] -> out_real[B,1,T,F], out_imag[B,1,T,F].                       */
+int cmgan_tscnet_forward(cmgan_handle* h, const float* spec_dev, int B, int T,
+                         float* out_real_dev, float* out_imag_dev,
+                         void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* est_real/est_imag [B,1,T,F] -> waveform wav_out[B, hop*(T-1)], divided by
+ * scale_dev[B] when it is not NULL.  Replaces permute + utils.power_uncompress +
+ * torch.istft + '/ c'  (src/evaluation.py:41-51, src/utils.py:32-39).          */
+int cmgan_uncompress_istft(cmgan_handle* h, const float* real_dev, const float* imag_dev,
+                           const float* scale_dev, int B, int T, float* wav_out_dev,
+                           void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* The whole device pipeline of enhance_one_track (src/evaluation.py:21-51) for a
+ * batch of equal-length rows: per-row RMS scale, STFT, TSCNet, ISTFT, un-scale.
+ * wav[B,L] -> wav_out[B,L];  L % hop == 0.                                      */
+int cmgan_enhance(cmgan_handle* h, const float* wav_dev, int B, int L, float* wav_out_dev,
+                  void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* utils.power_compress (src/utils.py:20-29): x[B,F,T,2] -> y[B,2,F,T].          */
+int cmgan_power_compress(cmgan_handle* h, const float* x_dev, int B, int F, int T,
+                         float* y_dev, void* stream);
+/* utils.power_uncompress (src/utils.py:32-39): real,imag[B,1,F,T] -> y[B,1,F,T,2]. */
+int cmgan_power_uncompress(cmgan_handle* h, const float* real_dev, const float* imag_dev,
+                           int B, int F, int T, float* y_dev, void* stream);
+
+/* ConformerBlock.forward (src/models/conformer.py:216-222), eval mode, for the
+ * conformer stored in slot `index` of the loaded weights (2*(k-1) = TSCB_k.time,
+ * 2*(k-1)+1 = TSCB_k.freq; a standalone block is packed into slot 0).
+ * x[N,L,64] contiguous -> y[N,L,64].  `taps_dev` (may be NULL) receives the
+ * residual stream after ff1 / attn / conv / ff2 as 4 consecutive [N,L,64] tensors
+ * (test hook).  Workspace: cmgan_conformer_workspace_bytes(h, N, L).            */
+size_t cmgan_conformer_workspace_bytes(const cmgan_handle* h, int N, int L);
+int cmgan_conformer_forward(cmgan_handle* h, int index, const float* x_dev, int N, int L,
+                            float* y_dev, float* taps_dev,
+                            void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Stage taps of TSCNet.forward for parity tests (NCHW like the reference so the
+ * tests read like the reference's module outputs); any pointer may be NULL:
+ *   encoder[B,64,T,F']  = dense_encoder(x_in)        generator.py:181
+ *   tscb[4][B,64,T,F']  = TSCB_1..4 outputs          generator.py:182-185
+ *   mask[B,1,T,F], complex_out[B,2,T,F]              generator.py:187,190
+ * Runs the same kernels as cmgan_tscnet_forward.                                */
+typedef struct cmgan_taps {
+    float* encoder_dev;
+    float* tscb_dev[4];
+    float* mask_dev;
+    float* complex_dev;
+} cmgan_taps;
+int cmgan_tscnet_forward_taps(cmgan_handle* h, const float* spec_dev, int B, int T,
+                              float* out_real_dev, float* out_imag_dev, const cmgan_taps* taps,
+                              void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Self-test of the MFMA fragment conventions every kernel relies on: computes
+ * D = A(16xK) * B(Kx16) with the f32 16x16x4 MFMA and the library's fragment
+ * packing; returns max |D - reference| through *max_err_host (synchronises).   */
+int cmgan_selftest_mfma(cmgan_handle* h, float* max_err_host);
+
+/* Names + durations (ms) of the kernels of the most recent forward when
+ * profiling is enabled with cmgan_set_profiling(h, 1): HIP events are recorded
+ * around every launch on the caller's stream.  cmgan_profile_read synchronises
+ * the events, writes up to `cap` entries and returns the count.  bench.py uses it
+ * for the live per-kernel roofline figure.                                      */
+typedef struct cmgan_kernel_time { const char* name; float ms; } cmgan_kernel_time;
+int cmgan_set_profiling(cmgan_handle* h, int enabled);
+int cmgan_profile_read(cmgan_handle* h, cmgan_kernel_time* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMGAN_HIP_H */

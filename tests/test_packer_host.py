@@ -1,0 +1,104 @@
+"""CPU tests of the host side: the packed blob evaluated on CPU (tests/blob_model.py)
+reproduces the oracle, the blob directory is well formed, the C-ABI library loads and
+exports every declared symbol, and argument errors surface through the ABI."""
+import ctypes
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from blob_model import BlobModel, parse_blob, unfm
+from cmgan_amd import _lib, packer
+from conftest import ROOT, load_golden, rel_err
+from oracle import cmgan_oracle as O
+from oracle.weights import conformer_state_dict, make_state_dict
+
+
+def test_fm_roundtrip_and_lane_formula():
+    m = np.arange(32 * 48, dtype=np.float64).reshape(32, 48)
+    f = packer.fm(m)
+    back = unfm(torch.from_numpy(f.astype(np.float32)), 32, 48).numpy()
+    assert np.array_equal(back, m)
+    # spot-check the documented formula fm[rb][kb][lane][r] = M[16rb + (lane&15)][16kb + 4(lane>>4) + r]
+    f4 = f.reshape(2, 3, 64, 4)
+    for rb, kb, lane, r in [(0, 0, 0, 0), (1, 2, 37, 3), (0, 1, 63, 2), (1, 0, 16, 1)]:
+        assert f4[rb, kb, lane, r] == m[16 * rb + (lane & 15), 16 * kb + 4 * (lane >> 4) + r]
+
+
+def test_blob_directory_well_formed():
+    blob = packer.pack_state_dict(make_state_dict(0))
+    magic, ver, n, payload = struct.unpack_from("<4I", blob.tobytes(), 0)
+    assert magic == packer.MAGIC and ver == packer.VERSION
+    assert blob.nbytes == 16 + 16 * n + 4 * payload
+    ents = parse_blob(blob)
+    assert len(ents) == n == 7 + 3 * 16 + 5 + 6 + 8 * 20
+    assert ents[packer.wid(packer.G_CONF0 + 7, packer.CF_REL)].numel() == 1025 * 16
+
+
+def test_blob_conformer_matches_oracle_stagewise():
+    g = load_golden("conformer.npz")
+    csd = conformer_state_dict(seed=3)
+    bm = BlobModel(packer.pack_conformer_state_dict(csd, slot=0))
+    st = {}
+    y, _ = bm.conformer(0, g["x"], st)
+    for name in ("ff1", "attn", "conv", "ff2"):
+        assert rel_err(st[name], g[name]) < 2e-5, name
+    assert rel_err(y, g["out"]) < 2e-5
+
+
+def test_blob_tscnet_matches_golden():
+    g = load_golden("tscnet.npz")
+    bm = BlobModel(packer.pack_state_dict(make_state_dict(0)))
+    st = {}
+    real, imag = bm.forward(g["x"], st)
+    for name in ("encoder", "tscb1", "tscb4", "mask", "complex"):
+        assert rel_err(st[name], g[name]) < 5e-5, name
+    assert rel_err(real, g["real"]) < 5e-5
+    assert rel_err(imag, g["imag"]) < 5e-5
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "cmgan_hip.h")).read()
+    declared = set(re.findall(r"\b(cmgan_[a-z_0-9]+)\s*\(", header))
+    declared -= {"cmgan_amd"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.cmgan_abi_version() == 1
+
+
+def test_default_config_and_argument_errors_without_gpu():
+    lib = _lib.load()
+    cfg = _lib.default_config()
+    assert (cfg.n_fft, cfg.hop, cfg.num_features, cfg.num_channel, cfg.num_tscb) == (400, 100, 201, 64, 4)
+    assert (cfg.heads, cfg.dim_head, cfg.conv_kernel, cfg.max_pos_emb) == (4, 16, 31, 512)
+    h = ctypes.c_void_p()
+    assert lib.cmgan_create(ctypes.byref(h), None) == -1                      # CMGAN_E_BADARG
+    bad = _lib.default_config()
+    bad.num_channel = 32
+    assert lib.cmgan_create(ctypes.byref(h), ctypes.byref(bad)) == -3          # CMGAN_E_UNSUPPORTED
+    assert b"num_channel=64" in lib.cmgan_last_error(None)
+    bad = _lib.default_config()
+    bad.num_features = 200
+    assert lib.cmgan_create(ctypes.byref(h), ctypes.byref(bad)) == -3
+    assert lib.cmgan_workspace_bytes(None, 1, 1) == 0
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "cmgan_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src, fn
+
+
+def test_engine_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cmgan_amd import TSCNet
+    with pytest.raises(RuntimeError, match="needs a ROCm GPU"):
+        TSCNet(64, 201)
