@@ -55,21 +55,38 @@ def flops_per_clip():
 
 def cpu_baseline(sd, seconds_budget=20.0):
     """The oracle (CPU restatement of the reference path, torch fp32 on the host cores) timed on a
-    bounded sample of the same workload: B=1 clips of the same shape, repeated."""
+    bounded sample of the same workload: B=1 clips of the same shape, repeated.  torch's intra-op
+    pool scales badly past a few dozen threads on these small ops, so a short sweep picks the
+    thread count with the best throughput and the figure is quoted at that count."""
     from oracle import cmgan_oracle as O
     from oracle.weights import synthetic_clips
-    torch.set_num_threads(os.cpu_count() or 1)
     wav = synthetic_clips(1, CLIP_LEN, seed=0)
-    O.enhance_batch(sd, wav)                                   # warm-up
+    ncpu = os.cpu_count() or 1
+    cands = sorted({c for c in (8, 16, 32, 64) if c <= ncpu} | ({ncpu} if ncpu <= 64 else set()))
+    best, best_t = cands[0], float("inf")
+    t_start = time.perf_counter()
+    for c in cands:
+        torch.set_num_threads(c)
+        O.enhance_batch(sd, wav)                               # warm-up at this thread count
+        t0 = time.perf_counter()
+        O.enhance_batch(sd, wav)
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best, best_t = c, dt
+        if time.perf_counter() - t_start > seconds_budget:
+            break
+    torch.set_num_threads(best)
+    O.enhance_batch(sd, wav)
     n, t0 = 0, time.perf_counter()
     while True:
         O.enhance_batch(sd, wav)
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds_budget or n >= 12:
+        if dt >= seconds_budget * 0.5 or n >= 12:
             break
-    return {"value": n * T_FRAMES / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} x (B=1, 2 s clip, full pipeline) after 1 warm-up, {dt:.1f} s of CPU time"}
+    return {"value": n * T_FRAMES / dt, "unit": "frames/s", "cores": best, "host_cpus": ncpu, "kind": "port",
+            "sample": f"{n} x (B=1, 2 s clip, full pipeline wav->wav) at {best} threads (best of {cands}), "
+                      f"{dt:.1f} s timed"}
 
 
 def main():

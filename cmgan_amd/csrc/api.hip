@@ -399,7 +399,7 @@ extern "C" int cmgan_conformer_forward(cmgan_handle* h, int index, const float* 
     const size_t M = (size_t)N * L;
     HIPCHK(h, hipMemcpyAsync(b.xa, x, M * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
     const TokMap seq = make_seq_map(N, L, 1, L, 0, 1);
-    conformer_forward(begin(h, stream), w, b, seq, (long)M, taps);
+    conformer_forward(begin(h, stream), w, b, seq, (long)M, taps, false);
     HIPCHK(h, hipMemcpyAsync(y, b.xa, M * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return check_launch(h, "conformer_forward");
 }
@@ -505,8 +505,8 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
     const TokMap tmap = make_seq_map(B * F2, T, F2, (long)T * F2, 1, F2);
     const TokMap fmap = make_seq_map(B * T, F2, 1, F2, 0, 1);
     for (int k = 0; k < h->cfg.num_tscb; ++k) {
-        conformer_forward(ctx, cw[2 * k], cb, tmap, M, nullptr);
-        conformer_forward(ctx, cw[2 * k + 1], cb, fmap, M, nullptr);
+        conformer_forward(ctx, cw[2 * k], cb, tmap, M, nullptr, true);
+        conformer_forward(ctx, cw[2 * k + 1], cb, fmap, M, nullptr, true);
         if (taps && taps->tscb_dev[k]) launch_cl_to_nchw(ctx, f + p.xa, taps->tscb_dev[k], B, P2);
     }
 

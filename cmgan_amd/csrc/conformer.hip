@@ -101,8 +101,8 @@ __global__ __launch_bounds__(256) void ffn_kernel(const float* xin, float* xout,
             for (int ob = 0; ob < 4; ++ob) {
                 const f32x4 gm = ldg4(post_gb + 16 * ob + 4 * g);
                 const f32x4 bt = ldg4(post_gb + 64 + 16 * ob + 4 * g);
-                const f32x4 res = ldg4(x0 + row[tb] * 64 + 16 * ob + 4 * g);
-                y[tb][ob] = (y[tb][ob] - splat4(mean)) * splat4(rstd) * gm + bt + res;
+                y[tb][ob] = (y[tb][ob] - splat4(mean)) * splat4(rstd) * gm + bt;
+                if (x0) y[tb][ob] += ldg4(x0 + row[tb] * 64 + 16 * ob + 4 * g);   // TSCB outer residual
             }
         }
         if (ok[tb]) {
@@ -484,7 +484,7 @@ static inline int grid_for_blocks(int nblocks) {
 }
 
 void conformer_forward(LaunchCtx ctx, const ConfWeights& w, const ConfBuffers& b, const TokMap& seq, long M,
-                       float* taps) {
+                       float* taps, bool outer_residual) {
     const TokMap flat = make_flat_map(M);
     const int N = seq.nblocks / seq.Lb;
     hipStream_t s = ctx.stream;
@@ -519,7 +519,7 @@ void conformer_forward(LaunchCtx ctx, const ConfWeights& w, const ConfBuffers& b
                                w.ff2_b2, M, flat.nblocks)));
     }
     LAUNCH(ctx, "ffn_post", (ffn_kernel<true><<<grid_for_blocks(flat.nblocks), 256, 0, s>>>(
-                                b.xb, b.xa, b.xa, w.post_gb, w.ff2_w1, w.ff2_b1, w.ff2_w2, w.ff2_b2, M,
+                                b.xb, b.xa, outer_residual ? b.xa : nullptr, w.post_gb, w.ff2_w1, w.ff2_b1, w.ff2_w2, w.ff2_b2, M,
                                 flat.nblocks)));
 }
 

