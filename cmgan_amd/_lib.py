@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libcmgan_hip.so")
 
 OK = 0
-ABI_VERSION = 1
+ABI_VERSION = 2
+MFMA_F32, MFMA_F16X3 = 0, 1
 
 
 class CmganError(RuntimeError):
@@ -24,7 +25,7 @@ class CmganError(RuntimeError):
 
 class Config(Structure):
     _fields_ = [(n, c_int32) for n in ("n_fft", "hop", "num_features", "num_channel", "num_tscb",
-                                       "heads", "dim_head", "conv_kernel", "max_pos_emb")]
+                                       "heads", "dim_head", "conv_kernel", "max_pos_emb", "mfma_mode")]
 
 
 class Taps(Structure):
@@ -57,6 +58,7 @@ SIGNATURES = {
     "cmgan_conformer_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cmgan_tscnet_forward_taps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(Taps), c_void_p, c_size_t, c_void_p]),
     "cmgan_selftest_mfma": (c_int, [c_void_p, POINTER(c_float)]),
+    "cmgan_selftest_mfma_x3": (c_int, [c_void_p, POINTER(c_float)]),
     "cmgan_set_profiling": (c_int, [c_void_p, c_int]),
     "cmgan_profile_read": (c_int, [c_void_p, POINTER(KernelTime), c_int]),
 }

@@ -29,6 +29,9 @@ struct cmgan_handle {
     float* d_weights = nullptr;
     size_t weight_floats = 0;
     std::map<uint32_t, WEntry> dir;
+    // x3 (f16 split) operand images, built from the fp32 fragment-major weights at load time
+    _Float16* d_w16 = nullptr;
+    std::map<uint32_t, size_t> dir16;     // id -> offset in halfs (rel-pos lo plane at id | 0x8000)
     Profiler prof;
     std::vector<std::string> prof_names;
 };
@@ -59,6 +62,7 @@ extern "C" void cmgan_default_config(cmgan_config* c) {
     if (!c) return;
     c->n_fft = 400; c->hop = 100; c->num_features = 201; c->num_channel = 64; c->num_tscb = 4;
     c->heads = 4; c->dim_head = 16; c->conv_kernel = 31; c->max_pos_emb = 512;
+    c->mfma_mode = CMGAN_MFMA_F16X3;
 }
 
 extern "C" int cmgan_abi_version(void) { return CMGAN_ABI_VERSION; }
@@ -91,6 +95,8 @@ extern "C" int cmgan_create(cmgan_handle** out, const cmgan_config* cfg) {
                     "need n_fft %% 16 == 0, hop %% 4 == 0, hop | n_fft, num_features == n_fft/2+1 (odd)");
     if (cfg->num_tscb < 1 || cfg->num_tscb > 4 || cfg->max_pos_emb < 1)
         return fail(nullptr, CMGAN_E_UNSUPPORTED, "num_tscb must be 1..4, max_pos_emb >= 1");
+    if (cfg->mfma_mode != CMGAN_MFMA_F32 && cfg->mfma_mode != CMGAN_MFMA_F16X3)
+        return fail(nullptr, CMGAN_E_UNSUPPORTED, "mfma_mode must be CMGAN_MFMA_F32 (0) or CMGAN_MFMA_F16X3 (1)");
     cmgan_handle* h = new cmgan_handle();
     h->cfg = *cfg;
     hipError_t e = hipGetDevice(&h->device);
@@ -139,6 +145,7 @@ extern "C" void cmgan_destroy(cmgan_handle* h) {
     if (!h) return;
     if (h->d_tables) hipFree(h->d_tables);
     if (h->d_weights) hipFree(h->d_weights);
+    if (h->d_w16) hipFree(h->d_w16);
     for (auto ev : h->prof.pool) hipEventDestroy(ev);
     delete h;
 }
@@ -189,6 +196,87 @@ static size_t expected_count(const cmgan_config& c, uint32_t id) {
     return 0;
 }
 
+// ---- x3 operand images (common.hip.h): pure re-indexing of the fp32 fragment-major data ----------
+static void split_h(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+// fm [RB][KB][64][4]  ->  [RB][KB/2][hi|lo][64][8]
+static void x3_image(const float* fm, int RB, int KB, std::vector<_Float16>& out) {
+    const size_t base = out.size();
+    out.resize(base + (size_t)RB * (KB / 2) * 1024);
+    for (int rb = 0; rb < RB; ++rb)
+        for (int m = 0; m < KB / 2; ++m)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const float v = fm[(((size_t)rb * KB + 2 * m + (e >> 2)) * 64 + lane) * 4 + (e & 3)];
+                    _Float16 hi, lo;
+                    split_h(v, hi, lo);
+                    const size_t o = base + ((size_t)rb * (KB / 2) + m) * 1024 + lane * 8 + e;
+                    out[o] = hi;
+                    out[o + 512] = lo;
+                }
+}
+// conv fm [chunk16][taps][CB][64][4]  ->  [chunk32][taps][CB][hi|lo][64][8]
+static void x3_conv_image(const float* fm, int nchunk16, int taps, int CB, std::vector<_Float16>& out) {
+    const size_t base = out.size();
+    out.resize(base + (size_t)(nchunk16 / 2) * taps * CB * 1024);
+    for (int c32 = 0; c32 < nchunk16 / 2; ++c32)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int cb = 0; cb < CB; ++cb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int c16 = 2 * c32 + (e >> 2);
+                        const float v = fm[((((size_t)c16 * taps + tap) * CB + cb) * 64 + lane) * 4 + (e & 3)];
+                        _Float16 hi, lo;
+                        split_h(v, hi, lo);
+                        const size_t o = base + (((size_t)c32 * taps + tap) * CB + cb) * 1024 + lane * 8 + e;
+                        out[o] = hi;
+                        out[o + 512] = lo;
+                    }
+}
+
+static int build_x3_images(cmgan_handle* h, const float* payload, const std::map<uint32_t, WEntry>& dir) {
+    std::vector<_Float16> img;
+    std::map<uint32_t, size_t> d16;
+    auto pad = [&]() { while (img.size() % 64) img.push_back((_Float16)0.f); };
+    for (auto& kv : dir) {
+        const uint32_t id = kv.first, grp = id / 64, item = id % 64;
+        const float* src = payload + kv.second.off;
+        if (grp >= G_CONF0 && grp < G_CONF0 + 8) {
+            int RB = 0, KB = 0;
+            switch (item) {
+                case CF_FF1_W1: case CF_FF2_W1: case CF_PW1_W: RB = 16; KB = 4; break;
+                case CF_FF1_W2: case CF_FF2_W2: RB = 4; KB = 16; break;
+                case CF_QKV_W: RB = 12; KB = 4; break;
+                case CF_WO: RB = 4; KB = 4; break;
+                case CF_PW2_W: RB = 4; KB = 8; break;
+                default: break;
+            }
+            if (RB) { pad(); d16[id] = img.size(); x3_image(src, RB, KB, img); }
+            if (item == CF_REL) {
+                const size_t n = kv.second.count;
+                pad(); d16[id] = img.size();
+                for (size_t i = 0; i < n; ++i) img.push_back((_Float16)src[i]);
+                pad(); d16[id | 0x8000u] = img.size();
+                for (size_t i = 0; i < n; ++i) { _Float16 hi, lo; split_h(src[i], hi, lo); img.push_back(lo); }
+            }
+        } else if (grp == G_DB_E || grp == G_DB_M || grp == G_DB_C) {
+            if (item % 4 == 0) { pad(); d16[id] = img.size(); x3_conv_image(src, 4 * (item / 4 + 1), 6, 4, img); }
+        } else if (grp == G_ENC && item == ENC_C2_W) {
+            pad(); d16[id] = img.size(); x3_conv_image(src, 4, 3, 4, img);
+        } else if ((grp == G_MASK && item == MK_SP_W) || (grp == G_CPLX && item == CX_SP_W)) {
+            pad(); d16[id] = img.size(); x3_conv_image(src, 4, 3, 8, img);
+        }
+    }
+    pad();
+    if (h->d_w16) { hipFree(h->d_w16); h->d_w16 = nullptr; }
+    HIPCHK(h, hipMalloc(&h->d_w16, img.size() * sizeof(_Float16) + 256));
+    HIPCHK(h, hipMemcpy(h->d_w16, img.data(), img.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    h->dir16.swap(d16);
+    return CMGAN_OK;
+}
+
 extern "C" int cmgan_load_weights(cmgan_handle* h, const void* blob, size_t bytes) {
     if (!h) return CMGAN_E_BADARG;
     if (!blob || bytes < 16) return fail(h, CMGAN_E_BADARG, "cmgan_load_weights: null / short blob");
@@ -215,6 +303,7 @@ extern "C" int cmgan_load_weights(cmgan_handle* h, const void* blob, size_t byte
     HIPCHK(h, hipMalloc(&h->d_weights, (size_t)payload * 4 + 256));
     HIPCHK(h, hipMemcpy(h->d_weights, (const char*)blob + head, (size_t)payload * 4, hipMemcpyHostToDevice));
     h->weight_floats = payload;
+    if (int rc = build_x3_images(h, (const float*)((const char*)blob + head), dir)) return rc;
     h->dir.swap(dir);
     return CMGAN_OK;
 }
@@ -227,6 +316,27 @@ static const float* W(cmgan_handle* h, uint32_t id, bool& okflag) {
         return nullptr;
     }
     return h->d_weights + it->second.off;
+}
+
+static const _Float16* W16(cmgan_handle* h, uint32_t id, bool& okflag) {
+    auto it = h->dir16.find(id);
+    if (it == h->dir16.end()) {
+        if (okflag) fail(h, CMGAN_E_WEIGHTS, "x3 image of weight id %u not built", id);
+        okflag = false;
+        return nullptr;
+    }
+    return h->d_w16 + it->second;
+}
+
+static bool conf_weights_x3(cmgan_handle* h, int index, ConfWeightsX3& w) {
+    bool ok = true;
+    const int g = G_CONF0 + index;
+    w.ff1_w1 = W16(h, WID(g, CF_FF1_W1), ok); w.ff1_w2 = W16(h, WID(g, CF_FF1_W2), ok);
+    w.qkv_w = W16(h, WID(g, CF_QKV_W), ok);   w.wo = W16(h, WID(g, CF_WO), ok);
+    w.pw1_w = W16(h, WID(g, CF_PW1_W), ok);   w.pw2_w = W16(h, WID(g, CF_PW2_W), ok);
+    w.ff2_w1 = W16(h, WID(g, CF_FF2_W1), ok); w.ff2_w2 = W16(h, WID(g, CF_FF2_W2), ok);
+    w.rel_h = W16(h, WID(g, CF_REL), ok);     w.rel_l = W16(h, WID(g, CF_REL) | 0x8000u, ok);
+    return ok;
 }
 
 static bool conf_weights(cmgan_handle* h, int index, ConfWeights& w) {
@@ -399,7 +509,13 @@ extern "C" int cmgan_conformer_forward(cmgan_handle* h, int index, const float* 
     const size_t M = (size_t)N * L;
     HIPCHK(h, hipMemcpyAsync(b.xa, x, M * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
     const TokMap seq = make_seq_map(N, L, 1, L, 0, 1);
-    conformer_forward(begin(h, stream), w, b, seq, (long)M, taps, false);
+    if (h->cfg.mfma_mode == CMGAN_MFMA_F16X3) {
+        ConfWeightsX3 w16;
+        if (!conf_weights_x3(h, index, w16)) return CMGAN_E_WEIGHTS;
+        conformer_forward_x3(begin(h, stream), w, w16, b, seq, (long)M, taps, false);
+    } else {
+        conformer_forward(begin(h, stream), w, b, seq, (long)M, taps, false);
+    }
     HIPCHK(h, hipMemcpyAsync(y, b.xa, M * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return check_launch(h, "conformer_forward");
 }
@@ -407,22 +523,23 @@ extern "C" int cmgan_conformer_forward(cmgan_handle* h, int index, const float* 
 // ------------------------------------------------------------------------------------
 // TSCNet.forward
 // ------------------------------------------------------------------------------------
-struct DenseW { const float *w[4], *bias[4], *gb[4], *prelu[4]; };
+struct DenseW { const float *w[4], *bias[4], *gb[4], *prelu[4]; const _Float16* w16[4]; };
 static bool dense_weights(cmgan_handle* h, int grp, DenseW& d) {
     bool ok = true;
     for (int i = 0; i < 4; ++i) {
         d.w[i] = W(h, WID(grp, DB_W(i)), ok); d.bias[i] = W(h, WID(grp, DB_BIAS(i)), ok);
         d.gb[i] = W(h, WID(grp, DB_GB(i)), ok); d.prelu[i] = W(h, WID(grp, DB_PRELU(i)), ok);
+        d.w16[i] = W16(h, WID(grp, DB_W(i)), ok);
     }
     return ok;
 }
 
 // DilatedDenseNet (generator.py:39-47): slot 0 = x0 (with optional norm-on-load), layer i writes slot i+1.
 // ns(j) -> {scale, shift} storage for norm instance j; returns the instance index used by the last layer.
-static void run_dense_block(LaunchCtx ctx, const DenseW& d, const float* x0, const float* x0_scale,
+static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float* x0, const float* x0_scale,
                             const float* x0_shift, const float* x0_alpha, float* const slots[4], float* partials,
                             float* const nsc[4], float* const nsh[4], int B, int T, int F) {
-    const int nt = conv3_ntiles(T, F);
+    const int nt = x3 ? conv3x_ntiles(T, F, 64) : conv3_ntiles(T, F);
     for (int i = 0; i < 4; ++i) {
         ConvArgs a{};
         a.in[0] = x0; a.nscale[0] = x0_scale; a.nshift[0] = x0_shift; a.nalpha[0] = x0_alpha;
@@ -433,7 +550,8 @@ static void run_dense_block(LaunchCtx ctx, const DenseW& d, const float* x0, con
         a.w = d.w[i]; a.bias = d.bias[i];
         a.out = slots[i]; a.partials = partials;
         a.T = T; a.F = F; a.dil = 1 << i; a.mode = 0; a.ntiles = nt;
-        launch_conv3(ctx, a, B, 2, 64);
+        if (x3) launch_conv3_x3(ctx, a, d.w16[i], B, 2, 64);
+        else launch_conv3(ctx, a, B, 2, 64);
         launch_in_finalize(ctx, partials, B, nt, 64, 0, (double)T * F, d.gb[i], nsc[i], nsh[i]);
     }
 }
@@ -472,8 +590,16 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
     const float* cx_pr = W(h, WID(G_CPLX, CX_PRELU), ok);
     const float* cx_tail = W(h, WID(G_CPLX, CX_TAIL_W), ok);
     const float* cx_bias = W(h, WID(G_CPLX, CX_BIAS), ok);
+    const bool x3 = h->cfg.mfma_mode == CMGAN_MFMA_F16X3;
     ConfWeights cw[8];
-    for (int i = 0; i < 2 * h->cfg.num_tscb; ++i) ok = conf_weights(h, i, cw[i]) && ok;
+    ConfWeightsX3 cw16[8];
+    for (int i = 0; i < 2 * h->cfg.num_tscb; ++i) {
+        ok = conf_weights(h, i, cw[i]) && ok;
+        if (x3) ok = conf_weights_x3(h, i, cw16[i]) && ok;
+    }
+    const _Float16* c2w16 = x3 ? W16(h, WID(G_ENC, ENC_C2_W), ok) : nullptr;
+    const _Float16* mk_spw16 = x3 ? W16(h, WID(G_MASK, MK_SP_W), ok) : nullptr;
+    const _Float16* cx_spw16 = x3 ? W16(h, WID(G_CPLX, CX_SP_W), ok) : nullptr;
     if (!ok) return CMGAN_E_WEIGHTS;
 
     auto nsc = [&](int j) { return f + p.ns + (size_t)j * 2 * B * 64; };
@@ -487,14 +613,15 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
         float* slots[4] = {f + p.e[1], f + p.e[2], f + p.e[3], f + p.e[4]};
         float* sc[4] = {nsc(1), nsc(2), nsc(3), nsc(4)};
         float* sh[4] = {nsh(1), nsh(2), nsh(3), nsh(4)};
-        run_dense_block(ctx, dbe, f + p.e[0], nsc(0), nsh(0), c1pr, slots, partials, sc, sh, B, T, F);
+        run_dense_block(ctx, x3, dbe, f + p.e[0], nsc(0), nsh(0), c1pr, slots, partials, sc, sh, B, T, F);
     }
     {   // conv_2: (1,3) stride (1,2) pad (0,1) == stride-1 conv keeping the even columns
         ConvArgs a{};
         a.in[0] = f + p.e[4]; a.nscale[0] = nsc(4); a.nshift[0] = nsh(4); a.nalpha[0] = dbe.prelu[3];
         a.nslots = 1; a.w = c2w; a.bias = c2b; a.out = f + p.xb; a.partials = partials;
-        a.T = T; a.F = F; a.dil = 1; a.mode = 1; a.ntiles = conv3_ntiles(T, F);
-        launch_conv3(ctx, a, B, 1, 64);
+        a.T = T; a.F = F; a.dil = 1; a.mode = 1; a.ntiles = x3 ? conv3x_ntiles(T, F, 64) : conv3_ntiles(T, F);
+        if (x3) launch_conv3_x3(ctx, a, c2w16, B, 1, 64);
+        else launch_conv3(ctx, a, B, 1, 64);
         launch_in_finalize(ctx, partials, B, a.ntiles, 64, 0, (double)P2, c2gb, nsc(5), nsh(5));
         launch_in_apply(ctx, f + p.xb, nsc(5), nsh(5), c2pr, f + p.xa, B, P2);
     }
@@ -505,27 +632,33 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
     const TokMap tmap = make_seq_map(B * F2, T, F2, (long)T * F2, 1, F2);
     const TokMap fmap = make_seq_map(B * T, F2, 1, F2, 0, 1);
     for (int k = 0; k < h->cfg.num_tscb; ++k) {
-        conformer_forward(ctx, cw[2 * k], cb, tmap, M, nullptr, true);
-        conformer_forward(ctx, cw[2 * k + 1], cb, fmap, M, nullptr, true);
+        if (x3) {
+            conformer_forward_x3(ctx, cw[2 * k], cw16[2 * k], cb, tmap, M, nullptr, true);
+            conformer_forward_x3(ctx, cw[2 * k + 1], cw16[2 * k + 1], cb, fmap, M, nullptr, true);
+        } else {
+            conformer_forward(ctx, cw[2 * k], cb, tmap, M, nullptr, true);
+            conformer_forward(ctx, cw[2 * k + 1], cb, fmap, M, nullptr, true);
+        }
         if (taps && taps->tscb_dev[k]) launch_cl_to_nchw(ctx, f + p.xa, taps->tscb_dev[k], B, P2);
     }
 
     // ---- decoders (generator.py:133-139, 151-156) ------------------------------------
     float* dslots[4] = {f + p.e[1], f + p.e[2], f + p.e[3], f + p.e[4]};
     float* sp = f + p.e[0];
-    const int nt2 = conv3_ntiles(T, F2);
+    const int nt2 = x3 ? conv3x_ntiles(T, F2, 128) : conv3_ntiles(T, F2);
     for (int dec = 0; dec < 2; ++dec) {
         const DenseW& d = dec == 0 ? dbm : dbc;
         const int j0 = dec == 0 ? 6 : 10;
         float* sc[4] = {nsc(j0), nsc(j0 + 1), nsc(j0 + 2), nsc(j0 + 3)};
         float* sh[4] = {nsh(j0), nsh(j0 + 1), nsh(j0 + 2), nsh(j0 + 3)};
-        run_dense_block(ctx, d, f + p.xa, nullptr, nullptr, nullptr, dslots, partials, sc, sh, B, T, F2);
+        run_dense_block(ctx, x3, d, f + p.xa, nullptr, nullptr, nullptr, dslots, partials, sc, sh, B, T, F2);
         ConvArgs a{};
         a.in[0] = dslots[3]; a.nscale[0] = sc[3]; a.nshift[0] = sh[3]; a.nalpha[0] = d.prelu[3];
         a.nslots = 1; a.w = dec == 0 ? mk_spw : cx_spw; a.bias = dec == 0 ? mk_spb : cx_spb;
         a.out = sp; a.partials = dec == 0 ? nullptr : partials;
         a.T = T; a.F = F2; a.dil = 1; a.mode = 2; a.ntiles = nt2;
-        launch_conv3(ctx, a, B, 1, 128);
+        if (x3) launch_conv3_x3(ctx, a, dec == 0 ? mk_spw16 : cx_spw16, B, 1, 128);
+        else launch_conv3(ctx, a, B, 1, 128);
         if (dec == 0) {
             launch_tail_proj(ctx, sp, nullptr, nullptr, nullptr, mk_tail, f + p.dm, B, (long)T * W2);
         } else {
@@ -594,6 +727,39 @@ extern "C" int cmgan_selftest_mfma(cmgan_handle* h, float* max_err_host) {
     HIPCHK(h, hipMemcpy(da, af.data(), af.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(db, bf.data(), bf.size() * 4, hipMemcpyHostToDevice));
     launch_selftest_mfma(nullptr, da, db, dd, KB);
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(d.data(), dd, 1024, hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dd);
+    double worst = 0.0;
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            double ref = 0.0;
+            for (int k = 0; k < K; ++k) ref += (double)(float)A[i * K + k] * (double)(float)Bt[j * K + k];
+            worst = std::max(worst, fabs(ref - (double)d[i * 16 + j]));
+        }
+    *max_err_host = (float)worst;
+    return CMGAN_OK;
+}
+
+extern "C" int cmgan_selftest_mfma_x3(cmgan_handle* h, float* max_err_host) {
+    if (!h || !max_err_host) return CMGAN_E_BADARG;
+    const int KB = 4, K = 16 * KB;                   // two k32 blocks
+    std::vector<double> A(16 * K), Bt(16 * K);
+    for (int i = 0; i < 16; ++i)
+        for (int k = 0; k < K; ++k) {
+            A[i * K + k] = 0.173 * ((i * 7 + k * 3) % 11) - 0.83 + 1e-3 * k;
+            Bt[i * K + k] = 0.0917 * ((i * 5 + k * 13) % 17) - 0.61 + 0.013 * i;
+        }
+    std::vector<float> af(16 * K), bf(16 * K), d(256);
+    pack_fm(A, 16, K, af.data());
+    pack_fm(Bt, 16, K, bf.data());
+    std::vector<_Float16> aimg;
+    x3_image(af.data(), 1, KB, aimg);
+    _Float16* da; float *db, *dd;
+    HIPCHK(h, hipMalloc(&da, aimg.size() * 2)); HIPCHK(h, hipMalloc(&db, bf.size() * 4)); HIPCHK(h, hipMalloc(&dd, 1024));
+    HIPCHK(h, hipMemcpy(da, aimg.data(), aimg.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(db, bf.data(), bf.size() * 4, hipMemcpyHostToDevice));
+    launch_selftest_x3(nullptr, da, db, dd, KB / 2);
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(d.data(), dd, 1024, hipMemcpyDeviceToHost));
     hipFree(da); hipFree(db); hipFree(dd);

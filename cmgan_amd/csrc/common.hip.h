@@ -127,3 +127,71 @@ __device__ __forceinline__ void ln_stats(const f32x4 (&x)[4], float& mean, float
     }
     rstd = rsqrtf(red_g_sum(v) * (1.0f / 64.0f) + CMGAN_EPS);
 }
+
+// =====================================================================================
+// "x3" mode: fp32-accurate products on the f16 matrix pipe.
+// gfx950 has no TF32/xf32 and its fp32 MFMA runs at 1/16 of the f16/bf16 rate, so every
+// operand x is split as x = hi + lo with hi = fp16(x), lo = fp16(x - hi) and a product is
+// evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation:
+// ~2^-21 relative error per product (fp32-class) at ~5x the fp32-MFMA throughput.
+// All MFMA operands on this path are bounded (post-LayerNorm / InstanceNorm activations,
+// softmax probabilities, O(0.1) weights), far inside fp16 range; the unbounded STFT/ISTFT
+// stay on the fp32 pipe.
+//
+// 16x16x32 f16 convention: lane l (c = l & 15, g = l >> 4) feeds 8 halfs; k-slot (g, e),
+// e = 0..7.  Which contraction index a slot means is ours to choose, consistently for A
+// and B.  Chain convention: slot (g, e) of k32-block m  <->  feature 32m + 16(e>>2) + 4g + (e&3),
+// i.e. the concatenation of the two f32x4 C-fragments (blocks 2m, 2m+1) a lane already
+// holds - so layer outputs feed the next layer's B operand without any data movement.
+// A weight image is [ob][m][hi|lo][64 lanes][8 halfs] (built from the fp32 fragment-major
+// weights on the host at load time, api.hip).
+// =====================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x4 mfma32h(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f16x2 pkrtz(float a, float b) {
+    return __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+// 4 floats -> hi / lo halves (hi by round-toward-zero, lo = x - hi exactly representable residual, RTZ)
+__device__ __forceinline__ void split4(f32x4 v, f16x4& hi, f16x4& lo) {
+    const f16x2 h0 = pkrtz(v[0], v[1]), h1 = pkrtz(v[2], v[3]);
+    const f16x2 l0 = pkrtz(v[0] - (float)h0[0], v[1] - (float)h0[1]);
+    const f16x2 l1 = pkrtz(v[2] - (float)h1[0], v[3] - (float)h1[1]);
+    hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
+    lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
+}
+// two C-fragments (k-blocks 2m, 2m+1) -> one k32 B/A operand pair
+__device__ __forceinline__ void split8(f32x4 a, f32x4 b, f16x8& hi, f16x8& lo) {
+    f16x4 ha, la, hb, lb;
+    split4(a, ha, la);
+    split4(b, hb, lb);
+    hi = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
+    lo = __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// acc[tb] += W(ob, m = 0..M32) x B[tb][m]  with the three split products.
+// wp = image + ob*M32*1024 + lane*8 (halfs); image may live in LDS or global.
+template <int M32, int NTB_>
+__device__ __forceinline__ void lin_acc_x3(const _Float16* wp, const f16x8 (&bh)[NTB_][M32],
+                                           const f16x8 (&bl)[NTB_][M32], f32x4 (&acc)[NTB_]) {
+#pragma unroll
+    for (int m = 0; m < M32; ++m) {
+        const f16x8 ah = *reinterpret_cast<const f16x8*>(wp + m * 1024);
+        const f16x8 al = *reinterpret_cast<const f16x8*>(wp + m * 1024 + 512);
+#pragma unroll
+        for (int tb = 0; tb < NTB_; ++tb) acc[tb] = mfma32h(ah, bh[tb][m], acc[tb]);
+#pragma unroll
+        for (int tb = 0; tb < NTB_; ++tb) acc[tb] = mfma32h(ah, bl[tb][m], acc[tb]);
+#pragma unroll
+        for (int tb = 0; tb < NTB_; ++tb) acc[tb] = mfma32h(al, bh[tb][m], acc[tb]);
+    }
+}
+// block-cooperative linear copy global -> LDS in 16-byte units
+__device__ __forceinline__ void stage_lds16(const void* __restrict__ g, void* l, int n16) {
+    const uint4* src = reinterpret_cast<const uint4*>(g);
+    uint4* dst = reinterpret_cast<uint4*>(l);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+}

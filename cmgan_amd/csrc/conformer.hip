@@ -476,11 +476,17 @@ TokMap make_seq_map(int N, int L, int inner, long outer, long istride, long lstr
     return m;
 }
 
-size_t conf_qkv_floats(int N, int L) { return (size_t)N * 4 * ((L + 15) / 16) * 256; }
+size_t conf_qkv_floats(int N, int L) { return (size_t)N * 4 * (2 * ((L + 31) / 32)) * 256; }
 
 static inline int grid_for_blocks(int nblocks) {
     const int waves = (nblocks + NTB - 1) / NTB;
     return (waves + 3) / 4;
+}
+
+void launch_dwconv(LaunchCtx ctx, const float* u, float* out, const float* dw_w, const float* dw_b, const TokMap& seq) {
+    const int N = seq.nblocks / seq.Lb;
+    dim3 dwgrid(N, (seq.L + DW_TL - 1) / DW_TL);
+    LAUNCH(ctx, "dwconv", (dwconv_kernel<<<dwgrid, 256, 0, ctx.stream>>>(u, out, dw_w, dw_b, seq)));
 }
 
 void conformer_forward(LaunchCtx ctx, const ConfWeights& w, const ConfBuffers& b, const TokMap& seq, long M,
@@ -506,8 +512,7 @@ void conformer_forward(LaunchCtx ctx, const ConfWeights& w, const ConfBuffers& b
 
     LAUNCH(ctx, "pw1glu", (pw1glu_kernel<<<grid_for_blocks(flat.nblocks), 256, 0, s>>>(b.xb, b.u, w.pw1_w, w.pw1_b,
                                                                                         M, flat.nblocks)));
-    dim3 dwgrid(N, (seq.L + DW_TL - 1) / DW_TL);
-    LAUNCH(ctx, "dwconv", (dwconv_kernel<<<dwgrid, 256, 0, s>>>(b.u, b.w, w.dw_w, w.dw_b, seq)));
+    launch_dwconv(ctx, b.u, b.w, w.dw_w, w.dw_b, seq);
     LAUNCH(ctx, "pw2", (pw2_kernel<<<grid_for_blocks(flat.nblocks), 256, 0, s>>>(b.xb, b.w, w.pw2_w, w.pw2_b, M,
                                                                                   flat.nblocks)));
     if (taps) hipMemcpyAsync(taps + (size_t)2 * M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);

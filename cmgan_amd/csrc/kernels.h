@@ -98,11 +98,22 @@ struct ConfBuffers {
 };
 TokMap make_flat_map(long M);
 TokMap make_seq_map(int N, int L, int inner, long outer, long istride, long lstride);
-size_t conf_qkv_floats(int N, int L);   // floats of one of q/k/v/o for N sequences of length L
+size_t conf_qkv_floats(int N, int L);   // floats of one of q/k/v/o for N sequences of length L (Lb rounded up to even)
 // one ConformerBlock on the residual stream in bufs.xa (in place); taps (may be NULL) -> 4 x [M,64].
 // outer_residual: add the block's input again after post_norm (what TSCB does, generator.py:95,97).
 void conformer_forward(LaunchCtx, const ConfWeights&, const ConfBuffers&, const TokMap& seq, long M, float* taps,
                        bool outer_residual);
+
+// --------------------------- x3 mode (f16 split products) ------------------------
+struct ConfWeightsX3 {
+    const _Float16 *ff1_w1, *ff1_w2, *qkv_w, *wo, *pw1_w, *pw2_w, *ff2_w1, *ff2_w2, *rel_h, *rel_l;
+};
+void conformer_forward_x3(LaunchCtx, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&, const TokMap& seq,
+                          long M, float* taps, bool outer_residual);
+void launch_dwconv(LaunchCtx, const float* u, float* out, const float* dw_w, const float* dw_b, const TokMap& seq);
+int  conv3x_ntiles(int T, int F, int cout);
+void launch_conv3_x3(LaunchCtx, const ConvArgs&, const void* w16, int B, int time_taps, int cout);
+void launch_selftest_x3(hipStream_t, const void* a_img, const float* b_fm, float* d, int M32);
 
 // ------------------------------- selftest ---------------------------------------
 void launch_selftest_mfma(hipStream_t, const float* a_fm, const float* b_fm, float* d, int KB);

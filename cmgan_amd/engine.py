@@ -34,7 +34,10 @@ class Engine:
     """One handle = one device = one set of weights."""
 
     def __init__(self, n_fft: int = 400, hop: int = 100, num_features: Optional[int] = None,
-                 num_tscb: int = 4, max_pos_emb: int = 512, device: Optional[torch.device] = None):
+                 num_tscb: int = 4, max_pos_emb: int = 512, device: Optional[torch.device] = None,
+                 mfma_mode: Optional[str] = None):
+        """mfma_mode: "f16x3" (default; fp32-accurate split products on the f16 matrix pipe) or
+        "f32" (bit-exact fp32 MFMA) - see include/cmgan_hip.h."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("cmgan_amd needs a ROCm GPU: torch.cuda.is_available() is False")
@@ -43,6 +46,12 @@ class Engine:
         cfg.n_fft, cfg.hop = n_fft, hop
         cfg.num_features = num_features if num_features is not None else n_fft // 2 + 1
         cfg.num_tscb, cfg.max_pos_emb = num_tscb, max_pos_emb
+        if mfma_mode is not None:
+            modes = {"f32": _lib.MFMA_F32, "f16x3": _lib.MFMA_F16X3}
+            if mfma_mode not in modes:
+                raise ValueError(f"mfma_mode must be one of {sorted(modes)}")
+            cfg.mfma_mode = modes[mfma_mode]
+        self.mfma_mode = "f16x3" if cfg.mfma_mode == _lib.MFMA_F16X3 else "f32"
         self.cfg = cfg
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
@@ -201,6 +210,11 @@ class Engine:
     def selftest_mfma(self) -> float:
         err = ctypes.c_float()
         check(self._h, self.lib.cmgan_selftest_mfma(self._h, ctypes.byref(err)))
+        return float(err.value)
+
+    def selftest_mfma_x3(self) -> float:
+        err = ctypes.c_float()
+        check(self._h, self.lib.cmgan_selftest_mfma_x3(self._h, ctypes.byref(err)))
         return float(err.value)
 
     def set_profiling(self, on: bool):

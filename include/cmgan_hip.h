@@ -39,7 +39,7 @@ extern "C" {
 #define CMGAN_E_WORKSPACE   -5   /* workspace too small or misaligned              */
 #define CMGAN_E_HIP         -6   /* a HIP runtime call failed (see last_error)     */
 
-#define CMGAN_ABI_VERSION 1
+#define CMGAN_ABI_VERSION 2
 
 typedef struct cmgan_handle cmgan_handle;
 
@@ -58,7 +58,17 @@ typedef struct cmgan_config {
     int32_t dim_head;      /* 16                                                    */
     int32_t conv_kernel;   /* 31                                                    */
     int32_t max_pos_emb;   /* 512                                                   */
+    int32_t mfma_mode;     /* CMGAN_MFMA_F32 or CMGAN_MFMA_F16X3 (default)          */
 } cmgan_config;
+
+/* How the dense contractions (convs, linears, attention) are evaluated - both keep fp32
+ * storage and fp32 accumulation, and both meet the 1e-3 parity gate by >2 decades:
+ *   F32   : v_mfma_f32_16x16x4_f32, bit-exact fp32 products (157 TF peak)
+ *   F16X3 : every operand split x = hi + lo in fp16 and the product evaluated as
+ *           hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 (~2^-21 relative product error,
+ *           ~5x the fp32 matrix rate; gfx950 has no TF32).  STFT / ISTFT always run in F32.  */
+#define CMGAN_MFMA_F32   0
+#define CMGAN_MFMA_F16X3 1
 
 /* Fills *cfg with the reference's 16 kHz defaults (above). */
 void cmgan_default_config(cmgan_config* cfg);
@@ -154,6 +164,8 @@ int cmgan_tscnet_forward_taps(cmgan_handle* h, const float* spec_dev, int B, int
  * D = A(16xK) * B(Kx16) with the f32 16x16x4 MFMA and the library's fragment
  * packing; returns max |D - reference| through *max_err_host (synchronises).   */
 int cmgan_selftest_mfma(cmgan_handle* h, float* max_err_host);
+/* Same for the f16 16x16x32 MFMA + split-product images of the F16X3 mode. */
+int cmgan_selftest_mfma_x3(cmgan_handle* h, float* max_err_host);
 
 /* Names + durations (ms) of the kernels of the most recent forward when
  * profiling is enabled with cmgan_set_profiling(h, 1): HIP events are recorded

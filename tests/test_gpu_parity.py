@@ -28,16 +28,23 @@ def sd():
     return make_state_dict(seed=0, num_features=201)
 
 
-@pytest.fixture(scope="module")
-def model(sd):
+MODES = ["f16x3", "f32"]     # both matrix modes of the library are held to the same tolerances
+
+
+@pytest.fixture(scope="module", params=MODES)
+def model(request, sd):
     from cmgan_amd import TSCNet
-    return TSCNet(num_channel=64, num_features=201).cuda().load_state_dict(sd).eval()
+    m = TSCNet(num_channel=64, num_features=201, mfma_mode=request.param).cuda().load_state_dict(sd).eval()
+    print(f"[mode] TSCNet mfma_mode={m.engine.mfma_mode}")
+    return m
 
 
-@pytest.fixture(scope="module")
-def conf():
+@pytest.fixture(scope="module", params=MODES)
+def conf(request):
     from cmgan_amd import ConformerBlock
-    blk = ConformerBlock(dim=64, dim_head=16, heads=4, conv_kernel_size=31, attn_dropout=0.2, ff_dropout=0.2)
+    blk = ConformerBlock(dim=64, dim_head=16, heads=4, conv_kernel_size=31, attn_dropout=0.2, ff_dropout=0.2,
+                         mfma_mode=request.param)
+    print(f"[mode] ConformerBlock mfma_mode={blk.engine.mfma_mode}")
     return blk.load_state_dict(conformer_state_dict(seed=3)).eval()
 
 
@@ -46,6 +53,7 @@ def test_native_library_is_loaded_and_mfma_convention_holds(model):
     import cmgan_amd._lib as L
     assert L._lib is not None and "libcmgan_hip.so" in L.LIB_PATH
     assert model.engine.selftest_mfma() < 1e-5
+    assert _report("x3 split-product MFMA self-test (abs err on O(10) dot products)", model.engine.selftest_mfma_x3()) < 2e-5
 
 
 # ------------------------------------------------------------------ front / back end
@@ -155,10 +163,11 @@ def test_tscnet_matches_oracle_on_a_2s_clip(model, sd):
     assert _report("tscnet[2x321].imag", rel_err(imag, wi)) < GATE
 
 
-def test_tscnet_48k_variant_matches_reference_golden():
+@pytest.mark.parametrize("mode", MODES)
+def test_tscnet_48k_variant_matches_reference_golden(mode):
     from cmgan_amd import TSCNet
     g = load_golden("tscnet48.npz")
-    m48 = TSCNet(64, 601).load_state_dict(make_state_dict(seed=5, num_features=601))
+    m48 = TSCNet(64, 601, mfma_mode=mode).load_state_dict(make_state_dict(seed=5, num_features=601))
     real, imag = m48(g["x"].to(DEV))
     assert _report("tscnet48.real vs golden", rel_err(real, g["real"])) < STAGE
     assert _report("tscnet48.imag vs golden", rel_err(imag, g["imag"])) < STAGE

@@ -68,7 +68,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.cmgan_abi_version() == 1
+    assert lib.cmgan_abi_version() == _lib.ABI_VERSION
 
 
 def test_default_config_and_argument_errors_without_gpu():
@@ -76,6 +76,7 @@ def test_default_config_and_argument_errors_without_gpu():
     cfg = _lib.default_config()
     assert (cfg.n_fft, cfg.hop, cfg.num_features, cfg.num_channel, cfg.num_tscb) == (400, 100, 201, 64, 4)
     assert (cfg.heads, cfg.dim_head, cfg.conv_kernel, cfg.max_pos_emb) == (4, 16, 31, 512)
+    assert cfg.mfma_mode == _lib.MFMA_F16X3
     h = ctypes.c_void_p()
     assert lib.cmgan_create(ctypes.byref(h), None) == -1                      # CMGAN_E_BADARG
     bad = _lib.default_config()
