@@ -35,7 +35,7 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(const float* xin, float* xo
                                                      const _Float16* __restrict__ w1i, const float* __restrict__ b1,
                                                      const _Float16* __restrict__ w2i, const float* __restrict__ b2,
                                                      long M, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];
+    __shared__ __attribute__((aligned(16))) _Float16 wlds[65536];          // 128 KB
     _Float16* w1 = wlds;                 // 16*2*1024 halfs
     _Float16* w2 = wlds + 32768;         // 4*8*1024 halfs
     stage_lds16(w1i, w1, 4096);
@@ -136,7 +136,7 @@ struct QkvOut {
 __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x, TokMap m, int Lb2,
                                                      const _Float16* __restrict__ wi, const float* __restrict__ b,
                                                      QkvOut o, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];
+    __shared__ __attribute__((aligned(16))) _Float16 wlds[24576 + 4352];   // 48 KB image + 8.5 KB scratch
     _Float16* w = wlds;                                        // 12*2*1024 halfs = 48 KB
     float* scratch = reinterpret_cast<float*>(wlds + 24576);   // 8 waves x 16 x 17 floats
     stage_lds16(wi, w, 3072);
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(512) void outproj_x3_kernel(float* __restrict__ x, 
                                                          const float* __restrict__ o,
                                                          const _Float16* __restrict__ wi,
                                                          const float* __restrict__ bo, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];
+    __shared__ __attribute__((aligned(16))) _Float16 wlds[8192];
     stage_lds16(wi, wlds, 1024);                             // [4][2] image = 16 KB
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(512) void outproj_x3_kernel(float* __restrict__ x, 
 __global__ __launch_bounds__(512) void pw1glu_x3_kernel(const float* __restrict__ x, float* __restrict__ u,
                                                         const _Float16* __restrict__ wi,
                                                         const float* __restrict__ b, long M, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];
+    __shared__ __attribute__((aligned(16))) _Float16 wlds[32768];          // 64 KB
     stage_lds16(wi, wlds, 4096);
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(512) void pw1glu_x3_kernel(const float* __restrict_
 __global__ __launch_bounds__(512) void pw2_x3_kernel(float* __restrict__ x, const float* __restrict__ vin,
                                                      const _Float16* __restrict__ wi, const float* __restrict__ b,
                                                      long M, int ntiles) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 wlds[];
+    __shared__ __attribute__((aligned(16))) _Float16 wlds[16384];          // 32 KB
     stage_lds16(wi, wlds, 2048);
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
@@ -444,11 +444,6 @@ __global__ __launch_bounds__(512) void pw2_x3_kernel(float* __restrict__ x, cons
 // ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
-template <typename K>
-static void allow_lds(K kernel, size_t bytes) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-
 static int persistent_grid(int ntiles, int blocks_per_cu) {
     const int want = (ntiles + XWAVES - 1) / XWAVES;
     const int cap = 256 * blocks_per_cu;
@@ -457,16 +452,6 @@ static int persistent_grid(int ntiles, int blocks_per_cu) {
 
 void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeightsX3& w16, const ConfBuffers& b,
                           const TokMap& seq, long M, float* taps, bool outer_residual) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        allow_lds(ffn_x3_kernel<false>, 131072);
-        allow_lds(ffn_x3_kernel<true>, 131072);
-        allow_lds(qkv_x3_kernel, 49152 + 8704);
-        allow_lds(outproj_x3_kernel, 16384);
-        allow_lds(pw1glu_x3_kernel, 65536);
-        allow_lds(pw2_x3_kernel, 32768);
-        attr_done = true;
-    }
     hipStream_t s = ctx.stream;
     const int N = seq.nblocks / seq.Lb;
     const int Lb2 = (seq.Lb + 1) / 2;
@@ -479,33 +464,33 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
     io.kh = reinterpret_cast<_Float16*>(b.k); io.kl = io.kh + plane;
     io.vimg = reinterpret_cast<_Float16*>(b.v);
 
-    LAUNCH(ctx, "ffn", (ffn_x3_kernel<false><<<persistent_grid(flat_tiles, 1), 512, 131072, s>>>(
+    LAUNCH(ctx, "ffn", (ffn_x3_kernel<false><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(
                            b.xa, b.xb, nullptr, nullptr, w16.ff1_w1, w.ff1_b1, w16.ff1_w2, w.ff1_b2, M, flat_tiles)));
     if (taps) hipMemcpyAsync(taps, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
 
     const int qtiles = N * Lb2;
-    LAUNCH(ctx, "qkv", (qkv_x3_kernel<<<persistent_grid(qtiles, 2), 512, 49152 + 8704, s>>>(
+    LAUNCH(ctx, "qkv", (qkv_x3_kernel<<<persistent_grid(qtiles, 2), 512, 0, s>>>(
                            b.xb, seq, Lb2, w16.qkv_w, w.qkv_b, io, qtiles)));
     const long items = (long)N * 4 * seq.Lb;
     LAUNCH(ctx, "attn", (attn_x3_kernel<<<(unsigned)((items + 3) / 4), 256, 0, s>>>(
                             io, w16.rel_h, w16.rel_l, w.max_pos, b.o, seq.L, seq.Lb, Lb2, items)));
     const int otiles = (seq.nblocks + XNTB - 1) / XNTB;
-    LAUNCH(ctx, "outproj", (outproj_x3_kernel<<<persistent_grid(otiles, 2), 512, 16384, s>>>(b.xb, seq, b.o, w16.wo,
+    LAUNCH(ctx, "outproj", (outproj_x3_kernel<<<persistent_grid(otiles, 2), 512, 0, s>>>(b.xb, seq, b.o, w16.wo,
                                                                                            w.bo, otiles)));
     if (taps) hipMemcpyAsync(taps + (size_t)M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
 
-    LAUNCH(ctx, "pw1glu", (pw1glu_x3_kernel<<<persistent_grid(flat_tiles, 2), 512, 65536, s>>>(
+    LAUNCH(ctx, "pw1glu", (pw1glu_x3_kernel<<<persistent_grid(flat_tiles, 2), 512, 0, s>>>(
                               b.xb, b.u, w16.pw1_w, w.pw1_b, M, flat_tiles)));
     launch_dwconv(ctx, b.u, b.w, w.dw_w, w.dw_b, seq);
-    LAUNCH(ctx, "pw2", (pw2_x3_kernel<<<persistent_grid(flat_tiles, 2), 512, 32768, s>>>(b.xb, b.w, w16.pw2_w,
+    LAUNCH(ctx, "pw2", (pw2_x3_kernel<<<persistent_grid(flat_tiles, 2), 512, 0, s>>>(b.xb, b.w, w16.pw2_w,
                                                                                        w.pw2_b, M, flat_tiles)));
     if (taps) {
         hipMemcpyAsync(taps + (size_t)2 * M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
-        LAUNCH(ctx, "ffn", (ffn_x3_kernel<false><<<persistent_grid(flat_tiles, 1), 512, 131072, s>>>(
+        LAUNCH(ctx, "ffn", (ffn_x3_kernel<false><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(
                                b.xb, taps + (size_t)3 * M * 64, nullptr, nullptr, w16.ff2_w1, w.ff2_b1, w16.ff2_w2,
                                w.ff2_b2, M, flat_tiles)));
     }
-    LAUNCH(ctx, "ffn_post", (ffn_x3_kernel<true><<<persistent_grid(flat_tiles, 1), 512, 131072, s>>>(
+    LAUNCH(ctx, "ffn_post", (ffn_x3_kernel<true><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(
                                 b.xb, b.xa, outer_residual ? b.xa : nullptr, w.post_gb, w16.ff2_w1, w.ff2_b1,
                                 w16.ff2_w2, w.ff2_b2, M, flat_tiles)));
 }
