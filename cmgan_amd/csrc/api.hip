@@ -254,12 +254,15 @@ static int build_x3_images(cmgan_handle* h, const float* payload, const std::map
                 default: break;
             }
             if (RB) { pad(); d16[id] = img.size(); x3_image(src, RB, KB, img); }
-            if (item == CF_REL) {
-                const size_t n = kv.second.count;
+            if (item == CF_REL) {                               // rows of [hi 16 | lo 16] halfs
+                const size_t rows = kv.second.count / 16;
                 pad(); d16[id] = img.size();
-                for (size_t i = 0; i < n; ++i) img.push_back((_Float16)src[i]);
-                pad(); d16[id | 0x8000u] = img.size();
-                for (size_t i = 0; i < n; ++i) { _Float16 hi, lo; split_h(src[i], hi, lo); img.push_back(lo); }
+                for (size_t r = 0; r < rows; ++r) {
+                    _Float16 hi[16], lo[16];
+                    for (int d = 0; d < 16; ++d) split_h(src[r * 16 + d], hi[d], lo[d]);
+                    for (int d = 0; d < 16; ++d) img.push_back(hi[d]);
+                    for (int d = 0; d < 16; ++d) img.push_back(lo[d]);
+                }
             }
         } else if (grp == G_DB_E || grp == G_DB_M || grp == G_DB_C) {
             if (item % 4 == 0) { pad(); d16[id] = img.size(); x3_conv_image(src, 4 * (item / 4 + 1), 6, 4, img); }
@@ -335,7 +338,7 @@ static bool conf_weights_x3(cmgan_handle* h, int index, ConfWeightsX3& w) {
     w.qkv_w = W16(h, WID(g, CF_QKV_W), ok);   w.wo = W16(h, WID(g, CF_WO), ok);
     w.pw1_w = W16(h, WID(g, CF_PW1_W), ok);   w.pw2_w = W16(h, WID(g, CF_PW2_W), ok);
     w.ff2_w1 = W16(h, WID(g, CF_FF2_W1), ok); w.ff2_w2 = W16(h, WID(g, CF_FF2_W2), ok);
-    w.rel_h = W16(h, WID(g, CF_REL), ok);     w.rel_l = W16(h, WID(g, CF_REL) | 0x8000u, ok);
+    w.rel_img = W16(h, WID(g, CF_REL), ok);
     return ok;
 }
 

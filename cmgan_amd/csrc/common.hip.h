@@ -28,16 +28,32 @@ __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast
 __device__ __forceinline__ void stg4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ f32x4 splat4(float v) { f32x4 r = {v, v, v, v}; return r; }
 
-// reduce over the 4 lane groups (lanes c, c+16, c+32, c+48)
+// reduce over the 4 lane groups (lanes c, c+16, c+32, c+48) with v_permlane16/32_swap: two VALU
+// ops per step instead of a ds_bpermute round trip through the LDS crossbar.
+// permlane16_swap(v, v): {r0, r1} = {rows (0,0,2,2), rows (1,1,3,3)} of v; permlane32_swap: halves.
+__device__ __forceinline__ float xchg16(float v, float& other) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    other = __uint_as_float(r[1]);
+    return __uint_as_float(r[0]);
+}
+__device__ __forceinline__ float xchg32(float v, float& other) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    other = __uint_as_float(r[1]);
+    return __uint_as_float(r[0]);
+}
 __device__ __forceinline__ float red_g_sum(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    float b;
+    float a = xchg16(v, b);
+    v = a + b;
+    a = xchg32(v, b);
+    return a + b;
 }
 __device__ __forceinline__ float red_g_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
+    float b;
+    float a = xchg16(v, b);
+    v = fmaxf(a, b);
+    a = xchg32(v, b);
+    return fmaxf(a, b);
 }
 // reduce over the 16 lanes of one lane group (same g, c = 0..15)
 __device__ __forceinline__ float red_c_sum(float v) {

@@ -240,8 +240,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = j0 + 16 * jb + 4 * g + r;
-                float sv = -INFINITY;
-                if (jb < nb && key < L) sv = s[jb][r] + R[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE + c];
+                float sv = s[jb][r] + R[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE + c];   // always in range
+                sv = (jb < nb && key < L) ? sv : -INFINITY;       // select, not a per-lane branch
                 s[jb][r] = sv;
                 mx = fmaxf(mx, sv);
             }
@@ -249,13 +249,13 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
         wave_lds_fence();
         mx = red_g_max(mx);
         const float mnew = fmaxf(mrun, mx);
-        const float alpha = __expf(mrun - mnew);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);   // scores are in log2 units (packer)
         float psum = 0.f;
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(s[jb][r] - mnew);
+                const float p = __builtin_amdgcn_exp2f(s[jb][r] - mnew);
                 s[jb][r] = p;
                 psum += p;
             }

@@ -7,6 +7,8 @@
 //     d = 16 costs two MFMAs per 16x16 tile and yields all four split terms
 //   * Q / K are exchanged as row-major fp16 hi/lo rows, V as ready-made A-operand images
 //     (transposed through 1 KB of wave-private LDS in the producer)
+#include <stdlib.h>
+
 #include "kernels.h"
 
 #define XNTB 2
@@ -36,27 +38,38 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(const float* xin, float* xo
                                                      const _Float16* __restrict__ w2i, const float* __restrict__ b2,
                                                      long M, int ntiles) {
     __shared__ __attribute__((aligned(16))) _Float16 wlds[65536];          // 128 KB
+    __shared__ __attribute__((aligned(16))) float bias_l[320];             // b1[256] | b2[64]
     _Float16* w1 = wlds;                 // 16*2*1024 halfs
     _Float16* w2 = wlds + 32768;         // 4*8*1024 halfs
     stage_lds16(w1i, w1, 4096);
     stage_lds16(w2i, w2, 4096);
+    for (int i = threadIdx.x; i < 320; i += blockDim.x) bias_l[i] = i < 256 ? b1[i] : b2[i - 256];
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+
+// hidden units 32*M2 .. 32*M2+31 (two 16-blocks) for both token blocks: bias + W1 x (3 products)
+#define FFN_GEMM1(M2, H)                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
+        const int hb = 2 * (M2) + j;                                                                  \
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(&bias_l[16 * hb + 4 * g]);                 \
+        _Pragma("unroll") for (int tb = 0; tb < XNTB; ++tb) H[j][tb] = bias;                          \
+        lin_acc_x3<2, XNTB>(w1 + hb * 2048 + lane * 8, xbh, xbl, H[j]);                               \
+    }
 
 #pragma unroll 1
     for (int tile = blockIdx.x * XWAVES + wv; tile < ntiles; tile += gridDim.x * XWAVES) {
         long row[XNTB];
         bool ok[XNTB];
-        f32x4 x[XNTB][4];
         f16x8 xbh[XNTB][2], xbl[XNTB][2];
 #pragma unroll
         for (int tb = 0; tb < XNTB; ++tb) {
             const long t = ((long)tile * XNTB + tb) * 16 + c;
             ok[tb] = t < M;
             row[tb] = ok[tb] ? t : M - 1;
+            f32x4 x[4];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) x[tb][kb] = ldg4(xin + row[tb] * 64 + 16 * kb + 4 * g);
-            ln_split(x[tb], xbh[tb], xbl[tb]);
+            for (int kb = 0; kb < 4; ++kb) x[kb] = ldg4(xin + row[tb] * 64 + 16 * kb + 4 * g);
+            ln_split(x, xbh[tb], xbl[tb]);      // the residual is re-read in the epilogue (L2 hit): 32 VGPRs saved
         }
         f32x4 y[XNTB][4];
 #pragma unroll
@@ -64,26 +77,23 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(const float* xin, float* xo
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) y[tb][ob] = splat4(0.f);
 
+        // software pipeline over the 8 hidden k32-blocks: GEMM1(m2+1) is issued before the
+        // Swish/split of block m2, so its MFMAs overlap that VALU work inside one wave
+        f32x4 hcur[2][XNTB];
+        FFN_GEMM1(0, hcur)
 #pragma unroll 1
-        for (int m2 = 0; m2 < 8; ++m2) {              // hidden k32 blocks = pairs of 16-unit blocks
-            f32x4 hacc[2][XNTB];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int hb = 2 * m2 + j;
-                const f32x4 bias = ldg4(b1 + 16 * hb + 4 * g);
-#pragma unroll
-                for (int tb = 0; tb < XNTB; ++tb) hacc[j][tb] = bias;
-                lin_acc_x3<2, XNTB>(w1 + hb * 2048 + lane * 8, xbh, xbl, hacc[j]);
-            }
+        for (int m2 = 0; m2 < 8; ++m2) {
+            f32x4 hnext[2][XNTB];
+            if (m2 < 7) { FFN_GEMM1(m2 + 1, hnext) }
             f16x8 hh[XNTB], hl[XNTB];
 #pragma unroll
             for (int tb = 0; tb < XNTB; ++tb) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    hacc[0][tb][r] = swish_x(hacc[0][tb][r]);
-                    hacc[1][tb][r] = swish_x(hacc[1][tb][r]);
+                    hcur[0][tb][r] = swish_x(hcur[0][tb][r]);
+                    hcur[1][tb][r] = swish_x(hcur[1][tb][r]);
                 }
-                split8(hacc[0][tb], hacc[1][tb], hh[tb], hl[tb]);
+                split8(hcur[0][tb], hcur[1][tb], hh[tb], hl[tb]);
             }
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) {
@@ -97,11 +107,19 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(const float* xin, float* xo
 #pragma unroll
                 for (int tb = 0; tb < XNTB; ++tb) y[tb][ob] = mfma32h(al, hh[tb], y[tb][ob]);
             }
+            if (m2 < 7) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int tb = 0; tb < XNTB; ++tb) hcur[j][tb] = hnext[j][tb];
+            }
         }
 #pragma unroll
         for (int tb = 0; tb < XNTB; ++tb) {
 #pragma unroll
-            for (int ob = 0; ob < 4; ++ob) y[tb][ob] = y[tb][ob] + ldg4(b2 + 16 * ob + 4 * g) + x[tb][ob];
+            for (int ob = 0; ob < 4; ++ob)
+                y[tb][ob] = y[tb][ob] + *reinterpret_cast<const f32x4*>(&bias_l[256 + 16 * ob + 4 * g]) +
+                            ldg4(xin + row[tb] * 64 + 16 * ob + 4 * g);
             if (FINAL) {
                 float mean, rstd;
                 ln_stats(y[tb], mean, rstd);
@@ -124,13 +142,14 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(const float* xin, float* xo
 // ---------------------------------------------------------------------------------
 // LN -> q (x0.25 folded), k, v.  A wave owns a PAIR of 16-token blocks (32 consecutive
 // positions of one sequence).  Outputs per (sequence n, head h):
-//   qh/ql, kh/kl : fp16 rows [Lp = 32*Lb2][16]      (hi and lo planes)
+//   qimg, kimg   : [2*Lb2 blocks of 16 tokens][part 0..3][16 tokens][8 halfs]
+//                  (parts 0,1 = hi of d 0..7 / 8..15, parts 2,3 = lo)
 //   vimg         : [Lb2][hi|lo][64 lanes][8 halfs]   A operand of O^T = V^T P^T:
 //                  lane (d, g) slot e <-> key 32*ip + 16*(e>>2) + 4*g + (e&3)
 // LDS: weight image [12][2] = 48 KB + 1 KB transposition scratch per wave.
 // ---------------------------------------------------------------------------------
 struct QkvOut {
-    _Float16 *qh, *ql, *kh, *kl, *vimg;
+    _Float16 *qimg, *kimg, *vimg;
 };
 
 __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x, TokMap m, int Lb2,
@@ -139,7 +158,9 @@ __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x
     __shared__ __attribute__((aligned(16))) _Float16 wlds[24576 + 4352];   // 48 KB image + 8.5 KB scratch
     _Float16* w = wlds;                                        // 12*2*1024 halfs = 48 KB
     float* scratch = reinterpret_cast<float*>(wlds + 24576);   // 8 waves x 16 x 17 floats
+    __shared__ __attribute__((aligned(16))) float bias_l[192];
     stage_lds16(wi, w, 3072);
+    for (int i = threadIdx.x; i < 192; i += blockDim.x) bias_l[i] = b[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     float* T = scratch + wv * 272;
@@ -159,9 +180,9 @@ __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x
             for (int kb = 0; kb < 4; ++kb) xr[kb] = ldg4(x + row * 64 + 16 * kb + 4 * g);
             ln_split(xr, xbh[tb], xbl[tb]);
         }
-#pragma unroll 1
+#pragma unroll 2
         for (int ob = 0; ob < 12; ++ob) {
-            const f32x4 bias = ldg4(b + 16 * ob + 4 * g);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(&bias_l[16 * ob + 4 * g]);
             f32x4 acc[XNTB];
 #pragma unroll
             for (int tb = 0; tb < XNTB; ++tb) acc[tb] = bias;
@@ -169,15 +190,16 @@ __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x
             const int which = ob >> 2, h = ob & 3;
             const long nh = (long)n * 4 + h;
             if (which < 2) {
-                _Float16* ph = which == 0 ? o.qh : o.kh;
-                _Float16* pl = which == 0 ? o.ql : o.kl;
+                // Q / K image: per 16-token block [part 0..3][token 0..15][8 halfs], parts 0,1 = hi of
+                // d 0..7 / 8..15, parts 2,3 = lo: a 16-token operand is one lane-linear 1 KiB read
+                _Float16* img = which == 0 ? o.qimg : o.kimg;
 #pragma unroll
                 for (int tb = 0; tb < XNTB; ++tb) {
                     f16x4 hi, lo;
                     split4(acc[tb], hi, lo);
-                    const long off = (nh * Lp + ip * 32 + tb * 16 + c) * 16 + 4 * g;
-                    *reinterpret_cast<f16x4*>(ph + off) = hi;
-                    *reinterpret_cast<f16x4*>(pl + off) = lo;
+                    _Float16* blk = img + ((nh * 2 * Lb2) + 2 * ip + tb) * 512 + 4 * (g & 1);
+                    *reinterpret_cast<f16x4*>(blk + (((g >> 1)) * 16 + c) * 8) = hi;
+                    *reinterpret_cast<f16x4*>(blk + (((g >> 1) + 2) * 16 + c) * 8) = lo;
                 }
             } else {
                 f32x4 vt[XNTB];
@@ -201,109 +223,190 @@ __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------
-// Attention core, one (sequence, head, 16-query block) per wave - see attn_kernel for the
-// algorithm.  Contraction slots of the 32-wide MFMA: lane groups g = 0,1 carry the hi half
-// of K (resp. E), g = 2,3 the lo half, both over d = 8*(g&1) + e; B carries Q_hi in both
-// halves (MFMA 1) then Q_lo (MFMA 2): two MFMAs give (K_hi + K_lo) . (Q_hi + Q_lo).
+// Attention core (see attn_kernel in conformer.hip for the algorithm).  Barrier-free:
+// every wave is independent and owns FOUR consecutive 16-query blocks of one (sequence,
+// head), processed as two pairs so that two independent dependency chains (MFMA -> LDS skew
+// -> softmax -> MFMA) are in flight per wave.  K / V / E operand images are read straight
+// from L2 as lane-linear 1 KiB fragments and shared by the four query blocks (operand
+// traffic per query is 1/3 of the one-block-per-wave layout); LDS is only the wave-private
+// Toeplitz skew scratch (2 x 6.4 KB per wave).
+// Contraction slots of the 32-wide MFMA: lane groups g = 0,1 carry the hi half of K (resp. E),
+// g = 2,3 the lo half, both over d = 8*(g&1) + e; B carries Q_hi in both halves (MFMA 1) then
+// Q_lo (MFMA 2): two MFMAs give (K_hi + K_lo) . (Q_hi + Q_lo).
 // ---------------------------------------------------------------------------------
 #define RSTRIDE_X 20
-__global__ __launch_bounds__(256) void attn_x3_kernel(QkvOut io, const _Float16* __restrict__ eh,
-                                                      const _Float16* __restrict__ el, int max_pos,
-                                                      float* __restrict__ o, int L, int Lb, int Lb2, long total) {
-    __shared__ float rbuf[4][80 * RSTRIDE_X];
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-    const long item = (long)blockIdx.x * 4 + wv;          // ((n*4 + h) * Lb + ib)
-    if (item >= total) return;
-    const int ib = (int)(item % Lb);
-    const long nh = item / Lb;
-    float* R = rbuf[wv];
-    const int Lp = Lb2 * 32;
-    const int dsel = 8 * (g & 1);
-    const bool lo_half = g >= 2;
+#define ATT_NQ 4
 
-    const long qoff = (nh * Lp + ib * 16 + c) * 16 + dsel;
-    const f16x8 q1 = *reinterpret_cast<const f16x8*>(io.qh + qoff);
-    const f16x8 q2 = *reinterpret_cast<const f16x8*>(io.ql + qoff);
-    const _Float16* kp = (lo_half ? io.kl : io.kh) + (nh * Lp + c) * 16 + dsel;
-    const _Float16* ep = (lo_half ? el : eh) + dsel;
-    const _Float16* vp = io.vimg + nh * Lb2 * 1024 + lane * 8;
-    const int i0 = ib * 16;
+struct AttState {
+    float m, l;
+    f32x4 o;
+};
 
-    float mrun = -INFINITY, lrun = 0.f;
-    f32x4 oacc = splat4(0.f);
-
-#pragma unroll 1
-    for (int j0 = 0; j0 < L; j0 += 64) {
-        const int rem = (L - j0 + 15) >> 4;
-        const int nb = rem < 4 ? rem : 4;
-        f32x4 s[4];
+// scores + rel-pos bias -> probabilities (in place), running max / sum / output rescale.
+// Scores arrive in log2 units (log2(e) is folded into the q projection by the packer), so the
+// exponential is a bare v_exp_f32.  FULL chunks (all 64 keys valid) need no masking; the skew
+// scratch is always read unconditionally (every index is in range) and masked by a select -
+// a per-lane branch here costs an exec-mask round trip per score.
+template <bool FULL>
+__device__ __forceinline__ void att_softmax(f32x4 (&s)[4], const float* R, int c, int g, int j0, int nb, int L,
+                                            AttState& st) {
+    float mx = -INFINITY;
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-            s[jb] = splat4(0.f);
-            if (jb < nb) {
-                const f16x8 kf = *reinterpret_cast<const f16x8*>(kp + (long)(j0 + 16 * jb) * 16);
-                s[jb] = mfma32h(kf, q1, s[jb]);
-                s[jb] = mfma32h(kf, q2, s[jb]);
-            }
-        }
-        const int rmin = i0 - j0 - 63;
-#pragma unroll 1
-        for (int cb = 4 - nb; cb < 5; ++cb) {
-            int rl = rmin + 16 * cb + c;
-            rl = rl < -max_pos ? -max_pos : (rl > max_pos ? max_pos : rl);
-            const f16x8 ef = *reinterpret_cast<const f16x8*>(ep + (long)(rl + max_pos) * 16);
-            f32x4 rt = splat4(0.f);
-            rt = mfma32h(ef, q1, rt);
-            rt = mfma32h(ef, q2, rt);
+    for (int jb = 0; jb < 4; ++jb) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) R[(16 * cb + 4 * g + r) * RSTRIDE_X + c] = rt[r];
-        }
-        wave_lds_fence();
-        float mx = -INFINITY;
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r) {
+            float sv = s[jb][r] + R[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE_X + c];
+            if (!FULL) {
                 const int key = j0 + 16 * jb + 4 * g + r;
-                float sv = -INFINITY;
-                if (jb < nb && key < L) sv = s[jb][r] + R[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE_X + c];
-                s[jb][r] = sv;
-                mx = fmaxf(mx, sv);
+                sv = (jb < nb && key < L) ? sv : -INFINITY;
             }
+            s[jb][r] = sv;
+            mx = fmaxf(mx, sv);
         }
-        wave_lds_fence();
-        mx = red_g_max(mx);
-        const float mnew = fmaxf(mrun, mx);
-        const float alpha = __expf(mrun - mnew);
-        float psum = 0.f;
+    }
+    mx = red_g_max(mx);
+    const float mnew = fmaxf(st.m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(st.m - mnew);
+    float psum = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(s[jb][r] - mnew);
+            s[jb][r] = p;
+            psum += p;
+        }
+    psum = red_g_sum(psum);
+    st.l = st.l * alpha + psum;
+    st.o = st.o * splat4(alpha);
+    st.m = mnew;
+}
+
+struct AttCtx {
+    const _Float16 *qbase, *kbase, *vbase, *ebase;
+    float *RA, *RB;
+    int qoff1, qoff2, nblk16, Lb, Lb2, L, max_pos, c, g;
+};
+
+// one 64-key chunk for the wave's (up to) four query blocks; FULL = all 64 keys exist
+template <bool FULL>
+__device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttState (&st)[ATT_NQ]) {
+    const int nb = FULL ? 4 : ((a.L - j0 + 15) >> 4);     // live 16-key blocks (tail chunk: 1..4)
+    const int c = a.c, g = a.g;
+    f16x8 kf[4], vh[2], vl[2];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        int kb = (j0 >> 4) + jb;
+        if (!FULL) kb = kb < a.nblk16 ? kb : a.nblk16 - 1;
+        kf[jb] = *reinterpret_cast<const f16x8*>(a.kbase + (long)kb * 512);
+    }
+#pragma unroll
+    for (int mp = 0; mp < 2; ++mp) {
+        int pr = (j0 >> 5) + mp;
+        if (!FULL) pr = pr < a.Lb2 ? pr : a.Lb2 - 1;
+        vh[mp] = *reinterpret_cast<const f16x8*>(a.vbase + (long)pr * 1024);
+        vl[mp] = *reinterpret_cast<const f16x8*>(a.vbase + (long)pr * 1024 + 512);
+    }
+#pragma unroll
+    for (int pair = 0; pair < 2; ++pair) {
+        const int ibA = ibb + 2 * pair;
+        if (ibA >= a.Lb) break;
+        const int qB = ibA + 1 < a.Lb ? ibA + 1 : a.Lb - 1;
+        const f16x8 qA1 = *reinterpret_cast<const f16x8*>(a.qbase + ibA * 512 + a.qoff1);
+        const f16x8 qA2 = *reinterpret_cast<const f16x8*>(a.qbase + ibA * 512 + a.qoff2);
+        const f16x8 qB1 = *reinterpret_cast<const f16x8*>(a.qbase + qB * 512 + a.qoff1);
+        const f16x8 qB2 = *reinterpret_cast<const f16x8*>(a.qbase + qB * 512 + a.qoff2);
+        // relative-position window of the pair: 6 row blocks starting at rminA = 16 ibA - j0 - 63;
+        // block A uses window blocks 0..4 as its cb 0..4, block B (16 queries later) blocks 1..5
+        f16x8 ef[6];
+        const int rminA = ibA * 16 - j0 - 63;
+#pragma unroll
+        for (int we = 0; we < 6; ++we) {
+            int rl = rminA + 16 * we + c;
+            rl = rl < -a.max_pos ? -a.max_pos : (rl > a.max_pos ? a.max_pos : rl);
+            ef[we] = *reinterpret_cast<const f16x8*>(a.ebase + (long)(rl + a.max_pos) * 32);
+        }
+        f32x4 sA[4], sB[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) { sA[jb] = splat4(0.f); sB[jb] = splat4(0.f); }
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
+            if (FULL || jb < nb) { sA[jb] = mfma32h(kf[jb], qA1, sA[jb]); sB[jb] = mfma32h(kf[jb], qB1, sB[jb]); }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __expf(s[jb][r] - mnew);
-                s[jb][r] = p;
-                psum += p;
+        for (int jb = 0; jb < 4; ++jb)
+            if (FULL || jb < nb) { sA[jb] = mfma32h(kf[jb], qA2, sA[jb]); sB[jb] = mfma32h(kf[jb], qB2, sB[jb]); }
+        wave_lds_fence();                                 // previous pair's skew reads are done
+#pragma unroll
+        for (int we = 0; we < 6; ++we) {
+            if (we < 5 && (FULL || we >= 4 - nb)) {       // cb = we for block A
+                f32x4 rt = splat4(0.f);
+                rt = mfma32h(ef[we], qA1, rt);
+                rt = mfma32h(ef[we], qA2, rt);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a.RA[(16 * we + 4 * g + r) * RSTRIDE_X + c] = rt[r];
             }
-        psum = red_g_sum(psum);
-        lrun = lrun * alpha + psum;
-        oacc = oacc * splat4(alpha);
-        mrun = mnew;
+            if (we >= 1 && (FULL || we - 1 >= 4 - nb)) {  // cb = we - 1 for block B
+                f32x4 rt = splat4(0.f);
+                rt = mfma32h(ef[we], qB1, rt);
+                rt = mfma32h(ef[we], qB2, rt);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a.RB[(16 * (we - 1) + 4 * g + r) * RSTRIDE_X + c] = rt[r];
+            }
+        }
+        wave_lds_fence();
+        att_softmax<FULL>(sA, a.RA, c, g, j0, nb, a.L, st[2 * pair]);
+        att_softmax<FULL>(sB, a.RB, c, g, j0, nb, a.L, st[2 * pair + 1]);
 #pragma unroll
         for (int mp = 0; mp < 2; ++mp) {
-            if (2 * mp < nb) {
-                f16x8 ph, pl;
-                split8(s[2 * mp], s[2 * mp + 1], ph, pl);
-                const _Float16* vb = vp + (long)((j0 >> 5) + mp) * 1024;
-                const f16x8 vh = *reinterpret_cast<const f16x8*>(vb);
-                const f16x8 vl = *reinterpret_cast<const f16x8*>(vb + 512);
-                oacc = mfma32h(vh, ph, oacc);
-                oacc = mfma32h(vh, pl, oacc);
-                oacc = mfma32h(vl, ph, oacc);
+            if (FULL || 2 * mp < nb) {
+                f16x8 pAh, pAl, pBh, pBl;
+                split8(sA[2 * mp], sA[2 * mp + 1], pAh, pAl);
+                split8(sB[2 * mp], sB[2 * mp + 1], pBh, pBl);
+                st[2 * pair].o = mfma32h(vh[mp], pAh, st[2 * pair].o);
+                st[2 * pair + 1].o = mfma32h(vh[mp], pBh, st[2 * pair + 1].o);
+                st[2 * pair].o = mfma32h(vh[mp], pAl, st[2 * pair].o);
+                st[2 * pair + 1].o = mfma32h(vh[mp], pBl, st[2 * pair + 1].o);
+                st[2 * pair].o = mfma32h(vl[mp], pAh, st[2 * pair].o);
+                st[2 * pair + 1].o = mfma32h(vl[mp], pBh, st[2 * pair + 1].o);
             }
         }
     }
-    const float inv = 1.0f / lrun;
-    stg4(o + item * 256 + lane * 4, oacc * splat4(inv));
+}
+
+template <int OCC>    // waves per SIMD the register allocator is asked to fit
+__global__ __launch_bounds__(256, OCC) void attn_x3_kernel(QkvOut io, const _Float16* __restrict__ eimg, int max_pos,
+                                                         float* __restrict__ o, int L, int Lb, int Lb2, int nqg,
+                                                         long total) {
+    __shared__ float rbuf[4][2][80 * RSTRIDE_X];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long item = (long)blockIdx.x * 4 + wv;
+    if (item >= total) return;                            // no block-level synchronisation below
+    const long nh = item / nqg;
+    const int ibb = (int)(item % nqg) * ATT_NQ;           // first query block of this wave
+    AttCtx a;
+    a.c = lane & 15; a.g = lane >> 4;
+    a.RA = rbuf[wv][0]; a.RB = rbuf[wv][1];
+    a.nblk16 = 2 * Lb2; a.Lb = Lb; a.Lb2 = Lb2; a.L = L; a.max_pos = max_pos;
+    a.qbase = io.qimg + nh * a.nblk16 * 512;
+    a.kbase = io.kimg + nh * a.nblk16 * 512 + lane * 8;
+    a.vbase = io.vimg + nh * Lb2 * 1024 + lane * 8;
+    a.ebase = eimg + a.g * 8;
+    a.qoff1 = ((a.g & 1) * 16 + a.c) * 8; a.qoff2 = ((2 + (a.g & 1)) * 16 + a.c) * 8;
+
+    AttState st[ATT_NQ];
+#pragma unroll
+    for (int i = 0; i < ATT_NQ; ++i) { st[i].m = -INFINITY; st[i].l = 0.f; st[i].o = splat4(0.f); }
+
+    const int nfull = L >> 6;
+#pragma unroll 1
+    for (int ch = 0; ch < nfull; ++ch) att_chunk<true>(a, ibb, ch * 64, st);
+    if (L & 63) att_chunk<false>(a, ibb, nfull * 64, st);
+
+#pragma unroll
+    for (int i = 0; i < ATT_NQ; ++i) {
+        const int ib = ibb + i;
+        if (ib < Lb) stg4(o + (nh * Lb + ib) * 256 + lane * 4, st[i].o * splat4(1.0f / st[i].l));
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -314,7 +417,9 @@ __global__ __launch_bounds__(512) void outproj_x3_kernel(float* __restrict__ x, 
                                                          const _Float16* __restrict__ wi,
                                                          const float* __restrict__ bo, int ntiles) {
     __shared__ __attribute__((aligned(16))) _Float16 wlds[8192];
+    __shared__ __attribute__((aligned(16))) float bias_l[64];
     stage_lds16(wi, wlds, 1024);                             // [4][2] image = 16 KB
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) bias_l[i] = bo[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     const long hstride = (long)m.Lb * 256;
@@ -336,7 +441,7 @@ __global__ __launch_bounds__(512) void outproj_x3_kernel(float* __restrict__ x, 
         }
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {
-            const f32x4 bias = ldg4(bo + 16 * ob + 4 * g);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(&bias_l[16 * ob + 4 * g]);
             f32x4 acc[XNTB];
 #pragma unroll
             for (int tb = 0; tb < XNTB; ++tb) acc[tb] = bias;
@@ -359,7 +464,9 @@ __global__ __launch_bounds__(512) void pw1glu_x3_kernel(const float* __restrict_
                                                         const _Float16* __restrict__ wi,
                                                         const float* __restrict__ b, long M, int ntiles) {
     __shared__ __attribute__((aligned(16))) _Float16 wlds[32768];          // 64 KB
+    __shared__ __attribute__((aligned(16))) float bias_l[256];
     stage_lds16(wi, wlds, 4096);
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) bias_l[i] = b[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
 #pragma unroll 1
@@ -377,10 +484,11 @@ __global__ __launch_bounds__(512) void pw1glu_x3_kernel(const float* __restrict_
             for (int kb = 0; kb < 4; ++kb) xr[kb] = ldg4(x + row[tb] * 64 + 16 * kb + 4 * g);
             ln_split(xr, bh[tb], bl[tb]);
         }
-#pragma unroll 1
+#pragma unroll 2
         for (int ob = 0; ob < 8; ++ob) {
             f32x4 aa[XNTB], ag[XNTB];
-            const f32x4 ba = ldg4(b + 16 * ob + 4 * g), bg = ldg4(b + 128 + 16 * ob + 4 * g);
+            const f32x4 ba = *reinterpret_cast<const f32x4*>(&bias_l[16 * ob + 4 * g]);
+            const f32x4 bg = *reinterpret_cast<const f32x4*>(&bias_l[128 + 16 * ob + 4 * g]);
 #pragma unroll
             for (int tb = 0; tb < XNTB; ++tb) { aa[tb] = ba; ag[tb] = bg; }
             lin_acc_x3<2, XNTB>(wlds + ob * 2048 + lane * 8, bh, bl, aa);
@@ -405,7 +513,9 @@ __global__ __launch_bounds__(512) void pw2_x3_kernel(float* __restrict__ x, cons
                                                      const _Float16* __restrict__ wi, const float* __restrict__ b,
                                                      long M, int ntiles) {
     __shared__ __attribute__((aligned(16))) _Float16 wlds[16384];          // 32 KB
+    __shared__ __attribute__((aligned(16))) float bias_l[64];
     stage_lds16(wi, wlds, 2048);
+    for (int i = threadIdx.x; i < 64; i += blockDim.x) bias_l[i] = b[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
 #pragma unroll 1
@@ -425,7 +535,7 @@ __global__ __launch_bounds__(512) void pw2_x3_kernel(float* __restrict__ x, cons
         }
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {
-            const f32x4 bias = ldg4(b + 16 * ob + 4 * g);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(&bias_l[16 * ob + 4 * g]);
             f32x4 acc[XNTB];
 #pragma unroll
             for (int tb = 0; tb < XNTB; ++tb) acc[tb] = bias;
@@ -458,10 +568,9 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
     const int flat_blocks = (int)((M + 15) / 16);
     const int flat_tiles = (flat_blocks + XNTB - 1) / XNTB;
     const size_t tap_bytes = (size_t)M * 64 * sizeof(float);
-    const size_t plane = (size_t)N * 4 * Lb2 * 32 * 16;          // halfs in one hi (or lo) Q/K plane
     QkvOut io;
-    io.qh = reinterpret_cast<_Float16*>(b.q); io.ql = io.qh + plane;
-    io.kh = reinterpret_cast<_Float16*>(b.k); io.kl = io.kh + plane;
+    io.qimg = reinterpret_cast<_Float16*>(b.q);
+    io.kimg = reinterpret_cast<_Float16*>(b.k);
     io.vimg = reinterpret_cast<_Float16*>(b.v);
 
     LAUNCH(ctx, "ffn", (ffn_x3_kernel<false><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(
@@ -471,9 +580,17 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
     const int qtiles = N * Lb2;
     LAUNCH(ctx, "qkv", (qkv_x3_kernel<<<persistent_grid(qtiles, 2), 512, 0, s>>>(
                            b.xb, seq, Lb2, w16.qkv_w, w.qkv_b, io, qtiles)));
-    const long items = (long)N * 4 * seq.Lb;
-    LAUNCH(ctx, "attn", (attn_x3_kernel<<<(unsigned)((items + 3) / 4), 256, 0, s>>>(
-                            io, w16.rel_h, w16.rel_l, w.max_pos, b.o, seq.L, seq.Lb, Lb2, items)));
+    {
+        const int nqg = (seq.Lb + ATT_NQ - 1) / ATT_NQ;
+        const long waves = (long)N * 4 * nqg;
+        static const int occ = getenv("CMGAN_ATTN_OCC") ? atoi(getenv("CMGAN_ATTN_OCC")) : 2;
+        if (occ == 3)
+            LAUNCH(ctx, "attn", (attn_x3_kernel<3><<<(unsigned)((waves + 3) / 4), 256, 0, s>>>(
+                                    io, w16.rel_img, w.max_pos, b.o, seq.L, seq.Lb, Lb2, nqg, waves)));
+        else
+            LAUNCH(ctx, "attn", (attn_x3_kernel<2><<<(unsigned)((waves + 3) / 4), 256, 0, s>>>(
+                                    io, w16.rel_img, w.max_pos, b.o, seq.L, seq.Lb, Lb2, nqg, waves)));
+    }
     const int otiles = (seq.nblocks + XNTB - 1) / XNTB;
     LAUNCH(ctx, "outproj", (outproj_x3_kernel<<<persistent_grid(otiles, 2), 512, 0, s>>>(b.xb, seq, b.o, w16.wo,
                                                                                            w.bo, otiles)));

@@ -106,7 +106,8 @@ void conformer_forward(LaunchCtx, const ConfWeights&, const ConfBuffers&, const 
 
 // --------------------------- x3 mode (f16 split products) ------------------------
 struct ConfWeightsX3 {
-    const _Float16 *ff1_w1, *ff1_w2, *qkv_w, *wo, *pw1_w, *pw2_w, *ff2_w1, *ff2_w2, *rel_h, *rel_l;
+    const _Float16 *ff1_w1, *ff1_w2, *qkv_w, *wo, *pw1_w, *pw2_w, *ff2_w1, *ff2_w2;
+    const _Float16* rel_img;    // [2*max_pos+1][hi 16 | lo 16] halfs
 };
 void conformer_forward_x3(LaunchCtx, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&, const TokMap& seq,
                           long M, float* taps, bool outer_residual);

@@ -70,7 +70,7 @@ enum {
     CF_FF1_B1 = 1,    // [256]        b1 + W1 @ beta
     CF_FF1_W2 = 2,    // fm [4][16]   0.5 * Linear(256,64)   (Scale(0.5), conformer.py:211)
     CF_FF1_B2 = 3,    // [64]         0.5 * b2
-    CF_QKV_W = 4,     // fm [12][4]   rows 0..63 = 0.25*to_q, 64..191 = to_kv; attn LayerNorm folded
+    CF_QKV_W = 4,     // fm [12][4]   rows 0..63 = 0.25*log2(e)*to_q, 64..191 = to_kv; attn LayerNorm folded
     CF_QKV_B = 5,     // [192]        W @ beta (the reference has no bias; this is the folded LN shift)
     CF_WO = 6,        // fm [4][4]    to_out
     CF_BO = 7,        // [64]

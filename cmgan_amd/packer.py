@@ -9,6 +9,7 @@ in float64, then rounded to fp32:
   (``W' = W diag(gamma)``, ``b' = b + W beta``)           conformer.py:54-72,161-163
 * ``Scale(0.5)`` folded into the second FeedForward Linear   conformer.py:211-212
 * attention ``scale = dim_head**-0.5`` folded into ``to_q``  conformer.py:80,103,110
+  together with log2(e), so the kernels' softmax is a bare exp2
 * eval-mode ``BatchNorm1d`` folded into the depthwise conv    conformer.py:165-168
 * dense-block input channels reordered from the reference's newest-first concat
   (generator.py:46) to slot order (block input first)
@@ -101,7 +102,7 @@ def _conformer(sd, p, group, out, heads=4, dim_head=16):
         out[wid(group, ib1)] = b1
         out[wid(group, iw2)] = fm(0.5 * _np(sd[f"{pre}{ff}.fn.fn.net.3.weight"]))
         out[wid(group, ib2)] = 0.5 * _np(sd[f"{pre}{ff}.fn.fn.net.3.bias"])
-    scale = dim_head ** -0.5
+    scale = dim_head ** -0.5 * np.log2(np.e)      # attention scale, and scores in log2 units (kernels use exp2)
     wq = scale * _np(sd[f"{pre}attn.fn.to_q.weight"])
     wkv = _np(sd[f"{pre}attn.fn.to_kv.weight"])
     g, bt = _np(sd[f"{pre}attn.norm.weight"]), _np(sd[f"{pre}attn.norm.bias"])

@@ -83,7 +83,8 @@ class BlobModel:
         idx = torch.arange(n)
         rel = (idx[:, None] - idx[None, :]).clamp(-self.max_pos, self.max_pos) + self.max_pos
         s = q @ k.transpose(-1, -2) + torch.gather(q @ emb.t(), -1, rel.expand(x.shape[0], 4, n, n))
-        o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(x.shape[0], n, 64)
+        # scores are in log2 units (log2(e) folded into the q projection)
+        o = (torch.softmax(s * float(np.log(2.0)), -1) @ v).transpose(1, 2).reshape(x.shape[0], n, 64)
         return x + o @ unfm(self.g(grp, P.CF_WO), 64, 64).t() + self.g(grp, P.CF_BO)
 
     def convmod(self, grp, x):
