@@ -65,7 +65,12 @@ __device__ __forceinline__ float red_c_sum(float v) {
 }
 __device__ __forceinline__ float wave_sum(float v) { return red_g_sum(red_c_sum(v)); }
 
-__device__ __forceinline__ float sigmoidf_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// sigmoid / Swish on the hardware transcendentals (v_exp_f32, v_rcp_f32: 1 ulp each).  NOT
+// __frcp_rn / 1.0f/x: those expand to the ~12-instruction correctly-rounded division sequence
+// and made the FFN VALU-bound.
+__device__ __forceinline__ float sigmoidf_fast(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 __device__ __forceinline__ float swishf(float x) { return x * sigmoidf_fast(x); }
 
 // orders a wave's LDS writes before its later LDS reads (cross-lane, same wave)

@@ -14,7 +14,7 @@
 #define XNTB 2
 #define XWAVES 8
 
-__device__ __forceinline__ float swish_x(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float swish_x(float x) { return swishf(x); }
 
 // LN'd input rows -> B operands (hi/lo) for K = 64 (two k32 blocks)
 __device__ __forceinline__ void ln_split(const f32x4 (&x)[4], f16x8 (&bh)[2], f16x8 (&bl)[2]) {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, OCC) void attn_x3_kernel(QkvOut io, const _Flo
 #pragma unroll
     for (int i = 0; i < ATT_NQ; ++i) {
         const int ib = ibb + i;
-        if (ib < Lb) stg4(o + (nh * Lb + ib) * 256 + lane * 4, st[i].o * splat4(1.0f / st[i].l));
+        if (ib < Lb) stg4(o + (nh * Lb + ib) * 256 + lane * 4, st[i].o * splat4(__builtin_amdgcn_rcpf(st[i].l)));
     }
 }
 
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(512) void pw1glu_x3_kernel(const float* __restrict_
                 if (ok[tb]) {
                     f32x4 r;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) r[e] = aa[tb][e] * __frcp_rn(1.0f + __expf(-ag[tb][e]));
+                    for (int e = 0; e < 4; ++e) r[e] = aa[tb][e] * sigmoidf_fast(ag[tb][e]);
                     stg4(u + row[tb] * 128 + 16 * ob + 4 * g, r);
                 }
             }

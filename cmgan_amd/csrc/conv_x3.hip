@@ -42,9 +42,16 @@ __global__ __launch_bounds__(256) void conv3x_kernel(ConvArgs a, const _Float16*
     __shared__ float red[4][COUT][2];
 
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4, wv = tid >> 6;
-    const int b = blockIdx.y;
+    // XCD-aware block order: the dispatcher deals consecutive workgroups round-robin to the 8
+    // XCDs (private L2 each).  Re-map so XCD x walks a CONTIGUOUS range of (clip, tile): the
+    // rows a tile reads as its t-dil plane were read moments earlier as the t plane of a
+    // neighbouring tile on the SAME XCD -> second read is an L2 hit, not a second HBM fetch.
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int qn = nwg >> 3, rn = nwg & 7;
+    const int logical = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+    const int b = logical / a.ntiles, tile = logical - b * a.ntiles;
     const int Fp = a.F + 1;
-    const int q0 = blockIdx.x * CX_TILE;
+    const int q0 = tile * CX_TILE;
 
     // per-thread staging map: row p = (tid >> 3) + 32 e, channel quad qd = tid & 7 of the 32-chunk
     const int qd = tid & 7;
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256) void conv3x_kernel(ConvArgs a, const _Float16*
         const float* src_ = sel4(a.in, slot_) + half_ * 32 + qd * 4;                                                 \
         _Pragma("unroll") for (int e = 0; e < NACT; ++e) {                                               \
             const int ap_ = (NT == 2 && kt_ == 0) ? apos0[e] : apos1[e];                                 \
-            pre[e] = ap_ >= 0 ? ldg4(src_ + (long)ap_ * 64) : splat4(0.f);                               \
+            pre[e] = ldg4(src_ + (long)(ap_ >= 0 ? ap_ : 0) * 64);   /* unconditional; masked at write */ \
         }                                                                                                \
         const float* nsc_ = sel4(a.nscale, slot_);                                                       \
         tr = nsc_ != nullptr;                                                                            \
@@ -109,7 +116,8 @@ __global__ __launch_bounds__(256) void conv3x_kernel(ConvArgs a, const _Float16*
             if (p < CX_ROWS) {
                 const int ap = (NT == 2 && kt == 0) ? apos0[e] : apos1[e];
                 f32x4 v = pre[e];
-                if (tr && ap >= 0) v = norm_prelu4x(v, sc, sh, al);
+                if (tr) v = norm_prelu4x(v, sc, sh, al);
+                if (ap < 0) v = splat4(0.f);              // zero padding (select, no branch)
                 f16x4 hi, lo;
                 split4(v, hi, lo);
                 *reinterpret_cast<f16x4*>(&act_h[p * CX_STRIDE + lds_col]) = hi;
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(256) void conv3x_kernel(ConvArgs a, const _Float16*
         for (int i = tid; i < COUT * 2; i += 256) {
             const int co = i >> 1, wh = i & 1;
             const float t = (red[0][co][wh] + red[1][co][wh]) + (red[2][co][wh] + red[3][co][wh]);
-            a.partials[(((long)b * a.ntiles + blockIdx.x) * COUT + co) * 2 + wh] = t;
+            a.partials[(((long)b * a.ntiles + tile) * COUT + co) * 2 + wh] = t;
         }
     }
 }
@@ -205,7 +213,7 @@ int conv3x_ntiles(int T, int F, int cout) {
 }
 
 void launch_conv3_x3(LaunchCtx ctx, const ConvArgs& a, const void* w16, int B, int time_taps, int cout) {
-    dim3 grid(a.ntiles, B);
+    dim3 grid(a.ntiles * B);                              // 1-D: see the XCD re-map in the kernel
     const _Float16* w = reinterpret_cast<const _Float16*>(w16);
     if (time_taps == 2 && cout == 64)
         LAUNCH(ctx, "conv_dense", (conv3x_kernel<2, 64, 4><<<grid, 256, 0, ctx.stream>>>(a, w)));
