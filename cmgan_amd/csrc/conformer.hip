@@ -175,105 +175,159 @@ __global__ __launch_bounds__(256) void qkv_kernel(const float* __restrict__ x, T
 }
 
 // ---------------------------------------------------------------------------------
-// Attention core for one (sequence, head, 16-query block) per wave.
+// Attention core (fp32 MFMA).  Every wave is independent (no block barriers) and owns a
+// PAIR of consecutive 16-query blocks of one (sequence, head), so two independent
+// MFMA -> LDS skew -> softmax -> MFMA chains are in flight and K / V / E operand fragments
+// are shared by both.
 //   dots = (q k^T + q E[clamp(i-j)]^T) * scale ; softmax_j ; out = attn v
 //                                                          conformer.py:103-130
 // Transposed: S^T[key][query] so a lane owns one query column -> softmax reductions
-// are in-lane + two shuffles, and P^T is already the B fragment of O^T = V^T P^T.
+// are in-lane + two permlane swaps, and P^T is already the B fragment of O^T = V^T P^T.
 // Relative positions: R^T[rel][query] = E_window q^T is a second MFMA product over the
 // 79 relative offsets a (16 query x 64 key) tile can see; bias[key][query] =
-// R^T[query - key - rmin][query] is a Toeplitz read-back through 6.4 KB of
-// wave-private LDS (row stride 20 floats: conflict-free for both the write and the read).
+// R^T[query - key - rmin][query] is a Toeplitz read-back through 6.4 KB of wave-private
+// LDS per query block (row stride 20 floats: conflict-free for both the write and the read).
+// Scores are in log2 units (log2(e) folded into the q projection): softmax is a bare v_exp_f32.
 // ---------------------------------------------------------------------------------
 #define RSTRIDE 20
-__global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
-                                                   const float* __restrict__ v, const float* __restrict__ rel,
-                                                   int max_pos, float* __restrict__ o, int L, int Lb,
-                                                   long total) {
-    __shared__ float rbuf[4][80 * RSTRIDE];
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const int wv = threadIdx.x >> 6;
-    const long item = (long)blockIdx.x * 4 + wv;          // ((n*4 + h) * Lb + ib)
-    if (item >= total) return;
-    const int ib = (int)(item % Lb);
-    const long nh = item / Lb;
-    float* R = rbuf[wv];
 
-    const f32x4 qf = ldg4(q + item * 256 + lane * 4);
-    const float* kp = k + nh * Lb * 256 + lane * 4;
-    const float* vp = v + nh * Lb * 256 + lane * 4;
-    const int i0 = ib * 16;
+struct AttnState {
+    float m, l;
+    f32x4 o;
+};
 
-    float mrun = -INFINITY, lrun = 0.f;
-    f32x4 oacc = splat4(0.f);
-
-#pragma unroll 1
-    for (int j0 = 0; j0 < L; j0 += 64) {
-        const int rem = (L - j0 + 15) >> 4;
-        const int nb = rem < 4 ? rem : 4;                  // live 16-key blocks in this chunk
-        f32x4 s[4];
+template <bool FULL>
+__device__ __forceinline__ void attn_softmax(f32x4 (&s)[4], const float* R, int c, int g, int j0, int nb, int L,
+                                             AttnState& st) {
+    float mx = -INFINITY;
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-            s[jb] = splat4(0.f);
-            if (jb < nb) {
-                const f32x4 kf = ldg4(kp + (long)((j0 >> 4) + jb) * 256);
+    for (int jb = 0; jb < 4; ++jb) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[jb] = mfma16(kf[r], qf[r], s[jb]);
-            }
-        }
-        const int rmin = i0 - j0 - 63;
-#pragma unroll 1
-        for (int cb = 4 - nb; cb < 5; ++cb) {
-            int rl = rmin + 16 * cb + c;
-            rl = rl < -max_pos ? -max_pos : (rl > max_pos ? max_pos : rl);
-            const f32x4 ef = ldg4(rel + (long)(rl + max_pos) * 16 + 4 * g);
-            f32x4 rt = splat4(0.f);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rt = mfma16(ef[r], qf[r], rt);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) R[(16 * cb + 4 * g + r) * RSTRIDE + c] = rt[r];
-        }
-        wave_lds_fence();
-        float mx = -INFINITY;
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r) {
+            float sv = s[jb][r] + R[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE + c];     // always in range
+            if (!FULL) {
                 const int key = j0 + 16 * jb + 4 * g + r;
-                float sv = s[jb][r] + R[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE + c];   // always in range
-                sv = (jb < nb && key < L) ? sv : -INFINITY;       // select, not a per-lane branch
-                s[jb][r] = sv;
-                mx = fmaxf(mx, sv);
+                sv = (jb < nb && key < L) ? sv : -INFINITY;                            // select, no branch
             }
+            s[jb][r] = sv;
+            mx = fmaxf(mx, sv);
         }
-        wave_lds_fence();
-        mx = red_g_max(mx);
-        const float mnew = fmaxf(mrun, mx);
-        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);   // scores are in log2 units (packer)
-        float psum = 0.f;
+    }
+    mx = red_g_max(mx);
+    const float mnew = fmaxf(st.m, mx);
+    const float alpha = __builtin_amdgcn_exp2f(st.m - mnew);
+    float psum = 0.f;
 #pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(s[jb][r] - mnew);
+            s[jb][r] = p;
+            psum += p;
+        }
+    psum = red_g_sum(psum);
+    st.l = st.l * alpha + psum;
+    st.o = st.o * splat4(alpha);
+    st.m = mnew;
+}
+
+struct AttnCtx {
+    const float *qp, *kp, *vp, *rel;
+    float *RA, *RB;
+    int Lb, L, max_pos, c, g, lane;
+};
+
+template <bool FULL>
+__device__ __forceinline__ void attn_chunk(const AttnCtx& a, int ibA, int j0, const f32x4& qA, const f32x4& qB,
+                                           AttnState& sa, AttnState& sb) {
+    const int nb = FULL ? 4 : ((a.L - j0 + 15) >> 4);
+    const int c = a.c, g = a.g;
+    f32x4 sA[4], sB[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        sA[jb] = splat4(0.f);
+        sB[jb] = splat4(0.f);
+        if (FULL || jb < nb) {
+            const f32x4 kf = ldg4(a.kp + (long)((j0 >> 4) + jb) * 256);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[jb][r] - mnew);
-                s[jb][r] = p;
-                psum += p;
-            }
-        psum = red_g_sum(psum);
-        lrun = lrun * alpha + psum;
-        oacc = oacc * splat4(alpha);
-        mrun = mnew;
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) {
-            if (jb < nb) {
-                const f32x4 vf = ldg4(vp + (long)((j0 >> 4) + jb) * 256);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) oacc = mfma16(vf[r], s[jb][r], oacc);
+                sA[jb] = mfma16(kf[r], qA[r], sA[jb]);
+                sB[jb] = mfma16(kf[r], qB[r], sB[jb]);
             }
         }
     }
-    const float inv = 1.0f / lrun;
-    stg4(o + item * 256 + lane * 4, oacc * splat4(inv));
+    // window of the pair: 6 row blocks from rminA = 16 ibA - j0 - 63; A uses blocks 0..4, B blocks 1..5
+    const int rminA = ibA * 16 - j0 - 63;
+    wave_lds_fence();                                     // previous chunk's skew reads are done
+#pragma unroll
+    for (int we = 0; we < 6; ++we) {
+        const bool useA = we < 5 && (FULL || we >= 4 - nb);
+        const bool useB = we >= 1 && (FULL || we - 1 >= 4 - nb);
+        if (useA || useB) {
+            int rl = rminA + 16 * we + c;
+            rl = rl < -a.max_pos ? -a.max_pos : (rl > a.max_pos ? a.max_pos : rl);
+            const f32x4 ef = ldg4(a.rel + (long)(rl + a.max_pos) * 16 + 4 * g);
+            if (useA) {
+                f32x4 rt = splat4(0.f);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rt = mfma16(ef[r], qA[r], rt);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a.RA[(16 * we + 4 * g + r) * RSTRIDE + c] = rt[r];
+            }
+            if (useB) {
+                f32x4 rt = splat4(0.f);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rt = mfma16(ef[r], qB[r], rt);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a.RB[(16 * (we - 1) + 4 * g + r) * RSTRIDE + c] = rt[r];
+            }
+        }
+    }
+    wave_lds_fence();
+    attn_softmax<FULL>(sA, a.RA, c, g, j0, nb, a.L, sa);
+    attn_softmax<FULL>(sB, a.RB, c, g, j0, nb, a.L, sb);
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        if (FULL || jb < nb) {
+            const f32x4 vf = ldg4(a.vp + (long)((j0 >> 4) + jb) * 256);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sa.o = mfma16(vf[r], sA[jb][r], sa.o);
+                sb.o = mfma16(vf[r], sB[jb][r], sb.o);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                   const float* __restrict__ v, const float* __restrict__ rel,
+                                                   int max_pos, float* __restrict__ o, int L, int Lb, int npairs,
+                                                   long total) {
+    __shared__ float rbuf[4][2][80 * RSTRIDE];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long item = (long)blockIdx.x * 4 + wv;          // (n*4 + h) * npairs + pair
+    if (item >= total) return;                            // waves are independent: no barriers below
+    const long nh = item / npairs;
+    const int ibA = (int)(item % npairs) * 2;
+    const int ibB = ibA + 1 < Lb ? ibA + 1 : Lb - 1;      // odd Lb: the last wave's B is a clamped duplicate
+    AttnCtx a;
+    a.lane = lane; a.c = lane & 15; a.g = lane >> 4;
+    a.RA = rbuf[wv][0]; a.RB = rbuf[wv][1];
+    a.Lb = Lb; a.L = L; a.max_pos = max_pos; a.rel = rel;
+    a.qp = q + nh * Lb * 256 + lane * 4;
+    a.kp = k + nh * Lb * 256 + lane * 4;
+    a.vp = v + nh * Lb * 256 + lane * 4;
+    const f32x4 qA = ldg4(a.qp + (long)ibA * 256), qB = ldg4(a.qp + (long)ibB * 256);
+
+    AttnState sa, sb;
+    sa.m = sb.m = -INFINITY; sa.l = sb.l = 0.f; sa.o = sb.o = splat4(0.f);
+    const int nfull = L >> 6;
+#pragma unroll 1
+    for (int ch = 0; ch < nfull; ++ch) attn_chunk<true>(a, ibA, ch * 64, qA, qB, sa, sb);
+    if (L & 63) attn_chunk<false>(a, ibA, nfull * 64, qA, qB, sa, sb);
+
+    stg4(o + (nh * Lb + ibA) * 256 + lane * 4, sa.o * splat4(__builtin_amdgcn_rcpf(sa.l)));
+    if (ibA + 1 < Lb) stg4(o + (nh * Lb + ibA + 1) * 256 + lane * 4, sb.o * splat4(__builtin_amdgcn_rcpf(sb.l)));
 }
 
 // ---------------------------------------------------------------------------------
@@ -503,9 +557,10 @@ void conformer_forward(LaunchCtx ctx, const ConfWeights& w, const ConfBuffers& b
 
     LAUNCH(ctx, "qkv", (qkv_kernel<<<grid_for_blocks(seq.nblocks), 256, 0, s>>>(b.xb, seq, w.qkv_w, w.qkv_b,
                                                                                   b.q, b.k, b.v)));
-    const long items = (long)N * 4 * seq.Lb;
+    const int npairs = (seq.Lb + 1) / 2;
+    const long items = (long)N * 4 * npairs;
     LAUNCH(ctx, "attn", (attn_kernel<<<(unsigned)((items + 3) / 4), 256, 0, s>>>(b.q, b.k, b.v, w.rel, w.max_pos,
-                                                                                  b.o, seq.L, seq.Lb, items)));
+                                                                                  b.o, seq.L, seq.Lb, npairs, items)));
     LAUNCH(ctx, "outproj",
            (outproj_kernel<<<grid_for_blocks(seq.nblocks), 256, 0, s>>>(b.xb, seq, b.o, w.wo, w.bo)));
     if (taps) hipMemcpyAsync(taps + (size_t)M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
