@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--mfma-mode", choices=["f16x3", "f32"], default="f16x3",
                     help="f16x3: fp32-accurate 3-term split products on the f16 matrix pipe (default); "
                          "f32: bit-exact fp32 MFMA")
@@ -133,8 +134,10 @@ def main():
     wav = synthetic_clips(BATCH_PER_GPU, CLIP_LEN, seed=rank).to(dev)    # resident in HBM before timing
     scal = torch.zeros(2, device=dev)
 
+    run = eng.enhance if args.no_graph else eng.enhance_graphed
+
     def step():
-        out = eng.enhance(wav)
+        out = run(wav)
         # two per-step "loss" scalars (time-domain L1 / L2 against the input) and their single all-reduce
         d = out - wav
         scal[0] = d.abs().mean()
@@ -215,7 +218,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: batch=32 x 2 s synthetic 16 kHz noisy clips per GPU, n_fft=400 "
                                    "hop=100, TSCNet(64,201) random-init, full pipeline wav->wav",
-                       "mfma_mode": args.mfma_mode,
+                       "mfma_mode": args.mfma_mode, "launch": "eager" if args.no_graph else "hipGraph replay",
                        "batch_per_gpu": BATCH_PER_GPU, "global_batch": world * BATCH_PER_GPU,
                        "frames_per_clip": T_FRAMES, "parallelism": f"dp{world}"},
             "path_tflops": round(total_flop / (ms_per_step * 1e-3) / 1e12, 2),

@@ -18,6 +18,7 @@
 
 #define CONV_TILE 128
 #define CONV_ROWS (CONV_TILE + 2)
+#define CONV_RS 24            // floats per LDS activation row (16 used): 96 B pitch = conflict-free ds_read_b128
 
 __device__ __forceinline__ f32x4 norm_prelu4(f32x4 v, f32x4 sc, f32x4 sh, f32x4 al) {
     f32x4 y = v * sc + sh;
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(ConvArgs a) {
     constexpr int TAPS = NT * 3;
     constexpr int NSTAGE = (NT * CONV_ROWS * 4 + 255) / 256;   // float4 per thread per chunk
     constexpr int WF4 = TAPS * CB * 64;                         // float4 of weights per chunk
-    __shared__ __attribute__((aligned(16))) float act[NT * CONV_ROWS * 16];
+    __shared__ __attribute__((aligned(16))) float act[NT * CONV_ROWS * CONV_RS];
     __shared__ __attribute__((aligned(16))) float wl[TAPS * CB * 256];
     __shared__ float red[4][COUT][2];
 
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(ConvArgs a) {
                     val = ldg4(src + (long)apos[e] * 64 + cc * 16 + qd * 4);
                     if (tr) val = norm_prelu4(val, sc, sh, al);
                 }
-                *reinterpret_cast<f32x4*>(&act[idx * 4]) = val;
+                *reinterpret_cast<f32x4*>(&act[(idx >> 2) * CONV_RS + (idx & 3) * 4]) = val;
             }
         }
         const float* wsrc = a.w + (long)chunk * WF4 * 4;
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(ConvArgs a) {
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb)
                 bf[tb] = *reinterpret_cast<const f32x4*>(
-                    &act[((kt * CONV_ROWS) + 32 * wv + 16 * tb + c + kf) * 16 + 4 * g]);
+                    &act[((kt * CONV_ROWS) + 32 * wv + 16 * tb + c + kf) * CONV_RS + 4 * g]);
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
                 const f32x4 af = *reinterpret_cast<const f32x4*>(&wl[(tap * CB + cb) * 256 + lane * 4]);

@@ -12,7 +12,9 @@
 #include "kernels.h"
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#define CX_STRIDE 40          // halfs per LDS activation row (32 used): 80 B, keeps 16 B alignment
+#define CX_STRIDE 48          // halfs per LDS activation row (32 used): 96 B = 6 x 16 B slots, the row pitch at which
+                              // the B-operand ds_read_b128 (16 consecutive rows x 4 lane groups) is bank-conflict free
+                              // for every base row (80 B was 2-way; brute-forced over the b128 lane-group map)
 
 __device__ __forceinline__ f32x4 norm_prelu4x(f32x4 v, f32x4 sc, f32x4 sh, f32x4 al) {
     f32x4 y = v * sc + sh;

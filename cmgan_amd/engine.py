@@ -206,6 +206,45 @@ class Engine:
                                               ws.numel(), _stream()))
         return out
 
+    # ---- hipGraph replay of the whole pipeline -------------------------------------------
+    def enhance_graphed(self, wav: torch.Tensor) -> torch.Tensor:
+        """Same result as enhance(), but the ~250 kernel launches of cmgan_enhance are captured once
+        per input shape into a hipGraph (torch.cuda.CUDAGraph on the capture stream) and replayed:
+        the C ABI never allocates or synchronises, so it is capturable as is.  The returned tensor is
+        a static buffer that the next call with the same shape overwrites."""
+        self._need_weights()
+        wav = _f32c(wav, "wav")
+        key = tuple(wav.shape)
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        ent = self._graphs.get(key)
+        if ent is None:
+            B, L = wav.shape
+            ws = self._workspace(B, self.num_frames(L))
+            g_in, g_out = torch.empty_like(wav), torch.empty_like(wav)
+            g_in.copy_(wav)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                       # warm-up outside capture
+                check(self._h, self.lib.cmgan_enhance(self._h, g_in.data_ptr(), B, L, g_out.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), _stream()))
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                check(self._h, self.lib.cmgan_enhance(self._h, g_in.data_ptr(), B, L, g_out.data_ptr(),
+                                                      ws.data_ptr(), ws.numel(), _stream()))
+            ent = (graph, g_in, g_out, ws)
+            self._graphs[key] = ent
+        graph, g_in, g_out, ws = ent
+        if self._ws is not ws:
+            # the workspace was re-allocated for a larger shape: graphs captured on the old one are stale
+            self._graphs = {}
+            return self.enhance_graphed(wav)
+        g_in.copy_(wav)
+        graph.replay()
+        return g_out
+
     # ---- diagnostics ---------------------------------------------------------------
     def selftest_mfma(self) -> float:
         err = ctypes.c_float()

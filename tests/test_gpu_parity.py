@@ -189,6 +189,18 @@ def test_batch_rows_are_independent_and_bit_reproducible(model):
     assert torch.equal(one, out[31:32])
 
 
+def test_hipgraph_replay_is_bit_identical_to_eager(model):
+    """cmgan_enhance never allocates or synchronises, so the whole forward is capturable."""
+    wav = synthetic_clips(4, 8000, seed=12).to(DEV)
+    eager = model.engine.enhance(wav).clone()
+    g1 = model.engine.enhance_graphed(wav).clone()
+    assert torch.equal(eager, g1)
+    wav2 = synthetic_clips(4, 8000, seed=13).to(DEV)
+    g2 = model.engine.enhance_graphed(wav2).clone()            # replay with new data
+    assert torch.equal(g2, model.engine.enhance(wav2))
+    assert not torch.equal(g1, g2)
+
+
 # ------------------------------------------------------------------ pipeline
 def test_enhance_one_track_matches_reference_golden_ragged_and_chunked(model):
     from cmgan_amd.evaluation import enhance_one_track
