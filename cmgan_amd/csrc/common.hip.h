@@ -210,9 +210,25 @@ __device__ __forceinline__ void lin_acc_x3(const _Float16* wp, const f16x8 (&bh)
         for (int tb = 0; tb < NTB_; ++tb) acc[tb] = mfma32h(al, bh[tb][m], acc[tb]);
     }
 }
-// block-cooperative linear copy global -> LDS in 16-byte units
-__device__ __forceinline__ void stage_lds16(const void* __restrict__ g, void* l, int n16) {
-    const uint4* src = reinterpret_cast<const uint4*>(g);
-    uint4* dst = reinterpret_cast<uint4*>(l);
-    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// block-cooperative linear copy global -> LDS of N16 16-byte units by NTHR threads.  All loads are
+// issued before the first LDS store: a plain `for (i = tid; i < n; i += nthr) lds[i] = g[i]` loop has a
+// runtime trip count, so each load is waited for before its store and the copy pays one full memory
+// round trip PER ITERATION (measured: 8 serial round trips = ~24k cycles per 32-token dwconv block).
+template <int N16, int NTHR>
+__device__ __forceinline__ void stage_lds16(const void* __restrict__ g, void* l) {
+    constexpr int IT = (N16 + NTHR - 1) / NTHR;
+    const u32x4* src = reinterpret_cast<const u32x4*>(g);
+    u32x4* dst = reinterpret_cast<u32x4*>(l);
+    u32x4 t[IT];
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = threadIdx.x + NTHR * k;
+        if (N16 % NTHR == 0 || i < N16) t[k] = src[i];
+    }
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int i = threadIdx.x + NTHR * k;
+        if (N16 % NTHR == 0 || i < N16) dst[i] = t[k];
+    }
 }

@@ -435,12 +435,21 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ u
     const int l0 = blockIdx.y * DW_TL;
     const long nbase = (long)(n / m.inner) * m.outer + (long)(n % m.inner) * m.istride;
     constexpr int ROWS = DW_TL + DW_K - 1;
-    for (int i = threadIdx.x; i < ROWS * 32; i += 256) {
-        const int rr = i >> 5, qd = i & 31;
+    constexpr int NLD = (ROWS * 32 + 255) / 256;
+    f32x4 stg[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {                         // all loads first, then the LDS stores (see stage_lds16)
+        const int i = threadIdx.x + 256 * k, rr = i >> 5, qd = i & 31;
         const int l = l0 - (DW_K / 2) + rr;
-        f32x4 val = splat4(0.f);
-        if (l >= 0 && l < m.L) val = ldg4(u + (nbase + (long)l * m.lstride) * 128 + qd * 4);
-        *reinterpret_cast<f32x4*>(&tile[rr * 128 + qd * 4]) = val;
+        const bool inb = i < ROWS * 32 && l >= 0 && l < m.L;
+        const int lc = l < 0 ? 0 : (l < m.L ? l : m.L - 1);
+        stg[k] = ldg4(u + (nbase + (long)lc * m.lstride) * 128 + qd * 4);
+        if (!inb) stg[k] = splat4(0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        if (i < ROWS * 32) *reinterpret_cast<f32x4*>(&tile[(i >> 5) * 128 + (i & 31) * 4]) = stg[k];
     }
     const int ch = threadIdx.x & 127, sub = threadIdx.x >> 7;
     float wt[DW_K];

@@ -41,8 +41,8 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(const float* xin, float* xo
     __shared__ __attribute__((aligned(16))) float bias_l[320];             // b1[256] | b2[64]
     _Float16* w1 = wlds;                 // 16*2*1024 halfs
     _Float16* w2 = wlds + 32768;         // 4*8*1024 halfs
-    stage_lds16(w1i, w1, 4096);
-    stage_lds16(w2i, w2, 4096);
+    stage_lds16<4096, 512>(w1i, w1);
+    stage_lds16<4096, 512>(w2i, w2);
     for (int i = threadIdx.x; i < 320; i += blockDim.x) bias_l[i] = i < 256 ? b1[i] : b2[i - 256];
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x
     _Float16* w = wlds;                                        // 12*2*1024 halfs = 48 KB
     float* scratch = reinterpret_cast<float*>(wlds + 24576);   // 8 waves x 16 x 17 floats
     __shared__ __attribute__((aligned(16))) float bias_l[192];
-    stage_lds16(wi, w, 3072);
+    stage_lds16<3072, 512>(wi, w);
     for (int i = threadIdx.x; i < 192; i += blockDim.x) bias_l[i] = b[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(512) void outproj_x3_kernel(float* __restrict__ x, 
                                                          const float* __restrict__ bo, int ntiles) {
     __shared__ __attribute__((aligned(16))) _Float16 wlds[8192];
     __shared__ __attribute__((aligned(16))) float bias_l[64];
-    stage_lds16(wi, wlds, 1024);                             // [4][2] image = 16 KB
+    stage_lds16<1024, 512>(wi, wlds);                        // [4][2] image = 16 KB
     for (int i = threadIdx.x; i < 64; i += blockDim.x) bias_l[i] = bo[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(512) void pw1glu_x3_kernel(const float* __restrict_
                                                         const float* __restrict__ b, long M, int ntiles) {
     __shared__ __attribute__((aligned(16))) _Float16 wlds[32768];          // 64 KB
     __shared__ __attribute__((aligned(16))) float bias_l[256];
-    stage_lds16(wi, wlds, 4096);
+    stage_lds16<4096, 512>(wi, wlds);
     for (int i = threadIdx.x; i < 256; i += blockDim.x) bias_l[i] = b[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(512) void pw2_x3_kernel(float* __restrict__ x, cons
                                                      long M, int ntiles) {
     __shared__ __attribute__((aligned(16))) _Float16 wlds[16384];          // 32 KB
     __shared__ __attribute__((aligned(16))) float bias_l[64];
-    stage_lds16(wi, wlds, 2048);
+    stage_lds16<2048, 512>(wi, wlds);
     for (int i = threadIdx.x; i < 64; i += blockDim.x) bias_l[i] = b[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
@@ -547,6 +547,121 @@ __global__ __launch_bounds__(512) void pw2_x3_kernel(float* __restrict__ x, cons
                     stg4(p, ldg4(p) + acc[tb]);
                 }
             }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------
+// conv module parts 2+3 fused: depthwise Conv1d k=31 (+folded BatchNorm) -> Swish ->
+// pointwise 128->64 + bias + residual (conformer.py:165-170, 219).  The [M,128] depthwise
+// output (1 GB written + read per conformer at B=32 when done as two kernels) never leaves the
+// CU: a block owns 32 consecutive positions of one sequence, stages the (32+30) x 128 GLU
+// tile in LDS, runs the depthwise taps channel-per-thread (34-tap sliding window, as
+// dwconv_kernel), writes Swish(v) to LDS already split into fp16 hi/lo in B-operand order,
+// and the four waves finish with the 128->64 product on the matrix pipe.
+// The 32 KB pointwise weight image is fetched straight into registers at kernel start (its
+// consumers are two barriers away, so the L2 latency is free).  Row pitch of the v tile is
+// 288 B: conflict-free for the ds_read_b128 of 16 consecutive rows.
+// ---------------------------------------------------------------------------------
+#define DP_TL 32
+#define DP_K 31
+#define DP_VS 144                 // halfs per v-tile row (128 used)
+__global__ __launch_bounds__(256) void dwpw2_x3_kernel(float* __restrict__ x, const float* __restrict__ u,
+                                                       const float* __restrict__ dw_w,
+                                                       const float* __restrict__ dw_b,
+                                                       const _Float16* __restrict__ w2i,
+                                                       const float* __restrict__ b2, TokMap m) {
+    __shared__ __attribute__((aligned(16))) float utile[(DP_TL + DP_K - 1) * 128];
+    __shared__ __attribute__((aligned(16))) _Float16 vth[DP_TL * DP_VS];
+    __shared__ __attribute__((aligned(16))) _Float16 vtl[DP_TL * DP_VS];
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4, wv = tid >> 6;
+    const int n = blockIdx.x;
+    const int l0 = blockIdx.y * DP_TL;
+    const long nbase = (long)(n / m.inner) * m.outer + (long)(n % m.inner) * m.istride;
+
+    // pointwise operands for this wave: token block tb = wv >> 1, output blocks ob0, ob0 + 1
+    const int tb = wv >> 1, ob0 = (wv & 1) * 2;
+    f16x8 ah[2][4], al[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            const _Float16* wp = w2i + ((ob0 + o) * 4 + mm) * 1024 + lane * 8;
+            ah[o][mm] = *reinterpret_cast<const f16x8*>(wp);
+            al[o][mm] = *reinterpret_cast<const f16x8*>(wp + 512);
+        }
+
+    constexpr int ROWS = DP_TL + DP_K - 1;
+    constexpr int NLD = (ROWS * 32 + 255) / 256;
+    f32x4 stg[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {                         // all loads first (see stage_lds16)
+        const int i = tid + 256 * k, rr = i >> 5, qd = i & 31;
+        const int l = l0 - (DP_K / 2) + rr;
+        const bool inb = i < ROWS * 32 && l >= 0 && l < m.L;   // 'same' zero padding outside the sequence
+        const int lc = l < 0 ? 0 : (l < m.L ? l : m.L - 1);
+        stg[k] = ldg4(u + (nbase + (long)lc * m.lstride) * 128 + qd * 4);
+        if (!inb) stg[k] = splat4(0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + 256 * k;
+        if (i < ROWS * 32) *reinterpret_cast<f32x4*>(&utile[(i >> 5) * 128 + (i & 31) * 4]) = stg[k];
+    }
+    const int chn = tid & 127, sub = tid >> 7;
+    float wt[DP_K];
+#pragma unroll
+    for (int t = 0; t < DP_K; ++t) wt[t] = dw_w[t * 128 + chn];
+    const float bias = dw_b[chn];
+    // B-operand order inside a row: channel 32m + 16h + 4gq + r  ->  32m + 8gq + 4h + r
+    const int vcol = (chn & ~31) + ((chn >> 2) & 3) * 8 + ((chn >> 4) & 1) * 4 + (chn & 3);
+    __syncthreads();
+#pragma unroll 1
+    for (int og = 0; og < 4; ++og) {
+        const int base = sub * 16 + og * 4;
+        float acc[4] = {bias, bias, bias, bias};
+#pragma unroll
+        for (int kk = 0; kk < DP_K + 3; ++kk) {
+            const float uv = utile[(base + kk) * 128 + chn];
+#pragma unroll
+            for (int oo = 0; oo < 4; ++oo) {
+                const int t = kk - oo;
+                if (t >= 0 && t < DP_K) acc[oo] = fmaf(wt[t], uv, acc[oo]);
+            }
+        }
+#pragma unroll
+        for (int oo = 0; oo < 4; ++oo) {
+            const float v = swishf(acc[oo]);
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            vth[(base + oo) * DP_VS + vcol] = hi;
+            vtl[(base + oo) * DP_VS + vcol] = lo;
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc2[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) acc2[o] = ldg4(b2 + 16 * (ob0 + o) + 4 * g);
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) {
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(&vth[(16 * tb + c) * DP_VS + 32 * mm + 8 * g]);
+        const f16x8 bl = *reinterpret_cast<const f16x8*>(&vtl[(16 * tb + c) * DP_VS + 32 * mm + 8 * g]);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) acc2[o] = mfma32h(ah[o][mm], bh, acc2[o]);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) acc2[o] = mfma32h(ah[o][mm], bl, acc2[o]);
+#pragma unroll
+        for (int o = 0; o < 2; ++o) acc2[o] = mfma32h(al[o][mm], bh, acc2[o]);
+    }
+    const int l = l0 + 16 * tb + c;
+    if (l < m.L) {
+        float* xr = x + (nbase + (long)l * m.lstride) * 64;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            float* p = xr + 16 * (ob0 + o) + 4 * g;
+            stg4(p, ldg4(p) + acc2[o]);
         }
     }
 }
@@ -598,9 +713,15 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
 
     LAUNCH(ctx, "pw1glu", (pw1glu_x3_kernel<<<persistent_grid(flat_tiles, 2), 512, 0, s>>>(
                               b.xb, b.u, w16.pw1_w, w.pw1_b, M, flat_tiles)));
-    launch_dwconv(ctx, b.u, b.w, w.dw_w, w.dw_b, seq);
-    LAUNCH(ctx, "pw2", (pw2_x3_kernel<<<persistent_grid(flat_tiles, 2), 512, 0, s>>>(b.xb, b.w, w16.pw2_w,
-                                                                                       w.pw2_b, M, flat_tiles)));
+    static const bool unfused = getenv("CMGAN_DWPW2_UNFUSED") != nullptr;   // A/B switch
+    if (unfused) {
+        launch_dwconv(ctx, b.u, b.w, w.dw_w, w.dw_b, seq);
+        LAUNCH(ctx, "pw2", (pw2_x3_kernel<<<persistent_grid(flat_tiles, 2), 512, 0, s>>>(b.xb, b.w, w16.pw2_w,
+                                                                                           w.pw2_b, M, flat_tiles)));
+    } else {
+        dim3 dgrid(N, (seq.L + DP_TL - 1) / DP_TL);
+        LAUNCH(ctx, "dwpw2", (dwpw2_x3_kernel<<<dgrid, 256, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq)));
+    }
     if (taps) {
         hipMemcpyAsync(taps + (size_t)2 * M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
         LAUNCH(ctx, "ffn", (ffn_x3_kernel<false><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(

@@ -77,22 +77,27 @@ __global__ __launch_bounds__(256) void conv3_kernel(ConvArgs a) {
             sh = ldg4(a.nshift[s] + b * 64 + cc * 16 + qd * 4);
             al = ldg4(a.nalpha[s] + cc * 16 + qd * 4);
         }
+        // all global loads of the chunk are issued before the barrier / any LDS store (no per-iteration waits)
+        f32x4 aval[NSTAGE], wval[WF4 / 256];
+#pragma unroll
+        for (int e = 0; e < NSTAGE; ++e)
+            aval[e] = ldg4(src + (long)(apos[e] >= 0 ? apos[e] : 0) * 64 + cc * 16 + qd * 4);
+        const float* wsrc = a.w + (long)chunk * WF4 * 4;
+#pragma unroll
+        for (int i = 0; i < WF4 / 256; ++i) wval[i] = ldg4(wsrc + (tid + 256 * i) * 4);
         __syncthreads();          // previous chunk's fragments are consumed
 #pragma unroll
         for (int e = 0; e < NSTAGE; ++e) {
             const int idx = tid + 256 * e;
             if (idx < NT * CONV_ROWS * 4) {
-                f32x4 val = splat4(0.f);
-                if (apos[e] >= 0) {
-                    val = ldg4(src + (long)apos[e] * 64 + cc * 16 + qd * 4);
-                    if (tr) val = norm_prelu4(val, sc, sh, al);
-                }
+                f32x4 val = aval[e];
+                if (tr) val = norm_prelu4(val, sc, sh, al);
+                if (apos[e] < 0) val = splat4(0.f);
                 *reinterpret_cast<f32x4*>(&act[(idx >> 2) * CONV_RS + (idx & 3) * 4]) = val;
             }
         }
-        const float* wsrc = a.w + (long)chunk * WF4 * 4;
-        for (int i = tid; i < WF4; i += 256)
-            *reinterpret_cast<f32x4*>(&wl[i * 4]) = ldg4(wsrc + i * 4);
+#pragma unroll
+        for (int i = 0; i < WF4 / 256; ++i) *reinterpret_cast<f32x4*>(&wl[(tid + 256 * i) * 4]) = wval[i];
         __syncthreads();
 
 #pragma unroll
@@ -354,11 +359,21 @@ __global__ __launch_bounds__(1024) void mask_stats_kernel(const float* __restric
     const float bias = scalars[0];
     double s1 = 0.0, s2 = 0.0;
     const long n = (long)T * F;
-    for (long i = threadIdx.x; i < n; i += 1024) {
-        const int t = (int)(i / F), f = (int)(i - (long)t * F);
-        const double m = (double)mask_raw(dm, ((long)b * T + t) * W + f, bias);
-        s1 += m;
-        s2 += m * m;
+    for (long i0 = threadIdx.x; i0 < n; i0 += 1024 * 4) {           // 4 independent loads in flight per thread
+        float mv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long i = i0 + 1024 * k < n ? i0 + 1024 * k : n - 1;
+            const int t = (int)(i / F), f = (int)(i - (long)t * F);
+            mv[k] = mask_raw(dm, ((long)b * T + t) * W + f, bias);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + 1024 * k < n) {
+                s1 += (double)mv[k];
+                s2 += (double)mv[k] * (double)mv[k];
+            }
+        }
     }
     r1[threadIdx.x] = s1;
     r2[threadIdx.x] = s2;

@@ -51,12 +51,19 @@ __global__ __launch_bounds__(256) void stft_compress_kernel(SpectralTables tb, c
     const int start = fb * 16 * tb.hop - tb.n_fft / 2;
     const float sc = scale ? scale[b] : 1.0f;
     const float* x = wav + (long)b * L;
-    for (int i = threadIdx.x; i < seglen; i += 256) {
-        int s = start + i;
-        if (s < 0) s = -s;
-        if (s >= L) s = 2 * (L - 1) - s;
-        s = s < 0 ? 0 : (s >= L ? L - 1 : s);      // frames past T in the last block: any finite value
-        seg[i] = x[s] * sc;
+    for (int i0 = threadIdx.x; i0 < seglen; i0 += 256 * 8) {      // 8 independent loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            int s = start + i0 + 256 * k;
+            if (s < 0) s = -s;
+            if (s >= L) s = 2 * (L - 1) - s;
+            s = s < 0 ? 0 : (s >= L ? L - 1 : s);  // frames past T in the last block: any finite value
+            v[k] = x[s];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (i0 + 256 * k < seglen) seg[i0 + 256 * k] = v[k] * sc;
     }
     __syncthreads();
     const int KB = tb.n_fft / 16;
@@ -116,19 +123,36 @@ __global__ __launch_bounds__(256) void uncompress_irfft_kernel(SpectralTables tb
     const int K = 2 * tb.FB * 16;              // padded contraction length
     const int ld = K + 4;                      // row pitch (floats), keeps 16 B alignment
     const long P = (long)T * tb.F;
-    for (int i = threadIdx.x; i < 16 * tb.FB * 16; i += 256) {
-        const int fr = i / (tb.FB * 16), bin = i - fr * (tb.FB * 16);
-        const int t = fb * 16 + fr;
-        float yr = 0.f, yi = 0.f;
-        if (t < T && bin < tb.F) {
-            const float a = re[(long)b * P + (long)t * tb.F + bin], bq = im[(long)b * P + (long)t * tb.F + bin];
-            const float m2 = a * a + bq * bq;
-            const float s = m2 > 0.f ? powf(m2, 7.0f / 6.0f) : 0.f;
-            yr = a * s;
-            yi = bq * s;
+    const int nstage = 16 * tb.FB * 16;
+    for (int i0 = threadIdx.x; i0 < nstage; i0 += 256 * 4) {       // 4 independent (re, im) loads in flight per thread
+        float ar[4], ai[4];
+        bool okv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 256 * k;
+            const int fr = i / (tb.FB * 16), bin = i - fr * (tb.FB * 16);
+            const int t = fb * 16 + fr;
+            okv[k] = i < nstage && t < T && bin < tb.F;
+            const long off = (long)b * P + (long)(okv[k] ? t : 0) * tb.F + (okv[k] ? bin : 0);
+            ar[k] = re[off];
+            ai[k] = im[off];
         }
-        ysp[fr * ld + bin] = yr;
-        ysp[fr * ld + tb.FB * 16 + bin] = yi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + 256 * k;
+            if (i < nstage) {
+                const int fr = i / (tb.FB * 16), bin = i - fr * (tb.FB * 16);
+                float yr = 0.f, yi = 0.f;
+                if (okv[k]) {
+                    const float m2 = ar[k] * ar[k] + ai[k] * ai[k];
+                    const float sc = m2 > 0.f ? powf(m2, 7.0f / 6.0f) : 0.f;
+                    yr = ar[k] * sc;
+                    yi = ai[k] * sc;
+                }
+                ysp[fr * ld + bin] = yr;
+                ysp[fr * ld + tb.FB * 16 + bin] = yi;
+            }
+        }
     }
     __syncthreads();
     const int KB = K / 16;
