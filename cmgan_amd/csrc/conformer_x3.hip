@@ -238,48 +238,81 @@ __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x
 #define ATT_NQ 4
 
 struct AttState {
-    float m, l;
+    float m, run, l;      // reference level, running max relative to it, denominator (relative to m)
     f32x4 o;
 };
 
-// scores + rel-pos bias -> probabilities (in place), running max / sum / output rescale.
-// Scores arrive in log2 units (log2(e) is folded into the q projection by the packer), so the
-// exponential is a bare v_exp_f32.  FULL chunks (all 64 keys valid) need no masking; the skew
-// scratch is always read unconditionally (every index is in range) and masked by a select -
-// a per-lane branch here costs an exec-mask round trip per score.
+// Online softmax with a STALE reference (T13-style), arranged so the common path has no per-score
+// subtract or add at all:
+//   * the rel-pos accumulator starts at -m_ref, so R' = E q - m_ref comes out of the MFMA for free;
+//   * the skewed R' is read from LDS straight INTO the score accumulators, and the K q MFMAs
+//     accumulate on top: s = K q + E q - m_ref;
+//   * p = exp2(s) directly (scores are in log2 units: log2(e) is folded into the q projection).
+// m_ref (st.m) is the reference level of the query block (0 before the first chunk); st.run is the
+// true running maximum RELATIVE to it.  The reference is kept inside the band
+//   ATT_LO < run <= ATT_HI      (-4, +12]
+// +12 bounds p <= 2^12 (inside fp16 range for the split-product P V MFMAs), -4 keeps the largest p
+// >= 2^-4 so the fp16 lo half of P stays normal (a reference that is too HIGH would silently cost
+// mantissa bits).  Leaving the band takes the re-reference path (m_ref += run, p = exp2(s - run),
+// o and l rescaled by exp2(-run)); the branch is wave-uniform (__any) and exact for every lane.
+// Scaling an empty accumulator is skipped (0 * exp2(+big) would be NaN).
+#define ATT_HI 12.0f
+#define ATT_LO -4.0f
 template <bool FULL>
-__device__ __forceinline__ void att_softmax(f32x4 (&s)[4], const float* R, int c, int g, int j0, int nb, int L,
-                                            AttState& st) {
+__device__ __forceinline__ void att_softmax(f32x4 (&s)[4], int c, int g, int j0, int nb, int L, AttState& st) {
     float mx = -INFINITY;
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
+        if (FULL || jb < nb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float sv = s[jb][r] + R[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE_X + c];
-            if (!FULL) {
-                const int key = j0 + 16 * jb + 4 * g + r;
-                sv = (jb < nb && key < L) ? sv : -INFINITY;
+            for (int r = 0; r < 4; ++r) {
+                if (!FULL) {
+                    const int key = j0 + 16 * jb + 4 * g + r;
+                    s[jb][r] = key < L ? s[jb][r] : -INFINITY;          // select, no branch
+                }
+                mx = fmaxf(mx, s[jb][r]);
             }
-            s[jb][r] = sv;
-            mx = fmaxf(mx, sv);
         }
     }
-    mx = red_g_max(mx);
-    const float mnew = fmaxf(st.m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(st.m - mnew);
+    const float run = fmaxf(st.run, red_g_max(mx));
+    const bool drift = run > ATT_HI || run < ATT_LO;
     float psum = 0.f;
+    if (__any(drift)) {                                  // rare: re-reference this query block to its running maximum
+        const float alpha = st.l > 0.f ? __builtin_amdgcn_exp2f(-run) : 1.0f;
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
+        for (int jb = 0; jb < 4; ++jb) {
+            if (FULL || jb < nb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(s[jb][r] - mnew);
-            s[jb][r] = p;
-            psum += p;
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[jb][r] - run);
+                    s[jb][r] = p;
+                    psum += p;
+                }
+            } else {
+                s[jb] = splat4(0.f);
+            }
         }
-    psum = red_g_sum(psum);
-    st.l = st.l * alpha + psum;
-    st.o = st.o * splat4(alpha);
-    st.m = mnew;
+        st.l *= alpha;
+        st.o = st.o * splat4(alpha);
+        st.m += run;
+        st.run = 0.f;
+    } else {
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            if (FULL || jb < nb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[jb][r]);
+                    s[jb][r] = p;
+                    psum += p;
+                }
+            } else {
+                s[jb] = splat4(0.f);
+            }
+        }
+        st.run = run;
+    }
+    st.l += red_g_sum(psum);
 }
 
 struct AttCtx {
@@ -326,27 +359,20 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
             rl = rl < -a.max_pos ? -a.max_pos : (rl > a.max_pos ? a.max_pos : rl);
             ef[we] = *reinterpret_cast<const f16x8*>(a.ebase + (long)(rl + a.max_pos) * 32);
         }
-        f32x4 sA[4], sB[4];
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb) { sA[jb] = splat4(0.f); sB[jb] = splat4(0.f); }
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
-            if (FULL || jb < nb) { sA[jb] = mfma32h(kf[jb], qA1, sA[jb]); sB[jb] = mfma32h(kf[jb], qB1, sB[jb]); }
-#pragma unroll
-        for (int jb = 0; jb < 4; ++jb)
-            if (FULL || jb < nb) { sA[jb] = mfma32h(kf[jb], qA2, sA[jb]); sB[jb] = mfma32h(kf[jb], qB2, sB[jb]); }
+        AttState& sa = st[2 * pair];
+        AttState& sb = st[2 * pair + 1];
         wave_lds_fence();                                 // previous pair's skew reads are done
 #pragma unroll
         for (int we = 0; we < 6; ++we) {
             if (we < 5 && (FULL || we >= 4 - nb)) {       // cb = we for block A
-                f32x4 rt = splat4(0.f);
+                f32x4 rt = splat4(-sa.m);
                 rt = mfma32h(ef[we], qA1, rt);
                 rt = mfma32h(ef[we], qA2, rt);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a.RA[(16 * we + 4 * g + r) * RSTRIDE_X + c] = rt[r];
             }
             if (we >= 1 && (FULL || we - 1 >= 4 - nb)) {  // cb = we - 1 for block B
-                f32x4 rt = splat4(0.f);
+                f32x4 rt = splat4(-sb.m);
                 rt = mfma32h(ef[we], qB1, rt);
                 rt = mfma32h(ef[we], qB2, rt);
 #pragma unroll
@@ -354,8 +380,30 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
             }
         }
         wave_lds_fence();
-        att_softmax<FULL>(sA, a.RA, c, g, j0, nb, a.L, st[2 * pair]);
-        att_softmax<FULL>(sB, a.RB, c, g, j0, nb, a.L, st[2 * pair + 1]);
+        // the skewed (E q - m_ref) tile is read straight into the score accumulators (every index is
+        // in range, so the read is unconditional); K q accumulates on top of it
+        f32x4 sA[4], sB[4];
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            if (FULL || jb < nb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sA[jb][r] = a.RA[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE_X + c];
+                    sB[jb][r] = a.RB[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE_X + c];
+                }
+            } else {
+                sA[jb] = splat4(0.f);
+                sB[jb] = splat4(0.f);
+            }
+        }
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+            if (FULL || jb < nb) { sA[jb] = mfma32h(kf[jb], qA1, sA[jb]); sB[jb] = mfma32h(kf[jb], qB1, sB[jb]); }
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb)
+            if (FULL || jb < nb) { sA[jb] = mfma32h(kf[jb], qA2, sA[jb]); sB[jb] = mfma32h(kf[jb], qB2, sB[jb]); }
+        att_softmax<FULL>(sA, c, g, j0, nb, a.L, sa);
+        att_softmax<FULL>(sB, c, g, j0, nb, a.L, sb);
 #pragma unroll
         for (int mp = 0; mp < 2; ++mp) {
             if (FULL || 2 * mp < nb) {
@@ -395,7 +443,7 @@ __global__ __launch_bounds__(256, OCC) void attn_x3_kernel(QkvOut io, const _Flo
 
     AttState st[ATT_NQ];
 #pragma unroll
-    for (int i = 0; i < ATT_NQ; ++i) { st[i].m = -INFINITY; st[i].l = 0.f; st[i].o = splat4(0.f); }
+    for (int i = 0; i < ATT_NQ; ++i) { st[i].m = 0.f; st[i].run = -INFINITY; st[i].l = 0.f; st[i].o = splat4(0.f); }
 
     const int nfull = L >> 6;
 #pragma unroll 1

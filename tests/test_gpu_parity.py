@@ -140,6 +140,25 @@ def test_conformer_rel_pos_clamp_beyond_512(conf):
     assert _report("conformer[n=600].out", rel_err(y, want)) < STAGE
 
 
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("gain", [40.0, 0.02])
+def test_attention_softmax_rereference_branch(mode, gain):
+    """The F16X3 attention keeps a stale softmax reference and only re-references when a chunk's
+    scores drift by more than 2^12 from it; random weights never take that branch, so force it:
+    to_q scaled x40 makes |scores| >> 12 (peaky softmax, positive and negative drifts), x0.02 keeps
+    everything on the common path.  Both must match the oracle (a rare branch needs its own test)."""
+    from cmgan_amd import ConformerBlock
+    csd = dict(conformer_state_dict(seed=3))
+    csd["attn.fn.to_q.weight"] = csd["attn.fn.to_q.weight"] * gain
+    blk = ConformerBlock(dim=64, dim_head=16, heads=4, conv_kernel_size=31, mfma_mode=mode).load_state_dict(csd)
+    x = torch.from_numpy(np.random.Generator(np.random.PCG64(77)).standard_normal((3, 200, 64)).astype(np.float32))
+    st = {}
+    want = O.conformer_block(csd, "", x, st)
+    y, taps = blk.forward_with_taps(x.to(DEV))
+    assert _report(f"attn re-reference gain={gain} [{mode}]", rel_err(taps[1], st["attn"])) < STAGE
+    assert _report(f"conformer out gain={gain} [{mode}]", rel_err(y, want)) < STAGE
+
+
 # ------------------------------------------------------------------ generator
 def test_tscnet_stages_match_reference_golden(model):
     g = load_golden("tscnet.npz")
