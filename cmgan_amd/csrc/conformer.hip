@@ -192,43 +192,71 @@ __global__ __launch_bounds__(256) void qkv_kernel(const float* __restrict__ x, T
 #define RSTRIDE 20
 
 struct AttnState {
-    float m, l;
+    float m, run, l;      // reference level, running max relative to it, denominator (relative to m)
     f32x4 o;
 };
 
+// Online softmax with a stale reference kept in the band (-4, +12] around the running maximum; see
+// att_softmax in conformer_x3.hip for the derivation.  The rel-pos accumulator starts at -m_ref and
+// the skewed tile is read straight into the score accumulators, so the common path has no per-score
+// add or subtract: p = exp2(K q + E q - m_ref).
+#define ATTN_HI 12.0f
+#define ATTN_LO -4.0f
 template <bool FULL>
-__device__ __forceinline__ void attn_softmax(f32x4 (&s)[4], const float* R, int c, int g, int j0, int nb, int L,
-                                             AttnState& st) {
+__device__ __forceinline__ void attn_softmax(f32x4 (&s)[4], int c, int g, int j0, int nb, int L, AttnState& st) {
     float mx = -INFINITY;
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
+        if (FULL || jb < nb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float sv = s[jb][r] + R[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE + c];     // always in range
-            if (!FULL) {
-                const int key = j0 + 16 * jb + 4 * g + r;
-                sv = (jb < nb && key < L) ? sv : -INFINITY;                            // select, no branch
+            for (int r = 0; r < 4; ++r) {
+                if (!FULL) {
+                    const int key = j0 + 16 * jb + 4 * g + r;
+                    s[jb][r] = key < L ? s[jb][r] : -INFINITY;
+                }
+                mx = fmaxf(mx, s[jb][r]);
             }
-            s[jb][r] = sv;
-            mx = fmaxf(mx, sv);
         }
     }
-    mx = red_g_max(mx);
-    const float mnew = fmaxf(st.m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(st.m - mnew);
+    const float run = fmaxf(st.run, red_g_max(mx));
+    const bool drift = run > ATTN_HI || run < ATTN_LO;
     float psum = 0.f;
+    if (__any(drift)) {
+        const float alpha = st.l > 0.f ? __builtin_amdgcn_exp2f(-run) : 1.0f;
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
+        for (int jb = 0; jb < 4; ++jb) {
+            if (FULL || jb < nb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(s[jb][r] - mnew);
-            s[jb][r] = p;
-            psum += p;
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[jb][r] - run);
+                    s[jb][r] = p;
+                    psum += p;
+                }
+            } else {
+                s[jb] = splat4(0.f);
+            }
         }
-    psum = red_g_sum(psum);
-    st.l = st.l * alpha + psum;
-    st.o = st.o * splat4(alpha);
-    st.m = mnew;
+        st.l *= alpha;
+        st.o = st.o * splat4(alpha);
+        st.m += run;
+        st.run = 0.f;
+    } else {
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) {
+            if (FULL || jb < nb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[jb][r]);
+                    s[jb][r] = p;
+                    psum += p;
+                }
+            } else {
+                s[jb] = splat4(0.f);
+            }
+        }
+        st.run = run;
+    }
+    st.l += red_g_sum(psum);
 }
 
 struct AttnCtx {
@@ -242,20 +270,6 @@ __device__ __forceinline__ void attn_chunk(const AttnCtx& a, int ibA, int j0, co
                                            AttnState& sa, AttnState& sb) {
     const int nb = FULL ? 4 : ((a.L - j0 + 15) >> 4);
     const int c = a.c, g = a.g;
-    f32x4 sA[4], sB[4];
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) {
-        sA[jb] = splat4(0.f);
-        sB[jb] = splat4(0.f);
-        if (FULL || jb < nb) {
-            const f32x4 kf = ldg4(a.kp + (long)((j0 >> 4) + jb) * 256);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                sA[jb] = mfma16(kf[r], qA[r], sA[jb]);
-                sB[jb] = mfma16(kf[r], qB[r], sB[jb]);
-            }
-        }
-    }
     // window of the pair: 6 row blocks from rminA = 16 ibA - j0 - 63; A uses blocks 0..4, B blocks 1..5
     const int rminA = ibA * 16 - j0 - 63;
     wave_lds_fence();                                     // previous chunk's skew reads are done
@@ -268,14 +282,14 @@ __device__ __forceinline__ void attn_chunk(const AttnCtx& a, int ibA, int j0, co
             rl = rl < -a.max_pos ? -a.max_pos : (rl > a.max_pos ? a.max_pos : rl);
             const f32x4 ef = ldg4(a.rel + (long)(rl + a.max_pos) * 16 + 4 * g);
             if (useA) {
-                f32x4 rt = splat4(0.f);
+                f32x4 rt = splat4(-sa.m);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rt = mfma16(ef[r], qA[r], rt);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a.RA[(16 * we + 4 * g + r) * RSTRIDE + c] = rt[r];
             }
             if (useB) {
-                f32x4 rt = splat4(0.f);
+                f32x4 rt = splat4(-sb.m);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rt = mfma16(ef[r], qB[r], rt);
 #pragma unroll
@@ -284,8 +298,29 @@ __device__ __forceinline__ void attn_chunk(const AttnCtx& a, int ibA, int j0, co
         }
     }
     wave_lds_fence();
-    attn_softmax<FULL>(sA, a.RA, c, g, j0, nb, a.L, sa);
-    attn_softmax<FULL>(sB, a.RB, c, g, j0, nb, a.L, sb);
+    // skewed (E q - m_ref) tile read straight into the score accumulators; K q accumulates on top
+    f32x4 sA[4], sB[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) {
+        if (FULL || jb < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sA[jb][r] = a.RA[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE + c];
+                sB[jb][r] = a.RB[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE + c];
+            }
+            const f32x4 kf = ldg4(a.kp + (long)((j0 >> 4) + jb) * 256);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sA[jb] = mfma16(kf[r], qA[r], sA[jb]);
+                sB[jb] = mfma16(kf[r], qB[r], sB[jb]);
+            }
+        } else {
+            sA[jb] = splat4(0.f);
+            sB[jb] = splat4(0.f);
+        }
+    }
+    attn_softmax<FULL>(sA, c, g, j0, nb, a.L, sa);
+    attn_softmax<FULL>(sB, c, g, j0, nb, a.L, sb);
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
         if (FULL || jb < nb) {
@@ -320,7 +355,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
     const f32x4 qA = ldg4(a.qp + (long)ibA * 256), qB = ldg4(a.qp + (long)ibB * 256);
 
     AttnState sa, sb;
-    sa.m = sb.m = -INFINITY; sa.l = sb.l = 0.f; sa.o = sb.o = splat4(0.f);
+    sa.m = sb.m = 0.f; sa.run = sb.run = -INFINITY; sa.l = sb.l = 0.f; sa.o = sb.o = splat4(0.f);
     const int nfull = L >> 6;
 #pragma unroll 1
     for (int ch = 0; ch < nfull; ++ch) attn_chunk<true>(a, ibA, ch * 64, qA, qB, sa, sb);

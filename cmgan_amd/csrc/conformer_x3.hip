@@ -7,8 +7,6 @@
 //     d = 16 costs two MFMAs per 16x16 tile and yields all four split terms
 //   * Q / K are exchanged as row-major fp16 hi/lo rows, V as ready-made A-operand images
 //     (transposed through 1 KB of wave-private LDS in the producer)
-#include <stdlib.h>
-
 #include "kernels.h"
 
 #define XNTB 2
@@ -31,8 +29,8 @@ __device__ __forceinline__ void ln_split(const f32x4 (&x)[4], f16x8 (&bh)[2], f1
 // FeedForward (+ post LayerNorm + TSCB residual when FINAL), see ffn_kernel.
 // LDS: W1 image [16][2] + W2 image [4][8] = 128 KB.
 // ---------------------------------------------------------------------------------
-template <bool FINAL>
-__global__ __launch_bounds__(512) void ffn_x3_kernel(const float* xin, float* xout, const float* x0,
+template <bool FINAL, int TNTB, int TWAVES>   // token blocks per wave, waves per block
+__global__ __launch_bounds__(TWAVES * 64) void ffn_x3_kernel(const float* xin, float* xout, const float* x0,
                                                      const float* __restrict__ post_gb,
                                                      const _Float16* __restrict__ w1i, const float* __restrict__ b1,
                                                      const _Float16* __restrict__ w2i, const float* __restrict__ b2,
@@ -41,8 +39,8 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(const float* xin, float* xo
     __shared__ __attribute__((aligned(16))) float bias_l[320];             // b1[256] | b2[64]
     _Float16* w1 = wlds;                 // 16*2*1024 halfs
     _Float16* w2 = wlds + 32768;         // 4*8*1024 halfs
-    stage_lds16<4096, 512>(w1i, w1);
-    stage_lds16<4096, 512>(w2i, w2);
+    stage_lds16<4096, TWAVES * 64>(w1i, w1);
+    stage_lds16<4096, TWAVES * 64>(w2i, w2);
     for (int i = threadIdx.x; i < 320; i += blockDim.x) bias_l[i] = i < 256 ? b1[i] : b2[i - 256];
     __syncthreads();
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
@@ -52,18 +50,18 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(const float* xin, float* xo
     _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
         const int hb = 2 * (M2) + j;                                                                  \
         const f32x4 bias = *reinterpret_cast<const f32x4*>(&bias_l[16 * hb + 4 * g]);                 \
-        _Pragma("unroll") for (int tb = 0; tb < XNTB; ++tb) H[j][tb] = bias;                          \
-        lin_acc_x3<2, XNTB>(w1 + hb * 2048 + lane * 8, xbh, xbl, H[j]);                               \
+        _Pragma("unroll") for (int tb = 0; tb < TNTB; ++tb) H[j][tb] = bias;                          \
+        lin_acc_x3<2, TNTB>(w1 + hb * 2048 + lane * 8, xbh, xbl, H[j]);                               \
     }
 
 #pragma unroll 1
-    for (int tile = blockIdx.x * XWAVES + wv; tile < ntiles; tile += gridDim.x * XWAVES) {
-        long row[XNTB];
-        bool ok[XNTB];
-        f16x8 xbh[XNTB][2], xbl[XNTB][2];
+    for (int tile = blockIdx.x * TWAVES + wv; tile < ntiles; tile += gridDim.x * TWAVES) {
+        long row[TNTB];
+        bool ok[TNTB];
+        f16x8 xbh[TNTB][2], xbl[TNTB][2];
 #pragma unroll
-        for (int tb = 0; tb < XNTB; ++tb) {
-            const long t = ((long)tile * XNTB + tb) * 16 + c;
+        for (int tb = 0; tb < TNTB; ++tb) {
+            const long t = ((long)tile * TNTB + tb) * 16 + c;
             ok[tb] = t < M;
             row[tb] = ok[tb] ? t : M - 1;
             f32x4 x[4];
@@ -71,23 +69,23 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(const float* xin, float* xo
             for (int kb = 0; kb < 4; ++kb) x[kb] = ldg4(xin + row[tb] * 64 + 16 * kb + 4 * g);
             ln_split(x, xbh[tb], xbl[tb]);      // the residual is re-read in the epilogue (L2 hit): 32 VGPRs saved
         }
-        f32x4 y[XNTB][4];
+        f32x4 y[TNTB][4];
 #pragma unroll
-        for (int tb = 0; tb < XNTB; ++tb)
+        for (int tb = 0; tb < TNTB; ++tb)
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) y[tb][ob] = splat4(0.f);
 
         // software pipeline over the 8 hidden k32-blocks: GEMM1(m2+1) is issued before the
         // Swish/split of block m2, so its MFMAs overlap that VALU work inside one wave
-        f32x4 hcur[2][XNTB];
+        f32x4 hcur[2][TNTB];
         FFN_GEMM1(0, hcur)
 #pragma unroll 1
         for (int m2 = 0; m2 < 8; ++m2) {
-            f32x4 hnext[2][XNTB];
+            f32x4 hnext[2][TNTB];
             if (m2 < 7) { FFN_GEMM1(m2 + 1, hnext) }
-            f16x8 hh[XNTB], hl[XNTB];
+            f16x8 hh[TNTB], hl[TNTB];
 #pragma unroll
-            for (int tb = 0; tb < XNTB; ++tb) {
+            for (int tb = 0; tb < TNTB; ++tb) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     hcur[0][tb][r] = swish_x(hcur[0][tb][r]);
@@ -101,21 +99,21 @@ __global__ __launch_bounds__(512) void ffn_x3_kernel(const float* xin, float* xo
                 const f16x8 ah = *reinterpret_cast<const f16x8*>(wp);
                 const f16x8 al = *reinterpret_cast<const f16x8*>(wp + 512);
 #pragma unroll
-                for (int tb = 0; tb < XNTB; ++tb) y[tb][ob] = mfma32h(ah, hh[tb], y[tb][ob]);
+                for (int tb = 0; tb < TNTB; ++tb) y[tb][ob] = mfma32h(ah, hh[tb], y[tb][ob]);
 #pragma unroll
-                for (int tb = 0; tb < XNTB; ++tb) y[tb][ob] = mfma32h(ah, hl[tb], y[tb][ob]);
+                for (int tb = 0; tb < TNTB; ++tb) y[tb][ob] = mfma32h(ah, hl[tb], y[tb][ob]);
 #pragma unroll
-                for (int tb = 0; tb < XNTB; ++tb) y[tb][ob] = mfma32h(al, hh[tb], y[tb][ob]);
+                for (int tb = 0; tb < TNTB; ++tb) y[tb][ob] = mfma32h(al, hh[tb], y[tb][ob]);
             }
             if (m2 < 7) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int tb = 0; tb < XNTB; ++tb) hcur[j][tb] = hnext[j][tb];
+                    for (int tb = 0; tb < TNTB; ++tb) hcur[j][tb] = hnext[j][tb];
             }
         }
 #pragma unroll
-        for (int tb = 0; tb < XNTB; ++tb) {
+        for (int tb = 0; tb < TNTB; ++tb) {
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob)
                 y[tb][ob] = y[tb][ob] + *reinterpret_cast<const f32x4*>(&bias_l[256 + 16 * ob + 4 * g]) +
@@ -421,8 +419,7 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
     }
 }
 
-template <int OCC>    // waves per SIMD the register allocator is asked to fit
-__global__ __launch_bounds__(256, OCC) void attn_x3_kernel(QkvOut io, const _Float16* __restrict__ eimg, int max_pos,
+__global__ __launch_bounds__(256, 2) void attn_x3_kernel(QkvOut io, const _Float16* __restrict__ eimg, int max_pos,
                                                          float* __restrict__ o, int L, int Lb, int Lb2, int nqg,
                                                          long total) {
     __shared__ float rbuf[4][2][80 * RSTRIDE_X];
@@ -548,51 +545,6 @@ __global__ __launch_bounds__(512) void pw1glu_x3_kernel(const float* __restrict_
 #pragma unroll
                     for (int e = 0; e < 4; ++e) r[e] = aa[tb][e] * sigmoidf_fast(ag[tb][e]);
                     stg4(u + row[tb] * 128 + 16 * ob + 4 * g, r);
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------
-// conv module part 3: pointwise 128->64 + bias + residual.   LDS: [4][4] image = 32 KB.
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void pw2_x3_kernel(float* __restrict__ x, const float* __restrict__ vin,
-                                                     const _Float16* __restrict__ wi, const float* __restrict__ b,
-                                                     long M, int ntiles) {
-    __shared__ __attribute__((aligned(16))) _Float16 wlds[16384];          // 32 KB
-    __shared__ __attribute__((aligned(16))) float bias_l[64];
-    stage_lds16<2048, 512>(wi, wlds);
-    for (int i = threadIdx.x; i < 64; i += blockDim.x) bias_l[i] = b[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-#pragma unroll 1
-    for (int tile = blockIdx.x * XWAVES + wv; tile < ntiles; tile += gridDim.x * XWAVES) {
-        long row[XNTB];
-        bool ok[XNTB];
-        f16x8 bh[XNTB][4], bl[XNTB][4];
-#pragma unroll
-        for (int tb = 0; tb < XNTB; ++tb) {
-            const long t = ((long)tile * XNTB + tb) * 16 + c;
-            ok[tb] = t < M;
-            row[tb] = ok[tb] ? t : M - 1;
-#pragma unroll
-            for (int mm = 0; mm < 4; ++mm)
-                split8(ldg4(vin + row[tb] * 128 + 32 * mm + 4 * g), ldg4(vin + row[tb] * 128 + 32 * mm + 16 + 4 * g),
-                       bh[tb][mm], bl[tb][mm]);
-        }
-#pragma unroll
-        for (int ob = 0; ob < 4; ++ob) {
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(&bias_l[16 * ob + 4 * g]);
-            f32x4 acc[XNTB];
-#pragma unroll
-            for (int tb = 0; tb < XNTB; ++tb) acc[tb] = bias;
-            lin_acc_x3<4, XNTB>(wlds + ob * 4096 + lane * 8, bh, bl, acc);
-#pragma unroll
-            for (int tb = 0; tb < XNTB; ++tb) {
-                if (ok[tb]) {
-                    float* p = x + row[tb] * 64 + 16 * ob + 4 * g;
-                    stg4(p, ldg4(p) + acc[tb]);
                 }
             }
         }
@@ -736,7 +688,7 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
     io.kimg = reinterpret_cast<_Float16*>(b.k);
     io.vimg = reinterpret_cast<_Float16*>(b.v);
 
-    LAUNCH(ctx, "ffn", (ffn_x3_kernel<false><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(
+    LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, 8><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(
                            b.xa, b.xb, nullptr, nullptr, w16.ff1_w1, w.ff1_b1, w16.ff1_w2, w.ff1_b2, M, flat_tiles)));
     if (taps) hipMemcpyAsync(taps, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
 
@@ -746,13 +698,8 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
     {
         const int nqg = (seq.Lb + ATT_NQ - 1) / ATT_NQ;
         const long waves = (long)N * 4 * nqg;
-        static const int occ = getenv("CMGAN_ATTN_OCC") ? atoi(getenv("CMGAN_ATTN_OCC")) : 2;
-        if (occ == 3)
-            LAUNCH(ctx, "attn", (attn_x3_kernel<3><<<(unsigned)((waves + 3) / 4), 256, 0, s>>>(
-                                    io, w16.rel_img, w.max_pos, b.o, seq.L, seq.Lb, Lb2, nqg, waves)));
-        else
-            LAUNCH(ctx, "attn", (attn_x3_kernel<2><<<(unsigned)((waves + 3) / 4), 256, 0, s>>>(
-                                    io, w16.rel_img, w.max_pos, b.o, seq.L, seq.Lb, Lb2, nqg, waves)));
+        LAUNCH(ctx, "attn", (attn_x3_kernel<<<(unsigned)((waves + 3) / 4), 256, 0, s>>>(
+                                io, w16.rel_img, w.max_pos, b.o, seq.L, seq.Lb, Lb2, nqg, waves)));
     }
     const int otiles = (seq.nblocks + XNTB - 1) / XNTB;
     LAUNCH(ctx, "outproj", (outproj_x3_kernel<<<persistent_grid(otiles, 2), 512, 0, s>>>(b.xb, seq, b.o, w16.wo,
@@ -761,22 +708,16 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
 
     LAUNCH(ctx, "pw1glu", (pw1glu_x3_kernel<<<persistent_grid(flat_tiles, 2), 512, 0, s>>>(
                               b.xb, b.u, w16.pw1_w, w.pw1_b, M, flat_tiles)));
-    static const bool unfused = getenv("CMGAN_DWPW2_UNFUSED") != nullptr;   // A/B switch
-    if (unfused) {
-        launch_dwconv(ctx, b.u, b.w, w.dw_w, w.dw_b, seq);
-        LAUNCH(ctx, "pw2", (pw2_x3_kernel<<<persistent_grid(flat_tiles, 2), 512, 0, s>>>(b.xb, b.w, w16.pw2_w,
-                                                                                           w.pw2_b, M, flat_tiles)));
-    } else {
-        dim3 dgrid(N, (seq.L + DP_TL - 1) / DP_TL);
-        LAUNCH(ctx, "dwpw2", (dwpw2_x3_kernel<<<dgrid, 256, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq)));
-    }
+    dim3 dgrid(N, (seq.L + DP_TL - 1) / DP_TL);
+    LAUNCH(ctx, "dwpw2", (dwpw2_x3_kernel<<<dgrid, 256, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq)));
     if (taps) {
         hipMemcpyAsync(taps + (size_t)2 * M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
-        LAUNCH(ctx, "ffn", (ffn_x3_kernel<false><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(
+        LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, 8><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(
                                b.xb, taps + (size_t)3 * M * 64, nullptr, nullptr, w16.ff2_w1, w.ff2_b1, w16.ff2_w2,
                                w.ff2_b2, M, flat_tiles)));
     }
-    LAUNCH(ctx, "ffn_post", (ffn_x3_kernel<true><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(
+    // (a 16-wave x 1-token-block geometry, 4 waves / SIMD, measured no faster: occupancy is not the limiter)
+    LAUNCH(ctx, "ffn_post", (ffn_x3_kernel<true, 2, 8><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(
                                 b.xb, b.xa, outer_residual ? b.xa : nullptr, w.post_gb, w16.ff2_w1, w.ff2_b1,
                                 w16.ff2_w2, w.ff2_b2, M, flat_tiles)));
 }

@@ -248,13 +248,25 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restric
     const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int b = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int t = part; t < ntiles; t += 4) {
-        const float* p = partials + (((long)b * ntiles + t) * cstride + c) * 2;
-        s1 += (double)p[0];
-        s2 += (double)p[1];
-        if (fold2) {
-            s1 += (double)p[128];
-            s2 += (double)p[129];
+    for (int t0 = part; t0 < ntiles; t0 += 4 * 8) {           // 8 independent loads in flight, fixed summation order
+        float v1[8], v2[8], f1[8], f2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int t = t0 + 4 * k < ntiles ? t0 + 4 * k : ntiles - 1;
+            const float* p = partials + (((long)b * ntiles + t) * cstride + c) * 2;
+            v1[k] = p[0];
+            v2[k] = p[1];
+            f1[k] = fold2 ? p[128] : 0.f;
+            f2[k] = fold2 ? p[129] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (t0 + 4 * k < ntiles) {
+                s1 += (double)v1[k];
+                s2 += (double)v2[k];
+                s1 += (double)f1[k];
+                s2 += (double)f2[k];
+            }
         }
     }
     acc[part][c][0] = s1;

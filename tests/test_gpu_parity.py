@@ -246,6 +246,19 @@ def test_long_track_runs_unchunked_like_the_reference(model, sd):
     assert _report("enhance 6 s track vs oracle", rel_err(got, O.enhance(sd, noisy))) < GATE
 
 
+def test_config5_ten_second_clip_in_400_frame_windows(model, sd):
+    """BASELINE.json configs[4]: a 10 s clip processed as 400-frame windows.  The reference has no state
+    carry; its own mechanism for windows is the reshape-to-rows rule of
+    evaluation.py:30-34, so parity is defined per window: cut_len = 400 frames x hop = 40000 samples ->
+    4 independent rows of 401 frames each."""
+    from cmgan_amd.evaluation import enhance_one_track
+    noisy = synthetic_clips(1, 160000, seed=21)
+    got = enhance_one_track(model, noisy.to(DEV), cut_len=40000)
+    want = O.enhance(sd, noisy, cut_len=40000)
+    assert got.shape == (160000,)
+    assert _report("10 s clip, 4 x 400-frame windows vs oracle", rel_err(got, want)) < GATE
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_argument_errors_surface_as_exceptions(model):
     from cmgan_amd._lib import CmganError
