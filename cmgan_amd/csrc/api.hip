@@ -398,7 +398,8 @@ static WsPlan plan_ws(const cmgan_config& c, int B, int T) {
     p.w = take(cur, M * 128);
     p.dm = take(cur, (size_t)B * T * W2 * 4 + 64);
     p.dc = take(cur, (size_t)B * T * W2 * 4 + 64);
-    const size_t nt = std::max((size_t)conv3_ntiles(T, (int)F), (size_t)conv_in_ntiles((int)P));
+    const size_t nt = std::max({(size_t)conv3_ntiles(T, (int)F), (size_t)conv_in_ntiles((int)P),
+                                (size_t)conv3x_ntiles(T, (int)F, 64), (size_t)conv3x_ntiles(T, (int)F, 128)});
     p.partials = take(cur, (size_t)B * nt * 128 * 2);
     p.ns = take(cur, (size_t)16 * 2 * B * 64);
     p.mstat = take(cur, (size_t)B * 2);

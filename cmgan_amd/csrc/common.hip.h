@@ -56,11 +56,18 @@ __device__ __forceinline__ float red_g_max(float v) {
     return fmaxf(a, b);
 }
 // reduce over the 16 lanes of one lane group (same g, c = 0..15)
+// sum over the 16 lanes that share lane>>4 (one DPP row): four DPP adds (quad swaps, then the
+// half-row and row mirrors), no LDS permute traffic.  (As __shfl_xor this was 4 ds_bpermute
+// round trips per value: 128 of them made the dense-conv epilogue cost 14k cycles per tile.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float red_c_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v += dpp_perm<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_perm<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_perm<0x141>(v);      // row_half_mirror: other quad of the 8-lane half
+    v += dpp_perm<0x140>(v);      // row_mirror: other half of the row
     return v;
 }
 __device__ __forceinline__ float wave_sum(float v) { return red_g_sum(red_c_sum(v)); }
@@ -178,10 +185,24 @@ __device__ __forceinline__ f16x2 pkrtz(float a, float b) {
     return __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b));
 }
 // 4 floats -> hi / lo halves (hi by round-toward-zero, lo = x - hi exactly representable residual, RTZ)
+// hi = fp16 RTZ of (a, b); lo = fp16(a - hi.x, b - hi.y).  The f16 -> f32 widening of hi, the
+// subtraction and the fp16 rounding of the residual are ONE v_fma_mix{lo,hi}_f16 per value
+// (mixed-precision FMA: f16 source, f32 addend, f16 result into one half of the destination):
+// 1.5 VALU per value instead of the 2.5-3 the compiler emits for cvt / sub / pack.  VALU issue
+// is not hidden behind MFMAs on this machine, so this is kernel time.
+__device__ __forceinline__ void split2(float a, float b, f16x2& hi, f16x2& lo) {
+    hi = pkrtz(a, b);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(l)
+        : "v"(hi), "v"(a), "v"(b));
+    lo = __builtin_bit_cast(f16x2, l);
+}
 __device__ __forceinline__ void split4(f32x4 v, f16x4& hi, f16x4& lo) {
-    const f16x2 h0 = pkrtz(v[0], v[1]), h1 = pkrtz(v[2], v[3]);
-    const f16x2 l0 = pkrtz(v[0] - (float)h0[0], v[1] - (float)h0[1]);
-    const f16x2 l1 = pkrtz(v[2] - (float)h1[0], v[3] - (float)h1[1]);
+    f16x2 h0, h1, l0, l1;
+    split2(v[0], v[1], h0, l0);
+    split2(v[2], v[3], h1, l1);
     hi[0] = h0[0]; hi[1] = h0[1]; hi[2] = h1[0]; hi[3] = h1[1];
     lo[0] = l0[0]; lo[1] = l0[1]; lo[2] = l1[0]; lo[3] = l1[1];
 }

@@ -29,175 +29,221 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
     return i == 0 ? p[0] : (i == 1 ? p[1] : (i == 2 ? p[2] : p[3]));
 }
 
-template <int NT, int COUT, int NPB>
-__global__ __launch_bounds__(256) void conv3x_kernel(ConvArgs a, const _Float16* __restrict__ w16) {
-    constexpr int CX_TILE = 64 * NPB;                         // positions per block (4 waves x NPB x 16)
-    constexpr int CX_ROWS = CX_TILE + 2;
-    constexpr int CB = COUT / 16;
-    constexpr int TAPS = NT * 3;
-    constexpr int NACT = (CX_ROWS * 8 + 255) / 256;          // float4 loads per thread per stage
-    constexpr int W16 = 3 * CB * 2 * 64;                      // 16-byte units of weights per stage
-    constexpr int NW = W16 / 256;
-    __shared__ __attribute__((aligned(16))) _Float16 act_h[CX_ROWS * CX_STRIDE];
-    __shared__ __attribute__((aligned(16))) _Float16 act_l[CX_ROWS * CX_STRIDE];
-    __shared__ __attribute__((aligned(16))) _Float16 wl[W16 * 8];
-    __shared__ float red[4][COUT][2];
+// ---------------------------------------------------------------------------------
+// The kernel body is written once as macros over a fixed set of local names and used by two
+// schedulers:
+//   conv3x_kernel  - 4 waves, one tile, stage-write -> barrier -> MFMA -> barrier
+//   conv3p_kernel  - 8 waves = two groups of 4 (waves w and w+4 share a SIMD), each group owns
+//                    a tile and its own LDS buffers, and the block-wide barriers hold the two
+//                    groups in ANTI-PHASE: while group 0 runs the MFMAs of stage s, group 1
+//                    normalises / splits / writes its stage s, and vice versa.
+// Why: with independent 4-wave blocks the two waves that share a SIMD start together and stay
+// phase-locked (both in the MFMA phase, then both in the VALU staging phase), so MFMA time and
+// VALU time ADD - measured by compile-time ablation: removing the MFMAs saved 2.5 ms of 7.25,
+// removing the staging VALU 1.6 ms, i.e. exactly their stand-alone costs.  In anti-phase the
+// SIMD's matrix pipe and VALU work on different waves at the same time.
+// ---------------------------------------------------------------------------------
+#define CX_DECLS                                                                                         \
+    constexpr int CX_ROWS = 64 * NPB;                         /* staged rows = MFMA positions (4 waves x NPB x 16) */ \
+    constexpr int CX_TILE = CX_ROWS - 2;                      /* outputs per tile: the last two MFMA positions lack \
+                                                                 their right halo and are discarded, which makes  \
+                                                                 the staged tile exactly NACT rows per thread */   \
+    constexpr int CB = COUT / 16;                                                                        \
+    constexpr int TAPS = NT * 3;                                                                         \
+    constexpr int NACT = CX_ROWS * 8 / 256;                  /* float4 loads per thread per stage */     \
+    constexpr int W16 = 3 * CB * 2 * 64;                      /* 16-byte units of weights per stage */    \
+    constexpr int NW = W16 / 256;                                                                        \
+    constexpr int ACT = CX_ROWS * CX_STRIDE;                  /* halfs per activation plane (hi or lo) */ \
+    constexpr int SMEM = 2 * ACT + W16 * 8;                   /* [act hi | act lo | weights]: one base register, constant offsets */
 
-    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4, wv = tid >> 6;
-    // XCD-aware block order: the dispatcher deals consecutive workgroups round-robin to the 8
-    // XCDs (private L2 each).  Re-map so XCD x walks a CONTIGUOUS range of (clip, tile): the
-    // rows a tile reads as its t-dil plane were read moments earlier as the t plane of a
-    // neighbouring tile on the SAME XCD -> second read is an L2 hit, not a second HBM fetch.
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int qn = nwg >> 3, rn = nwg & 7;
-    const int logical = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
-    const int b = logical / a.ntiles, tile = logical - b * a.ntiles;
-    const int Fp = a.F + 1;
-    const int q0 = tile * CX_TILE;
-
-    // per-thread staging map: row p = (tid >> 3) + 32 e, channel quad qd = tid & 7 of the 32-chunk
-    const int qd = tid & 7;
-    const int lds_col = 8 * (qd & 3) + 4 * (qd >> 2);       // chain slot order: [4g..4g+3 | 16+4g..]
-    int apos1[NACT], apos0[NACT];
-#pragma unroll
-    for (int e = 0; e < NACT; ++e) {
-        const int p = (tid >> 3) + 32 * e;
-        apos1[e] = apos0[e] = -1;
-        if (p < CX_ROWS) {
-            const int q = q0 - 1 + p;
-            if (q >= 0) {
-                const int t = q / Fp, f = q - t * Fp;
-                if (f < a.F && t < a.T) {
-                    apos1[e] = (b * a.T + t) * a.F + f;
-                    if (NT == 2 && t >= a.dil) apos0[e] = apos1[e] - a.dil * a.F;
-                }
-            }
-        }
-    }
-
-    f32x4 acc[CB][NPB];
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-        for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = splat4(0.f);
-
-    const int nst = a.nslots * 2 * NT;
-    f32x4 pre[NACT];
-    u32x4 wpre[NW];
+// per-thread staging map: row p = (tid >> 3) + 32 e, channel quad qd = tid & 7 of the 32-chunk.
+// off1[e] = byte offset inside the clip of this thread's 16 B of the t plane (first row when the
+// row is zero padding); inv1 / inv0 = per-lane padding bits of the t / t - dil plane.
+#define CX_SETUP(VALID)                                                                                  \
+    const int Fp = a.F + 1;                                                                              \
+    const int q0 = tile * CX_TILE;                                                                       \
+    const int qd = tid & 7;                                                                              \
+    const int lds_col = 8 * (qd & 3) + 4 * (qd >> 2);       /* chain slot order: [4g..4g+3 | 16+4g..] */ \
+    _Float16* const wrow = sm + (tid >> 3) * CX_STRIDE + lds_col;           /* staging writes */           \
+    const _Float16* const brow = sm + (16 * NPB * wv + c) * CX_STRIDE + 8 * g;   /* B-operand reads */    \
+    const _Float16* const alane = sm + 2 * ACT + lane * 8;                       /* A-operand reads */    \
+    unsigned off1[NACT];                                                                                 \
+    unsigned inv1 = 0, inv0 = 0;                                                                         \
+    const unsigned dFb = (unsigned)(a.dil * a.F) * 256u;                                                 \
+    /* (t, f) of row e by one division and 32-row steps (every F + 1 here is > 32) */                    \
+    const int qfirst_ = q0 - 1 + (tid >> 3);                                                             \
+    int tt_ = (qfirst_ < 0 ? 0 : qfirst_) / Fp, ff_ = qfirst_ - tt_ * Fp;    /* q = -1 -> (0, -1): padding */ \
+    _Pragma("unroll") for (int e = 0; e < NACT; ++e) {                                                   \
+        bool ok1 = false, ok0 = false;                                                                   \
+        off1[e] = qd * 16;                                                                               \
+        if ((VALID) && ff_ >= 0 && ff_ < a.F && tt_ < a.T) {                                             \
+            ok1 = true;                                                                                  \
+            off1[e] = (unsigned)(tt_ * a.F + ff_) * 256u + qd * 16;                                      \
+            if (NT == 2 && tt_ >= a.dil) ok0 = true;                                                     \
+        }                                                                                                \
+        if (!ok1) inv1 |= 1u << e;                                                                       \
+        if (!ok0) inv0 |= 1u << e;                                                                       \
+        ff_ += 32;                                                                                       \
+        if (ff_ >= Fp) { ff_ -= Fp; ++tt_; }                                                             \
+    }                                                                                                    \
+    const size_t clip_bytes = (size_t)a.T * a.F * 256;                                                   \
+    f32x4 acc[CB][NPB];               /* start from the bias: its load latency hides in the prologue */ \
+    _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) {                                                  \
+        const f32x4 bias_ = ldg4(a.bias + 16 * cb + 4 * g);                                              \
+        _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = bias_;                          \
+    }                                                                                                    \
+    const int nst = a.nslots * 2 * NT;                                                                   \
+    f32x4 pre[NACT];                                                                                     \
     f32x4 sc = splat4(1.f), sh = splat4(0.f), al = splat4(1.f);
-    bool tr = false;
 
+// issue stage S's activation loads into registers (consumed by CX_WRITE(S) one phase later):
+// uniform 64-bit base (slot, clip, channel half) + per-lane 32-bit offset, no 64-bit VALU math
 #define CX_PREFETCH(S)                                                                                   \
     do {                                                                                                 \
         const int chunk_ = (S) / NT, kt_ = (S) - chunk_ * NT;                                            \
         const int slot_ = chunk_ >> 1, half_ = chunk_ & 1;                                               \
-        const float* src_ = sel4(a.in, slot_) + half_ * 32 + qd * 4;                                                 \
+        const char* src_ = reinterpret_cast<const char*>(sel4(a.in, slot_)) + b * clip_bytes + half_ * 128; \
         _Pragma("unroll") for (int e = 0; e < NACT; ++e) {                                               \
-            const int ap_ = (NT == 2 && kt_ == 0) ? apos0[e] : apos1[e];                                 \
-            pre[e] = ldg4(src_ + (long)(ap_ >= 0 ? ap_ : 0) * 64);   /* unconditional; masked at write */ \
+            /* t - dil plane: same row dil*F positions earlier where it exists, else any in-bounds row */ \
+            const unsigned o_ = (NT == 2 && kt_ == 0) ? off1[e] - ((inv0 >> e) & 1u ? 0u : dFb) : off1[e]; \
+            pre[e] = *reinterpret_cast<const f32x4*>(src_ + o_);     /* unconditional; masked at write */ \
         }                                                                                                \
         const float* nsc_ = sel4(a.nscale, slot_);                                                       \
-        tr = nsc_ != nullptr;                                                                            \
-        if (tr) {                                                                                        \
+        if (nsc_ != nullptr) {                                                                           \
             sc = ldg4(nsc_ + b * 64 + half_ * 32 + qd * 4);                                              \
             sh = ldg4(sel4(a.nshift, slot_) + b * 64 + half_ * 32 + qd * 4);                             \
-            al = ldg4(sel4(a.nalpha, slot_) + half_ * 32 + qd * 4);                                      \
+            al = ldg4(sel4(a.nalpha, slot_) + half_ * 32 + qd * 4);   /* no arithmetic on loaded data here: \
+                                                                           it would wait for every load above */ \
+        } else {                                          /* un-normalised slot: identity (exact) */      \
+            sc = splat4(1.f); sh = splat4(0.f); al = splat4(1.f);                                        \
         }                                                                                                \
-        const u32x4* wsrc_ = reinterpret_cast<const u32x4*>(w16) + ((long)chunk_ * TAPS + kt_ * 3) * (CB * 128); \
-        _Pragma("unroll") for (int i = 0; i < NW; ++i) wpre[i] = wsrc_[tid + 256 * i];                   \
     } while (0)
+
+// normalise + PReLU + fp16 hi/lo split of the prefetched stage S, written to this tile's LDS buffers.
+// PReLU(y) = y + (alpha - 1) min(y, 0): one v_min + half a packed FMA per value.
+// (the stage's 24 KB weight image is L2-resident: its loads are issued at the top and land while
+// the activation VALU work runs, so they never occupy registers during the MFMA phase)
+#define CX_WRITE(S)                                                                                      \
+    do {                                                                                                 \
+        const int chunkw_ = (S) / NT, ktw_ = (S) - chunkw_ * NT;                                         \
+        const u32x4* wsrc_ = reinterpret_cast<const u32x4*>(w16) + ((long)chunkw_ * TAPS + ktw_ * 3) * (CB * 128); \
+        u32x4 wpre[NW];                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i) wpre[i] = wsrc_[tid + 256 * i];                   \
+        const unsigned inv_ = (NT == 2 && ktw_ == 0) ? inv0 : inv1;                                      \
+        const f32x4 am1 = al - splat4(1.f);                                                              \
+        _Pragma("unroll") for (int e = 0; e < NACT; ++e) {                                               \
+            {                                                                                            \
+                f32x4 v = pre[e];                                                                        \
+                v = v * sc + sh;                          /* branch-free: identity slots carry (1, 0, 0) */ \
+                f32x4 mn;                                                                                \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) mn[r] = fminf(v[r], 0.f);                  \
+                v = mn * am1 + v;                                                                        \
+                if (inv_ & (1u << e)) v = splat4(0.f);   /* zero padding (select, no branch) */          \
+                f16x4 hi, lo;                                                                            \
+                split4(v, hi, lo);                                                                       \
+                *reinterpret_cast<f16x4*>(wrow + 32 * e * CX_STRIDE) = hi;                               \
+                *reinterpret_cast<f16x4*>(wrow + 32 * e * CX_STRIDE + ACT) = lo;                         \
+            }                                                                                            \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                   \
+            *reinterpret_cast<u32x4*>(sm + 2 * ACT + (tid + 256 * i) * 8) = wpre[i];                     \
+    } while (0)
+
+// 3 taps x CB output blocks x NPB position blocks x 3 split products from this tile's LDS buffers
+#define CX_MFMA()                                                                                        \
+    do {                                                                                                 \
+        _Pragma("unroll") for (int kf = 0; kf < 3; ++kf) {                                               \
+            __builtin_amdgcn_sched_barrier(0);            /* no hoisting of the next tap's fragments: it  \
+                                                             only buys register spills (2 waves / SIMD) */ \
+            f16x8 bh[NPB], bl[NPB];                                                                      \
+            _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb) {                                         \
+                bh[tb] = *reinterpret_cast<const f16x8*>(brow + (16 * tb + kf) * CX_STRIDE);             \
+                bl[tb] = *reinterpret_cast<const f16x8*>(brow + (16 * tb + kf) * CX_STRIDE + ACT);       \
+            }                                                                                            \
+            _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) {                                          \
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(alane + ((kf * CB + cb) * 2 + 0) * 512); \
+                const f16x8 alo = *reinterpret_cast<const f16x8*>(alane + ((kf * CB + cb) * 2 + 1) * 512); \
+                _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = mfma32h(ah, bh[tb], acc[cb][tb]);  \
+                _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = mfma32h(ah, bl[tb], acc[cb][tb]);  \
+                _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = mfma32h(alo, bh[tb], acc[cb][tb]); \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+
+// bias, store, per-wave InstanceNorm partial sums into red[wv] (same contract as conv3_kernel)
+#define CX_EPILOGUE(VALID)                                                                               \
+    do {                                                                                                 \
+        bool ok[NPB];                                                                                    \
+        long obase[NPB];                                                                                 \
+        const int qe_ = q0 + 16 * NPB * wv + c;                                                          \
+        int t = qe_ / Fp, f = qe_ - t * Fp;                                                              \
+        _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb) {                                             \
+            if (tb > 0) { f += 16; if (f >= Fp) { f -= Fp; ++t; } }                                      \
+            ok[tb] = (VALID) && (t < a.T) && (f < a.F) && (16 * NPB * wv + 16 * tb + c < CX_TILE);       \
+            if (a.mode == 1) {                                                                           \
+                ok[tb] = ok[tb] && ((f & 1) == 0);                                                       \
+                const int F2 = (a.F + 1) >> 1;                                                           \
+                obase[tb] = ((long)(b * a.T + t) * F2 + (f >> 1)) * 64;                                  \
+            } else if (a.mode == 2) {                                                                    \
+                obase[tb] = ((long)(b * a.T + t) * (2 * a.F) + 2 * f) * 64;                              \
+            } else {                                                                                     \
+                obase[tb] = ((long)(b * a.T + t) * a.F + f) * 64;                                        \
+            }                                                                                            \
+        }                                                                                                \
+        _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) {                                              \
+            f32x4 s1 = splat4(0.f), s2 = splat4(0.f);                                                    \
+            _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb) {                                         \
+                const f32x4 v = acc[cb][tb];                                                             \
+                if (ok[tb]) {                                                                            \
+                    long off = obase[tb] + 16 * (cb & 3) + 4 * g;                                        \
+                    if (a.mode == 2) off += (cb >> 2) * 64;                                              \
+                    stg4(a.out + off, v);                                                                \
+                    s1 += v;                                                                             \
+                    s2 += v * v;                                                                         \
+                }                                                                                        \
+            }                                                                                            \
+            if (a.partials) {                                                                            \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                          \
+                    const float t1 = red_c_sum(s1[r]), t2 = red_c_sum(s2[r]);                            \
+                    if (c == 0) {                                                                        \
+                        red[wv][16 * cb + 4 * g + r][0] = t1;                                            \
+                        red[wv][16 * cb + 4 * g + r][1] = t2;                                            \
+                    }                                                                                    \
+                }                                                                                        \
+            }                                                                                            \
+        }                                                                                                \
+    } while (0)
+
+// XCD-aware block order: the dispatcher deals consecutive workgroups round-robin to the 8
+// XCDs (private L2 each).  Re-map so XCD x walks a CONTIGUOUS range of (clip, tile): the
+// rows a tile reads as its t-dil plane were read moments earlier as the t plane of a
+// neighbouring tile on the SAME XCD -> second read is an L2 hit, not a second HBM fetch.
+__device__ __forceinline__ int xcd_contiguous_block() {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int qn = nwg >> 3, rn = nwg & 7;
+    return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+}
+
+template <int NT, int COUT, int NPB>
+__global__ __launch_bounds__(256) void conv3x_kernel(ConvArgs a, const _Float16* __restrict__ w16) {
+    CX_DECLS
+    __shared__ __attribute__((aligned(16))) _Float16 sm[SMEM];
+    __shared__ float red[4][COUT][2];
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4, wv = tid >> 6;
+    const int logical = xcd_contiguous_block();
+    const int b = logical / a.ntiles, tile = logical - b * a.ntiles;
+    CX_SETUP(true)
 
     CX_PREFETCH(0);
 #pragma unroll 1
     for (int s = 0; s < nst; ++s) {
-        const int kt = s % NT;
         __syncthreads();                                  // stage s-1 fully consumed
-#pragma unroll
-        for (int e = 0; e < NACT; ++e) {
-            const int p = (tid >> 3) + 32 * e;
-            if (p < CX_ROWS) {
-                const int ap = (NT == 2 && kt == 0) ? apos0[e] : apos1[e];
-                f32x4 v = pre[e];
-                if (tr) v = norm_prelu4x(v, sc, sh, al);
-                if (ap < 0) v = splat4(0.f);              // zero padding (select, no branch)
-                f16x4 hi, lo;
-                split4(v, hi, lo);
-                *reinterpret_cast<f16x4*>(&act_h[p * CX_STRIDE + lds_col]) = hi;
-                *reinterpret_cast<f16x4*>(&act_l[p * CX_STRIDE + lds_col]) = lo;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NW; ++i) reinterpret_cast<u32x4*>(wl)[tid + 256 * i] = wpre[i];
+        CX_WRITE(s);
         __syncthreads();
         if (s + 1 < nst) CX_PREFETCH(s + 1);              // in flight during the MFMAs below
-
-#pragma unroll
-        for (int kf = 0; kf < 3; ++kf) {
-            f16x8 bh[NPB], bl[NPB];
-#pragma unroll
-            for (int tb = 0; tb < NPB; ++tb) {
-                const int row = 16 * NPB * wv + 16 * tb + c + kf;
-                bh[tb] = *reinterpret_cast<const f16x8*>(&act_h[row * CX_STRIDE + 8 * g]);
-                bl[tb] = *reinterpret_cast<const f16x8*>(&act_l[row * CX_STRIDE + 8 * g]);
-            }
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-                const f16x8 ah = *reinterpret_cast<const f16x8*>(&wl[((kf * CB + cb) * 2 + 0) * 512 + lane * 8]);
-                const f16x8 alo = *reinterpret_cast<const f16x8*>(&wl[((kf * CB + cb) * 2 + 1) * 512 + lane * 8]);
-#pragma unroll
-                for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = mfma32h(ah, bh[tb], acc[cb][tb]);
-#pragma unroll
-                for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = mfma32h(ah, bl[tb], acc[cb][tb]);
-#pragma unroll
-                for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = mfma32h(alo, bh[tb], acc[cb][tb]);
-            }
-        }
+        CX_MFMA();
     }
-
-    // ---- epilogue: bias, store, InstanceNorm partial sums (same contract as conv3_kernel) ----
-    bool ok[NPB];
-    long obase[NPB];
-#pragma unroll
-    for (int tb = 0; tb < NPB; ++tb) {
-        const int q = q0 + 16 * NPB * wv + 16 * tb + c;
-        const int t = q / Fp, f = q - t * Fp;
-        ok[tb] = (t < a.T) && (f < a.F);
-        if (a.mode == 1) {
-            ok[tb] = ok[tb] && ((f & 1) == 0);
-            const int F2 = (a.F + 1) >> 1;
-            obase[tb] = ((long)(b * a.T + t) * F2 + (f >> 1)) * 64;
-        } else if (a.mode == 2) {
-            obase[tb] = ((long)(b * a.T + t) * (2 * a.F) + 2 * f) * 64;
-        } else {
-            obase[tb] = ((long)(b * a.T + t) * a.F + f) * 64;
-        }
-    }
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-        const f32x4 bias = ldg4(a.bias + 16 * cb + 4 * g);
-        f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
-#pragma unroll
-        for (int tb = 0; tb < NPB; ++tb) {
-            const f32x4 v = acc[cb][tb] + bias;
-            if (ok[tb]) {
-                long off = obase[tb] + 16 * (cb & 3) + 4 * g;
-                if (a.mode == 2) off += (cb >> 2) * 64;
-                stg4(a.out + off, v);
-                s1 += v;
-                s2 += v * v;
-            }
-        }
-        if (a.partials) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float t1 = red_c_sum(s1[r]), t2 = red_c_sum(s2[r]);
-                if (c == 0) {
-                    red[wv][16 * cb + 4 * g + r][0] = t1;
-                    red[wv][16 * cb + 4 * g + r][1] = t2;
-                }
-            }
-        }
-    }
+    CX_EPILOGUE(true);
     if (a.partials) {
         __syncthreads();
         for (int i = tid; i < COUT * 2; i += 256) {
@@ -208,17 +254,75 @@ __global__ __launch_bounds__(256) void conv3x_kernel(ConvArgs a, const _Float16*
     }
 }
 
-// the dense / 1x3 convs use 256-position tiles; the 128-channel sub-pixel conv 128-position tiles
+// Ping-pong scheduler (see the note above).  Block = 512 threads; group grp = wave >> 2 owns tile
+// 2 * pair + grp of clip b.  Barrier schedule per stage s (B = block-wide s_barrier):
+//   group 0:  prefetch(s+1)  MFMA(s)        B   write(s+1)        B
+//   group 1:  write(s)       prefetch(s+1)  B   MFMA(s)           B
+// Each group only touches its own LDS buffers; inside a group, write(s+1) follows every wave's
+// MFMA(s) (first B) and precedes MFMA(s+1) (second B), so two barriers per stage suffice.
+template <int NT, int COUT, int NPB>
+__global__ __launch_bounds__(512) void conv3p_kernel(ConvArgs a, const _Float16* __restrict__ w16) {
+    CX_DECLS
+    __shared__ __attribute__((aligned(16))) _Float16 sm2[2][SMEM];
+    __shared__ float red2[2][4][COUT][2];
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+    const int tid = threadIdx.x & 255, lane = tid & 63, c = lane & 15, g = lane >> 4, wv = tid >> 6;
+    _Float16* const sm = sm2[grp];
+    float (*red)[COUT][2] = red2[grp];
+    const int npairs = (a.ntiles + 1) >> 1;
+    const int logical = xcd_contiguous_block();
+    const int b = logical / npairs, tile = 2 * (logical - b * npairs) + grp;
+    const bool valid = tile < a.ntiles;                  // odd tile count: the last pair's second half idles
+    CX_SETUP(valid)
+
+    CX_PREFETCH(0);
+    if (grp == 0) {
+        CX_WRITE(0);
+        __syncthreads();
+#pragma unroll 1
+        for (int s = 0; s < nst; ++s) {
+            if (s + 1 < nst) CX_PREFETCH(s + 1);
+            CX_MFMA();
+            __syncthreads();
+            if (s + 1 < nst) CX_WRITE(s + 1);
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+#pragma unroll 1
+        for (int s = 0; s < nst; ++s) {
+            CX_WRITE(s);
+            if (s + 1 < nst) CX_PREFETCH(s + 1);
+            __syncthreads();
+            CX_MFMA();
+            __syncthreads();
+        }
+    }
+    CX_EPILOGUE(valid);
+    if (a.partials) {
+        __syncthreads();
+        if (valid) {
+            for (int i = tid; i < COUT * 2; i += 256) {
+                const int co = i >> 1, wh = i & 1;
+                const float t = (red[0][co][wh] + red[1][co][wh]) + (red[2][co][wh] + red[3][co][wh]);
+                a.partials[(((long)b * a.ntiles + tile) * COUT + co) * 2 + wh] = t;
+            }
+        }
+    }
+}
+
+// the dense / 1x3 convs stage 256-row tiles (254 outputs); the 128-channel sub-pixel conv 128-row tiles (126 outputs)
 int conv3x_ntiles(int T, int F, int cout) {
-    const int tile = cout == 128 ? 128 : 256;
+    const int tile = (cout == 128 ? 128 : 256) - 2;
     return (T * (F + 1) + tile - 1) / tile;
 }
 
 void launch_conv3_x3(LaunchCtx ctx, const ConvArgs& a, const void* w16, int B, int time_taps, int cout) {
     dim3 grid(a.ntiles * B);                              // 1-D: see the XCD re-map in the kernel
+    dim3 pgrid(((a.ntiles + 1) / 2) * B);                 // ping-pong kernels: two tiles per block
     const _Float16* w = reinterpret_cast<const _Float16*>(w16);
     if (time_taps == 2 && cout == 64)
-        LAUNCH(ctx, "conv_dense", (conv3x_kernel<2, 64, 4><<<grid, 256, 0, ctx.stream>>>(a, w)));
+        LAUNCH(ctx, "conv_dense", (conv3p_kernel<2, 64, 4><<<pgrid, 512, 0, ctx.stream>>>(a, w)));
     else if (time_taps == 1 && cout == 64)
         LAUNCH(ctx, "conv_1x3", (conv3x_kernel<1, 64, 4><<<grid, 256, 0, ctx.stream>>>(a, w)));
     else
