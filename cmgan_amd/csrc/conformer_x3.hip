@@ -237,6 +237,8 @@ __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x
 
 struct AttState {
     float m, run, l;      // reference level, running max relative to it, denominator (relative to m)
+    f32x4 nm;             // splat(-m), kept as a register tuple: it is the C operand of every rel-pos MFMA
+                          // (re-materialising the splat cost 4 VALU per MFMA pair)
     f32x4 o;
 };
 
@@ -293,6 +295,7 @@ __device__ __forceinline__ void att_softmax(f32x4 (&s)[4], int c, int g, int j0,
         st.l *= alpha;
         st.o = st.o * splat4(alpha);
         st.m += run;
+        st.nm = splat4(-st.m);
         st.run = 0.f;
     } else {
 #pragma unroll
@@ -363,15 +366,13 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
 #pragma unroll
         for (int we = 0; we < 6; ++we) {
             if (we < 5 && (FULL || we >= 4 - nb)) {       // cb = we for block A
-                f32x4 rt = splat4(-sa.m);
-                rt = mfma32h(ef[we], qA1, rt);
+                f32x4 rt = mfma32h(ef[we], qA1, sa.nm);
                 rt = mfma32h(ef[we], qA2, rt);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a.RA[(16 * we + 4 * g + r) * RSTRIDE_X + c] = rt[r];
             }
             if (we >= 1 && (FULL || we - 1 >= 4 - nb)) {  // cb = we - 1 for block B
-                f32x4 rt = splat4(-sb.m);
-                rt = mfma32h(ef[we], qB1, rt);
+                f32x4 rt = mfma32h(ef[we], qB1, sb.nm);
                 rt = mfma32h(ef[we], qB2, rt);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a.RB[(16 * (we - 1) + 4 * g + r) * RSTRIDE_X + c] = rt[r];
@@ -422,7 +423,8 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
 __global__ __launch_bounds__(256, 2) void attn_x3_kernel(QkvOut io, const _Float16* __restrict__ eimg, int max_pos,
                                                          float* __restrict__ o, int L, int Lb, int Lb2, int nqg,
                                                          long total) {
-    __shared__ float rbuf[4][2][80 * RSTRIDE_X];
+    __shared__ float rbuf[4][2][80 * RSTRIDE_X + 4];   // +4: keeps RA/RB 1604 dwords apart, which no ds_read2* form can span, so each skew read
+                                                       // lands directly in its accumulator register (paired A/B reads cost a v_mov per value)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long item = (long)blockIdx.x * 4 + wv;
     if (item >= total) return;                            // no block-level synchronisation below
@@ -440,7 +442,9 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(QkvOut io, const _Float
 
     AttState st[ATT_NQ];
 #pragma unroll
-    for (int i = 0; i < ATT_NQ; ++i) { st[i].m = 0.f; st[i].run = -INFINITY; st[i].l = 0.f; st[i].o = splat4(0.f); }
+    for (int i = 0; i < ATT_NQ; ++i) {
+        st[i].m = 0.f; st[i].run = -INFINITY; st[i].l = 0.f; st[i].nm = splat4(0.f); st[i].o = splat4(0.f);
+    }
 
     const int nfull = L >> 6;
 #pragma unroll 1

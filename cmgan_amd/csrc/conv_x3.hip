@@ -30,18 +30,14 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
 }
 
 // ---------------------------------------------------------------------------------
-// The kernel body is written once as macros over a fixed set of local names and used by two
-// schedulers:
-//   conv3x_kernel  - 4 waves, one tile, stage-write -> barrier -> MFMA -> barrier
-//   conv3p_kernel  - 8 waves = two groups of 4 (waves w and w+4 share a SIMD), each group owns
-//                    a tile and its own LDS buffers, and the block-wide barriers hold the two
-//                    groups in ANTI-PHASE: while group 0 runs the MFMAs of stage s, group 1
-//                    normalises / splits / writes its stage s, and vice versa.
-// Why: with independent 4-wave blocks the two waves that share a SIMD start together and stay
-// phase-locked (both in the MFMA phase, then both in the VALU staging phase), so MFMA time and
-// VALU time ADD - measured by compile-time ablation: removing the MFMAs saved 2.5 ms of 7.25,
-// removing the staging VALU 1.6 ms, i.e. exactly their stand-alone costs.  In anti-phase the
-// SIMD's matrix pipe and VALU work on different waves at the same time.
+// The kernel body is written as macros over a fixed set of local names (setup / prefetch /
+// write / MFMA / epilogue) so that alternative schedules can reuse it.  Measured alternatives
+// (DESIGN.md section 7): an 8-wave "ping-pong" block whose two 4-wave groups are held in
+// anti-phase by the barriers (one group's MFMAs over the other's staging VALU) was 9% SLOWER than
+// two independent 4-wave blocks per CU: on this machine a wave's VALU instructions take issue
+// slots from the MFMA stream of the wave it shares a SIMD with, so MFMA time and VALU time add
+// whichever way they are interleaved, and the forced rendezvous only adds barrier idle time.
+// What pays is removing instructions: see CX_WRITE.
 // ---------------------------------------------------------------------------------
 #define CX_DECLS                                                                                         \
     constexpr int CX_ROWS = 64 * NPB;                         /* staged rows = MFMA positions (4 waves x NPB x 16) */ \
@@ -254,63 +250,6 @@ __global__ __launch_bounds__(256) void conv3x_kernel(ConvArgs a, const _Float16*
     }
 }
 
-// Ping-pong scheduler (see the note above).  Block = 512 threads; group grp = wave >> 2 owns tile
-// 2 * pair + grp of clip b.  Barrier schedule per stage s (B = block-wide s_barrier):
-//   group 0:  prefetch(s+1)  MFMA(s)        B   write(s+1)        B
-//   group 1:  write(s)       prefetch(s+1)  B   MFMA(s)           B
-// Each group only touches its own LDS buffers; inside a group, write(s+1) follows every wave's
-// MFMA(s) (first B) and precedes MFMA(s+1) (second B), so two barriers per stage suffice.
-template <int NT, int COUT, int NPB>
-__global__ __launch_bounds__(512) void conv3p_kernel(ConvArgs a, const _Float16* __restrict__ w16) {
-    CX_DECLS
-    __shared__ __attribute__((aligned(16))) _Float16 sm2[2][SMEM];
-    __shared__ float red2[2][4][COUT][2];
-    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
-    const int tid = threadIdx.x & 255, lane = tid & 63, c = lane & 15, g = lane >> 4, wv = tid >> 6;
-    _Float16* const sm = sm2[grp];
-    float (*red)[COUT][2] = red2[grp];
-    const int npairs = (a.ntiles + 1) >> 1;
-    const int logical = xcd_contiguous_block();
-    const int b = logical / npairs, tile = 2 * (logical - b * npairs) + grp;
-    const bool valid = tile < a.ntiles;                  // odd tile count: the last pair's second half idles
-    CX_SETUP(valid)
-
-    CX_PREFETCH(0);
-    if (grp == 0) {
-        CX_WRITE(0);
-        __syncthreads();
-#pragma unroll 1
-        for (int s = 0; s < nst; ++s) {
-            if (s + 1 < nst) CX_PREFETCH(s + 1);
-            CX_MFMA();
-            __syncthreads();
-            if (s + 1 < nst) CX_WRITE(s + 1);
-            __syncthreads();
-        }
-    } else {
-        __syncthreads();
-#pragma unroll 1
-        for (int s = 0; s < nst; ++s) {
-            CX_WRITE(s);
-            if (s + 1 < nst) CX_PREFETCH(s + 1);
-            __syncthreads();
-            CX_MFMA();
-            __syncthreads();
-        }
-    }
-    CX_EPILOGUE(valid);
-    if (a.partials) {
-        __syncthreads();
-        if (valid) {
-            for (int i = tid; i < COUT * 2; i += 256) {
-                const int co = i >> 1, wh = i & 1;
-                const float t = (red[0][co][wh] + red[1][co][wh]) + (red[2][co][wh] + red[3][co][wh]);
-                a.partials[(((long)b * a.ntiles + tile) * COUT + co) * 2 + wh] = t;
-            }
-        }
-    }
-}
-
 // the dense / 1x3 convs stage 256-row tiles (254 outputs); the 128-channel sub-pixel conv 128-row tiles (126 outputs)
 int conv3x_ntiles(int T, int F, int cout) {
     const int tile = (cout == 128 ? 128 : 256) - 2;
@@ -319,10 +258,9 @@ int conv3x_ntiles(int T, int F, int cout) {
 
 void launch_conv3_x3(LaunchCtx ctx, const ConvArgs& a, const void* w16, int B, int time_taps, int cout) {
     dim3 grid(a.ntiles * B);                              // 1-D: see the XCD re-map in the kernel
-    dim3 pgrid(((a.ntiles + 1) / 2) * B);                 // ping-pong kernels: two tiles per block
     const _Float16* w = reinterpret_cast<const _Float16*>(w16);
     if (time_taps == 2 && cout == 64)
-        LAUNCH(ctx, "conv_dense", (conv3p_kernel<2, 64, 4><<<pgrid, 512, 0, ctx.stream>>>(a, w)));
+        LAUNCH(ctx, "conv_dense", (conv3x_kernel<2, 64, 4><<<grid, 256, 0, ctx.stream>>>(a, w)));
     else if (time_taps == 1 && cout == 64)
         LAUNCH(ctx, "conv_1x3", (conv3x_kernel<1, 64, 4><<<grid, 256, 0, ctx.stream>>>(a, w)));
     else
