@@ -10,7 +10,9 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libcmgan_hip.so")
+# CMGAN_HIP_LIB selects an alternative BUILD of the same HIP library (cmgan_amd.build variants, used for
+# same-session A/B timing); it is never a fallback: a missing file is a hard error either way.
+LIB_PATH = os.environ.get("CMGAN_HIP_LIB") or os.path.join(HERE, "lib", "libcmgan_hip.so")
 
 OK = 0
 ABI_VERSION = 2

@@ -19,8 +19,14 @@ LIB = os.path.join(LIBDIR, "libcmgan_hip.so")
 SOURCES = ["api.hip", "conformer.hip", "conformer_x3.hip", "conv.hip", "conv_x3.hip", "stft.hip"]
 HEADERS = ["common.hip.h", "kernels.h", "weights.h", os.path.join("..", "..", "include", "cmgan_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -packed-fp32-ops: v_pk_{fma,mul,add}_f32 issue slower than the scalar pair they replace when the SIMD is
+# also feeding MFMAs (measured: the whole step is 0.6% faster without them, dwpw2 with hand-packed FMAs
+# was 18% slower), so the SLP vectoriser is told the target has none.  The flag is a device feature; the
+# host pass of hipcc prints one "not a recognized feature" line per file for it, filtered below.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
-         "-Wno-unused-result", "-Wno-unused-value"]
+         "-Wno-unused-result", "-Wno-unused-value",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+_NOISE = "is not a recognized feature for this target"
 
 
 def _digest() -> str:
@@ -32,31 +38,42 @@ def _digest() -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    os.makedirs(LIBDIR, exist_ok=True)
-    stamp = os.path.join(LIBDIR, "libcmgan_hip.stamp")
-    digest = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == digest:
-        return LIB
+def build(force: bool = False, verbose: bool = True, variant: str | None = None, extra_flags=()) -> str:
+    """Build the library.  `variant` builds a side-by-side copy under lib/variants/<name>/ (with
+    `extra_flags`), which `CMGAN_HIP_LIB=<path>` selects at load time: A/B timing of two builds inside
+    ONE GPU session is the only comparison that is not swamped by box-to-box clock differences."""
+    libdir = LIBDIR if variant is None else os.path.join(LIBDIR, "variants", variant)
+    lib = os.path.join(libdir, "libcmgan_hip.so")
+    flags = [*FLAGS, *extra_flags]
+    os.makedirs(libdir, exist_ok=True)
+    stamp = os.path.join(libdir, "libcmgan_hip.stamp")
+    digest = _digest() + "|" + " ".join(extra_flags)
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return lib
     objs = []
 
     def compile_one(src):
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(libdir, src.replace(".hip", ".o"))
+        cmd = [HIPCC, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        err = "\n".join(l for l in r.stderr.splitlines() if _NOISE not in l)
+        if err.strip():
+            print(err, file=sys.stderr, flush=True)
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     with open(stamp, "w") as f:
         f.write(digest)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define CMGAN_EPS 1e-5f
 
@@ -56,6 +57,15 @@ __device__ __forceinline__ float red_g_max(float v) {
     return fmaxf(a, b);
 }
 // reduce over the 16 lanes of one lane group (same g, c = 0..15)
+// acc (2 x f32) += w (2 x f32) * broadcast(u.lo) / broadcast(u.hi): packed FMA with the scalar operand
+// selected by op_sel from either half of a register pair
+__device__ __forceinline__ void pk_fma_lo(f32x2& acc, f32x2 w, f32x2 u) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "v"(u));
+}
+__device__ __forceinline__ void pk_fma_hi(f32x2& acc, f32x2 w, f32x2 u) {
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "v"(u));
+}
+
 // sum over the 16 lanes that share lane>>4 (one DPP row): four DPP adds (quad swaps, then the
 // half-row and row mirrors), no LDS permute traffic.  (As __shfl_xor this was 4 ds_bpermute
 // round trips per value: 128 of them made the dense-conv epilogue cost 14k cycles per tile.)

@@ -251,8 +251,11 @@ __global__ __launch_bounds__(256) void conv3x_kernel(ConvArgs a, const _Float16*
 }
 
 // the dense / 1x3 convs stage 256-row tiles (254 outputs); the 128-channel sub-pixel conv 128-row tiles (126 outputs)
+#ifndef CX_NPB64
+#define CX_NPB64 4            // position blocks per wave of the 64-channel kernels (tile = 64 * NPB rows)
+#endif
 int conv3x_ntiles(int T, int F, int cout) {
-    const int tile = (cout == 128 ? 128 : 256) - 2;
+    const int tile = (cout == 128 ? 128 : 64 * CX_NPB64) - 2;
     return (T * (F + 1) + tile - 1) / tile;
 }
 
@@ -260,9 +263,9 @@ void launch_conv3_x3(LaunchCtx ctx, const ConvArgs& a, const void* w16, int B, i
     dim3 grid(a.ntiles * B);                              // 1-D: see the XCD re-map in the kernel
     const _Float16* w = reinterpret_cast<const _Float16*>(w16);
     if (time_taps == 2 && cout == 64)
-        LAUNCH(ctx, "conv_dense", (conv3x_kernel<2, 64, 4><<<grid, 256, 0, ctx.stream>>>(a, w)));
+        LAUNCH(ctx, "conv_dense", (conv3x_kernel<2, 64, CX_NPB64><<<grid, 256, 0, ctx.stream>>>(a, w)));
     else if (time_taps == 1 && cout == 64)
-        LAUNCH(ctx, "conv_1x3", (conv3x_kernel<1, 64, 4><<<grid, 256, 0, ctx.stream>>>(a, w)));
+        LAUNCH(ctx, "conv_1x3", (conv3x_kernel<1, 64, CX_NPB64><<<grid, 256, 0, ctx.stream>>>(a, w)));
     else
         LAUNCH(ctx, "conv_subpixel", (conv3x_kernel<1, 128, 2><<<grid, 256, 0, ctx.stream>>>(a, w)));
 }
