@@ -198,6 +198,20 @@ def main():
                 "avg_launch_ms": round(kern[dom]["ms_per_step"] / max(1, kern[dom]["launches_per_step"]), 4),
                 "note": ("algorithmic FLOPs; the f16x3 mode issues 3 MFMA products per algorithmic product, so the "
                          "matrix pipe is doing 3x this" if x3 else "exact fp32 MFMA")}
+        # HBM bytes per launch from the committed PMC passes of this same command (profiles/README.md);
+        # the counters cannot be read from inside the process, so this is the one field not measured live
+        tsrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                            "r01_x3_hbm_traffic.json" if x3 else "r01_fp32_hbm_traffic.json")
+        pmc_traffic = {}
+        if os.path.exists(tsrc):
+            with open(tsrc) as f:
+                pmc_traffic = json.load(f).get("per_launch", {})
+        if dom in pmc_traffic and BATCH_PER_GPU == 32:
+            roof["traffic"] = pmc_traffic[dom]["hbm_bytes"]
+            roof["traffic_note"] = ("HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, "
+                                    "from profiles/" + os.path.basename(tsrc))
+            roof["algorithmic_hbm_bytes_per_launch"] = round(
+                hbm_bytes_per_clip().get(dom, 0) * BATCH_PER_GPU / max(1, kern[dom]["launches_per_step"]))
         hb = hbm_bytes_per_clip()
         extra = {}
         if dom in hb:

@@ -89,6 +89,11 @@ __device__ __forceinline__ float sigmoidf_fast(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 __device__ __forceinline__ float swishf(float x) { return x * sigmoidf_fast(x); }
+// FeedForward activation on the pre-scaled hidden value h' = -log2(e) h (weights.h, CF_FF1_W1):
+// Swish(h) = -ln2 * h' / (1 + 2^h'); the -ln2 lives in the second Linear.
+__device__ __forceinline__ float swish_scaled(float hp) {
+    return hp * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(hp));
+}
 
 // orders a wave's LDS writes before its later LDS reads (cross-lane, same wave)
 __device__ __forceinline__ void wave_lds_fence() {

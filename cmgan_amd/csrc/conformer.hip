@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void ffn_kernel(const float* xin, float* xout,
 #pragma unroll
             for (int tb = 0; tb < NTB; ++tb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h[tb][hb][r] = swishf(acc[tb][r]);
+                for (int r = 0; r < 4; ++r) h[tb][hb][r] = swish_scaled(acc[tb][r]);
         }
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {

@@ -12,7 +12,7 @@
 #define XNTB 2
 #define XWAVES 8
 
-__device__ __forceinline__ float swish_x(float x) { return swishf(x); }
+__device__ __forceinline__ float swish_x(float hp) { return swish_scaled(hp); }
 
 // LN'd input rows -> B operands (hi/lo) for K = 64 (two k32 blocks)
 __device__ __forceinline__ void ln_split(const f32x4 (&x)[4], f16x8 (&bh)[2], f16x8 (&bl)[2]) {

@@ -66,9 +66,9 @@ enum {
 };
 // conformer items                                                        conformer.py:75-222
 enum {
-    CF_FF1_W1 = 0,    // fm [16][4]   Linear(64,256) with the PreNorm LayerNorm affine folded in
-    CF_FF1_B1 = 1,    // [256]        b1 + W1 @ beta
-    CF_FF1_W2 = 2,    // fm [4][16]   0.5 * Linear(256,64)   (Scale(0.5), conformer.py:211)
+    CF_FF1_W1 = 0,    // fm [16][4]   -log2(e) * Linear(64,256) with the PreNorm LayerNorm affine folded in
+    CF_FF1_B1 = 1,    // [256]        -log2(e) * (b1 + W1 @ beta)      (Swish evaluated on h' = -log2(e) h)
+    CF_FF1_W2 = 2,    // fm [4][16]   -ln2 * 0.5 * Linear(256,64)   (Scale(0.5), conformer.py:211)
     CF_FF1_B2 = 3,    // [64]         0.5 * b2
     CF_QKV_W = 4,     // fm [12][4]   rows 0..63 = 0.25*log2(e)*to_q, 64..191 = to_kv; attn LayerNorm folded
     CF_QKV_B = 5,     // [192]        W @ beta (the reference has no bias; this is the folded LN shift)

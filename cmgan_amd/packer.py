@@ -8,6 +8,7 @@ in float64, then rounded to fp32:
 * LayerNorm affine of every PreNorm folded into the following Linear / pointwise conv
   (``W' = W diag(gamma)``, ``b' = b + W beta``)           conformer.py:54-72,161-163
 * ``Scale(0.5)`` folded into the second FeedForward Linear   conformer.py:211-212
+* FeedForward Swish evaluated on ``h' = -log2(e) h``: first Linear scaled by -log2(e), second by -ln 2
 * attention ``scale = dim_head**-0.5`` folded into ``to_q``  conformer.py:80,103,110
   together with log2(e), so the kernels' softmax is a bare exp2
 * eval-mode ``BatchNorm1d`` folded into the depthwise conv    conformer.py:165-168
@@ -98,9 +99,14 @@ def _conformer(sd, p, group, out, heads=4, dim_head=16):
                                      ("ff2", (CF_FF2_W1, CF_FF2_B1, CF_FF2_W2, CF_FF2_B2))):
         g, bt = _np(sd[f"{pre}{ff}.fn.norm.weight"]), _np(sd[f"{pre}{ff}.fn.norm.bias"])
         w1, b1 = _fold_ln(_np(sd[f"{pre}{ff}.fn.fn.net.0.weight"]), _np(sd[f"{pre}{ff}.fn.fn.net.0.bias"]), g, bt)
-        out[wid(group, iw1)] = fm(w1)
-        out[wid(group, ib1)] = b1
-        out[wid(group, iw2)] = fm(0.5 * _np(sd[f"{pre}{ff}.fn.fn.net.3.weight"]))
+        # Swish(h) = h / (1 + e^-h) = -ln2 * h' / (1 + 2^h') with h' = -log2(e) * h: the first Linear is
+        # stored pre-multiplied by -log2(e) and the second by -ln2, so the kernel's activation is
+        # h' * rcp(1 + exp2(h')) - one multiply per hidden value fewer (conformer.py:25-27,141-147)
+        k1 = np.float32(-np.log2(np.e))
+        k2 = np.float32(-np.log(2.0) * 0.5)
+        out[wid(group, iw1)] = fm(k1 * w1)
+        out[wid(group, ib1)] = k1 * b1
+        out[wid(group, iw2)] = fm(k2 * _np(sd[f"{pre}{ff}.fn.fn.net.3.weight"]))
         out[wid(group, ib2)] = 0.5 * _np(sd[f"{pre}{ff}.fn.fn.net.3.bias"])
     scale = dim_head ** -0.5 * np.log2(np.e)      # attention scale, and scores in log2 units (kernels use exp2)
     wq = scale * _np(sd[f"{pre}attn.fn.to_q.weight"])

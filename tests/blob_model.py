@@ -71,8 +71,8 @@ class BlobModel:
         iw1, ib1, iw2, ib2 = ((P.CF_FF1_W1, P.CF_FF1_B1, P.CF_FF1_W2, P.CF_FF1_B2) if first else
                               (P.CF_FF2_W1, P.CF_FF2_B1, P.CF_FF2_W2, P.CF_FF2_B2))
         w1, w2 = unfm(self.g(grp, iw1), 256, 64), unfm(self.g(grp, iw2), 64, 256)
-        h = _swish(_xhat(x) @ w1.t() + self.g(grp, ib1))
-        return x + h @ w2.t() + self.g(grp, ib2)
+        hp = _xhat(x) @ w1.t() + self.g(grp, ib1)        # h' = -log2(e) h  (scale folded by the packer)
+        return x + (hp / (1.0 + torch.exp2(hp))) @ w2.t() + self.g(grp, ib2)
 
     def attn(self, grp, x):
         n = x.shape[1]

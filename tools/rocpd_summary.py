@@ -3,6 +3,7 @@
 
     python tools/rocpd_summary.py trace <trace_results.db>            # = --kernel-trace --stats
     python tools/rocpd_summary.py pmc   <pmc_results.db> [...]        # one DB per --pmc pass
+    python tools/rocpd_summary.py traffic <FETCH_SIZE db> <WRITE_SIZE db>   # JSON: HBM bytes per launch per kernel label
 
 PMC values are summed over the per-XCD/SE instances rocprofv3 reports and averaged per launch.
 FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 definition); on gfx950 FETCH_SIZE under-reports wide
@@ -69,10 +70,48 @@ def pmc(dbs):
         print(line)
 
 
+# mangled-name fragment -> the label bench.py's profiler uses for that kernel
+LABELS = [("conv3x_kernelILi2ELi64", "conv_dense"), ("conv3x_kernelILi1ELi128", "conv_subpixel"),
+          ("conv3x_kernelILi1ELi64", "conv_1x3"), ("conv3_kernelILi2ELi64", "conv_dense"),
+          ("conv3_kernelILi1ELi128", "conv_subpixel"), ("conv3_kernelILi1ELi64", "conv_1x3"),
+          ("attn_x3_kernel", "attn"), ("attn_kernel", "attn"), ("dwpw2_x3_kernel", "dwpw2"),
+          ("ffn_x3_kernelILb1", "ffn_post"), ("ffn_x3_kernelILb0", "ffn"), ("ffn_kernelILb1", "ffn_post"),
+          ("ffn_kernelILb0", "ffn"), ("qkv_x3_kernel", "qkv"), ("qkv_kernel", "qkv"),
+          ("pw1glu_x3_kernel", "pw1glu"), ("pw1glu_kernel", "pw1glu"), ("outproj_x3_kernel", "outproj"),
+          ("outproj_kernel", "outproj"), ("dwconv_kernel", "dwconv"), ("pw2_kernel", "pw2"),
+          ("stft_compress_kernel", "stft_compress"), ("uncompress_irfft_kernel", "uncompress_irfft"),
+          ("tail_proj_kernel", "tail_proj")]
+
+
+def traffic(fetch_db, write_db):
+    """HBM bytes per launch (FETCH_SIZE with the gfx950 2x correction for 16 B/lane reads + WRITE_SIZE)."""
+    import json
+    out = {}
+    for db, cname, scale in ((fetch_db, "FETCH_SIZE", 2.0), (write_db, "WRITE_SIZE", 1.0)):
+        cur = sqlite3.connect(db).cursor()
+        acc = defaultdict(lambda: [0.0, set()])
+        q = "select kernel_name, dispatch_id, value from counters_collection where counter_name = ?"
+        for kname, disp, val in cur.execute(q, (cname,)):
+            label = next((lab for frag, lab in LABELS if frag in kname), None)
+            if label:
+                acc[label][0] += float(val)
+                acc[label][1].add(disp)
+        for label, (tot, disps) in acc.items():
+            e = out.setdefault(label, {"launches": len(disps)})
+            e["fetch_bytes" if cname == "FETCH_SIZE" else "write_bytes"] = round(scale * tot * 1024 / len(disps))
+    for e in out.values():
+        e["hbm_bytes"] = e.get("fetch_bytes", 0) + e.get("write_bytes", 0)
+    print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, "
+                                "FETCH x2 per MI355X_MICROARCH.md (gfx950 under-reports 16 B/lane reads)",
+                      "per_launch": out}, indent=1))
+
+
 if __name__ == "__main__":
     if len(sys.argv) < 3:
         sys.exit(__doc__)
     if sys.argv[1] == "trace":
         trace(sys.argv[2])
+    elif sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2:])
