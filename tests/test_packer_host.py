@@ -103,3 +103,34 @@ def test_engine_fails_loudly_without_gpu():
     from cmgan_amd import TSCNet
     with pytest.raises(RuntimeError, match="needs a ROCm GPU"):
         TSCNet(64, 201)
+
+
+def test_no_kernel_uses_scratch_memory():
+    """A single kernel with a private (scratch) segment slows EVERY kernel on the queue by ~2 % on
+    MI355X (measured with a 12-byte spill in one conformer kernel), besides the spill's own cost:
+    compile each source to gfx950 assembly and require .private_segment_fixed_size == 0 everywhere."""
+    import re
+    import subprocess
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from cmgan_amd import build as B
+
+    kernels_seen = [0]
+
+    def check(src):
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "k.s")
+            cmd = [B.HIPCC, *[f for f in B.FLAGS if f != "-fPIC"], "-S", "--cuda-device-only",
+                   os.path.join(B.CSRC, src), "-o", out]
+            subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+            text = open(out).read()
+        names = re.findall(r"\.amdhsa_kernel\s+(\S+)", text)
+        sizes = [int(v) for v in re.findall(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", text)]
+        assert len(names) == len(sizes)
+        kernels_seen[0] += len(names)
+        return [(src, n, s) for n, s in zip(names, sizes) if s != 0]
+
+    with ThreadPoolExecutor(max_workers=len(B.SOURCES)) as ex:
+        bad = [b for res in ex.map(check, B.SOURCES) for b in res]
+    assert not bad, f"kernels with scratch: {bad}"
+    assert kernels_seen[0] >= 30            # the check really saw the library's kernels
