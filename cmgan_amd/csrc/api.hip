@@ -24,6 +24,7 @@ struct cmgan_handle {
     std::string err;
     // tables
     float* d_tables = nullptr;
+    void* d_fold = nullptr;               // folded-DFT fp16 hi/lo images (x3 mode, n_fft 400)
     SpectralTables st{};
     // weights
     float* d_weights = nullptr;
@@ -83,6 +84,34 @@ static void pack_fm(const std::vector<double>& M, int R, int K, float* out) {
                 }
 }
 
+static void split_h(float v, _Float16& hi, _Float16& lo);
+
+// Folded forward DFT images for stft_fold_x3_kernel (see kernels.h).  k-slot of lane group g, slot e in
+// k32 block m is sample n = 32 m + 8 g + e; columns are the 16 bins of block bb.
+static void build_fold_fwd(int N, int F, const std::vector<double>& win, std::vector<_Float16>& img) {
+    const int FB = (F + 15) / 16, H = N / 2, M32 = (H + 1 + 31) / 32;
+    const double PI2 = 6.283185307179586476925286766559;
+    img.assign((size_t)FB * 2 * M32 * 1024, (_Float16)0.f);
+    for (int bb = 0; bb < FB; ++bb)
+        for (int cs = 0; cs < 2; ++cs)
+            for (int m = 0; m < M32; ++m)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int k = 16 * bb + (lane & 15), n = 32 * m + 8 * (lane >> 4) + e;
+                        double v = 0.0;
+                        if (k < F && n <= H) {
+                            const long mm = ((long)k * n) % N;
+                            if (cs == 0) v = win[n] * cos(PI2 * mm / N);
+                            else if (n >= 1 && n < H) v = -win[n] * sin(PI2 * mm / N);
+                        }
+                        _Float16 hi, lo;
+                        split_h((float)v, hi, lo);
+                        const size_t o = (((size_t)bb * 2 + cs) * M32 + m) * 1024 + lane * 8 + e;
+                        img[o] = hi;
+                        img[o + 512] = lo;
+                    }
+}
+
 extern "C" int cmgan_create(cmgan_handle** out, const cmgan_config* cfg) {
     if (!out || !cfg) return fail(nullptr, CMGAN_E_BADARG, "cmgan_create: null argument");
     *out = nullptr;
@@ -137,6 +166,21 @@ extern "C" int cmgan_create(cmgan_handle** out, const cmgan_config* cfg) {
     }
     h->st.n_fft = N; h->st.hop = cfg->hop; h->st.F = F; h->st.FB = FB;
     h->st.fwd_fm = h->d_tables; h->st.inv_fm = h->d_tables + n_fwd; h->st.window = h->d_tables + n_fwd + n_inv;
+    h->st.fold_fwd16 = nullptr; h->st.fold_inv16 = nullptr;
+    if (cfg->mfma_mode == CMGAN_MFMA_F16X3 && N == 400 && cfg->hop == 100) {
+        std::vector<_Float16> img;
+        build_fold_fwd(N, F, win, img);
+        e = hipMalloc(&h->d_fold, img.size() * sizeof(_Float16));
+        if (e == hipSuccess) e = hipMemcpy(h->d_fold, img.data(), img.size() * sizeof(_Float16), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            fail(nullptr, CMGAN_E_HIP, "folded DFT upload: %s", hipGetErrorString(e));
+            hipFree(h->d_tables);
+            if (h->d_fold) hipFree(h->d_fold);
+            delete h;
+            return CMGAN_E_HIP;
+        }
+        h->st.fold_fwd16 = h->d_fold;
+    }
     *out = h;
     return CMGAN_OK;
 }
@@ -144,6 +188,7 @@ extern "C" int cmgan_create(cmgan_handle** out, const cmgan_config* cfg) {
 extern "C" void cmgan_destroy(cmgan_handle* h) {
     if (!h) return;
     if (h->d_tables) hipFree(h->d_tables);
+    if (h->d_fold) hipFree(h->d_fold);
     if (h->d_weights) hipFree(h->d_weights);
     if (h->d_w16) hipFree(h->d_w16);
     for (auto ev : h->prof.pool) hipEventDestroy(ev);

@@ -43,6 +43,13 @@ struct SpectralTables {
     const float* fwd_fm;            // fm [2*FB][n_fft/16][64][4]: rows = re bins | im bins, window folded
     const float* inv_fm;            // fm [n_fft/16][2*FB][64][4]: rows = output sample n, cols = re|im bins, window/N folded
     const float* window;            // [n_fft]
+    // F16X3 mode, n_fft = 400 / hop = 100 only (else null): forward real DFT folded about n = N/2
+    // (u_c[n] = x[n] + x[N-n], u_s[n] = x[n] - x[N-n]; the symmetric window lives in the matrix), as
+    // B-operand images [FB][cos | -sin][7 k32 blocks][hi | lo][64 lanes][8 halfs]   (stft.hip)
+    const void* fold_fwd16;
+    // inverse counterpart: [13 sample blocks of 16 (n = 0..207)][cos | sin][7 k32 blocks][hi | lo][64][8],
+    // Hermitian weights and 1/N folded in, window applied in the epilogue
+    const void* fold_inv16;
 };
 void launch_rms_scale(LaunchCtx, const float* wav, int B, int L, float* scale);
 void launch_stft_compress(LaunchCtx, const SpectralTables&, const float* wav, const float* scale,

@@ -10,6 +10,16 @@
 // the inverse DFT matrix) followed by a small overlap-add / envelope / un-scale kernel.
 #include "kernels.h"
 
+// m2^p for the power-law (de)compression: 2^(p log2 m2) on the transcendental unit (v_log_f32 / v_exp_f32,
+// relative error ~1e-7 |log2 m2|) instead of libm powf (~60 instructions; 52 of them per lane used to be most
+// of the STFT kernel).  v_log_f32 flushes denormal inputs, so the argument is pre-scaled by 2^60 (exact) and
+// the 60 subtracted again: branch-free and correct down to the smallest denormal; m2 = 0 -> 0.
+__device__ __forceinline__ float pow_pos(float m2, float p) {
+    const float l2 = __builtin_amdgcn_logf(m2 * 1152921504606846976.0f) - 60.0f;
+    const float r = __builtin_amdgcn_exp2f(p * l2);
+    return m2 > 0.f ? r : 0.f;
+}
+
 // ---------------------------------------------------------------------------------
 // c[b] = sqrt(L / sum x^2)                    evaluation.py:21, train.py:75-79
 // ---------------------------------------------------------------------------------
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(256) void stft_compress_kernel(SpectralTables tb, c
                 const int t = fb * 16 + 4 * g + r;
                 if (t < T) {
                     const float m2 = are[r] * are[r] + aim[r] * aim[r];
-                    const float s = m2 > 0.f ? powf(m2, -0.35f) : 0.f;
+                    const float s = pow_pos(m2, -0.35f);
                     spec[((long)b * 2 + 0) * P + (long)t * tb.F + bin] = are[r] * s;
                     spec[((long)b * 2 + 1) * P + (long)t * tb.F + bin] = aim[r] * s;
                 }
@@ -98,8 +108,157 @@ __global__ __launch_bounds__(256) void stft_compress_kernel(SpectralTables tb, c
     }
 }
 
+// ---------------------------------------------------------------------------------
+// F16X3 mode, n_fft 400 / hop 100: the same STFT + compression as above with
+//   * the real DFT FOLDED about n = N/2: with u_c[n] = x[n] + x[N-n], u_s[n] = x[n] - x[N-n] (n = 1..N/2-1;
+//     u_c[0] = x[0], u_c[N/2] = x[N/2]) and the symmetric Hamming window moved into the matrices,
+//     re X[k] = sum_{n <= N/2} (w[n] cos(2 pi k n / N)) u_c[n],   im X[k] = sum (-w[n] sin(..)) u_s[n]:
+//     contraction 201 -> 7 k32 blocks instead of 400, so half the matrix bytes and half the MFMAs;
+//   * split-f16 products on the 16x16x32 pipe (3 MFMAs per k32 block instead of 8 fp32 ones);
+//   * a block = 64 frames of one clip (4 waves x 16 frames): the folded operands of a wave's frames
+//     stay in registers (A fragments), the 364 KB matrix image streams through a double-buffered
+//     28 KB LDS chunk per 16-bin block, shared by the four waves.
+// Per launch at B = 32: 6 x 32 blocks, 546 MFMAs per wave, 87 MB of matrix reads from L2.
+// ---------------------------------------------------------------------------------
+template <int NFFT, int HOP>
+__global__ __launch_bounds__(256) void stft_fold_x3_kernel(SpectralTables tb, const float* __restrict__ wav,
+                                                           const float* __restrict__ scale, int L, int T,
+                                                           float* __restrict__ spec) {
+    constexpr int H = NFFT / 2, M32 = (H + 1 + 31) / 32, SEG = 63 * HOP + NFFT;
+    constexpr int CHUNK = 2 * M32 * 1024;                    // halfs per bin block: [cos | -sin][M32][hi | lo][64][8]
+    constexpr int NLD = CHUNK / 8 / 256;                     // 16-byte loads per thread per chunk
+    static_assert(CHUNK % (8 * 256) == 0, "chunk must split evenly over the block");
+    __shared__ __attribute__((aligned(16))) float seg[SEG + 4];
+    __shared__ __attribute__((aligned(16))) _Float16 chunk[2][CHUNK];
+    __shared__ float wmax[4];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y, fb = blockIdx.x;               // 64-frame tile of clip b
+    const int start = fb * 64 * HOP - NFFT / 2;
+    const float sc = scale ? scale[b] : 1.0f;
+    const float* x = wav + (long)b * L;
+    const u32x4* img = reinterpret_cast<const u32x4*>(tb.fold_fwd16);
+    // matrix chunks are prefetched DEPTH bin blocks ahead into registers (an L2 round trip is ~3 chunks of MFMA work)
+    constexpr int DEPTH = 3;
+    u32x4 pre[DEPTH][NLD];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) pre[d][i] = img[(long)d * (CHUNK / 8) + threadIdx.x + 256 * i];
+    {
+        constexpr int NSEG = (SEG + 255) / 256;             // every segment load of the thread in flight at once
+        float v[NSEG];
+#pragma unroll
+        for (int k = 0; k < NSEG; ++k) {
+            int sidx = start + threadIdx.x + 256 * k;
+            if (sidx < 0) sidx = -sidx;
+            if (sidx >= L) sidx = 2 * (L - 1) - sidx;
+            sidx = sidx < 0 ? 0 : (sidx >= L ? L - 1 : sidx);   // frames past T in the last tile: any finite value
+            v[k] = x[sidx];
+        }
+        float amax = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSEG; ++k)
+            if (threadIdx.x + 256 * k < SEG) {
+                seg[threadIdx.x + 256 * k] = v[k] * sc;
+                amax = fmaxf(amax, fabsf(v[k] * sc));
+            }
+        amax = red_g_max(amax);                               // over the 4 lane groups ...
+        amax = fmaxf(amax, dpp_perm<0xB1>(amax));            // ... and the 16 lanes of a row
+        amax = fmaxf(amax, dpp_perm<0x4E>(amax));
+        amax = fmaxf(amax, dpp_perm<0x141>(amax));
+        amax = fmaxf(amax, dpp_perm<0x140>(amax));
+        if (lane == 0) wmax[wv] = amax;
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) reinterpret_cast<u32x4*>(chunk[0])[threadIdx.x + 256 * i] = pre[0][i];
+    __syncthreads();
+    // fp16 hi/lo operands only cover ~2^-24 .. 2^16 around 1: bring the tile's samples to [0.5, 1) with an exact
+    // power-of-two factor (and undo it on the fp32 result), so the transform works at any input amplitude
+    const float tile_max = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    int ex = (int)((__float_as_uint(tile_max) >> 23) & 0xff);
+    ex = ex < 1 ? 1 : (ex > 252 ? 252 : ex);
+    const float up = __uint_as_float((unsigned)(253 - ex) << 23);       // 2^(126 - ex)
+    const float down = __uint_as_float((unsigned)(ex + 1) << 23);        // 2^(ex - 126)
+
+    // folded operands of this wave's 16 frames: lane (frame c, group g), k32 block m, slot e <-> n = 32 m + 8 g + e
+    f16x8 uch[M32], ucl[M32], ush[M32], usl[M32];
+    const float* fr = seg + (wv * 16 + c) * HOP;
+#pragma unroll
+    for (int m = 0; m < M32; ++m) {
+        const int n0 = 32 * m + 8 * g;
+        f32x4 uc[2], us[2];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = n0 + e;
+            // unconditional (clamped) LDS reads + selects: a per-lane `cond ? lds[..] : 0` becomes a branch per element
+            const int na = n <= H ? n : H, nb = (n >= 1 && n < H) ? NFFT - n : H;
+            float a = fr[na], bm = fr[nb];
+            if (32 * m + 31 > H) a = n <= H ? a : 0.f;                      // only the last k32 block crosses N/2
+            const bool pair = (32 * m > 0 || n >= 1) && (32 * m + 31 < H || n < H);
+            bm = pair ? bm : 0.f;
+            uc[e >> 2][e & 3] = (a + bm) * up;
+            us[e >> 2][e & 3] = pair ? (a - bm) * up : 0.f;
+        }
+        split8(uc[0], uc[1], uch[m], ucl[m]);
+        split8(us[0], us[1], ush[m], usl[m]);
+    }
+
+    const long P = (long)T * tb.F;
+    constexpr int FBC = (NFFT / 2 + 1 + 15) / 16;           // bin blocks (compile time: the loop is fully unrolled
+                                                            // so the prefetch ring is statically indexed)
+#pragma unroll
+    for (int bb = 0; bb < FBC; ++bb) {
+        if (bb >= 1 && bb + DEPTH - 1 < FBC) {               // slot of chunk bb-1 is free again: fetch chunk bb+DEPTH-1
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                pre[(bb + DEPTH - 1) % DEPTH][i] = img[(long)(bb + DEPTH - 1) * (CHUNK / 8) + threadIdx.x + 256 * i];
+        }
+        const _Float16* cb = chunk[bb & 1] + lane * 8;
+        f32x4 are = splat4(0.f), aim = splat4(0.f);
+#pragma unroll
+        for (int m = 0; m < M32; ++m) {
+            const f16x8 ch = *reinterpret_cast<const f16x8*>(cb + m * 1024);
+            const f16x8 cl = *reinterpret_cast<const f16x8*>(cb + m * 1024 + 512);
+            const f16x8 sh = *reinterpret_cast<const f16x8*>(cb + (M32 + m) * 1024);
+            const f16x8 sl = *reinterpret_cast<const f16x8*>(cb + (M32 + m) * 1024 + 512);
+            are = mfma32h(uch[m], ch, are);
+            aim = mfma32h(ush[m], sh, aim);
+            are = mfma32h(uch[m], cl, are);
+            aim = mfma32h(ush[m], sl, aim);
+            are = mfma32h(ucl[m], ch, are);
+            aim = mfma32h(usl[m], sh, aim);
+        }
+        const int bin = bb * 16 + c;
+        if (bin < tb.F) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = fb * 64 + wv * 16 + 4 * g + r;
+                if (t < T) {
+                    const float xr = are[r] * down, xi = aim[r] * down;
+                    const float m2 = xr * xr + xi * xi;
+                    const float s = pow_pos(m2, -0.35f);
+                    spec[((long)b * 2 + 0) * P + (long)t * tb.F + bin] = xr * s;
+                    spec[((long)b * 2 + 1) * P + (long)t * tb.F + bin] = xi * s;
+                }
+            }
+        }
+        if (bb + 1 < FBC) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                reinterpret_cast<u32x4*>(chunk[(bb + 1) & 1])[threadIdx.x + 256 * i] = pre[(bb + 1) % DEPTH][i];
+        }
+        __syncthreads();
+    }
+}
+
 void launch_stft_compress(LaunchCtx ctx, const SpectralTables& tb, const float* wav, const float* scale, int B,
                           int L, int T, float* spec) {
+    if (tb.fold_fwd16 && tb.n_fft == 400 && tb.hop == 100) {
+        dim3 grid64((T + 63) / 64, B);
+        LAUNCH(ctx, "stft_compress",
+               (stft_fold_x3_kernel<400, 100><<<grid64, 256, 0, ctx.stream>>>(tb, wav, scale, L, T, spec)));
+        return;
+    }
     dim3 grid((T + 15) / 16, B);
     const size_t shm = (size_t)(15 * tb.hop + tb.n_fft) * sizeof(float);
     LAUNCH(ctx, "stft_compress",
@@ -145,7 +304,7 @@ __global__ __launch_bounds__(256) void uncompress_irfft_kernel(SpectralTables tb
                 float yr = 0.f, yi = 0.f;
                 if (okv[k]) {
                     const float m2 = ar[k] * ar[k] + ai[k] * ai[k];
-                    const float sc = m2 > 0.f ? powf(m2, 7.0f / 6.0f) : 0.f;
+                    const float sc = pow_pos(m2, 7.0f / 6.0f);
                     yr = ar[k] * sc;
                     yi = ai[k] * sc;
                 }

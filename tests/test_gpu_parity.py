@@ -92,6 +92,15 @@ def test_rms_scale_and_scaled_stft(model):
     assert _report("scaled stft_compress vs oracle", rel_err(spec, want)) < 5e-5
 
 
+def test_stft_compress_tiny_amplitudes_stay_finite_and_accurate(model):
+    """|X|^2 down in the fp32 denormal range: the log2/exp2 power law must not flush it to 0 or inf."""
+    wav = synthetic_clips(2, 3200, seed=6) * 1e-19
+    spec = model.engine.stft_compress(wav.to(DEV))
+    want = O.stft_compress(wav)
+    assert torch.isfinite(spec).all() and torch.count_nonzero(spec) > 0.9 * spec.numel()
+    assert _report("stft_compress at 1e-19 amplitude vs oracle", rel_err(spec, want)) < 1e-3
+
+
 def test_stft_istft_round_trip_full_size(model):
     """BASELINE config 2 shape: 32 x 32000 samples -> [32,2,321,201] -> back (identity)."""
     wav = synthetic_clips(32, 32000, seed=5).to(DEV)
