@@ -2,7 +2,8 @@
 
     from cmgan_amd import TSCNet, ConformerBlock           # mirrors of the reference classes
     from cmgan_amd.utils import power_compress, power_uncompress, stft_compress, uncompress_istft
-    from cmgan_amd.evaluation import enhance_one_track
+    from cmgan_amd.evaluation import enhance_one_track, evaluation   # src/evaluation.py
+    from cmgan_amd.metrics import compute_metrics                    # src/tools/compute_metrics.py (CPU, numpy)
 
 Importing the package is cheap and GPU-free; the shared library is loaded (and must
 exist) the moment an Engine / model is constructed.
