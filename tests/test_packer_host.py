@@ -134,3 +134,28 @@ def test_no_kernel_uses_scratch_memory():
         bad = [b for res in ex.map(check, B.SOURCES) for b in res]
     assert not bad, f"kernels with scratch: {bad}"
     assert kernels_seen[0] >= 30            # the check really saw the library's kernels
+
+
+def test_committed_bench_line_carries_the_contract_fields():
+    """profiles/r01_bench_x3.json is the round's `python bench.py` line: every field the bench contract names
+    must be present and self-consistent (value = frames / time, roofline fraction = achieved / peak)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "r01_bench_x3.json")) as f:
+        d = json.load(f)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    frames = d["n_gpus"] * 32 * 321
+    assert abs(d["value"] - frames / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1
