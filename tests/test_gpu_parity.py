@@ -247,6 +247,17 @@ def test_enhance_batch_matches_oracle(model, sd):
     assert _report("enhance_batch vs oracle", rel_err(got, O.enhance_batch(sd, wav))) < GATE
 
 
+@pytest.mark.parametrize("b,l", [(1, 300), (1, 800), (3, 1600), (5, 4100 - 100), (2, 6400)])
+def test_enhance_batch_small_and_odd_shapes(model, sd, b, l):
+    """T = L / 100 + 1 from 4 frames up: conv tiles that are mostly padding, time sequences shorter than one
+    64-key attention chunk, the 64-frame STFT tile with a single live frame group, batch 1."""
+    from cmgan_amd.evaluation import enhance_batch
+    wav = synthetic_clips(b, l, seed=50 + b)
+    got = enhance_batch(model, wav.to(DEV))
+    assert got.shape == (b, l)
+    assert _report(f"enhance_batch [{b} x {l}] vs oracle", rel_err(got, O.enhance_batch(sd, wav))) < GATE
+
+
 def test_long_track_runs_unchunked_like_the_reference(model, sd):
     """6 s < 16 s: one row of T = 961 frames (distances beyond 512 saturate in the time conformer)."""
     from cmgan_amd.evaluation import enhance_one_track
