@@ -214,6 +214,14 @@ def main():
                 hbm_bytes_per_clip().get(dom, 0) * BATCH_PER_GPU / max(1, kern[dom]["launches_per_step"]))
         hb = hbm_bytes_per_clip()
         extra = {}
+        # the same figure for every MFMA kernel family (the dominant one changes with a few % of run-to-run noise:
+        # attention and the dense convs are within 3 % of each other)
+        extra["roofline_by_kernel"] = {
+            k: {"ms_per_step": round(kern[k]["ms_per_step"], 4),
+                "achieved_tflops": round(fl[k] * BATCH_PER_GPU / (kern[k]["ms_per_step"] * 1e-3) / 1e12, 2),
+                "frac_of_mfma_peak": round(fl[k] * BATCH_PER_GPU / (kern[k]["ms_per_step"] * 1e-3) / 1e12 / peak_tf, 4),
+                "hbm_bytes_per_launch_pmc": pmc_traffic.get(k, {}).get("hbm_bytes")}
+            for k in sorted((k for k in kern if k in fl and fl[k] > 0), key=lambda k: -kern[k]["ms_per_step"])[:5]}
         if dom in hb:
             gbs = hb[dom] * BATCH_PER_GPU / dom_s / 1e9
             extra["roofline_hbm"] = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
