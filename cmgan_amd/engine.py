@@ -80,6 +80,10 @@ class Engine:
         self.weights_loaded = True
 
     # ---- workspace -----------------------------------------------------------------
+    def _ws_token(self):
+        """Identity of the current workspace allocation: graphs captured on an older one are stale."""
+        return self._ws
+
     def _workspace(self, B: int, T: int) -> torch.Tensor:
         need = self.lib.cmgan_workspace_bytes(self._h, B, T)
         if need == 0:

@@ -306,6 +306,27 @@ def test_evaluation_directory_driver_scores_like_the_oracle_path(model, sd, tmp_
     assert _report("evaluation() averages vs oracle-enhanced", rel_err(torch.tensor(got), torch.tensor(want / 2))) < 1e-3
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_windowed_inference_matches_the_per_window_contract(model, sd, graph):
+    """cmgan_amd.streaming.enhance_windows: window k = samples [kW - C, (k+1)W + C) of the file-scaled signal,
+    enhanced like one reference row, central W samples kept; hipGraph replay must not change a bit."""
+    from cmgan_amd.streaming import enhance_windows
+    W, C, L = 8000, 1600, 21700                                     # 3 windows, the last one partly zero padding
+    noisy = synthetic_clips(1, L, seed=60)
+    got = enhance_windows(model, noisy.to(DEV), window=W, context=C, batch=2, graph=graph)
+    c = O.rms_scale(noisy)
+    padded = torch.zeros(3 * W + 2 * C)
+    padded[C:C + L] = noisy[0] * c
+    rows = padded.unfold(0, W + 2 * C, W)
+    est = O.uncompress_istft(*O.tscnet_forward(sd, O.stft_compress(rows)))
+    want = (est[:, C:C + W].reshape(-1)[:L] / c)
+    assert got.shape == (L,)
+    assert _report(f"enhance_windows (graph={graph}) vs oracle windows", rel_err(got, want)) < GATE
+    if graph:
+        eager = enhance_windows(model, noisy.to(DEV), window=W, context=C, batch=2, graph=False)
+        assert torch.equal(got, eager)
+
+
 # ------------------------------------------------------------------ error behaviour
 def test_argument_errors_surface_as_exceptions(model):
     from cmgan_amd._lib import CmganError
