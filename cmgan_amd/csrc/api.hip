@@ -112,6 +112,33 @@ static void build_fold_fwd(int N, int F, const std::vector<double>& win, std::ve
                     }
 }
 
+// Folded inverse DFT images for irfft_fold_x3_kernel: [13 sample blocks][cos | sin][7 k32 blocks][hi | lo][64][8];
+// lane (c = sample n within the block, g) slot e of block m <-> bin k = 32 m + 8 g + e.
+static void build_fold_inv(int N, const std::vector<double>& /*win*/, std::vector<_Float16>& img) {
+    const int H = N / 2, NB = (H + 1 + 15) / 16, M32 = (H + 1 + 31) / 32;
+    const double PI2 = 6.283185307179586476925286766559;
+    img.assign((size_t)NB * 2 * M32 * 1024, (_Float16)0.f);
+    for (int nb = 0; nb < NB; ++nb)
+        for (int cs = 0; cs < 2; ++cs)
+            for (int m = 0; m < M32; ++m)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int n = 16 * nb + (lane & 15), k = 32 * m + 8 * (lane >> 4) + e;
+                        double v = 0.0;
+                        if (n <= H && k <= H) {
+                            const long mm = ((long)k * n) % N;
+                            const double wk = (k == 0 || k == H) ? 1.0 : 2.0;
+                            if (cs == 0) v = wk * cos(PI2 * mm / N) / N;
+                            else if (k >= 1 && k < H) v = wk * sin(PI2 * mm / N) / N;
+                        }
+                        _Float16 hi, lo;
+                        split_h((float)v, hi, lo);
+                        const size_t o = (((size_t)nb * 2 + cs) * M32 + m) * 1024 + lane * 8 + e;
+                        img[o] = hi;
+                        img[o + 512] = lo;
+                    }
+}
+
 extern "C" int cmgan_create(cmgan_handle** out, const cmgan_config* cfg) {
     if (!out || !cfg) return fail(nullptr, CMGAN_E_BADARG, "cmgan_create: null argument");
     *out = nullptr;
@@ -168,8 +195,11 @@ extern "C" int cmgan_create(cmgan_handle** out, const cmgan_config* cfg) {
     h->st.fwd_fm = h->d_tables; h->st.inv_fm = h->d_tables + n_fwd; h->st.window = h->d_tables + n_fwd + n_inv;
     h->st.fold_fwd16 = nullptr; h->st.fold_inv16 = nullptr;
     if (cfg->mfma_mode == CMGAN_MFMA_F16X3 && N == 400 && cfg->hop == 100) {
-        std::vector<_Float16> img;
+        std::vector<_Float16> img, inv_img;
         build_fold_fwd(N, F, win, img);
+        build_fold_inv(N, win, inv_img);
+        const size_t fwd_halfs = img.size();
+        img.insert(img.end(), inv_img.begin(), inv_img.end());
         e = hipMalloc(&h->d_fold, img.size() * sizeof(_Float16));
         if (e == hipSuccess) e = hipMemcpy(h->d_fold, img.data(), img.size() * sizeof(_Float16), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
@@ -180,6 +210,7 @@ extern "C" int cmgan_create(cmgan_handle** out, const cmgan_config* cfg) {
             return CMGAN_E_HIP;
         }
         h->st.fold_fwd16 = h->d_fold;
+        h->st.fold_inv16 = reinterpret_cast<const _Float16*>(h->d_fold) + fwd_halfs;
     }
     *out = h;
     return CMGAN_OK;

@@ -363,12 +363,155 @@ __global__ __launch_bounds__(256) void ola_kernel(const float* __restrict__ fram
     wav[(long)b * Lout + s] = v;
 }
 
+// ---------------------------------------------------------------------------------
+// F16X3 mode, n_fft 400 / hop 100: power uncompress + inverse real DFT, the mirror image of
+// stft_fold_x3_kernel.  With theta = 2 pi k n / N and Hermitian weights c_k (1 at DC / Nyquist, else 2)
+//   C[n] = sum_k (c_k cos(theta) / N) Yr_k,   S[n] = sum_k (c_k sin(theta) / N) Yi_k     for n = 0 .. N/2
+//   x[n] = w[n] (C[n] - S[n]),   x[N - n] = w[N - n] (C[n] + S[n])                         (n = 1 .. N/2 - 1)
+// so the contraction is over the 201 bins (7 k32 blocks) and only 201 output columns are computed for the
+// 400 samples.  A block = 64 frames of one clip: the uncompressed re (then im) tile is staged in LDS as fp32,
+// scaled to [0.5, 1) by an exact power of two per tile and part, split into fp16 hi/lo A fragments kept in
+// registers; the two matrix images stream through the same double-buffered 28 KB chunks as the forward kernel.
+// ---------------------------------------------------------------------------------
+template <int NFFT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void irfft_fold_x3_kernel(SpectralTables tb, const float* __restrict__ re,
+                                                            const float* __restrict__ im, int T,
+                                                            float* __restrict__ frames) {
+    constexpr int H = NFFT / 2, M32 = (H + 1 + 31) / 32, KP = 32 * M32, LD = KP + 4;
+    constexpr int CHUNK = 2 * M32 * 1024, NLD = CHUNK / 8 / 256, NBC = (H + 1 + 15) / 16, DEPTH = 3;
+    __shared__ __attribute__((aligned(16))) float ytile[64 * LD];
+    __shared__ __attribute__((aligned(16))) _Float16 chunk[2][CHUNK];
+    __shared__ float wmax[4];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y, fb = blockIdx.x;
+    const long P = (long)T * tb.F;
+    const u32x4* img = reinterpret_cast<const u32x4*>(tb.fold_inv16);
+    u32x4 pre[DEPTH][NLD];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) pre[d][i] = img[(long)d * (CHUNK / 8) + threadIdx.x + 256 * i];
+
+    f16x8 uh[2][M32], ul[2][M32];                            // [re | im][k32 block]
+    float down[2];
+    // one pass over the 64 x 201 (re, im) pairs with every load of the thread in flight at once; the uncompressed
+    // real parts go to the LDS tile, the imaginary parts wait in registers for the second use of the tile
+    constexpr int NST = 64 * KP / 256;
+    float vre[NST], vim[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int fr = i / KP, bin = i - fr * KP;
+        const int t = fb * 64 + fr;
+        const long off = (long)b * P + (long)(t < T ? t : 0) * tb.F + (bin <= H ? bin : 0);
+        vre[k] = re[off];
+        vim[k] = im[off];
+    }
+    float amax_r = 0.f, amax_i = 0.f;
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int fr = i / KP, bin = i - fr * KP;
+        const int t = fb * 64 + fr;
+        const bool ok = t < T && bin <= H;
+        const float sc = pow_pos(vre[k] * vre[k] + vim[k] * vim[k], 7.0f / 6.0f);
+        vre[k] = ok ? vre[k] * sc : 0.f;
+        vim[k] = (ok && bin >= 1 && bin < H) ? vim[k] * sc : 0.f;          // imag of DC / Nyquist is ignored
+        amax_r = fmaxf(amax_r, fabsf(vre[k]));
+        amax_i = fmaxf(amax_i, fabsf(vim[k]));
+    }
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        if (part) __syncthreads();                            // every wave has built its re fragments
+        float amax = part ? amax_i : amax_r;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            const int fr = i / KP, bin = i - fr * KP;
+            ytile[fr * LD + bin] = part ? vim[k] : vre[k];
+        }
+        amax = red_g_max(amax);
+        amax = fmaxf(amax, dpp_perm<0xB1>(amax));
+        amax = fmaxf(amax, dpp_perm<0x4E>(amax));
+        amax = fmaxf(amax, dpp_perm<0x141>(amax));
+        amax = fmaxf(amax, dpp_perm<0x140>(amax));
+        if (lane == 0) wmax[wv] = amax;
+        if (part == 0) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) reinterpret_cast<u32x4*>(chunk[0])[threadIdx.x + 256 * i] = pre[0][i];
+        }
+        __syncthreads();
+        const float tile_max = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        int ex = (int)((__float_as_uint(tile_max) >> 23) & 0xff);
+        ex = ex < 1 ? 1 : (ex > 252 ? 252 : ex);
+        const float up = __uint_as_float((unsigned)(253 - ex) << 23);
+        down[part] = __uint_as_float((unsigned)(ex + 1) << 23);
+        const float* row = ytile + (wv * 16 + c) * LD + 8 * g;
+#pragma unroll
+        for (int m = 0; m < M32; ++m) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(row + 32 * m) * splat4(up);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(row + 32 * m + 4) * splat4(up);
+            split8(a0, a1, uh[part][m], ul[part][m]);
+        }
+    }
+
+#pragma unroll
+    for (int nb = 0; nb < NBC; ++nb) {
+        if (nb >= 1 && nb + DEPTH - 1 < NBC) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                pre[(nb + DEPTH - 1) % DEPTH][i] = img[(long)(nb + DEPTH - 1) * (CHUNK / 8) + threadIdx.x + 256 * i];
+        }
+        const _Float16* cb = chunk[nb & 1] + lane * 8;
+        f32x4 ac = splat4(0.f), as = splat4(0.f);
+#pragma unroll
+        for (int m = 0; m < M32; ++m) {
+            const f16x8 ch = *reinterpret_cast<const f16x8*>(cb + m * 1024);
+            const f16x8 cl = *reinterpret_cast<const f16x8*>(cb + m * 1024 + 512);
+            const f16x8 sh = *reinterpret_cast<const f16x8*>(cb + (M32 + m) * 1024);
+            const f16x8 sl = *reinterpret_cast<const f16x8*>(cb + (M32 + m) * 1024 + 512);
+            ac = mfma32h(uh[0][m], ch, ac);
+            as = mfma32h(uh[1][m], sh, as);
+            ac = mfma32h(uh[0][m], cl, ac);
+            as = mfma32h(uh[1][m], sl, as);
+            ac = mfma32h(ul[0][m], ch, ac);
+            as = mfma32h(ul[1][m], sh, as);
+        }
+        const int n = nb * 16 + c;
+        if (n <= H) {
+            const float w0 = tb.window[n], w1 = tb.window[n >= 1 && n < H ? NFFT - n : n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = fb * 64 + wv * 16 + 4 * g + r;
+                if (t < T) {
+                    const float C = ac[r] * down[0], S = as[r] * down[1];
+                    float* fr = frames + ((long)b * T + t) * NFFT;
+                    fr[n] = (C - S) * w0;
+                    if (n >= 1 && n < H) fr[NFFT - n] = (C + S) * w1;
+                }
+            }
+        }
+        if (nb + 1 < NBC) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                reinterpret_cast<u32x4*>(chunk[(nb + 1) & 1])[threadIdx.x + 256 * i] = pre[(nb + 1) % DEPTH][i];
+        }
+        __syncthreads();
+    }
+}
+
 void launch_uncompress_istft(LaunchCtx ctx, const SpectralTables& tb, const float* re, const float* im,
                              const float* scale, int B, int T, float* frames_ws, float* wav_out) {
-    dim3 grid((T + 15) / 16, B);
-    const size_t shm = (size_t)16 * (2 * tb.FB * 16 + 4) * sizeof(float);
-    LAUNCH(ctx, "uncompress_irfft",
-           (uncompress_irfft_kernel<<<grid, 256, shm, ctx.stream>>>(tb, re, im, T, frames_ws)));
+    if (tb.fold_inv16 && tb.n_fft == 400 && tb.hop == 100) {
+        dim3 grid64((T + 63) / 64, B);
+        LAUNCH(ctx, "uncompress_irfft",
+               (irfft_fold_x3_kernel<400><<<grid64, 256, 0, ctx.stream>>>(tb, re, im, T, frames_ws)));
+    } else {
+        dim3 grid((T + 15) / 16, B);
+        const size_t shm = (size_t)16 * (2 * tb.FB * 16 + 4) * sizeof(float);
+        LAUNCH(ctx, "uncompress_irfft",
+               (uncompress_irfft_kernel<<<grid, 256, shm, ctx.stream>>>(tb, re, im, T, frames_ws)));
+    }
     const int Lout = tb.hop * (T - 1);
     dim3 g2((Lout + 255) / 256, B);
     LAUNCH(ctx, "ola", (ola_kernel<<<g2, 256, 0, ctx.stream>>>(frames_ws, tb.window, scale, tb.n_fft, tb.hop, T, Lout,

@@ -72,6 +72,18 @@ def test_uncompress_istft_matches_reference_golden(model):
     assert _report("uncompress_istft vs golden", rel_err(wav, g["istft"])) < 1e-5
 
 
+@pytest.mark.parametrize("gain", [1e-6, 30.0])
+def test_uncompress_istft_is_amplitude_independent(model, gain):
+    """The split-f16 inverse transform rescales each tile by a power of two: spectra whose uncompressed
+    magnitudes are ~1e-20 or ~1e5 must come out as accurately as O(1) ones."""
+    g = load_golden("stft.npz")
+    comp = (g["compressed"].permute(0, 1, 3, 2).contiguous() * gain)
+    want = O.uncompress_istft(comp[:, 0:1], comp[:, 1:2])
+    got = model.engine.uncompress_istft(comp[:, 0:1].contiguous().to(DEV), comp[:, 1:2].contiguous().to(DEV))
+    assert torch.isfinite(got).all()
+    assert _report(f"uncompress_istft at gain {gain:g} vs oracle", rel_err(got, want)) < 2e-5
+
+
 def test_power_compress_uncompress_standalone_match_golden():
     from cmgan_amd.utils import power_compress, power_uncompress
     g = load_golden("stft.npz")
