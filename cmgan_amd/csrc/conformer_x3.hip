@@ -222,23 +222,29 @@ __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x
 
 // ---------------------------------------------------------------------------------
 // Attention core (see attn_kernel in conformer.hip for the algorithm).  Barrier-free:
-// every wave is independent and owns FOUR consecutive 16-query blocks of one (sequence,
-// head), processed as two pairs so that two independent dependency chains (MFMA -> LDS skew
+// every wave is independent and owns ATT_NQ consecutive 16-query blocks of one (sequence,
+// head), processed as pairs so that two independent dependency chains (MFMA -> LDS skew
 // -> softmax -> MFMA) are in flight per wave.  K / V / E operand images are read straight
-// from L2 as lane-linear 1 KiB fragments and shared by the four query blocks (operand
-// traffic per query is 1/3 of the one-block-per-wave layout); LDS is only the wave-private
+// from L2 as lane-linear 1 KiB fragments and shared by the wave's query blocks; LDS is only the wave-private
 // Toeplitz skew scratch (2 x 6.4 KB per wave).
 // Contraction slots of the 32-wide MFMA: lane groups g = 0,1 carry the hi half of K (resp. E),
 // g = 2,3 the lo half, both over d = 8*(g&1) + e; B carries Q_hi in both halves (MFMA 1) then
 // Q_lo (MFMA 2): two MFMAs give (K_hi + K_lo) . (Q_hi + Q_lo).
 // ---------------------------------------------------------------------------------
 #define RSTRIDE_X 20
-#define ATT_NQ 4
+// Query blocks per wave / waves per SIMD the kernel is compiled for.  Measured in one session: a lone wave per
+// SIMD 9.8 ms, two waves (4 query blocks each, 216 VGPRs) 6.0 ms, three waves (2 query blocks = one pair each,
+// 168 VGPRs, no spill) 5.4 ms: the kernel is a long dependency chain (MFMA -> LDS skew -> MFMA -> softmax -> MFMA)
+// that more resident waves hide better than more work per wave does, even though K / V / E operand reuse halves.
+#ifndef ATT_NQ
+#define ATT_NQ 2
+#endif
+#ifndef ATT_WAVES
+#define ATT_WAVES 3
+#endif
 
 struct AttState {
     float m, run, l;      // reference level, running max relative to it, denominator (relative to m)
-    f32x4 nm;             // splat(-m), kept as a register tuple: it is the C operand of every rel-pos MFMA
-                          // (re-materialising the splat cost 4 VALU per MFMA pair)
     f32x4 o;
 };
 
@@ -295,7 +301,6 @@ __device__ __forceinline__ void att_softmax(f32x4 (&s)[4], int c, int g, int j0,
         st.l *= alpha;
         st.o = st.o * splat4(alpha);
         st.m += run;
-        st.nm = splat4(-st.m);
         st.run = 0.f;
     } else {
 #pragma unroll
@@ -342,7 +347,7 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
         vl[mp] = *reinterpret_cast<const f16x8*>(a.vbase + (long)pr * 1024 + 512);
     }
 #pragma unroll
-    for (int pair = 0; pair < 2; ++pair) {
+    for (int pair = 0; pair < ATT_NQ / 2; ++pair) {
         const int ibA = ibb + 2 * pair;
         if (ibA >= a.Lb) break;
         const int qB = ibA + 1 < a.Lb ? ibA + 1 : a.Lb - 1;
@@ -366,13 +371,13 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
 #pragma unroll
         for (int we = 0; we < 6; ++we) {
             if (we < 5 && (FULL || we >= 4 - nb)) {       // cb = we for block A
-                f32x4 rt = mfma32h(ef[we], qA1, sa.nm);
+                f32x4 rt = mfma32h(ef[we], qA1, splat4(-sa.m));
                 rt = mfma32h(ef[we], qA2, rt);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a.RA[(16 * we + 4 * g + r) * RSTRIDE_X + c] = rt[r];
             }
             if (we >= 1 && (FULL || we - 1 >= 4 - nb)) {  // cb = we - 1 for block B
-                f32x4 rt = mfma32h(ef[we], qB1, sb.nm);
+                f32x4 rt = mfma32h(ef[we], qB1, splat4(-sb.m));
                 rt = mfma32h(ef[we], qB2, rt);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a.RB[(16 * (we - 1) + 4 * g + r) * RSTRIDE_X + c] = rt[r];
@@ -420,7 +425,7 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
     }
 }
 
-__global__ __launch_bounds__(256, 2) void attn_x3_kernel(QkvOut io, const _Float16* __restrict__ eimg, int max_pos,
+__global__ __launch_bounds__(256, ATT_WAVES) void attn_x3_kernel(QkvOut io, const _Float16* __restrict__ eimg, int max_pos,
                                                          float* __restrict__ o, int L, int Lb, int Lb2, int nqg,
                                                          long total) {
     __shared__ float rbuf[4][2][80 * RSTRIDE_X + 4];   // +4: keeps RA/RB 1604 dwords apart, which no ds_read2* form can span, so each skew read
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void attn_x3_kernel(QkvOut io, const _Float
     AttState st[ATT_NQ];
 #pragma unroll
     for (int i = 0; i < ATT_NQ; ++i) {
-        st[i].m = 0.f; st[i].run = -INFINITY; st[i].l = 0.f; st[i].nm = splat4(0.f); st[i].o = splat4(0.f);
+        st[i].m = 0.f; st[i].run = -INFINITY; st[i].l = 0.f; st[i].o = splat4(0.f);
     }
 
     const int nfull = L >> 6;
