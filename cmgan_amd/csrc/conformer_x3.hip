@@ -11,6 +11,10 @@
 
 #define XNTB 2
 #define XWAVES 8
+#ifndef FFN_WAVES
+#define FFN_WAVES 12          // waves per FeedForward block (one block per CU: 128 KB of weight images); three waves
+                              // per SIMD at 150 VGPRs measured 7 % faster than two, a fourth would spill
+#endif
 
 __device__ __forceinline__ float swish_x(float hp) { return swish_scaled(hp); }
 
@@ -684,6 +688,11 @@ static int persistent_grid(int ntiles, int blocks_per_cu) {
     return want < cap ? (want > 0 ? want : 1) : cap;
 }
 
+static int ffn_grid(int ntiles) {                         // one persistent FeedForward block per CU
+    const int want = (ntiles + FFN_WAVES - 1) / FFN_WAVES;
+    return want < 256 ? (want > 0 ? want : 1) : 256;
+}
+
 void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeightsX3& w16, const ConfBuffers& b,
                           const TokMap& seq, long M, float* taps, bool outer_residual) {
     hipStream_t s = ctx.stream;
@@ -697,7 +706,7 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
     io.kimg = reinterpret_cast<_Float16*>(b.k);
     io.vimg = reinterpret_cast<_Float16*>(b.v);
 
-    LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, 8><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(
+    LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, FFN_WAVES><<<ffn_grid(flat_tiles), 64 * FFN_WAVES, 0, s>>>(
                            b.xa, b.xb, nullptr, nullptr, w16.ff1_w1, w.ff1_b1, w16.ff1_w2, w.ff1_b2, M, flat_tiles)));
     if (taps) hipMemcpyAsync(taps, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
 
@@ -721,12 +730,11 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
     LAUNCH(ctx, "dwpw2", (dwpw2_x3_kernel<<<dgrid, 256, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq)));
     if (taps) {
         hipMemcpyAsync(taps + (size_t)2 * M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
-        LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, 8><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(
+        LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, FFN_WAVES><<<ffn_grid(flat_tiles), 64 * FFN_WAVES, 0, s>>>(
                                b.xb, taps + (size_t)3 * M * 64, nullptr, nullptr, w16.ff2_w1, w.ff2_b1, w16.ff2_w2,
                                w.ff2_b2, M, flat_tiles)));
     }
-    // (a 16-wave x 1-token-block geometry, 4 waves / SIMD, measured no faster: occupancy is not the limiter)
-    LAUNCH(ctx, "ffn_post", (ffn_x3_kernel<true, 2, 8><<<persistent_grid(flat_tiles, 1), 512, 0, s>>>(
+    LAUNCH(ctx, "ffn_post", (ffn_x3_kernel<true, 2, FFN_WAVES><<<ffn_grid(flat_tiles), 64 * FFN_WAVES, 0, s>>>(
                                 b.xb, b.xa, outer_residual ? b.xa : nullptr, w.post_gb, w16.ff2_w1, w.ff2_b1,
                                 w16.ff2_w2, w.ff2_b2, M, flat_tiles)));
 }
