@@ -288,8 +288,15 @@ __global__ __launch_bounds__(64 * NWV) void conv3x_kernel(ConvArgs a, const _Flo
 #ifndef CX_NWV64
 #define CX_NWV64 8            // waves per block (tile = 16 * NPB * NWV rows)
 #endif
+#ifndef CX_NPB128
+#define CX_NPB128 2           // 128-channel sub-pixel conv: 4 waves x 2 position blocks = 128-row tile (8 x 1 needs
+                              // 82 KB of LDS with its 8 KB of partial sums -> one block per CU, 8 % slower)
+#endif
+#ifndef CX_NWV128
+#define CX_NWV128 4
+#endif
 int conv3x_ntiles(int T, int F, int cout) {
-    const int tile = (cout == 128 ? 128 : 16 * CX_NPB64 * CX_NWV64) - 2;
+    const int tile = (cout == 128 ? 16 * CX_NPB128 * CX_NWV128 : 16 * CX_NPB64 * CX_NWV64) - 2;
     return (T * (F + 1) + tile - 1) / tile;
 }
 
@@ -301,5 +308,5 @@ void launch_conv3_x3(LaunchCtx ctx, const ConvArgs& a, const void* w16, int B, i
     else if (time_taps == 1 && cout == 64)
         LAUNCH(ctx, "conv_1x3", (conv3x_kernel<1, 64, CX_NPB64, CX_NWV64><<<grid, 64 * CX_NWV64, 0, ctx.stream>>>(a, w)));
     else
-        LAUNCH(ctx, "conv_subpixel", (conv3x_kernel<1, 128, 2><<<grid, 256, 0, ctx.stream>>>(a, w)));
+        LAUNCH(ctx, "conv_subpixel", (conv3x_kernel<1, 128, CX_NPB128, CX_NWV128><<<grid, 64 * CX_NWV128, 0, ctx.stream>>>(a, w)));
 }
