@@ -580,7 +580,12 @@ __global__ __launch_bounds__(512) void pw1glu_x3_kernel(const float* __restrict_
 #define DP_TL 32
 #define DP_K 31
 #define DP_VS 144                 // halfs per v-tile row (128 used)
-__global__ __launch_bounds__(256) void dwpw2_x3_kernel(float* __restrict__ x, const float* __restrict__ u,
+#ifndef DP_WAVES
+#define DP_WAVES 4              // waves per block: 4 (two 16-token groups x 128 channels); 8 (four 8-token groups, 108
+                                // VGPRs, twice the resident waves) measured 23 % slower: the per-thread tap loads and
+                                // window warm-up are amortised over half as many outputs
+#endif
+__global__ __launch_bounds__(64 * DP_WAVES) void dwpw2_x3_kernel(float* __restrict__ x, const float* __restrict__ u,
                                                        const float* __restrict__ dw_w,
                                                        const float* __restrict__ dw_b,
                                                        const _Float16* __restrict__ w2i,
@@ -593,11 +598,12 @@ __global__ __launch_bounds__(256) void dwpw2_x3_kernel(float* __restrict__ x, co
     const int l0 = blockIdx.y * DP_TL;
     const long nbase = (long)(n / m.inner) * m.outer + (long)(n % m.inner) * m.istride;
 
-    // pointwise operands for this wave: token block tb = wv >> 1, output blocks ob0, ob0 + 1
-    const int tb = wv >> 1, ob0 = (wv & 1) * 2;
-    f16x8 ah[2][4], al[2][4];
+    // pointwise operands for this wave: token block tb, output blocks ob0 .. ob0 + NOB - 1
+    constexpr int NTHR = 64 * DP_WAVES, NOB = 8 / DP_WAVES, TOK = 4096 / NTHR;   // tokens per thread in the depthwise phase
+    const int tb = wv / (DP_WAVES / 2), ob0 = (wv % (DP_WAVES / 2)) * NOB;
+    f16x8 ah[NOB][4], al[NOB][4];
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+    for (int o = 0; o < NOB; ++o)
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
             const _Float16* wp = w2i + ((ob0 + o) * 4 + mm) * 1024 + lane * 8;
@@ -606,11 +612,11 @@ __global__ __launch_bounds__(256) void dwpw2_x3_kernel(float* __restrict__ x, co
         }
 
     constexpr int ROWS = DP_TL + DP_K - 1;
-    constexpr int NLD = (ROWS * 32 + 255) / 256;
+    constexpr int NLD = (ROWS * 32 + NTHR - 1) / NTHR;
     f32x4 stg[NLD];
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {                         // all loads first (see stage_lds16)
-        const int i = tid + 256 * k, rr = i >> 5, qd = i & 31;
+        const int i = tid + NTHR * k, rr = i >> 5, qd = i & 31;
         const int l = l0 - (DP_K / 2) + rr;
         const bool inb = i < ROWS * 32 && l >= 0 && l < m.L;   // 'same' zero padding outside the sequence
         const int lc = l < 0 ? 0 : (l < m.L ? l : m.L - 1);
@@ -619,7 +625,7 @@ __global__ __launch_bounds__(256) void dwpw2_x3_kernel(float* __restrict__ x, co
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
-        const int i = tid + 256 * k;
+        const int i = tid + NTHR * k;
         if (i < ROWS * 32) *reinterpret_cast<f32x4*>(&utile[(i >> 5) * 128 + (i & 31) * 4]) = stg[k];
     }
     const int chn = tid & 127, sub = tid >> 7;
@@ -631,8 +637,8 @@ __global__ __launch_bounds__(256) void dwpw2_x3_kernel(float* __restrict__ x, co
     const int vcol = (chn & ~31) + ((chn >> 2) & 3) * 8 + ((chn >> 4) & 1) * 4 + (chn & 3);
     __syncthreads();
 #pragma unroll 1
-    for (int og = 0; og < 4; ++og) {
-        const int base = sub * 16 + og * 4;
+    for (int og = 0; og < TOK / 4; ++og) {
+        const int base = sub * TOK + og * 4;
         float acc[4] = {bias, bias, bias, bias};
 #pragma unroll
         for (int kk = 0; kk < DP_K + 3; ++kk) {
@@ -654,25 +660,25 @@ __global__ __launch_bounds__(256) void dwpw2_x3_kernel(float* __restrict__ x, co
     }
     __syncthreads();
 
-    f32x4 acc2[2];
+    f32x4 acc2[NOB];
 #pragma unroll
-    for (int o = 0; o < 2; ++o) acc2[o] = ldg4(b2 + 16 * (ob0 + o) + 4 * g);
+    for (int o = 0; o < NOB; ++o) acc2[o] = ldg4(b2 + 16 * (ob0 + o) + 4 * g);
 #pragma unroll
     for (int mm = 0; mm < 4; ++mm) {
         const f16x8 bh = *reinterpret_cast<const f16x8*>(&vth[(16 * tb + c) * DP_VS + 32 * mm + 8 * g]);
         const f16x8 bl = *reinterpret_cast<const f16x8*>(&vtl[(16 * tb + c) * DP_VS + 32 * mm + 8 * g]);
 #pragma unroll
-        for (int o = 0; o < 2; ++o) acc2[o] = mfma32h(ah[o][mm], bh, acc2[o]);
+        for (int o = 0; o < NOB; ++o) acc2[o] = mfma32h(ah[o][mm], bh, acc2[o]);
 #pragma unroll
-        for (int o = 0; o < 2; ++o) acc2[o] = mfma32h(ah[o][mm], bl, acc2[o]);
+        for (int o = 0; o < NOB; ++o) acc2[o] = mfma32h(ah[o][mm], bl, acc2[o]);
 #pragma unroll
-        for (int o = 0; o < 2; ++o) acc2[o] = mfma32h(al[o][mm], bh, acc2[o]);
+        for (int o = 0; o < NOB; ++o) acc2[o] = mfma32h(al[o][mm], bh, acc2[o]);
     }
     const int l = l0 + 16 * tb + c;
     if (l < m.L) {
         float* xr = x + (nbase + (long)l * m.lstride) * 64;
 #pragma unroll
-        for (int o = 0; o < 2; ++o) {
+        for (int o = 0; o < NOB; ++o) {
             float* p = xr + 16 * (ob0 + o) + 4 * g;
             stg4(p, ldg4(p) + acc2[o]);
         }
@@ -727,7 +733,7 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
     LAUNCH(ctx, "pw1glu", (pw1glu_x3_kernel<<<persistent_grid(flat_tiles, 2), 512, 0, s>>>(
                               b.xb, b.u, w16.pw1_w, w.pw1_b, M, flat_tiles)));
     dim3 dgrid(N, (seq.L + DP_TL - 1) / DP_TL);
-    LAUNCH(ctx, "dwpw2", (dwpw2_x3_kernel<<<dgrid, 256, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq)));
+    LAUNCH(ctx, "dwpw2", (dwpw2_x3_kernel<<<dgrid, 64 * DP_WAVES, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq)));
     if (taps) {
         hipMemcpyAsync(taps + (size_t)2 * M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
         LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, FFN_WAVES><<<ffn_grid(flat_tiles), 64 * FFN_WAVES, 0, s>>>(
