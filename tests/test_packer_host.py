@@ -159,3 +159,12 @@ def test_committed_bench_line_carries_the_contract_fields():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+
+
+def test_public_header_is_valid_c_and_cxx():
+    """include/cmgan_hip.h is the drop-in boundary: it must compile on its own as C99 and as C++."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = os.path.join(root, "include", "cmgan_hip.h")
+    subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-Werror", hdr], check=True)
+    subprocess.run(["g++", "-fsyntax-only", "-x", "c++", "-Wall", "-Wextra", "-Werror", hdr], check=True)
