@@ -2,18 +2,26 @@
 """Benchmark of the CMGAN generator forward path on MI355X (BASELINE.json metric:
 enhanced audio frames/sec, 16 kHz, 2 s clips, batch 32 per GPU).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 16k|48k]
 
 A "step" = one pass of the whole device pipeline (RMS scale -> STFT -> power compress ->
-TSCNet -> power uncompress -> ISTFT) over one batch of 32 synthetic 2 s clips per GPU that
-are already resident in HBM.  For N > 1 the driver launches one rank per GPU with
-torch.distributed.run; utterances are sharded by rank (weak scaling: 32 clips per GPU), the
-forward needs no collective, and each step ends with ONE all-reduce of two scalars
-(RCCL over xGMI), as north_star specifies.  Rank 0 prints one JSON line.
+TSCNet -> power uncompress -> ISTFT) over one batch of synthetic 2 s clips per GPU that are
+already resident in HBM, followed by the validation-step loss scalars (a HIP reduction from
+the library, src/train.py:139-141) and ONE all-reduce of them (RCCL over xGMI), as north_star
+specifies.  Utterances are sharded by rank (weak scaling: 32 clips per GPU); the forward
+needs no collective.
+
+`--gpus N` launches the N ranks itself (one process per GPU under torch.distributed.run, like
+the reference's mp.spawn in src/train.py:294-297) unless it is already running as a rank of
+such a launch (WORLD_SIZE set by the driver); a world size that differs from --gpus, or fewer
+visible GPUs than requested, is a hard error - never a silent 1-GPU run.  Rank 0 prints one
+JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,21 +30,36 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-CLIP_LEN = 32000          # 2 s @ 16 kHz                       (src/train.py:22)
-BATCH_PER_GPU = 32        # BASELINE.json configs[1]
-N_FFT, HOP = 400, 100
-T_FRAMES = CLIP_LEN // HOP + 1                                 # 321 (src/train.py:53)
-F_BINS, F2 = 201, 101
 FP32_MFMA_PEAK_TF = 157.3                                      # MI355X_MICROARCH.md (f32 in / f32 acc MFMA)
 F16_MFMA_PEAK_TF = 2500.0                                      # dense f16/bf16 MFMA (not the 2:1-sparse headline)
 HBM_PEAK_GBS = 8000.0
 
+# BASELINE.json configs: [1] is the metric's workload; [3] (48 kHz) is measured with --workload 48k
+WORKLOADS = {
+    "16k": dict(n_fft=400, hop=100, clip_len=32000, batch=32,            # src/train.py:22,47-48,53
+                name="configs[1]: batch=32 x 2 s synthetic 16 kHz noisy clips per GPU, n_fft=400 hop=100, "
+                     "TSCNet(64,201) random-init, full pipeline wav->wav",
+                metric="enhanced audio frames/sec (16 kHz, 2 s clips, batch 32 per GPU)"),
+    "48k": dict(n_fft=1200, hop=300, clip_len=96000, batch=8,
+                name="configs[3]: batch=8 x 2 s synthetic 48 kHz clips per GPU, n_fft=1200 hop=300, "
+                     "TSCNet(64,601) random-init, full pipeline wav->wav",
+                metric="enhanced audio frames/sec (48 kHz super-wideband variant, 2 s clips, batch 8 per GPU)"),
+}
 
-def flops_per_clip():
-    """Algorithmic FLOPs (2 x MAC) per 2 s clip by kernel family."""
-    P, P2, T = T_FRAMES * F_BINS, T_FRAMES * F2, T_FRAMES
+
+class Shape:
+    def __init__(self, wl):
+        self.n_fft, self.hop, self.L, self.B = wl["n_fft"], wl["hop"], wl["clip_len"], wl["batch"]
+        self.F = self.n_fft // 2 + 1
+        self.F2 = (self.F + 1) // 2
+        self.T = self.L // self.hop + 1                                    # 321 (src/train.py:53)
+
+
+def flops_per_clip(sh: Shape):
+    """Algorithmic FLOPs (2 x MAC) per clip by kernel family."""
+    T, P, P2, F2 = sh.T, sh.T * sh.F, sh.T * sh.F2, sh.F2
     per_tok_ffn = 2 * (64 * 256 + 256 * 64)
-    fl = {
+    return {
         "conv_in": 2 * 3 * 64 * P,
         "conv_dense": 491520 * P + 2 * 491520 * P2,
         "conv_1x3": 2 * 3 * 64 * 64 * P2,
@@ -47,131 +70,117 @@ def flops_per_clip():
         "qkv": 8 * 2 * 64 * 192 * P2,
         "outproj": 8 * 2 * 64 * 64 * P2,
         "attn": 4 * 384 * (F2 * T * T + T * F2 * F2),
+        "attn_out": 4 * 384 * (F2 * T * T + T * F2 * F2) + 8 * 2 * 64 * 64 * P2,   # attention + to_out fused
         "pw1glu": 8 * 2 * 64 * 256 * P2,
         "dwconv": 8 * 2 * 31 * 128 * P2,
         "pw2": 8 * 2 * 128 * 64 * P2,
         "dwpw2": 8 * 2 * (31 * 128 + 128 * 64) * P2,      # fused depthwise + pointwise (x3 mode)
     }
-    return fl
 
 
-def hbm_bytes_per_clip():
-    """Algorithmic (compulsory) HBM bytes per 2 s clip by kernel family at the current fusion level:
+# families that are the same arithmetic under a different fusion: counted once in the path total
+_FUSED_ALIASES = {"dwpw2": ("dwconv", "pw2"), "attn_out": ("attn", "outproj")}
+
+
+def path_flops_per_clip(sh: Shape) -> float:
+    fl = flops_per_clip(sh)
+    return float(sum(v for k, v in fl.items() if k not in _FUSED_ALIASES))
+
+
+def hbm_bytes_per_clip(sh: Shape):
+    """Algorithmic (compulsory) HBM bytes per clip by kernel family at the current fusion level:
     every kernel-boundary tensor written once and read once per consumer, fp32."""
-    P, P2 = T_FRAMES * F_BINS, T_FRAMES * F2
+    P, P2 = sh.T * sh.F, sh.T * sh.F2
     row = 64 * 4
     return {
         # dense blocks: layer i reads i slots and writes one; encoder at F, two decoders at F'
         "conv_dense": (10 + 4) * P * row + 2 * (10 + 4) * P2 * row,
         "attn": 8 * (3 * P2 * row + P2 * row),          # q, k, v images in, o out
+        "attn_out": 8 * (3 * P2 * row + 2 * P2 * row),  # q, k, v in; residual read + write (o stays on chip)
         "ffn": 8 * 2 * P2 * row, "ffn_post": 8 * 3 * P2 * row,
         "qkv": 8 * 4 * P2 * row, "outproj": 8 * 3 * P2 * row,
         "pw1glu": 8 * 3 * P2 * row, "dwconv": 8 * 4 * P2 * row, "pw2": 8 * 4 * P2 * row,
         "dwpw2": 8 * 4 * P2 * row,                          # u in (2 rows of 64), x in, x out
-        "stft_compress": 4 * CLIP_LEN + 8 * F_BINS * T_FRAMES,
+        "stft_compress": 4 * sh.L + 8 * sh.F * sh.T,
     }
 
 
-def cpu_baseline(sd, seconds_budget=20.0):
-    """The oracle (CPU restatement of the reference path, torch fp32 on the host cores) timed on a
-    bounded sample of the same workload: B=1 clips of the same shape, repeated.  torch's intra-op
-    pool scales badly past a few dozen threads on these small ops, so a short sweep picks the
-    thread count with the best throughput and the figure is quoted at that count."""
+def csrc_digest() -> str:
+    from cmgan_amd import build as _build
+    return _build._digest()[:16]
+
+
+def cpu_baseline(sd, sh: Shape, seconds_budget=20.0):
+    """The oracle (CPU restatement of the reference path, torch fp32 on the host cores: kind = "port") timed on a
+    bounded sample of the same workload: B=1 clips of the same shape (thread-count sweep, then repeated at the
+    best count) plus one B=4 point (SURVEY.md 8d).  The reference's own modules cannot travel to the GPU box;
+    their speed relative to this port was measured once in the build container."""
     from oracle import cmgan_oracle as O
-    from oracle.weights import synthetic_clips
-    wav = synthetic_clips(1, CLIP_LEN, seed=0)
+    from cmgan_amd.synth import synthetic_clips
+    wav = synthetic_clips(1, sh.L, seed=0)
     ncpu = os.cpu_count() or 1
     cands = sorted({c for c in (8, 16, 32, 64) if c <= ncpu} | ({ncpu} if ncpu <= 64 else set()))
     best, best_t = cands[0], float("inf")
     t_start = time.perf_counter()
     for c in cands:
         torch.set_num_threads(c)
-        O.enhance_batch(sd, wav)                               # warm-up at this thread count
+        O.enhance_batch(sd, wav, sh.n_fft, sh.hop)             # warm-up at this thread count
         t0 = time.perf_counter()
-        O.enhance_batch(sd, wav)
+        O.enhance_batch(sd, wav, sh.n_fft, sh.hop)
         dt = time.perf_counter() - t0
         if dt < best_t:
             best, best_t = c, dt
         if time.perf_counter() - t_start > seconds_budget:
             break
     torch.set_num_threads(best)
-    O.enhance_batch(sd, wav)
+    O.enhance_batch(sd, wav, sh.n_fft, sh.hop)
     n, t0 = 0, time.perf_counter()
     while True:
-        O.enhance_batch(sd, wav)
+        O.enhance_batch(sd, wav, sh.n_fft, sh.hop)
         n += 1
         dt = time.perf_counter() - t0
         if dt >= seconds_budget * 0.5 or n >= 12:
             break
-    return {"value": n * T_FRAMES / dt, "unit": "frames/s", "cores": best, "host_cpus": ncpu, "kind": "port",
+    wav4 = synthetic_clips(4, sh.L, seed=1)
+    t4 = time.perf_counter()
+    O.enhance_batch(sd, wav4, sh.n_fft, sh.hop)
+    dt4 = time.perf_counter() - t4
+    return {"value": n * sh.T / dt, "unit": "frames/s", "cores": best, "host_cpus": ncpu, "kind": "port",
             "sample": f"{n} x (B=1, 2 s clip, full pipeline wav->wav) at {best} threads (best of {cands}), "
-                      f"{dt:.1f} s timed"}
+                      f"{dt:.1f} s timed",
+            "b4": {"value": 4 * sh.T / dt4, "unit": "frames/s", "cores": best,
+                   "sample": f"1 x (B=4, 2 s clips) at {best} threads, {dt4:.1f} s"},
+            "kind_note": "port = oracle/cmgan_oracle.py (torch CPU restatement pinned to the reference by "
+                         "tests/golden); the reference's own nn.Modules, which cannot travel to the GPU box, ran 1.7x (B=1) / "
+                         "1.3x (B=4) FASTER than this port in the build container (8 cores; DESIGN.md section 5), "
+                         "so scale this figure by that to compare against the reference itself"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--mfma-mode", choices=["f16x3", "f32"], default="f16x3",
-                    help="f16x3: fp32-accurate 3-term split products on the f16 matrix pipe (default); "
-                         "f32: bit-exact fp32 MFMA")
-    args = ap.parse_args()
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    from cmgan_amd import TSCNet, dist as cdist
-    from oracle.weights import make_state_dict, synthetic_clips
 
-    rank, local, world = cdist.init_from_env()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
+def launch_ranks(args) -> int:
+    """One process per GPU on this node (the reference: mp.spawn(main, nprocs=#GPUs), src/train.py:294-297)."""
+    if not args.stub_cpu:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to fall "
+                  "back to fewer ranks", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC for RCCL on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
 
-    sd = make_state_dict(seed=0)                               # random-init weights of the architecture
-    model = TSCNet(64, F_BINS, device=dev, mfma_mode=args.mfma_mode).load_state_dict(sd).eval()
-    eng = model.engine
-    wav = synthetic_clips(BATCH_PER_GPU, CLIP_LEN, seed=rank).to(dev)    # resident in HBM before timing
-    scal = torch.zeros(2, device=dev)
 
-    run = eng.enhance if args.no_graph else eng.enhance_graphed
-
-    def step():
-        out = run(wav)
-        # two per-step "loss" scalars (time-domain L1 / L2 against the input) and their single all-reduce
-        d = out - wav
-        scal[0] = d.abs().mean()
-        scal[1] = (d * d).mean()
-        cdist.allreduce_scalars(scal)
-        return out
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        torch.distributed.all_reduce(et, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(et.item())
-
-    # ---- per-kernel durations, measured live with HIP events on the launch stream ----------
+def kernel_table(eng, wav, reps=3):
+    """Per-kernel durations of one forward, measured live with HIP events on the launch stream."""
     eng.set_profiling(True)
     agg = {}
-    reps = 3
     for _ in range(reps):
         eng.enhance(wav)
         torch.cuda.synchronize()
@@ -180,80 +189,247 @@ def main():
             a[0] += ms
             a[1] += 1
     eng.set_profiling(False)
+    return {k: {"ms_per_step": v[0] / reps, "launches_per_step": v[1] // reps} for k, v in agg.items()}
 
+
+def roofline_of(kern, sh: Shape, x3: bool, pmc_traffic=None, traffic_src=None):
+    fl = flops_per_clip(sh)
+    hb = hbm_bytes_per_clip(sh)
+    peak_tf = F16_MFMA_PEAK_TF if x3 else FP32_MFMA_PEAK_TF
+    dom = max((k for k in kern if k in fl), key=lambda k: kern[k]["ms_per_step"])
+    dom_s = kern[dom]["ms_per_step"] * 1e-3
+    dom_tf = fl[dom] * sh.B / dom_s / 1e12
+    n_launch = max(1, kern[dom]["launches_per_step"])
+    roof = {"bound": "mfma", "kernel": dom, "achieved": round(dom_tf, 2), "peak": peak_tf,
+            "unit": "TFLOP/s", "frac": round(dom_tf / peak_tf, 4), "traffic": None,
+            "launches_per_step": kern[dom]["launches_per_step"],
+            "avg_launch_ms": round(kern[dom]["ms_per_step"] / n_launch, 4),
+            "note": ("algorithmic FLOPs; the f16x3 mode issues 3 MFMA products per algorithmic product, so the "
+                     "matrix pipe is doing 3x this" if x3 else "exact fp32 MFMA")}
+    if dom in hb:
+        roof["algorithmic_hbm_bytes_per_launch"] = round(hb[dom] * sh.B / n_launch)
+    if pmc_traffic is not None and dom in pmc_traffic:
+        roof["traffic"] = pmc_traffic[dom]["hbm_bytes"]
+        roof["traffic_note"] = ("HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, "
+                                "from " + traffic_src)
+    return roof, dom
+
+
+def load_pmc_traffic(x3: bool, sh: Shape, workload: str):
+    """HBM bytes per launch from the committed PMC passes of this same command (the counters cannot be read from
+    inside the process).  Only used when the file was produced from EXACTLY the kernel sources now built
+    (csrc digest match) at the same workload: a kernel edit without a profile refresh publishes null, not
+    stale counters."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{'x3' if x3 else 'fp32'}_hbm_traffic.json")))
+    for path in reversed(cands):
+        with open(path) as f:
+            d = json.load(f)
+        if d.get("csrc_digest") == csrc_digest() and d.get("workload", "16k") == workload and \
+                d.get("batch", 32) == sh.B:
+            return d.get("per_launch", {}), "profiles/" + os.path.basename(path), None
+    why = "no profiles/*_hbm_traffic.json matches the built kernel sources (digest %s)" % csrc_digest()
+    return None, None, why
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="16k")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32", action="store_true", help="skip the bit-exact fp32-MFMA mode leg of the line")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--mfma-mode", choices=["f16x3", "f32"], default="f16x3",
+                    help="f16x3: fp32-accurate 3-term split products on the f16 matrix pipe (default); "
+                         "f32: bit-exact fp32 MFMA")
+    ap.add_argument("--stub-cpu", action="store_true",
+                    help="launcher / collective self-test without a GPU: gloo backend, the forward replaced by a "
+                         "trivial CPU op (tests/test_bench_launcher.py); prints a line marked \"stub\": true")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+
+    from cmgan_amd import dist as cdist
+    from cmgan_amd.synth import make_state_dict, synthetic_clips
+
+    rank, local, world = cdist.init_from_env("gloo" if args.stub_cpu else None)
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launch has WORLD_SIZE={world}; refusing to mislabel the run",
+              file=sys.stderr)
+        sys.exit(2)
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.batch:
+        wl["batch"] = args.batch
+    sh = Shape(wl)
+    x3 = args.mfma_mode == "f16x3"
+
+    if args.stub_cpu:
+        dev = torch.device("cpu")
+        wav = synthetic_clips(2, 1600, seed=rank)
+        clean = synthetic_clips(2, 1600, seed=100 + rank)
+        scal = torch.zeros(4)
+
+        def step():
+            out = wav * 0.5
+            d = out - clean
+            scal[2], scal[3] = d.abs().mean(), (d * d).mean()
+            cdist.allreduce_scalars(scal[2:4])
+            return out
+
+        def sync():
+            pass
+    else:
+        from cmgan_amd import TSCNet
+        if torch.cuda.device_count() <= local:
+            print(f"bench.py: rank {rank} needs cuda:{local} but only {torch.cuda.device_count()} GPU(s) are visible",
+                  file=sys.stderr)
+            sys.exit(2)
+        torch.cuda.set_device(local)
+        dev = torch.device(f"cuda:{local}")
+        sd = make_state_dict(seed=0, num_features=sh.F)        # random-init weights of the architecture
+        model = TSCNet(64, sh.F, n_fft=sh.n_fft, hop=sh.hop, device=dev, mfma_mode=args.mfma_mode)
+        model.load_state_dict(sd).eval()
+        eng = model.engine
+        wav = synthetic_clips(sh.B, sh.L, seed=rank).to(dev)            # resident in HBM before timing
+        clean = synthetic_clips(sh.B, sh.L, seed=1000 + rank).to(dev)   # validation target (src/train.py:207-220)
+        scal = torch.zeros(4, device=dev)
+        run = eng.enhance if args.no_graph else eng.enhance_graphed
+
+        def step():
+            out = run(wav)
+            # the validation step's time-domain loss scalars (train.py:139-141): one HIP reduction from the
+            # library, then the path's single collective
+            eng.loss_terms(est_audio=out, clean_audio=clean, out=scal)
+            cdist.allreduce_scalars(scal[2:4])
+            return out
+
+        def sync():
+            torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    # did the collective really span `world` ranks?
+    ones = torch.ones(1, device=dev)
+    cdist.allreduce_scalars(ones)
+    ranks_seen = int(round(float(ones.item())))
+    backend = torch.distributed.get_backend() if world > 1 else "none (single process)"
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    own = time.perf_counter() - t0                            # this rank's K steps
+    barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    et = torch.tensor([elapsed, own], device=dev, dtype=torch.float64)
+    per_rank = [et.clone() for _ in range(world)]
+    if world > 1:
+        torch.distributed.all_gather(per_rank, et)
+    elapsed = max(float(t[0]) for t in per_rank)              # MAX over ranks
+    unit_frames = sh.B * sh.T if not args.stub_cpu else 2 * 17
+    per_rank_fps = [unit_frames * args.steps / float(t[1]) for t in per_rank]
+    loss_scalars = [float(v) / world for v in scal[2:4].tolist()]
+
+    line = None
     if rank == 0:
-        frames_per_step = world * BATCH_PER_GPU * T_FRAMES
+        frames_per_step = world * unit_frames
         ms_per_step = 1e3 * elapsed / args.steps
-        fl = flops_per_clip()
-        total_flop = sum(v for k, v in fl.items() if k != "dwpw2") * BATCH_PER_GPU   # algorithmic, fusion-independent
-        kern = {k: {"ms_per_step": v[0] / reps, "launches_per_step": v[1] // reps} for k, v in agg.items()}
-        dom = max((k for k in kern if k in fl), key=lambda k: kern[k]["ms_per_step"])
-        x3 = args.mfma_mode == "f16x3"
-        peak_tf = F16_MFMA_PEAK_TF if x3 else FP32_MFMA_PEAK_TF
-        dom_s = kern[dom]["ms_per_step"] * 1e-3
-        dom_tf = fl[dom] * BATCH_PER_GPU / dom_s / 1e12
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(dom_tf, 2), "peak": peak_tf,
-                "unit": "TFLOP/s", "frac": round(dom_tf / peak_tf, 4), "traffic": None,
-                "launches_per_step": kern[dom]["launches_per_step"],
-                "avg_launch_ms": round(kern[dom]["ms_per_step"] / max(1, kern[dom]["launches_per_step"]), 4),
-                "note": ("algorithmic FLOPs; the f16x3 mode issues 3 MFMA products per algorithmic product, so the "
-                         "matrix pipe is doing 3x this" if x3 else "exact fp32 MFMA")}
-        # HBM bytes per launch from the committed PMC passes of this same command (profiles/README.md);
-        # the counters cannot be read from inside the process, so this is the one field not measured live
-        tsrc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                            "r01_x3_hbm_traffic.json" if x3 else "r01_fp32_hbm_traffic.json")
-        pmc_traffic = {}
-        if os.path.exists(tsrc):
-            with open(tsrc) as f:
-                pmc_traffic = json.load(f).get("per_launch", {})
-        if dom in pmc_traffic and BATCH_PER_GPU == 32:
-            roof["traffic"] = pmc_traffic[dom]["hbm_bytes"]
-            roof["traffic_note"] = ("HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + WRITE_SIZE, "
-                                    "from profiles/" + os.path.basename(tsrc))
-            roof["algorithmic_hbm_bytes_per_launch"] = round(
-                hbm_bytes_per_clip().get(dom, 0) * BATCH_PER_GPU / max(1, kern[dom]["launches_per_step"]))
-        hb = hbm_bytes_per_clip()
-        extra = {}
-        # the same figure for every MFMA kernel family (the dominant one changes with a few % of run-to-run noise:
-        # attention and the dense convs are within 3 % of each other)
-        extra["roofline_by_kernel"] = {
-            k: {"ms_per_step": round(kern[k]["ms_per_step"], 4),
-                "achieved_tflops": round(fl[k] * BATCH_PER_GPU / (kern[k]["ms_per_step"] * 1e-3) / 1e12, 2),
-                "frac_of_mfma_peak": round(fl[k] * BATCH_PER_GPU / (kern[k]["ms_per_step"] * 1e-3) / 1e12 / peak_tf, 4),
-                "hbm_bytes_per_launch_pmc": pmc_traffic.get(k, {}).get("hbm_bytes")}
-            for k in sorted((k for k in kern if k in fl and fl[k] > 0), key=lambda k: -kern[k]["ms_per_step"])[:5]}
-        if dom in hb:
-            gbs = hb[dom] * BATCH_PER_GPU / dom_s / 1e9
-            extra["roofline_hbm"] = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
-                                     "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                                     "note": "algorithmic bytes (each boundary tensor written once, read once per consumer)"}
-        if "stft_compress" in kern:
-            gbs = hb["stft_compress"] * BATCH_PER_GPU / (kern["stft_compress"]["ms_per_step"] * 1e-3) / 1e9
-            extra["stft_hbm"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        value = frames_per_step * args.steps / elapsed
         line = {
-            "metric": "enhanced audio frames/sec (16 kHz, 2 s clips, batch 32 per GPU)",
-            "value": frames_per_step * args.steps / elapsed,
+            "metric": wl["metric"],
+            "value": value,
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 storage/accumulate; products as 3 x f16 split MFMA (fp32-class accuracy)" if x3 else "f32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: batch=32 x 2 s synthetic 16 kHz noisy clips per GPU, n_fft=400 "
-                                   "hop=100, TSCNet(64,201) random-init, full pipeline wav->wav",
-                       "mfma_mode": args.mfma_mode, "launch": "eager" if args.no_graph else "hipGraph replay",
-                       "batch_per_gpu": BATCH_PER_GPU, "global_batch": world * BATCH_PER_GPU,
-                       "frames_per_clip": T_FRAMES, "parallelism": f"dp{world}"},
-            "path_tflops": round(total_flop / (ms_per_step * 1e-3) / 1e12, 2),
-            "path_frac_of_mfma_peak": round(total_flop / (ms_per_step * 1e-3) / 1e12 / peak_tf, 4),
-            "roofline": roof,
-            "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items(),
-                                                                                   key=lambda kv: -kv[1]["ms_per_step"])},
+            "config": {"workload": wl["name"], "mfma_mode": args.mfma_mode,
+                       "launch": "eager" if args.no_graph else "hipGraph replay",
+                       "batch_per_gpu": sh.B, "global_batch": world * sh.B,
+                       "frames_per_clip": sh.T, "parallelism": f"dp{world}"},
+            "per_rank_frames_per_s": [round(v, 1) for v in per_rank_fps],
+            "scaling_efficiency_vs_rank_sum": round(value / sum(per_rank_fps), 4),
+            "collective": {"backend": ("nccl = RCCL" if backend == "nccl" else backend), "ranks_seen": ranks_seen,
+                           "per_step": "1 all-reduce of 2 fp32 loss scalars", "loss_scalars_mean": loss_scalars},
         }
-        line.update(extra)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(sd)
+        if args.stub_cpu:
+            line["stub"] = True
+            line["config"]["workload"] = "launcher self-test (CPU stub, gloo)"
+
+    if not args.stub_cpu:
+        kern = kernel_table(eng, wav)
+        if rank == 0:
+            total_flop = path_flops_per_clip(sh) * sh.B                  # algorithmic, fusion-independent
+            peak_tf = F16_MFMA_PEAK_TF if x3 else FP32_MFMA_PEAK_TF
+            pmc, src, why = load_pmc_traffic(x3, sh, args.workload)
+            roof, dom = roofline_of(kern, sh, x3, pmc, src)
+            if pmc is None:
+                roof["traffic_note"] = why
+            fl, hb = flops_per_clip(sh), hbm_bytes_per_clip(sh)
+            line["csrc_digest"] = csrc_digest()
+            line["path_tflops"] = round(total_flop / (ms_per_step * 1e-3) / 1e12, 2)
+            line["path_frac_of_mfma_peak"] = round(total_flop / (ms_per_step * 1e-3) / 1e12 / peak_tf, 4)
+            line["roofline"] = roof
+            line["kernels_ms_per_step"] = {k: round(v["ms_per_step"], 4)
+                                           for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+            # the same figure for every MFMA kernel family (the top two are within a few % of each other)
+            line["roofline_by_kernel"] = {
+                k: {"ms_per_step": round(kern[k]["ms_per_step"], 4),
+                    "achieved_tflops": round(fl[k] * sh.B / (kern[k]["ms_per_step"] * 1e-3) / 1e12, 2),
+                    "frac_of_mfma_peak": round(fl[k] * sh.B / (kern[k]["ms_per_step"] * 1e-3) / 1e12 / peak_tf, 4),
+                    "hbm_bytes_per_launch_pmc": (pmc or {}).get(k, {}).get("hbm_bytes")}
+                for k in sorted((k for k in kern if k in fl and fl[k] > 0), key=lambda k: -kern[k]["ms_per_step"])[:5]}
+            if dom in hb:
+                gbs = hb[dom] * sh.B / (kern[dom]["ms_per_step"] * 1e-3) / 1e9
+                line["roofline_hbm"] = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS,
+                                        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                        "note": "algorithmic bytes (each boundary tensor written once, read once per consumer)"}
+            if "stft_compress" in kern:
+                gbs = hb["stft_compress"] * sh.B / (kern["stft_compress"]["ms_per_step"] * 1e-3) / 1e9
+                line["stft_hbm"] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+        # ---- the bit-exact fp32-MFMA mode of the same library, in the same line (N = 1 only) -------------
+        if world == 1 and x3 and not args.no_f32:
+            eng._graphs.clear()
+            m32 = TSCNet(64, sh.F, n_fft=sh.n_fft, hop=sh.hop, device=dev, mfma_mode="f32").load_state_dict(sd).eval()
+            e32 = m32.engine
+            k32 = max(2, min(args.steps, 5))
+            e32.enhance(wav)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k32):
+                e32.enhance(wav)
+            torch.cuda.synchronize()
+            dt32 = (time.perf_counter() - t0) / k32
+            kern32 = kernel_table(e32, wav, reps=1)
+            roof32, _ = roofline_of(kern32, sh, False)
+            line["f32_mode"] = {"ms_per_step": round(1e3 * dt32, 3), "value": round(sh.B * sh.T / dt32, 1),
+                                "unit": "frames/s", "steps": k32, "launch": "eager", "dtype": "f32 (exact fp32 MFMA products)",
+                                "path_frac_of_fp32_mfma_peak": round(path_flops_per_clip(sh) * sh.B / dt32 / 1e12 /
+                                                                     FP32_MFMA_PEAK_TF, 4),
+                                "roofline": roof32}
+            del m32, e32
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd, sh)
+
+    if rank == 0:
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMGAN_HIP_LIB") or os.path.join(HERE, "lib", "libcmgan_hip.so")
 
 OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 MFMA_F32, MFMA_F16X3 = 0, 1
 
 
@@ -47,6 +47,9 @@ SIGNATURES = {
     "cmgan_destroy": (None, [c_void_p]),
     "cmgan_last_error": (c_char_p, [c_void_p]),
     "cmgan_load_weights": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "cmgan_weights_generation": (c_int, [c_void_p]),
+    "cmgan_loss_terms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
+                                 c_void_p, c_void_p]),
     "cmgan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "cmgan_rms_scale": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "cmgan_num_frames": (c_int, [c_void_p, c_int]),

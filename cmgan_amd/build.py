@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcmgan_hip.so")
-SOURCES = ["api.hip", "conformer.hip", "conformer_x3.hip", "conv.hip", "conv_x3.hip", "stft.hip"]
+SOURCES = ["api.hip", "conformer.hip", "conformer_x3.hip", "conv.hip", "conv_x3.hip", "stft.hip", "train.hip"]
 HEADERS = ["common.hip.h", "kernels.h", "weights.h", os.path.join("..", "..", "include", "cmgan_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -packed-fp32-ops: v_pk_{fma,mul,add}_f32 issue slower than the scalar pair they replace when the SIMD is

@@ -25,10 +25,12 @@ struct cmgan_handle {
     // tables
     float* d_tables = nullptr;
     void* d_fold = nullptr;               // folded-DFT fp16 hi/lo images (x3 mode, n_fft 400)
+    double* d_loss = nullptr;             // LOSS_BLOCKS x 4 partial sums of cmgan_loss_terms
     SpectralTables st{};
     // weights
     float* d_weights = nullptr;
     size_t weight_floats = 0;
+    int weights_generation = 0;           // bumped by every successful cmgan_load_weights (stale-graph detection)
     std::map<uint32_t, WEntry> dir;
     // x3 (f16 split) operand images, built from the fp32 fragment-major weights at load time
     _Float16* d_w16 = nullptr;
@@ -191,6 +193,13 @@ extern "C" int cmgan_create(cmgan_handle** out, const cmgan_config* cfg) {
         delete h;
         return CMGAN_E_HIP;
     }
+    e = hipMalloc(&h->d_loss, (size_t)LOSS_BLOCKS * 4 * sizeof(double));
+    if (e != hipSuccess) {
+        fail(nullptr, CMGAN_E_HIP, "loss scratch: %s", hipGetErrorString(e));
+        hipFree(h->d_tables);
+        delete h;
+        return CMGAN_E_HIP;
+    }
     h->st.n_fft = N; h->st.hop = cfg->hop; h->st.F = F; h->st.FB = FB;
     h->st.fwd_fm = h->d_tables; h->st.inv_fm = h->d_tables + n_fwd; h->st.window = h->d_tables + n_fwd + n_inv;
     h->st.fold_fwd16 = nullptr; h->st.fold_inv16 = nullptr;
@@ -205,6 +214,7 @@ extern "C" int cmgan_create(cmgan_handle** out, const cmgan_config* cfg) {
         if (e != hipSuccess) {
             fail(nullptr, CMGAN_E_HIP, "folded DFT upload: %s", hipGetErrorString(e));
             hipFree(h->d_tables);
+            hipFree(h->d_loss);
             if (h->d_fold) hipFree(h->d_fold);
             delete h;
             return CMGAN_E_HIP;
@@ -220,6 +230,7 @@ extern "C" void cmgan_destroy(cmgan_handle* h) {
     if (!h) return;
     if (h->d_tables) hipFree(h->d_tables);
     if (h->d_fold) hipFree(h->d_fold);
+    if (h->d_loss) hipFree(h->d_loss);
     if (h->d_weights) hipFree(h->d_weights);
     if (h->d_w16) hipFree(h->d_w16);
     for (auto ev : h->prof.pool) hipEventDestroy(ev);
@@ -312,7 +323,9 @@ static void x3_conv_image(const float* fm, int nchunk16, int taps, int CB, std::
                     }
 }
 
-static int build_x3_images(cmgan_handle* h, const float* payload, const std::map<uint32_t, WEntry>& dir) {
+// host-side only: the caller uploads the image and swaps it in together with the fp32 payload
+static int build_x3_images(const float* payload, const std::map<uint32_t, WEntry>& dir,
+                           std::vector<_Float16>& host_img, std::map<uint32_t, size_t>& d16_out) {
     std::vector<_Float16> img;
     std::map<uint32_t, size_t> d16;
     auto pad = [&]() { while (img.size() % 64) img.push_back((_Float16)0.f); };
@@ -349,10 +362,8 @@ static int build_x3_images(cmgan_handle* h, const float* payload, const std::map
         }
     }
     pad();
-    if (h->d_w16) { hipFree(h->d_w16); h->d_w16 = nullptr; }
-    HIPCHK(h, hipMalloc(&h->d_w16, img.size() * sizeof(_Float16) + 256));
-    HIPCHK(h, hipMemcpy(h->d_w16, img.data(), img.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-    h->dir16.swap(d16);
+    host_img.swap(img);
+    d16_out.swap(d16);
     return CMGAN_OK;
 }
 
@@ -376,16 +387,37 @@ extern "C" int cmgan_load_weights(cmgan_handle* h, const void* blob, size_t byte
         if (want != cnt) return fail(h, CMGAN_E_WEIGHTS, "weight id %u has %u floats, expected %zu", id, cnt, want);
         dir[id] = {off, cnt};
     }
+    // Atomic swap: the new fp32 payload and the new x3 image are built and uploaded into fresh buffers first; the
+    // handle's pointers and both directories change only after every step has succeeded, so a failed load leaves
+    // the previous weights fully usable.
+    std::vector<_Float16> img;
+    std::map<uint32_t, size_t> d16;
+    if (int rc = build_x3_images((const float*)((const char*)blob + head), dir, img, d16)) return rc;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipDeviceSynchronize());
-    if (h->d_weights) { hipFree(h->d_weights); h->d_weights = nullptr; }
-    HIPCHK(h, hipMalloc(&h->d_weights, (size_t)payload * 4 + 256));
-    HIPCHK(h, hipMemcpy(h->d_weights, (const char*)blob + head, (size_t)payload * 4, hipMemcpyHostToDevice));
+    float* nw = nullptr;
+    _Float16* nw16 = nullptr;
+    hipError_t e = hipMalloc(&nw, (size_t)payload * 4 + 256);
+    if (e == hipSuccess) e = hipMalloc(&nw16, img.size() * sizeof(_Float16) + 256);
+    if (e == hipSuccess) e = hipMemcpy(nw, (const char*)blob + head, (size_t)payload * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(nw16, img.data(), img.size() * sizeof(_Float16), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipDeviceSynchronize();          // no launch may still be reading the old buffers
+    if (e != hipSuccess) {
+        if (nw) hipFree(nw);
+        if (nw16) hipFree(nw16);
+        return fail(h, CMGAN_E_HIP, "cmgan_load_weights: %s (previous weights kept)", hipGetErrorString(e));
+    }
+    if (h->d_weights) hipFree(h->d_weights);
+    if (h->d_w16) hipFree(h->d_w16);
+    h->d_weights = nw;
+    h->d_w16 = nw16;
     h->weight_floats = payload;
-    if (int rc = build_x3_images(h, (const float*)((const char*)blob + head), dir)) return rc;
     h->dir.swap(dir);
+    h->dir16.swap(d16);
+    ++h->weights_generation;
     return CMGAN_OK;
 }
+
+extern "C" int cmgan_weights_generation(const cmgan_handle* h) { return h ? h->weights_generation : -1; }
 
 static const float* W(cmgan_handle* h, uint32_t id, bool& okflag) {
     auto it = h->dir.find(id);
@@ -508,8 +540,11 @@ static LaunchCtx begin(cmgan_handle* h, void* stream) {
 // ------------------------------------------------------------------------------------
 extern "C" int cmgan_num_frames(const cmgan_handle* h, int L) { return h ? L / h->cfg.hop + 1 : 0; }
 
-static int check_wave_len(cmgan_handle* h, int L) {
-    if (L <= 0 || L % h->cfg.hop != 0) return fail(h, CMGAN_E_BADSHAPE, "L=%d must be a positive multiple of hop=%d", L, h->cfg.hop);
+// torch.stft(center=True) takes any L > n_fft/2 and yields 1 + L / hop frames; only the fused wav -> wav call
+// (equal input and output length) needs a whole number of hops.
+static int check_wave_len(cmgan_handle* h, int L, bool whole_hops) {
+    if (L <= 0 || (whole_hops && L % h->cfg.hop != 0))
+        return fail(h, CMGAN_E_BADSHAPE, "L=%d must be a positive multiple of hop=%d", L, h->cfg.hop);
     if (L <= h->cfg.n_fft / 2) return fail(h, CMGAN_E_BADSHAPE, "L=%d must exceed n_fft/2=%d (reflect padding)", L, h->cfg.n_fft / 2);
     return CMGAN_OK;
 }
@@ -525,7 +560,7 @@ extern "C" int cmgan_stft_compress(cmgan_handle* h, const float* wav, const floa
                                    float* spec, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!wav || !spec || B <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_stft_compress: bad argument");
-    if (int rc = check_wave_len(h, L)) return rc;
+    if (int rc = check_wave_len(h, L, false)) return rc;
     launch_stft_compress(begin(h, stream), h->st, wav, scale, B, L, L / h->cfg.hop + 1, spec);
     return check_launch(h, "stft_compress");
 }
@@ -769,7 +804,7 @@ extern "C" int cmgan_enhance(cmgan_handle* h, const float* wav, int B, int L, fl
                              size_t ws_bytes, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!wav || !wav_out || B <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_enhance: bad argument");
-    if (int rc = check_wave_len(h, L)) return rc;
+    if (int rc = check_wave_len(h, L, true)) return rc;
     const int T = L / h->cfg.hop + 1;
     const WsPlan p = plan_ws(h->cfg, B, T);
     if (int rc = check_ws(h, ws, ws_bytes, p.total * sizeof(float))) return rc;
@@ -785,6 +820,24 @@ extern "C" int cmgan_enhance(cmgan_handle* h, const float* wav, int B, int L, fl
         return rc;
     launch_uncompress_istft(ctx, h->st, f + p.est, f + p.est + (size_t)B * P, f + p.scale, B, T, f + p.frames, wav_out);
     return check_launch(h, "enhance");
+}
+
+// ------------------------------------------------------------------------------------
+// training / validation step pieces (src/train.py)
+// ------------------------------------------------------------------------------------
+extern "C" int cmgan_loss_terms(cmgan_handle* h, const float* est_real, const float* est_imag,
+                                const float* clean_spec, int B, int T, const float* est_audio,
+                                const float* clean_audio, int L_audio, float* out4, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    const bool spec = est_real || est_imag || clean_spec, audio = est_audio || clean_audio;
+    if (!out4 || B <= 0 || (!spec && !audio)) return fail(h, CMGAN_E_BADARG, "cmgan_loss_terms: bad argument");
+    if (spec && (!est_real || !est_imag || !clean_spec || T <= 0))
+        return fail(h, CMGAN_E_BADARG, "cmgan_loss_terms: spectral terms need est_real, est_imag, clean_spec and T > 0");
+    if (audio && (!est_audio || !clean_audio || L_audio <= 0))
+        return fail(h, CMGAN_E_BADARG, "cmgan_loss_terms: time term needs est_audio, clean_audio and L_audio > 0");
+    launch_loss_terms(begin(h, stream), est_real, est_imag, clean_spec, B, (long)T * h->cfg.num_features, est_audio,
+                      clean_audio, (long)B * L_audio, h->d_loss, out4);
+    return check_launch(h, "loss_terms");
 }
 
 // ------------------------------------------------------------------------------------

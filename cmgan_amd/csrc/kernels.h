@@ -123,5 +123,11 @@ int  conv3x_ntiles(int T, int F, int cout);
 void launch_conv3_x3(LaunchCtx, const ConvArgs&, const void* w16, int B, int time_taps, int cout);
 void launch_selftest_x3(hipStream_t, const void* a_img, const float* b_fm, float* d, int M32);
 
+// ------------------------------- train.hip ---------------------------------------
+#define LOSS_BLOCKS 256                       // fixed partial-sum shape: results do not depend on the batch split
+void launch_loss_terms(LaunchCtx, const float* est_real, const float* est_imag, const float* clean_spec, int B,
+                       long P, const float* est_audio, const float* clean_audio, long naudio, double* partials,
+                       float* out4);
+
 // ------------------------------- selftest ---------------------------------------
 void launch_selftest_mfma(hipStream_t, const float* a_fm, const float* b_fm, float* d, int KB);

@@ -79,12 +79,16 @@ class DemandDataset(torch.utils.data.Dataset):
 
 def load_data(ds_dir: str, batch_size: int, n_cpu: int, cut_len: int):
     """(train_loader, test_loader) over `<ds_dir>/train` and `<ds_dir>/test`   (dataloader.py:53-81): batches of
-    `(clean [B, cut_len], noisy [B, cut_len], length [B])`, pinned, one DistributedSampler shard per rank.  The
-    reference requires an initialised process group; here a single process simply gets the whole set."""
+    `(clean [B, cut_len], noisy [B, cut_len], length [B])`, pinned, one DistributedSampler shard per rank.
+    The reference always samples through `DistributedSampler` (default shuffle=True) and needs an initialised
+    process group; a single process gets the same behaviour from a one-replica sampler, so BOTH splits are
+    shuffled exactly as there (yes, the reference shuffles the test split too).  The sampler is reachable as
+    `loader.sampler`; call `loader.sampler.set_epoch(e)` per epoch for a new permutation (the reference never
+    does, so it replays one fixed permutation - kept as its default here)."""
     def loader(split: str, drop_last: bool):
         ds = DemandDataset(os.path.join(ds_dir, split), cut_len)
         dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
-        sampler = DistributedSampler(ds) if dist_on else None
+        sampler = DistributedSampler(ds) if dist_on else DistributedSampler(ds, num_replicas=1, rank=0)
         return torch.utils.data.DataLoader(dataset=ds, batch_size=batch_size, pin_memory=torch.cuda.is_available(),
                                            shuffle=False, sampler=sampler, drop_last=drop_last, num_workers=n_cpu)
 

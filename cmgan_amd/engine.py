@@ -16,22 +16,34 @@ from . import _lib
 from ._lib import Config, KernelTime, Taps, check
 
 
-def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+def _f32c(t: torch.Tensor, name: str, device: Optional[torch.device] = None) -> torch.Tensor:
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name}: expected a torch.Tensor")
     if not t.is_cuda:
         raise RuntimeError(f"{name}: tensor must live on the GPU (cmgan_amd has no CPU path)")
     if t.dtype != torch.float32:
         raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    if device is not None and t.device != device:
+        raise RuntimeError(f"{name}: tensor is on {t.device} but this Engine is bound to {device} "
+                           "(one handle = one device; build one Engine per GPU)")
     return t.contiguous()
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _on_device(fn):
+    """Run an Engine method with the Engine's device current, so the launch stream, the workspace and the
+    handle's own buffers all belong to the same GPU even when another device is current in the caller."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        with torch.cuda.device(self.device):
+            return fn(self, *a, **k)
+    return wrapper
 
 
 class Engine:
-    """One handle = one device = one set of weights."""
+    """One handle = one device = one set of weights.  Not re-entrant: the workspace is shared by all calls,
+    so use an Engine from ONE stream at a time (the stream current on its device when a method is called)."""
 
     def __init__(self, n_fft: int = 400, hop: int = 100, num_features: Optional[int] = None,
                  num_tscb: int = 4, max_pos_emb: int = 512, device: Optional[torch.device] = None,
@@ -42,6 +54,10 @@ class Engine:
         if not torch.cuda.is_available():
             raise RuntimeError("cmgan_amd needs a ROCm GPU: torch.cuda.is_available() is False")
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise RuntimeError(f"cmgan_amd has no CPU path: device must be a GPU, got {self.device}")
+        if self.device.index is None:
+            self.device = torch.device(f"cuda:{torch.cuda.current_device()}")
         cfg = _lib.default_config()
         cfg.n_fft, cfg.hop = n_fft, hop
         cfg.num_features = num_features if num_features is not None else n_fft // 2 + 1
@@ -61,6 +77,8 @@ class Engine:
             raise _lib.CmganError(rc, msg.decode() if msg else "?")
         self._ws: Optional[torch.Tensor] = None
         self._cws: Optional[torch.Tensor] = None
+        self._graphs: dict = {}          # enhance_graphed: input shape -> (graph, in, out, token)
+        self._row_graphs: dict = {}      # streaming.enhance_windows: row shape -> (graph, in, out, token)
         self.weights_loaded = False
 
     def __del__(self):
@@ -75,20 +93,35 @@ class Engine:
     # ---- weights -------------------------------------------------------------------
     def load_blob(self, blob: np.ndarray):
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        # cmgan_load_weights re-allocates the device weight buffers: every captured graph holds kernel arguments
+        # pointing into the old ones, so they are dropped BEFORE the swap (a failed load keeps the old weights,
+        # and the graphs are simply re-captured on next use)
+        self._graphs.clear()
+        self._row_graphs.clear()
         with torch.cuda.device(self.device):
             check(self._h, self.lib.cmgan_load_weights(self._h, blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes))
         self.weights_loaded = True
 
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _in(self, t: torch.Tensor, name: str) -> torch.Tensor:
+        return self._in(t, name, self.device)
+
     # ---- workspace -----------------------------------------------------------------
     def _ws_token(self):
-        """Identity of the current workspace allocation: graphs captured on an older one are stale."""
-        return self._ws
+        """Identity of what a captured graph's kernel arguments point into: the workspace allocation and the
+        weight buffers (cmgan_weights_generation).  A graph whose token differs is stale and is re-captured."""
+        return (self._ws, self.lib.cmgan_weights_generation(self._h))
 
     def _workspace(self, B: int, T: int) -> torch.Tensor:
         need = self.lib.cmgan_workspace_bytes(self._h, B, T)
         if need == 0:
             raise ValueError(f"bad batch/frames ({B}, {T})")
         if self._ws is None or self._ws.numel() < need:
+            # graphs captured on the old allocation are stale AND keep it (multi-GB) alive: evict them all
+            self._graphs.clear()
+            self._row_graphs.clear()
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
@@ -108,48 +141,53 @@ class Engine:
         return L // self.cfg.hop + 1
 
     # ---- front / back end ----------------------------------------------------------
+    @_on_device
     def rms_scale(self, wav: torch.Tensor) -> torch.Tensor:
-        wav = _f32c(wav, "wav")
+        wav = self._in(wav, "wav")
         B, L = wav.shape
         out = torch.empty(B, dtype=torch.float32, device=wav.device)
-        check(self._h, self.lib.cmgan_rms_scale(self._h, wav.data_ptr(), B, L, out.data_ptr(), _stream()))
+        check(self._h, self.lib.cmgan_rms_scale(self._h, wav.data_ptr(), B, L, out.data_ptr(), self._stream()))
         return out
 
+    @_on_device
     def stft_compress(self, wav: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
-        wav = _f32c(wav, "wav")
+        wav = self._in(wav, "wav")
         B, L = wav.shape
-        sp = _f32c(scale, "scale").data_ptr() if scale is not None else None
+        sp = self._in(scale, "scale").data_ptr() if scale is not None else None
         out = torch.empty(B, 2, self.num_frames(L), self.F, dtype=torch.float32, device=wav.device)
-        check(self._h, self.lib.cmgan_stft_compress(self._h, wav.data_ptr(), sp, B, L, out.data_ptr(), _stream()))
+        check(self._h, self.lib.cmgan_stft_compress(self._h, wav.data_ptr(), sp, B, L, out.data_ptr(), self._stream()))
         return out
 
+    @_on_device
     def uncompress_istft(self, real: torch.Tensor, imag: torch.Tensor,
                          scale: Optional[torch.Tensor] = None) -> torch.Tensor:
-        real, imag = _f32c(real, "real"), _f32c(imag, "imag")
+        real, imag = self._in(real, "real"), self._in(imag, "imag")
         B, _, T, F = real.shape
         if F != self.F or imag.shape != real.shape:
             raise ValueError(f"expected 2 x [B,1,T,{self.F}], got {tuple(real.shape)} / {tuple(imag.shape)}")
         ws = self._workspace(B, T)
-        sp = _f32c(scale, "scale").data_ptr() if scale is not None else None
+        sp = self._in(scale, "scale").data_ptr() if scale is not None else None
         out = torch.empty(B, self.cfg.hop * (T - 1), dtype=torch.float32, device=real.device)
         check(self._h, self.lib.cmgan_uncompress_istft(self._h, real.data_ptr(), imag.data_ptr(), sp, B, T,
-                                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+                                                       out.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return out
 
+    @_on_device
     def power_compress(self, x: torch.Tensor) -> torch.Tensor:
-        x = _f32c(x, "x")
+        x = self._in(x, "x")
         B, F, T, two = x.shape
         assert two == 2
         y = torch.empty(B, 2, F, T, dtype=torch.float32, device=x.device)
-        check(self._h, self.lib.cmgan_power_compress(self._h, x.data_ptr(), B, F, T, y.data_ptr(), _stream()))
+        check(self._h, self.lib.cmgan_power_compress(self._h, x.data_ptr(), B, F, T, y.data_ptr(), self._stream()))
         return y
 
+    @_on_device
     def power_uncompress(self, real: torch.Tensor, imag: torch.Tensor) -> torch.Tensor:
-        real, imag = _f32c(real, "real"), _f32c(imag, "imag")
+        real, imag = self._in(real, "real"), self._in(imag, "imag")
         B, one, F, T = real.shape
         y = torch.empty(B, 1, F, T, 2, dtype=torch.float32, device=real.device)
         check(self._h, self.lib.cmgan_power_uncompress(self._h, real.data_ptr(), imag.data_ptr(), B, F, T,
-                                                       y.data_ptr(), _stream()))
+                                                       y.data_ptr(), self._stream()))
         return y
 
     # ---- model ---------------------------------------------------------------------
@@ -157,9 +195,10 @@ class Engine:
         if not self.weights_loaded:
             raise RuntimeError("no weights loaded: call load_state_dict() first")
 
+    @_on_device
     def tscnet_forward(self, x: torch.Tensor, taps: bool = False):
         self._need_weights()
-        x = _f32c(x, "x")
+        x = self._in(x, "x")
         B, two, T, F = x.shape
         if two != 2 or F != self.F:
             raise ValueError(f"expected [B,2,T,{self.F}], got {tuple(x.shape)}")
@@ -168,7 +207,7 @@ class Engine:
         imag = torch.empty_like(real)
         if not taps:
             check(self._h, self.lib.cmgan_tscnet_forward(self._h, x.data_ptr(), B, T, real.data_ptr(),
-                                                         imag.data_ptr(), ws.data_ptr(), ws.numel(), _stream()))
+                                                         imag.data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
             return real, imag
         F2 = (F + 1) // 2
         st = {"encoder": torch.empty(B, 64, T, F2, dtype=torch.float32, device=x.device),
@@ -182,12 +221,13 @@ class Engine:
         tp.mask_dev, tp.complex_dev = st["mask"].data_ptr(), st["complex"].data_ptr()
         check(self._h, self.lib.cmgan_tscnet_forward_taps(self._h, x.data_ptr(), B, T, real.data_ptr(),
                                                           imag.data_ptr(), ctypes.byref(tp), ws.data_ptr(),
-                                                          ws.numel(), _stream()))
+                                                          ws.numel(), self._stream()))
         return real, imag, st
 
+    @_on_device
     def conformer_forward(self, index: int, x: torch.Tensor, taps: bool = False):
         self._need_weights()
-        x = _f32c(x, "x")
+        x = self._in(x, "x")
         N, L, C = x.shape
         if C != 64:
             raise ValueError("conformer dim must be 64")
@@ -196,65 +236,97 @@ class Engine:
         tp = torch.empty(4, N, L, 64, dtype=torch.float32, device=x.device) if taps else None
         check(self._h, self.lib.cmgan_conformer_forward(self._h, index, x.data_ptr(), N, L, y.data_ptr(),
                                                         tp.data_ptr() if taps else None, ws.data_ptr(),
-                                                        ws.numel(), _stream()))
+                                                        ws.numel(), self._stream()))
         return (y, tp) if taps else y
 
+    @_on_device
     def enhance(self, wav: torch.Tensor) -> torch.Tensor:
         """wav[B,L] -> enhanced[B,L]: the whole device pipeline in one ABI call."""
         self._need_weights()
-        wav = _f32c(wav, "wav")
+        wav = self._in(wav, "wav")
         B, L = wav.shape
         ws = self._workspace(B, self.num_frames(L))
         out = torch.empty_like(wav)
         check(self._h, self.lib.cmgan_enhance(self._h, wav.data_ptr(), B, L, out.data_ptr(), ws.data_ptr(),
-                                              ws.numel(), _stream()))
+                                              ws.numel(), self._stream()))
         return out
 
     # ---- hipGraph replay of the whole pipeline -------------------------------------------
+    @_on_device
     def enhance_graphed(self, wav: torch.Tensor) -> torch.Tensor:
         """Same result as enhance(), but the ~250 kernel launches of cmgan_enhance are captured once
         per input shape into a hipGraph (torch.cuda.CUDAGraph on the capture stream) and replayed:
         the C ABI never allocates or synchronises, so it is capturable as is.  The returned tensor is
         a static buffer that the next call with the same shape overwrites."""
         self._need_weights()
-        wav = _f32c(wav, "wav")
+        wav = self._in(wav, "wav")
         key = tuple(wav.shape)
-        if not hasattr(self, "_graphs"):
-            self._graphs = {}
+        B, L = wav.shape
+        ws = self._workspace(B, self.num_frames(L))             # may grow (and evict every graph) first
         ent = self._graphs.get(key)
+        if ent is not None and ent[3] != self._ws_token():      # workspace or weights changed since capture
+            ent = None
         if ent is None:
-            B, L = wav.shape
-            ws = self._workspace(B, self.num_frames(L))
             g_in, g_out = torch.empty_like(wav), torch.empty_like(wav)
             g_in.copy_(wav)
             side = torch.cuda.Stream(device=self.device)
-            side.wait_stream(torch.cuda.current_stream())
+            side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):                       # warm-up outside capture
                 check(self._h, self.lib.cmgan_enhance(self._h, g_in.data_ptr(), B, L, g_out.data_ptr(),
-                                                      ws.data_ptr(), ws.numel(), _stream()))
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
+                                                      ws.data_ptr(), ws.numel(), self._stream()))
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 check(self._h, self.lib.cmgan_enhance(self._h, g_in.data_ptr(), B, L, g_out.data_ptr(),
-                                                      ws.data_ptr(), ws.numel(), _stream()))
-            ent = (graph, g_in, g_out, ws)
+                                                      ws.data_ptr(), ws.numel(), self._stream()))
+            ent = (graph, g_in, g_out, self._ws_token())
             self._graphs[key] = ent
-        graph, g_in, g_out, ws = ent
-        if self._ws is not ws:
-            # the workspace was re-allocated for a larger shape: graphs captured on the old one are stale
-            self._graphs = {}
-            return self.enhance_graphed(wav)
+        graph, g_in, g_out, _ = ent
         g_in.copy_(wav)
         graph.replay()
         return g_out
 
+    # ---- training / validation step pieces (src/train.py) ----------------------------------
+    def loss_terms(self, est_real=None, est_imag=None, clean_spec=None, est_audio=None, clean_audio=None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """{loss_ri, loss_mag, time_loss, time_mse} of Trainer.calculate_generator_loss (train.py:124-151) as a
+        float32[4] device tensor (deterministic two-pass reduction).  Spectral operands in the model layout:
+        est_real/est_imag [B,1,T,F], clean_spec [B,2,T,F]; audio [B,L].  Either group may be omitted."""
+        spec = [est_real, est_imag, clean_spec]
+        audio = [est_audio, clean_audio]
+        if any(t is None for t in spec) and not all(t is None for t in spec):
+            raise ValueError("spectral terms need est_real, est_imag and clean_spec together")
+        if any(t is None for t in audio) and not all(t is None for t in audio):
+            raise ValueError("the time term needs est_audio and clean_audio together")
+        B = T = L = 0
+        ptr = [None] * 5
+        if spec[0] is not None:
+            er, ei, cs = (self._in(t, n) for t, n in zip(spec, ("est_real", "est_imag", "clean_spec")))
+            B, _, T, F = er.shape
+            if F != self.F or ei.shape != er.shape or tuple(cs.shape) != (B, 2, T, F):
+                raise ValueError(f"expected est [B,1,T,{self.F}] x2 and clean_spec [B,2,T,{self.F}]")
+            ptr[0:3] = [er.data_ptr(), ei.data_ptr(), cs.data_ptr()]
+        if audio[0] is not None:
+            ea, ca = self._in(audio[0], "est_audio"), self._in(audio[1], "clean_audio")
+            if ea.shape != ca.shape or ea.dim() != 2 or (B and ea.size(0) != B):
+                raise ValueError("est_audio / clean_audio must both be [B, L]")
+            B, L = ea.shape
+            ptr[3:5] = [ea.data_ptr(), ca.data_ptr()]
+        if out is None:
+            out = torch.empty(4, dtype=torch.float32, device=self.device)
+        check(self._h, self.lib.cmgan_loss_terms(self._h, ptr[0], ptr[1], ptr[2], B, T, ptr[3], ptr[4], L,
+                                                 self._in(out, "out").data_ptr(), self._stream()))
+        return out
+
     # ---- diagnostics ---------------------------------------------------------------
+    @_on_device
     def selftest_mfma(self) -> float:
         err = ctypes.c_float()
         check(self._h, self.lib.cmgan_selftest_mfma(self._h, ctypes.byref(err)))
         return float(err.value)
 
+    @_on_device
     def selftest_mfma_x3(self) -> float:
         err = ctypes.c_float()
         check(self._h, self.lib.cmgan_selftest_mfma_x3(self._h, ctypes.byref(err)))

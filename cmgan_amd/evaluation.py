@@ -81,18 +81,30 @@ def _read_wav(path: str):
 
 @torch.no_grad()
 def evaluation(model, noisy_dir: str, clean_dir: str, save_tracks: bool = False, saved_dir: str | None = None,
-               pesq_fn=None, verbose: bool = True):
+               pesq_fn=None, verbose: bool = True, subtype: str = "PCM_16", allow_missing_pesq: bool = False):
     """Enhance every .wav of `noisy_dir`, score it against the file of the same name in `clean_dir`, and
     return the six averages in the reference's order (pesq, csig, cbak, covl, ssnr, stoi).
 
     `model` is a loaded cmgan_amd.TSCNet or the path of a reference checkpoint (a state_dict saved by
     src/train.py, loaded exactly like evaluation.py:63-65).  `pesq_fn(fs, clean, enhanced)` overrides the
-    `pesq` wheel lookup of cmgan_amd.metrics; without either, the PESQ-dependent averages are NaN."""
+    `pesq` wheel lookup of cmgan_amd.metrics.  The reference imports `pesq` unconditionally and fails without
+    it (compute_metrics.py:7); so does this driver (ImportError) unless `allow_missing_pesq=True`, in which case
+    the four PESQ-dependent averages are NaN and a warning says so.  Saved tracks are 16-bit PCM like the
+    reference's `sf.write(path, est, sr)` default (`subtype="FLOAT"` keeps float32 samples instead)."""
     from . import metrics
     n_fft = 400
     if isinstance(model, (str, os.PathLike)):
         sd = torch.load(model, map_location="cpu")
         model = TSCNet(num_channel=64, num_features=n_fft // 2 + 1).load_state_dict(sd).eval()
+    if subtype not in ("PCM_16", "FLOAT"):
+        raise ValueError("subtype must be 'PCM_16' (soundfile's default for .wav) or 'FLOAT'")
+    if pesq_fn is None and not metrics.have_pesq():
+        if not allow_missing_pesq:
+            raise ImportError("the `pesq` package (ITU-T P.862, src/requirements.txt:6) is not installed and no "
+                              "pesq_fn was given: PESQ / CSIG / CBAK / COVL cannot be computed.  Pass "
+                              "allow_missing_pesq=True to get SSNR and STOI with the others as NaN.")
+        import warnings
+        warnings.warn("pesq is unavailable: the pesq, csig, cbak and covl averages will be NaN", RuntimeWarning)
     if save_tracks:
         if saved_dir is None:
             raise ValueError("save_tracks needs saved_dir")
@@ -110,7 +122,11 @@ def evaluation(model, noisy_dir: str, clean_dir: str, save_tracks: bool = False,
                                 16000 * 16, n_fft, n_fft // 4).cpu().numpy().astype(np.float64)
         if save_tracks:
             from scipy.io import wavfile
-            wavfile.write(os.path.join(saved_dir, name), sr, est.astype(np.float32))
+            if subtype == "PCM_16":     # libsndfile's float -> int16 conversion: scale by 2^15, round, clip
+                pcm = np.clip(np.rint(est * 32768.0), -32768, 32767).astype(np.int16)
+                wavfile.write(os.path.join(saved_dir, name), sr, pcm)
+            else:
+                wavfile.write(os.path.join(saved_dir, name), sr, est.astype(np.float32))
         clean, sr_c = _read_wav(os.path.join(clean_dir, name))
         if sr_c != 16000:
             raise ValueError(f"{name}: clean file is not 16 kHz")

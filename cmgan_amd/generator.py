@@ -11,6 +11,7 @@ import torch
 
 from . import packer
 from .engine import Engine
+from .synth import state_dict_shapes
 
 
 class TSCNet:
@@ -24,10 +25,27 @@ class TSCNet:
         self.engine = Engine(n_fft=n_fft, hop=hop, num_features=num_features, device=device, mfma_mode=mfma_mode)
 
     # nn.Module look-alikes so evaluation-style code runs unchanged
-    def cuda(self, *a, **k):
+    def _check_device(self, device):
+        if device is None:
+            return
+        dev = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+        if dev.type != "cuda":
+            raise RuntimeError("cmgan_amd has no CPU path: the model lives on the GPU it was constructed on")
+        if dev.index is not None and dev != self.engine.device:
+            raise RuntimeError(f"this model's engine is bound to {self.engine.device}; construct "
+                               f"TSCNet(..., device='{dev}') instead of moving it (one handle = one device)")
+
+    def cuda(self, device=None):
+        self._check_device(device)
         return self
 
-    def to(self, *a, **k):
+    def to(self, *args, **kwargs):
+        for a in list(args) + [kwargs.get("device"), kwargs.get("dtype")]:
+            if isinstance(a, torch.dtype):
+                if a != torch.float32:
+                    raise TypeError("the HIP path stores and accumulates in float32 only")
+            elif a is not None and not isinstance(a, bool):
+                self._check_device(a)
         return self
 
     def eval(self):
@@ -35,17 +53,32 @@ class TSCNet:
 
     def train(self, mode: bool = True):
         if mode:
-            raise NotImplementedError("cmgan_amd implements the inference (eval) forward path only")
+            raise NotImplementedError(
+                "train-mode forward of the whole generator (Dropout 0.2, BatchNorm1d batch statistics, autograd; "
+                "src/train.py:72-122) is not built: cmgan_amd.training holds the pieces that are (loss terms, "
+                "FeedForward forward/backward)")
         return self
 
     def load_state_dict(self, state_dict: dict, strict: bool = True):
-        missing = [k for k in _expected_keys() if k not in state_dict]
+        """Consumes the reference generator state_dict (src/evaluation.py:63-64; 359 entries).
+        Every expected tensor must be present with the reference's shape (there are no Python-side parameters
+        to fall back on, so a missing key is fatal even with strict=False); strict=True also rejects keys the
+        reference model does not have, like nn.Module.load_state_dict."""
+        expected = state_dict_shapes(self.num_features)
+        missing = [k for k in expected if k not in state_dict]
         if missing:
-            raise KeyError(f"state_dict is missing {len(missing)} keys, e.g. {missing[:3]}")
-        pout = state_dict["mask_decoder.prelu_out.weight"]
-        if pout.numel() != self.num_features:
-            raise ValueError(f"prelu_out has {pout.numel()} slopes, model was built for {self.num_features}")
-        self.engine.load_blob(packer.pack_state_dict(state_dict))
+            raise KeyError(f"state_dict is missing {len(missing)} of {len(expected)} keys, e.g. {missing[:3]}")
+        unexpected = [k for k in state_dict if k not in expected]
+        if unexpected and strict:
+            raise KeyError(f"state_dict has {len(unexpected)} unexpected keys, e.g. {unexpected[:3]} "
+                           "(a DDP checkpoint? strip the 'module.' prefix, or pass strict=False)")
+        for k, shape in expected.items():
+            got = tuple(state_dict[k].shape)
+            if got != shape:
+                what = (f"prelu_out has {state_dict[k].numel()} slopes, model was built for {self.num_features}"
+                        if k == "mask_decoder.prelu_out.weight" else f"{k}: shape {got}, expected {shape}")
+                raise ValueError(what)
+        self.engine.load_blob(packer.pack_state_dict({k: state_dict[k] for k in expected}))
         return self
 
     @torch.no_grad()
@@ -57,12 +90,3 @@ class TSCNet:
     def forward_with_taps(self, x: torch.Tensor):
         """(real, imag, {encoder, tscb1..4, mask, complex}) - NCHW like the reference modules."""
         return self.engine.tscnet_forward(x, taps=True)
-
-
-def _expected_keys():
-    keys = ["dense_encoder.conv_1.0.weight", "dense_encoder.conv_2.0.weight",
-            "mask_decoder.prelu_out.weight", "complex_decoder.conv.weight"]
-    for b in range(1, 5):
-        for ax in ("time", "freq"):
-            keys.append(f"TSCB_{b}.{ax}_conformer.attn.fn.rel_pos_emb.weight")
-    return keys

@@ -245,6 +245,11 @@ def _default_pesq() -> Optional[Callable]:
     return lambda fs, ref, deg: float(_pesq(fs, ref, deg, "wb"))
 
 
+def have_pesq() -> bool:
+    """True when the `pesq` wheel the reference scores with (compute_metrics.py:7) can be imported."""
+    return _default_pesq() is not None
+
+
 def compute_metrics(clean, enhanced, fs: int, path: int = 0, *, pesq_mos: Optional[float] = None) -> Scores:
     """`pesq, csig, cbak, covl, ssnr, stoi = compute_metrics(clean, enhanced, Fs, path)` with the reference's
     argument meaning (compute_metrics.py:26-77): `path=1` reads two .wav files, `path=0` takes arrays.

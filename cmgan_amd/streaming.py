@@ -61,11 +61,9 @@ def _enhance_rows(model: TSCNet, rows: torch.Tensor, graph: bool) -> torch.Tenso
         real, imag = model(spec)
         return eng.uncompress_istft(real, imag)
     key = ("rows",) + tuple(rows.shape)
-    cache = getattr(eng, "_row_graphs", None)
-    if cache is None:
-        cache = eng._row_graphs = {}
+    cache = eng._row_graphs
     ent = cache.get(key)
-    if ent is None or ent[3] is not eng._ws_token():
+    if ent is None or ent[3] != eng._ws_token():
         g_in = torch.empty_like(rows)
         g_in.copy_(rows)
         side = torch.cuda.Stream(device=rows.device)

@@ -1,0 +1,155 @@
+"""Deterministic random-init generator weights in the reference's state_dict format, and
+synthetic noisy clips of the benchmark shape (BASELINE.json: "synthetic 16 kHz noisy clips",
+random-init weights of the architecture - there is no network for checkpoints or datasets).
+
+Lives in the package (not under oracle/) so that bench.py's GPU leg and the examples never
+import test infrastructure; oracle/weights.py re-exports it for the tests.
+
+The reference checkpoint is absent (``.MISSING_LARGE_BLOBS``), so parity runs on
+seeded random weights.  torch's default initialisers are not guaranteed stable
+across versions, so the 359 tensors of ``TSCNet(num_channel=64, num_features=F)``
+(key names and shapes: /root/reference/src/models/generator.py:159-172,
+/root/reference/src/models/conformer.py:75-214) are drawn from
+a numpy PCG64 stream instead; the same seed gives the same bytes on any box.
+
+Distributions follow the torch defaults in spirit (uniform +-1/sqrt(fan_in) for
+conv/linear, N(0,1) embedding) but norm gains/biases, PReLU slopes and the
+BatchNorm running statistics are randomised too, so every affine path, the
+BN fold and the per-frequency PReLU are exercised.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+C = 64            # num_channel (generator.py:160)
+HEADS = 4         # generator.py:78
+DIM_HEAD = 16     # generator.py:77
+FF_MULT = 4       # conformer.py:189
+CONV_EXP = 2      # conformer.py:190
+CONV_K = 31       # generator.py:79
+MAX_POS = 512     # conformer.py:76
+
+
+def _to_torch(v: np.ndarray) -> torch.Tensor:
+    return torch.tensor(v.item()) if v.ndim == 0 else torch.from_numpy(np.ascontiguousarray(v))
+
+
+class _Stream:
+    def __init__(self, seed: int):
+        self.rng = np.random.Generator(np.random.PCG64(seed))
+
+    def uniform(self, shape, bound):
+        return self.rng.uniform(-bound, bound, size=shape).astype(np.float32)
+
+    def normal(self, shape, mean=0.0, std=1.0):
+        return (mean + std * self.rng.standard_normal(size=shape)).astype(np.float32)
+
+
+def _conv(s, sd, name, cout, cin, kh, kw):
+    bound = 1.0 / np.sqrt(cin * kh * kw)
+    sd[name + ".weight"] = s.uniform((cout, cin, kh, kw), bound)
+    sd[name + ".bias"] = s.uniform((cout,), bound)
+
+
+def _linear(s, sd, name, out_f, in_f, bias=True, conv1d=False):
+    bound = 1.0 / np.sqrt(in_f)
+    shape = (out_f, in_f, 1) if conv1d else (out_f, in_f)
+    sd[name + ".weight"] = s.uniform(shape, bound)
+    if bias:
+        sd[name + ".bias"] = s.uniform((out_f,), bound)
+
+
+def _norm(s, sd, name, n):
+    sd[name + ".weight"] = s.normal((n,), 1.0, 0.1)
+    sd[name + ".bias"] = s.normal((n,), 0.0, 0.1)
+
+
+def _prelu(s, sd, name, n, init=0.25):
+    sd[name + ".weight"] = s.normal((n,), init, 0.05)
+
+
+def _dense_block(s, sd, prefix):
+    for i in range(1, 5):
+        _conv(s, sd, f"{prefix}.conv{i}", C, C * i, 2, 3)
+        _norm(s, sd, f"{prefix}.norm{i}", C)
+        _prelu(s, sd, f"{prefix}.prelu{i}", C)
+
+
+def _conformer(s, sd, p):
+    inner = C * CONV_EXP
+    for ff in ("ff1", "ff2"):
+        _linear(s, sd, f"{p}.{ff}.fn.fn.net.0", C * FF_MULT, C)
+        _linear(s, sd, f"{p}.{ff}.fn.fn.net.3", C, C * FF_MULT)
+        _norm(s, sd, f"{p}.{ff}.fn.norm", C)
+    _linear(s, sd, f"{p}.attn.fn.to_q", HEADS * DIM_HEAD, C, bias=False)
+    _linear(s, sd, f"{p}.attn.fn.to_kv", 2 * HEADS * DIM_HEAD, C, bias=False)
+    _linear(s, sd, f"{p}.attn.fn.to_out", C, HEADS * DIM_HEAD)
+    sd[f"{p}.attn.fn.rel_pos_emb.weight"] = s.normal((2 * MAX_POS + 1, DIM_HEAD), 0.0, 1.0)
+    _norm(s, sd, f"{p}.attn.norm", C)
+    _norm(s, sd, f"{p}.conv.net.0", C)
+    _linear(s, sd, f"{p}.conv.net.2", inner * 2, C, conv1d=True)
+    bound = 1.0 / np.sqrt(CONV_K)
+    sd[f"{p}.conv.net.4.conv.weight"] = s.uniform((inner, 1, CONV_K), bound)
+    sd[f"{p}.conv.net.4.conv.bias"] = s.uniform((inner,), bound)
+    _norm(s, sd, f"{p}.conv.net.5", inner)
+    sd[f"{p}.conv.net.5.running_mean"] = s.normal((inner,), 0.0, 0.2)
+    sd[f"{p}.conv.net.5.running_var"] = s.rng.uniform(0.5, 2.0, size=(inner,)).astype(np.float32)
+    sd[f"{p}.conv.net.5.num_batches_tracked"] = np.array(100, dtype=np.int64)
+    _linear(s, sd, f"{p}.conv.net.7", C, inner, conv1d=True)
+    _norm(s, sd, f"{p}.post_norm", C)
+
+
+def conformer_state_dict(seed: int = 0) -> dict:
+    """State dict of one standalone ``ConformerBlock(dim=64, dim_head=16, heads=4,
+    conv_kernel_size=31)`` (keys without a prefix)."""
+    s = _Stream(seed)
+    sd: dict = {}
+    _conformer(s, sd, "X")
+    return {k[2:]: _to_torch(v) for k, v in sd.items()}
+
+
+def make_state_dict(seed: int = 0, num_features: int = 201) -> dict:
+    """All 359 entries of ``TSCNet(64, num_features).state_dict()``."""
+    s = _Stream(seed)
+    sd: dict = {}
+    _conv(s, sd, "dense_encoder.conv_1.0", C, 3, 1, 1)
+    _norm(s, sd, "dense_encoder.conv_1.1", C)
+    _prelu(s, sd, "dense_encoder.conv_1.2", C)
+    _dense_block(s, sd, "dense_encoder.dilated_dense")
+    _conv(s, sd, "dense_encoder.conv_2.0", C, C, 1, 3)
+    _norm(s, sd, "dense_encoder.conv_2.1", C)
+    _prelu(s, sd, "dense_encoder.conv_2.2", C)
+    for b in range(1, 5):
+        for axis in ("time", "freq"):
+            _conformer(s, sd, f"TSCB_{b}.{axis}_conformer")
+    _dense_block(s, sd, "mask_decoder.dense_block")
+    _conv(s, sd, "mask_decoder.sub_pixel.conv", 2 * C, C, 1, 3)
+    _conv(s, sd, "mask_decoder.conv_1", 1, C, 1, 2)
+    _norm(s, sd, "mask_decoder.norm", 1)
+    _prelu(s, sd, "mask_decoder.prelu", 1)
+    _conv(s, sd, "mask_decoder.final_conv", 1, 1, 1, 1)
+    _prelu(s, sd, "mask_decoder.prelu_out", num_features, init=-0.25)
+    _dense_block(s, sd, "complex_decoder.dense_block")
+    _conv(s, sd, "complex_decoder.sub_pixel.conv", 2 * C, C, 1, 3)
+    _prelu(s, sd, "complex_decoder.prelu", C)
+    _norm(s, sd, "complex_decoder.norm", C)
+    _conv(s, sd, "complex_decoder.conv", 2, C, 1, 2)
+    return {k: _to_torch(v) for k, v in sd.items()}
+
+
+def synthetic_clips(batch: int, length: int, seed: int = 0) -> torch.Tensor:
+    """``0.1 * N(0,1)`` noisy clips, float32 [batch, length]."""
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    return torch.from_numpy((0.1 * rng.standard_normal((batch, length))).astype(np.float32))
+
+
+_SHAPES: dict = {}
+
+
+def state_dict_shapes(num_features: int = 201) -> dict:
+    """{key: shape} of all 359 entries of ``TSCNet(64, num_features).state_dict()``; what
+    ``cmgan_amd.TSCNet.load_state_dict`` validates an incoming checkpoint against."""
+    if num_features not in _SHAPES:
+        _SHAPES[num_features] = {k: tuple(v.shape) for k, v in make_state_dict(0, num_features).items()}
+    return _SHAPES[num_features]

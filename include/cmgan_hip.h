@@ -39,7 +39,7 @@ extern "C" {
 #define CMGAN_E_WORKSPACE   -5   /* workspace too small or misaligned              */
 #define CMGAN_E_HIP         -6   /* a HIP runtime call failed (see last_error)     */
 
-#define CMGAN_ABI_VERSION 2
+#define CMGAN_ABI_VERSION 3
 
 typedef struct cmgan_handle cmgan_handle;
 
@@ -66,7 +66,9 @@ typedef struct cmgan_config {
  *   F32   : v_mfma_f32_16x16x4_f32, bit-exact fp32 products (157 TF peak)
  *   F16X3 : every operand split x = hi + lo in fp16 and the product evaluated as
  *           hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 (~2^-21 relative product error,
- *           ~5x the fp32 matrix rate; gfx950 has no TF32).  STFT / ISTFT always run in F32.  */
+ *           ~5x the fp32 matrix rate; gfx950 has no TF32).  At n_fft 400 / hop 100 the STFT / ISTFT
+ *           use folded split-f16 DFT kernels too; other sizes (48 kHz: 1200 / 300) run the
+ *           dense fp32 DFT kernels in either mode.                                          */
 #define CMGAN_MFMA_F32   0
 #define CMGAN_MFMA_F16X3 1
 
@@ -86,8 +88,13 @@ const char* cmgan_last_error(const cmgan_handle* h);
 /* Uploads packed weights.  `blob` is the host buffer produced by
  * cmgan_amd.packer.pack_state_dict() from the reference generator state_dict
  * (the 359-entry dict loaded at src/evaluation.py:63-64).  Layout: see
- * cmgan_amd/csrc/weights.h.  May be called again to swap weights (synchronises). */
+ * cmgan_amd/csrc/weights.h.  May be called again to swap weights (synchronises the
+ * device).  The swap is atomic: on any failure the previously loaded weights stay in
+ * place.  Device buffers are re-allocated, so hipGraphs captured before the call hold
+ * stale pointers: re-capture when cmgan_weights_generation() has changed.          */
 int  cmgan_load_weights(cmgan_handle* h, const void* blob, size_t bytes);
+/* Number of successful cmgan_load_weights calls on this handle (-1 for NULL).      */
+int  cmgan_weights_generation(const cmgan_handle* h);
 
 /* Bytes of scratch the forward calls need for a batch of B spectrograms of T
  * frames (0 on bad arguments).  The caller allocates it once (256-byte aligned). */
@@ -103,7 +110,8 @@ int cmgan_num_frames(const cmgan_handle* h, int L);
 /* wav[B,L] (optionally scaled by scale_dev[B]; NULL = 1) -> power-compressed
  * spectrogram spec[B,2,T,F] = the tensor fed to TSCNet.forward.
  * Replaces torch.stft + utils.power_compress + permute
- * (src/evaluation.py:36-39, src/utils.py:20-29).  L % hop == 0, L > n_fft/2.  */
+ * (src/evaluation.py:36-39, src/utils.py:20-29).  Any L > n_fft/2 (reflect padding):
+ * T = L / hop + 1 frames, exactly torch.stft(center=True).                      */
 int cmgan_stft_compress(cmgan_handle* h, const float* wav_dev, const float* scale_dev,
                         int B, int L, float* spec_dev, void* stream);
 
@@ -125,6 +133,21 @@ int cmgan_uncompress_istft(cmgan_handle* h, const float* real_dev, const float* 
  * wav[B,L] -> wav_out[B,L];  L % hop == 0.                                      */
 int cmgan_enhance(cmgan_handle* h, const float* wav_dev, int B, int L, float* wav_out_dev,
                   void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* The non-adversarial terms of Trainer.calculate_generator_loss (src/train.py:124-151)
+ * as deterministic device reductions, out4_dev = {loss_ri, loss_mag, time_loss, time_mse}:
+ *   loss_ri   = mse(est_real, clean_real) + mse(est_imag, clean_imag)      train.py:135-137
+ *   loss_mag  = mse(|est|, |clean|)                                         train.py:132-134
+ *   time_loss = mean |est_audio - clean_audio|                              train.py:139-141
+ *   time_mse  = mean (est_audio - clean_audio)^2   (logging only, not in the reference)
+ * est_real/est_imag [B,1,T,F] are the TSCNet outputs, clean_spec [B,2,T,F] the
+ * power-compressed clean spectrogram in the model layout (cmgan_stft_compress of the
+ * clean rows; the reference's permutes do not change an elementwise mean), est/clean
+ * audio [B,L_audio].  Either group may be all-NULL (its terms are then 0).  These are
+ * the per-rank scalars the data-parallel step all-reduces (one RCCL call).          */
+int cmgan_loss_terms(cmgan_handle* h, const float* est_real_dev, const float* est_imag_dev,
+                     const float* clean_spec_dev, int B, int T, const float* est_audio_dev,
+                     const float* clean_audio_dev, int L_audio, float* out4_dev, void* stream);
 
 /* utils.power_compress (src/utils.py:20-29): x[B,F,T,2] -> y[B,2,F,T].          */
 int cmgan_power_compress(cmgan_handle* h, const float* x_dev, int B, int F, int T,

@@ -35,3 +35,17 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def assert_close(a: torch.Tensor, b: torch.Tensor, rtol: float, atol_rel: float, name: str = ""):
+    """Elementwise |a-b| <= atol + rtol |b| with atol = atol_rel * max|b| (torch.allclose semantics).  rel_err
+    alone leaves elements far below the peak unconstrained; this also bounds their RELATIVE error, with an
+    absolute floor for the near-zero ones (spectrogram bins of silence, waveform zero crossings)."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    atol = atol_rel * float(b.abs().max())
+    excess = (a - b).abs() - (atol + rtol * b.abs())
+    worst = float(excess.max())
+    assert worst <= 0.0, f"{name}: {int((excess > 0).sum())} of {a.numel()} elements outside rtol={rtol:g} " \
+                         f"atol={atol:g}; worst excess {worst:.3e}"

@@ -145,6 +145,33 @@ def main():
     r48, i48 = m48(x48)
     save("tscnet48.npz", x=x48, real=r48, imag=i48)
 
+    # -- 7. 48 kHz variant end to end (wav -> wav, n_fft 1200 / hop 300): ragged, chunked, and a length whose
+    #       100-sample padding (evaluation.py:25) is NOT a multiple of hop = 300: torch.stft then yields
+    #       1 + padded // 300 frames and torch.istft returns 300 * (T - 1) samples, i.e. a SHORTER track
+    n48 = synthetic_clips(1, 4150, seed=22)                   # padded 4200 = 14 hops
+    n48s = synthetic_clips(1, 2450, seed=23)                  # padded 2500: T = 9, output 2400 samples
+    save("pipeline48.npz", noisy=n48, enhanced=ref_enhance(m48, n48, 48000 * 16, 1200, 300),
+         enhanced_chunked=ref_enhance(m48, n48, 2100, 1200, 300), cut_len_chunked=np.int64(2100),
+         noisy_short=n48s, enhanced_short=ref_enhance(m48, n48s, 48000 * 16, 1200, 300))
+
+    # -- 8. real recordings: two noisy VoiceBank+DEMAND test tracks that ship with the reference
+    #       (AudioSamples/noisy, int16 PCM / 32768 as torchaudio.load does) and a clean track with
+    #       0.3 s + 0.6 s of exact digital silence gated into it (zero bins through |X|^-0.7, sparse
+    #       InstanceNorm planes, the split-f16 operand ranges)
+    from scipy.io import wavfile
+    tracks = {}
+    for tag, rel in (("a", "noisy/p232_170.wav"), ("b", "noisy/p257_054.wav"), ("silence", "clean/p232_052.wav")):
+        sr, pcm = wavfile.read(os.path.join("/root/reference/AudioSamples", rel))
+        assert sr == 16000 and pcm.dtype == np.int16
+        pcm = pcm.copy()
+        if tag == "silence":
+            pcm[:4800] = 0
+            pcm[14000:23600] = 0
+        x = torch.from_numpy(pcm.astype(np.float32) / 32768.0)[None, :]
+        tracks[f"pcm_{tag}"] = pcm
+        tracks[f"enhanced_{tag}"] = ref_enhance(model, x, 16000 * 16)
+    save("tracks.npz", **tracks)
+
 
 if __name__ == "__main__":
     main()

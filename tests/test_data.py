@@ -68,5 +68,13 @@ def test_load_data_batches_have_the_front_end_shape(tmp_path):
     batches = list(train)
     assert len(batches) == 2                                             # drop_last: 5 clips -> 2 batches of 2
     clean, noisy, length = batches[0]
-    assert clean.shape == (2, 1200) and noisy.shape == (2, 1200) and length.tolist() == [600, 1000]
+    # the reference samples through DistributedSampler(shuffle=True, seed=0): epoch-0 permutation of the 5 clips
+    g = torch.Generator()
+    g.manual_seed(0)
+    perm = torch.randperm(5, generator=g).tolist()
+    assert clean.shape == (2, 1200) and noisy.shape == (2, 1200)
+    assert length.tolist() == [600 + 400 * perm[0], 600 + 400 * perm[1]]
+    assert perm != sorted(perm)                                          # really shuffled, like the reference
+    train.sampler.set_epoch(1)
+    assert [b[2].tolist() for b in train] != [b[2].tolist() for b in batches]
     assert sum(b[0].size(0) for b in test) == 3                          # test keeps the ragged last batch

@@ -6,7 +6,7 @@ import os
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden, rel_err
+from conftest import GOLDEN, assert_close, load_golden, rel_err
 from oracle import cmgan_oracle as O
 from oracle.weights import conformer_state_dict, make_state_dict
 
@@ -96,6 +96,30 @@ def test_pipeline_ragged_and_chunked(sd):
     assert rel_err(out, g["enhanced"]) < 5e-5
     out_c = O.enhance(sd, g["noisy"], cut_len=int(g["cut_len_chunked"]))
     assert rel_err(out_c, g["enhanced_chunked"]) < 5e-5
+
+
+def test_pipeline_48k_variant_ragged_chunked_and_short_output():
+    """configs[3]: n_fft 1200 / hop 300 wav -> wav through the reference's own enhance_one_track glue, incl. the
+    reference quirk that a 100-sample padding which is not a multiple of hop returns a SHORTER track."""
+    g = load_golden("pipeline48.npz")
+    sd48 = make_state_dict(seed=5, num_features=601)
+    out = O.enhance(sd48, g["noisy"], cut_len=48000 * 16, n_fft=1200, hop=300)
+    assert out.shape == (4150,) and rel_err(out, g["enhanced"]) < 5e-5
+    out_c = O.enhance(sd48, g["noisy"], cut_len=int(g["cut_len_chunked"]), n_fft=1200, hop=300)
+    assert rel_err(out_c, g["enhanced_chunked"]) < 5e-5
+    out_s = O.enhance(sd48, g["noisy_short"], cut_len=48000 * 16, n_fft=1200, hop=300)
+    assert out_s.shape == (2400,) == tuple(g["enhanced_short"].shape)
+    assert rel_err(out_s, g["enhanced_short"]) < 5e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "silence"])
+def test_real_recordings_match_the_reference(sd, tag):
+    """AudioSamples tracks (and one with gated digital silence) enhanced by the reference modules."""
+    g = load_golden("tracks.npz")
+    noisy = (g[f"pcm_{tag}"].float() / 32768.0)[None, :]
+    out = O.enhance(sd, noisy)
+    assert rel_err(out, g[f"enhanced_{tag}"]) < 5e-5
+    assert_close(out, g[f"enhanced_{tag}"], rtol=1e-3, atol_rel=1e-4, name=f"track {tag}")
 
 
 def test_chunk_rows_rule():

@@ -3,7 +3,9 @@
 
     python tools/rocpd_summary.py trace <trace_results.db>            # = --kernel-trace --stats
     python tools/rocpd_summary.py pmc   <pmc_results.db> [...]        # one DB per --pmc pass
-    python tools/rocpd_summary.py traffic <FETCH_SIZE db> <WRITE_SIZE db>   # JSON: HBM bytes per launch per kernel label
+    python tools/rocpd_summary.py traffic <FETCH_SIZE db> <WRITE_SIZE db> [bench.json]
+                                          # JSON: HBM bytes per launch per kernel label, stamped with the csrc digest /
+                                          # workload / batch of the bench line produced in the SAME GPU session
 
 PMC values are summed over the per-XCD/SE instances rocprofv3 reports and averaged per launch.
 FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 definition); on gfx950 FETCH_SIZE under-reports wide
@@ -74,7 +76,7 @@ def pmc(dbs):
 LABELS = [("conv3x_kernelILi2ELi64", "conv_dense"), ("conv3x_kernelILi1ELi128", "conv_subpixel"),
           ("conv3x_kernelILi1ELi64", "conv_1x3"), ("conv3_kernelILi2ELi64", "conv_dense"),
           ("conv3_kernelILi1ELi128", "conv_subpixel"), ("conv3_kernelILi1ELi64", "conv_1x3"),
-          ("attn_x3_kernel", "attn"), ("attn_kernel", "attn"), ("dwpw2_x3_kernel", "dwpw2"),
+          ("attn_out_x3_kernel", "attn_out"), ("attn_x3_kernel", "attn"), ("attn_kernel", "attn"), ("dwpw2_x3_kernel", "dwpw2"),
           ("ffn_x3_kernelILb1", "ffn_post"), ("ffn_x3_kernelILb0", "ffn"), ("ffn_kernelILb1", "ffn_post"),
           ("ffn_kernelILb0", "ffn"), ("qkv_x3_kernel", "qkv"), ("qkv_kernel", "qkv"),
           ("pw1glu_x3_kernel", "pw1glu"), ("pw1glu_kernel", "pw1glu"), ("outproj_x3_kernel", "outproj"),
@@ -83,7 +85,7 @@ LABELS = [("conv3x_kernelILi2ELi64", "conv_dense"), ("conv3x_kernelILi1ELi128", 
           ("tail_proj_kernel", "tail_proj")]
 
 
-def traffic(fetch_db, write_db):
+def traffic(fetch_db, write_db, bench_json=None):
     """HBM bytes per launch (FETCH_SIZE with the gfx950 2x correction for 16 B/lane reads + WRITE_SIZE)."""
     import json
     out = {}
@@ -101,9 +103,17 @@ def traffic(fetch_db, write_db):
             e["fetch_bytes" if cname == "FETCH_SIZE" else "write_bytes"] = round(scale * tot * 1024 / len(disps))
     for e in out.values():
         e["hbm_bytes"] = e.get("fetch_bytes", 0) + e.get("write_bytes", 0)
-    print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, "
-                                "FETCH x2 per MI355X_MICROARCH.md (gfx950 under-reports 16 B/lane reads)",
-                      "per_launch": out}, indent=1))
+    doc = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, "
+                     "FETCH x2 per MI355X_MICROARCH.md (gfx950 under-reports 16 B/lane reads)"}
+    if bench_json:
+        # bench.py only publishes these counters while the built kernel sources still hash to this digest
+        with open(bench_json) as f:
+            b = json.loads([l for l in f.read().splitlines() if l.startswith("{")][-1])
+        doc["csrc_digest"] = b["csrc_digest"]
+        doc["workload"] = "48k" if "48 kHz" in b["config"]["workload"] else "16k"
+        doc["batch"] = b["config"]["batch_per_gpu"]
+    doc["per_launch"] = out
+    print(json.dumps(doc, indent=1))
 
 
 if __name__ == "__main__":
@@ -112,6 +122,6 @@ if __name__ == "__main__":
     if sys.argv[1] == "trace":
         trace(sys.argv[2])
     elif sys.argv[1] == "traffic":
-        traffic(sys.argv[2], sys.argv[3])
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
     else:
         pmc(sys.argv[2:])
