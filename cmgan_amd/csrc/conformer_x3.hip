@@ -235,6 +235,15 @@ __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x
 // g = 2,3 the lo half, both over d = 8*(g&1) + e; B carries Q_hi in both halves (MFMA 1) then
 // Q_lo (MFMA 2): two MFMAs give (K_hi + K_lo) . (Q_hi + Q_lo).
 // ---------------------------------------------------------------------------------
+#ifndef XCD_ORDER
+#define XCD_ORDER 1          // XCD-contiguous work order for attention and the depthwise kernel (0 = dispatch order)
+#endif
+#ifndef ATTN_FUSE_OUT
+#define ATTN_FUSE_OUT 1      // attention + to_out + residual in one kernel (0 = attn_x3_kernel, then outproj_x3_kernel)
+#endif
+#ifndef DWPW2_SLIDE
+#define DWPW2_SLIDE 1        // sliding-window depthwise + pointwise kernel (0 = one block per 32-position tile)
+#endif
 #define RSTRIDE_X 20
 // Query blocks per wave / waves per SIMD the kernel is compiled for.  Measured in one session: a lone wave per
 // SIMD 9.8 ms, two waves (4 query blocks each, 216 VGPRs) 6.0 ms, three waves (2 query blocks = one pair each,
@@ -435,7 +444,11 @@ __global__ __launch_bounds__(256, ATT_WAVES) void attn_x3_kernel(QkvOut io, cons
     __shared__ float rbuf[4][2][80 * RSTRIDE_X + 4];   // +4: keeps RA/RB 1604 dwords apart, which no ds_read2* form can span, so each skew read
                                                        // lands directly in its accumulator register (paired A/B reads cost a v_mov per value)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long item = (long)blockIdx.x * 4 + wv;
+    // Workgroup b runs on XCD b % 8 (each XCD has its own L2).  The query-block waves of one (sequence, head)
+    // read the same K / V images, so every XCD walks a CONTIGUOUS range of work items: the grid is a multiple
+    // of 8 blocks and block b takes logical block (b % 8) * (grid / 8) + b / 8.
+    const long lblk = XCD_ORDER ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+    const long item = lblk * 4 + wv;
     if (item >= total) return;                            // no block-level synchronisation below
     const long nh = item / nqg;
     const int ibb = (int)(item % nqg) * ATT_NQ;           // first query block of this wave
@@ -464,6 +477,84 @@ __global__ __launch_bounds__(256, ATT_WAVES) void attn_x3_kernel(QkvOut io, cons
     for (int i = 0; i < ATT_NQ; ++i) {
         const int ib = ibb + i;
         if (ib < Lb) stg4(o + (nh * Lb + ib) * 256 + lane * 4, st[i].o * splat4(__builtin_amdgcn_rcpf(st[i].l)));
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Attention core + to_out + bias + residual in ONE kernel (the default): a block is the four heads of one
+// (sequence, query-block pair), one head per wave, same barrier-free chunk loop as attn_x3_kernel.  When a wave's
+// head is done its normalised O tile (2 x 1 KB of fp32 C-fragments, which ARE the B-fragments of k-block h of
+// to_out) goes into its own - now idle - skew scratch; after the block's only barrier wave w evaluates output
+// block w of  x += Wo . concat_h(O_h) + bo  for the pair's 32 tokens and updates the residual stream in place.
+// O never touches HBM (1 row written + 1 row read per token and conformer before), the to_out launch and its
+// second pass over the residual are gone, and the arithmetic is bit-identical to attn_x3 + outproj_x3.
+// Blocks run in XCD-contiguous order: the query pairs of a sequence follow each other on one XCD, so the
+// K / V images of its four heads are fetched into that L2 once.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, ATT_WAVES) void attn_out_x3_kernel(QkvOut io, const _Float16* __restrict__ eimg,
+                                                             int max_pos, float* __restrict__ x, TokMap m,
+                                                             const _Float16* __restrict__ woi,
+                                                             const float* __restrict__ bo, int Lb2, int nqg,
+                                                             long nblocks) {
+    __shared__ __attribute__((aligned(16))) float rbuf[4][2][80 * RSTRIDE_X + 4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long lblk = XCD_ORDER ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+    if (lblk >= nblocks) return;                          // padding blocks of the rounded-up grid (block-uniform)
+    const int n = (int)(lblk / nqg);
+    const int ibb = (int)(lblk - (long)n * nqg) * ATT_NQ; // first query block of the pair
+    const long nh = (long)n * 4 + wv;                     // this wave's head
+    const int L = m.L, Lb = m.Lb;
+    AttCtx a;
+    a.c = lane & 15; a.g = lane >> 4;
+    a.RA = rbuf[wv][0]; a.RB = rbuf[wv][1];
+    a.nblk16 = 2 * Lb2; a.Lb = Lb; a.Lb2 = Lb2; a.L = L; a.max_pos = max_pos;
+    a.qbase = io.qimg + nh * a.nblk16 * 512;
+    a.kbase = io.kimg + nh * a.nblk16 * 512 + lane * 8;
+    a.vbase = io.vimg + nh * Lb2 * 1024 + lane * 8;
+    a.ebase = eimg + a.g * 8;
+    a.qoff1 = ((a.g & 1) * 16 + a.c) * 8; a.qoff2 = ((2 + (a.g & 1)) * 16 + a.c) * 8;
+
+    AttState st[ATT_NQ];
+#pragma unroll
+    for (int i = 0; i < ATT_NQ; ++i) {
+        st[i].m = 0.f; st[i].run = -INFINITY; st[i].l = 0.f; st[i].o = splat4(0.f);
+    }
+    const int nfull = L >> 6;
+#pragma unroll 1
+    for (int ch = 0; ch < nfull; ++ch) att_chunk<true>(a, ibb, ch * 64, st);
+    if (L & 63) att_chunk<false>(a, ibb, nfull * 64, st);
+
+    // the to_out operands of this wave's output block are fetched now: their L2 latency hides behind the barrier
+    const _Float16* wp = woi + wv * 2048 + lane * 8;       // [ob = wv][m][hi | lo][64][8]
+    const f16x8 ah0 = *reinterpret_cast<const f16x8*>(wp), al0 = *reinterpret_cast<const f16x8*>(wp + 512);
+    const f16x8 ah1 = *reinterpret_cast<const f16x8*>(wp + 1024), al1 = *reinterpret_cast<const f16x8*>(wp + 1536);
+    const f32x4 bias = ldg4(bo + 16 * wv + 4 * a.g);
+
+    wave_lds_fence();                                     // this wave's last skew reads are done
+    f32x4* stash = reinterpret_cast<f32x4*>(&rbuf[0][0][0]);       // O tile of (head h, block i) at [(h * 2 + i) * 64 + lane]
+    constexpr int HSTRIDE = 2 * (80 * RSTRIDE_X + 4) / 4;          // float4s between two waves' scratch areas
+#pragma unroll
+    for (int i = 0; i < ATT_NQ; ++i)
+        stash[wv * HSTRIDE + i * 64 + lane] = st[i].o * splat4(__builtin_amdgcn_rcpf(st[i].l));
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ATT_NQ; ++i) {
+        const int ib = ibb + i, l = ib * 16 + a.c;
+        f16x8 bh[1][2], bl[1][2];
+        split8(stash[0 * HSTRIDE + i * 64 + lane], stash[1 * HSTRIDE + i * 64 + lane], bh[0][0], bl[0][0]);
+        split8(stash[2 * HSTRIDE + i * 64 + lane], stash[3 * HSTRIDE + i * 64 + lane], bh[0][1], bl[0][1]);
+        f32x4 acc = bias;                                  // same product order as lin_acc_x3 / outproj_x3_kernel
+        acc = mfma32h(ah0, bh[0][0], acc);
+        acc = mfma32h(ah0, bl[0][0], acc);
+        acc = mfma32h(al0, bh[0][0], acc);
+        acc = mfma32h(ah1, bh[0][1], acc);
+        acc = mfma32h(ah1, bl[0][1], acc);
+        acc = mfma32h(al1, bh[0][1], acc);
+        if (ib < Lb && l < L) {
+            const long row = (long)(n / m.inner) * m.outer + (long)(n % m.inner) * m.istride + (long)l * m.lstride;
+            float* p = x + row * 64 + 16 * wv + 4 * a.g;
+            stg4(p, ldg4(p) + acc);
+        }
     }
 }
 
@@ -589,13 +680,23 @@ __global__ __launch_bounds__(64 * DP_WAVES) void dwpw2_x3_kernel(float* __restri
                                                        const float* __restrict__ dw_w,
                                                        const float* __restrict__ dw_b,
                                                        const _Float16* __restrict__ w2i,
-                                                       const float* __restrict__ b2, TokMap m) {
+                                                       const float* __restrict__ b2, TokMap m, int nseq, int ntl) {
     __shared__ __attribute__((aligned(16))) float utile[(DP_TL + DP_K - 1) * 128];
     __shared__ __attribute__((aligned(16))) _Float16 vth[DP_TL * DP_VS];
     __shared__ __attribute__((aligned(16))) _Float16 vtl[DP_TL * DP_VS];
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4, wv = tid >> 6;
-    const int n = blockIdx.x;
-    const int l0 = blockIdx.y * DP_TL;
+    // XCD-contiguous order with the l-tile fastest: consecutive tiles of a sequence (which share 30 halo rows of
+    // u) run back to back on one XCD, so the halo is an L2 hit instead of a second HBM read
+    int n, l0;
+    if (XCD_ORDER) {
+        const int lt = (int)(((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) % ntl);
+        n = (int)(((long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) / ntl);
+        if (n >= nseq) return;                              // padding blocks of the rounded-up grid (block-uniform)
+        l0 = lt * DP_TL;
+    } else {
+        n = blockIdx.x;
+        l0 = blockIdx.y * DP_TL;
+    }
     const long nbase = (long)(n / m.inner) * m.outer + (long)(n % m.inner) * m.istride;
 
     // pointwise operands for this wave: token block tb, output blocks ob0 .. ob0 + NOB - 1
@@ -686,6 +787,176 @@ __global__ __launch_bounds__(64 * DP_WAVES) void dwpw2_x3_kernel(float* __restri
 }
 
 // ---------------------------------------------------------------------------------
+// Sliding-window form of dwpw2_x3_kernel (the default): a block owns DS_SEG consecutive 32-position tiles of
+// one sequence and walks them in order.  The 62-row u window lives in LDS; after a tile its last 30 rows are
+// moved to the front and only the 32 NEW rows are fetched - into registers one tile ahead, so the HBM latency
+// of tile t+1 is covered by the depthwise arithmetic of tile t.  Compared with one block per tile:
+//   * u is read (128 + 30) / 128 = 1.23x per segment instead of 62 / 32 = 1.94x (a frequency-axis sequence,
+//     L = 101, is a single segment: exactly 1.0x),
+//   * the 32 KB pointwise weight image and the 31 depthwise taps are fetched once per segment, not per tile,
+//   * the depthwise window slides over all 16 outputs of a thread (46 LDS reads per 496 FMAs instead of 136).
+// Work items are (sequence, segment) in XCD-contiguous order so the 30 halo rows between two segments of a
+// sequence are an L2 hit.
+// ---------------------------------------------------------------------------------
+#ifndef DS_SEG
+#define DS_SEG 4
+#endif
+#ifndef DS_OCC
+#define DS_OCC 2             // blocks (= waves per SIMD) the register allocation is sized for
+#endif
+__global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restrict__ x, const float* __restrict__ u,
+                                                        const float* __restrict__ dw_w,
+                                                        const float* __restrict__ dw_b,
+                                                        const _Float16* __restrict__ w2i,
+                                                        const float* __restrict__ b2, TokMap m, int nseq, int nsegs) {
+    constexpr int ROWS = DP_TL + DP_K - 1;                       // 62
+    __shared__ __attribute__((aligned(16))) float utile[ROWS * 128];
+    __shared__ __attribute__((aligned(16))) _Float16 vth[DP_TL * DP_VS];
+    __shared__ __attribute__((aligned(16))) _Float16 vtl[DP_TL * DP_VS];
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4, wv = tid >> 6;
+    const long item = XCD_ORDER ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+    const int n = (int)(item / nsegs), seg = (int)(item - (long)n * nsegs);
+    if (n >= nseq) return;                                       // padding blocks of the rounded-up grid
+    const int l_begin = seg * DS_SEG * DP_TL;
+    const int l_end = l_begin + DS_SEG * DP_TL < m.L ? l_begin + DS_SEG * DP_TL : m.L;
+    const int ntiles = (l_end - l_begin + DP_TL - 1) / DP_TL;
+    const long nbase = (long)(n / m.inner) * m.outer + (long)(n % m.inner) * m.istride;
+
+    // pointwise operands of this wave: token block tb, output blocks ob0, ob0 + 1 (held for the whole segment)
+    const int tb = wv >> 1, ob0 = (wv & 1) * 2;
+    f16x8 ah[2][4], al[2][4];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            const _Float16* wp = w2i + ((ob0 + o) * 4 + mm) * 1024 + lane * 8;
+            ah[o][mm] = *reinterpret_cast<const f16x8*>(wp);
+            al[o][mm] = *reinterpret_cast<const f16x8*>(wp + 512);
+        }
+    f32x4 bias2[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) bias2[o] = ldg4(b2 + 16 * (ob0 + o) + 4 * g);
+
+    // window row r of the tile at l0 <-> sequence position l0 - 15 + r; rows outside [0, L) are the conv's zero padding
+    auto load_row4 = [&](int l0, int rr, int qd) -> f32x4 {
+        const int l = l0 - (DP_K / 2) + rr;
+        const int lc = l < 0 ? 0 : (l < m.L ? l : m.L - 1);
+        f32x4 v = ldg4(u + (nbase + (long)lc * m.lstride) * 128 + qd * 4);
+        if (l < 0 || l >= m.L) v = splat4(0.f);
+        return v;
+    };
+    {
+        constexpr int NLD = (ROWS * 32 + 255) / 256;             // 8: all loads first (see stage_lds16)
+        f32x4 stg[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 256 * k;
+            stg[k] = load_row4(l_begin, i < ROWS * 32 ? (i >> 5) : ROWS - 1, i & 31);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = tid + 256 * k;
+            if (i < ROWS * 32) *reinterpret_cast<f32x4*>(&utile[(i >> 5) * 128 + (i & 31) * 4]) = stg[k];
+        }
+    }
+    const int chn = tid & 127, sub = tid >> 7;
+    float wt[DP_K];
+#pragma unroll
+    for (int t = 0; t < DP_K; ++t) wt[t] = dw_w[t * 128 + chn];
+    const float bias = dw_b[chn];
+    // B-operand order inside a row: channel 32m + 16h + 4gq + r  ->  32m + 8gq + 4h + r
+    const int vcol = (chn & ~31) + ((chn >> 2) & 3) * 8 + ((chn >> 4) & 1) * 4 + (chn & 3);
+    const float* ucol = utile + sub * 16 * 128 + chn;
+    __syncthreads();
+
+#pragma unroll 1
+    for (int t = 0; t < ntiles; ++t) {
+        const int l0 = l_begin + t * DP_TL;
+        const bool has_next = t + 1 < ntiles;
+        // ---- prefetch: the 32 new rows of the next tile, and this tile's residual rows for the epilogue ----
+        f32x4 nxt[4];
+        if (has_next) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = tid + 256 * k;
+                nxt[k] = load_row4(l0 + DP_TL, DP_K - 1 + (i >> 5), i & 31);
+            }
+        }
+        const int lrow = l0 + 16 * tb + c;
+        const bool live = lrow < m.L;
+        float* xr = x + (nbase + (long)(live ? lrow : m.L - 1) * m.lstride) * 64;
+        f32x4 xold[2];
+#pragma unroll
+        for (int o = 0; o < 2; ++o) xold[o] = ldg4(xr + 16 * (ob0 + o) + 4 * g);
+
+        // ---- depthwise: 16 outputs of channel chn from a 46-row sliding window ----
+        // (a half tile that lies entirely beyond the sequence end is skipped: 16 of the 128 slots of a frequency-axis
+        // sequence, L = 101; its v rows keep stale values that feed only outputs which are never stored)
+        if (l0 + sub * 16 < m.L) {
+            float acc[16];
+#pragma unroll
+            for (int oo = 0; oo < 16; ++oo) acc[oo] = bias;
+#pragma unroll
+            for (int kk = 0; kk < 16 + DP_K - 1; ++kk) {
+                const float uv = ucol[kk * 128];
+#pragma unroll
+                for (int oo = 0; oo < 16; ++oo) {
+                    const int tp = kk - oo;
+                    if (tp >= 0 && tp < DP_K) acc[oo] = fmaf(wt[tp], uv, acc[oo]);
+                }
+            }
+#pragma unroll
+            for (int oo = 0; oo < 16; oo += 2) {
+                f16x2 hi, lo;
+                split2(swishf(acc[oo]), swishf(acc[oo + 1]), hi, lo);
+                vth[(sub * 16 + oo) * DP_VS + vcol] = hi[0];
+                vth[(sub * 16 + oo + 1) * DP_VS + vcol] = hi[1];
+                vtl[(sub * 16 + oo) * DP_VS + vcol] = lo[0];
+                vtl[(sub * 16 + oo + 1) * DP_VS + vcol] = lo[1];
+            }
+        }
+        // the 30 rows the next window shares with this one (read before the barrier, written after it)
+        f32x4 keep[4];
+        if (has_next) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = tid + 256 * k;                      // 30 rows x 32 quads = 960
+                const int ii = i < (DP_K - 1) * 32 ? i : (DP_K - 1) * 32 - 1;
+                keep[k] = *reinterpret_cast<const f32x4*>(&utile[(DP_TL + (ii >> 5)) * 128 + (ii & 31) * 4]);
+            }
+        }
+        __syncthreads();                                          // all u-window reads and v-tile writes are done
+
+        // ---- pointwise 128 -> 64 on the matrix pipe + bias + residual ----
+        f32x4 acc2[2] = {bias2[0], bias2[1]};
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(&vth[(16 * tb + c) * DP_VS + 32 * mm + 8 * g]);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(&vtl[(16 * tb + c) * DP_VS + 32 * mm + 8 * g]);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) acc2[o] = mfma32h(ah[o][mm], bh, acc2[o]);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) acc2[o] = mfma32h(ah[o][mm], bl, acc2[o]);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) acc2[o] = mfma32h(al[o][mm], bh, acc2[o]);
+        }
+        if (live) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) stg4(xr + 16 * (ob0 + o) + 4 * g, xold[o] + acc2[o]);
+        }
+        if (has_next) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = tid + 256 * k;
+                if (i < (DP_K - 1) * 32) *reinterpret_cast<f32x4*>(&utile[(i >> 5) * 128 + (i & 31) * 4]) = keep[k];
+                *reinterpret_cast<f32x4*>(&utile[(DP_K - 1 + (i >> 5)) * 128 + (i & 31) * 4]) = nxt[k];
+            }
+        }
+        __syncthreads();                                          // window and v tiles are free for the next tile
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
 static int persistent_grid(int ntiles, int blocks_per_cu) {
@@ -721,19 +992,41 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
                            b.xb, seq, Lb2, w16.qkv_w, w.qkv_b, io, qtiles)));
     {
         const int nqg = (seq.Lb + ATT_NQ - 1) / ATT_NQ;
+#if ATTN_FUSE_OUT
+        static_assert(ATT_NQ == 2, "the fused to_out epilogue stashes one pair of O tiles per head");
+        const long nb = (long)N * nqg;
+        LAUNCH(ctx, "attn_out", (attn_out_x3_kernel<<<XCD_ORDER ? (unsigned)(((nb + 7) / 8) * 8) : (unsigned)nb, 256, 0, s>>>(
+                                    io, w16.rel_img, w.max_pos, b.xb, seq, w16.wo, w.bo, Lb2, nqg, nb)));
+    }
+#else
         const long waves = (long)N * 4 * nqg;
-        LAUNCH(ctx, "attn", (attn_x3_kernel<<<(unsigned)((waves + 3) / 4), 256, 0, s>>>(
+        const unsigned ablk = (unsigned)((waves + 3) / 4);
+        LAUNCH(ctx, "attn", (attn_x3_kernel<<<XCD_ORDER ? ((ablk + 7) / 8) * 8 : ablk, 256, 0, s>>>(
                                 io, w16.rel_img, w.max_pos, b.o, seq.L, seq.Lb, Lb2, nqg, waves)));
     }
     const int otiles = (seq.nblocks + XNTB - 1) / XNTB;
     LAUNCH(ctx, "outproj", (outproj_x3_kernel<<<persistent_grid(otiles, 2), 512, 0, s>>>(b.xb, seq, b.o, w16.wo,
                                                                                            w.bo, otiles)));
+#endif
     if (taps) hipMemcpyAsync(taps + (size_t)M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
 
     LAUNCH(ctx, "pw1glu", (pw1glu_x3_kernel<<<persistent_grid(flat_tiles, 2), 512, 0, s>>>(
                               b.xb, b.u, w16.pw1_w, w.pw1_b, M, flat_tiles)));
-    dim3 dgrid(N, (seq.L + DP_TL - 1) / DP_TL);
-    LAUNCH(ctx, "dwpw2", (dwpw2_x3_kernel<<<dgrid, 64 * DP_WAVES, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq)));
+    const int ntl = (seq.L + DP_TL - 1) / DP_TL;
+#if DWPW2_SLIDE
+    {
+        const int nsegs = (ntl + DS_SEG - 1) / DS_SEG;
+        const long items = (long)N * nsegs;
+        const unsigned grid = XCD_ORDER ? (unsigned)(((items + 7) / 8) * 8) : (unsigned)items;
+        LAUNCH(ctx, "dwpw2", (dwpw2s_x3_kernel<<<grid, 256, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
+                                                                   nsegs)));
+    }
+#else
+    dim3 dgrid(N, ntl);
+    if (XCD_ORDER) dgrid = dim3((unsigned)((((long)N * ntl + 7) / 8) * 8), 1);
+    LAUNCH(ctx, "dwpw2", (dwpw2_x3_kernel<<<dgrid, 64 * DP_WAVES, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq,
+                                                                          N, ntl)));
+#endif
     if (taps) {
         hipMemcpyAsync(taps + (size_t)2 * M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
         LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, FFN_WAVES><<<ffn_grid(flat_tiles), 64 * FFN_WAVES, 0, s>>>(

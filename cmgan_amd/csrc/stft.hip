@@ -120,16 +120,21 @@ __global__ __launch_bounds__(256) void stft_compress_kernel(SpectralTables tb, c
 //     28 KB LDS chunk per 16-bin block, shared by the four waves.
 // Per launch at B = 32: 6 x 32 blocks, 546 MFMAs per wave, 87 MB of matrix reads from L2.
 // ---------------------------------------------------------------------------------
-template <int NFFT, int HOP>
-__global__ __launch_bounds__(256) void stft_fold_x3_kernel(SpectralTables tb, const float* __restrict__ wav,
-                                                           const float* __restrict__ scale, int L, int T,
-                                                           float* __restrict__ spec) {
+template <int NFFT, int HOP, int BSPLIT>
+__global__ __launch_bounds__(256, 2) void stft_fold_x3_kernel(SpectralTables tb, const float* __restrict__ wav,
+                                                              const float* __restrict__ scale, int L, int T,
+                                                              float* __restrict__ spec) {
     constexpr int H = NFFT / 2, M32 = (H + 1 + 31) / 32, SEG = 63 * HOP + NFFT;
     constexpr int CHUNK = 2 * M32 * 1024;                    // halfs per bin block: [cos | -sin][M32][hi | lo][64][8]
     constexpr int NLD = CHUNK / 8 / 256;                     // 16-byte loads per thread per chunk
     static_assert(CHUNK % (8 * 256) == 0, "chunk must split evenly over the block");
-    __shared__ __attribute__((aligned(16))) float seg[SEG + 4];
-    __shared__ __attribute__((aligned(16))) _Float16 chunk[2][CHUNK];
+    // LDS: 2 x 28 KB = two blocks per CU.  The staged waveform segment is only needed until the folded operands
+    // are in registers, so it shares its bytes with the second matrix buffer (first written after bin block 0).
+    constexpr int RAWB = (SEG + 4) * 4 > CHUNK * 2 ? (SEG + 4) * 4 : CHUNK * 2;
+    __shared__ __attribute__((aligned(16))) _Float16 chunk0[CHUNK];
+    __shared__ __attribute__((aligned(16))) unsigned char raw[RAWB];
+    float* const seg = reinterpret_cast<float*>(raw);
+    _Float16* const chunk1 = reinterpret_cast<_Float16*>(raw);
     __shared__ float wmax[4];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     const int b = blockIdx.y, fb = blockIdx.x;               // 64-frame tile of clip b
@@ -137,13 +142,19 @@ __global__ __launch_bounds__(256) void stft_fold_x3_kernel(SpectralTables tb, co
     const float sc = scale ? scale[b] : 1.0f;
     const float* x = wav + (long)b * L;
     const u32x4* img = reinterpret_cast<const u32x4*>(tb.fold_fwd16);
+    constexpr int FBC = (NFFT / 2 + 1 + 15) / 16;           // bin blocks
+    // Small batches leave most CUs idle and the 13-step chain of one block IS the kernel time: blockIdx.z then
+    // splits the bin blocks BSPLIT ways (every bin is computed by exactly the same instructions either way).
+    constexpr int NBPER = (FBC + BSPLIT - 1) / BSPLIT;
+    const int bb0 = BSPLIT > 1 ? (int)blockIdx.z * NBPER : 0;
+    auto chunk_of = [&](int i) { const int bb = bb0 + i; return bb < FBC ? bb : FBC - 1; };   // clamped: any valid chunk
     // matrix chunks are prefetched DEPTH bin blocks ahead into registers (an L2 round trip is ~3 chunks of MFMA work)
     constexpr int DEPTH = 3;
     u32x4 pre[DEPTH][NLD];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) pre[d][i] = img[(long)d * (CHUNK / 8) + threadIdx.x + 256 * i];
+        for (int i = 0; i < NLD; ++i) pre[d][i] = img[(long)chunk_of(d) * (CHUNK / 8) + threadIdx.x + 256 * i];
     {
         constexpr int NSEG = (SEG + 255) / 256;             // every segment load of the thread in flight at once
         float v[NSEG];
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(256) void stft_fold_x3_kernel(SpectralTables tb, co
         if (lane == 0) wmax[wv] = amax;
     }
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) reinterpret_cast<u32x4*>(chunk[0])[threadIdx.x + 256 * i] = pre[0][i];
+    for (int i = 0; i < NLD; ++i) reinterpret_cast<u32x4*>(chunk0)[threadIdx.x + 256 * i] = pre[0][i];
     __syncthreads();
     // fp16 hi/lo operands only cover ~2^-24 .. 2^16 around 1: bring the tile's samples to [0.5, 1) with an exact
     // power-of-two factor (and undo it on the fp32 result), so the transform works at any input amplitude
@@ -203,49 +214,52 @@ __global__ __launch_bounds__(256) void stft_fold_x3_kernel(SpectralTables tb, co
         split8(us[0], us[1], ush[m], usl[m]);
     }
 
+    __syncthreads();                                          // every wave has folded: the segment's bytes become chunk1
+
     const long P = (long)T * tb.F;
-    constexpr int FBC = (NFFT / 2 + 1 + 15) / 16;           // bin blocks (compile time: the loop is fully unrolled
-                                                            // so the prefetch ring is statically indexed)
 #pragma unroll
-    for (int bb = 0; bb < FBC; ++bb) {
-        if (bb >= 1 && bb + DEPTH - 1 < FBC) {               // slot of chunk bb-1 is free again: fetch chunk bb+DEPTH-1
+    for (int i = 0; i < NBPER; ++i) {                        // fully unrolled: the prefetch ring is statically indexed
+        const int bb = bb0 + i;
+        if (i >= 1 && i + DEPTH - 1 < NBPER) {               // slot of chunk i-1 is free again: fetch chunk i+DEPTH-1
 #pragma unroll
-            for (int i = 0; i < NLD; ++i)
-                pre[(bb + DEPTH - 1) % DEPTH][i] = img[(long)(bb + DEPTH - 1) * (CHUNK / 8) + threadIdx.x + 256 * i];
+            for (int k = 0; k < NLD; ++k)
+                pre[(i + DEPTH - 1) % DEPTH][k] = img[(long)chunk_of(i + DEPTH - 1) * (CHUNK / 8) + threadIdx.x + 256 * k];
         }
-        const _Float16* cb = chunk[bb & 1] + lane * 8;
-        f32x4 are = splat4(0.f), aim = splat4(0.f);
+        if (BSPLIT == 1 || bb < FBC) {                        // block-uniform
+            const _Float16* cb = ((i & 1) ? chunk1 : chunk0) + lane * 8;
+            f32x4 are = splat4(0.f), aim = splat4(0.f);
 #pragma unroll
-        for (int m = 0; m < M32; ++m) {
-            const f16x8 ch = *reinterpret_cast<const f16x8*>(cb + m * 1024);
-            const f16x8 cl = *reinterpret_cast<const f16x8*>(cb + m * 1024 + 512);
-            const f16x8 sh = *reinterpret_cast<const f16x8*>(cb + (M32 + m) * 1024);
-            const f16x8 sl = *reinterpret_cast<const f16x8*>(cb + (M32 + m) * 1024 + 512);
-            are = mfma32h(uch[m], ch, are);
-            aim = mfma32h(ush[m], sh, aim);
-            are = mfma32h(uch[m], cl, are);
-            aim = mfma32h(ush[m], sl, aim);
-            are = mfma32h(ucl[m], ch, are);
-            aim = mfma32h(usl[m], sh, aim);
-        }
-        const int bin = bb * 16 + c;
-        if (bin < tb.F) {
+            for (int m = 0; m < M32; ++m) {
+                const f16x8 ch = *reinterpret_cast<const f16x8*>(cb + m * 1024);
+                const f16x8 cl = *reinterpret_cast<const f16x8*>(cb + m * 1024 + 512);
+                const f16x8 sh = *reinterpret_cast<const f16x8*>(cb + (M32 + m) * 1024);
+                const f16x8 sl = *reinterpret_cast<const f16x8*>(cb + (M32 + m) * 1024 + 512);
+                are = mfma32h(uch[m], ch, are);
+                aim = mfma32h(ush[m], sh, aim);
+                are = mfma32h(uch[m], cl, are);
+                aim = mfma32h(ush[m], sl, aim);
+                are = mfma32h(ucl[m], ch, are);
+                aim = mfma32h(usl[m], sh, aim);
+            }
+            const int bin = bb * 16 + c;
+            if (bin < tb.F) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int t = fb * 64 + wv * 16 + 4 * g + r;
-                if (t < T) {
-                    const float xr = are[r] * down, xi = aim[r] * down;
-                    const float m2 = xr * xr + xi * xi;
-                    const float s = pow_pos(m2, -0.35f);
-                    spec[((long)b * 2 + 0) * P + (long)t * tb.F + bin] = xr * s;
-                    spec[((long)b * 2 + 1) * P + (long)t * tb.F + bin] = xi * s;
+                for (int r = 0; r < 4; ++r) {
+                    const int t = fb * 64 + wv * 16 + 4 * g + r;
+                    if (t < T) {
+                        const float xr = are[r] * down, xi = aim[r] * down;
+                        const float m2 = xr * xr + xi * xi;
+                        const float s = pow_pos(m2, -0.35f);
+                        spec[((long)b * 2 + 0) * P + (long)t * tb.F + bin] = xr * s;
+                        spec[((long)b * 2 + 1) * P + (long)t * tb.F + bin] = xi * s;
+                    }
                 }
             }
         }
-        if (bb + 1 < FBC) {
+        if (i + 1 < NBPER) {
 #pragma unroll
-            for (int i = 0; i < NLD; ++i)
-                reinterpret_cast<u32x4*>(chunk[(bb + 1) & 1])[threadIdx.x + 256 * i] = pre[(bb + 1) % DEPTH][i];
+            for (int k = 0; k < NLD; ++k)
+                reinterpret_cast<u32x4*>(((i + 1) & 1) ? chunk1 : chunk0)[threadIdx.x + 256 * k] = pre[(i + 1) % DEPTH][k];
         }
         __syncthreads();
     }
@@ -254,9 +268,16 @@ __global__ __launch_bounds__(256) void stft_fold_x3_kernel(SpectralTables tb, co
 void launch_stft_compress(LaunchCtx ctx, const SpectralTables& tb, const float* wav, const float* scale, int B,
                           int L, int T, float* spec) {
     if (tb.fold_fwd16 && tb.n_fft == 400 && tb.hop == 100) {
-        dim3 grid64((T + 63) / 64, B);
-        LAUNCH(ctx, "stft_compress",
-               (stft_fold_x3_kernel<400, 100><<<grid64, 256, 0, ctx.stream>>>(tb, wav, scale, L, T, spec)));
+        const int tiles = (T + 63) / 64;
+        if ((long)tiles * B >= 512) {                         // two blocks per CU already cover the chip
+            dim3 grid64(tiles, B);
+            LAUNCH(ctx, "stft_compress",
+                   (stft_fold_x3_kernel<400, 100, 1><<<grid64, 256, 0, ctx.stream>>>(tb, wav, scale, L, T, spec)));
+        } else {
+            dim3 grid64(tiles, B, 3);
+            LAUNCH(ctx, "stft_compress",
+                   (stft_fold_x3_kernel<400, 100, 3><<<grid64, 256, 0, ctx.stream>>>(tb, wav, scale, L, T, spec)));
+        }
         return;
     }
     dim3 grid((T + 15) / 16, B);

@@ -106,13 +106,15 @@ class Engine:
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _in(self, t: torch.Tensor, name: str) -> torch.Tensor:
-        return self._in(t, name, self.device)
+        return _f32c(t, name, self.device)
 
     # ---- workspace -----------------------------------------------------------------
     def _ws_token(self):
         """Identity of what a captured graph's kernel arguments point into: the workspace allocation and the
         weight buffers (cmgan_weights_generation).  A graph whose token differs is stale and is re-captured."""
-        return (self._ws, self.lib.cmgan_weights_generation(self._h))
+        ws = self._ws
+        return (ws.data_ptr() if ws is not None else 0, ws.numel() if ws is not None else 0,
+                int(self.lib.cmgan_weights_generation(self._h)))
 
     def _workspace(self, B: int, T: int) -> torch.Tensor:
         need = self.lib.cmgan_workspace_bytes(self._h, B, T)
@@ -288,6 +290,7 @@ class Engine:
         return g_out
 
     # ---- training / validation step pieces (src/train.py) ----------------------------------
+    @_on_device
     def loss_terms(self, est_real=None, est_imag=None, clean_spec=None, est_audio=None, clean_audio=None,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """{loss_ri, loss_mag, time_loss, time_mse} of Trainer.calculate_generator_loss (train.py:124-151) as a

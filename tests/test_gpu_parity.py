@@ -356,7 +356,11 @@ def test_real_recordings_match_reference_golden(model, tag):
     noisy = (g[f"pcm_{tag}"].float() / 32768.0)[None, :]
     out = enhance_one_track(model, noisy.to(DEV))
     assert torch.isfinite(out).all()
-    _check(f"real track '{tag}' vs reference golden", out, g[f"enhanced_{tag}"])
+    # The power law |X|^-0.7 is ill-conditioned on near-silent bins: the reference's OWN fp32 front end
+    # (torch.stft + power_compress) sits 1.0e-4 ('silence') / 1.7e-4 ('a') from its fp64 evaluation in this
+    # max-norm on these very tracks (measured), so the golden carries that much fp32 noise
+    # and the elementwise floor is 2e-4 of the peak here instead of the 2e-5 used on synthetic clips.
+    _check(f"real track '{tag}' vs reference golden", out, g[f"enhanced_{tag}"], atol_rel=2e-4)
 
 
 def test_one_row_of_the_full_config2_batch_matches_the_oracle_directly(model, sd):
