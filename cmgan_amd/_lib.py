@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # CMGAN_HIP_LIB selects an alternative BUILD of the same HIP library (cmgan_amd.build variants, used for
@@ -35,6 +35,10 @@ class Taps(Structure):
                 ("complex_dev", c_void_p)]
 
 
+class FfnParams(Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln_weight", "ln_bias", "w1", "b1", "w2", "b2")]
+
+
 class KernelTime(Structure):
     _fields_ = [("name", c_char_p), ("ms", c_float)]
 
@@ -50,6 +54,11 @@ SIGNATURES = {
     "cmgan_weights_generation": (c_int, [c_void_p]),
     "cmgan_loss_terms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
                                  c_void_p, c_void_p]),
+    "cmgan_ffn_train_workspace_bytes": (c_size_t, [c_void_p, c_longlong]),
+    "cmgan_ffn_train_forward": (c_int, [c_void_p, c_void_p, c_longlong, POINTER(FfnParams), c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cmgan_ffn_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, POINTER(FfnParams), c_void_p,
+                                         c_void_p, c_void_p, POINTER(FfnParams), c_void_p, c_size_t, c_void_p]),
     "cmgan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "cmgan_rms_scale": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "cmgan_num_frames": (c_int, [c_void_p, c_int]),

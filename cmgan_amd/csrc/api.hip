@@ -840,6 +840,41 @@ extern "C" int cmgan_loss_terms(cmgan_handle* h, const float* est_real, const fl
     return check_launch(h, "loss_terms");
 }
 
+extern "C" size_t cmgan_ffn_train_workspace_bytes(const cmgan_handle* h, long long M) {
+    if (!h || M <= 0) return 0;
+    return ffn_train_ws_floats((long)M) * sizeof(float);
+}
+
+static bool ffn_params_ok(const cmgan_ffn_params* p) {
+    return p && p->ln_weight && p->ln_bias && p->w1 && p->b1 && p->w2 && p->b2;
+}
+static FfnTrainParams ffn_params(const cmgan_ffn_params* p) {
+    return FfnTrainParams{p->ln_weight, p->ln_bias, p->w1, p->b1, p->w2, p->b2};
+}
+
+extern "C" int cmgan_ffn_train_forward(cmgan_handle* h, const float* x, long long M, const cmgan_ffn_params* params,
+                                       const float* mask1, const float* mask2, float* y, void* ws, size_t ws_bytes,
+                                       void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !y || M <= 0 || !ffn_params_ok(params)) return fail(h, CMGAN_E_BADARG, "cmgan_ffn_train_forward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, ffn_train_ws_floats((long)M) * sizeof(float))) return rc;
+    launch_ffn_train_forward(begin(h, stream), x, (long)M, ffn_params(params), mask1, mask2, y, (float*)ws);
+    return check_launch(h, "ffn_train_forward");
+}
+
+extern "C" int cmgan_ffn_train_backward(cmgan_handle* h, const float* x, const float* dy, long long M,
+                                        const cmgan_ffn_params* params, const float* mask1, const float* mask2,
+                                        float* dx, const cmgan_ffn_params* grads, void* ws, size_t ws_bytes,
+                                        void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !dy || !dx || M <= 0 || !ffn_params_ok(params) || !ffn_params_ok(grads))
+        return fail(h, CMGAN_E_BADARG, "cmgan_ffn_train_backward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, ffn_train_ws_floats((long)M) * sizeof(float))) return rc;
+    launch_ffn_train_backward(begin(h, stream), x, dy, (long)M, ffn_params(params), mask1, mask2, dx, ffn_params(grads),
+                              (float*)ws);
+    return check_launch(h, "ffn_train_backward");
+}
+
 // ------------------------------------------------------------------------------------
 // diagnostics
 // ------------------------------------------------------------------------------------

@@ -129,5 +129,19 @@ void launch_loss_terms(LaunchCtx, const float* est_real, const float* est_imag, 
                        long P, const float* est_audio, const float* clean_audio, long naudio, double* partials,
                        float* out4);
 
+// training-mode FeedForward (forward with dropout masks, full backward) on raw parameters
+struct FfnTrainParams {
+    float *gamma, *beta;      // PreNorm LayerNorm(64)                      conformer.py:68
+    float *w1, *b1;           // Linear(64, 256): weight [256,64], bias     conformer.py:140
+    float *w2, *b2;           // Linear(256, 64): weight [64,256], bias     conformer.py:143
+};
+#define FFN_WGRAD_SPLIT 64
+#define FFN_COLSUM_BLOCKS 128
+size_t ffn_train_ws_floats(long M);
+void launch_ffn_train_forward(LaunchCtx, const float* x, long M, const FfnTrainParams& p, const float* m1,
+                              const float* m2, float* y, float* ws);
+void launch_ffn_train_backward(LaunchCtx, const float* x, const float* dy, long M, const FfnTrainParams& p,
+                               const float* m1, const float* m2, float* dx, const FfnTrainParams& grad, float* ws);
+
 // ------------------------------- selftest ---------------------------------------
 void launch_selftest_mfma(hipStream_t, const float* a_fm, const float* b_fm, float* d, int KB);

@@ -90,3 +90,288 @@ void launch_loss_terms(LaunchCtx ctx, const float* est_real, const float* est_im
     LAUNCH(ctx, "loss_terms", (loss_final_kernel<<<1, 256, 0, ctx.stream>>>(partials, LOSS_BLOCKS, (double)nspec,
                                                                             audio ? (double)naudio : 0.0, out4)));
 }
+
+// =====================================================================================
+// Training-mode FeedForward (first backward slice of SURVEY.md N2).
+//   y = 0.5 * m2 * (W2 (m1 * Swish(W1 LN(x) + b1)) + b2)
+// = Scale(0.5, PreNorm(dim, FeedForward(dim, mult=4, dropout)))(x) of src/models/conformer.py:54-72,136-148,211 in
+// TRAIN mode, with the two nn.Dropout layers expressed as caller-supplied keep-masks m1 [M,256], m2 [M,64] (entries 0
+// or 1/(1-p); NULL = no dropout) so that the result is reproducible and comparable with autograd on the oracle.
+// The residual add of ConformerBlock.forward (conformer.py:217) stays with the caller (dx_total = dy + dx).
+//
+// Same per-token transposed MFMA chain as the inference kernels (out^T = W x^T on v_mfma_f32_16x16x4_f32, a wave owns
+// 16 tokens, C-fragments of one layer are the B-fragments of the next), on RAW parameters: the four A-operand images
+// (W1, W2, W2^T, W1^T, fragment-major) are re-packed on the device at every call because an optimiser step changes them.
+// Backward recomputes LN / W1 / Swish from x instead of saving the [M,256] hidden activations of the forward
+// (1 GB at B = 32): on this machine the extra 64x256 GEMM is cheaper than the HBM round trip.
+//   dz = 0.5 m2 dy              dW2 = dz^T d1     db2 = colsum dz
+//   dd1 = W2^T dz               dh = m1 dd1 Swish'(h),  Swish'(h) = s(h) (1 + h (1 - s(h)))
+//   dW1 = dh^T xn   db1 = colsum dh               dxn = W1^T dh
+//   dgamma = colsum(dxn xh)  dbeta = colsum dxn   dx = rstd (g dxn - mean(g dxn) - xh mean(g dxn xh))
+// Weight gradients are token-contractions (K = M): split-K MFMA products into fixed-shape partial slabs that a
+// second kernel adds in a fixed order - deterministic, no atomics.
+// =====================================================================================
+__global__ void pack_fm_kernel(const float* __restrict__ w, int R, int K, int ldw, int transpose, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * K) return;
+    const int r = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+    const int KB = K / 16, rb = blk / KB, kb = blk - rb * KB;
+    const int row = 16 * rb + (lane & 15), col = 16 * kb + 4 * (lane >> 4) + r;
+    out[i] = transpose ? w[(long)col * ldw + row] : w[(long)row * ldw + col];
+}
+
+struct FfnTrainImg {
+    const float *w1, *w2, *w2t, *w1t;     // fm [16][4], [4][16], [16][4], [4][16]
+    const float *gamma, *beta, *b1, *b2;
+};
+
+__device__ __forceinline__ bool ffn_load_norm(const float* __restrict__ x, long M, long t0, int c, int g,
+                                              const FfnTrainImg& w, f32x4 (&xh)[4], f32x4 (&xn)[1][4], float& rstd,
+                                              long& row) {
+    const long t = t0 + c;
+    const bool ok = t < M;
+    row = ok ? t : M - 1;
+    f32x4 xv[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) xv[kb] = ldg4(x + row * 64 + 16 * kb + 4 * g);
+    float mean;
+    ln_stats(xv, mean, rstd);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        xh[kb] = (xv[kb] - splat4(mean)) * splat4(rstd);
+        xn[0][kb] = xh[kb] * ldg4(w.gamma + 16 * kb + 4 * g) + ldg4(w.beta + 16 * kb + 4 * g);
+    }
+    return ok;
+}
+
+__global__ __launch_bounds__(256) void ffn_train_fwd_kernel(const float* __restrict__ x, long M, FfnTrainImg w,
+                                                            const float* __restrict__ m1,
+                                                            const float* __restrict__ m2, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (t0 >= M) return;
+    f32x4 xh[4], xn[1][4];
+    float rstd;
+    long row;
+    const bool ok = ffn_load_norm(x, M, t0, c, g, w, xh, xn, rstd, row);
+    f32x4 acc[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) acc[ob] = ldg4(w.b2 + 16 * ob + 4 * g);
+#pragma unroll 2
+    for (int hb = 0; hb < 16; ++hb) {
+        f32x4 h[1] = {ldg4(w.b1 + 16 * hb + 4 * g)};
+        lin_acc<4, 1>(w.w1 + (long)hb * 4 * 256 + lane * 4, xn, h);
+        f32x4 s;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] = swishf(h[0][r]);
+        if (m1) s = s * ldg4(m1 + row * 256 + 16 * hb + 4 * g);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            const f32x4 a = ldg4(w.w2 + ((long)ob * 16 + hb) * 256 + lane * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ob] = mfma16(a[r], s[r], acc[ob]);
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x4 v = acc[ob] * splat4(0.5f);
+            if (m2) v = v * ldg4(m2 + row * 64 + 16 * ob + 4 * g);
+            stg4(y + row * 64 + 16 * ob + 4 * g, v);
+        }
+    }
+}
+
+struct FfnBwdBufs {
+    float *dz, *d1, *dh, *xn, *g1, *dxn;      // [M,64] [M,256] [M,256] [M,64] [M,64] [M,64]
+};
+
+__global__ __launch_bounds__(256) void ffn_train_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            long M, FfnTrainImg w, const float* __restrict__ m1,
+                                                            const float* __restrict__ m2, float* __restrict__ dx,
+                                                            FfnBwdBufs o) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (t0 >= M) return;
+    f32x4 xh[4], xn[1][4];
+    float rstd;
+    long row;
+    const bool ok = ffn_load_norm(x, M, t0, c, g, w, xh, xn, rstd, row);
+    f32x4 dz[1][4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+        f32x4 v = ldg4(dy + row * 64 + 16 * ob + 4 * g) * splat4(0.5f);
+        if (m2) v = v * ldg4(m2 + row * 64 + 16 * ob + 4 * g);
+        if (!ok) v = splat4(0.f);                       // padding tokens of the last block contribute nothing
+        dz[0][ob] = v;
+        if (ok) {
+            stg4(o.dz + row * 64 + 16 * ob + 4 * g, v);
+            stg4(o.xn + row * 64 + 16 * ob + 4 * g, xn[0][ob]);
+        }
+    }
+    f32x4 dxn[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) dxn[kb] = splat4(0.f);
+#pragma unroll 2
+    for (int hb = 0; hb < 16; ++hb) {
+        f32x4 h[1] = {ldg4(w.b1 + 16 * hb + 4 * g)};
+        lin_acc<4, 1>(w.w1 + (long)hb * 4 * 256 + lane * 4, xn, h);
+        f32x4 dd1[1] = {splat4(0.f)};
+        lin_acc<4, 1>(w.w2t + (long)hb * 4 * 256 + lane * 4, dz, dd1);
+        f32x4 mk = splat4(1.f);
+        if (m1) mk = ldg4(m1 + row * 256 + 16 * hb + 4 * g);
+        f32x4 d1v, dhv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float hv = h[0][r], sg = sigmoidf_fast(hv);
+            d1v[r] = hv * sg * mk[r];
+            dhv[r] = dd1[0][r] * mk[r] * (sg * (1.f + hv * (1.f - sg)));
+        }
+        if (ok) {
+            stg4(o.d1 + row * 256 + 16 * hb + 4 * g, d1v);
+            stg4(o.dh + row * 256 + 16 * hb + 4 * g, dhv);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const f32x4 a = ldg4(w.w1t + ((long)kb * 16 + hb) * 256 + lane * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dxn[kb] = mfma16(a[r], dhv[r], dxn[kb]);
+        }
+    }
+    // LayerNorm backward (per token: the 64 channels live in the 4 lanes c, c+16, c+32, c+48)
+    f32x4 dxh[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        dxh[kb] = dxn[kb] * ldg4(w.gamma + 16 * kb + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s1 += dxh[kb][r];
+            s2 = fmaf(dxh[kb][r], xh[kb][r], s2);
+        }
+    }
+    const float mu1 = red_g_sum(s1) * (1.0f / 64.0f), mu2 = red_g_sum(s2) * (1.0f / 64.0f);
+    if (ok) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            stg4(dx + row * 64 + 16 * kb + 4 * g, (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd));
+            stg4(o.g1 + row * 64 + 16 * kb + 4 * g, dxn[kb] * xh[kb]);
+            stg4(o.dxn + row * 64 + 16 * kb + 4 * g, dxn[kb]);
+        }
+    }
+}
+
+// out_partial[s][i][j] = sum over the s-th token range of P[m][i] * Q[m][j]   (P [M,R], Q [M,C], row-major);
+// block = (16 rows i, 64 columns j, split s); its 4 waves take interleaved 16-token steps, combined through LDS.
+__global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                            long M, int R, int C, int nsplit,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[4][16 * 64];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int ib = blockIdx.x, jc = blockIdx.y, s = blockIdx.z;
+    const long steps = (M + 15) / 16, per = (steps + nsplit - 1) / nsplit;
+    const long st0 = (long)s * per, st1 = st0 + per < steps ? st0 + per : steps;
+    f32x4 acc[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = splat4(0.f);
+    for (long st = st0 + wv; st < st1; st += 4) {
+        float a[4];
+        f32x4 b[4];                                   // b[jb][r]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = st * 16 + 4 * g + r;
+            const bool ok = m < M;
+            const long mm = ok ? m : M - 1;
+            a[r] = ok ? P[mm * R + 16 * ib + c] : 0.f;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) b[jb][r] = ok ? Q[mm * C + 64 * jc + 16 * jb + c] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[jb] = mfma16(a[r], b[jb][r], acc[jb]);
+    }
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][(4 * g + r) * 64 + 16 * jb + c] = acc[jb][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        const int i = e >> 6, j = e & 63;
+        partial[((long)s * R + 16 * ib + i) * C + 64 * jc + j] = v;
+    }
+}
+
+// column sums of X [M,C] over NB fixed row ranges -> partial [NB][C]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long M, int C,
+                                                             float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int col = threadIdx.x % C, sub = threadIdx.x / C, nsub = 256 / C;     // C divides 256
+    const long per = (M + gridDim.x - 1) / gridDim.x;
+    const long m0 = (long)blockIdx.x * per, m1 = m0 + per < M ? m0 + per : M;
+    float s = 0.f;
+    for (long m = m0 + sub; m < m1; m += nsub) s += X[m * C + col];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (sub == 0) {
+        for (int k = 1; k < nsub; ++k) s += red[k * C + col];
+        partial[(long)blockIdx.x * C + col] = s;
+    }
+}
+
+// out[e] = sum_s partial[s][e] in index order
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nsplit, long n, float* __restrict__ out) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(long)k * n + e];
+    out[e] = s;
+}
+
+static FfnTrainImg ffn_pack_images(LaunchCtx ctx, const FfnTrainParams& p, float* img) {
+    hipStream_t s = ctx.stream;
+    float *w1 = img, *w2 = img + 16384, *w2t = img + 2 * 16384, *w1t = img + 3 * 16384;
+    LAUNCH(ctx, "ffn_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.w1, 256, 64, 64, 0, w1)));     // rows = hidden
+    LAUNCH(ctx, "ffn_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.w2, 64, 256, 256, 0, w2)));    // rows = out
+    LAUNCH(ctx, "ffn_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.w2, 256, 64, 256, 1, w2t)));   // rows = hidden
+    LAUNCH(ctx, "ffn_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.w1, 64, 256, 64, 1, w1t)));    // rows = in
+    return FfnTrainImg{w1, w2, w2t, w1t, p.gamma, p.beta, p.b1, p.b2};
+}
+
+size_t ffn_train_ws_floats(long M) {
+    return (size_t)4 * 16384 + (size_t)M * 768 + (size_t)FFN_WGRAD_SPLIT * 16384 * 2 + (size_t)FFN_COLSUM_BLOCKS * 256;
+}
+
+void launch_ffn_train_forward(LaunchCtx ctx, const float* x, long M, const FfnTrainParams& p, const float* m1,
+                              const float* m2, float* y, float* ws) {
+    const FfnTrainImg w = ffn_pack_images(ctx, p, ws);
+    const unsigned grid = (unsigned)((M + 63) / 64);
+    LAUNCH(ctx, "ffn_train_fwd", (ffn_train_fwd_kernel<<<grid, 256, 0, ctx.stream>>>(x, M, w, m1, m2, y)));
+}
+
+void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, long M, const FfnTrainParams& p,
+                               const float* m1, const float* m2, float* dx, const FfnTrainParams& grad, float* ws) {
+    hipStream_t s = ctx.stream;
+    const FfnTrainImg w = ffn_pack_images(ctx, p, ws);
+    float* act = ws + 4 * 16384;
+    FfnBwdBufs o{act, act + M * 64, act + M * 320, act + M * 576, act + M * 640, act + M * 704};
+    float* part = act + M * 768;                                  // [SPLIT][16384] x 2, then colsum slabs
+    float* cpart = part + (size_t)FFN_WGRAD_SPLIT * 16384 * 2;
+    const unsigned grid = (unsigned)((M + 63) / 64);
+    LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_kernel<<<grid, 256, 0, s>>>(x, dy, M, w, m1, m2, dx, o)));
+    // dW2 [64,256] = dz^T d1 ; dW1 [256,64] = dh^T xn
+    LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial_kernel<<<dim3(4, 4, FFN_WGRAD_SPLIT), 256, 0, s>>>(
+                                       o.dz, o.d1, M, 64, 256, FFN_WGRAD_SPLIT, part)));
+    LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial_kernel<<<dim3(16, 1, FFN_WGRAD_SPLIT), 256, 0, s>>>(
+                                       o.dh, o.xn, M, 256, 64, FFN_WGRAD_SPLIT, part + (size_t)FFN_WGRAD_SPLIT * 16384)));
+    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<64, 256, 0, s>>>(part, FFN_WGRAD_SPLIT, 16384, grad.w2)));
+    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<64, 256, 0, s>>>(part + (size_t)FFN_WGRAD_SPLIT * 16384,
+                                                                               FFN_WGRAD_SPLIT, 16384, grad.w1)));
+    struct { const float* X; int C; float* out; } sums[4] = {
+        {o.dh, 256, grad.b1}, {o.dz, 64, grad.b2}, {o.g1, 64, grad.gamma}, {o.dxn, 64, grad.beta}};
+    for (auto& cs : sums) {
+        LAUNCH(ctx, "ffn_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(cs.X, M, cs.C, cpart)));
+        LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<1, 256, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, cs.C, cs.out)));
+    }
+}

@@ -1,0 +1,121 @@
+"""Pieces of the reference's training step (src/train.py) that are built on the HIP path so far
+(SURVEY.md N2 - a bounded slice, not the whole trainer):
+
+* `generator_loss_terms`   - the non-adversarial terms of Trainer.calculate_generator_loss (train.py:124-151) as one
+                             deterministic device reduction; the per-rank scalars a data-parallel step all-reduces.
+* `FeedForwardTrain`       - a ConformerBlock's `Scale(0.5, PreNorm(dim, FeedForward(dim, mult=4, dropout)))` branch
+                             (conformer.py:54-72, 136-148, 211-212) in TRAIN mode: forward with the two Dropout layers
+                             as explicit keep-masks, and the full backward (dL/dx and all six parameter gradients).
+
+Everything numerical runs in libcmgan_hip (csrc/train.hip); this module only owns parameter tensors, draws the
+dropout masks with torch's generator (plumbing) and passes pointers.  The remaining backward kernels (attention,
+conv module, dense convs, InstanceNorm, STFT), the metric discriminator and the optimiser are not built.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from ._lib import FfnParams, check
+from .engine import Engine
+
+__all__ = ["FeedForwardTrain", "generator_loss_terms", "dropout_mask"]
+
+_KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.net.0.weight", "fn.fn.net.0.bias",
+         "fn.fn.net.3.weight", "fn.fn.net.3.bias")
+_FIELDS = ("ln_weight", "ln_bias", "w1", "b1", "w2", "b2")
+_SHAPES = ((64,), (64,), (256, 64), (256,), (64, 256), (64,))
+
+
+def dropout_mask(shape, p: float, device, generator: Optional[torch.Generator] = None) -> Optional[torch.Tensor]:
+    """Keep-mask of nn.Dropout(p) in train mode: Bernoulli(1-p) / (1-p), float32 (None when p == 0)."""
+    if p <= 0.0:
+        return None
+    keep = torch.rand(shape, device=device, generator=generator) >= p
+    return keep.to(torch.float32) / (1.0 - p)
+
+
+def generator_loss_terms(engine: Engine, est_real, est_imag, clean_spec, est_audio, clean_audio,
+                         loss_weights=(0.1, 0.9, 0.2)) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(weighted loss without the GAN term, float32[4] = {loss_ri, loss_mag, time_loss, time_mse}) on the device.
+    loss = w0 loss_ri + w1 loss_mag + w2 time_loss   (train.py:143-148; default weights train.py:28)."""
+    terms = engine.loss_terms(est_real, est_imag, clean_spec, est_audio, clean_audio)
+    w = torch.tensor(list(loss_weights) + [0.0], dtype=torch.float32, device=terms.device)
+    return (terms * w).sum(), terms
+
+
+class FeedForwardTrain:
+    """ff1 / ff2 branch of one ConformerBlock in train mode on the HIP kernels.
+
+    `state` holds the branch's six tensors under the reference's key names relative to `ff1.` / `ff2.`
+    (`fn.norm.weight`, `fn.fn.net.0.weight`, ...), e.g. a slice of `TSCNet.state_dict()`."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], dropout: float = 0.2, engine: Optional[Engine] = None,
+                 device=None):
+        self.engine = engine if engine is not None else Engine(device=device)
+        self.p = float(dropout)
+        dev = self.engine.device
+        self.params = {}
+        for key, shape in zip(_KEYS, _SHAPES):
+            t = state[key].detach().to(dev, torch.float32).contiguous()
+            if tuple(t.shape) != shape:
+                raise ValueError(f"{key}: shape {tuple(t.shape)}, expected {shape}")
+            self.params[key] = t.clone()
+        self.grads = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self._ws: Optional[torch.Tensor] = None
+
+    def _struct(self, tensors: Dict[str, torch.Tensor]) -> FfnParams:
+        s = FfnParams()
+        for key, field in zip(_KEYS, _FIELDS):
+            setattr(s, field, tensors[key].data_ptr())
+        return s
+
+    def _workspace(self, M: int) -> torch.Tensor:
+        need = self.engine.lib.cmgan_ffn_train_workspace_bytes(self.engine._h, M)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.engine.device)
+        return self._ws
+
+    def masks(self, M: int, generator: Optional[torch.Generator] = None):
+        """Fresh keep-masks for the two Dropout layers (conformer.py:142,144)."""
+        dev = self.engine.device
+        return dropout_mask((M, 256), self.p, dev, generator), dropout_mask((M, 64), self.p, dev, generator)
+
+    def forward(self, x: torch.Tensor, mask1: Optional[torch.Tensor] = None,
+                mask2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [..., 64] -> 0.5 * FeedForward(LayerNorm(x)) with the given dropout masks (add the residual yourself)."""
+        eng = self.engine
+        shape = x.shape
+        x2 = eng._in(x.reshape(-1, 64), "x")
+        M = x2.size(0)
+        m1 = eng._in(mask1.reshape(M, 256), "mask1") if mask1 is not None else None
+        m2 = eng._in(mask2.reshape(M, 64), "mask2") if mask2 is not None else None
+        y = torch.empty_like(x2)
+        ws = self._workspace(M)
+        p = self._struct(self.params)
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_ffn_train_forward(
+                eng._h, x2.data_ptr(), M, ctypes.byref(p), m1.data_ptr() if m1 is not None else None,
+                m2.data_ptr() if m2 is not None else None, y.data_ptr(), ws.data_ptr(), ws.numel(), eng._stream()))
+        return y.reshape(shape)
+
+    def backward(self, x: torch.Tensor, dy: torch.Tensor, mask1: Optional[torch.Tensor] = None,
+                 mask2: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """(dL/dx of the branch, {key: dL/dparam}) for upstream gradient dy; masks must be the forward's."""
+        eng = self.engine
+        shape = x.shape
+        x2, dy2 = eng._in(x.reshape(-1, 64), "x"), eng._in(dy.reshape(-1, 64), "dy")
+        M = x2.size(0)
+        m1 = eng._in(mask1.reshape(M, 256), "mask1") if mask1 is not None else None
+        m2 = eng._in(mask2.reshape(M, 64), "mask2") if mask2 is not None else None
+        dx = torch.empty_like(x2)
+        ws = self._workspace(M)
+        p, g = self._struct(self.params), self._struct(self.grads)
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_ffn_train_backward(
+                eng._h, x2.data_ptr(), dy2.data_ptr(), M, ctypes.byref(p), m1.data_ptr() if m1 is not None else None,
+                m2.data_ptr() if m2 is not None else None, dx.data_ptr(), ctypes.byref(g), ws.data_ptr(), ws.numel(),
+                eng._stream()))
+        return dx.reshape(shape), self.grads

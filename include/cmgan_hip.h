@@ -149,6 +149,29 @@ int cmgan_loss_terms(cmgan_handle* h, const float* est_real_dev, const float* es
                      const float* clean_spec_dev, int B, int T, const float* est_audio_dev,
                      const float* clean_audio_dev, int L_audio, float* out4_dev, void* stream);
 
+/* Training-mode FeedForward branch of a ConformerBlock with its backward - the first slice of the training
+ * step:  y = Scale(0.5, PreNorm(64, FeedForward(64, mult=4, dropout)))(x)
+ *                         = 0.5 * m2 * (W2 (m1 * Swish(W1 LayerNorm(x) + b1)) + b2)
+ * (src/models/conformer.py:54-72, 136-148, 211-212; the residual add of :217 stays with the caller).
+ * Parameters are the RAW tensors of the reference state_dict for one ff{1,2} branch (row-major, device):
+ *   ln_weight/ln_bias [64] = ff.fn.norm.{weight,bias};  w1 [256,64], b1 [256] = ff.fn.fn.net.0;
+ *   w2 [64,256], b2 [64] = ff.fn.fn.net.3.
+ * x, y, dy, dx are [M,64].  mask1 [M,256] / mask2 [M,64] are the keep-masks of the two nn.Dropout layers
+ * (0 or 1/(1-p)); NULL = no dropout (p = 0 or eval).  The backward recomputes the hidden activations from x,
+ * writes dL/dx to dx and dL/dparam to the six tensors of *grads (overwritten, not accumulated), with
+ * fixed-order reductions (bit-reproducible).  Workspace: cmgan_ffn_train_workspace_bytes(h, M).            */
+typedef struct cmgan_ffn_params {
+    float *ln_weight, *ln_bias, *w1, *b1, *w2, *b2;
+} cmgan_ffn_params;
+size_t cmgan_ffn_train_workspace_bytes(const cmgan_handle* h, long long M);
+int cmgan_ffn_train_forward(cmgan_handle* h, const float* x_dev, long long M, const cmgan_ffn_params* params,
+                            const float* mask1_dev, const float* mask2_dev, float* y_dev,
+                            void* workspace_dev, size_t workspace_bytes, void* stream);
+int cmgan_ffn_train_backward(cmgan_handle* h, const float* x_dev, const float* dy_dev, long long M,
+                             const cmgan_ffn_params* params, const float* mask1_dev, const float* mask2_dev,
+                             float* dx_dev, const cmgan_ffn_params* grads,
+                             void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* utils.power_compress (src/utils.py:20-29): x[B,F,T,2] -> y[B,2,F,T].          */
 int cmgan_power_compress(cmgan_handle* h, const float* x_dev, int B, int F, int T,
                          float* y_dev, void* stream);

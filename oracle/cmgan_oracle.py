@@ -94,6 +94,22 @@ def feed_forward(sd, p, x):
     return 0.5 * h
 
 
+def feed_forward_train(sd, p, x, mask1=None, mask2=None):
+    """TRAIN-mode Scale(0.5, PreNorm(dim, FeedForward(dim, mult=4, dropout))) (conformer.py:54-72, 136-148,
+    211-212): the two nn.Dropout layers (conformer.py:142, 144) as explicit keep-masks (entries 0 or 1/(1-p);
+    None = no dropout).  Differentiable: torch autograd through this function is the gradient oracle of
+    cmgan_amd.training.FeedForwardTrain.  `p` is the branch prefix, e.g. "ff1" (keys p + ".fn.norm.weight", ...)."""
+    h = F.layer_norm(x, (x.shape[-1],), sd[p + ".fn.norm.weight"], sd[p + ".fn.norm.bias"], 1e-5)
+    h = F.linear(h, sd[p + ".fn.fn.net.0.weight"], sd[p + ".fn.fn.net.0.bias"])
+    h = h * torch.sigmoid(h)                                   # Swish (conformer.py:25-27)
+    if mask1 is not None:
+        h = h * mask1
+    h = F.linear(h, sd[p + ".fn.fn.net.3.weight"], sd[p + ".fn.fn.net.3.bias"])
+    if mask2 is not None:
+        h = h * mask2
+    return 0.5 * h
+
+
 def attention(sd, p, x, heads: int = 4, max_pos: int = 512):
     """PreNorm(Attention) with Shaw relative positions (conformer.py:75-133).
     bias[i,j] = q_i . E[clamp(i-j, +-512) + 512]; the reference materialises

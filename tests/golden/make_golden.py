@@ -172,6 +172,46 @@ def main():
         tracks[f"enhanced_{tag}"] = ref_enhance(model, x, 16000 * 16)
     save("tracks.npz", **tracks)
 
+    # -- 9. training-mode FeedForward branch with its gradients (SURVEY.md N2 slice): the reference ConformerBlock's
+    #       ff1 = Scale(0.5, PreNorm(dim, FeedForward(dim, mult=4, dropout=0.2))) in TRAIN mode, its two nn.Dropout
+    #       layers replaced by multiplications with explicit keep-masks (same arithmetic as F.dropout: x * mask,
+    #       mask in {0, 1/(1-p)}), differentiated by torch autograd
+    class _Mask(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, t):
+            return t * self.m
+
+    with torch.enable_grad():
+        blk_t = ConformerBlock(dim=64, dim_head=16, heads=4, conv_kernel_size=31, attn_dropout=0.2, ff_dropout=0.2)
+        blk_t.load_state_dict(csd, strict=True)
+        blk_t.train()
+        ff = blk_t.ff1
+        Mtok, pdrop = 3 * 37, 0.2
+        gen = torch.Generator().manual_seed(17)
+        m1 = (torch.rand(3, 37, 256, generator=gen) >= pdrop).float() / (1 - pdrop)
+        m2 = (torch.rand(3, 37, 64, generator=gen) >= pdrop).float() / (1 - pdrop)
+        ff.fn.fn.net[2] = _Mask(m1)
+        ff.fn.fn.net[4] = _Mask(m2)
+        xt = rnd((3, 37, 64), 21).requires_grad_(True)
+        dy = rnd((3, 37, 64), 22)
+        yt = ff(xt)
+        yt.backward(dy)
+        grads = {k.replace(".", "_"): v.grad.detach() for k, v in ff.named_parameters()}
+        # and without dropout (masks of ones = eval arithmetic), for the mask = NULL path
+        ff.fn.fn.net[2] = _Mask(torch.ones(()))
+        ff.fn.fn.net[4] = _Mask(torch.ones(()))
+        for v in ff.parameters():
+            v.grad = None
+        x0 = xt.detach().clone().requires_grad_(True)
+        y0 = ff(x0)
+        y0.backward(dy)
+        grads0 = {"nomask_" + k.replace(".", "_"): v.grad.detach() for k, v in ff.named_parameters()}
+    save("ffn_train.npz", x=xt.detach(), dy=dy, mask1=m1, mask2=m2, y=yt.detach(), dx=xt.grad.detach(),
+         y_nomask=y0.detach(), dx_nomask=x0.grad.detach(), **grads, **grads0)
+
 
 if __name__ == "__main__":
     main()

@@ -122,6 +122,27 @@ def test_real_recordings_match_the_reference(sd, tag):
     assert_close(out, g[f"enhanced_{tag}"], rtol=1e-3, atol_rel=1e-4, name=f"track {tag}")
 
 
+FFN_KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.net.0.weight", "fn.fn.net.0.bias", "fn.fn.net.3.weight",
+            "fn.fn.net.3.bias")
+
+
+@pytest.mark.parametrize("masked", [True, False])
+def test_train_mode_feed_forward_and_its_gradients(masked):
+    """The gradient oracle (autograd through O.feed_forward_train) against the reference module's own autograd."""
+    g = load_golden("ffn_train.npz")
+    csd = conformer_state_dict(seed=3)
+    leaf = {"ff1." + k: csd["ff1." + k].clone().requires_grad_(True) for k in FFN_KEYS}
+    x = g["x"].clone().requires_grad_(True)
+    with torch.enable_grad():
+        y = O.feed_forward_train(leaf, "ff1", x, g["mask1"] if masked else None, g["mask2"] if masked else None)
+        y.backward(g["dy"])
+    pre = "" if masked else "nomask_"
+    assert rel_err(y, g["y" if masked else "y_nomask"]) < TOL
+    assert rel_err(x.grad, g["dx" if masked else "dx_nomask"]) < TOL
+    for k in FFN_KEYS:
+        assert rel_err(leaf["ff1." + k].grad, g[pre + k.replace(".", "_")]) < TOL, k
+
+
 def test_chunk_rows_rule():
     # evaluation.py:30-34: smallest divisor of 100 that is >= ceil(len / cut_len)
     assert O.chunk_rows(2400, 1000) == 4

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cmgan_amd import TSCNet
-from oracle.weights import make_state_dict, synthetic_clips
+from cmgan_amd.synth import make_state_dict, synthetic_clips
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 model = TSCNet(64, 201, mfma_mode=mode).load_state_dict(make_state_dict(0))
@@ -38,3 +38,14 @@ for B in (32, 256, 1024):
     dt = (time.perf_counter() - t0) / n
     nbytes = B * (4 * 32000 + 8 * 201 * 321)
     print(f"stft_compress B={B:4d}  {1e6 * dt:8.1f} us  {nbytes / dt / 1e9:8.1f} GB/s algorithmic = {nbytes / dt / 8e12:.3f} of 8 TB/s", flush=True)
+    spec = eng.stft_compress(wav, c)
+    re, im = spec[:, 0:1].contiguous(), spec[:, 1:2].contiguous()
+    for _ in range(3):
+        eng.uncompress_istft(re, im, c)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        eng.uncompress_istft(re, im, c)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"uncompress_istft B={B:4d}  {1e6 * dt:8.1f} us  {nbytes / dt / 1e9:8.1f} GB/s algorithmic = {nbytes / dt / 8e12:.3f} of 8 TB/s", flush=True)

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4]: a 10 s 16 kHz clip processed as 400-frame windows from ONE captured hipGraph
+(cmgan_amd.streaming.enhance_windows: fixed windows of W samples with C samples of recomputed context, the
+per-window contract of DESIGN.md section 8), next to the reference's own long-audio rule (reshape into rows,
+evaluation.py:30-34).  Prints one JSON line for profiles/."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cmgan_amd import TSCNet
+from cmgan_amd.evaluation import enhance_one_track
+from cmgan_amd.streaming import enhance_windows
+from cmgan_amd.synth import make_state_dict, synthetic_clips
+
+model = TSCNet(64, 201).load_state_dict(make_state_dict(0)).eval()
+noisy = synthetic_clips(1, 160000, seed=3).cuda()
+W, C = 40000, 4000                                   # 400-frame windows, 40 frames of context each side
+
+
+def timed(fn, n=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+res = {}
+for name, fn in (("windows_graph_batch1", lambda: enhance_windows(model, noisy, W, C, batch=1, graph=True)),
+                 ("windows_graph_batch4", lambda: enhance_windows(model, noisy, W, C, batch=4, graph=True)),
+                 ("windows_eager_batch4", lambda: enhance_windows(model, noisy, W, C, batch=4, graph=False)),
+                 ("reference_rows_rule_cut40000", lambda: enhance_one_track(model, noisy, cut_len=40000)),
+                 ("whole_clip_one_row", lambda: enhance_one_track(model, noisy))):
+    dt = timed(fn)
+    res[name] = {"ms_per_10s_clip": round(1e3 * dt, 3), "frames_per_s": round(1601 / dt, 1),
+                 "real_time_factor": round(10.0 / dt, 1)}
+print(json.dumps({"workload": "configs[4]: 10 s 16 kHz clip, 400-frame windows (W=40000 samples, context 4000), "
+                              "TSCNet(64,201) random-init, f16x3 mode, 1 x MI355X", "results": res}))
