@@ -105,9 +105,9 @@ __global__ __launch_bounds__(TWAVES * 64) void ffn_x3_kernel(const float* xin, f
 #pragma unroll
                 for (int tb = 0; tb < TNTB; ++tb) y[tb][ob] = mfma32h(ah, hh[tb], y[tb][ob]);
 #pragma unroll
-                for (int tb = 0; tb < TNTB; ++tb) y[tb][ob] = mfma32h(ah, hl[tb], y[tb][ob]);
+                for (int tb = 0; tb < TNTB; ++tb) y[tb][ob] = mfma32l(ah, hl[tb], y[tb][ob]);
 #pragma unroll
-                for (int tb = 0; tb < TNTB; ++tb) y[tb][ob] = mfma32h(al, hh[tb], y[tb][ob]);
+                for (int tb = 0; tb < TNTB; ++tb) y[tb][ob] = mfma32l(al, hh[tb], y[tb][ob]);
             }
             if (m2 < 7) {
 #pragma unroll
@@ -385,13 +385,13 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
         for (int we = 0; we < 6; ++we) {
             if (we < 5 && (FULL || we >= 4 - nb)) {       // cb = we for block A
                 f32x4 rt = mfma32h(ef[we], qA1, splat4(-sa.m));
-                rt = mfma32h(ef[we], qA2, rt);
+                rt = mfma32l(ef[we], qA2, rt);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a.RA[(16 * we + 4 * g + r) * RSTRIDE_X + c] = rt[r];
             }
             if (we >= 1 && (FULL || we - 1 >= 4 - nb)) {  // cb = we - 1 for block B
                 f32x4 rt = mfma32h(ef[we], qB1, splat4(-sb.m));
-                rt = mfma32h(ef[we], qB2, rt);
+                rt = mfma32l(ef[we], qB2, rt);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a.RB[(16 * (we - 1) + 4 * g + r) * RSTRIDE_X + c] = rt[r];
             }
@@ -418,7 +418,7 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
             if (FULL || jb < nb) { sA[jb] = mfma32h(kf[jb], qA1, sA[jb]); sB[jb] = mfma32h(kf[jb], qB1, sB[jb]); }
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
-            if (FULL || jb < nb) { sA[jb] = mfma32h(kf[jb], qA2, sA[jb]); sB[jb] = mfma32h(kf[jb], qB2, sB[jb]); }
+            if (FULL || jb < nb) { sA[jb] = mfma32l(kf[jb], qA2, sA[jb]); sB[jb] = mfma32l(kf[jb], qB2, sB[jb]); }
         att_softmax<FULL>(sA, c, g, j0, nb, a.L, sa);
         att_softmax<FULL>(sB, c, g, j0, nb, a.L, sb);
 #pragma unroll
@@ -429,10 +429,10 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
                 split8(sB[2 * mp], sB[2 * mp + 1], pBh, pBl);
                 st[2 * pair].o = mfma32h(vh[mp], pAh, st[2 * pair].o);
                 st[2 * pair + 1].o = mfma32h(vh[mp], pBh, st[2 * pair + 1].o);
-                st[2 * pair].o = mfma32h(vh[mp], pAl, st[2 * pair].o);
-                st[2 * pair + 1].o = mfma32h(vh[mp], pBl, st[2 * pair + 1].o);
-                st[2 * pair].o = mfma32h(vl[mp], pAh, st[2 * pair].o);
-                st[2 * pair + 1].o = mfma32h(vl[mp], pBh, st[2 * pair + 1].o);
+                st[2 * pair].o = mfma32l(vh[mp], pAl, st[2 * pair].o);
+                st[2 * pair + 1].o = mfma32l(vh[mp], pBl, st[2 * pair + 1].o);
+                st[2 * pair].o = mfma32l(vl[mp], pAh, st[2 * pair].o);
+                st[2 * pair + 1].o = mfma32l(vl[mp], pBh, st[2 * pair + 1].o);
             }
         }
     }
@@ -545,11 +545,11 @@ __global__ __launch_bounds__(256, ATT_WAVES) void attn_out_x3_kernel(QkvOut io, 
         split8(stash[2 * HSTRIDE + i * 64 + lane], stash[3 * HSTRIDE + i * 64 + lane], bh[0][1], bl[0][1]);
         f32x4 acc = bias;                                  // same product order as lin_acc_x3 / outproj_x3_kernel
         acc = mfma32h(ah0, bh[0][0], acc);
-        acc = mfma32h(ah0, bl[0][0], acc);
-        acc = mfma32h(al0, bh[0][0], acc);
+        acc = mfma32l(ah0, bl[0][0], acc);
+        acc = mfma32l(al0, bh[0][0], acc);
         acc = mfma32h(ah1, bh[0][1], acc);
-        acc = mfma32h(ah1, bl[0][1], acc);
-        acc = mfma32h(al1, bh[0][1], acc);
+        acc = mfma32l(ah1, bl[0][1], acc);
+        acc = mfma32l(al1, bh[0][1], acc);
         if (ib < Lb && l < L) {
             const long row = (long)(n / m.inner) * m.outer + (long)(n % m.inner) * m.istride + (long)l * m.lstride;
             float* p = x + row * 64 + 16 * wv + 4 * a.g;
@@ -771,9 +771,9 @@ __global__ __launch_bounds__(64 * DP_WAVES) void dwpw2_x3_kernel(float* __restri
 #pragma unroll
         for (int o = 0; o < NOB; ++o) acc2[o] = mfma32h(ah[o][mm], bh, acc2[o]);
 #pragma unroll
-        for (int o = 0; o < NOB; ++o) acc2[o] = mfma32h(ah[o][mm], bl, acc2[o]);
+        for (int o = 0; o < NOB; ++o) acc2[o] = mfma32l(ah[o][mm], bl, acc2[o]);
 #pragma unroll
-        for (int o = 0; o < NOB; ++o) acc2[o] = mfma32h(al[o][mm], bh, acc2[o]);
+        for (int o = 0; o < NOB; ++o) acc2[o] = mfma32l(al[o][mm], bh, acc2[o]);
     }
     const int l = l0 + 16 * tb + c;
     if (l < m.L) {
@@ -936,9 +936,9 @@ __global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restric
 #pragma unroll
             for (int o = 0; o < 2; ++o) acc2[o] = mfma32h(ah[o][mm], bh, acc2[o]);
 #pragma unroll
-            for (int o = 0; o < 2; ++o) acc2[o] = mfma32h(ah[o][mm], bl, acc2[o]);
+            for (int o = 0; o < 2; ++o) acc2[o] = mfma32l(ah[o][mm], bl, acc2[o]);
 #pragma unroll
-            for (int o = 0; o < 2; ++o) acc2[o] = mfma32h(al[o][mm], bh, acc2[o]);
+            for (int o = 0; o < 2; ++o) acc2[o] = mfma32l(al[o][mm], bh, acc2[o]);
         }
         if (live) {
 #pragma unroll

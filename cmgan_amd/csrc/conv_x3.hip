@@ -12,6 +12,10 @@
 #include "kernels.h"
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifndef CX_EARLY
+#define CX_EARLY 0            // 1 = weave the next stage's activation loads into the staging phase (CX_WRITE_PREFETCH):
+                              // measured 3 % SLOWER on the dense conv (6.05 vs 5.87 ms, same-session A/B), kept as a probe
+#endif
 #define CX_STRIDE 48          // halfs per LDS activation row (32 used): 96 B = 6 x 16 B slots, the row pitch at which
                               // the B-operand ds_read_b128 (16 consecutive rows x 4 lane groups) is bank-conflict free
                               // for every base row (80 B was 2-way; brute-forced over the b128 lane-group map)
@@ -147,6 +151,54 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
             *reinterpret_cast<u32x4*>(sm + 2 * ACT + (tid + NTHR * i) * 8) = wpre[i];                     \
     } while (0)
 
+// PROBE (CX_EARLY=1, off by default): CX_WRITE(S) with stage S+1's prefetch woven in: as soon as row group e of
+// stage S has been normalised, split and stored, its registers take stage S+1's load, so the next stage's HBM
+// requests are in flight during the rest of the staging VALU work, the barrier AND the MFMAs, instead of only during
+// the MFMAs.  Motivation: the single-product probe showed that dropping 2/3 of the MFMAs only
+// buys 30 % on this kernel and that the remainder equals its HBM time at 5 TB/s.  Result: 3 % slower - the loads
+// issued mid-staging make every later `pre[e]` consumer wait behind younger requests (in-order vmcnt) and delay the
+// weight-image wait at the end of the staging phase; the one-stage-ahead form stays.
+#define CX_WRITE_PREFETCH(S, HAS_NEXT)                                                                   \
+    do {                                                                                                 \
+        const int chunkw_ = (S) / NT, ktw_ = (S) - chunkw_ * NT;                                         \
+        const u32x4* wsrc_ = reinterpret_cast<const u32x4*>(w16) + ((long)chunkw_ * TAPS + ktw_ * 3) * (CB * 128); \
+        u32x4 wpre[NW];                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i) wpre[i] = wsrc_[tid + NTHR * i];                   \
+        const unsigned inv_ = (NT == 2 && ktw_ == 0) ? inv0 : inv1;                                      \
+        const f32x4 am1 = al - splat4(1.f);                                                              \
+        const int chunkn_ = ((S) + 1) / NT, ktn_ = ((S) + 1) - chunkn_ * NT;                             \
+        const int slotn_ = chunkn_ >> 1, halfn_ = chunkn_ & 1;                                           \
+        const char* srcn_ = reinterpret_cast<const char*>(sel4(a.in, (HAS_NEXT) ? slotn_ : 0)) + b * clip_bytes + halfn_ * 128; \
+        _Pragma("unroll") for (int e = 0; e < NACT; ++e) {                                               \
+            f32x4 v = pre[e];                                                                            \
+            if (HAS_NEXT) {                                                                              \
+                const unsigned o_ = (NT == 2 && ktn_ == 0) ? off1[e] - ((inv0 >> e) & 1u ? 0u : dFb) : off1[e]; \
+                pre[e] = *reinterpret_cast<const f32x4*>(srcn_ + o_);                                    \
+            }                                                                                            \
+            v = v * sc + sh;                                                                             \
+            f32x4 mn;                                                                                    \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) mn[r] = fminf(v[r], 0.f);                      \
+            v = mn * am1 + v;                                                                            \
+            if (inv_ & (1u << e)) v = splat4(0.f);                                                       \
+            f16x4 hi, lo;                                                                                \
+            split4(v, hi, lo);                                                                           \
+            *reinterpret_cast<f16x4*>(wrow + RSTEP * e * CX_STRIDE) = hi;                                \
+            *reinterpret_cast<f16x4*>(wrow + RSTEP * e * CX_STRIDE + ACT) = lo;                          \
+        }                                                                                                \
+        if (HAS_NEXT) {                                                                                  \
+            const float* nsc_ = sel4(a.nscale, slotn_);                                                  \
+            if (nsc_ != nullptr) {                                                                       \
+                sc = ldg4(nsc_ + b * 64 + halfn_ * 32 + qd * 4);                                         \
+                sh = ldg4(sel4(a.nshift, slotn_) + b * 64 + halfn_ * 32 + qd * 4);                       \
+                al = ldg4(sel4(a.nalpha, slotn_) + halfn_ * 32 + qd * 4);                                \
+            } else {                                                                                     \
+                sc = splat4(1.f); sh = splat4(0.f); al = splat4(1.f);                                    \
+            }                                                                                            \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                   \
+            *reinterpret_cast<u32x4*>(sm + 2 * ACT + (tid + NTHR * i) * 8) = wpre[i];                     \
+    } while (0)
+
 // 3 taps x CB output blocks x NPB position blocks x 3 split products from this tile's LDS buffers, software-
 // pipelined by hand: the A fragments of group j+1 (and, at the end of a tap, the B fragments of the next tap)
 // are requested BEFORE group j's 3 * NPB MFMAs are issued, and sched_barriers keep the compiler from sinking
@@ -170,7 +222,7 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
                 aln = *reinterpret_cast<const f16x8*>(alane + (j + 1) * 1024 + 512);                     \
             }                                                                                            \
             __builtin_amdgcn_sched_barrier(0);                                                           \
-            _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = mfma32h(ah, bl[tb], acc[cb][tb]); \
+            _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = mfma32l(ah, bl[tb], acc[cb][tb]); \
             if (last_cb) {                                                                               \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
                 _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb)                                       \
@@ -178,7 +230,7 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
                 __builtin_amdgcn_sched_barrier(0);                                                       \
             }                                                                                            \
             _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = mfma32h(ah, bh[tb], acc[cb][tb]);  \
-            _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = mfma32h(alo, bh[tb], acc[cb][tb]); \
+            _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = mfma32l(alo, bh[tb], acc[cb][tb]); \
             if (last_cb) {                                                                               \
                 __builtin_amdgcn_sched_barrier(0);                                                       \
                 _Pragma("unroll") for (int tb = 0; tb < NPB; ++tb) {                                     \
@@ -260,9 +312,15 @@ __global__ __launch_bounds__(64 * NWV) void conv3x_kernel(ConvArgs a, const _Flo
 #pragma unroll 1
     for (int s = 0; s < nst; ++s) {
         __syncthreads();                                  // stage s-1 fully consumed
+#if CX_EARLY
+        if (s + 1 < nst) CX_WRITE_PREFETCH(s, true);      // stage s+1's loads issued row group by row group
+        else CX_WRITE_PREFETCH(s, false);
+        __syncthreads();
+#else
         CX_WRITE(s);
         __syncthreads();
         if (s + 1 < nst) CX_PREFETCH(s + 1);              // in flight during the MFMAs below
+#endif
         CX_MFMA();
     }
     CX_EPILOGUE(true);

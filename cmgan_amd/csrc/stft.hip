@@ -236,10 +236,10 @@ __global__ __launch_bounds__(256, 2) void stft_fold_x3_kernel(SpectralTables tb,
                 const f16x8 sl = *reinterpret_cast<const f16x8*>(cb + (M32 + m) * 1024 + 512);
                 are = mfma32h(uch[m], ch, are);
                 aim = mfma32h(ush[m], sh, aim);
-                are = mfma32h(uch[m], cl, are);
-                aim = mfma32h(ush[m], sl, aim);
-                are = mfma32h(ucl[m], ch, are);
-                aim = mfma32h(usl[m], sh, aim);
+                are = mfma32l(uch[m], cl, are);
+                aim = mfma32l(ush[m], sl, aim);
+                are = mfma32l(ucl[m], ch, are);
+                aim = mfma32l(usl[m], sh, aim);
             }
             const int bin = bb * 16 + c;
             if (bin < tb.F) {
@@ -493,10 +493,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             const f16x8 sl = *reinterpret_cast<const f16x8*>(cb + (M32 + m) * 1024 + 512);
             ac = mfma32h(uh[0][m], ch, ac);
             as = mfma32h(uh[1][m], sh, as);
-            ac = mfma32h(uh[0][m], cl, ac);
-            as = mfma32h(uh[1][m], sl, as);
-            ac = mfma32h(ul[0][m], ch, ac);
-            as = mfma32h(ul[1][m], sh, as);
+            ac = mfma32l(uh[0][m], cl, ac);
+            as = mfma32l(uh[1][m], sl, as);
+            ac = mfma32l(ul[0][m], ch, ac);
+            as = mfma32l(ul[1][m], sh, as);
         }
         const int n = nb * 16 + c;
         if (n <= H) {

@@ -3,6 +3,10 @@
 
 * `generator_loss_terms`   - the non-adversarial terms of Trainer.calculate_generator_loss (train.py:124-151) as one
                              deterministic device reduction; the per-rank scalars a data-parallel step all-reduces.
+* `forward_generator_step` - Trainer.forward_generator_step (train.py:72-122) in eval mode: per-row RMS scale, STFT +
+                             power compression of the noisy AND the clean batch, TSCNet, inverse transform.
+* `validation_step`        - the generator half of Trainer.test_step (train.py:207-220): the above + the loss terms
+                             + ONE all-reduce of the scalars across ranks (RCCL on the GPU box).
 * `FeedForwardTrain`       - a ConformerBlock's `Scale(0.5, PreNorm(dim, FeedForward(dim, mult=4, dropout)))` branch
                              (conformer.py:54-72, 136-148, 211-212) in TRAIN mode: forward with the two Dropout layers
                              as explicit keep-masks, and the full backward (dL/dx and all six parameter gradients).
@@ -21,7 +25,7 @@ import torch
 from ._lib import FfnParams, check
 from .engine import Engine
 
-__all__ = ["FeedForwardTrain", "generator_loss_terms", "dropout_mask"]
+__all__ = ["FeedForwardTrain", "generator_loss_terms", "dropout_mask", "forward_generator_step", "validation_step"]
 
 _KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.net.0.weight", "fn.fn.net.0.bias",
          "fn.fn.net.3.weight", "fn.fn.net.3.bias")
@@ -119,3 +123,34 @@ class FeedForwardTrain:
                 m2.data_ptr() if m2 is not None else None, dx.data_ptr(), ctypes.byref(g), ws.data_ptr(), ws.numel(),
                 eng._stream()))
         return dx.reshape(shape), self.grads
+
+
+@torch.no_grad()
+def forward_generator_step(model, clean: torch.Tensor, noisy: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Trainer.forward_generator_step (src/train.py:72-122), eval mode.  clean, noisy: float32 [B, L] on the GPU
+    (L a multiple of hop).  Everything is a HIP kernel; the x c scaling is fused into the STFT."""
+    eng = model.engine
+    c = eng.rms_scale(noisy)                                    # train.py:75: c of the NOISY rows scales both
+    noisy_spec = eng.stft_compress(noisy, c)                    # train.py:76-94, 95 (model layout [B,2,T,F])
+    clean_spec = eng.stft_compress(clean, c)                    # train.py:88-98
+    est_real, est_imag = model(noisy_spec)                      # train.py:99
+    est_audio = eng.uncompress_istft(est_real, est_imag)        # train.py:104-112 (stays in the scaled domain)
+    return {"est_real": est_real, "est_imag": est_imag, "clean_spec": clean_spec, "est_audio": est_audio,
+            "clean": clean}                                     # train.py:218: the RAW clean batch
+
+
+@torch.no_grad()
+def validation_step(model, clean: torch.Tensor, noisy: torch.Tensor, loss_weights=(0.1, 0.9, 0.2),
+                    reduce: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Generator half of Trainer.test_step (train.py:207-220): (weighted loss, float32[4] terms), summed over ranks
+    with ONE all-reduce when a process group is initialised (divide by world size for the mean).  The adversarial
+    term needs the metric discriminator (src/models/discriminator.py), which is outside this build."""
+    from . import dist as cdist
+    out = forward_generator_step(model, clean, noisy)
+    loss, terms = generator_loss_terms(model.engine, out["est_real"], out["est_imag"], out["clean_spec"],
+                                       out["est_audio"], out["clean"], loss_weights)
+    if reduce:
+        packed = torch.cat([loss.reshape(1), terms])
+        cdist.allreduce_scalars(packed)
+        loss, terms = packed[0], packed[1:]
+    return loss, terms

@@ -297,3 +297,30 @@ def enhance_batch(sd, wav: torch.Tensor, n_fft: int = 400, hop: int = 100):
     spec = stft_compress(wav * c[:, None], n_fft, hop)
     real, imag = tscnet_forward(sd, spec)
     return uncompress_istft(real, imag, n_fft, hop) / c[:, None]
+
+
+# --------------------------------------------------------------------------- #
+# generator half of the training / validation step: src/train.py:72-151
+# --------------------------------------------------------------------------- #
+@torch.no_grad()
+def forward_generator_step(sd, clean: torch.Tensor, noisy: torch.Tensor, n_fft: int = 400, hop: int = 100):
+    """Trainer.forward_generator_step (train.py:72-122), eval mode.  clean, noisy: [B, L]."""
+    c = rms_scale(noisy)                                        # train.py:75 (of the NOISY rows)
+    noisy_s, clean_s = noisy * c[:, None], clean * c[:, None]  # train.py:76-79
+    noisy_spec = stft_compress(noisy_s, n_fft, hop)            # [B,2,T,F]  (train.py:81-94)
+    clean_spec = stft_compress(clean_s, n_fft, hop)            # model layout; the reference keeps [B,2,F,T]
+    est_real, est_imag = tscnet_forward(sd, noisy_spec)        # train.py:99
+    est_audio = uncompress_istft(est_real, est_imag, n_fft, hop)   # train.py:104-112 (NOT divided by c)
+    return {"est_real": est_real, "est_imag": est_imag, "clean_spec": clean_spec, "est_audio": est_audio}
+
+
+def generator_loss(out: dict, clean: torch.Tensor, loss_weights=(0.1, 0.9, 0.2)):
+    """calculate_generator_loss without the GAN term (train.py:124-151): (loss, loss_ri, loss_mag, time_loss).
+    `clean` is the RAW batch (train.py:218), while est_audio lives in the RMS-scaled domain - a reference quirk."""
+    cr, ci = out["clean_spec"][:, 0:1], out["clean_spec"][:, 1:2]
+    er, ei = out["est_real"], out["est_imag"]
+    loss_mag = F.mse_loss(torch.sqrt(er ** 2 + ei ** 2), torch.sqrt(cr ** 2 + ci ** 2))
+    loss_ri = F.mse_loss(er, cr) + F.mse_loss(ei, ci)
+    time_loss = torch.mean(torch.abs(out["est_audio"] - clean))
+    loss = loss_weights[0] * loss_ri + loss_weights[1] * loss_mag + loss_weights[2] * time_loss
+    return loss, loss_ri, loss_mag, time_loss

@@ -209,6 +209,29 @@ def main():
         y0 = ff(x0)
         y0.backward(dy)
         grads0 = {"nomask_" + k.replace(".", "_"): v.grad.detach() for k, v in ff.named_parameters()}
+    # -- 10. generator half of Trainer.test_step (train.py:72-151, 207-220) on a tiny batch: per-row RMS scale of
+    #        noisy AND clean by the noisy row's c, STFT + power_compress of both, TSCNet, losses (GAN term excluded:
+    #        the metric discriminator is outside this build).  Note the reference compares est_audio (scaled domain,
+    #        never divided by c) with the RAW clean batch (train.py:139-141, 218).
+    import torch.nn.functional as Fn
+    vclean, vnoisy = synthetic_clips(2, 1600, seed=41) * 0.5, synthetic_clips(2, 1600, seed=42)
+    vc = torch.sqrt(vnoisy.size(-1) / torch.sum((vnoisy ** 2.0), dim=-1))
+    n_s = torch.transpose(torch.transpose(vnoisy, 0, 1) * vc, 0, 1)
+    c_s = torch.transpose(torch.transpose(vclean, 0, 1) * vc, 0, 1)
+    n_spec = ref_utils.power_compress(ref_stft(n_s)).permute(0, 1, 3, 2)
+    c_spec = ref_utils.power_compress(ref_stft(c_s))
+    c_real, c_imag = c_spec[:, 0, :, :].unsqueeze(1), c_spec[:, 1, :, :].unsqueeze(1)
+    e_real, e_imag = model(n_spec)
+    e_real, e_imag = e_real.permute(0, 1, 3, 2), e_imag.permute(0, 1, 3, 2)
+    e_mag = torch.sqrt(e_real ** 2 + e_imag ** 2)
+    c_mag = torch.sqrt(c_real ** 2 + c_imag ** 2)
+    e_audio = ref_istft(ref_utils.power_uncompress(e_real, e_imag).squeeze(1))
+    l_mag = Fn.mse_loss(e_mag, c_mag)
+    l_ri = Fn.mse_loss(e_real, c_real) + Fn.mse_loss(e_imag, c_imag)
+    l_time = torch.mean(torch.abs(e_audio - vclean))
+    save("valstep.npz", clean=vclean, noisy=vnoisy, est_audio=e_audio, loss_ri=l_ri, loss_mag=l_mag, time_loss=l_time,
+         loss=0.1 * l_ri + 0.9 * l_mag + 0.2 * l_time)
+
     save("ffn_train.npz", x=xt.detach(), dy=dy, mask1=m1, mask2=m2, y=yt.detach(), dx=xt.grad.detach(),
          y_nomask=y0.detach(), dx_nomask=x0.grad.detach(), **grads, **grads0)
 

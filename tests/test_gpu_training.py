@@ -93,3 +93,53 @@ def test_weighted_generator_loss(ff):
             + 0.2 * torch.mean(torch.abs(ea - ca)))
     assert abs(float(loss) - float(want)) < 2e-6 * abs(float(want))
     assert terms.shape == (4,)
+
+
+def test_validation_step_matches_reference_golden_and_oracle():
+    """Generator half of Trainer.test_step through the HIP path: losses of the reference's own modules (golden)."""
+    from cmgan_amd import TSCNet
+    from cmgan_amd.training import forward_generator_step, validation_step
+    from oracle.weights import make_state_dict
+    g = load_golden("valstep.npz")
+    model = TSCNet(64, 201).load_state_dict(make_state_dict(seed=0)).eval()
+    out = forward_generator_step(model, g["clean"].to(DEV), g["noisy"].to(DEV))
+    assert _report("validation est_audio vs golden", rel_err(out["est_audio"], g["est_audio"])) < 1e-3
+    loss, terms = validation_step(model, g["clean"].to(DEV), g["noisy"].to(DEV))
+    for got, key in ((loss, "loss"), (terms[0], "loss_ri"), (terms[1], "loss_mag"), (terms[2], "time_loss")):
+        err = abs(float(got) - float(g[key])) / abs(float(g[key]))
+        assert _report(f"validation {key} vs golden", err) < 1e-4, key
+
+
+def test_data_path_feeds_device_batches_to_the_validation_step(tmp_path):
+    """SURVEY.md N4 wired end to end: wav pairs on disk -> DemandDataset / load_data (sharded sampler) ->
+    DevicePrefetcher (pinned, side-stream H2D into a two-slot ring) -> validation_step on the HIP kernels;
+    every batch's losses equal the CPU oracle's on the same host batch."""
+    import os
+    from scipy.io import wavfile
+    from cmgan_amd import TSCNet
+    from cmgan_amd.data import DevicePrefetcher, load_data
+    from cmgan_amd.training import validation_step
+    from oracle.weights import make_state_dict, synthetic_clips
+    sd = make_state_dict(seed=0)
+    model = TSCNet(64, 201).load_state_dict(sd).eval()
+    for split, n in (("train", 5), ("test", 5)):
+        for sub in ("clean", "noisy"):
+            os.makedirs(tmp_path / split / sub)
+        for i in range(n):
+            clean = synthetic_clips(1, 900 + 450 * i, seed=70 + i)[0].numpy() * 0.3
+            noisy = clean + 0.1 * synthetic_clips(1, clean.size, seed=80 + i)[0].numpy()
+            for sub, sig in (("clean", clean), ("noisy", noisy)):
+                wavfile.write(str(tmp_path / split / sub / f"p_{i}.wav"), 16000, np.round(sig * 32767).astype(np.int16))
+    _, test_loader = load_data(str(tmp_path), batch_size=2, n_cpu=0, cut_len=1600)
+    import random
+    random.seed(123)                                                   # clips longer than cut_len are cropped at random.randint
+    host = [(c.clone(), n.clone()) for c, n, _ in test_loader]        # same sampler order + same crops on the second pass
+    random.seed(123)
+    seen = 0
+    for (clean_d, noisy_d, length), (clean_h, noisy_h) in zip(DevicePrefetcher(test_loader, DEV), host):
+        assert clean_d.is_cuda and clean_d.shape == clean_h.shape and torch.equal(clean_d.cpu(), clean_h)
+        loss, terms = validation_step(model, clean_d, noisy_d)
+        want = O.generator_loss(O.forward_generator_step(sd, clean_h, noisy_h), clean_h)
+        assert abs(float(loss) - float(want[0])) < 1e-4 * abs(float(want[0]))
+        seen += clean_d.size(0)
+    assert seen == 5                                                     # drop_last=False keeps the odd batch

@@ -143,6 +143,16 @@ def test_train_mode_feed_forward_and_its_gradients(masked):
         assert rel_err(leaf["ff1." + k].grad, g[pre + k.replace(".", "_")]) < TOL, k
 
 
+def test_validation_step_losses_match_the_reference(sd):
+    """Generator half of Trainer.test_step: forward_generator_step + the three non-adversarial loss terms."""
+    g = load_golden("valstep.npz")
+    out = O.forward_generator_step(sd, g["clean"], g["noisy"])
+    assert rel_err(out["est_audio"], g["est_audio"]) < 5e-5
+    loss, l_ri, l_mag, l_time = O.generator_loss(out, g["clean"])
+    for got, key in ((loss, "loss"), (l_ri, "loss_ri"), (l_mag, "loss_mag"), (l_time, "time_loss")):
+        assert abs(float(got) - float(g[key])) < 2e-5 * abs(float(g[key])), key
+
+
 def test_chunk_rows_rule():
     # evaluation.py:30-34: smallest divisor of 100 that is >= ceil(len / cut_len)
     assert O.chunk_rows(2400, 1000) == 4
