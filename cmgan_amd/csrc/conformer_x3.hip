@@ -238,6 +238,9 @@ __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x
 #ifndef XCD_ORDER
 #define XCD_ORDER 1          // XCD-contiguous work order for attention and the depthwise kernel (0 = dispatch order)
 #endif
+#ifndef ATT_SKIP_DEAD
+#define ATT_SKIP_DEAD 1      // do not compute the non-existent second query block of a sequence's last pair
+#endif
 #ifndef ATTN_FUSE_OUT
 #define ATTN_FUSE_OUT 1      // attention + to_out + residual in one kernel (0 = attn_x3_kernel, then outproj_x3_kernel)
 #endif
@@ -340,8 +343,10 @@ struct AttCtx {
     int qoff1, qoff2, nblk16, Lb, Lb2, L, max_pos, c, g;
 };
 
-// one 64-key chunk for the wave's (up to) four query blocks; FULL = all 64 keys exist
-template <bool FULL>
+// one 64-key chunk for the wave's (up to) four query blocks; FULL = all 64 keys exist; HASB = the second block of
+// the pair exists (false only for the last pair of a sequence with an odd number of 16-token blocks - L = 321 -> 21,
+// L = 101 -> 7: one of 8 query-block slots of a frequency-axis sequence - whose B half is then not computed at all)
+template <bool FULL, bool HASB = true>
 __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttState (&st)[ATT_NQ]) {
     const int nb = FULL ? 4 : ((a.L - j0 + 15) >> 4);     // live 16-key blocks (tail chunk: 1..4)
     const int c = a.c, g = a.g;
@@ -366,8 +371,11 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
         const int qB = ibA + 1 < a.Lb ? ibA + 1 : a.Lb - 1;
         const f16x8 qA1 = *reinterpret_cast<const f16x8*>(a.qbase + ibA * 512 + a.qoff1);
         const f16x8 qA2 = *reinterpret_cast<const f16x8*>(a.qbase + ibA * 512 + a.qoff2);
-        const f16x8 qB1 = *reinterpret_cast<const f16x8*>(a.qbase + qB * 512 + a.qoff1);
-        const f16x8 qB2 = *reinterpret_cast<const f16x8*>(a.qbase + qB * 512 + a.qoff2);
+        f16x8 qB1 = qA1, qB2 = qA2;
+        if (HASB) {
+            qB1 = *reinterpret_cast<const f16x8*>(a.qbase + qB * 512 + a.qoff1);
+            qB2 = *reinterpret_cast<const f16x8*>(a.qbase + qB * 512 + a.qoff2);
+        }
         // relative-position window of the pair: 6 row blocks starting at rminA = 16 ibA - j0 - 63;
         // block A uses window blocks 0..4 as its cb 0..4, block B (16 queries later) blocks 1..5
         f16x8 ef[6];
@@ -389,7 +397,7 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a.RA[(16 * we + 4 * g + r) * RSTRIDE_X + c] = rt[r];
             }
-            if (we >= 1 && (FULL || we - 1 >= 4 - nb)) {  // cb = we - 1 for block B
+            if (HASB && we >= 1 && (FULL || we - 1 >= 4 - nb)) {  // cb = we - 1 for block B
                 f32x4 rt = mfma32h(ef[we], qB1, splat4(-sb.m));
                 rt = mfma32l(ef[we], qB2, rt);
 #pragma unroll
@@ -406,33 +414,34 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     sA[jb][r] = a.RA[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE_X + c];
-                    sB[jb][r] = a.RB[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE_X + c];
+                    if (HASB) sB[jb][r] = a.RB[(c - 16 * jb - 4 * g - r + 63) * RSTRIDE_X + c];
                 }
             } else {
                 sA[jb] = splat4(0.f);
                 sB[jb] = splat4(0.f);
             }
+            if (!HASB) sB[jb] = splat4(0.f);
         }
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
-            if (FULL || jb < nb) { sA[jb] = mfma32h(kf[jb], qA1, sA[jb]); sB[jb] = mfma32h(kf[jb], qB1, sB[jb]); }
+            if (FULL || jb < nb) { sA[jb] = mfma32h(kf[jb], qA1, sA[jb]); if (HASB) sB[jb] = mfma32h(kf[jb], qB1, sB[jb]); }
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
-            if (FULL || jb < nb) { sA[jb] = mfma32l(kf[jb], qA2, sA[jb]); sB[jb] = mfma32l(kf[jb], qB2, sB[jb]); }
+            if (FULL || jb < nb) { sA[jb] = mfma32l(kf[jb], qA2, sA[jb]); if (HASB) sB[jb] = mfma32l(kf[jb], qB2, sB[jb]); }
         att_softmax<FULL>(sA, c, g, j0, nb, a.L, sa);
-        att_softmax<FULL>(sB, c, g, j0, nb, a.L, sb);
+        if (HASB) att_softmax<FULL>(sB, c, g, j0, nb, a.L, sb);
 #pragma unroll
         for (int mp = 0; mp < 2; ++mp) {
             if (FULL || 2 * mp < nb) {
                 f16x8 pAh, pAl, pBh, pBl;
                 split8(sA[2 * mp], sA[2 * mp + 1], pAh, pAl);
-                split8(sB[2 * mp], sB[2 * mp + 1], pBh, pBl);
+                if (HASB) split8(sB[2 * mp], sB[2 * mp + 1], pBh, pBl);
                 st[2 * pair].o = mfma32h(vh[mp], pAh, st[2 * pair].o);
-                st[2 * pair + 1].o = mfma32h(vh[mp], pBh, st[2 * pair + 1].o);
+                if (HASB) st[2 * pair + 1].o = mfma32h(vh[mp], pBh, st[2 * pair + 1].o);
                 st[2 * pair].o = mfma32l(vh[mp], pAl, st[2 * pair].o);
-                st[2 * pair + 1].o = mfma32l(vh[mp], pBl, st[2 * pair + 1].o);
+                if (HASB) st[2 * pair + 1].o = mfma32l(vh[mp], pBl, st[2 * pair + 1].o);
                 st[2 * pair].o = mfma32l(vl[mp], pAh, st[2 * pair].o);
-                st[2 * pair + 1].o = mfma32l(vl[mp], pBh, st[2 * pair + 1].o);
+                if (HASB) st[2 * pair + 1].o = mfma32l(vl[mp], pBh, st[2 * pair + 1].o);
             }
         }
     }
@@ -520,9 +529,16 @@ __global__ __launch_bounds__(256, ATT_WAVES) void attn_out_x3_kernel(QkvOut io, 
         st[i].m = 0.f; st[i].run = -INFINITY; st[i].l = 0.f; st[i].o = splat4(0.f);
     }
     const int nfull = L >> 6;
+    if (!ATT_SKIP_DEAD || ibb + 1 < Lb) {                  // block-uniform: both query blocks of the pair exist
 #pragma unroll 1
-    for (int ch = 0; ch < nfull; ++ch) att_chunk<true>(a, ibb, ch * 64, st);
-    if (L & 63) att_chunk<false>(a, ibb, nfull * 64, st);
+        for (int ch = 0; ch < nfull; ++ch) att_chunk<true, true>(a, ibb, ch * 64, st);
+        if (L & 63) att_chunk<false, true>(a, ibb, nfull * 64, st);
+    } else {
+#pragma unroll 1
+        for (int ch = 0; ch < nfull; ++ch) att_chunk<true, false>(a, ibb, ch * 64, st);
+        if (L & 63) att_chunk<false, false>(a, ibb, nfull * 64, st);
+        st[1].l = 1.f;                                     // never accumulated: keep the (unused) stash finite
+    }
 
     // the to_out operands of this wave's output block are fetched now: their L2 latency hides behind the barrier
     const _Float16* wp = woi + wv * 2048 + lane * 8;       // [ob = wv][m][hi | lo][64][8]
