@@ -59,6 +59,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
     "cmgan_ffn_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, POINTER(FfnParams), c_void_p,
                                          c_void_p, c_void_p, POINTER(FfnParams), c_void_p, c_size_t, c_void_p]),
+    "cmgan_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float,
+                                 c_float, c_float, c_float, c_int, c_void_p]),
     "cmgan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "cmgan_rms_scale": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "cmgan_num_frames": (c_int, [c_void_p, c_int]),

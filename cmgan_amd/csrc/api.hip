@@ -875,6 +875,17 @@ extern "C" int cmgan_ffn_train_backward(cmgan_handle* h, const float* x, const f
     return check_launch(h, "ffn_train_backward");
 }
 
+extern "C" int cmgan_adamw_step(cmgan_handle* h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                int step, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) ||
+        !(beta2 >= 0.f && beta2 < 1.f))
+        return fail(h, CMGAN_E_BADARG, "cmgan_adamw_step: bad argument");
+    launch_adamw(begin(h, stream), params, grads, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, step);
+    return check_launch(h, "adamw_step");
+}
+
 // ------------------------------------------------------------------------------------
 // diagnostics
 // ------------------------------------------------------------------------------------

@@ -143,5 +143,8 @@ void launch_ffn_train_forward(LaunchCtx, const float* x, long M, const FfnTrainP
 void launch_ffn_train_backward(LaunchCtx, const float* x, const float* dy, long M, const FfnTrainParams& p,
                                const float* m1, const float* m2, float* dx, const FfnTrainParams& grad, float* ws);
 
+void launch_adamw(LaunchCtx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                  float eps, float wd, int step);
+
 // ------------------------------- selftest ---------------------------------------
 void launch_selftest_mfma(hipStream_t, const float* a_fm, const float* b_fm, float* d, int KB);

@@ -375,3 +375,36 @@ void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, l
         LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<1, 256, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, cs.C, cs.out)));
     }
 }
+
+// ---------------------------------------------------------------------------------
+// torch.optim.AdamW (src/train.py:63-66: AdamW(parameters, lr), defaults betas (0.9, 0.999), eps 1e-8,
+// weight_decay 0.01) as ONE launch over a flat parameter bucket - parameters, gradients and both moment buffers are
+// flat fp32 arrays (the same bucket the gradient all-reduce runs over), so the update is a single coalesced pass:
+//   p <- p (1 - lr wd);  m <- b1 m + (1 - b1) g;  v <- b2 v + (1 - b2) g^2;
+//   p <- p - (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// (the operation order of torch's single-tensor implementation, so results agree to rounding).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1,
+                                                    float rsqrt_bc2) {
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i];
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+        pi -= step_size * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
+void launch_adamw(LaunchCtx ctx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                  float eps, float wd, int step) {
+    const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+    const long want = (n + 255) / 256;
+    const unsigned grid = (unsigned)(want < 2048 ? (want > 0 ? want : 1) : 2048);
+    LAUNCH(ctx, "adamw", (adamw_kernel<<<grid, 256, 0, ctx.stream>>>(p, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1,
+                                                                     (float)(1.0 / sqrt(bc2)))));
+}

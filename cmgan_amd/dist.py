@@ -60,3 +60,37 @@ def gather_shards(local: torch.Tensor, n_items: int) -> torch.Tensor:
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
+
+
+class FlatBucket:
+    """Named tensors as views of ONE flat fp32 buffer - the shape the reference's DDP gives its gradient buckets
+    (7.3 MB generator + 0.7 MB discriminator, src/train.py:68-69) and the shape that suits a fully connected xGMI
+    mesh: a single all-reduce over the whole bucket instead of one per tensor (latency-bound at this size), and a
+    single optimiser launch over the same memory (cmgan_adamw_step).  Works on CPU tensors too (gloo tests)."""
+
+    def __init__(self, shapes: dict, device="cpu"):
+        self.shapes = {k: tuple(v) for k, v in shapes.items()}
+        self.numel = sum(int(torch.Size(s).numel()) for s in self.shapes.values())
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.views, off = {}, 0
+        for k, shp in self.shapes.items():
+            n = int(torch.Size(shp).numel())
+            self.views[k] = self.flat[off:off + n].view(shp)
+            off += n
+
+    def load(self, tensors: dict):
+        for k, v in self.views.items():
+            v.copy_(tensors[k])
+        return self
+
+    def __getitem__(self, key):
+        return self.views[key]
+
+
+def allreduce_mean(flat: torch.Tensor) -> torch.Tensor:
+    """Gradient averaging over ranks as ONE collective on a flat bucket (what DDP's bucketed all-reduce computes,
+    src/train.py:192,200); identity in a single process."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= dist.get_world_size()
+    return flat

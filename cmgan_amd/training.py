@@ -7,6 +7,9 @@
                              power compression of the noisy AND the clean batch, TSCNet, inverse transform.
 * `validation_step`        - the generator half of Trainer.test_step (train.py:207-220): the above + the loss terms
                              + ONE all-reduce of the scalars across ranks (RCCL on the GPU box).
+* `AdamW`, `step_lr`       - torch.optim.AdamW (train.py:63-66) as one HIP launch over a flat parameter bucket, and the
+                             StepLR(30, 0.5) schedule (train.py:248-253); `FeedForwardTrain.allreduce_gradients()` is
+                             the data-parallel gradient mean as ONE all-reduce over the same bucket (train.py:192).
 * `FeedForwardTrain`       - a ConformerBlock's `Scale(0.5, PreNorm(dim, FeedForward(dim, mult=4, dropout)))` branch
                              (conformer.py:54-72, 136-148, 211-212) in TRAIN mode: forward with the two Dropout layers
                              as explicit keep-masks, and the full backward (dL/dx and all six parameter gradients).
@@ -23,9 +26,11 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from ._lib import FfnParams, check
+from .dist import FlatBucket, allreduce_mean
 from .engine import Engine
 
-__all__ = ["FeedForwardTrain", "generator_loss_terms", "dropout_mask", "forward_generator_step", "validation_step"]
+__all__ = ["FeedForwardTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
+           "validation_step"]
 
 _KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.net.0.weight", "fn.fn.net.0.bias",
          "fn.fn.net.3.weight", "fn.fn.net.3.bias")
@@ -61,13 +66,14 @@ class FeedForwardTrain:
         self.engine = engine if engine is not None else Engine(device=device)
         self.p = float(dropout)
         dev = self.engine.device
-        self.params = {}
         for key, shape in zip(_KEYS, _SHAPES):
-            t = state[key].detach().to(dev, torch.float32).contiguous()
-            if tuple(t.shape) != shape:
-                raise ValueError(f"{key}: shape {tuple(t.shape)}, expected {shape}")
-            self.params[key] = t.clone()
-        self.grads = {k: torch.zeros_like(v) for k, v in self.params.items()}
+            if tuple(state[key].shape) != shape:
+                raise ValueError(f"{key}: shape {tuple(state[key].shape)}, expected {shape}")
+        # parameters and gradients live in two flat buckets (views per tensor): one collective, one optimiser launch
+        shapes = dict(zip(_KEYS, _SHAPES))
+        self.param_bucket = FlatBucket(shapes, dev).load({k: state[k].detach().to(dev, torch.float32) for k in _KEYS})
+        self.grad_bucket = FlatBucket(shapes, dev)
+        self.params, self.grads = self.param_bucket.views, self.grad_bucket.views
         self._ws: Optional[torch.Tensor] = None
 
     def _struct(self, tensors: Dict[str, torch.Tensor]) -> FfnParams:
@@ -123,6 +129,42 @@ class FeedForwardTrain:
                 m2.data_ptr() if m2 is not None else None, dx.data_ptr(), ctypes.byref(g), ws.data_ptr(), ws.numel(),
                 eng._stream()))
         return dx.reshape(shape), self.grads
+
+    def allreduce_gradients(self) -> torch.Tensor:
+        """Mean of the six gradients over the data-parallel ranks: ONE all-reduce (RCCL) over the flat bucket."""
+        return allreduce_mean(self.grad_bucket.flat)
+
+
+def step_lr(epoch: int, init_lr: float = 5e-4, decay_epoch: int = 30, gamma: float = 0.5) -> float:
+    """torch.optim.lr_scheduler.StepLR(optimizer, step_size=decay_epoch, gamma=0.5) stepped once per epoch
+    (src/train.py:17-19, 248-253, 275): the learning rate in force during `epoch` (0-based)."""
+    return init_lr * gamma ** (epoch // decay_epoch)
+
+
+class AdamW:
+    """torch.optim.AdamW(params, lr=init_lr) of src/train.py:63 on a FlatBucket pair: one cmgan_adamw_step launch
+    updates every parameter of the bucket.  Defaults are torch's (betas (0.9, 0.999), eps 1e-8, weight_decay 1e-2)."""
+
+    def __init__(self, engine: Engine, params: FlatBucket, grads: FlatBucket, lr: float = 5e-4,
+                 betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
+        if params.numel != grads.numel:
+            raise ValueError("parameter and gradient buckets differ in size")
+        self.engine, self.params, self.grads = engine, params, grads
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.exp_avg = torch.zeros_like(params.flat)
+        self.exp_avg_sq = torch.zeros_like(params.flat)
+        self.t = 0
+
+    def step(self, lr: Optional[float] = None):
+        eng = self.engine
+        self.t += 1
+        p, g = eng._in(self.params.flat, "params"), eng._in(self.grads.flat, "grads")
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_adamw_step(eng._h, p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
+                                                   self.exp_avg_sq.data_ptr(), self.params.numel,
+                                                   float(self.lr if lr is None else lr), float(self.betas[0]),
+                                                   float(self.betas[1]), float(self.eps), float(self.weight_decay),
+                                                   self.t, eng._stream()))
 
 
 @torch.no_grad()

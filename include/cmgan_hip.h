@@ -172,6 +172,14 @@ int cmgan_ffn_train_backward(cmgan_handle* h, const float* x_dev, const float* d
                              float* dx_dev, const cmgan_ffn_params* grads,
                              void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* One torch.optim.AdamW step (src/train.py:63-66, 192-193; defaults betas (0.9, 0.999), eps 1e-8, weight_decay
+ * 0.01) over a FLAT fp32 bucket of n parameters: params, grads and the two moment buffers are parallel device
+ * arrays (the bucket the gradient all-reduce runs over), `step` = 1, 2, ... is the update count for the bias
+ * corrections, `lr` the scheduled learning rate (StepLR(30, 0.5) is host arithmetic, train.py:248-253).          */
+int cmgan_adamw_step(cmgan_handle* h, float* params_dev, const float* grads_dev, float* exp_avg_dev,
+                     float* exp_avg_sq_dev, long long n, float lr, float beta1, float beta2, float eps,
+                     float weight_decay, int step, void* stream);
+
 /* utils.power_compress (src/utils.py:20-29): x[B,F,T,2] -> y[B,2,F,T].          */
 int cmgan_power_compress(cmgan_handle* h, const float* x_dev, int B, int F, int T,
                          float* y_dev, void* stream);

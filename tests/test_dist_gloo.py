@@ -71,3 +71,30 @@ def test_single_process_is_identity():
     v = torch.tensor([1.0, 2.0])
     assert torch.equal(cdist.allreduce_scalars(v.clone()), v)
     assert cdist.init_from_env() == (0, 0, 1) or True
+
+
+def _bucket_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    cdist.init_from_env("gloo")
+    shapes = {"w1": (256, 64), "b1": (256,), "gamma": (64,)}
+    b = cdist.FlatBucket(shapes)
+    assert b.numel == 256 * 64 + 256 + 64 and b["w1"].data_ptr() == b.flat.data_ptr()
+    for i, k in enumerate(shapes):                      # rank-dependent "gradients"
+        b[k].fill_(float(rank + 1) * (i + 1))
+    cdist.allreduce_mean(b.flat)                        # ONE collective for all tensors
+    if rank == 0:
+        want = sum(r + 1 for r in range(world)) / world
+        ret["ok"] = all(torch.allclose(b[k], torch.full(shapes[k], want * (i + 1))) for i, k in enumerate(shapes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_bucket_is_averaged_with_one_allreduce():
+    """The gradient path of BASELINE configs[2] on CPU: every tensor is a view of one flat buffer, one all-reduce."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bucket_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret["ok"] is True
+    b = cdist.FlatBucket({"a": (3,), "b": (2, 2)}).load({"a": torch.arange(3.0), "b": torch.ones(2, 2)})
+    assert b.flat.tolist() == [0, 1, 2, 1, 1, 1, 1] and torch.equal(cdist.allreduce_mean(b.flat), b.flat)

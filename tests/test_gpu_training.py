@@ -143,3 +143,36 @@ def test_data_path_feeds_device_batches_to_the_validation_step(tmp_path):
         assert abs(float(loss) - float(want[0])) < 1e-4 * abs(float(want[0]))
         seen += clean_d.size(0)
     assert seen == 5                                                     # drop_last=False keeps the odd batch
+
+
+def test_three_adamw_steps_of_the_feed_forward_branch_match_torch():
+    """forward (dropout masks) -> backward -> gradient bucket -> AdamW, three times, on the HIP kernels, against
+    autograd through the oracle + torch.optim.AdamW on the CPU (train.py:63, 191-193: lr 5e-4, torch defaults)."""
+    from cmgan_amd.training import AdamW, FeedForwardTrain, step_lr
+    assert step_lr(0) == 5e-4 and step_lr(29) == 5e-4 and step_lr(30) == 2.5e-4 and step_lr(95) == 5e-4 / 8
+    csd = conformer_state_dict(seed=3)
+    ffm = FeedForwardTrain({k: csd["ff1." + k] for k in KEYS}, dropout=0.2)
+    opt = AdamW(ffm.engine, ffm.param_bucket, ffm.grad_bucket, lr=5e-4)
+    leaf = {"ff1." + k: csd["ff1." + k].clone().requires_grad_(True) for k in KEYS}
+    ref_opt = torch.optim.AdamW([leaf["ff1." + k] for k in KEYS], lr=5e-4)
+    rng = np.random.Generator(np.random.PCG64(9))
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    for it in range(3):
+        x = torch.from_numpy(rng.standard_normal((200, 64)).astype(np.float32))
+        tgt = torch.from_numpy(rng.standard_normal((200, 64)).astype(np.float32))
+        m1, m2 = ffm.masks(200, gen)
+        y = ffm.forward(x.to(DEV), m1, m2)
+        dy = (2.0 / y.numel()) * (y - tgt.to(DEV))                       # d/dy of mean((y - tgt)^2)
+        ffm.backward(x.to(DEV), dy, m1, m2)
+        ffm.allreduce_gradients()                                        # identity in one process
+        opt.step(step_lr(0))
+        ref_opt.zero_grad()
+        with torch.enable_grad():
+            yr = O.feed_forward_train(leaf, "ff1", x, m1.cpu(), m2.cpu())
+            torch.mean((yr - tgt) ** 2).backward()
+        ref_opt.step()
+    for k in KEYS:
+        assert _report(f"param {k} after 3 AdamW steps", rel_err(ffm.params[k], leaf["ff1." + k].detach())) < 1e-5, k
+        # the update itself (3 x lr = 1.5e-3 per element at most) is resolved, not just the unchanged bulk
+        moved = (leaf["ff1." + k].detach() - csd["ff1." + k]).abs().max()
+        assert float((ffm.params[k].cpu() - leaf["ff1." + k].detach()).abs().max()) < 2e-2 * float(moved), k
