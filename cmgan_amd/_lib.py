@@ -39,6 +39,11 @@ class FfnParams(Structure):
     _fields_ = [(n, c_void_p) for n in ("ln_weight", "ln_bias", "w1", "b1", "w2", "b2")]
 
 
+class ConvModParams(Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln_weight", "ln_bias", "pw1_weight", "pw1_bias", "dw_weight", "dw_bias",
+                                        "bn_weight", "bn_bias", "pw2_weight", "pw2_bias")]
+
+
 class KernelTime(Structure):
     _fields_ = [("name", c_char_p), ("ms", c_float)]
 
@@ -59,6 +64,11 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_size_t, c_void_p]),
     "cmgan_ffn_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, POINTER(FfnParams), c_void_p,
                                          c_void_p, c_void_p, POINTER(FfnParams), c_void_p, c_size_t, c_void_p]),
+    "cmgan_convmod_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "cmgan_convmod_train_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(ConvModParams), c_void_p,
+                                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cmgan_convmod_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(ConvModParams),
+                                             c_void_p, POINTER(ConvModParams), c_void_p, c_size_t, c_void_p]),
     "cmgan_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float,
                                  c_float, c_float, c_float, c_int, c_void_p]),
     "cmgan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),

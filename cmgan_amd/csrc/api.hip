@@ -875,6 +875,45 @@ extern "C" int cmgan_ffn_train_backward(cmgan_handle* h, const float* x, const f
     return check_launch(h, "ffn_train_backward");
 }
 
+extern "C" size_t cmgan_convmod_train_workspace_bytes(const cmgan_handle* h, int N, int L) {
+    if (!h || N <= 0 || L <= 0) return 0;
+    return convmod_train_ws_floats(N, L) * sizeof(float);
+}
+
+static bool convmod_params_ok(const cmgan_convmod_params* p) {
+    return p && p->ln_weight && p->ln_bias && p->pw1_weight && p->pw1_bias && p->dw_weight && p->dw_bias &&
+           p->bn_weight && p->bn_bias && p->pw2_weight && p->pw2_bias;
+}
+static ConvModTrainParams convmod_params(const cmgan_convmod_params* p) {
+    return ConvModTrainParams{p->ln_weight, p->ln_bias, p->pw1_weight, p->pw1_bias, p->dw_weight, p->dw_bias,
+                              p->bn_weight, p->bn_bias, p->pw2_weight, p->pw2_bias};
+}
+
+extern "C" int cmgan_convmod_train_forward(cmgan_handle* h, const float* x, int N, int L,
+                                           const cmgan_convmod_params* params, float* running_mean,
+                                           float* running_var, float* y, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !y || N <= 0 || L <= 0 || !convmod_params_ok(params) || (!running_mean != !running_var))
+        return fail(h, CMGAN_E_BADARG, "cmgan_convmod_train_forward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, convmod_train_ws_floats(N, L) * sizeof(float))) return rc;
+    launch_convmod_train_forward(begin(h, stream), x, N, L, convmod_params(params), running_mean, running_var, y,
+                                 (float*)ws);
+    return check_launch(h, "convmod_train_forward");
+}
+
+extern "C" int cmgan_convmod_train_backward(cmgan_handle* h, const float* x, const float* dy, int N, int L,
+                                            const cmgan_convmod_params* params, float* dx,
+                                            const cmgan_convmod_params* grads, void* ws, size_t ws_bytes,
+                                            void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !dy || !dx || N <= 0 || L <= 0 || !convmod_params_ok(params) || !convmod_params_ok(grads))
+        return fail(h, CMGAN_E_BADARG, "cmgan_convmod_train_backward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, convmod_train_ws_floats(N, L) * sizeof(float))) return rc;
+    launch_convmod_train_backward(begin(h, stream), x, dy, N, L, convmod_params(params), dx, convmod_params(grads),
+                                  (float*)ws);
+    return check_launch(h, "convmod_train_backward");
+}
+
 extern "C" int cmgan_adamw_step(cmgan_handle* h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                 long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int step, void* stream) {

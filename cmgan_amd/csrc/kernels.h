@@ -143,6 +143,19 @@ void launch_ffn_train_forward(LaunchCtx, const float* x, long M, const FfnTrainP
 void launch_ffn_train_backward(LaunchCtx, const float* x, const float* dy, long M, const FfnTrainParams& p,
                                const float* m1, const float* m2, float* dx, const FfnTrainParams& grad, float* ws);
 
+// training-mode ConformerConvModule (BatchNorm1d on batch statistics) forward + backward on raw parameters
+struct ConvModTrainParams {
+    float *ln_w, *ln_b;       // net.0  LayerNorm(64)                          conformer.py:161
+    float *pw1_w, *pw1_b;     // net.2  Conv1d(64, 256, 1): [256,64], [256]    conformer.py:163
+    float *dw_w, *dw_b;       // net.4  depthwise Conv1d k=31: [128,31], [128] conformer.py:165-167
+    float *bn_w, *bn_b;       // net.5  BatchNorm1d(128) gamma, beta           conformer.py:168
+    float *pw2_w, *pw2_b;     // net.7  Conv1d(128, 64, 1): [64,128], [64]     conformer.py:170
+};
+size_t convmod_train_ws_floats(int N, int L);
+void launch_convmod_train_forward(LaunchCtx, const float* x, int N, int L, const ConvModTrainParams& p,
+                                  float* running_mean, float* running_var, float* y, float* ws);
+void launch_convmod_train_backward(LaunchCtx, const float* x, const float* dy, int N, int L,
+                                   const ConvModTrainParams& p, float* dx, const ConvModTrainParams& grad, float* ws);
 void launch_adamw(LaunchCtx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                   float eps, float wd, int step);
 

@@ -408,3 +408,423 @@ void launch_adamw(LaunchCtx ctx, float* p, const float* g, float* m, float* v, l
     LAUNCH(ctx, "adamw", (adamw_kernel<<<grid, 256, 0, ctx.stream>>>(p, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1,
                                                                      (float)(1.0 / sqrt(bc2)))));
 }
+
+// =====================================================================================
+// Training-mode ConformerConvModule (second backward slice of SURVEY.md N2; conformer.py:151-176):
+//   LayerNorm -> Conv1d(64,256,1) -> GLU -> DepthWiseConv1d(k=31, 'same') -> BatchNorm1d(128, BATCH statistics)
+//   -> Swish -> Conv1d(128,64,1)            (its Dropout has p = conv_dropout = 0)
+// on contiguous sequences x [N, L, 64] (token m = n L + l).  The pointwise stages are the per-token fp32-MFMA chain of
+// the FeedForward slice; the depthwise conv (and its data-gradient, the same kernel with flipped taps) is a 16-output
+// sliding window per thread; BatchNorm statistics and every parameter gradient are fixed-order two-pass reductions.
+// The forward leaves u (GLU output), d (depthwise output) and the batch statistics in the workspace for the backward.
+// =====================================================================================
+struct CmImg {
+    const float *w1, *w1t, *w2, *w2t;       // fm: pw1 [16][4], pw1^T [4][16], pw2 [4][8], pw2^T [8][4]
+};
+struct CmStats { float *mean, *rstd, *scale, *shift; };   // [128] each: batch mean, 1/sqrt(var+eps), gamma rstd, beta - mean gamma rstd
+
+__device__ __forceinline__ bool cm_load_norm(const float* __restrict__ x, long M, long t0, int c, int g,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             f32x4 (&xh)[4], f32x4 (&xn)[1][4], float& rstd, long& row) {
+    const long t = t0 + c;
+    const bool ok = t < M;
+    row = ok ? t : M - 1;
+    f32x4 xv[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) xv[kb] = ldg4(x + row * 64 + 16 * kb + 4 * g);
+    float mean;
+    ln_stats(xv, mean, rstd);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        xh[kb] = (xv[kb] - splat4(mean)) * splat4(rstd);
+        xn[0][kb] = xh[kb] * ldg4(gamma + 16 * kb + 4 * g) + ldg4(beta + 16 * kb + 4 * g);
+    }
+    return ok;
+}
+
+// LN -> pointwise 64 -> 256 -> GLU:  u [M,128]
+__global__ __launch_bounds__(256) void cm_pw1glu_kernel(const float* __restrict__ x, long M, const float* __restrict__ w1fm,
+                                                        ConvModTrainParams p, float* __restrict__ u) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (t0 >= M) return;
+    f32x4 xh[4], xn[1][4];
+    float rstd;
+    long row;
+    const bool ok = cm_load_norm(x, M, t0, c, g, p.ln_w, p.ln_b, xh, xn, rstd, row);
+#pragma unroll 2
+    for (int ob = 0; ob < 8; ++ob) {
+        f32x4 a[1] = {ldg4(p.pw1_b + 16 * ob + 4 * g)}, gt[1] = {ldg4(p.pw1_b + 128 + 16 * ob + 4 * g)};
+        lin_acc<4, 1>(w1fm + (long)ob * 4 * 256 + lane * 4, xn, a);
+        lin_acc<4, 1>(w1fm + (long)(ob + 8) * 4 * 256 + lane * 4, xn, gt);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = a[0][e] * sigmoidf_fast(gt[0][e]);
+        if (ok) stg4(u + row * 128 + 16 * ob + 4 * g, r);
+    }
+}
+
+// out[(n,l)][ch] = bias[ch] + sum_t taps[ch][flip ? 30 - t : t] * in[(n, l + t - 15)][ch], zero outside [0, L).
+// flip = 0: the forward depthwise conv; flip = 1 (bias = NULL): its gradient w.r.t. the input.
+// stats (forward only): per block and channel (sum, sum of squares) of the outputs -> partial [blk][128][2].
+__global__ __launch_bounds__(256) void cm_depthwise_kernel(const float* __restrict__ in, const float* __restrict__ taps,
+                                                           const float* __restrict__ bias, int flip, int L,
+                                                           float* __restrict__ out, float* __restrict__ stats) {
+    __shared__ float red[2][128][2];
+    const int ch = threadIdx.x & 127, sub = threadIdx.x >> 7;
+    const int n = blockIdx.x, l0 = blockIdx.y * 32 + sub * 16;
+    float w[31];
+#pragma unroll
+    for (int t = 0; t < 31; ++t) w[t] = taps[ch * 31 + (flip ? 30 - t : t)];
+    const float b = bias ? bias[ch] : 0.f;
+    float acc[16];
+#pragma unroll
+    for (int oo = 0; oo < 16; ++oo) acc[oo] = b;
+    const float* base = in + (long)n * L * 128 + ch;
+#pragma unroll
+    for (int kk = 0; kk < 46; ++kk) {
+        const int l = l0 - 15 + kk;
+        const float v = (l >= 0 && l < L) ? base[(long)l * 128] : 0.f;
+#pragma unroll
+        for (int oo = 0; oo < 16; ++oo) {
+            const int t = kk - oo;
+            if (t >= 0 && t < 31) acc[oo] = fmaf(w[t], v, acc[oo]);
+        }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int oo = 0; oo < 16; ++oo) {
+        const int l = l0 + oo;
+        if (l < L) {
+            out[((long)n * L + l) * 128 + ch] = acc[oo];
+            s1 += acc[oo];
+            s2 = fmaf(acc[oo], acc[oo], s2);
+        }
+    }
+    if (stats) {
+        red[sub][ch][0] = s1;
+        red[sub][ch][1] = s2;
+        __syncthreads();
+        if (sub == 0) {
+            const long blk = (long)blockIdx.x * gridDim.y + blockIdx.y;
+            stats[(blk * 128 + ch) * 2 + 0] = red[0][ch][0] + red[1][ch][0];
+            stats[(blk * 128 + ch) * 2 + 1] = red[0][ch][1] + red[1][ch][1];
+        }
+    }
+}
+
+// batch statistics of BatchNorm1d(128) in train mode (biased variance, eps 1e-5) from the per-block partial sums, in
+// fp64 and block order; running statistics updated like torch (momentum 0.1, unbiased variance)   conformer.py:168
+__global__ void cm_bn_finalize_kernel(const float* __restrict__ stats, long nblk, double count,
+                                      const float* __restrict__ bn_w, const float* __restrict__ bn_b, CmStats st,
+                                      float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int ch = threadIdx.x;
+    if (ch >= 128) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (long k = 0; k < nblk; ++k) {
+        s1 += (double)stats[(k * 128 + ch) * 2];
+        s2 += (double)stats[(k * 128 + ch) * 2 + 1];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double rstd = 1.0 / sqrt(var + 1e-5);
+    st.mean[ch] = (float)mean;
+    st.rstd[ch] = (float)rstd;
+    st.scale[ch] = (float)((double)bn_w[ch] * rstd);
+    st.shift[ch] = (float)((double)bn_b[ch] - mean * (double)bn_w[ch] * rstd);
+    if (running_mean && running_var) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[ch] = (float)(0.9 * (double)running_mean[ch] + 0.1 * mean);
+        running_var[ch] = (float)(0.9 * (double)running_var[ch] + 0.1 * unbiased);
+    }
+}
+
+// BatchNorm apply -> Swish -> pointwise 128 -> 64 + bias
+__global__ __launch_bounds__(256) void cm_bn_swish_pw2_kernel(const float* __restrict__ d, long M, CmStats st,
+                                                              const float* __restrict__ w2fm,
+                                                              const float* __restrict__ b2, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (t0 >= M) return;
+    const long t = t0 + c;
+    const bool ok = t < M;
+    const long row = ok ? t : M - 1;
+    f32x4 s[1][8];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const f32x4 dn = ldg4(d + row * 128 + 16 * kb + 4 * g) * ldg4(st.scale + 16 * kb + 4 * g) +
+                         ldg4(st.shift + 16 * kb + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[0][kb][e] = swishf(dn[e]);
+    }
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+        f32x4 acc[1] = {ldg4(b2 + 16 * ob + 4 * g)};
+        lin_acc<8, 1>(w2fm + (long)ob * 8 * 256 + lane * 4, s, acc);
+        if (ok) stg4(y + row * 64 + 16 * ob + 4 * g, acc[0]);
+    }
+}
+
+// backward, part 1 (per token): ds = pw2^T dy, through Swish; writes ddn = dL/d(bn output), s (for dW_pw2) and
+// g2 = ddn * dhat (for the BatchNorm reductions)
+__global__ __launch_bounds__(256) void cm_bwd1_kernel(const float* __restrict__ dy, const float* __restrict__ d, long M,
+                                                      CmStats st, const float* __restrict__ w2tfm,
+                                                      float* __restrict__ ddn, float* __restrict__ s_out,
+                                                      float* __restrict__ g2) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (t0 >= M) return;
+    const long t = t0 + c;
+    const bool ok = t < M;
+    const long row = ok ? t : M - 1;
+    f32x4 dyf[1][4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) dyf[0][ob] = ldg4(dy + row * 64 + 16 * ob + 4 * g);
+#pragma unroll 2
+    for (int hb = 0; hb < 8; ++hb) {
+        f32x4 ds[1] = {splat4(0.f)};
+        lin_acc<4, 1>(w2tfm + (long)hb * 4 * 256 + lane * 4, dyf, ds);
+        const f32x4 dv = ldg4(d + row * 128 + 16 * hb + 4 * g);
+        const f32x4 dhat = (dv - ldg4(st.mean + 16 * hb + 4 * g)) * ldg4(st.rstd + 16 * hb + 4 * g);
+        const f32x4 dn = dv * ldg4(st.scale + 16 * hb + 4 * g) + ldg4(st.shift + 16 * hb + 4 * g);
+        f32x4 o_ddn, o_s;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sg = sigmoidf_fast(dn[e]);
+            o_s[e] = dn[e] * sg;
+            o_ddn[e] = ds[0][e] * (sg * (1.f + dn[e] * (1.f - sg)));
+        }
+        if (ok) {
+            stg4(ddn + row * 128 + 16 * hb + 4 * g, o_ddn);
+            stg4(s_out + row * 128 + 16 * hb + 4 * g, o_s);
+            stg4(g2 + row * 128 + 16 * hb + 4 * g, o_ddn * dhat);
+        }
+    }
+}
+
+// BatchNorm backward (batch statistics): dd = gamma rstd (ddn - mean(ddn) - dhat mean(ddn dhat)), in place on ddn
+__global__ __launch_bounds__(256) void cm_bn_bwd_kernel(float* __restrict__ ddn, const float* __restrict__ d, long total,
+                                                        CmStats st, const float* __restrict__ sum_ddn,
+                                                        const float* __restrict__ sum_g2, float inv_count) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ch = (int)(i & 127);
+        const float dhat = (d[i] - st.mean[ch]) * st.rstd[ch];
+        ddn[i] = st.scale[ch] * (ddn[i] - sum_ddn[ch] * inv_count - dhat * (sum_g2[ch] * inv_count));
+    }
+}
+
+// depthwise weight gradient: dw[ch][t] = sum_{n,l} dd[(n,l)][ch] u[(n, l + t - 15)][ch] -> partial [blk][128*31]
+__global__ __launch_bounds__(256) void cm_dw_wgrad_kernel(const float* __restrict__ dd, const float* __restrict__ u, int L,
+                                                          float* __restrict__ partial) {
+    __shared__ float red[128 * 31];
+    const int ch = threadIdx.x & 127, sub = threadIdx.x >> 7;
+    const int n = blockIdx.x, l0 = blockIdx.y * 32 + sub * 16;
+    const float* ub = u + (long)n * L * 128 + ch;
+    const float* db = dd + (long)n * L * 128 + ch;
+    // unconditional (clamped) loads + selects, and tap-major loops with compile-time indices only: the
+    // output-major form with `acc[kk - oo]` left the 46-step loop rolled and indexed registers dynamically
+    float g[16], uw[46];
+#pragma unroll
+    for (int oo = 0; oo < 16; ++oo) {
+        const int l = l0 + oo, lc = l < L ? l : L - 1;
+        const float v = db[(long)lc * 128];
+        g[oo] = l < L ? v : 0.f;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 46; ++kk) {
+        const int l = l0 - 15 + kk, lc = l < 0 ? 0 : (l < L ? l : L - 1);
+        const float v = ub[(long)lc * 128];
+        uw[kk] = (l >= 0 && l < L) ? v : 0.f;
+    }
+    float acc[31];
+#pragma unroll
+    for (int t = 0; t < 31; ++t) {
+        float a = 0.f;
+#pragma unroll
+        for (int oo = 0; oo < 16; ++oo) a = fmaf(g[oo], uw[oo + t], a);
+        acc[t] = a;
+    }
+    if (sub == 1) {
+#pragma unroll
+        for (int t = 0; t < 31; ++t) red[ch * 31 + t] = acc[t];
+    }
+    __syncthreads();
+    if (sub == 0) {
+        const long blk = (long)blockIdx.x * gridDim.y + blockIdx.y;
+#pragma unroll
+        for (int t = 0; t < 31; ++t) partial[blk * 3968 + ch * 31 + t] = acc[t] + red[ch * 31 + t];
+    }
+}
+
+// backward, part 2 (per token): GLU backward with a, g recomputed from x, dxn = pw1^T [da; dg], LayerNorm backward
+__global__ __launch_bounds__(256) void cm_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ du, long M,
+                                                      const float* __restrict__ w1fm, const float* __restrict__ w1tfm,
+                                                      ConvModTrainParams p, float* __restrict__ dx,
+                                                      float* __restrict__ dag, float* __restrict__ xn_out,
+                                                      float* __restrict__ g1, float* __restrict__ dxn_out) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (t0 >= M) return;
+    f32x4 xh[4], xn[1][4];
+    float rstd;
+    long row;
+    const bool ok = cm_load_norm(x, M, t0, c, g, p.ln_w, p.ln_b, xh, xn, rstd, row);
+    f32x4 dxn[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) dxn[kb] = splat4(0.f);
+#pragma unroll 2
+    for (int ob = 0; ob < 8; ++ob) {
+        f32x4 a[1] = {ldg4(p.pw1_b + 16 * ob + 4 * g)}, gt[1] = {ldg4(p.pw1_b + 128 + 16 * ob + 4 * g)};
+        lin_acc<4, 1>(w1fm + (long)ob * 4 * 256 + lane * 4, xn, a);
+        lin_acc<4, 1>(w1fm + (long)(ob + 8) * 4 * 256 + lane * 4, xn, gt);
+        f32x4 duv = ldg4(du + row * 128 + 16 * ob + 4 * g);
+        if (!ok) duv = splat4(0.f);
+        f32x4 da, dg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sg = sigmoidf_fast(gt[0][e]);
+            da[e] = duv[e] * sg;
+            dg[e] = duv[e] * a[0][e] * sg * (1.f - sg);
+        }
+        if (ok) {
+            stg4(dag + row * 256 + 16 * ob + 4 * g, da);
+            stg4(dag + row * 256 + 128 + 16 * ob + 4 * g, dg);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const f32x4 wa = ldg4(w1tfm + ((long)kb * 16 + ob) * 256 + lane * 4);
+            const f32x4 wg = ldg4(w1tfm + ((long)kb * 16 + ob + 8) * 256 + lane * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dxn[kb] = mfma16(wa[r], da[r], dxn[kb]);
+                dxn[kb] = mfma16(wg[r], dg[r], dxn[kb]);
+            }
+        }
+    }
+    f32x4 dxh[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        dxh[kb] = dxn[kb] * ldg4(p.ln_w + 16 * kb + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s1 += dxh[kb][r];
+            s2 = fmaf(dxh[kb][r], xh[kb][r], s2);
+        }
+    }
+    const float mu1 = red_g_sum(s1) * (1.0f / 64.0f), mu2 = red_g_sum(s2) * (1.0f / 64.0f);
+    if (ok) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            stg4(dx + row * 64 + 16 * kb + 4 * g, (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd));
+            stg4(xn_out + row * 64 + 16 * kb + 4 * g, xn[0][kb]);
+            stg4(g1 + row * 64 + 16 * kb + 4 * g, dxn[kb] * xh[kb]);
+            stg4(dxn_out + row * 64 + 16 * kb + 4 * g, dxn[kb]);
+        }
+    }
+}
+
+// workspace layout (floats): images | u | d | stats (4 x 128) | bwd buffers | partials
+struct CmPlan {
+    size_t img, u, d, st, ddn, s, g2, du, dag, xn, g1, dxn, wpart, dwpart, bnpart, cpart, sums, total;
+};
+static CmPlan cm_plan(int N, int L) {
+    CmPlan p;
+    const size_t M = (size_t)N * L, nblk = (size_t)N * ((L + 31) / 32);
+    size_t cur = 0;
+    auto take = [&](size_t n) { const size_t o = cur; cur += (n + 63) & ~(size_t)63; return o; };
+    p.img = take(16384 * 2 + 8192 * 2);
+    p.u = take(M * 128); p.d = take(M * 128); p.st = take(512);
+    p.ddn = take(M * 128); p.s = take(M * 128); p.g2 = take(M * 128); p.du = take(M * 128);
+    p.dag = take(M * 256); p.xn = take(M * 64); p.g1 = take(M * 64); p.dxn = take(M * 64);
+    p.wpart = take((size_t)FFN_WGRAD_SPLIT * 16384);
+    p.dwpart = take(nblk * 3968);
+    p.bnpart = take(nblk * 256);
+    p.cpart = take((size_t)FFN_COLSUM_BLOCKS * 256);
+    p.sums = take(256);
+    p.total = cur;
+    return p;
+}
+size_t convmod_train_ws_floats(int N, int L) { return cm_plan(N, L).total; }
+
+static CmImg cm_pack_images(LaunchCtx ctx, const ConvModTrainParams& p, float* img) {
+    hipStream_t s = ctx.stream;
+    float *w1 = img, *w1t = img + 16384, *w2 = img + 32768, *w2t = img + 32768 + 8192;
+    LAUNCH(ctx, "convmod_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.pw1_w, 256, 64, 64, 0, w1)));
+    LAUNCH(ctx, "convmod_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.pw1_w, 64, 256, 64, 1, w1t)));
+    LAUNCH(ctx, "convmod_train_pack", (pack_fm_kernel<<<32, 256, 0, s>>>(p.pw2_w, 64, 128, 128, 0, w2)));
+    LAUNCH(ctx, "convmod_train_pack", (pack_fm_kernel<<<32, 256, 0, s>>>(p.pw2_w, 128, 64, 128, 1, w2t)));
+    return CmImg{w1, w1t, w2, w2t};
+}
+
+void launch_convmod_train_forward(LaunchCtx ctx, const float* x, int N, int L, const ConvModTrainParams& p,
+                                  float* running_mean, float* running_var, float* y, float* ws) {
+    hipStream_t s = ctx.stream;
+    const CmPlan pl = cm_plan(N, L);
+    const long M = (long)N * L;
+    const CmImg im = cm_pack_images(ctx, p, ws + pl.img);
+    const CmStats st{ws + pl.st, ws + pl.st + 128, ws + pl.st + 256, ws + pl.st + 384};
+    const unsigned grid = (unsigned)((M + 63) / 64);
+    const dim3 dgrid(N, (L + 31) / 32);
+    LAUNCH(ctx, "convmod_train_fwd", (cm_pw1glu_kernel<<<grid, 256, 0, s>>>(x, M, im.w1, p, ws + pl.u)));
+    LAUNCH(ctx, "convmod_train_fwd", (cm_depthwise_kernel<<<dgrid, 256, 0, s>>>(ws + pl.u, p.dw_w, p.dw_b, 0, L, ws + pl.d,
+                                                                                ws + pl.bnpart)));
+    LAUNCH(ctx, "convmod_train_fwd", (cm_bn_finalize_kernel<<<1, 128, 0, s>>>(ws + pl.bnpart, (long)dgrid.x * dgrid.y,
+                                                                              (double)M, p.bn_w, p.bn_b, st, running_mean,
+                                                                              running_var)));
+    LAUNCH(ctx, "convmod_train_fwd", (cm_bn_swish_pw2_kernel<<<grid, 256, 0, s>>>(ws + pl.d, M, st, im.w2, p.pw2_b, y)));
+}
+
+void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* dy, int N, int L,
+                                   const ConvModTrainParams& p, float* dx, const ConvModTrainParams& grad, float* ws) {
+    hipStream_t s = ctx.stream;
+    const CmPlan pl = cm_plan(N, L);
+    const long M = (long)N * L;
+    const CmImg im = cm_pack_images(ctx, p, ws + pl.img);          // (the optimiser may have run since the forward's pack)
+    const CmStats st{ws + pl.st, ws + pl.st + 128, ws + pl.st + 256, ws + pl.st + 384};
+    const unsigned grid = (unsigned)((M + 63) / 64);
+    const dim3 dgrid(N, (L + 31) / 32);
+    const long nblk = (long)dgrid.x * dgrid.y;
+    float* cpart = ws + pl.cpart;
+    float* sum_ddn = ws + pl.sums;
+    float* sum_g2 = ws + pl.sums + 128;
+    auto colsum = [&](const float* X, int C, float* out) {
+        LAUNCH(ctx, "convmod_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(X, M, C, cpart)));
+        LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<1, 256, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, C, out)));
+    };
+    LAUNCH(ctx, "convmod_train_bwd", (cm_bwd1_kernel<<<grid, 256, 0, s>>>(dy, ws + pl.d, M, st, im.w2t, ws + pl.ddn,
+                                                                          ws + pl.s, ws + pl.g2)));
+    // pointwise-2 gradients: dW_pw2 [64,128] = dy^T s, db_pw2 = colsum dy
+    LAUNCH(ctx, "convmod_train_wgrad", (wgrad_partial_kernel<<<dim3(4, 2, FFN_WGRAD_SPLIT), 256, 0, s>>>(
+                                           dy, ws + pl.s, M, 64, 128, FFN_WGRAD_SPLIT, ws + pl.wpart)));
+    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<32, 256, 0, s>>>(ws + pl.wpart, FFN_WGRAD_SPLIT, 8192,
+                                                                                   grad.pw2_w)));
+    colsum(dy, 64, grad.pw2_b);
+    // BatchNorm: dbeta = sum ddn, dgamma = sum ddn dhat; then dd in place
+    colsum(ws + pl.ddn, 128, sum_ddn);
+    colsum(ws + pl.g2, 128, sum_g2);
+    hipMemcpyAsync(grad.bn_b, sum_ddn, 128 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    hipMemcpyAsync(grad.bn_w, sum_g2, 128 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    LAUNCH(ctx, "convmod_train_bwd", (cm_bn_bwd_kernel<<<2048, 256, 0, s>>>(ws + pl.ddn, ws + pl.d, M * 128, st, sum_ddn,
+                                                                            sum_g2, (float)(1.0 / (double)M))));
+    float* dd = ws + pl.ddn;
+    // depthwise: bias / weight gradients, then the data gradient (same kernel, flipped taps)
+    colsum(dd, 128, grad.dw_b);
+    LAUNCH(ctx, "convmod_train_wgrad", (cm_dw_wgrad_kernel<<<dgrid, 256, 0, s>>>(dd, ws + pl.u, L, ws + pl.dwpart)));
+    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<16, 256, 0, s>>>(ws + pl.dwpart, (int)nblk, 3968,
+                                                                                   grad.dw_w)));
+    LAUNCH(ctx, "convmod_train_bwd", (cm_depthwise_kernel<<<dgrid, 256, 0, s>>>(dd, p.dw_w, nullptr, 1, L, ws + pl.du,
+                                                                                nullptr)));
+    LAUNCH(ctx, "convmod_train_bwd", (cm_bwd2_kernel<<<grid, 256, 0, s>>>(x, ws + pl.du, M, im.w1, im.w1t, p, dx,
+                                                                          ws + pl.dag, ws + pl.xn, ws + pl.g1,
+                                                                          ws + pl.dxn)));
+    // pointwise-1 and LayerNorm gradients
+    LAUNCH(ctx, "convmod_train_wgrad", (wgrad_partial_kernel<<<dim3(16, 1, FFN_WGRAD_SPLIT), 256, 0, s>>>(
+                                           ws + pl.dag, ws + pl.xn, M, 256, 64, FFN_WGRAD_SPLIT, ws + pl.wpart)));
+    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<64, 256, 0, s>>>(ws + pl.wpart, FFN_WGRAD_SPLIT, 16384,
+                                                                                   grad.pw1_w)));
+    colsum(ws + pl.dag, 256, grad.pw1_b);
+    colsum(ws + pl.g1, 64, grad.ln_w);
+    colsum(ws + pl.dxn, 64, grad.ln_b);
+}

@@ -55,8 +55,8 @@ class TSCNet:
         if mode:
             raise NotImplementedError(
                 "train-mode forward of the whole generator (Dropout 0.2, BatchNorm1d batch statistics, autograd; "
-                "src/train.py:72-122) is not built: cmgan_amd.training holds the pieces that are (loss terms, "
-                "FeedForward forward/backward)")
+                "src/train.py:72-122) is not built: cmgan_amd.training holds the pieces that are (loss terms, validation "
+                "step, FeedForward and ConformerConvModule forward/backward, AdamW)")
         return self
 
     def load_state_dict(self, state_dict: dict, strict: bool = True):

@@ -10,6 +10,8 @@
 * `AdamW`, `step_lr`       - torch.optim.AdamW (train.py:63-66) as one HIP launch over a flat parameter bucket, and the
                              StepLR(30, 0.5) schedule (train.py:248-253); `FeedForwardTrain.allreduce_gradients()` is
                              the data-parallel gradient mean as ONE all-reduce over the same bucket (train.py:192).
+* `ConvModuleTrain`        - the ConformerConvModule (conformer.py:151-176) in TRAIN mode: BatchNorm1d on batch
+                             statistics with running-stat update, forward + full backward (ten parameter gradients).
 * `FeedForwardTrain`       - a ConformerBlock's `Scale(0.5, PreNorm(dim, FeedForward(dim, mult=4, dropout)))` branch
                              (conformer.py:54-72, 136-148, 211-212) in TRAIN mode: forward with the two Dropout layers
                              as explicit keep-masks, and the full backward (dL/dx and all six parameter gradients).
@@ -25,11 +27,11 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from ._lib import FfnParams, check
+from ._lib import ConvModParams, FfnParams, check
 from .dist import FlatBucket, allreduce_mean
 from .engine import Engine
 
-__all__ = ["FeedForwardTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
+__all__ = ["FeedForwardTrain", "ConvModuleTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
            "validation_step"]
 
 _KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.net.0.weight", "fn.fn.net.0.bias",
@@ -196,3 +198,82 @@ def validation_step(model, clean: torch.Tensor, noisy: torch.Tensor, loss_weight
         cdist.allreduce_scalars(packed)
         loss, terms = packed[0], packed[1:]
     return loss, terms
+
+
+_CM_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.conv.weight", "net.4.conv.bias",
+            "net.5.weight", "net.5.bias", "net.7.weight", "net.7.bias")
+_CM_FIELDS = ("ln_weight", "ln_bias", "pw1_weight", "pw1_bias", "dw_weight", "dw_bias", "bn_weight", "bn_bias",
+              "pw2_weight", "pw2_bias")
+_CM_SHAPES = ((64,), (64,), (256, 64, 1), (256,), (128, 1, 31), (128,), (128,), (128,), (64, 128, 1), (64,))
+
+
+class ConvModuleTrain:
+    """`conv` branch of one ConformerBlock in train mode on the HIP kernels (csrc/train.hip).
+
+    `state` holds the module's tensors under the reference's key names relative to `conv.` (`net.0.weight`,
+    `net.4.conv.weight`, `net.5.running_mean`, ...).  BatchNorm1d uses the statistics of the batch and updates
+    `running_mean` / `running_var` like torch (momentum 0.1).  `backward` must follow the `forward` of the same x."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], engine: Optional[Engine] = None, device=None):
+        self.engine = engine if engine is not None else Engine(device=device)
+        dev = self.engine.device
+        for key, shape in zip(_CM_KEYS, _CM_SHAPES):
+            if tuple(state[key].shape) != shape:
+                raise ValueError(f"{key}: shape {tuple(state[key].shape)}, expected {shape}")
+        shapes = dict(zip(_CM_KEYS, _CM_SHAPES))
+        self.param_bucket = FlatBucket(shapes, dev).load({k: state[k].detach().to(dev, torch.float32) for k in _CM_KEYS})
+        self.grad_bucket = FlatBucket(shapes, dev)
+        self.params, self.grads = self.param_bucket.views, self.grad_bucket.views
+        self.running_mean = state["net.5.running_mean"].detach().to(dev, torch.float32).clone()
+        self.running_var = state["net.5.running_var"].detach().to(dev, torch.float32).clone()
+        self._ws: Optional[torch.Tensor] = None
+        self._shape = None
+
+    def _struct(self, tensors) -> ConvModParams:
+        s = ConvModParams()
+        for key, field in zip(_CM_KEYS, _CM_FIELDS):
+            setattr(s, field, tensors[key].data_ptr())
+        return s
+
+    def _workspace(self, N: int, L: int) -> torch.Tensor:
+        need = self.engine.lib.cmgan_convmod_train_workspace_bytes(self.engine._h, N, L)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.engine.device)
+        return self._ws
+
+    def forward(self, x: torch.Tensor, update_running_stats: bool = True) -> torch.Tensor:
+        """x [N, L, 64] -> ConformerConvModule(x) in train mode (add the residual yourself)."""
+        eng = self.engine
+        x = eng._in(x, "x")
+        N, L, C = x.shape
+        if C != 64:
+            raise ValueError("conformer dim must be 64")
+        ws = self._workspace(N, L)
+        y = torch.empty_like(x)
+        p = self._struct(self.params)
+        rm = self.running_mean.data_ptr() if update_running_stats else None
+        rv = self.running_var.data_ptr() if update_running_stats else None
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_convmod_train_forward(eng._h, x.data_ptr(), N, L, ctypes.byref(p), rm, rv,
+                                                              y.data_ptr(), ws.data_ptr(), ws.numel(), eng._stream()))
+        self._shape = (N, L)
+        return y
+
+    def backward(self, x: torch.Tensor, dy: torch.Tensor) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """(dL/dx, {key: dL/dparam}) for upstream gradient dy; uses the activations the last forward left behind."""
+        eng = self.engine
+        x, dy = eng._in(x, "x"), eng._in(dy, "dy")
+        N, L, _ = x.shape
+        if self._shape != (N, L) or dy.shape != x.shape:
+            raise RuntimeError("backward() needs the forward() of the same [N, L, 64] input first")
+        ws = self._workspace(N, L)
+        dx = torch.empty_like(x)
+        p, g = self._struct(self.params), self._struct(self.grads)
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_convmod_train_backward(eng._h, x.data_ptr(), dy.data_ptr(), N, L, ctypes.byref(p),
+                                                               dx.data_ptr(), ctypes.byref(g), ws.data_ptr(),
+                                                               ws.numel(), eng._stream()))
+        return dx, self.grads
+
+    def allreduce_gradients(self) -> torch.Tensor:
+        return allreduce_mean(self.grad_bucket.flat)

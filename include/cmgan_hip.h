@@ -172,6 +172,29 @@ int cmgan_ffn_train_backward(cmgan_handle* h, const float* x_dev, const float* d
                              float* dx_dev, const cmgan_ffn_params* grads,
                              void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Training-mode ConformerConvModule with its backward - second slice of the training step:
+ *   y = Conv1d(128,64,1)(Swish(BatchNorm1d(DepthWiseConv1d_31(GLU(Conv1d(64,256,1)(LayerNorm(x)))))))
+ * (src/models/conformer.py:151-176; the residual add of :219 stays with the caller; the module's Dropout has
+ * p = conv_dropout = 0).  TRAIN semantics: BatchNorm1d normalises with the statistics of this batch (biased
+ * variance over all N*L positions, eps 1e-5) and updates running_mean / running_var in place (momentum 0.1, unbiased
+ * variance) when both pointers are non-NULL.  x, y, dy, dx: contiguous sequences [N, L, 64].  Parameters are the
+ * RAW tensors of the reference state_dict (conv.net.{0,2,4.conv,5,7}.{weight,bias}; the [256,64,1], [128,1,31] and
+ * [64,128,1] conv weights are used as [256,64], [128,31], [64,128]).  The forward keeps its GLU output, depthwise
+ * output and batch statistics in the workspace; the backward must be given the SAME workspace, untouched in
+ * between, and writes dL/dx and the ten parameter gradients (overwritten, fixed-order reductions).               */
+typedef struct cmgan_convmod_params {
+    float *ln_weight, *ln_bias, *pw1_weight, *pw1_bias, *dw_weight, *dw_bias, *bn_weight, *bn_bias,
+          *pw2_weight, *pw2_bias;
+} cmgan_convmod_params;
+size_t cmgan_convmod_train_workspace_bytes(const cmgan_handle* h, int N, int L);
+int cmgan_convmod_train_forward(cmgan_handle* h, const float* x_dev, int N, int L, const cmgan_convmod_params* params,
+                                float* running_mean_dev, float* running_var_dev, float* y_dev,
+                                void* workspace_dev, size_t workspace_bytes, void* stream);
+int cmgan_convmod_train_backward(cmgan_handle* h, const float* x_dev, const float* dy_dev, int N, int L,
+                                 const cmgan_convmod_params* params, float* dx_dev,
+                                 const cmgan_convmod_params* grads,
+                                 void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* One torch.optim.AdamW step (src/train.py:63-66, 192-193; defaults betas (0.9, 0.999), eps 1e-8, weight_decay
  * 0.01) over a FLAT fp32 bucket of n parameters: params, grads and the two moment buffers are parallel device
  * arrays (the bucket the gradient all-reduce runs over), `step` = 1, 2, ... is the update count for the bias

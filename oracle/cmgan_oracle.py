@@ -152,6 +152,27 @@ def conv_module(sd, p, x, kernel: int = 31):
     return h.transpose(1, 2)
 
 
+def conv_module_train(sd, p, x, running: dict | None = None, kernel: int = 31):
+    """ConformerConvModule in TRAIN mode (conformer.py:151-176): BatchNorm1d(128) normalises with the statistics of
+    the batch (biased variance over all N*L positions, eps 1e-5) and, when `running` = {"mean", "var"} is given,
+    updates the running statistics in place with momentum 0.1 and the unbiased variance (torch semantics); the
+    module's Dropout has p = conv_dropout = 0 (conformer.py:193, generator.py:75-90).  Differentiable: autograd
+    through this function is the gradient oracle of cmgan_amd.training.ConvModuleTrain."""
+    h = layer_norm(sd, p + ".net.0", x).transpose(1, 2)                   # [N,64,L]
+    h = F.conv1d(h, sd[p + ".net.2.weight"], sd[p + ".net.2.bias"])      # pointwise 64 -> 256
+    a, g = h.chunk(2, dim=1)
+    h = a * torch.sigmoid(g)                                              # GLU(dim=1)
+    pad = kernel // 2
+    h = F.pad(h, (pad, pad - (kernel + 1) % 2))
+    h = F.conv1d(h, sd[p + ".net.4.conv.weight"], sd[p + ".net.4.conv.bias"], groups=h.shape[1])
+    rm = running["mean"] if running is not None else None
+    rv = running["var"] if running is not None else None
+    h = F.batch_norm(h, rm, rv, sd[p + ".net.5.weight"], sd[p + ".net.5.bias"], True, 0.1, EPS)
+    h = h * torch.sigmoid(h)
+    h = F.conv1d(h, sd[p + ".net.7.weight"], sd[p + ".net.7.bias"])
+    return h.transpose(1, 2)
+
+
 def conformer_block(sd, p, x, stages: dict | None = None):
     """ConformerBlock.forward (conformer.py:216-222).  x: [N, L, 64].
     ``stages`` (optional dict) receives the residual stream after each sub-module."""

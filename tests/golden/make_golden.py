@@ -232,6 +232,22 @@ def main():
     save("valstep.npz", clean=vclean, noisy=vnoisy, est_audio=e_audio, loss_ri=l_ri, loss_mag=l_mag, time_loss=l_time,
          loss=0.1 * l_ri + 0.9 * l_mag + 0.2 * l_time)
 
+    # -- 11. ConformerConvModule in TRAIN mode (BatchNorm1d on batch statistics, running stats updated with momentum
+    #        0.1; conv_dropout = 0 so its Dropout is the identity) with autograd gradients        conformer.py:151-176
+    with torch.enable_grad():
+        blk_c = ConformerBlock(dim=64, dim_head=16, heads=4, conv_kernel_size=31, attn_dropout=0.2, ff_dropout=0.2)
+        blk_c.load_state_dict(csd, strict=True)
+        blk_c.train()
+        cm = blk_c.conv
+        xc = rnd((3, 37, 64), 31).requires_grad_(True)
+        dyc = rnd((3, 37, 64), 32)
+        yc = cm(xc)
+        yc.backward(dyc)
+        cgr = {"grad_" + k.replace(".", "_"): v.grad.detach() for k, v in cm.named_parameters()}
+        bn = cm.net[5]
+    save("convmod_train.npz", x=xc.detach(), dy=dyc, y=yc.detach(), dx=xc.grad.detach(),
+         running_mean=bn.running_mean.detach().clone(), running_var=bn.running_var.detach().clone(), **cgr)
+
     save("ffn_train.npz", x=xt.detach(), dy=dy, mask1=m1, mask2=m2, y=yt.detach(), dx=xt.grad.detach(),
          y_nomask=y0.detach(), dx_nomask=x0.grad.detach(), **grads, **grads0)
 

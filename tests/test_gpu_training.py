@@ -176,3 +176,61 @@ def test_three_adamw_steps_of_the_feed_forward_branch_match_torch():
         # the update itself (3 x lr = 1.5e-3 per element at most) is resolved, not just the unchanged bulk
         moved = (leaf["ff1." + k].detach() - csd["ff1." + k]).abs().max()
         assert float((ffm.params[k].cpu() - leaf["ff1." + k].detach()).abs().max()) < 2e-2 * float(moved), k
+
+
+CM_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.conv.weight", "net.4.conv.bias",
+           "net.5.weight", "net.5.bias", "net.7.weight", "net.7.bias")
+CM_ALL = CM_KEYS + ("net.5.running_mean", "net.5.running_var")
+
+
+def test_conv_module_train_matches_reference_autograd():
+    """ConformerConvModule in TRAIN mode (BatchNorm1d on batch statistics + running-stat update): forward, dL/dx and
+    all ten parameter gradients against the reference module's own torch autograd (tests/golden/convmod_train.npz)."""
+    from cmgan_amd.training import ConvModuleTrain
+    g = load_golden("convmod_train.npz")
+    csd = conformer_state_dict(seed=3)
+    cm = ConvModuleTrain({k: csd["conv." + k] for k in CM_ALL})
+    y = cm.forward(g["x"].to(DEV))
+    assert _report("conv module train forward", rel_err(y, g["y"])) < GRAD_TOL
+    assert _report("BatchNorm running_mean", rel_err(cm.running_mean, g["running_mean"])) < 1e-5
+    assert _report("BatchNorm running_var", rel_err(cm.running_var, g["running_var"])) < 1e-5
+    dx, grads = cm.backward(g["x"].to(DEV), g["dy"].to(DEV))
+    assert _report("conv module dL/dx", rel_err(dx, g["dx"])) < GRAD_TOL
+    for k in CM_KEYS:
+        want = g["grad_" + k.replace(".", "_")]
+        if k == "net.4.conv.bias":
+            # a bias in front of a batch-statistics BatchNorm has an exactly zero gradient (sum of dd over the batch
+            # vanishes): both torch and the HIP path return rounding noise, compared on the scale of dL/d(bn bias)
+            scale = float(g["grad_net_5_bias"].abs().max())
+            assert float(grads[k].abs().max()) < 1e-4 * scale and float(want.abs().max()) < 1e-4 * scale
+            continue
+        assert _report(f"conv module dL/d[{k}]", rel_err(grads[k], want)) < GRAD_TOL, k
+        assert_close(grads[k], want, rtol=1e-3, atol_rel=2e-4, name=k)
+
+
+def test_conv_module_train_longer_sequences_vs_oracle_autograd():
+    """N = 5 sequences of L = 101 (a frequency-axis shape: 4 depthwise tiles, the last one ragged)."""
+    from cmgan_amd.training import ConvModuleTrain
+    csd = conformer_state_dict(seed=3)
+    cm = ConvModuleTrain({k: csd["conv." + k] for k in CM_ALL})
+    rng = np.random.Generator(np.random.PCG64(13))
+    x = torch.from_numpy(rng.standard_normal((5, 101, 64)).astype(np.float32))
+    dy = torch.from_numpy(rng.standard_normal((5, 101, 64)).astype(np.float32))
+    leaf = {"conv." + k: csd["conv." + k].clone().requires_grad_(True) for k in CM_KEYS}
+    xr = x.clone().requires_grad_(True)
+    with torch.enable_grad():
+        want = O.conv_module_train(leaf, "conv", xr)
+        want.backward(dy)
+    y = cm.forward(x.to(DEV), update_running_stats=False)
+    assert _report("conv module train forward [5x101]", rel_err(y, want.detach())) < GRAD_TOL
+    dx, grads = cm.backward(x.to(DEV), dy.to(DEV))
+    assert _report("conv module dL/dx [5x101]", rel_err(dx, xr.grad)) < GRAD_TOL
+    for k in CM_KEYS:
+        if k == "net.4.conv.bias":                                      # exactly zero in exact arithmetic (see above)
+            assert float(grads[k].abs().max()) < 1e-4 * float(leaf["conv.net.5.bias"].grad.abs().max())
+            continue
+        assert _report(f"conv module dL/d[{k}] [5x101]", rel_err(grads[k], leaf["conv." + k].grad)) < GRAD_TOL, k
+    dx2, grads2 = cm.backward(x.to(DEV), dy.to(DEV))                    # second backward on the same saved state:
+    assert _report("repeat backward dL/dx", rel_err(dx2, dx)) < 1e-6    # (ddn is overwritten in place, so the saved
+    with pytest.raises(RuntimeError):                                   #  forward activations must be intact)
+        cm.backward(x[:2].to(DEV), dy[:2].to(DEV))

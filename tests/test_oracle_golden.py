@@ -143,6 +143,26 @@ def test_train_mode_feed_forward_and_its_gradients(masked):
         assert rel_err(leaf["ff1." + k].grad, g[pre + k.replace(".", "_")]) < TOL, k
 
 
+CM_KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.conv.weight", "net.4.conv.bias",
+           "net.5.weight", "net.5.bias", "net.7.weight", "net.7.bias")
+
+
+def test_train_mode_conv_module_and_its_gradients():
+    """BatchNorm1d on batch statistics (+ running-stat update) and every gradient vs the reference module's autograd."""
+    g = load_golden("convmod_train.npz")
+    csd = conformer_state_dict(seed=3)
+    leaf = {"conv." + k: csd["conv." + k].clone().requires_grad_(True) for k in CM_KEYS}
+    running = {"mean": csd["conv.net.5.running_mean"].clone(), "var": csd["conv.net.5.running_var"].clone()}
+    x = g["x"].clone().requires_grad_(True)
+    with torch.enable_grad():
+        y = O.conv_module_train(leaf, "conv", x, running)
+        y.backward(g["dy"])
+    assert rel_err(y, g["y"]) < TOL and rel_err(x.grad, g["dx"]) < TOL
+    assert rel_err(running["mean"], g["running_mean"]) < 1e-6 and rel_err(running["var"], g["running_var"]) < 1e-6
+    for k in CM_KEYS:
+        assert rel_err(leaf["conv." + k].grad, g["grad_" + k.replace(".", "_")]) < TOL, k
+
+
 def test_validation_step_losses_match_the_reference(sd):
     """Generator half of Trainer.test_step: forward_generator_step + the three non-adversarial loss terms."""
     g = load_golden("valstep.npz")
