@@ -44,6 +44,11 @@ class ConvModParams(Structure):
                                         "bn_weight", "bn_bias", "pw2_weight", "pw2_bias")]
 
 
+class AttnParams(Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln_weight", "ln_bias", "to_q_weight", "to_kv_weight", "to_out_weight",
+                                        "to_out_bias", "rel_pos_emb")]
+
+
 class KernelTime(Structure):
     _fields_ = [("name", c_char_p), ("ms", c_float)]
 
@@ -69,6 +74,11 @@ SIGNATURES = {
                                             c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cmgan_convmod_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(ConvModParams),
                                              c_void_p, POINTER(ConvModParams), c_void_p, c_size_t, c_void_p]),
+    "cmgan_attn_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "cmgan_attn_train_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(AttnParams), c_void_p, c_void_p,
+                                         c_void_p, c_size_t, c_void_p]),
+    "cmgan_attn_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(AttnParams), c_void_p,
+                                          c_void_p, POINTER(AttnParams), c_void_p, c_size_t, c_void_p]),
     "cmgan_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float,
                                  c_float, c_float, c_float, c_int, c_void_p]),
     "cmgan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),

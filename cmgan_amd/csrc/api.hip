@@ -914,6 +914,46 @@ extern "C" int cmgan_convmod_train_backward(cmgan_handle* h, const float* x, con
     return check_launch(h, "convmod_train_backward");
 }
 
+extern "C" size_t cmgan_attn_train_workspace_bytes(const cmgan_handle* h, int N, int L) {
+    if (!h || N <= 0 || L <= 0 || L > attn_train_max_len()) return 0;
+    return attn_train_ws_floats(N, L) * sizeof(float);
+}
+
+static bool attn_params_ok(const cmgan_attn_params* p) {
+    return p && p->ln_weight && p->ln_bias && p->to_q_weight && p->to_kv_weight && p->to_out_weight &&
+           p->to_out_bias && p->rel_pos_emb;
+}
+static AttnTrainParams attn_params(const cmgan_attn_params* p) {
+    return AttnTrainParams{p->ln_weight, p->ln_bias, p->to_q_weight, p->to_kv_weight, p->to_out_weight, p->to_out_bias,
+                           p->rel_pos_emb};
+}
+
+extern "C" int cmgan_attn_train_forward(cmgan_handle* h, const float* x, int N, int L, const cmgan_attn_params* params,
+                                        const float* mask, float* y, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !y || N <= 0 || L <= 0 || !attn_params_ok(params))
+        return fail(h, CMGAN_E_BADARG, "cmgan_attn_train_forward: bad argument");
+    if (L > attn_train_max_len())
+        return fail(h, CMGAN_E_UNSUPPORTED, "cmgan_attn_train: sequences up to %d positions (got %d)", attn_train_max_len(), L);
+    if (int rc = check_ws(h, ws, ws_bytes, attn_train_ws_floats(N, L) * sizeof(float))) return rc;
+    launch_attn_train_forward(begin(h, stream), x, N, L, attn_params(params), h->cfg.max_pos_emb, mask, y, (float*)ws);
+    return check_launch(h, "attn_train_forward");
+}
+
+extern "C" int cmgan_attn_train_backward(cmgan_handle* h, const float* x, const float* dy, int N, int L,
+                                         const cmgan_attn_params* params, const float* mask, float* dx,
+                                         const cmgan_attn_params* grads, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !dy || !dx || N <= 0 || L <= 0 || !attn_params_ok(params) || !attn_params_ok(grads))
+        return fail(h, CMGAN_E_BADARG, "cmgan_attn_train_backward: bad argument");
+    if (L > attn_train_max_len())
+        return fail(h, CMGAN_E_UNSUPPORTED, "cmgan_attn_train: sequences up to %d positions (got %d)", attn_train_max_len(), L);
+    if (int rc = check_ws(h, ws, ws_bytes, attn_train_ws_floats(N, L) * sizeof(float))) return rc;
+    launch_attn_train_backward(begin(h, stream), x, dy, N, L, attn_params(params), h->cfg.max_pos_emb, mask, dx,
+                               attn_params(grads), (float*)ws);
+    return check_launch(h, "attn_train_backward");
+}
+
 extern "C" int cmgan_adamw_step(cmgan_handle* h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                 long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int step, void* stream) {

@@ -156,6 +156,19 @@ void launch_convmod_train_forward(LaunchCtx, const float* x, int N, int L, const
                                   float* running_mean, float* running_var, float* y, float* ws);
 void launch_convmod_train_backward(LaunchCtx, const float* x, const float* dy, int N, int L,
                                    const ConvModTrainParams& p, float* dx, const ConvModTrainParams& grad, float* ws);
+// training-mode PreNorm(Attention) forward + backward on raw parameters
+struct AttnTrainParams {
+    float *ln_w, *ln_b;       // attn.norm               LayerNorm(64)          conformer.py:68
+    float *wq, *wkv;          // attn.fn.to_q [64,64], attn.fn.to_kv [128,64]   conformer.py:81-82 (no bias)
+    float *wo, *bo;           // attn.fn.to_out [64,64], [64]                   conformer.py:83
+    float *rel;               // attn.fn.rel_pos_emb [2 max_pos + 1, 16]        conformer.py:86
+};
+size_t attn_train_ws_floats(int N, int L);
+int attn_train_max_len();
+void launch_attn_train_forward(LaunchCtx, const float* x, int N, int L, const AttnTrainParams& p, int max_pos,
+                               const float* mask, float* y, float* ws);
+void launch_attn_train_backward(LaunchCtx, const float* x, const float* dy, int N, int L, const AttnTrainParams& p,
+                                int max_pos, const float* mask, float* dx, const AttnTrainParams& grad, float* ws);
 void launch_adamw(LaunchCtx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                   float eps, float wd, int step);
 

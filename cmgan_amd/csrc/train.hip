@@ -828,3 +828,464 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     colsum(ws + pl.g1, 64, grad.ln_w);
     colsum(ws + pl.dxn, 64, grad.ln_b);
 }
+
+// =====================================================================================
+// Training-mode PreNorm(Attention) (third backward slice of SURVEY.md N2; conformer.py:54-72, 75-133):
+//   LayerNorm -> to_q / to_kv (no bias) -> per head softmax((q k^T + q E[clamp(i - j)]^T) / 4) v -> to_out + bias
+//   -> Dropout (keep-mask on the [M,64] output)
+// on contiguous sequences x [N, L, 64], L <= AT_MAX_L.  The projections are the per-token fp32-MFMA chain; the
+// attention core of THIS slice is a correctness-first row / column-parallel form (one block per (sequence, head),
+// K, V or Q, dO and the relative-position window in LDS, one thread per query row - forward, dq - or per key - dk,
+// dv - or per relative distance - dE), each recomputing the scores from q, k, E and the saved row log-sum-exp, so no
+// thread ever accumulates into another thread's output and every sum has a fixed order.  (The inference kernel of
+// conformer_x3.hip is the MFMA form; a flash-style MFMA backward is future work.)
+// =====================================================================================
+#define AT_MAX_L 512
+#define AT_P 17                       // LDS row pitch (floats) of the 16-wide per-head rows: conflict-free per-thread rows
+
+struct AtBufs {
+    float *qkv;      // [M,192]  q | k | v  (features 16 h + d inside each 64)
+    float *o;        // [M,64]   softmax(.) v, heads concatenated
+    float *lse;      // [N,4,L]  row log-sum-exp of the scaled scores
+};
+
+// LN -> [to_q ; to_kv] (A image [12][4]) -> qkv
+__global__ __launch_bounds__(256) void at_qkv_kernel(const float* __restrict__ x, long M, const float* __restrict__ wfm,
+                                                     const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                     float* __restrict__ qkv) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (t0 >= M) return;
+    f32x4 xh[4], xn[1][4];
+    float rstd;
+    long row;
+    const bool ok = cm_load_norm(x, M, t0, c, g, ln_w, ln_b, xh, xn, rstd, row);
+#pragma unroll 4
+    for (int ob = 0; ob < 12; ++ob) {
+        f32x4 acc[1] = {splat4(0.f)};
+        lin_acc<4, 1>(wfm + (long)ob * 4 * 256 + lane * 4, xn, acc);
+        if (ok) stg4(qkv + row * 192 + 16 * ob + 4 * g, acc[0]);
+    }
+}
+
+// rows of the per-head operand `which` (0 q, 1 k, 2 v; 3 = rows of a [M,64] tensor) of sequence n into LDS [L][AT_P]
+__device__ __forceinline__ void at_stage(float* lds, const float* __restrict__ src, int stride, int off, long base, int L) {
+    for (int i = threadIdx.x; i < L * 16; i += blockDim.x) {
+        const int l = i >> 4, d = i & 15;
+        lds[l * AT_P + d] = src[(base + l) * stride + off + d];
+    }
+}
+// relative-position window: row r <-> distance r - (L - 1) = i - j, table row clamp(distance, +-max_pos) + max_pos
+__device__ __forceinline__ void at_stage_rel(float* lds, const float* __restrict__ rel, int L, int max_pos) {
+    for (int i = threadIdx.x; i < (2 * L - 1) * 16; i += blockDim.x) {
+        const int r = i >> 4, d = i & 15;
+        int dist = r - (L - 1);
+        dist = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
+        lds[r * AT_P + d] = rel[(long)(dist + max_pos) * 16 + d];
+    }
+}
+__device__ __forceinline__ float at_dot16(const float (&a)[16], const float* __restrict__ b) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) s = fmaf(a[d], b[d], s);
+    return s;
+}
+
+// forward core: one block per (sequence, head), one thread per query row (two passes over the keys)
+__global__ __launch_bounds__(256) void at_core_fwd_kernel(AtBufs b, const float* __restrict__ rel, int L, int max_pos) {
+    extern __shared__ float sm[];
+    float* K = sm;                        // [L][AT_P]
+    float* V = K + L * AT_P;
+    float* E = V + L * AT_P;              // [2L-1][AT_P]
+    const int n = blockIdx.x, h = blockIdx.y;
+    const long base = (long)n * L;
+    at_stage(K, b.qkv, 192, 64 + 16 * h, base, L);
+    at_stage(V, b.qkv, 192, 128 + 16 * h, base, L);
+    at_stage_rel(E, rel, L, max_pos);
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        float q[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) q[d] = b.qkv[(base + i) * 192 + 16 * h + d] * 0.25f;     // scale = 16^-0.5
+        float m = -INFINITY;
+        for (int j = 0; j < L; ++j) m = fmaxf(m, at_dot16(q, K + j * AT_P) + at_dot16(q, E + (i - j + L - 1) * AT_P));
+        float l = 0.f, o[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) o[d] = 0.f;
+        for (int j = 0; j < L; ++j) {
+            const float p = __expf(at_dot16(q, K + j * AT_P) + at_dot16(q, E + (i - j + L - 1) * AT_P) - m);
+            l += p;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) o[d] = fmaf(p, V[j * AT_P + d], o[d]);
+        }
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int d = 0; d < 16; ++d) b.o[(base + i) * 64 + 16 * h + d] = o[d] * inv;
+        b.lse[((long)n * 4 + h) * L + i] = m + __logf(l);
+    }
+}
+
+// y = mask * (Wo O + bo)
+__global__ __launch_bounds__(256) void at_out_kernel(const float* __restrict__ o, long M, const float* __restrict__ wofm,
+                                                     const float* __restrict__ bo, const float* __restrict__ mask,
+                                                     float* __restrict__ y) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (t0 >= M) return;
+    const long t = t0 + c;
+    const bool ok = t < M;
+    const long row = ok ? t : M - 1;
+    f32x4 of[1][4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) of[0][kb] = ldg4(o + row * 64 + 16 * kb + 4 * g);
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+        f32x4 acc[1] = {ldg4(bo + 16 * ob + 4 * g)};
+        lin_acc<4, 1>(wofm + (long)ob * 4 * 256 + lane * 4, of, acc);
+        if (mask) acc[0] = acc[0] * ldg4(mask + row * 64 + 16 * ob + 4 * g);
+        if (ok) stg4(y + row * 64 + 16 * ob + 4 * g, acc[0]);
+    }
+}
+
+// backward of to_out: dout = mask dy (kept for dWo / dbo), dO = Wo^T dout, D[token][head] = sum_d dO O
+__global__ __launch_bounds__(256) void at_out_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ mask,
+                                                         const float* __restrict__ o, long M,
+                                                         const float* __restrict__ wotfm, float* __restrict__ dout,
+                                                         float* __restrict__ dO, float* __restrict__ D) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (t0 >= M) return;
+    const long t = t0 + c;
+    const bool ok = t < M;
+    const long row = ok ? t : M - 1;
+    f32x4 dyf[1][4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+        f32x4 v = ldg4(dy + row * 64 + 16 * ob + 4 * g);
+        if (mask) v = v * ldg4(mask + row * 64 + 16 * ob + 4 * g);
+        dyf[0][ob] = v;
+        if (ok) stg4(dout + row * 64 + 16 * ob + 4 * g, v);
+    }
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {                       // feature block hb = head hb
+        f32x4 acc[1] = {splat4(0.f)};
+        lin_acc<4, 1>(wotfm + (long)hb * 4 * 256 + lane * 4, dyf, acc);
+        const f32x4 ov = ldg4(o + row * 64 + 16 * hb + 4 * g);
+        float part = acc[0][0] * ov[0] + acc[0][1] * ov[1] + acc[0][2] * ov[2] + acc[0][3] * ov[3];
+        part = red_g_sum(part);
+        if (ok) {
+            stg4(dO + row * 64 + 16 * hb + 4 * g, acc[0]);
+            if (g == 0) D[row * 4 + hb] = part;
+        }
+    }
+}
+
+// p_ij and ds_ij of one (query i, key j) pair from staged operands; scores are recomputed, never stored
+struct AtPair { float p, ds; };
+__device__ __forceinline__ AtPair at_pair(const float (&qs)[16], const float* __restrict__ kj, const float* __restrict__ er,
+                                          const float (&dOi)[16], const float* __restrict__ vj, float lse, float Di) {
+    const float s = at_dot16(qs, kj) + at_dot16(qs, er);            // qs = q * scale
+    AtPair r;
+    r.p = __expf(s - lse);
+    r.ds = r.p * (at_dot16(dOi, vj) - Di);
+    return r;
+}
+
+// dq: thread per query row                      dq_i = scale * sum_j ds_ij (k_j + E[i - j])
+__global__ __launch_bounds__(256) void at_core_bwd_dq_kernel(AtBufs b, const float* __restrict__ rel,
+                                                             const float* __restrict__ dO, const float* __restrict__ D,
+                                                             int L, int max_pos, float* __restrict__ dqkv) {
+    extern __shared__ float sm[];
+    float* K = sm;
+    float* V = K + L * AT_P;
+    float* E = V + L * AT_P;
+    const int n = blockIdx.x, h = blockIdx.y;
+    const long base = (long)n * L;
+    at_stage(K, b.qkv, 192, 64 + 16 * h, base, L);
+    at_stage(V, b.qkv, 192, 128 + 16 * h, base, L);
+    at_stage_rel(E, rel, L, max_pos);
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        float qs[16], dOi[16], dq[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            qs[d] = b.qkv[(base + i) * 192 + 16 * h + d] * 0.25f;
+            dOi[d] = dO[(base + i) * 64 + 16 * h + d];
+            dq[d] = 0.f;
+        }
+        const float lse = b.lse[((long)n * 4 + h) * L + i], Di = D[(base + i) * 4 + h];
+        for (int j = 0; j < L; ++j) {
+            const float* er = E + (i - j + L - 1) * AT_P;
+            const AtPair pr = at_pair(qs, K + j * AT_P, er, dOi, V + j * AT_P, lse, Di);
+#pragma unroll
+            for (int d = 0; d < 16; ++d) dq[d] = fmaf(pr.ds, K[j * AT_P + d] + er[d], dq[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < 16; ++d) dqkv[(base + i) * 192 + 16 * h + d] = dq[d] * 0.25f;
+    }
+}
+
+// dk, dv: thread per key                        dk_j = scale * sum_i ds_ij q_i,  dv_j = sum_i p_ij dO_i
+__global__ __launch_bounds__(256) void at_core_bwd_dkv_kernel(AtBufs b, const float* __restrict__ rel,
+                                                              const float* __restrict__ dO, const float* __restrict__ D,
+                                                              int L, int max_pos, float* __restrict__ dqkv) {
+    extern __shared__ float sm[];
+    float* Q = sm;                         // q * scale
+    float* G = Q + L * AT_P;               // dO
+    float* E = G + L * AT_P;
+    float* lse = E + (2 * L - 1) * AT_P;
+    float* Dl = lse + L;
+    const int n = blockIdx.x, h = blockIdx.y;
+    const long base = (long)n * L;
+    at_stage(Q, b.qkv, 192, 16 * h, base, L);
+    at_stage(G, dO, 64, 16 * h, base, L);
+    at_stage_rel(E, rel, L, max_pos);
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        lse[i] = b.lse[((long)n * 4 + h) * L + i];
+        Dl[i] = D[(base + i) * 4 + h];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * 16; i += blockDim.x) Q[(i >> 4) * AT_P + (i & 15)] *= 0.25f;
+    __syncthreads();
+    for (int j = threadIdx.x; j < L; j += blockDim.x) {
+        float kj[16], vj[16], dk[16], dv[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            kj[d] = b.qkv[(base + j) * 192 + 64 + 16 * h + d];
+            vj[d] = b.qkv[(base + j) * 192 + 128 + 16 * h + d];
+            dk[d] = 0.f; dv[d] = 0.f;
+        }
+        for (int i = 0; i < L; ++i) {
+            float qs[16], dOi[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) { qs[d] = Q[i * AT_P + d]; dOi[d] = G[i * AT_P + d]; }
+            const AtPair pr = at_pair(qs, kj, E + (i - j + L - 1) * AT_P, dOi, vj, lse[i], Dl[i]);
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                dk[d] = fmaf(pr.ds, qs[d], dk[d]);            // qs already carries one factor of scale
+                dv[d] = fmaf(pr.p, dOi[d], dv[d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 16; ++d) {
+            dqkv[(base + j) * 192 + 64 + 16 * h + d] = dk[d];
+            dqkv[(base + j) * 192 + 128 + 16 * h + d] = dv[d];
+        }
+    }
+}
+
+// dE window: thread per relative distance       dEwin[r] = scale * sum_{i - j = r - (L-1)} ds_ij q_i  -> partial [(n,h)][2L-1][16]
+__global__ __launch_bounds__(256) void at_core_bwd_de_kernel(AtBufs b, const float* __restrict__ rel,
+                                                             const float* __restrict__ dO, const float* __restrict__ D,
+                                                             int L, int max_pos, float* __restrict__ partial) {
+    extern __shared__ float sm[];
+    float* Q = sm;                         // q * scale
+    float* G = Q + L * AT_P;
+    float* K = G + L * AT_P;
+    float* V = K + L * AT_P;
+    float* lse = V + L * AT_P;
+    float* Dl = lse + L;
+    const int n = blockIdx.x, h = blockIdx.y;
+    const long base = (long)n * L;
+    at_stage(Q, b.qkv, 192, 16 * h, base, L);
+    at_stage(K, b.qkv, 192, 64 + 16 * h, base, L);
+    at_stage(V, b.qkv, 192, 128 + 16 * h, base, L);
+    at_stage(G, dO, 64, 16 * h, base, L);
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        lse[i] = b.lse[((long)n * 4 + h) * L + i];
+        Dl[i] = D[(base + i) * 4 + h];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L * 16; i += blockDim.x) Q[(i >> 4) * AT_P + (i & 15)] *= 0.25f;
+    __syncthreads();
+    for (int r = threadIdx.x; r < 2 * L - 1; r += blockDim.x) {
+        const int dist = r - (L - 1);
+        int e = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
+        float er[16], acc[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) { er[d] = rel[(long)(e + max_pos) * 16 + d]; acc[d] = 0.f; }
+        const int i0 = dist > 0 ? dist : 0, i1 = dist > 0 ? L : L + dist;     // j = i - dist in [0, L)
+        for (int i = i0; i < i1; ++i) {
+            const int j = i - dist;
+            float qs[16], dOi[16];
+#pragma unroll
+            for (int d = 0; d < 16; ++d) { qs[d] = Q[i * AT_P + d]; dOi[d] = G[i * AT_P + d]; }
+            const AtPair pr = at_pair(qs, K + j * AT_P, er, dOi, V + j * AT_P, lse[i], Dl[i]);
+#pragma unroll
+            for (int d = 0; d < 16; ++d) acc[d] = fmaf(pr.ds, qs[d], acc[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < 16; ++d) partial[(((long)n * 4 + h) * (2 * L - 1) + r) * 16 + d] = acc[d];
+    }
+}
+
+// rel_pos_emb gradient [2 max_pos + 1][16]: row e sums, in (n, h) then distance order, every window row that maps to it
+__global__ void at_de_scatter_kernel(const float* __restrict__ partial, int NH, int L, int max_pos,
+                                     float* __restrict__ drel) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int rows = 2 * max_pos + 1;
+    if (idx >= rows * 16) return;
+    const int e = idx >> 4, d = idx & 15;
+    const int dist = e - max_pos;
+    // window rows r (distance r - (L-1)) whose clamped distance is `dist`
+    int r0 = dist + (L - 1), r1 = r0;
+    if (dist == -max_pos) r0 = 0;                          // every distance <= -max_pos
+    if (dist == max_pos) r1 = 2 * L - 2;                   // every distance >= +max_pos
+    float s = 0.f;
+    if (r1 >= 0 && r0 <= 2 * L - 2) {
+        r0 = r0 < 0 ? 0 : r0;
+        r1 = r1 > 2 * L - 2 ? 2 * L - 2 : r1;
+        for (int nh = 0; nh < NH; ++nh)
+            for (int r = r0; r <= r1; ++r) s += partial[((long)nh * (2 * L - 1) + r) * 16 + d];
+    }
+    drel[idx] = s;
+}
+
+// backward of the projections: dxn = [to_q ; to_kv]^T dqkv (A image [4][12]), LayerNorm backward
+__global__ __launch_bounds__(256) void at_qkv_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dqkv, long M,
+                                                         const float* __restrict__ wtfm, const float* __restrict__ ln_w,
+                                                         const float* __restrict__ ln_b, float* __restrict__ dx,
+                                                         float* __restrict__ xn_out, float* __restrict__ g1,
+                                                         float* __restrict__ dxn_out) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (t0 >= M) return;
+    f32x4 xh[4], xn[1][4];
+    float rstd;
+    long row;
+    const bool ok = cm_load_norm(x, M, t0, c, g, ln_w, ln_b, xh, xn, rstd, row);
+    f32x4 df[1][12];
+#pragma unroll
+    for (int kb = 0; kb < 12; ++kb) {
+        df[0][kb] = ldg4(dqkv + row * 192 + 16 * kb + 4 * g);
+        if (!ok) df[0][kb] = splat4(0.f);
+    }
+    f32x4 dxn[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        f32x4 acc[1] = {splat4(0.f)};
+        lin_acc<12, 1>(wtfm + (long)rb * 12 * 256 + lane * 4, df, acc);
+        dxn[rb] = acc[0];
+    }
+    f32x4 dxh[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        dxh[kb] = dxn[kb] * ldg4(ln_w + 16 * kb + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s1 += dxh[kb][r];
+            s2 = fmaf(dxh[kb][r], xh[kb][r], s2);
+        }
+    }
+    const float mu1 = red_g_sum(s1) * (1.0f / 64.0f), mu2 = red_g_sum(s2) * (1.0f / 64.0f);
+    if (ok) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            stg4(dx + row * 64 + 16 * kb + 4 * g, (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd));
+            stg4(xn_out + row * 64 + 16 * kb + 4 * g, xn[0][kb]);
+            stg4(g1 + row * 64 + 16 * kb + 4 * g, dxn[kb] * xh[kb]);
+            stg4(dxn_out + row * 64 + 16 * kb + 4 * g, dxn[kb]);
+        }
+    }
+}
+
+// dynamic LDS above the 64 KB default needs an explicit opt-in per kernel
+template <class KernelT>
+static void at_allow_lds(KernelT kernel, size_t bytes) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+struct AtPlan { size_t raw, wqkv, wqkvt, wo, wot, qkv, o, lse, dout, dO, D, dqkv, xn, g1, dxn, depart, wpart, cpart, total; };
+static AtPlan at_plan(int N, int L) {
+    AtPlan p;
+    const size_t M = (size_t)N * L;
+    size_t cur = 0;
+    auto take = [&](size_t n) { const size_t o = cur; cur += (n + 63) & ~(size_t)63; return o; };
+    p.raw = take(12288); p.wqkv = take(12288); p.wqkvt = take(12288); p.wo = take(4096); p.wot = take(4096);
+    p.qkv = take(M * 192); p.o = take(M * 64); p.lse = take((size_t)N * 4 * L);
+    p.dout = take(M * 64); p.dO = take(M * 64); p.D = take(M * 4); p.dqkv = take(M * 192);
+    p.xn = take(M * 64); p.g1 = take(M * 64); p.dxn = take(M * 64);
+    p.depart = take((size_t)N * 4 * (2 * L - 1) * 16);
+    p.wpart = take((size_t)FFN_WGRAD_SPLIT * 12288);
+    p.cpart = take((size_t)FFN_COLSUM_BLOCKS * 256);
+    p.total = cur;
+    return p;
+}
+size_t attn_train_ws_floats(int N, int L) { return at_plan(N, L).total; }
+int attn_train_max_len() { return AT_MAX_L; }
+
+static void at_pack_images(LaunchCtx ctx, const AttnTrainParams& p, float* ws, const AtPlan& pl) {
+    hipStream_t s = ctx.stream;
+    hipMemcpyAsync(ws + pl.raw, p.wq, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);            // rows 0..63
+    hipMemcpyAsync(ws + pl.raw + 4096, p.wkv, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);    // rows 64..191
+    LAUNCH(ctx, "attn_train_pack", (pack_fm_kernel<<<48, 256, 0, s>>>(ws + pl.raw, 192, 64, 64, 0, ws + pl.wqkv)));
+    LAUNCH(ctx, "attn_train_pack", (pack_fm_kernel<<<48, 256, 0, s>>>(ws + pl.raw, 64, 192, 64, 1, ws + pl.wqkvt)));
+    LAUNCH(ctx, "attn_train_pack", (pack_fm_kernel<<<16, 256, 0, s>>>(p.wo, 64, 64, 64, 0, ws + pl.wo)));
+    LAUNCH(ctx, "attn_train_pack", (pack_fm_kernel<<<16, 256, 0, s>>>(p.wo, 64, 64, 64, 1, ws + pl.wot)));
+}
+
+void launch_attn_train_forward(LaunchCtx ctx, const float* x, int N, int L, const AttnTrainParams& p, int max_pos,
+                               const float* mask, float* y, float* ws) {
+    hipStream_t s = ctx.stream;
+    const AtPlan pl = at_plan(N, L);
+    const long M = (long)N * L;
+    at_pack_images(ctx, p, ws, pl);
+    const AtBufs b{ws + pl.qkv, ws + pl.o, ws + pl.lse};
+    const unsigned grid = (unsigned)((M + 63) / 64);
+    LAUNCH(ctx, "attn_train_fwd", (at_qkv_kernel<<<grid, 256, 0, s>>>(x, M, ws + pl.wqkv, p.ln_w, p.ln_b, b.qkv)));
+    const size_t shm = ((size_t)2 * L * AT_P + (size_t)(2 * L - 1) * AT_P) * sizeof(float);
+    at_allow_lds(at_core_fwd_kernel, shm);
+    LAUNCH(ctx, "attn_train_fwd", (at_core_fwd_kernel<<<dim3(N, 4), 256, shm, s>>>(b, p.rel, L, max_pos)));
+    LAUNCH(ctx, "attn_train_fwd", (at_out_kernel<<<grid, 256, 0, s>>>(b.o, M, ws + pl.wo, p.bo, mask, y)));
+}
+
+void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, int N, int L, const AttnTrainParams& p,
+                                int max_pos, const float* mask, float* dx, const AttnTrainParams& grad, float* ws) {
+    hipStream_t s = ctx.stream;
+    const AtPlan pl = at_plan(N, L);
+    const long M = (long)N * L;
+    at_pack_images(ctx, p, ws, pl);
+    const AtBufs b{ws + pl.qkv, ws + pl.o, ws + pl.lse};
+    const unsigned grid = (unsigned)((M + 63) / 64);
+    float* cpart = ws + pl.cpart;
+    auto colsum = [&](const float* X, int C, float* out) {
+        LAUNCH(ctx, "attn_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(X, M, C, cpart)));
+        LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<1, 256, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, C, out)));
+    };
+    LAUNCH(ctx, "attn_train_bwd", (at_out_bwd_kernel<<<grid, 256, 0, s>>>(dy, mask, b.o, M, ws + pl.wot, ws + pl.dout,
+                                                                          ws + pl.dO, ws + pl.D)));
+    // to_out gradients: dWo [64,64] = dout^T O, dbo = colsum dout
+    LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial_kernel<<<dim3(4, 1, FFN_WGRAD_SPLIT), 256, 0, s>>>(
+                                        ws + pl.dout, b.o, M, 64, 64, FFN_WGRAD_SPLIT, ws + pl.wpart)));
+    LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<16, 256, 0, s>>>(ws + pl.wpart, FFN_WGRAD_SPLIT, 4096,
+                                                                                grad.wo)));
+    colsum(ws + pl.dout, 64, grad.bo);
+    // attention core: dq (rows), dk / dv (columns), dE (distances)
+    const size_t shm_q = ((size_t)2 * L * AT_P + (size_t)(2 * L - 1) * AT_P) * sizeof(float);
+    const size_t shm_kv = shm_q + (size_t)2 * L * sizeof(float);
+    const size_t shm_e = ((size_t)4 * L * AT_P + 2 * L) * sizeof(float);
+    at_allow_lds(at_core_bwd_dq_kernel, shm_q);
+    at_allow_lds(at_core_bwd_dkv_kernel, shm_kv);
+    at_allow_lds(at_core_bwd_de_kernel, shm_e);
+    LAUNCH(ctx, "attn_train_bwd", (at_core_bwd_dq_kernel<<<dim3(N, 4), 256, shm_q, s>>>(b, p.rel, ws + pl.dO, ws + pl.D, L,
+                                                                                       max_pos, ws + pl.dqkv)));
+    LAUNCH(ctx, "attn_train_bwd", (at_core_bwd_dkv_kernel<<<dim3(N, 4), 256, shm_kv, s>>>(b, p.rel, ws + pl.dO, ws + pl.D, L,
+                                                                                         max_pos, ws + pl.dqkv)));
+    LAUNCH(ctx, "attn_train_bwd", (at_core_bwd_de_kernel<<<dim3(N, 4), 256, shm_e, s>>>(b, p.rel, ws + pl.dO, ws + pl.D, L,
+                                                                                       max_pos, ws + pl.depart)));
+    const int rel_elems = (2 * max_pos + 1) * 16;
+    LAUNCH(ctx, "attn_train_reduce", (at_de_scatter_kernel<<<(rel_elems + 255) / 256, 256, 0, s>>>(ws + pl.depart, N * 4, L,
+                                                                                                  max_pos, grad.rel)));
+    // projections + LayerNorm
+    LAUNCH(ctx, "attn_train_bwd", (at_qkv_bwd_kernel<<<grid, 256, 0, s>>>(x, ws + pl.dqkv, M, ws + pl.wqkvt, p.ln_w, p.ln_b,
+                                                                          dx, ws + pl.xn, ws + pl.g1, ws + pl.dxn)));
+    LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial_kernel<<<dim3(12, 1, FFN_WGRAD_SPLIT), 256, 0, s>>>(
+                                        ws + pl.dqkv, ws + pl.xn, M, 192, 64, FFN_WGRAD_SPLIT, ws + pl.wpart)));
+    LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<48, 256, 0, s>>>(ws + pl.wpart, FFN_WGRAD_SPLIT, 12288,
+                                                                                ws + pl.raw)));      // [192,64], then split
+    hipMemcpyAsync(grad.wq, ws + pl.raw, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    hipMemcpyAsync(grad.wkv, ws + pl.raw + 4096, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    colsum(ws + pl.g1, 64, grad.ln_w);
+    colsum(ws + pl.dxn, 64, grad.ln_b);
+}

@@ -10,6 +10,9 @@
 * `AdamW`, `step_lr`       - torch.optim.AdamW (train.py:63-66) as one HIP launch over a flat parameter bucket, and the
                              StepLR(30, 0.5) schedule (train.py:248-253); `FeedForwardTrain.allreduce_gradients()` is
                              the data-parallel gradient mean as ONE all-reduce over the same bucket (train.py:192).
+* `AttentionTrain`         - PreNorm(Attention) (conformer.py:54-72, 75-133) in TRAIN mode: Shaw relative-position
+                             attention with the output Dropout as a keep-mask, forward + full backward incl. the
+                             relative-position embedding gradient.
 * `ConvModuleTrain`        - the ConformerConvModule (conformer.py:151-176) in TRAIN mode: BatchNorm1d on batch
                              statistics with running-stat update, forward + full backward (ten parameter gradients).
 * `FeedForwardTrain`       - a ConformerBlock's `Scale(0.5, PreNorm(dim, FeedForward(dim, mult=4, dropout)))` branch
@@ -27,11 +30,11 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from ._lib import ConvModParams, FfnParams, check
+from ._lib import AttnParams, ConvModParams, FfnParams, check
 from .dist import FlatBucket, allreduce_mean
 from .engine import Engine
 
-__all__ = ["FeedForwardTrain", "ConvModuleTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
+__all__ = ["FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
            "validation_step"]
 
 _KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.net.0.weight", "fn.fn.net.0.bias",
@@ -273,6 +276,87 @@ class ConvModuleTrain:
             check(eng._h, eng.lib.cmgan_convmod_train_backward(eng._h, x.data_ptr(), dy.data_ptr(), N, L, ctypes.byref(p),
                                                                dx.data_ptr(), ctypes.byref(g), ws.data_ptr(),
                                                                ws.numel(), eng._stream()))
+        return dx, self.grads
+
+    def allreduce_gradients(self) -> torch.Tensor:
+        return allreduce_mean(self.grad_bucket.flat)
+
+
+_AT_KEYS = ("norm.weight", "norm.bias", "fn.to_q.weight", "fn.to_kv.weight", "fn.to_out.weight", "fn.to_out.bias",
+            "fn.rel_pos_emb.weight")
+_AT_FIELDS = ("ln_weight", "ln_bias", "to_q_weight", "to_kv_weight", "to_out_weight", "to_out_bias", "rel_pos_emb")
+
+
+class AttentionTrain:
+    """`attn` branch (PreNorm + Attention) of one ConformerBlock in train mode on the HIP kernels (csrc/train.hip).
+    `state` holds the branch's tensors under the reference's key names relative to `attn.`.  Sequences of up to 512
+    positions; `backward` must follow the `forward` of the same x (it reads q|k|v, O and the row log-sum-exp)."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], dropout: float = 0.2, engine: Optional[Engine] = None,
+                 device=None):
+        self.engine = engine if engine is not None else Engine(device=device)
+        self.p = float(dropout)
+        dev = self.engine.device
+        rows = 2 * self.engine.cfg.max_pos_emb + 1
+        shapes = {"norm.weight": (64,), "norm.bias": (64,), "fn.to_q.weight": (64, 64), "fn.to_kv.weight": (128, 64),
+                  "fn.to_out.weight": (64, 64), "fn.to_out.bias": (64,), "fn.rel_pos_emb.weight": (rows, 16)}
+        for key, shape in shapes.items():
+            if tuple(state[key].shape) != shape:
+                raise ValueError(f"{key}: shape {tuple(state[key].shape)}, expected {shape}")
+        self.param_bucket = FlatBucket(shapes, dev).load({k: state[k].detach().to(dev, torch.float32) for k in _AT_KEYS})
+        self.grad_bucket = FlatBucket(shapes, dev)
+        self.params, self.grads = self.param_bucket.views, self.grad_bucket.views
+        self._ws: Optional[torch.Tensor] = None
+        self._shape = None
+
+    def _struct(self, tensors) -> AttnParams:
+        s = AttnParams()
+        for key, field in zip(_AT_KEYS, _AT_FIELDS):
+            setattr(s, field, tensors[key].data_ptr())
+        return s
+
+    def _workspace(self, N: int, L: int) -> torch.Tensor:
+        need = self.engine.lib.cmgan_attn_train_workspace_bytes(self.engine._h, N, L)
+        if need == 0:
+            raise ValueError(f"unsupported attention shape N={N}, L={L} (L <= 512)")
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.engine.device)
+        return self._ws
+
+    def mask(self, N: int, L: int, generator: Optional[torch.Generator] = None):
+        return dropout_mask((N, L, 64), self.p, self.engine.device, generator)
+
+    def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        eng = self.engine
+        x = eng._in(x, "x")
+        N, L, C = x.shape
+        if C != 64:
+            raise ValueError("conformer dim must be 64")
+        m = eng._in(mask.reshape(N, L, 64), "mask") if mask is not None else None
+        ws = self._workspace(N, L)
+        y = torch.empty_like(x)
+        p = self._struct(self.params)
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_attn_train_forward(eng._h, x.data_ptr(), N, L, ctypes.byref(p),
+                                                           m.data_ptr() if m is not None else None, y.data_ptr(),
+                                                           ws.data_ptr(), ws.numel(), eng._stream()))
+        self._shape = (N, L)
+        return y
+
+    def backward(self, x: torch.Tensor, dy: torch.Tensor, mask: Optional[torch.Tensor] = None):
+        eng = self.engine
+        x, dy = eng._in(x, "x"), eng._in(dy, "dy")
+        N, L, _ = x.shape
+        if self._shape != (N, L) or dy.shape != x.shape:
+            raise RuntimeError("backward() needs the forward() of the same [N, L, 64] input first")
+        m = eng._in(mask.reshape(N, L, 64), "mask") if mask is not None else None
+        ws = self._workspace(N, L)
+        dx = torch.empty_like(x)
+        p, g = self._struct(self.params), self._struct(self.grads)
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_attn_train_backward(eng._h, x.data_ptr(), dy.data_ptr(), N, L, ctypes.byref(p),
+                                                            m.data_ptr() if m is not None else None, dx.data_ptr(),
+                                                            ctypes.byref(g), ws.data_ptr(), ws.numel(), eng._stream()))
         return dx, self.grads
 
     def allreduce_gradients(self) -> torch.Tensor:

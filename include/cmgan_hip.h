@@ -195,6 +195,27 @@ int cmgan_convmod_train_backward(cmgan_handle* h, const float* x_dev, const floa
                                  const cmgan_convmod_params* grads,
                                  void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Training-mode PreNorm(Attention) with its backward - third slice of the training step:
+ *   y = mask * to_out(softmax((q k^T + q E[clamp(i - j, +-max_pos)]^T) / 4) v),  q = to_q(LN(x)), k|v = to_kv(LN(x))
+ * (src/models/conformer.py:54-72, 75-133; 4 heads of 16; the residual add of :218 stays with the caller).  `mask`
+ * [N,L,64] is the keep-mask of the nn.Dropout on the to_out output (conformer.py:133; NULL = none).  Parameters are
+ * the RAW tensors attn.norm.{weight,bias}, attn.fn.to_q.weight [64,64], attn.fn.to_kv.weight [128,64],
+ * attn.fn.to_out.{weight [64,64], bias}, attn.fn.rel_pos_emb.weight [2 max_pos + 1, 16].  L <= 512 in this slice
+ * (CMGAN_E_UNSUPPORTED beyond).  The forward keeps q|k|v, the attention output and the row log-sum-exp in the
+ * workspace; the backward needs the SAME workspace untouched and writes dL/dx and the seven parameter gradients
+ * (the embedding-table gradient is dense [2 max_pos + 1, 16], rows of unused distances are zero).                 */
+typedef struct cmgan_attn_params {
+    float *ln_weight, *ln_bias, *to_q_weight, *to_kv_weight, *to_out_weight, *to_out_bias, *rel_pos_emb;
+} cmgan_attn_params;
+size_t cmgan_attn_train_workspace_bytes(const cmgan_handle* h, int N, int L);
+int cmgan_attn_train_forward(cmgan_handle* h, const float* x_dev, int N, int L, const cmgan_attn_params* params,
+                             const float* mask_dev, float* y_dev,
+                             void* workspace_dev, size_t workspace_bytes, void* stream);
+int cmgan_attn_train_backward(cmgan_handle* h, const float* x_dev, const float* dy_dev, int N, int L,
+                              const cmgan_attn_params* params, const float* mask_dev, float* dx_dev,
+                              const cmgan_attn_params* grads,
+                              void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* One torch.optim.AdamW step (src/train.py:63-66, 192-193; defaults betas (0.9, 0.999), eps 1e-8, weight_decay
  * 0.01) over a FLAT fp32 bucket of n parameters: params, grads and the two moment buffers are parallel device
  * arrays (the bucket the gradient all-reduce runs over), `step` = 1, 2, ... is the update count for the bias

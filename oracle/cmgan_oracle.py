@@ -135,6 +135,15 @@ def attention(sd, p, x, heads: int = 4, max_pos: int = 512):
     return F.linear(out, sd[p + ".fn.to_out.weight"], sd[p + ".fn.to_out.bias"])
 
 
+def attention_train(sd, p, x, mask=None, heads: int = 4, max_pos: int = 512):
+    """PreNorm(dim, Attention) in TRAIN mode (conformer.py:54-72, 100-133): identical to `layer_norm` + `attention`
+    except for the nn.Dropout on the to_out output (conformer.py:133), given as a keep-mask [N, L, 64] (None = no
+    dropout).  Differentiable: autograd through it is the gradient oracle of cmgan_amd.training.AttentionTrain.
+    `p` is the branch prefix, e.g. "attn" (keys p + ".norm.weight", p + ".fn.to_q.weight", ...)."""
+    out = attention(sd, p, x, heads, max_pos)                  # includes the PreNorm LayerNorm
+    return out * mask if mask is not None else out
+
+
 def conv_module(sd, p, x, kernel: int = 31):
     """ConformerConvModule, eval mode (conformer.py:151-176, 30-48)."""
     h = layer_norm(sd, p + ".net.0", x).transpose(1, 2)                    # b c n

@@ -248,6 +248,24 @@ def main():
     save("convmod_train.npz", x=xc.detach(), dy=dyc, y=yc.detach(), dx=xc.grad.detach(),
          running_mean=bn.running_mean.detach().clone(), running_var=bn.running_var.detach().clone(), **cgr)
 
+    # -- 12. PreNorm(Attention) in TRAIN mode: Shaw relative-position attention with nn.Dropout on the to_out output
+    #        (conformer.py:100-133, 54-72) as an explicit keep-mask; gradients of x and of every parameter incl. the
+    #        relative-position embedding table
+    with torch.enable_grad():
+        blk_a = ConformerBlock(dim=64, dim_head=16, heads=4, conv_kernel_size=31, attn_dropout=0.2, ff_dropout=0.2)
+        blk_a.load_state_dict(csd, strict=True)
+        blk_a.train()
+        at = blk_a.attn
+        gen_a = torch.Generator().manual_seed(19)
+        ma = (torch.rand(3, 37, 64, generator=gen_a) >= 0.2).float() / 0.8
+        at.fn.dropout = _Mask(ma)
+        xa = rnd((3, 37, 64), 41).requires_grad_(True)
+        dya = rnd((3, 37, 64), 42)
+        ya = at(xa)
+        ya.backward(dya)
+        agr = {"grad_" + k.replace(".", "_"): v.grad.detach() for k, v in at.named_parameters()}
+    save("attn_train.npz", x=xa.detach(), dy=dya, mask=ma, y=ya.detach(), dx=xa.grad.detach(), **agr)
+
     save("ffn_train.npz", x=xt.detach(), dy=dy, mask1=m1, mask2=m2, y=yt.detach(), dx=xt.grad.detach(),
          y_nomask=y0.detach(), dx_nomask=x0.grad.detach(), **grads, **grads0)
 

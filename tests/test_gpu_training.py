@@ -234,3 +234,49 @@ def test_conv_module_train_longer_sequences_vs_oracle_autograd():
     assert _report("repeat backward dL/dx", rel_err(dx2, dx)) < 1e-6    # (ddn is overwritten in place, so the saved
     with pytest.raises(RuntimeError):                                   #  forward activations must be intact)
         cm.backward(x[:2].to(DEV), dy[:2].to(DEV))
+
+
+AT_KEYS = ("norm.weight", "norm.bias", "fn.to_q.weight", "fn.to_kv.weight", "fn.to_out.weight", "fn.to_out.bias",
+           "fn.rel_pos_emb.weight")
+
+
+def test_attention_train_matches_reference_autograd():
+    """PreNorm(Attention) in TRAIN mode (Shaw relative positions, dropout keep-mask on the to_out output): forward,
+    dL/dx and all seven parameter gradients incl. the embedding table vs the reference module's torch autograd."""
+    from cmgan_amd.training import AttentionTrain
+    g = load_golden("attn_train.npz")
+    csd = conformer_state_dict(seed=3)
+    at = AttentionTrain({k: csd["attn." + k] for k in AT_KEYS})
+    y = at.forward(g["x"].to(DEV), g["mask"].to(DEV))
+    assert _report("attention train forward", rel_err(y, g["y"])) < GRAD_TOL
+    dx, grads = at.backward(g["x"].to(DEV), g["dy"].to(DEV), g["mask"].to(DEV))
+    assert _report("attention dL/dx", rel_err(dx, g["dx"])) < GRAD_TOL
+    for k in AT_KEYS:
+        want = g["grad_" + k.replace(".", "_")]
+        assert _report(f"attention dL/d[{k}]", rel_err(grads[k], want)) < GRAD_TOL, k
+        assert_close(grads[k], want, rtol=1e-3, atol_rel=2e-4, name=k)
+
+
+@pytest.mark.parametrize("n,l", [(2, 321), (3, 101)])
+def test_attention_train_full_length_sequences_vs_oracle_autograd(n, l):
+    """the two sequence lengths of the 2 s training clip (time axis T = 321: 87 KB of LDS per block; frequency axis
+    F' = 101), no dropout."""
+    from cmgan_amd.training import AttentionTrain
+    csd = conformer_state_dict(seed=3)
+    at = AttentionTrain({k: csd["attn." + k] for k in AT_KEYS})
+    rng = np.random.Generator(np.random.PCG64(17 + l))
+    x = torch.from_numpy(rng.standard_normal((n, l, 64)).astype(np.float32))
+    dy = torch.from_numpy(rng.standard_normal((n, l, 64)).astype(np.float32))
+    leaf = {"attn." + k: csd["attn." + k].clone().requires_grad_(True) for k in AT_KEYS}
+    xr = x.clone().requires_grad_(True)
+    with torch.enable_grad():
+        want = O.attention_train(leaf, "attn", xr)
+        want.backward(dy)
+    y = at.forward(x.to(DEV))
+    assert _report(f"attention train forward [{n}x{l}]", rel_err(y, want.detach())) < GRAD_TOL
+    dx, grads = at.backward(x.to(DEV), dy.to(DEV))
+    assert _report(f"attention dL/dx [{n}x{l}]", rel_err(dx, xr.grad)) < GRAD_TOL
+    for k in AT_KEYS:
+        assert _report(f"attention dL/d[{k}] [{n}x{l}]", rel_err(grads[k], leaf["attn." + k].grad)) < GRAD_TOL, k
+    with pytest.raises(ValueError):
+        at.forward(torch.zeros(1, 600, 64, device=DEV))

@@ -163,6 +163,23 @@ def test_train_mode_conv_module_and_its_gradients():
         assert rel_err(leaf["conv." + k].grad, g["grad_" + k.replace(".", "_")]) < TOL, k
 
 
+AT_KEYS = ("norm.weight", "norm.bias", "fn.to_q.weight", "fn.to_kv.weight", "fn.to_out.weight", "fn.to_out.bias",
+           "fn.rel_pos_emb.weight")
+
+
+def test_train_mode_attention_and_its_gradients():
+    g = load_golden("attn_train.npz")
+    csd = conformer_state_dict(seed=3)
+    leaf = {"attn." + k: csd["attn." + k].clone().requires_grad_(True) for k in AT_KEYS}
+    x = g["x"].clone().requires_grad_(True)
+    with torch.enable_grad():
+        y = O.attention_train(leaf, "attn", x, g["mask"])
+        y.backward(g["dy"])
+    assert rel_err(y, g["y"]) < TOL and rel_err(x.grad, g["dx"]) < TOL
+    for k in AT_KEYS:
+        assert rel_err(leaf["attn." + k].grad, g["grad_" + k.replace(".", "_")]) < TOL, k
+
+
 def test_validation_step_losses_match_the_reference(sd):
     """Generator half of Trainer.test_step: forward_generator_step + the three non-adversarial loss terms."""
     g = load_golden("valstep.npz")
