@@ -954,6 +954,37 @@ extern "C" int cmgan_attn_train_backward(cmgan_handle* h, const float* x, const 
     return check_launch(h, "attn_train_backward");
 }
 
+extern "C" int cmgan_add(cmgan_handle* h, const float* a, const float* b, float* out, long long n, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!a || !b || !out || n <= 0 || (n & 3)) return fail(h, CMGAN_E_BADARG, "cmgan_add: bad argument (n must be a multiple of 4)");
+    launch_add(begin(h, stream), a, b, out, (long)n);
+    return check_launch(h, "add");
+}
+
+extern "C" size_t cmgan_layernorm_train_workspace_bytes(const cmgan_handle* h, long long M) {
+    if (!h || M <= 0) return 0;
+    return ln_train_ws_floats((long)M) * sizeof(float);
+}
+
+extern "C" int cmgan_layernorm_train_forward(cmgan_handle* h, const float* x, long long M, const float* weight,
+                                             const float* bias, float* y, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !y || !weight || !bias || M <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_layernorm_train_forward: bad argument");
+    launch_ln_train_forward(begin(h, stream), x, (long)M, weight, bias, y);
+    return check_launch(h, "layernorm_train_forward");
+}
+
+extern "C" int cmgan_layernorm_train_backward(cmgan_handle* h, const float* x, const float* dy, long long M,
+                                              const float* weight, const float* bias, float* dx, float* dweight,
+                                              float* dbias, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !dy || !dx || !weight || !bias || !dweight || !dbias || M <= 0)
+        return fail(h, CMGAN_E_BADARG, "cmgan_layernorm_train_backward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, ln_train_ws_floats((long)M) * sizeof(float))) return rc;
+    launch_ln_train_backward(begin(h, stream), x, dy, (long)M, weight, bias, dx, dweight, dbias, (float*)ws);
+    return check_launch(h, "layernorm_train_backward");
+}
+
 extern "C" int cmgan_adamw_step(cmgan_handle* h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                 long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int step, void* stream) {

@@ -169,6 +169,11 @@ void launch_attn_train_forward(LaunchCtx, const float* x, int N, int L, const At
                                const float* mask, float* y, float* ws);
 void launch_attn_train_backward(LaunchCtx, const float* x, const float* dy, int N, int L, const AttnTrainParams& p,
                                 int max_pos, const float* mask, float* dx, const AttnTrainParams& grad, float* ws);
+void launch_add(LaunchCtx, const float* a, const float* b, float* out, long n);
+size_t ln_train_ws_floats(long M);
+void launch_ln_train_forward(LaunchCtx, const float* x, long M, const float* gamma, const float* beta, float* y);
+void launch_ln_train_backward(LaunchCtx, const float* x, const float* dy, long M, const float* gamma, const float* beta,
+                              float* dx, float* dgamma, float* dbeta, float* ws);
 void launch_adamw(LaunchCtx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                   float eps, float wd, int step);
 

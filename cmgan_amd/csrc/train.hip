@@ -1289,3 +1289,85 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     colsum(ws + pl.g1, 64, grad.ln_w);
     colsum(ws + pl.dxn, 64, grad.ln_b);
 }
+
+// ---------------------------------------------------------------------------------
+// glue of ConformerBlock.forward in train mode (conformer.py:216-222): residual add, and the closing
+// post_norm LayerNorm(64) with its backward (same wave-level statistics as the branch kernels).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+        stg4(out + 4 * i, ldg4(a + 4 * i) + ldg4(b + 4 * i));
+}
+void launch_add(LaunchCtx ctx, const float* a, const float* b, float* out, long n) {
+    const long n4 = n / 4, want = (n4 + 255) / 256;
+    LAUNCH(ctx, "residual_add", (add_kernel<<<(unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096), 256, 0, ctx.stream>>>(
+                                    a, b, out, n4)));
+}
+
+__global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restrict__ x, long M,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (t0 >= M) return;
+    f32x4 xh[4], xn[1][4];
+    float rstd;
+    long row;
+    const bool ok = cm_load_norm(x, M, t0, c, g, gamma, beta, xh, xn, rstd, row);
+    if (ok) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) stg4(y + row * 64 + 16 * kb + 4 * g, xn[0][kb]);
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, long M,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ dx,
+                                                           float* __restrict__ g1) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (t0 >= M) return;
+    f32x4 xh[4], xn[1][4];
+    float rstd;
+    long row;
+    const bool ok = cm_load_norm(x, M, t0, c, g, gamma, beta, xh, xn, rstd, row);
+    f32x4 dyv[4], dxh[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        dyv[kb] = ldg4(dy + row * 64 + 16 * kb + 4 * g);
+        dxh[kb] = dyv[kb] * ldg4(gamma + 16 * kb + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s1 += dxh[kb][r];
+            s2 = fmaf(dxh[kb][r], xh[kb][r], s2);
+        }
+    }
+    const float mu1 = red_g_sum(s1) * (1.0f / 64.0f), mu2 = red_g_sum(s2) * (1.0f / 64.0f);
+    if (ok) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            stg4(dx + row * 64 + 16 * kb + 4 * g, (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd));
+            stg4(g1 + row * 64 + 16 * kb + 4 * g, dyv[kb] * xh[kb]);           // dgamma = colsum(dy xhat)
+        }
+    }
+}
+
+size_t ln_train_ws_floats(long M) { return (size_t)M * 64 + (size_t)FFN_COLSUM_BLOCKS * 256; }
+
+void launch_ln_train_forward(LaunchCtx ctx, const float* x, long M, const float* gamma, const float* beta, float* y) {
+    LAUNCH(ctx, "ln_train", (ln_train_fwd_kernel<<<(unsigned)((M + 63) / 64), 256, 0, ctx.stream>>>(x, M, gamma, beta, y)));
+}
+
+void launch_ln_train_backward(LaunchCtx ctx, const float* x, const float* dy, long M, const float* gamma,
+                              const float* beta, float* dx, float* dgamma, float* dbeta, float* ws) {
+    hipStream_t s = ctx.stream;
+    float* g1 = ws;
+    float* cpart = ws + (size_t)M * 64;
+    LAUNCH(ctx, "ln_train", (ln_train_bwd_kernel<<<(unsigned)((M + 63) / 64), 256, 0, s>>>(x, dy, M, gamma, beta, dx, g1)));
+    LAUNCH(ctx, "ln_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(g1, M, 64, cpart)));
+    LAUNCH(ctx, "ln_train", (reduce_partials_kernel<<<1, 256, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, 64, dgamma)));
+    LAUNCH(ctx, "ln_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(dy, M, 64, cpart)));
+    LAUNCH(ctx, "ln_train", (reduce_partials_kernel<<<1, 256, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, 64, dbeta)));
+}

@@ -10,6 +10,9 @@
 * `AdamW`, `step_lr`       - torch.optim.AdamW (train.py:63-66) as one HIP launch over a flat parameter bucket, and the
                              StepLR(30, 0.5) schedule (train.py:248-253); `FeedForwardTrain.allreduce_gradients()` is
                              the data-parallel gradient mean as ONE all-reduce over the same bucket (train.py:192).
+* `ConformerBlockTrain`    - the WHOLE reference ConformerBlock (conformer.py:182-222) in TRAIN mode from the pieces below
+                             plus HIP residual adds and the post_norm LayerNorm: forward, backward, all 31 parameter
+                             gradients in ONE flat bucket (one all-reduce, one AdamW launch).
 * `AttentionTrain`         - PreNorm(Attention) (conformer.py:54-72, 75-133) in TRAIN mode: Shaw relative-position
                              attention with the output Dropout as a keep-mask, forward + full backward incl. the
                              relative-position embedding gradient.
@@ -34,7 +37,7 @@ from ._lib import AttnParams, ConvModParams, FfnParams, check
 from .dist import FlatBucket, allreduce_mean
 from .engine import Engine
 
-__all__ = ["FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
+__all__ = ["ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
            "validation_step"]
 
 _KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.net.0.weight", "fn.fn.net.0.bias",
@@ -60,25 +63,38 @@ def generator_loss_terms(engine: Engine, est_real, est_imag, clean_spec, est_aud
     return (terms * w).sum(), terms
 
 
+def _buckets(shapes: Dict[str, tuple], state, views, device):
+    """(param_bucket, grad_bucket, params, grads): own FlatBuckets loaded from `state`, or the given views."""
+    if views is not None:
+        params, grads = views
+        for k, shp in shapes.items():
+            if tuple(params[k].shape) != tuple(shp) or tuple(grads[k].shape) != tuple(shp):
+                raise ValueError(f"{k}: view shape {tuple(params[k].shape)}, expected {tuple(shp)}")
+        return None, None, params, grads
+    for k, shp in shapes.items():
+        if tuple(state[k].shape) != tuple(shp):
+            raise ValueError(f"{k}: shape {tuple(state[k].shape)}, expected {tuple(shp)}")
+    pb = FlatBucket(shapes, device).load({k: state[k].detach().to(device, torch.float32) for k in shapes})
+    gb = FlatBucket(shapes, device)
+    return pb, gb, pb.views, gb.views
+
+
 class FeedForwardTrain:
     """ff1 / ff2 branch of one ConformerBlock in train mode on the HIP kernels.
 
     `state` holds the branch's six tensors under the reference's key names relative to `ff1.` / `ff2.`
     (`fn.norm.weight`, `fn.fn.net.0.weight`, ...), e.g. a slice of `TSCNet.state_dict()`."""
 
-    def __init__(self, state: Dict[str, torch.Tensor], dropout: float = 0.2, engine: Optional[Engine] = None,
-                 device=None):
+    SHAPES = dict(zip(_KEYS, _SHAPES))
+
+    def __init__(self, state: Optional[Dict[str, torch.Tensor]] = None, dropout: float = 0.2,
+                 engine: Optional[Engine] = None, device=None, views=None):
+        """`views` = (params, grads): dicts of tensors that are views of a larger FlatBucket (ConformerBlockTrain)."""
         self.engine = engine if engine is not None else Engine(device=device)
         self.p = float(dropout)
-        dev = self.engine.device
-        for key, shape in zip(_KEYS, _SHAPES):
-            if tuple(state[key].shape) != shape:
-                raise ValueError(f"{key}: shape {tuple(state[key].shape)}, expected {shape}")
         # parameters and gradients live in two flat buckets (views per tensor): one collective, one optimiser launch
-        shapes = dict(zip(_KEYS, _SHAPES))
-        self.param_bucket = FlatBucket(shapes, dev).load({k: state[k].detach().to(dev, torch.float32) for k in _KEYS})
-        self.grad_bucket = FlatBucket(shapes, dev)
-        self.params, self.grads = self.param_bucket.views, self.grad_bucket.views
+        self.param_bucket, self.grad_bucket, self.params, self.grads = _buckets(self.SHAPES, state, views,
+                                                                                self.engine.device)
         self._ws: Optional[torch.Tensor] = None
 
     def _struct(self, tensors: Dict[str, torch.Tensor]) -> FfnParams:
@@ -137,6 +153,8 @@ class FeedForwardTrain:
 
     def allreduce_gradients(self) -> torch.Tensor:
         """Mean of the six gradients over the data-parallel ranks: ONE all-reduce (RCCL) over the flat bucket."""
+        if self.grad_bucket is None:
+            raise RuntimeError("this module's gradients are views of its parent's bucket: all-reduce the parent")
         return allreduce_mean(self.grad_bucket.flat)
 
 
@@ -217,16 +235,12 @@ class ConvModuleTrain:
     `net.4.conv.weight`, `net.5.running_mean`, ...).  BatchNorm1d uses the statistics of the batch and updates
     `running_mean` / `running_var` like torch (momentum 0.1).  `backward` must follow the `forward` of the same x."""
 
-    def __init__(self, state: Dict[str, torch.Tensor], engine: Optional[Engine] = None, device=None):
+    SHAPES = dict(zip(_CM_KEYS, _CM_SHAPES))
+
+    def __init__(self, state: Dict[str, torch.Tensor], engine: Optional[Engine] = None, device=None, views=None):
         self.engine = engine if engine is not None else Engine(device=device)
         dev = self.engine.device
-        for key, shape in zip(_CM_KEYS, _CM_SHAPES):
-            if tuple(state[key].shape) != shape:
-                raise ValueError(f"{key}: shape {tuple(state[key].shape)}, expected {shape}")
-        shapes = dict(zip(_CM_KEYS, _CM_SHAPES))
-        self.param_bucket = FlatBucket(shapes, dev).load({k: state[k].detach().to(dev, torch.float32) for k in _CM_KEYS})
-        self.grad_bucket = FlatBucket(shapes, dev)
-        self.params, self.grads = self.param_bucket.views, self.grad_bucket.views
+        self.param_bucket, self.grad_bucket, self.params, self.grads = _buckets(self.SHAPES, state, views, dev)
         self.running_mean = state["net.5.running_mean"].detach().to(dev, torch.float32).clone()
         self.running_var = state["net.5.running_var"].detach().to(dev, torch.float32).clone()
         self._ws: Optional[torch.Tensor] = None
@@ -292,20 +306,18 @@ class AttentionTrain:
     `state` holds the branch's tensors under the reference's key names relative to `attn.`.  Sequences of up to 512
     positions; `backward` must follow the `forward` of the same x (it reads q|k|v, O and the row log-sum-exp)."""
 
-    def __init__(self, state: Dict[str, torch.Tensor], dropout: float = 0.2, engine: Optional[Engine] = None,
-                 device=None):
+    @staticmethod
+    def shapes(max_pos_emb: int = 512) -> Dict[str, tuple]:
+        return {"norm.weight": (64,), "norm.bias": (64,), "fn.to_q.weight": (64, 64), "fn.to_kv.weight": (128, 64),
+                "fn.to_out.weight": (64, 64), "fn.to_out.bias": (64,),
+                "fn.rel_pos_emb.weight": (2 * max_pos_emb + 1, 16)}
+
+    def __init__(self, state: Optional[Dict[str, torch.Tensor]] = None, dropout: float = 0.2,
+                 engine: Optional[Engine] = None, device=None, views=None):
         self.engine = engine if engine is not None else Engine(device=device)
         self.p = float(dropout)
-        dev = self.engine.device
-        rows = 2 * self.engine.cfg.max_pos_emb + 1
-        shapes = {"norm.weight": (64,), "norm.bias": (64,), "fn.to_q.weight": (64, 64), "fn.to_kv.weight": (128, 64),
-                  "fn.to_out.weight": (64, 64), "fn.to_out.bias": (64,), "fn.rel_pos_emb.weight": (rows, 16)}
-        for key, shape in shapes.items():
-            if tuple(state[key].shape) != shape:
-                raise ValueError(f"{key}: shape {tuple(state[key].shape)}, expected {shape}")
-        self.param_bucket = FlatBucket(shapes, dev).load({k: state[k].detach().to(dev, torch.float32) for k in _AT_KEYS})
-        self.grad_bucket = FlatBucket(shapes, dev)
-        self.params, self.grads = self.param_bucket.views, self.grad_bucket.views
+        self.param_bucket, self.grad_bucket, self.params, self.grads = _buckets(
+            self.shapes(self.engine.cfg.max_pos_emb), state, views, self.engine.device)
         self._ws: Optional[torch.Tensor] = None
         self._shape = None
 
@@ -358,6 +370,96 @@ class AttentionTrain:
                                                             m.data_ptr() if m is not None else None, dx.data_ptr(),
                                                             ctypes.byref(g), ws.data_ptr(), ws.numel(), eng._stream()))
         return dx, self.grads
+
+    def allreduce_gradients(self) -> torch.Tensor:
+        return allreduce_mean(self.grad_bucket.flat)
+
+
+class ConformerBlockTrain:
+    """`models.conformer.ConformerBlock(dim=64, dim_head=16, heads=4, conv_kernel_size=31, attn_dropout, ff_dropout)`
+    in TRAIN mode on the HIP kernels:  x -> ff1(x)+x -> attn(.)+. -> conv(.)+. -> ff2(.)+. -> post_norm
+    (conformer.py:216-222).  Dropout layers are explicit keep-masks (`masks()` draws them), BatchNorm1d runs on batch
+    statistics.  All 31 parameters (and their gradients) are views of one FlatBucket: `allreduce_gradients()` is one
+    collective, `AdamW(block.engine, block.param_bucket, block.grad_bucket)` one optimiser launch."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], attn_dropout: float = 0.2, ff_dropout: float = 0.2,
+                 engine: Optional[Engine] = None, device=None):
+        self.engine = eng = engine if engine is not None else Engine(device=device)
+        dev = eng.device
+        sub = {"ff1": FeedForwardTrain.SHAPES, "attn": AttentionTrain.shapes(eng.cfg.max_pos_emb),
+               "conv": ConvModuleTrain.SHAPES, "ff2": FeedForwardTrain.SHAPES,
+               "post_norm": {"weight": (64,), "bias": (64,)}}
+        shapes = {f"{p}.{k}": shp for p, d in sub.items() for k, shp in d.items()}
+        for k, shp in shapes.items():
+            if tuple(state[k].shape) != tuple(shp):
+                raise ValueError(f"{k}: shape {tuple(state[k].shape)}, expected {tuple(shp)}")
+        self.param_bucket = FlatBucket(shapes, dev).load({k: state[k].detach().to(dev, torch.float32) for k in shapes})
+        self.grad_bucket = FlatBucket(shapes, dev)
+        self.params, self.grads = self.param_bucket.views, self.grad_bucket.views
+
+        def views(prefix):
+            n = len(prefix) + 1
+            return ({k[n:]: v for k, v in self.params.items() if k.startswith(prefix + ".")},
+                    {k[n:]: v for k, v in self.grads.items() if k.startswith(prefix + ".")})
+        self.ff1 = FeedForwardTrain(dropout=ff_dropout, engine=eng, views=views("ff1"))
+        self.attn = AttentionTrain(dropout=attn_dropout, engine=eng, views=views("attn"))
+        self.conv = ConvModuleTrain({k[5:]: v for k, v in state.items() if k.startswith("conv.")}, engine=eng,
+                                    views=views("conv"))
+        self.ff2 = FeedForwardTrain(dropout=ff_dropout, engine=eng, views=views("ff2"))
+        self._saved = None
+        self._lnws: Optional[torch.Tensor] = None
+
+    def masks(self, N: int, L: int, generator: Optional[torch.Generator] = None) -> Dict[str, Optional[torch.Tensor]]:
+        a1, a2 = self.ff1.masks(N * L, generator)
+        at = self.attn.mask(N, L, generator)
+        b1, b2 = self.ff2.masks(N * L, generator)
+        return {"ff1_1": a1, "ff1_2": a2, "attn": at, "ff2_1": b1, "ff2_2": b2}
+
+    def _add(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        eng = self.engine
+        out = torch.empty_like(a)
+        check(eng._h, eng.lib.cmgan_add(eng._h, a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), eng._stream()))
+        return out
+
+    def forward(self, x: torch.Tensor, masks: Optional[Dict[str, Optional[torch.Tensor]]] = None) -> torch.Tensor:
+        eng = self.engine
+        m = masks or {}
+        x0 = eng._in(x, "x")
+        with torch.cuda.device(eng.device):
+            x1 = self._add(self.ff1.forward(x0, m.get("ff1_1"), m.get("ff1_2")), x0)
+            x2 = self._add(self.attn.forward(x1, m.get("attn")), x1)
+            x3 = self._add(self.conv.forward(x2), x2)
+            x4 = self._add(self.ff2.forward(x3, m.get("ff2_1"), m.get("ff2_2")), x3)
+            y = torch.empty_like(x4)
+            check(eng._h, eng.lib.cmgan_layernorm_train_forward(eng._h, x4.data_ptr(), x4.numel() // 64,
+                                                                self.params["post_norm.weight"].data_ptr(),
+                                                                self.params["post_norm.bias"].data_ptr(), y.data_ptr(),
+                                                                eng._stream()))
+        self._saved = (x0, x1, x2, x3, x4, m)
+        return y
+
+    def backward(self, dy: torch.Tensor) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """(dL/dx, {key: dL/dparam} = views of the flat gradient bucket) for the last forward()."""
+        if self._saved is None:
+            raise RuntimeError("backward() needs a forward() first")
+        eng = self.engine
+        x0, x1, x2, x3, x4, m = self._saved
+        dy = eng._in(dy, "dy")
+        M = x4.numel() // 64
+        need = eng.lib.cmgan_layernorm_train_workspace_bytes(eng._h, M)
+        if self._lnws is None or self._lnws.numel() < need:
+            self._lnws = torch.empty(need, dtype=torch.uint8, device=eng.device)
+        with torch.cuda.device(eng.device):
+            d4 = torch.empty_like(x4)
+            check(eng._h, eng.lib.cmgan_layernorm_train_backward(
+                eng._h, x4.data_ptr(), dy.data_ptr(), M, self.params["post_norm.weight"].data_ptr(),
+                self.params["post_norm.bias"].data_ptr(), d4.data_ptr(), self.grads["post_norm.weight"].data_ptr(),
+                self.grads["post_norm.bias"].data_ptr(), self._lnws.data_ptr(), self._lnws.numel(), eng._stream()))
+            d3 = self._add(self.ff2.backward(x3, d4, m.get("ff2_1"), m.get("ff2_2"))[0], d4)
+            d2 = self._add(self.conv.backward(x2, d3)[0], d3)
+            d1 = self._add(self.attn.backward(x1, d2, m.get("attn"))[0], d2)
+            d0 = self._add(self.ff1.backward(x0, d1, m.get("ff1_1"), m.get("ff1_2"))[0], d1)
+        return d0, self.grads
 
     def allreduce_gradients(self) -> torch.Tensor:
         return allreduce_mean(self.grad_bucket.flat)

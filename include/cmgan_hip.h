@@ -216,6 +216,18 @@ int cmgan_attn_train_backward(cmgan_handle* h, const float* x_dev, const float* 
                               const cmgan_attn_params* grads,
                               void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Glue of ConformerBlock.forward in train mode (src/models/conformer.py:216-222): out = a + b over n floats (the
+ * residual adds; n % 4 == 0), and the closing post_norm = nn.LayerNorm(64) (eps 1e-5) on [M,64] rows with its backward
+ * (dL/dx, dL/dweight, dL/dbias; fixed-order reductions).                                                          */
+int cmgan_add(cmgan_handle* h, const float* a_dev, const float* b_dev, float* out_dev, long long n, void* stream);
+size_t cmgan_layernorm_train_workspace_bytes(const cmgan_handle* h, long long M);
+int cmgan_layernorm_train_forward(cmgan_handle* h, const float* x_dev, long long M, const float* weight_dev,
+                                  const float* bias_dev, float* y_dev, void* stream);
+int cmgan_layernorm_train_backward(cmgan_handle* h, const float* x_dev, const float* dy_dev, long long M,
+                                   const float* weight_dev, const float* bias_dev, float* dx_dev,
+                                   float* dweight_dev, float* dbias_dev,
+                                   void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* One torch.optim.AdamW step (src/train.py:63-66, 192-193; defaults betas (0.9, 0.999), eps 1e-8, weight_decay
  * 0.01) over a FLAT fp32 bucket of n parameters: params, grads and the two moment buffers are parallel device
  * arrays (the bucket the gradient all-reduce runs over), `step` = 1, 2, ... is the update count for the bias

@@ -200,6 +200,19 @@ def conformer_block(sd, p, x, stages: dict | None = None):
 # --------------------------------------------------------------------------- #
 # generator: src/models/generator.py
 # --------------------------------------------------------------------------- #
+def conformer_block_train(sd, p, x, masks: dict | None = None, running: dict | None = None):
+    """ConformerBlock.forward in TRAIN mode (conformer.py:216-222): the five nn.Dropout layers as keep-masks
+    `masks` = {"ff1_1" [..,256], "ff1_2" [..,64], "attn" [..,64], "ff2_1", "ff2_2"} (missing / None = no dropout),
+    BatchNorm1d on batch statistics.  Differentiable (gradient oracle of cmgan_amd.training.ConformerBlockTrain)."""
+    pre = (p + ".") if p else ""
+    m = masks or {}
+    x = feed_forward_train(sd, pre + "ff1", x, m.get("ff1_1"), m.get("ff1_2")) + x
+    x = attention_train(sd, pre + "attn", x, m.get("attn")) + x
+    x = conv_module_train(sd, pre + "conv", x, running) + x
+    x = feed_forward_train(sd, pre + "ff2", x, m.get("ff2_1"), m.get("ff2_2")) + x
+    return layer_norm(sd, pre + "post_norm", x)
+
+
 def _in_prelu(sd, norm, prelu, x):
     x = F.instance_norm(x, weight=sd[norm + ".weight"], bias=sd[norm + ".bias"], eps=EPS)
     return F.prelu(x, sd[prelu + ".weight"])

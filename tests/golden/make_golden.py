@@ -266,6 +266,26 @@ def main():
         agr = {"grad_" + k.replace(".", "_"): v.grad.detach() for k, v in at.named_parameters()}
     save("attn_train.npz", x=xa.detach(), dy=dya, mask=ma, y=ya.detach(), dx=xa.grad.detach(), **agr)
 
+    # -- 13. the WHOLE ConformerBlock in TRAIN mode (conformer.py:216-222): every Dropout an explicit keep-mask,
+    #        BatchNorm1d on batch statistics; autograd gradients of x and of all 31 parameters
+    with torch.enable_grad():
+        blk_w = ConformerBlock(dim=64, dim_head=16, heads=4, conv_kernel_size=31, attn_dropout=0.2, ff_dropout=0.2)
+        blk_w.load_state_dict(csd, strict=True)
+        blk_w.train()
+        gen_w = torch.Generator().manual_seed(23)
+        km = lambda c: (torch.rand(2, 53, c, generator=gen_w) >= 0.2).float() / 0.8
+        wm = {"ff1_1": km(256), "ff1_2": km(64), "attn": km(64), "ff2_1": km(256), "ff2_2": km(64)}
+        blk_w.ff1.fn.fn.net[2], blk_w.ff1.fn.fn.net[4] = _Mask(wm["ff1_1"]), _Mask(wm["ff1_2"])
+        blk_w.attn.fn.dropout = _Mask(wm["attn"])
+        blk_w.ff2.fn.fn.net[2], blk_w.ff2.fn.fn.net[4] = _Mask(wm["ff2_1"]), _Mask(wm["ff2_2"])
+        xw = rnd((2, 53, 64), 51).requires_grad_(True)
+        dyw = rnd((2, 53, 64), 52)
+        yw = blk_w(xw)
+        yw.backward(dyw)
+        wgr = {"grad_" + k.replace(".", "_"): v.grad.detach() for k, v in blk_w.named_parameters()}
+    save("block_train.npz", x=xw.detach(), dy=dyw, y=yw.detach(), dx=xw.grad.detach(),
+         **{"mask_" + k: v for k, v in wm.items()}, **wgr)
+
     save("ffn_train.npz", x=xt.detach(), dy=dy, mask1=m1, mask2=m2, y=yt.detach(), dx=xt.grad.detach(),
          y_nomask=y0.detach(), dx_nomask=x0.grad.detach(), **grads, **grads0)
 

@@ -280,3 +280,38 @@ def test_attention_train_full_length_sequences_vs_oracle_autograd(n, l):
         assert _report(f"attention dL/d[{k}] [{n}x{l}]", rel_err(grads[k], leaf["attn." + k].grad)) < GRAD_TOL, k
     with pytest.raises(ValueError):
         at.forward(torch.zeros(1, 600, 64, device=DEV))
+
+
+def test_whole_conformer_block_trains_like_the_reference():
+    """The reference ConformerBlock in TRAIN mode end to end on the HIP kernels: forward, dL/dx and all 31 parameter
+    gradients (one flat bucket) against the module's own torch autograd (tests/golden/block_train.npz); then one
+    AdamW step over the whole bucket against torch.optim.AdamW."""
+    from cmgan_amd.training import AdamW, ConformerBlockTrain
+    g = load_golden("block_train.npz")
+    csd = conformer_state_dict(seed=3)
+    blk = ConformerBlockTrain(csd)
+    assert blk.param_bucket.numel == sum(v.numel() for k, v in csd.items() if v.dtype == torch.float32 and "running" not in k)
+    masks = {k[5:]: g[k].to(DEV) for k in g if k.startswith("mask_")}
+    y = blk.forward(g["x"].to(DEV), masks)
+    assert _report("conformer block train forward", rel_err(y, g["y"])) < GRAD_TOL
+    dx, grads = blk.backward(g["dy"].to(DEV))
+    assert _report("conformer block dL/dx", rel_err(dx, g["dx"])) < GRAD_TOL
+    worst = 0.0
+    for k, got in grads.items():
+        want = g["grad_" + k.replace(".", "_")]
+        if k == "conv.net.4.conv.bias":                                   # exactly zero behind batch-stat BatchNorm
+            assert float(got.abs().max()) < 1e-4 * float(g["grad_conv_net_5_bias"].abs().max())
+            continue
+        err = rel_err(got, want)
+        worst = max(worst, err)
+        assert err < GRAD_TOL, (k, err)
+    _report(f"conformer block: worst of {len(grads)} parameter gradients", worst)
+    # one optimiser step over the whole bucket
+    opt = AdamW(blk.engine, blk.param_bucket, blk.grad_bucket, lr=5e-4)
+    leaf = {k: csd[k].clone().requires_grad_(True) for k in grads}
+    for k, v in leaf.items():
+        v.grad = g["grad_" + k.replace(".", "_")].clone()
+    torch.optim.AdamW(list(leaf.values()), lr=5e-4).step()
+    opt.step()
+    for k in ("ff1.fn.fn.net.0.weight", "attn.fn.rel_pos_emb.weight", "conv.net.4.conv.weight", "post_norm.bias"):
+        assert _report(f"after AdamW: {k}", rel_err(blk.params[k], leaf[k].detach())) < 1e-5, k

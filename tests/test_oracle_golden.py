@@ -180,6 +180,26 @@ def test_train_mode_attention_and_its_gradients():
         assert rel_err(leaf["attn." + k].grad, g["grad_" + k.replace(".", "_")]) < TOL, k
 
 
+def test_train_mode_conformer_block_and_all_its_gradients():
+    g = load_golden("block_train.npz")
+    csd = conformer_state_dict(seed=3)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in csd.items() if v.dtype == torch.float32 and "running" not in k}
+    sdx = dict(csd)
+    sdx.update(leaf)
+    masks = {k[5:]: g[k] for k in g if k.startswith("mask_")}
+    x = g["x"].clone().requires_grad_(True)
+    with torch.enable_grad():
+        y = O.conformer_block_train(sdx, "", x, masks)
+        y.backward(g["dy"])
+    assert rel_err(y, g["y"]) < TOL and rel_err(x.grad, g["dx"]) < TOL
+    for k, v in leaf.items():
+        want = g["grad_" + k.replace(".", "_")]
+        if k == "conv.net.4.conv.bias":          # exactly zero behind a batch-statistics BatchNorm: rounding noise only
+            assert float(v.grad.abs().max()) < 1e-4 * float(g["grad_conv_net_5_bias"].abs().max())
+            continue
+        assert rel_err(v.grad, want) < 5e-5, k
+
+
 def test_validation_step_losses_match_the_reference(sd):
     """Generator half of Trainer.test_step: forward_generator_step + the three non-adversarial loss terms."""
     g = load_golden("valstep.npz")
