@@ -954,6 +954,13 @@ extern "C" int cmgan_attn_train_backward(cmgan_handle* h, const float* x, const 
     return check_launch(h, "attn_train_backward");
 }
 
+extern "C" int cmgan_swap_axes(cmgan_handle* h, const float* in, float* out, int B, int A, int C, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!in || !out || in == out || B <= 0 || A <= 0 || C <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_swap_axes: bad argument");
+    launch_swap_axes(begin(h, stream), in, out, B, A, C);
+    return check_launch(h, "swap_axes");
+}
+
 extern "C" int cmgan_add(cmgan_handle* h, const float* a, const float* b, float* out, long long n, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!a || !b || !out || n <= 0 || (n & 3)) return fail(h, CMGAN_E_BADARG, "cmgan_add: bad argument (n must be a multiple of 4)");

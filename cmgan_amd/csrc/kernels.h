@@ -169,6 +169,7 @@ void launch_attn_train_forward(LaunchCtx, const float* x, int N, int L, const At
                                const float* mask, float* y, float* ws);
 void launch_attn_train_backward(LaunchCtx, const float* x, const float* dy, int N, int L, const AttnTrainParams& p,
                                 int max_pos, const float* mask, float* dx, const AttnTrainParams& grad, float* ws);
+void launch_swap_axes(LaunchCtx, const float* in, float* out, int B, int A, int C);
 void launch_add(LaunchCtx, const float* a, const float* b, float* out, long n);
 size_t ln_train_ws_floats(long M);
 void launch_ln_train_forward(LaunchCtx, const float* x, long M, const float* gamma, const float* beta, float* y);

@@ -1371,3 +1371,23 @@ void launch_ln_train_backward(LaunchCtx ctx, const float* x, const float* dy, lo
     LAUNCH(ctx, "ln_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(dy, M, 64, cpart)));
     LAUNCH(ctx, "ln_train", (reduce_partials_kernel<<<1, 256, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, 64, dbeta)));
 }
+
+// [B, A, C, 64] -> [B, C, A, 64]: the layout flip between the time-axis and frequency-axis sequences of a TSCB
+// (the reference's permute(...).contiguous(), generator.py:94,96) on channels-last rows of 256 B
+__global__ __launch_bounds__(256) void swap_axes_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int C,
+                                                        long total4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int q = (int)(i & 15);
+        long r = i >> 4;                       // output row (b, c, a)
+        const int a = (int)(r % A);
+        r /= A;
+        const int c = (int)(r % C);
+        const long b = r / C;
+        stg4(out + 4 * i, ldg4(in + ((((b * A + a) * C + c) << 4) + q) * 4));
+    }
+}
+void launch_swap_axes(LaunchCtx ctx, const float* in, float* out, int B, int A, int C) {
+    const long total4 = (long)B * A * C * 16, want = (total4 + 255) / 256;
+    LAUNCH(ctx, "swap_axes", (swap_axes_kernel<<<(unsigned)(want < 8192 ? (want > 0 ? want : 1) : 8192), 256, 0, ctx.stream>>>(
+                                 in, out, A, C, total4)));
+}

@@ -10,6 +10,9 @@
 * `AdamW`, `step_lr`       - torch.optim.AdamW (train.py:63-66) as one HIP launch over a flat parameter bucket, and the
                              StepLR(30, 0.5) schedule (train.py:248-253); `FeedForwardTrain.allreduce_gradients()` is
                              the data-parallel gradient mean as ONE all-reduce over the same bucket (train.py:192).
+* `TSCBTrain`              - one two-stage conformer block of the generator (generator.py:72-99) in TRAIN mode on
+                             channels-last activations [B, T, F', 64]: time conformer per (b, f'), frequency conformer
+                             per (b, t), both residuals, the layout flips as a HIP kernel.
 * `ConformerBlockTrain`    - the WHOLE reference ConformerBlock (conformer.py:182-222) in TRAIN mode from the pieces below
                              plus HIP residual adds and the post_norm LayerNorm: forward, backward, all 31 parameter
                              gradients in ONE flat bucket (one all-reduce, one AdamW launch).
@@ -37,7 +40,7 @@ from ._lib import AttnParams, ConvModParams, FfnParams, check
 from .dist import FlatBucket, allreduce_mean
 from .engine import Engine
 
-__all__ = ["ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
+__all__ = ["TSCBTrain", "ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
            "validation_step"]
 
 _KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.net.0.weight", "fn.fn.net.0.bias",
@@ -463,3 +466,53 @@ class ConformerBlockTrain:
 
     def allreduce_gradients(self) -> torch.Tensor:
         return allreduce_mean(self.grad_bucket.flat)
+
+
+class TSCBTrain:
+    """`models.generator.TSCB(num_channel=64)` (generator.py:72-99) in TRAIN mode on the HIP kernels.  Activations are
+    channels-last `[B, T, F', 64]` (the layout of the inference path); the reference's NCHW `[B, 64, T, F']` tensor is
+    `x.permute(0, 2, 3, 1)`.  `state` = the block's slice of the generator state_dict (`time_conformer.*`,
+    `freq_conformer.*`)."""
+
+    def __init__(self, state: Dict[str, torch.Tensor], engine: Optional[Engine] = None, device=None):
+        self.engine = eng = engine if engine is not None else Engine(device=device)
+        sub = lambda p: {k[len(p) + 1:]: v for k, v in state.items() if k.startswith(p + ".")}
+        self.time = ConformerBlockTrain(sub("time_conformer"), engine=eng)
+        self.freq = ConformerBlockTrain(sub("freq_conformer"), engine=eng)
+        self._shape = None
+
+    def masks(self, B: int, T: int, F2: int, generator: Optional[torch.Generator] = None):
+        return self.time.masks(B * F2, T, generator), self.freq.masks(B * T, F2, generator)
+
+    def _swap(self, x: torch.Tensor, B: int, A: int, C: int) -> torch.Tensor:
+        eng = self.engine
+        out = torch.empty(B, C, A, 64, dtype=torch.float32, device=x.device)
+        check(eng._h, eng.lib.cmgan_swap_axes(eng._h, x.data_ptr(), out.data_ptr(), B, A, C, eng._stream()))
+        return out
+
+    def forward(self, x: torch.Tensor, masks_time=None, masks_freq=None) -> torch.Tensor:
+        eng = self.engine
+        x = eng._in(x, "x")
+        B, T, F2, C = x.shape
+        if C != 64:
+            raise ValueError("expected channels-last [B, T, F', 64]")
+        with torch.cuda.device(eng.device):
+            xt = self._swap(x, B, T, F2).view(B * F2, T, 64)                       # generator.py:94
+            xt = self.time._add(self.time.forward(xt, masks_time), xt)             # :95
+            xf = self._swap(xt, B, F2, T).view(B * T, F2, 64)                      # :96
+            xf = self.freq._add(self.freq.forward(xf, masks_freq), xf)             # :97
+        self._shape = (B, T, F2)
+        return xf.view(B, T, F2, 64)
+
+    def backward(self, dy: torch.Tensor) -> torch.Tensor:
+        """dL/dx [B, T, F', 64] for the last forward(); parameter gradients land in time.grads / freq.grads."""
+        if self._shape is None:
+            raise RuntimeError("backward() needs a forward() first")
+        eng = self.engine
+        B, T, F2 = self._shape
+        dy = eng._in(dy, "dy").view(B * T, F2, 64)
+        with torch.cuda.device(eng.device):
+            dxf = self.freq._add(self.freq.backward(dy)[0], dy)
+            dxt2 = self._swap(dxf, B, T, F2).view(B * F2, T, 64)
+            dxt = self.time._add(self.time.backward(dxt2)[0], dxt2)
+            return self._swap(dxt, B, F2, T)

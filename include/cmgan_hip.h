@@ -219,6 +219,9 @@ int cmgan_attn_train_backward(cmgan_handle* h, const float* x_dev, const float* 
 /* Glue of ConformerBlock.forward in train mode (src/models/conformer.py:216-222): out = a + b over n floats (the
  * residual adds; n % 4 == 0), and the closing post_norm = nn.LayerNorm(64) (eps 1e-5) on [M,64] rows with its backward
  * (dL/dx, dL/dweight, dL/dbias; fixed-order reductions).                                                          */
+/* in [B, A, C, 64] -> out [B, C, A, 64] (out != in): the time-axis <-> frequency-axis layout flip of a TSCB on
+ * channels-last activations (src/models/generator.py:94,96 permute + contiguous).                                */
+int cmgan_swap_axes(cmgan_handle* h, const float* in_dev, float* out_dev, int B, int A, int C, void* stream);
 int cmgan_add(cmgan_handle* h, const float* a_dev, const float* b_dev, float* out_dev, long long n, void* stream);
 size_t cmgan_layernorm_train_workspace_bytes(const cmgan_handle* h, long long M);
 int cmgan_layernorm_train_forward(cmgan_handle* h, const float* x_dev, long long M, const float* weight_dev,

@@ -213,6 +213,16 @@ def conformer_block_train(sd, p, x, masks: dict | None = None, running: dict | N
     return layer_norm(sd, pre + "post_norm", x)
 
 
+def tscb_train(sd, p, x, masks_time: dict | None = None, masks_freq: dict | None = None):
+    """TSCB.forward in TRAIN mode (generator.py:92-99).  x: NCHW [B, 64, T, F'] like the reference."""
+    b, c, t, f = x.shape
+    x_t = x.permute(0, 3, 2, 1).contiguous().view(b * f, t, c)
+    x_t = conformer_block_train(sd, p + ".time_conformer", x_t, masks_time) + x_t
+    x_f = x_t.view(b, f, t, c).permute(0, 2, 1, 3).contiguous().view(b * t, f, c)
+    x_f = conformer_block_train(sd, p + ".freq_conformer", x_f, masks_freq) + x_f
+    return x_f.view(b, t, f, c).permute(0, 3, 1, 2)
+
+
 def _in_prelu(sd, norm, prelu, x):
     x = F.instance_norm(x, weight=sd[norm + ".weight"], bias=sd[norm + ".bias"], eps=EPS)
     return F.prelu(x, sd[prelu + ".weight"])

@@ -286,6 +286,37 @@ def main():
     save("block_train.npz", x=xw.detach(), dy=dyw, y=yw.detach(), dx=xw.grad.detach(),
          **{"mask_" + k: v for k, v in wm.items()}, **wgr)
 
+    # -- 14. one TSCB (generator.py:72-99) in TRAIN mode: time conformer over T per (b, f') + residual, frequency
+    #        conformer over F' per (b, t) + residual; ten keep-masks; input / output NCHW [b, 64, t, f'] as in the model
+    from models.generator import TSCB
+    with torch.enable_grad():
+        tscb = TSCB(num_channel=64)
+        tsd = {k[len("TSCB_1."):]: v for k, v in sd.items() if k.startswith("TSCB_1.")}
+        tscb.load_state_dict(tsd, strict=True)
+        tscb.train()
+        bT, tT, fT = 2, 19, 11
+        gen_t = torch.Generator().manual_seed(29)
+        tm = {}
+        for ax, (nn_, ll) in (("time", (bT * fT, tT)), ("freq", (bT * tT, fT))):
+            conf = getattr(tscb, ax + "_conformer")
+            kmt = lambda c: (torch.rand(nn_, ll, c, generator=gen_t) >= 0.2).float() / 0.8
+            mk = {"ff1_1": kmt(256), "ff1_2": kmt(64), "attn": kmt(64), "ff2_1": kmt(256), "ff2_2": kmt(64)}
+            conf.ff1.fn.fn.net[2], conf.ff1.fn.fn.net[4] = _Mask(mk["ff1_1"]), _Mask(mk["ff1_2"])
+            conf.attn.fn.dropout = _Mask(mk["attn"])
+            conf.ff2.fn.fn.net[2], conf.ff2.fn.fn.net[4] = _Mask(mk["ff2_1"]), _Mask(mk["ff2_2"])
+            tm.update({f"mask_{ax}_{k}": v for k, v in mk.items()})
+        xs = rnd((bT, 64, tT, fT), 61).requires_grad_(True)
+        dys = rnd((bT, 64, tT, fT), 62)
+        ys = tscb(xs)
+        ys.backward(dys)
+        # a few representative parameter gradients (the full set is checked per block by block_train.npz)
+        pick = ("time_conformer.ff1.fn.fn.net.0.weight", "time_conformer.attn.fn.rel_pos_emb.weight",
+                "time_conformer.conv.net.4.conv.weight", "freq_conformer.attn.fn.to_kv.weight",
+                "freq_conformer.conv.net.5.weight", "freq_conformer.post_norm.weight")
+        named = dict(tscb.named_parameters())
+        tgr = {"grad_" + k.replace(".", "_"): named[k].grad.detach() for k in pick}
+    save("tscb_train.npz", x=xs.detach(), dy=dys, y=ys.detach().contiguous(), dx=xs.grad.detach(), **tm, **tgr)
+
     save("ffn_train.npz", x=xt.detach(), dy=dy, mask1=m1, mask2=m2, y=yt.detach(), dx=xt.grad.detach(),
          y_nomask=y0.detach(), dx_nomask=x0.grad.detach(), **grads, **grads0)
 

@@ -315,3 +315,27 @@ def test_whole_conformer_block_trains_like_the_reference():
     opt.step()
     for k in ("ff1.fn.fn.net.0.weight", "attn.fn.rel_pos_emb.weight", "conv.net.4.conv.weight", "post_norm.bias"):
         assert _report(f"after AdamW: {k}", rel_err(blk.params[k], leaf[k].detach())) < 1e-5, k
+
+
+def test_tscb_trains_like_the_reference():
+    """One two-stage conformer block of the generator (generator.py:72-99) in TRAIN mode: time conformer per
+    (b, f'), frequency conformer per (b, t), both residuals and the layout flips on the HIP kernels, channels-last
+    [B, T, F', 64]; forward, dL/dx and representative parameter gradients vs the reference TSCB's torch autograd."""
+    from cmgan_amd.training import TSCBTrain
+    from oracle.weights import make_state_dict
+    g = load_golden("tscb_train.npz")
+    sd = make_state_dict(seed=0)
+    blk = TSCBTrain({k[len("TSCB_1."):]: v for k, v in sd.items() if k.startswith("TSCB_1.")})
+    mt = {k[len("mask_time_"):]: g[k].to(DEV) for k in g if k.startswith("mask_time_")}
+    mf = {k[len("mask_freq_"):]: g[k].to(DEV) for k in g if k.startswith("mask_freq_")}
+    x_cl = g["x"].permute(0, 2, 3, 1).contiguous()                        # NCHW -> channels-last
+    y = blk.forward(x_cl.to(DEV), mt, mf)
+    assert _report("TSCB train forward", rel_err(y.permute(0, 3, 1, 2), g["y"])) < GRAD_TOL
+    dx = blk.backward(g["dy"].permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert _report("TSCB dL/dx", rel_err(dx.permute(0, 3, 1, 2), g["dx"])) < GRAD_TOL
+    for k in g:
+        if k.startswith("grad_"):
+            ax = "time" if k.startswith("grad_time") else "freq"
+            grads = getattr(blk, ax).grads
+            name = next(n for n in grads if n.replace(".", "_") == k[len(f"grad_{ax}_conformer_"):])
+            assert _report(f"TSCB dL/d[{ax}.{name}]", rel_err(grads[name], g[k])) < GRAD_TOL, k

@@ -200,6 +200,25 @@ def test_train_mode_conformer_block_and_all_its_gradients():
         assert rel_err(v.grad, want) < 5e-5, k
 
 
+def test_train_mode_tscb(sd):
+    g = load_golden("tscb_train.npz")
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()
+            if k.startswith("TSCB_1.") and v.dtype == torch.float32 and "running" not in k}
+    sdx = dict(sd)
+    sdx.update(leaf)
+    mt = {k[len("mask_time_"):]: g[k] for k in g if k.startswith("mask_time_")}
+    mf = {k[len("mask_freq_"):]: g[k] for k in g if k.startswith("mask_freq_")}
+    x = g["x"].clone().requires_grad_(True)
+    with torch.enable_grad():
+        y = O.tscb_train(sdx, "TSCB_1", x, mt, mf)
+        y.backward(g["dy"])
+    assert rel_err(y, g["y"]) < TOL and rel_err(x.grad, g["dx"]) < TOL
+    for k in g:
+        if k.startswith("grad_"):
+            name = next(n for n in leaf if n[len("TSCB_1."):].replace(".", "_") == k[5:])
+            assert rel_err(leaf[name].grad, g[k]) < 5e-5, k
+
+
 def test_validation_step_losses_match_the_reference(sd):
     """Generator half of Trainer.test_step: forward_generator_step + the three non-adversarial loss terms."""
     g = load_golden("valstep.npz")
