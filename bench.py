@@ -107,7 +107,7 @@ def hbm_bytes_per_clip(sh: Shape):
 
 def csrc_digest() -> str:
     from cmgan_amd import build as _build
-    return _build._digest()[:16]
+    return _build.inference_digest()[:16]
 
 
 def cpu_baseline(sd, sh: Shape, seconds_budget=20.0):

@@ -10,56 +10,8 @@
 #include <string>
 #include <vector>
 
-#include "../../include/cmgan_hip.h"
-#include "kernels.h"
+#include "api_internal.h"
 #include "weights.h"
-
-static thread_local std::string g_create_error;
-
-struct WEntry { size_t off; size_t count; };
-
-struct cmgan_handle {
-    cmgan_config cfg;
-    int device = 0;
-    std::string err;
-    // tables
-    float* d_tables = nullptr;
-    void* d_fold = nullptr;               // folded-DFT fp16 hi/lo images (x3 mode, n_fft 400)
-    double* d_loss = nullptr;             // LOSS_BLOCKS x 4 partial sums of cmgan_loss_terms
-    SpectralTables st{};
-    // weights
-    float* d_weights = nullptr;
-    size_t weight_floats = 0;
-    int weights_generation = 0;           // bumped by every successful cmgan_load_weights (stale-graph detection)
-    std::map<uint32_t, WEntry> dir;
-    // x3 (f16 split) operand images, built from the fp32 fragment-major weights at load time
-    _Float16* d_w16 = nullptr;
-    std::map<uint32_t, size_t> dir16;     // id -> offset in halfs (rel-pos lo plane at id | 0x8000)
-    Profiler prof;
-    std::vector<std::string> prof_names;
-};
-
-static int fail(cmgan_handle* h, int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    if (h) h->err = buf; else g_create_error = buf;
-    return code;
-}
-
-#define HIPCHK(h, call)                                                                          \
-    do {                                                                                         \
-        hipError_t _e = (call);                                                                  \
-        if (_e != hipSuccess) return fail(h, CMGAN_E_HIP, "%s: %s", #call, hipGetErrorString(_e)); \
-    } while (0)
-
-static int check_launch(cmgan_handle* h, const char* where) {
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(h, CMGAN_E_HIP, "%s: %s", where, hipGetErrorString(e));
-    return CMGAN_OK;
-}
 
 extern "C" void cmgan_default_config(cmgan_config* c) {
     if (!c) return;
@@ -524,17 +476,6 @@ extern "C" size_t cmgan_workspace_bytes(const cmgan_handle* h, int B, int T) {
     return plan_ws(h->cfg, B, T).total * sizeof(float);
 }
 
-static int check_ws(cmgan_handle* h, void* ws, size_t bytes, size_t need) {
-    if (!ws) return fail(h, CMGAN_E_BADARG, "workspace is null");
-    if (((uintptr_t)ws & 255) != 0) return fail(h, CMGAN_E_WORKSPACE, "workspace must be 256-byte aligned");
-    if (bytes < need) return fail(h, CMGAN_E_WORKSPACE, "workspace too small: %zu < %zu bytes", bytes, need);
-    return CMGAN_OK;
-}
-
-static LaunchCtx begin(cmgan_handle* h, void* stream) {
-    return LaunchCtx{(hipStream_t)stream, &h->prof};
-}
-
 // ------------------------------------------------------------------------------------
 // front / back end
 // ------------------------------------------------------------------------------------
@@ -820,187 +761,6 @@ extern "C" int cmgan_enhance(cmgan_handle* h, const float* wav, int B, int L, fl
         return rc;
     launch_uncompress_istft(ctx, h->st, f + p.est, f + p.est + (size_t)B * P, f + p.scale, B, T, f + p.frames, wav_out);
     return check_launch(h, "enhance");
-}
-
-// ------------------------------------------------------------------------------------
-// training / validation step pieces (src/train.py)
-// ------------------------------------------------------------------------------------
-extern "C" int cmgan_loss_terms(cmgan_handle* h, const float* est_real, const float* est_imag,
-                                const float* clean_spec, int B, int T, const float* est_audio,
-                                const float* clean_audio, int L_audio, float* out4, void* stream) {
-    if (!h) return CMGAN_E_BADARG;
-    const bool spec = est_real || est_imag || clean_spec, audio = est_audio || clean_audio;
-    if (!out4 || B <= 0 || (!spec && !audio)) return fail(h, CMGAN_E_BADARG, "cmgan_loss_terms: bad argument");
-    if (spec && (!est_real || !est_imag || !clean_spec || T <= 0))
-        return fail(h, CMGAN_E_BADARG, "cmgan_loss_terms: spectral terms need est_real, est_imag, clean_spec and T > 0");
-    if (audio && (!est_audio || !clean_audio || L_audio <= 0))
-        return fail(h, CMGAN_E_BADARG, "cmgan_loss_terms: time term needs est_audio, clean_audio and L_audio > 0");
-    launch_loss_terms(begin(h, stream), est_real, est_imag, clean_spec, B, (long)T * h->cfg.num_features, est_audio,
-                      clean_audio, (long)B * L_audio, h->d_loss, out4);
-    return check_launch(h, "loss_terms");
-}
-
-extern "C" size_t cmgan_ffn_train_workspace_bytes(const cmgan_handle* h, long long M) {
-    if (!h || M <= 0) return 0;
-    return ffn_train_ws_floats((long)M) * sizeof(float);
-}
-
-static bool ffn_params_ok(const cmgan_ffn_params* p) {
-    return p && p->ln_weight && p->ln_bias && p->w1 && p->b1 && p->w2 && p->b2;
-}
-static FfnTrainParams ffn_params(const cmgan_ffn_params* p) {
-    return FfnTrainParams{p->ln_weight, p->ln_bias, p->w1, p->b1, p->w2, p->b2};
-}
-
-extern "C" int cmgan_ffn_train_forward(cmgan_handle* h, const float* x, long long M, const cmgan_ffn_params* params,
-                                       const float* mask1, const float* mask2, float* y, void* ws, size_t ws_bytes,
-                                       void* stream) {
-    if (!h) return CMGAN_E_BADARG;
-    if (!x || !y || M <= 0 || !ffn_params_ok(params)) return fail(h, CMGAN_E_BADARG, "cmgan_ffn_train_forward: bad argument");
-    if (int rc = check_ws(h, ws, ws_bytes, ffn_train_ws_floats((long)M) * sizeof(float))) return rc;
-    launch_ffn_train_forward(begin(h, stream), x, (long)M, ffn_params(params), mask1, mask2, y, (float*)ws);
-    return check_launch(h, "ffn_train_forward");
-}
-
-extern "C" int cmgan_ffn_train_backward(cmgan_handle* h, const float* x, const float* dy, long long M,
-                                        const cmgan_ffn_params* params, const float* mask1, const float* mask2,
-                                        float* dx, const cmgan_ffn_params* grads, void* ws, size_t ws_bytes,
-                                        void* stream) {
-    if (!h) return CMGAN_E_BADARG;
-    if (!x || !dy || !dx || M <= 0 || !ffn_params_ok(params) || !ffn_params_ok(grads))
-        return fail(h, CMGAN_E_BADARG, "cmgan_ffn_train_backward: bad argument");
-    if (int rc = check_ws(h, ws, ws_bytes, ffn_train_ws_floats((long)M) * sizeof(float))) return rc;
-    launch_ffn_train_backward(begin(h, stream), x, dy, (long)M, ffn_params(params), mask1, mask2, dx, ffn_params(grads),
-                              (float*)ws);
-    return check_launch(h, "ffn_train_backward");
-}
-
-extern "C" size_t cmgan_convmod_train_workspace_bytes(const cmgan_handle* h, int N, int L) {
-    if (!h || N <= 0 || L <= 0) return 0;
-    return convmod_train_ws_floats(N, L) * sizeof(float);
-}
-
-static bool convmod_params_ok(const cmgan_convmod_params* p) {
-    return p && p->ln_weight && p->ln_bias && p->pw1_weight && p->pw1_bias && p->dw_weight && p->dw_bias &&
-           p->bn_weight && p->bn_bias && p->pw2_weight && p->pw2_bias;
-}
-static ConvModTrainParams convmod_params(const cmgan_convmod_params* p) {
-    return ConvModTrainParams{p->ln_weight, p->ln_bias, p->pw1_weight, p->pw1_bias, p->dw_weight, p->dw_bias,
-                              p->bn_weight, p->bn_bias, p->pw2_weight, p->pw2_bias};
-}
-
-extern "C" int cmgan_convmod_train_forward(cmgan_handle* h, const float* x, int N, int L,
-                                           const cmgan_convmod_params* params, float* running_mean,
-                                           float* running_var, float* y, void* ws, size_t ws_bytes, void* stream) {
-    if (!h) return CMGAN_E_BADARG;
-    if (!x || !y || N <= 0 || L <= 0 || !convmod_params_ok(params) || (!running_mean != !running_var))
-        return fail(h, CMGAN_E_BADARG, "cmgan_convmod_train_forward: bad argument");
-    if (int rc = check_ws(h, ws, ws_bytes, convmod_train_ws_floats(N, L) * sizeof(float))) return rc;
-    launch_convmod_train_forward(begin(h, stream), x, N, L, convmod_params(params), running_mean, running_var, y,
-                                 (float*)ws);
-    return check_launch(h, "convmod_train_forward");
-}
-
-extern "C" int cmgan_convmod_train_backward(cmgan_handle* h, const float* x, const float* dy, int N, int L,
-                                            const cmgan_convmod_params* params, float* dx,
-                                            const cmgan_convmod_params* grads, void* ws, size_t ws_bytes,
-                                            void* stream) {
-    if (!h) return CMGAN_E_BADARG;
-    if (!x || !dy || !dx || N <= 0 || L <= 0 || !convmod_params_ok(params) || !convmod_params_ok(grads))
-        return fail(h, CMGAN_E_BADARG, "cmgan_convmod_train_backward: bad argument");
-    if (int rc = check_ws(h, ws, ws_bytes, convmod_train_ws_floats(N, L) * sizeof(float))) return rc;
-    launch_convmod_train_backward(begin(h, stream), x, dy, N, L, convmod_params(params), dx, convmod_params(grads),
-                                  (float*)ws);
-    return check_launch(h, "convmod_train_backward");
-}
-
-extern "C" size_t cmgan_attn_train_workspace_bytes(const cmgan_handle* h, int N, int L) {
-    if (!h || N <= 0 || L <= 0 || L > attn_train_max_len()) return 0;
-    return attn_train_ws_floats(N, L) * sizeof(float);
-}
-
-static bool attn_params_ok(const cmgan_attn_params* p) {
-    return p && p->ln_weight && p->ln_bias && p->to_q_weight && p->to_kv_weight && p->to_out_weight &&
-           p->to_out_bias && p->rel_pos_emb;
-}
-static AttnTrainParams attn_params(const cmgan_attn_params* p) {
-    return AttnTrainParams{p->ln_weight, p->ln_bias, p->to_q_weight, p->to_kv_weight, p->to_out_weight, p->to_out_bias,
-                           p->rel_pos_emb};
-}
-
-extern "C" int cmgan_attn_train_forward(cmgan_handle* h, const float* x, int N, int L, const cmgan_attn_params* params,
-                                        const float* mask, float* y, void* ws, size_t ws_bytes, void* stream) {
-    if (!h) return CMGAN_E_BADARG;
-    if (!x || !y || N <= 0 || L <= 0 || !attn_params_ok(params))
-        return fail(h, CMGAN_E_BADARG, "cmgan_attn_train_forward: bad argument");
-    if (L > attn_train_max_len())
-        return fail(h, CMGAN_E_UNSUPPORTED, "cmgan_attn_train: sequences up to %d positions (got %d)", attn_train_max_len(), L);
-    if (int rc = check_ws(h, ws, ws_bytes, attn_train_ws_floats(N, L) * sizeof(float))) return rc;
-    launch_attn_train_forward(begin(h, stream), x, N, L, attn_params(params), h->cfg.max_pos_emb, mask, y, (float*)ws);
-    return check_launch(h, "attn_train_forward");
-}
-
-extern "C" int cmgan_attn_train_backward(cmgan_handle* h, const float* x, const float* dy, int N, int L,
-                                         const cmgan_attn_params* params, const float* mask, float* dx,
-                                         const cmgan_attn_params* grads, void* ws, size_t ws_bytes, void* stream) {
-    if (!h) return CMGAN_E_BADARG;
-    if (!x || !dy || !dx || N <= 0 || L <= 0 || !attn_params_ok(params) || !attn_params_ok(grads))
-        return fail(h, CMGAN_E_BADARG, "cmgan_attn_train_backward: bad argument");
-    if (L > attn_train_max_len())
-        return fail(h, CMGAN_E_UNSUPPORTED, "cmgan_attn_train: sequences up to %d positions (got %d)", attn_train_max_len(), L);
-    if (int rc = check_ws(h, ws, ws_bytes, attn_train_ws_floats(N, L) * sizeof(float))) return rc;
-    launch_attn_train_backward(begin(h, stream), x, dy, N, L, attn_params(params), h->cfg.max_pos_emb, mask, dx,
-                               attn_params(grads), (float*)ws);
-    return check_launch(h, "attn_train_backward");
-}
-
-extern "C" int cmgan_swap_axes(cmgan_handle* h, const float* in, float* out, int B, int A, int C, void* stream) {
-    if (!h) return CMGAN_E_BADARG;
-    if (!in || !out || in == out || B <= 0 || A <= 0 || C <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_swap_axes: bad argument");
-    launch_swap_axes(begin(h, stream), in, out, B, A, C);
-    return check_launch(h, "swap_axes");
-}
-
-extern "C" int cmgan_add(cmgan_handle* h, const float* a, const float* b, float* out, long long n, void* stream) {
-    if (!h) return CMGAN_E_BADARG;
-    if (!a || !b || !out || n <= 0 || (n & 3)) return fail(h, CMGAN_E_BADARG, "cmgan_add: bad argument (n must be a multiple of 4)");
-    launch_add(begin(h, stream), a, b, out, (long)n);
-    return check_launch(h, "add");
-}
-
-extern "C" size_t cmgan_layernorm_train_workspace_bytes(const cmgan_handle* h, long long M) {
-    if (!h || M <= 0) return 0;
-    return ln_train_ws_floats((long)M) * sizeof(float);
-}
-
-extern "C" int cmgan_layernorm_train_forward(cmgan_handle* h, const float* x, long long M, const float* weight,
-                                             const float* bias, float* y, void* stream) {
-    if (!h) return CMGAN_E_BADARG;
-    if (!x || !y || !weight || !bias || M <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_layernorm_train_forward: bad argument");
-    launch_ln_train_forward(begin(h, stream), x, (long)M, weight, bias, y);
-    return check_launch(h, "layernorm_train_forward");
-}
-
-extern "C" int cmgan_layernorm_train_backward(cmgan_handle* h, const float* x, const float* dy, long long M,
-                                              const float* weight, const float* bias, float* dx, float* dweight,
-                                              float* dbias, void* ws, size_t ws_bytes, void* stream) {
-    if (!h) return CMGAN_E_BADARG;
-    if (!x || !dy || !dx || !weight || !bias || !dweight || !dbias || M <= 0)
-        return fail(h, CMGAN_E_BADARG, "cmgan_layernorm_train_backward: bad argument");
-    if (int rc = check_ws(h, ws, ws_bytes, ln_train_ws_floats((long)M) * sizeof(float))) return rc;
-    launch_ln_train_backward(begin(h, stream), x, dy, (long)M, weight, bias, dx, dweight, dbias, (float*)ws);
-    return check_launch(h, "layernorm_train_backward");
-}
-
-extern "C" int cmgan_adamw_step(cmgan_handle* h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
-                                long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                int step, void* stream) {
-    if (!h) return CMGAN_E_BADARG;
-    if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) ||
-        !(beta2 >= 0.f && beta2 < 1.f))
-        return fail(h, CMGAN_E_BADARG, "cmgan_adamw_step: bad argument");
-    launch_adamw(begin(h, stream), params, grads, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, step);
-    return check_launch(h, "adamw_step");
 }
 
 // ------------------------------------------------------------------------------------

@@ -1,0 +1,188 @@
+// api_train.hip - C ABI of the training-step slices (include/cmgan_hip.h, "training" entry points): loss terms,
+// train-mode FeedForward / ConformerConvModule / Attention forward + backward, block glue, AdamW.  Kept apart from
+// api.hip so that the inference path's sources (and the digest bench.py ties its PMC evidence to) do not change
+// while the training side grows.
+#include "api_internal.h"
+#include "train.h"
+
+// ------------------------------------------------------------------------------------
+// training / validation step pieces (src/train.py)
+// ------------------------------------------------------------------------------------
+extern "C" int cmgan_loss_terms(cmgan_handle* h, const float* est_real, const float* est_imag,
+                                const float* clean_spec, int B, int T, const float* est_audio,
+                                const float* clean_audio, int L_audio, float* out4, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    const bool spec = est_real || est_imag || clean_spec, audio = est_audio || clean_audio;
+    if (!out4 || B <= 0 || (!spec && !audio)) return fail(h, CMGAN_E_BADARG, "cmgan_loss_terms: bad argument");
+    if (spec && (!est_real || !est_imag || !clean_spec || T <= 0))
+        return fail(h, CMGAN_E_BADARG, "cmgan_loss_terms: spectral terms need est_real, est_imag, clean_spec and T > 0");
+    if (audio && (!est_audio || !clean_audio || L_audio <= 0))
+        return fail(h, CMGAN_E_BADARG, "cmgan_loss_terms: time term needs est_audio, clean_audio and L_audio > 0");
+    launch_loss_terms(begin(h, stream), est_real, est_imag, clean_spec, B, (long)T * h->cfg.num_features, est_audio,
+                      clean_audio, (long)B * L_audio, h->d_loss, out4);
+    return check_launch(h, "loss_terms");
+}
+
+extern "C" size_t cmgan_ffn_train_workspace_bytes(const cmgan_handle* h, long long M) {
+    if (!h || M <= 0) return 0;
+    return ffn_train_ws_floats((long)M) * sizeof(float);
+}
+
+static bool ffn_params_ok(const cmgan_ffn_params* p) {
+    return p && p->ln_weight && p->ln_bias && p->w1 && p->b1 && p->w2 && p->b2;
+}
+static FfnTrainParams ffn_params(const cmgan_ffn_params* p) {
+    return FfnTrainParams{p->ln_weight, p->ln_bias, p->w1, p->b1, p->w2, p->b2};
+}
+
+extern "C" int cmgan_ffn_train_forward(cmgan_handle* h, const float* x, long long M, const cmgan_ffn_params* params,
+                                       const float* mask1, const float* mask2, float* y, void* ws, size_t ws_bytes,
+                                       void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !y || M <= 0 || !ffn_params_ok(params)) return fail(h, CMGAN_E_BADARG, "cmgan_ffn_train_forward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, ffn_train_ws_floats((long)M) * sizeof(float))) return rc;
+    launch_ffn_train_forward(begin(h, stream), x, (long)M, ffn_params(params), mask1, mask2, y, (float*)ws);
+    return check_launch(h, "ffn_train_forward");
+}
+
+extern "C" int cmgan_ffn_train_backward(cmgan_handle* h, const float* x, const float* dy, long long M,
+                                        const cmgan_ffn_params* params, const float* mask1, const float* mask2,
+                                        float* dx, const cmgan_ffn_params* grads, void* ws, size_t ws_bytes,
+                                        void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !dy || !dx || M <= 0 || !ffn_params_ok(params) || !ffn_params_ok(grads))
+        return fail(h, CMGAN_E_BADARG, "cmgan_ffn_train_backward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, ffn_train_ws_floats((long)M) * sizeof(float))) return rc;
+    launch_ffn_train_backward(begin(h, stream), x, dy, (long)M, ffn_params(params), mask1, mask2, dx, ffn_params(grads),
+                              (float*)ws);
+    return check_launch(h, "ffn_train_backward");
+}
+
+extern "C" size_t cmgan_convmod_train_workspace_bytes(const cmgan_handle* h, int N, int L) {
+    if (!h || N <= 0 || L <= 0) return 0;
+    return convmod_train_ws_floats(N, L) * sizeof(float);
+}
+
+static bool convmod_params_ok(const cmgan_convmod_params* p) {
+    return p && p->ln_weight && p->ln_bias && p->pw1_weight && p->pw1_bias && p->dw_weight && p->dw_bias &&
+           p->bn_weight && p->bn_bias && p->pw2_weight && p->pw2_bias;
+}
+static ConvModTrainParams convmod_params(const cmgan_convmod_params* p) {
+    return ConvModTrainParams{p->ln_weight, p->ln_bias, p->pw1_weight, p->pw1_bias, p->dw_weight, p->dw_bias,
+                              p->bn_weight, p->bn_bias, p->pw2_weight, p->pw2_bias};
+}
+
+extern "C" int cmgan_convmod_train_forward(cmgan_handle* h, const float* x, int N, int L,
+                                           const cmgan_convmod_params* params, float* running_mean,
+                                           float* running_var, float* y, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !y || N <= 0 || L <= 0 || !convmod_params_ok(params) || (!running_mean != !running_var))
+        return fail(h, CMGAN_E_BADARG, "cmgan_convmod_train_forward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, convmod_train_ws_floats(N, L) * sizeof(float))) return rc;
+    launch_convmod_train_forward(begin(h, stream), x, N, L, convmod_params(params), running_mean, running_var, y,
+                                 (float*)ws);
+    return check_launch(h, "convmod_train_forward");
+}
+
+extern "C" int cmgan_convmod_train_backward(cmgan_handle* h, const float* x, const float* dy, int N, int L,
+                                            const cmgan_convmod_params* params, float* dx,
+                                            const cmgan_convmod_params* grads, void* ws, size_t ws_bytes,
+                                            void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !dy || !dx || N <= 0 || L <= 0 || !convmod_params_ok(params) || !convmod_params_ok(grads))
+        return fail(h, CMGAN_E_BADARG, "cmgan_convmod_train_backward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, convmod_train_ws_floats(N, L) * sizeof(float))) return rc;
+    launch_convmod_train_backward(begin(h, stream), x, dy, N, L, convmod_params(params), dx, convmod_params(grads),
+                                  (float*)ws);
+    return check_launch(h, "convmod_train_backward");
+}
+
+extern "C" size_t cmgan_attn_train_workspace_bytes(const cmgan_handle* h, int N, int L) {
+    if (!h || N <= 0 || L <= 0 || L > attn_train_max_len()) return 0;
+    return attn_train_ws_floats(N, L) * sizeof(float);
+}
+
+static bool attn_params_ok(const cmgan_attn_params* p) {
+    return p && p->ln_weight && p->ln_bias && p->to_q_weight && p->to_kv_weight && p->to_out_weight &&
+           p->to_out_bias && p->rel_pos_emb;
+}
+static AttnTrainParams attn_params(const cmgan_attn_params* p) {
+    return AttnTrainParams{p->ln_weight, p->ln_bias, p->to_q_weight, p->to_kv_weight, p->to_out_weight, p->to_out_bias,
+                           p->rel_pos_emb};
+}
+
+extern "C" int cmgan_attn_train_forward(cmgan_handle* h, const float* x, int N, int L, const cmgan_attn_params* params,
+                                        const float* mask, float* y, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !y || N <= 0 || L <= 0 || !attn_params_ok(params))
+        return fail(h, CMGAN_E_BADARG, "cmgan_attn_train_forward: bad argument");
+    if (L > attn_train_max_len())
+        return fail(h, CMGAN_E_UNSUPPORTED, "cmgan_attn_train: sequences up to %d positions (got %d)", attn_train_max_len(), L);
+    if (int rc = check_ws(h, ws, ws_bytes, attn_train_ws_floats(N, L) * sizeof(float))) return rc;
+    launch_attn_train_forward(begin(h, stream), x, N, L, attn_params(params), h->cfg.max_pos_emb, mask, y, (float*)ws);
+    return check_launch(h, "attn_train_forward");
+}
+
+extern "C" int cmgan_attn_train_backward(cmgan_handle* h, const float* x, const float* dy, int N, int L,
+                                         const cmgan_attn_params* params, const float* mask, float* dx,
+                                         const cmgan_attn_params* grads, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !dy || !dx || N <= 0 || L <= 0 || !attn_params_ok(params) || !attn_params_ok(grads))
+        return fail(h, CMGAN_E_BADARG, "cmgan_attn_train_backward: bad argument");
+    if (L > attn_train_max_len())
+        return fail(h, CMGAN_E_UNSUPPORTED, "cmgan_attn_train: sequences up to %d positions (got %d)", attn_train_max_len(), L);
+    if (int rc = check_ws(h, ws, ws_bytes, attn_train_ws_floats(N, L) * sizeof(float))) return rc;
+    launch_attn_train_backward(begin(h, stream), x, dy, N, L, attn_params(params), h->cfg.max_pos_emb, mask, dx,
+                               attn_params(grads), (float*)ws);
+    return check_launch(h, "attn_train_backward");
+}
+
+extern "C" int cmgan_swap_axes(cmgan_handle* h, const float* in, float* out, int B, int A, int C, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!in || !out || in == out || B <= 0 || A <= 0 || C <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_swap_axes: bad argument");
+    launch_swap_axes(begin(h, stream), in, out, B, A, C);
+    return check_launch(h, "swap_axes");
+}
+
+extern "C" int cmgan_add(cmgan_handle* h, const float* a, const float* b, float* out, long long n, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!a || !b || !out || n <= 0 || (n & 3)) return fail(h, CMGAN_E_BADARG, "cmgan_add: bad argument (n must be a multiple of 4)");
+    launch_add(begin(h, stream), a, b, out, (long)n);
+    return check_launch(h, "add");
+}
+
+extern "C" size_t cmgan_layernorm_train_workspace_bytes(const cmgan_handle* h, long long M) {
+    if (!h || M <= 0) return 0;
+    return ln_train_ws_floats((long)M) * sizeof(float);
+}
+
+extern "C" int cmgan_layernorm_train_forward(cmgan_handle* h, const float* x, long long M, const float* weight,
+                                             const float* bias, float* y, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !y || !weight || !bias || M <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_layernorm_train_forward: bad argument");
+    launch_ln_train_forward(begin(h, stream), x, (long)M, weight, bias, y);
+    return check_launch(h, "layernorm_train_forward");
+}
+
+extern "C" int cmgan_layernorm_train_backward(cmgan_handle* h, const float* x, const float* dy, long long M,
+                                              const float* weight, const float* bias, float* dx, float* dweight,
+                                              float* dbias, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !dy || !dx || !weight || !bias || !dweight || !dbias || M <= 0)
+        return fail(h, CMGAN_E_BADARG, "cmgan_layernorm_train_backward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, ln_train_ws_floats((long)M) * sizeof(float))) return rc;
+    launch_ln_train_backward(begin(h, stream), x, dy, (long)M, weight, bias, dx, dweight, dbias, (float*)ws);
+    return check_launch(h, "layernorm_train_backward");
+}
+
+extern "C" int cmgan_adamw_step(cmgan_handle* h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                int step, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || n <= 0 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) ||
+        !(beta2 >= 0.f && beta2 < 1.f))
+        return fail(h, CMGAN_E_BADARG, "cmgan_adamw_step: bad argument");
+    launch_adamw(begin(h, stream), params, grads, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, step);
+    return check_launch(h, "adamw_step");
+}
+

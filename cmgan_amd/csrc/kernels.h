@@ -123,60 +123,5 @@ int  conv3x_ntiles(int T, int F, int cout);
 void launch_conv3_x3(LaunchCtx, const ConvArgs&, const void* w16, int B, int time_taps, int cout);
 void launch_selftest_x3(hipStream_t, const void* a_img, const float* b_fm, float* d, int M32);
 
-// ------------------------------- train.hip ---------------------------------------
-#define LOSS_BLOCKS 256                       // fixed partial-sum shape: results do not depend on the batch split
-void launch_loss_terms(LaunchCtx, const float* est_real, const float* est_imag, const float* clean_spec, int B,
-                       long P, const float* est_audio, const float* clean_audio, long naudio, double* partials,
-                       float* out4);
-
-// training-mode FeedForward (forward with dropout masks, full backward) on raw parameters
-struct FfnTrainParams {
-    float *gamma, *beta;      // PreNorm LayerNorm(64)                      conformer.py:68
-    float *w1, *b1;           // Linear(64, 256): weight [256,64], bias     conformer.py:140
-    float *w2, *b2;           // Linear(256, 64): weight [64,256], bias     conformer.py:143
-};
-#define FFN_WGRAD_SPLIT 64
-#define FFN_COLSUM_BLOCKS 128
-size_t ffn_train_ws_floats(long M);
-void launch_ffn_train_forward(LaunchCtx, const float* x, long M, const FfnTrainParams& p, const float* m1,
-                              const float* m2, float* y, float* ws);
-void launch_ffn_train_backward(LaunchCtx, const float* x, const float* dy, long M, const FfnTrainParams& p,
-                               const float* m1, const float* m2, float* dx, const FfnTrainParams& grad, float* ws);
-
-// training-mode ConformerConvModule (BatchNorm1d on batch statistics) forward + backward on raw parameters
-struct ConvModTrainParams {
-    float *ln_w, *ln_b;       // net.0  LayerNorm(64)                          conformer.py:161
-    float *pw1_w, *pw1_b;     // net.2  Conv1d(64, 256, 1): [256,64], [256]    conformer.py:163
-    float *dw_w, *dw_b;       // net.4  depthwise Conv1d k=31: [128,31], [128] conformer.py:165-167
-    float *bn_w, *bn_b;       // net.5  BatchNorm1d(128) gamma, beta           conformer.py:168
-    float *pw2_w, *pw2_b;     // net.7  Conv1d(128, 64, 1): [64,128], [64]     conformer.py:170
-};
-size_t convmod_train_ws_floats(int N, int L);
-void launch_convmod_train_forward(LaunchCtx, const float* x, int N, int L, const ConvModTrainParams& p,
-                                  float* running_mean, float* running_var, float* y, float* ws);
-void launch_convmod_train_backward(LaunchCtx, const float* x, const float* dy, int N, int L,
-                                   const ConvModTrainParams& p, float* dx, const ConvModTrainParams& grad, float* ws);
-// training-mode PreNorm(Attention) forward + backward on raw parameters
-struct AttnTrainParams {
-    float *ln_w, *ln_b;       // attn.norm               LayerNorm(64)          conformer.py:68
-    float *wq, *wkv;          // attn.fn.to_q [64,64], attn.fn.to_kv [128,64]   conformer.py:81-82 (no bias)
-    float *wo, *bo;           // attn.fn.to_out [64,64], [64]                   conformer.py:83
-    float *rel;               // attn.fn.rel_pos_emb [2 max_pos + 1, 16]        conformer.py:86
-};
-size_t attn_train_ws_floats(int N, int L);
-int attn_train_max_len();
-void launch_attn_train_forward(LaunchCtx, const float* x, int N, int L, const AttnTrainParams& p, int max_pos,
-                               const float* mask, float* y, float* ws);
-void launch_attn_train_backward(LaunchCtx, const float* x, const float* dy, int N, int L, const AttnTrainParams& p,
-                                int max_pos, const float* mask, float* dx, const AttnTrainParams& grad, float* ws);
-void launch_swap_axes(LaunchCtx, const float* in, float* out, int B, int A, int C);
-void launch_add(LaunchCtx, const float* a, const float* b, float* out, long n);
-size_t ln_train_ws_floats(long M);
-void launch_ln_train_forward(LaunchCtx, const float* x, long M, const float* gamma, const float* beta, float* y);
-void launch_ln_train_backward(LaunchCtx, const float* x, const float* dy, long M, const float* gamma, const float* beta,
-                              float* dx, float* dgamma, float* dbeta, float* ws);
-void launch_adamw(LaunchCtx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
-                  float eps, float wd, int step);
-
 // ------------------------------- selftest ---------------------------------------
 void launch_selftest_mfma(hipStream_t, const float* a_fm, const float* b_fm, float* d, int KB);

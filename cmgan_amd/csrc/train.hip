@@ -1,7 +1,7 @@
 // train.hip - device pieces of the reference's training / validation step (src/train.py) that sit directly on the
 // generator forward path: the non-adversarial loss terms of Trainer.calculate_generator_loss (train.py:124-151)
 // as deterministic reductions (the scalars the data-parallel step all-reduces over RCCL).
-#include "kernels.h"
+#include "train.h"
 
 // ---------------------------------------------------------------------------------
 // loss_ri  = mse(est_real, clean_real) + mse(est_imag, clean_imag)        train.py:135-137
