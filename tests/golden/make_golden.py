@@ -317,6 +317,23 @@ def main():
         tgr = {"grad_" + k.replace(".", "_"): named[k].grad.detach() for k in pick}
     save("tscb_train.npz", x=xs.detach(), dy=dys, y=ys.detach().contiguous(), dx=xs.grad.detach(), **tm, **tgr)
 
+    # -- 15. DilatedDenseNet (generator.py:6-47; the encoder's instance) with autograd gradients: dilated (2,3) convs
+    #        over a growing concat, InstanceNorm2d(affine) (identical in train and eval), PReLU; T > 8 so that the
+    #        dilation-8 layer sees real history
+    from models.generator import DilatedDenseNet
+    with torch.enable_grad():
+        ddn = DilatedDenseNet(depth=4, in_channels=64)
+        dsd = {k[len("dense_encoder.dilated_dense."):]: v for k, v in sd.items()
+               if k.startswith("dense_encoder.dilated_dense.")}
+        ddn.load_state_dict(dsd, strict=True)
+        ddn.train()
+        xd = rnd((2, 64, 13, 11), 71).requires_grad_(True)
+        dyd = rnd((2, 64, 13, 11), 72)
+        yd = ddn(xd)
+        yd.backward(dyd)
+        dgr = {"grad_" + k.replace(".", "_"): v.grad.detach() for k, v in ddn.named_parameters()}
+    save("dense_train.npz", x=xd.detach(), dy=dyd, y=yd.detach(), dx=xd.grad.detach(), **dgr)
+
     save("ffn_train.npz", x=xt.detach(), dy=dy, mask1=m1, mask2=m2, y=yt.detach(), dx=xt.grad.detach(),
          y_nomask=y0.detach(), dx_nomask=x0.grad.detach(), **grads, **grads0)
 

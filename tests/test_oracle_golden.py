@@ -219,6 +219,26 @@ def test_train_mode_tscb(sd):
             assert rel_err(leaf[name].grad, g[k]) < 5e-5, k
 
 
+def test_dense_block_gradients(sd):
+    """autograd through the oracle's dense_block (the gradient oracle of cmgan_amd.training.DenseBlockTrain)."""
+    g = load_golden("dense_train.npz")
+    pre = "dense_encoder.dilated_dense."
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith(pre)}
+    sdx = dict(sd)
+    sdx.update(leaf)
+    x = g["x"].clone().requires_grad_(True)
+    with torch.enable_grad():
+        y = O.dense_block(sdx, pre[:-1], x)
+        y.backward(g["dy"])
+    assert rel_err(y, g["y"]) < TOL and rel_err(x.grad, g["dx"]) < TOL
+    for k, v in leaf.items():
+        want = g["grad_" + k[len(pre):].replace(".", "_")]
+        if ".conv" in k and k.endswith(".bias"):     # a bias in front of an InstanceNorm: exactly zero gradient
+            assert float(v.grad.abs().max()) < 1e-4 * float(g["grad_norm1_bias"].abs().max())
+            continue
+        assert rel_err(v.grad, want) < 5e-5, k
+
+
 def test_validation_step_losses_match_the_reference(sd):
     """Generator half of Trainer.test_step: forward_generator_step + the three non-adversarial loss terms."""
     g = load_golden("valstep.npz")
