@@ -49,6 +49,10 @@ class AttnParams(Structure):
                                         "to_out_bias", "rel_pos_emb")]
 
 
+class DenseParams(Structure):
+    _fields_ = [(n, c_void_p * 4) for n in ("conv_weight", "conv_bias", "norm_weight", "norm_bias", "prelu_weight")]
+
+
 class KernelTime(Structure):
     _fields_ = [("name", c_char_p), ("ms", c_float)]
 
@@ -85,6 +89,11 @@ SIGNATURES = {
     "cmgan_layernorm_train_forward": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
     "cmgan_layernorm_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cmgan_dense_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "cmgan_dense_train_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DenseParams), c_void_p,
+                                          c_void_p, c_size_t, c_void_p]),
+    "cmgan_dense_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DenseParams),
+                                           c_void_p, POINTER(DenseParams), c_void_p, c_size_t, c_void_p]),
     "cmgan_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float,
                                  c_float, c_float, c_float, c_int, c_void_p]),
     "cmgan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),

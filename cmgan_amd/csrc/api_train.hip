@@ -175,6 +175,49 @@ extern "C" int cmgan_layernorm_train_backward(cmgan_handle* h, const float* x, c
     return check_launch(h, "layernorm_train_backward");
 }
 
+extern "C" size_t cmgan_dense_train_workspace_bytes(const cmgan_handle* h, int B, int T, int F) {
+    if (!h || B <= 0 || T <= 0 || F <= 0) return 0;
+    return dense_train_ws_floats(B, T, F) * sizeof(float);
+}
+
+static bool dense_params_ok(const cmgan_dense_params* p) {
+    if (!p) return false;
+    for (int i = 0; i < 4; ++i)
+        if (!p->conv_weight[i] || !p->conv_bias[i] || !p->norm_weight[i] || !p->norm_bias[i] || !p->prelu_weight[i]) return false;
+    return true;
+}
+static DenseTrainParams dense_params(const cmgan_dense_params* p) {
+    DenseTrainParams d;
+    for (int i = 0; i < 4; ++i) {
+        d.conv_w[i] = p->conv_weight[i]; d.conv_b[i] = p->conv_bias[i];
+        d.norm_w[i] = p->norm_weight[i]; d.norm_b[i] = p->norm_bias[i]; d.prelu_w[i] = p->prelu_weight[i];
+    }
+    return d;
+}
+
+extern "C" int cmgan_dense_train_forward(cmgan_handle* h, const float* x, int B, int T, int F,
+                                         const cmgan_dense_params* params, float* y, void* ws, size_t ws_bytes,
+                                         void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !y || B <= 0 || T <= 0 || F <= 0 || !dense_params_ok(params))
+        return fail(h, CMGAN_E_BADARG, "cmgan_dense_train_forward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, dense_train_ws_floats(B, T, F) * sizeof(float))) return rc;
+    launch_dense_train_forward(begin(h, stream), x, B, T, F, dense_params(params), y, (float*)ws);
+    return check_launch(h, "dense_train_forward");
+}
+
+extern "C" int cmgan_dense_train_backward(cmgan_handle* h, const float* x, const float* dy, int B, int T, int F,
+                                          const cmgan_dense_params* params, float* dx, const cmgan_dense_params* grads,
+                                          void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x || !dy || !dx || B <= 0 || T <= 0 || F <= 0 || !dense_params_ok(params) || !dense_params_ok(grads))
+        return fail(h, CMGAN_E_BADARG, "cmgan_dense_train_backward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, dense_train_ws_floats(B, T, F) * sizeof(float))) return rc;
+    launch_dense_train_backward(begin(h, stream), x, dy, B, T, F, dense_params(params), dx, dense_params(grads),
+                                (float*)ws);
+    return check_launch(h, "dense_train_backward");
+}
+
 extern "C" int cmgan_adamw_step(cmgan_handle* h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                 long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int step, void* stream) {

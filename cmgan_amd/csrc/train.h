@@ -56,6 +56,17 @@ size_t ln_train_ws_floats(long M);
 void launch_ln_train_forward(LaunchCtx, const float* x, long M, const float* gamma, const float* beta, float* y);
 void launch_ln_train_backward(LaunchCtx, const float* x, const float* dy, long M, const float* gamma, const float* beta,
                               float* dx, float* dgamma, float* dbeta, float* ws);
+// training-mode DilatedDenseNet (generator.py:6-47) forward + backward on raw parameters, channels-last [B,T,F,64]
+struct DenseTrainParams {
+    float *conv_w[4], *conv_b[4];     // conv{i+1}.weight [64, 64 (i+1), 2, 3], .bias [64]
+    float *norm_w[4], *norm_b[4];     // norm{i+1}  InstanceNorm2d(64, affine)
+    float *prelu_w[4];                // prelu{i+1} PReLU(64)
+};
+size_t dense_train_ws_floats(int B, int T, int F);
+void launch_dense_train_forward(LaunchCtx, const float* x, int B, int T, int F, const DenseTrainParams& p, float* y,
+                                float* ws);
+void launch_dense_train_backward(LaunchCtx, const float* x, const float* dy, int B, int T, int F,
+                                 const DenseTrainParams& p, float* dx, const DenseTrainParams& grad, float* ws);
 void launch_adamw(LaunchCtx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                   float eps, float wd, int step);
 

@@ -1391,3 +1391,418 @@ void launch_swap_axes(LaunchCtx ctx, const float* in, float* out, int B, int A, 
     LAUNCH(ctx, "swap_axes", (swap_axes_kernel<<<(unsigned)(want < 8192 ? (want > 0 ? want : 1) : 8192), 256, 0, ctx.stream>>>(
                                  in, out, A, C, total4)));
 }
+
+// =====================================================================================
+// Training-mode DilatedDenseNet (fourth backward slice of SURVEY.md N2; generator.py:6-47): four layers of
+//   pad(top = dil, left/right = 1) -> Conv2d(64 (i+1) -> 64, kernel (2,3), dilation (2^i, 1)) -> InstanceNorm2d(affine)
+//   -> PReLU(64) -> concat newest-first
+// on channels-last activations [B, T, F, 64].  The concat is never materialised: layer i reads "slots" a_0 = x,
+// a_s = output of layer s-1, and the reference's newest-first channel order is an index map into the weight
+// (slot s <-> input channels [64 (i - s), 64 (i - s + 1)) of conv{i+1}).  Convolutions are the per-position fp32-MFMA
+// chain (16 positions per wave, one 64x64 A image per (slot, tap), B fragments = the tap-shifted rows, zero outside
+// the plane); dgrad is the same chain with the transposed images and the opposite shifts, accumulated into per-slot
+// gradient planes; wgrad is a split-K token contraction with a shifted second operand.  InstanceNorm statistics and
+// its backward sums are per-(clip, channel) two-pass reductions in fp64.  A conv bias in front of an InstanceNorm
+// has an exactly zero gradient; it is still computed (column sum of dz) so that the ten "bias" tensors are written.
+// =====================================================================================
+#define DB_NCH 32                      // position chunks per clip of the per-(b, c) reductions
+
+// strided fragment-major pack: out[rb][kb][lane][r] = w[row * rs + col * cs]  (row/col swapped when transpose)
+__global__ void pack_fm_strided_kernel(const float* __restrict__ w, int R, int K, long rs, long cs, int transpose,
+                                       float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * K) return;
+    const int r = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+    const int KB = K / 16, rb = blk / KB, kb = blk - rb * KB;
+    const int row = 16 * rb + (lane & 15), col = 16 * kb + 4 * (lane >> 4) + r;
+    out[i] = transpose ? w[(long)col * rs + (long)row * cs] : w[(long)row * rs + (long)col * cs];
+}
+
+struct DbSlots { const float* p[5]; };
+
+// (b, t, f) of the 16 positions of a wave; `src` = flat row of the position shifted by (dt, df) or -1 outside the plane
+struct DbPos { long m; int b, t, f; bool ok; };
+__device__ __forceinline__ DbPos db_pos(long m0, int c, long M, int T, int F) {
+    DbPos q;
+    q.m = m0 + c;
+    q.ok = q.m < M;
+    const long mm = q.ok ? q.m : M - 1;
+    const long tf = (long)T * F;
+    q.b = (int)(mm / tf);
+    const int rem = (int)(mm - (long)q.b * tf);
+    q.t = rem / F;
+    q.f = rem - q.t * F;
+    return q;
+}
+__device__ __forceinline__ long db_shift(const DbPos& q, int dt, int df, int T, int F) {
+    const int t = q.t + dt, f = q.f + df;
+    return (q.ok && t >= 0 && t < T && f >= 0 && f < F) ? ((long)q.b * T + t) * F + f : -1;
+}
+
+// z[m][co] = bias[co] + sum_{slot, tap} W_{slot,tap} a_slot[m shifted by tap]      images: [slot][tap][4 ob][4 kb][64][4]
+template <int NS>
+__global__ __launch_bounds__(256) void db_conv_fwd_kernel(DbSlots in, const float* __restrict__ wimg,
+                                                          const float* __restrict__ bias, int B, int T, int F, int dil,
+                                                          float* __restrict__ z) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long M = (long)B * T * F;
+    const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (m0 >= M) return;
+    const DbPos q = db_pos(m0, c, M, T, F);
+    f32x4 acc[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) acc[ob] = ldg4(bias + 16 * ob + 4 * g);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+        for (int tap = 0; tap < 6; ++tap) {
+            const int kt = tap / 3, kf = tap - 3 * kt;
+            const long src = db_shift(q, (kt - 1) * dil, kf - 1, T, F);
+            f32x4 bfr[1][4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                bfr[0][kb] = ldg4(in.p[s] + (src < 0 ? 0 : src) * 64 + 16 * kb + 4 * g);
+                if (src < 0) bfr[0][kb] = splat4(0.f);
+            }
+            const float* wp = wimg + ((long)(s * 6 + tap) * 16) * 256 + lane * 4;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+                f32x4 a1[1] = {acc[ob]};
+                lin_acc<4, 1>(wp + (long)ob * 4 * 256, bfr, a1);
+                acc[ob] = a1[0];
+            }
+        }
+    }
+    if (q.ok) {
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) stg4(z + q.m * 64 + 16 * ob + 4 * g, acc[ob]);
+    }
+}
+
+// per-(clip, chunk, channel) sums over positions: MODE 0: (sum z, sum z^2) of z;  MODE 1 (backward): from z, the
+// incoming gradient ga and the layer's statistics / affine / slope: dn = ga * PReLU'(n) (written over ga) and
+// (sum dn, sum dn zhat, sum ga n [n < 0])
+template <int MODE>
+__global__ __launch_bounds__(256) void db_sums_kernel(const float* __restrict__ z, float* __restrict__ ga, int P,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ alpha, float* __restrict__ partial) {
+    __shared__ float red[4][64][3];
+    const int c = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int per = (P + DB_NCH - 1) / DB_NCH, p0 = chunk * per, p1 = p0 + per < P ? p0 + per : P;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    float mu = 0.f, rs = 0.f, gm = 0.f, bt = 0.f, al = 0.f;
+    if (MODE == 1) { mu = mean[b * 64 + c]; rs = rstd[b * 64 + c]; gm = gamma[c]; bt = beta[c]; al = alpha[c]; }
+    for (int p = p0 + sub; p < p1; p += 4) {
+        const long i = ((long)b * P + p) * 64 + c;
+        const float zv = z[i];
+        if (MODE == 0) {
+            s0 += zv;
+            s1 = fmaf(zv, zv, s1);
+        } else {
+            const float zh = (zv - mu) * rs, n = zh * gm + bt, gv = ga[i];
+            const float dn = n < 0.f ? gv * al : gv;
+            ga[i] = dn;
+            s0 += dn;
+            s1 = fmaf(dn, zh, s1);
+            s2 += n < 0.f ? gv * n : 0.f;
+        }
+    }
+    red[sub][c][0] = s0; red[sub][c][1] = s1; red[sub][c][2] = s2;
+    __syncthreads();
+    if (sub == 0) {
+        const long o = (((long)b * DB_NCH + chunk) * 64 + c) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) partial[o + k] = (red[0][c][k] + red[1][c][k]) + (red[2][c][k] + red[3][c][k]);
+    }
+}
+
+// forward statistics: mean, rstd per (b, c) from the chunk partials (fp64, chunk order)
+__global__ void db_stats_finalize_kernel(const float* __restrict__ partial, int B, double count, float* __restrict__ mean,
+                                         float* __restrict__ rstd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 64) return;
+    const int b = i >> 6, c = i & 63;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < DB_NCH; ++k) {
+        const long o = (((long)b * DB_NCH + k) * 64 + c) * 3;
+        s1 += (double)partial[o];
+        s2 += (double)partial[o + 1];
+    }
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    mean[i] = (float)mu;
+    rstd[i] = (float)(1.0 / sqrt(var + 1e-5));
+}
+
+// a = PReLU(InstanceNorm(z))
+__global__ __launch_bounds__(256) void db_norm_prelu_kernel(const float* __restrict__ z, long total, int P,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ alpha, float* __restrict__ a) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i & 63);
+        const long bc = (i >> 6) / P * 64 + c;
+        const float n = (z[i] - mean[bc]) * rstd[bc] * gamma[c] + beta[c];
+        a[i] = n >= 0.f ? n : alpha[c] * n;
+    }
+}
+
+// backward means per (b, c) and the per-channel parameter gradients (summed over clips in clip order)
+__global__ void db_bwd_finalize_kernel(const float* __restrict__ partial, int B, double count, float* __restrict__ m1,
+                                       float* __restrict__ m2, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ dalpha) {
+    const int c = threadIdx.x;
+    if (c >= 64) return;
+    double g = 0.0, bsum = 0.0, a = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < DB_NCH; ++k) {
+            const long o = (((long)b * DB_NCH + k) * 64 + c) * 3;
+            s0 += (double)partial[o]; s1 += (double)partial[o + 1]; s2 += (double)partial[o + 2];
+        }
+        m1[b * 64 + c] = (float)(s0 / count);
+        m2[b * 64 + c] = (float)(s1 / count);
+        bsum += s0; g += s1; a += s2;
+    }
+    dgamma[c] = (float)g; dbeta[c] = (float)bsum; dalpha[c] = (float)a;
+}
+
+// dz = gamma rstd (dn - mean(dn) - zhat mean(dn zhat)), in place on dn
+__global__ __launch_bounds__(256) void db_in_bwd_kernel(float* __restrict__ dn, const float* __restrict__ z, long total, int P,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ m1,
+                                                        const float* __restrict__ m2) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i & 63);
+        const long bc = (i >> 6) / P * 64 + c;
+        const float zh = (z[i] - mean[bc]) * rstd[bc];
+        dn[i] = gamma[c] * rstd[bc] * (dn[i] - m1[bc] - zh * m2[bc]);
+    }
+}
+
+// ga_slot[m][ci] += sum_tap W_{slot,tap}^T dz[m shifted by -tap]                images (transposed): [tap][4][4][64][4]
+__global__ __launch_bounds__(256) void db_conv_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ wimgT,
+                                                            int B, int T, int F, int dil, float* __restrict__ ga) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long M = (long)B * T * F;
+    const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (m0 >= M) return;
+    const DbPos q = db_pos(m0, c, M, T, F);
+    f32x4 acc[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) acc[ob] = splat4(0.f);
+#pragma unroll
+    for (int tap = 0; tap < 6; ++tap) {
+        const int kt = tap / 3, kf = tap - 3 * kt;
+        const long src = db_shift(q, -(kt - 1) * dil, -(kf - 1), T, F);     // the output position that read this input
+        f32x4 bfr[1][4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            bfr[0][kb] = ldg4(dz + (src < 0 ? 0 : src) * 64 + 16 * kb + 4 * g);
+            if (src < 0) bfr[0][kb] = splat4(0.f);
+        }
+        const float* wp = wimgT + ((long)tap * 16) * 256 + lane * 4;
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x4 a1[1] = {acc[ob]};
+            lin_acc<4, 1>(wp + (long)ob * 4 * 256, bfr, a1);
+            acc[ob] = a1[0];
+        }
+    }
+    if (q.ok) {
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            float* p = ga + q.m * 64 + 16 * ob + 4 * g;
+            stg4(p, ldg4(p) + acc[ob]);
+        }
+    }
+}
+
+// partial[tap][s][co][ci] = sum over the s-th token range of dz[m][co] * a_slot[m shifted by tap][ci]
+__global__ __launch_bounds__(256) void db_conv_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ a, int B,
+                                                            int T, int F, int dil, int nsplit,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[4][16 * 64];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int ib = blockIdx.x, tap = blockIdx.y, s = blockIdx.z;
+    const int kt = tap / 3, kf = tap - 3 * kt, dt = (kt - 1) * dil, df = kf - 1;
+    const long M = (long)B * T * F, tf = (long)T * F;
+    const long steps = (M + 15) / 16, per = (steps + nsplit - 1) / nsplit;
+    const long st0 = (long)s * per, st1 = st0 + per < steps ? st0 + per : steps;
+    f32x4 acc[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = splat4(0.f);
+    for (long st = st0 + wv; st < st1; st += 4) {
+        float av[4];
+        f32x4 bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = st * 16 + 4 * g + r;
+            const bool ok = m < M;
+            const long mm = ok ? m : M - 1;
+            const int b = (int)(mm / tf), rem = (int)(mm - (long)b * tf), t = rem / F + dt, f = rem % F + df;
+            const bool inb = ok && t >= 0 && t < T && f >= 0 && f < F;
+            const long src = inb ? ((long)b * T + t) * F + f : 0;
+            av[r] = ok ? dz[mm * 64 + 16 * ib + c] : 0.f;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const float v = a[src * 64 + 16 * jb + c];
+                bv[jb][r] = inb ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[jb] = mfma16(av[r], bv[jb][r], acc[jb]);
+    }
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][(4 * g + r) * 64 + 16 * jb + c] = acc[jb][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        const int i = e >> 6, j = e & 63;
+        partial[(((long)tap * nsplit + s) * 64 + 16 * ib + i) * 64 + j] = v;
+    }
+}
+
+// dW[co][cbase + ci][kt][kf] = sum_s partial[tap][s][co][ci]        (conv weight [64, Cin, 2, 3], tap = kt 3 + kf)
+__global__ void db_wgrad_scatter_kernel(const float* __restrict__ partial, int nsplit, int Cin, int cbase,
+                                        float* __restrict__ dW) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 6 * 4096) return;
+    const int tap = idx / 4096, e = idx - tap * 4096, co = e >> 6, ci = e & 63;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[((long)tap * nsplit + k) * 4096 + e];
+    dW[((long)co * Cin + cbase + ci) * 6 + tap] = s;
+}
+
+struct DbPlan { size_t img, imgT, a, z, ga, mean, rstd, part, m1, m2, wpart, cpart, total; };
+static DbPlan db_plan(int B, int T, int F) {
+    DbPlan p;
+    const size_t M = (size_t)B * T * F;
+    size_t cur = 0;
+    auto take = [&](size_t n) { const size_t o = cur; cur += (n + 63) & ~(size_t)63; return o; };
+    p.img = take(60 * 4096); p.imgT = take(60 * 4096);
+    p.a = take(4 * M * 64);            // a_1 .. a_4 (a_0 = x is the caller's)
+    p.z = take(4 * M * 64);
+    p.ga = take(5 * M * 64);           // gradients w.r.t. a_0 .. a_4
+    p.mean = take((size_t)4 * B * 64); p.rstd = take((size_t)4 * B * 64);
+    p.part = take((size_t)B * DB_NCH * 64 * 3);
+    p.m1 = take((size_t)B * 64); p.m2 = take((size_t)B * 64);
+    p.wpart = take((size_t)6 * FFN_WGRAD_SPLIT * 4096);
+    p.cpart = take((size_t)FFN_COLSUM_BLOCKS * 256);
+    p.total = cur;
+    return p;
+}
+size_t dense_train_ws_floats(int B, int T, int F) { return db_plan(B, T, F).total; }
+
+// image index of (layer i, slot s): layers own 6 (i+1) images each, in slot-major order
+static int db_img_index(int i, int s) { return 6 * (i * (i + 1) / 2 + s); }
+
+// all 6 (i+1) tap images of layer i, plain (blockIdx.z = 0) and transposed (1), in one launch
+__global__ void db_pack_layer_kernel(const float* __restrict__ w, int i, float* __restrict__ img, float* __restrict__ imgT) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;          // element of one 64x64 image
+    if (e >= 4096) return;
+    const int st = blockIdx.y, s = st / 6, tap = st - 6 * s, Cin = 64 * (i + 1);
+    const int cbase = 64 * (i - s);                                 // newest-first concat: slot s sits at channel block i - s
+    const int r = e & 3, lane = (e >> 2) & 63, blk = e >> 8, rb = blk >> 2, kb = blk & 3;
+    const int row = 16 * rb + (lane & 15), col = 16 * kb + 4 * (lane >> 4) + r;
+    const int co = blockIdx.z ? col : row, ci = blockIdx.z ? row : col;
+    const float v = w[((long)co * Cin + cbase + ci) * 6 + tap];
+    (blockIdx.z ? imgT : img)[(long)st * 4096 + e] = v;
+}
+
+static void db_pack_images(LaunchCtx ctx, const DenseTrainParams& p, float* ws, const DbPlan& pl) {
+    for (int i = 0; i < 4; ++i) {
+        const long off = (long)db_img_index(i, 0) * 4096;
+        LAUNCH(ctx, "dense_train_pack", (db_pack_layer_kernel<<<dim3(16, 6 * (i + 1), 2), 256, 0, ctx.stream>>>(
+                                            p.conv_w[i], i, ws + pl.img + off, ws + pl.imgT + off)));
+    }
+}
+
+template <int NS>
+static void db_launch_conv(LaunchCtx ctx, const DbSlots& in, const float* wimg, const float* bias, int B, int T, int F,
+                           int dil, float* z) {
+    const long M = (long)B * T * F;
+    LAUNCH(ctx, "dense_train_fwd", (db_conv_fwd_kernel<NS><<<(unsigned)((M + 63) / 64), 256, 0, ctx.stream>>>(
+                                       in, wimg, bias, B, T, F, dil, z)));
+}
+
+void launch_dense_train_forward(LaunchCtx ctx, const float* x, int B, int T, int F, const DenseTrainParams& p, float* y,
+                                float* ws) {
+    hipStream_t st = ctx.stream;
+    const DbPlan pl = db_plan(B, T, F);
+    const long M = (long)B * T * F;
+    const int P = T * F;
+    db_pack_images(ctx, p, ws, pl);
+    DbSlots in{};
+    in.p[0] = x;
+    for (int i = 0; i < 4; ++i) {
+        float* z = ws + pl.z + (size_t)i * M * 64;
+        float* a = i == 3 ? y : ws + pl.a + (size_t)i * M * 64;
+        const float* wimg = ws + pl.img + (long)db_img_index(i, 0) * 4096;
+        const int dil = 1 << i;
+        switch (i) {
+            case 0: db_launch_conv<1>(ctx, in, wimg, p.conv_b[i], B, T, F, dil, z); break;
+            case 1: db_launch_conv<2>(ctx, in, wimg, p.conv_b[i], B, T, F, dil, z); break;
+            case 2: db_launch_conv<3>(ctx, in, wimg, p.conv_b[i], B, T, F, dil, z); break;
+            default: db_launch_conv<4>(ctx, in, wimg, p.conv_b[i], B, T, F, dil, z); break;
+        }
+        float* mean = ws + pl.mean + (size_t)i * B * 64;
+        float* rstd = ws + pl.rstd + (size_t)i * B * 64;
+        LAUNCH(ctx, "dense_train_fwd", (db_sums_kernel<0><<<dim3(B, DB_NCH), 256, 0, st>>>(z, nullptr, P, nullptr, nullptr,
+                                                                                         nullptr, nullptr, nullptr,
+                                                                                         ws + pl.part)));
+        LAUNCH(ctx, "dense_train_fwd", (db_stats_finalize_kernel<<<(B * 64 + 255) / 256, 256, 0, st>>>(ws + pl.part, B,
+                                                                                                       (double)P, mean, rstd)));
+        LAUNCH(ctx, "dense_train_fwd", (db_norm_prelu_kernel<<<2048, 256, 0, st>>>(z, M * 64, P, mean, rstd, p.norm_w[i],
+                                                                                   p.norm_b[i], p.prelu_w[i], a)));
+        if (i < 3) in.p[i + 1] = a;
+    }
+}
+
+void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy, int B, int T, int F,
+                                 const DenseTrainParams& p, float* dx, const DenseTrainParams& grad, float* ws) {
+    hipStream_t st = ctx.stream;
+    const DbPlan pl = db_plan(B, T, F);
+    const long M = (long)B * T * F;
+    const int P = T * F;
+    db_pack_images(ctx, p, ws, pl);
+    auto ga = [&](int s) { return ws + pl.ga + (size_t)s * M * 64; };
+    auto aslot = [&](int s) -> const float* { return s == 0 ? x : ws + pl.a + (size_t)(s - 1) * M * 64; };
+    hipMemsetAsync(ws + pl.ga, 0, (size_t)4 * M * 64 * sizeof(float), st);                       // ga_0 .. ga_3
+    hipMemcpyAsync(ga(4), dy, (size_t)M * 64 * sizeof(float), hipMemcpyDeviceToDevice, st);      // only layer 3's output is returned
+    float* cpart = ws + pl.cpart;
+    for (int i = 3; i >= 0; --i) {
+        const float* z = ws + pl.z + (size_t)i * M * 64;
+        float* g = ga(i + 1);                              // dL/da_{i+1} -> dn -> dz, in place
+        const float* mean = ws + pl.mean + (size_t)i * B * 64;
+        const float* rstd = ws + pl.rstd + (size_t)i * B * 64;
+        LAUNCH(ctx, "dense_train_bwd", (db_sums_kernel<1><<<dim3(B, DB_NCH), 256, 0, st>>>(z, g, P, mean, rstd, p.norm_w[i],
+                                                                                         p.norm_b[i], p.prelu_w[i],
+                                                                                         ws + pl.part)));
+        LAUNCH(ctx, "dense_train_bwd", (db_bwd_finalize_kernel<<<1, 64, 0, st>>>(ws + pl.part, B, (double)P, ws + pl.m1,
+                                                                                ws + pl.m2, grad.norm_w[i], grad.norm_b[i],
+                                                                                grad.prelu_w[i])));
+        LAUNCH(ctx, "dense_train_bwd", (db_in_bwd_kernel<<<2048, 256, 0, st>>>(g, z, M * 64, P, mean, rstd, p.norm_w[i],
+                                                                               ws + pl.m1, ws + pl.m2)));
+        LAUNCH(ctx, "dense_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(g, M, 64, cpart)));
+        LAUNCH(ctx, "dense_train_reduce", (reduce_partials_kernel<<<1, 256, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64,
+                                                                                     grad.conv_b[i])));
+        const int dil = 1 << i, Cin = 64 * (i + 1);
+        for (int s = 0; s <= i; ++s) {
+            LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_kernel<<<dim3(4, 6, FFN_WGRAD_SPLIT), 256, 0, st>>>(
+                                                 g, aslot(s), B, T, F, dil, FFN_WGRAD_SPLIT, ws + pl.wpart)));
+            LAUNCH(ctx, "dense_train_reduce", (db_wgrad_scatter_kernel<<<96, 256, 0, st>>>(ws + pl.wpart, FFN_WGRAD_SPLIT, Cin,
+                                                                                           64 * (i - s), grad.conv_w[i])));
+            LAUNCH(ctx, "dense_train_bwd", (db_conv_dgrad_kernel<<<(unsigned)((M + 63) / 64), 256, 0, st>>>(
+                                               g, ws + pl.imgT + (long)db_img_index(i, s) * 4096, B, T, F, dil, ga(s))));
+        }
+    }
+    hipMemcpyAsync(dx, ga(0), (size_t)M * 64 * sizeof(float), hipMemcpyDeviceToDevice, st);
+}

@@ -10,6 +10,9 @@
 * `AdamW`, `step_lr`       - torch.optim.AdamW (train.py:63-66) as one HIP launch over a flat parameter bucket, and the
                              StepLR(30, 0.5) schedule (train.py:248-253); `FeedForwardTrain.allreduce_gradients()` is
                              the data-parallel gradient mean as ONE all-reduce over the same bucket (train.py:192).
+* `DenseBlockTrain`        - `DilatedDenseNet` (generator.py:6-47; encoder and both decoders) in train mode on
+                             channels-last [B, T, F, 64]: dilated (2,3) convs over slot views (no concat), InstanceNorm2d,
+                             PReLU; forward + full backward (twenty parameter gradients).
 * `TSCBTrain`              - one two-stage conformer block of the generator (generator.py:72-99) in TRAIN mode on
                              channels-last activations [B, T, F', 64]: time conformer per (b, f'), frequency conformer
                              per (b, t), both residuals, the layout flips as a HIP kernel.
@@ -36,11 +39,11 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from ._lib import AttnParams, ConvModParams, FfnParams, check
+from ._lib import AttnParams, ConvModParams, DenseParams, FfnParams, check
 from .dist import FlatBucket, allreduce_mean
 from .engine import Engine
 
-__all__ = ["TSCBTrain", "ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
+__all__ = ["DenseBlockTrain", "TSCBTrain", "ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
            "validation_step"]
 
 _KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.net.0.weight", "fn.fn.net.0.bias",
@@ -516,3 +519,73 @@ class TSCBTrain:
             dxt2 = self._swap(dxf, B, T, F2).view(B * F2, T, 64)
             dxt = self.time._add(self.time.backward(dxt2)[0], dxt2)
             return self._swap(dxt, B, F2, T)
+
+
+class DenseBlockTrain:
+    """`models.generator.DilatedDenseNet(depth=4, in_channels=64)` (generator.py:6-47) in train mode on the HIP kernels.
+    Activations are channels-last `[B, T, F, 64]`.  `state` = the block's tensors under the reference's key names
+    (`conv1.weight` ... `prelu4.weight`), e.g. the `dense_encoder.dilated_dense.` slice of the generator state_dict."""
+
+    SHAPES = {**{f"conv{i}.weight": (64, 64 * i, 2, 3) for i in range(1, 5)},
+              **{f"conv{i}.bias": (64,) for i in range(1, 5)},
+              **{f"norm{i}.weight": (64,) for i in range(1, 5)}, **{f"norm{i}.bias": (64,) for i in range(1, 5)},
+              **{f"prelu{i}.weight": (64,) for i in range(1, 5)}}
+
+    def __init__(self, state: Optional[Dict[str, torch.Tensor]] = None, engine: Optional[Engine] = None, device=None,
+                 views=None):
+        self.engine = engine if engine is not None else Engine(device=device)
+        self.param_bucket, self.grad_bucket, self.params, self.grads = _buckets(self.SHAPES, state, views,
+                                                                                self.engine.device)
+        self._ws: Optional[torch.Tensor] = None
+        self._shape = None
+
+    def _struct(self, tensors) -> DenseParams:
+        s = DenseParams()
+        for i in range(4):
+            s.conv_weight[i] = tensors[f"conv{i + 1}.weight"].data_ptr()
+            s.conv_bias[i] = tensors[f"conv{i + 1}.bias"].data_ptr()
+            s.norm_weight[i] = tensors[f"norm{i + 1}.weight"].data_ptr()
+            s.norm_bias[i] = tensors[f"norm{i + 1}.bias"].data_ptr()
+            s.prelu_weight[i] = tensors[f"prelu{i + 1}.weight"].data_ptr()
+        return s
+
+    def _workspace(self, B: int, T: int, F: int) -> torch.Tensor:
+        need = self.engine.lib.cmgan_dense_train_workspace_bytes(self.engine._h, B, T, F)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.engine.device)
+        return self._ws
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        eng = self.engine
+        x = eng._in(x, "x")
+        B, T, F, C = x.shape
+        if C != 64:
+            raise ValueError("expected channels-last [B, T, F, 64]")
+        ws = self._workspace(B, T, F)
+        y = torch.empty_like(x)
+        p = self._struct(self.params)
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_dense_train_forward(eng._h, x.data_ptr(), B, T, F, ctypes.byref(p), y.data_ptr(),
+                                                            ws.data_ptr(), ws.numel(), eng._stream()))
+        self._shape = (B, T, F)
+        return y
+
+    def backward(self, x: torch.Tensor, dy: torch.Tensor):
+        eng = self.engine
+        x, dy = eng._in(x, "x"), eng._in(dy, "dy")
+        B, T, F, _ = x.shape
+        if self._shape != (B, T, F) or dy.shape != x.shape:
+            raise RuntimeError("backward() needs the forward() of the same [B, T, F, 64] input first")
+        ws = self._workspace(B, T, F)
+        dx = torch.empty_like(x)
+        p, g = self._struct(self.params), self._struct(self.grads)
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_dense_train_backward(eng._h, x.data_ptr(), dy.data_ptr(), B, T, F, ctypes.byref(p),
+                                                             dx.data_ptr(), ctypes.byref(g), ws.data_ptr(), ws.numel(),
+                                                             eng._stream()))
+        return dx, self.grads
+
+    def allreduce_gradients(self) -> torch.Tensor:
+        if self.grad_bucket is None:
+            raise RuntimeError("this module's gradients are views of its parent's bucket: all-reduce the parent")
+        return allreduce_mean(self.grad_bucket.flat)

@@ -231,6 +231,26 @@ int cmgan_layernorm_train_backward(cmgan_handle* h, const float* x_dev, const fl
                                    float* dweight_dev, float* dbias_dev,
                                    void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Training-mode DilatedDenseNet with its backward - fourth slice of the training step:
+ * four layers of  pad(top = 2^i, l/r = 1) -> Conv2d(64 (i+1) -> 64, (2,3), dilation (2^i, 1)) -> InstanceNorm2d(affine)
+ * -> PReLU(64) -> cat([out, skip]) (newest first), returning the last layer's output (src/models/generator.py:6-47;
+ * used by the encoder and both decoders).  Activations are channels-last [B, T, F, 64] (the reference's NCHW tensor
+ * is x.permute(0, 2, 3, 1)).  Parameters are the RAW tensors conv{i}.weight [64, 64 i, 2, 3], conv{i}.bias,
+ * norm{i}.weight/bias, prelu{i}.weight for i = 1..4 (index i-1 below).  The forward keeps the layer outputs, the raw
+ * conv outputs and the InstanceNorm statistics in the workspace; the backward needs the SAME workspace untouched and
+ * writes dL/dx and the twenty parameter gradients (the conv biases sit in front of an InstanceNorm, so their
+ * gradients are zero up to rounding).                                                                            */
+typedef struct cmgan_dense_params {
+    float *conv_weight[4], *conv_bias[4], *norm_weight[4], *norm_bias[4], *prelu_weight[4];
+} cmgan_dense_params;
+size_t cmgan_dense_train_workspace_bytes(const cmgan_handle* h, int B, int T, int F);
+int cmgan_dense_train_forward(cmgan_handle* h, const float* x_dev, int B, int T, int F,
+                              const cmgan_dense_params* params, float* y_dev,
+                              void* workspace_dev, size_t workspace_bytes, void* stream);
+int cmgan_dense_train_backward(cmgan_handle* h, const float* x_dev, const float* dy_dev, int B, int T, int F,
+                               const cmgan_dense_params* params, float* dx_dev, const cmgan_dense_params* grads,
+                               void* workspace_dev, size_t workspace_bytes, void* stream);
+
 /* One torch.optim.AdamW step (src/train.py:63-66, 192-193; defaults betas (0.9, 0.999), eps 1e-8, weight_decay
  * 0.01) over a FLAT fp32 bucket of n parameters: params, grads and the two moment buffers are parallel device
  * arrays (the bucket the gradient all-reduce runs over), `step` = 1, 2, ... is the update count for the bias
