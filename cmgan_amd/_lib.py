@@ -53,6 +53,19 @@ class DenseParams(Structure):
     _fields_ = [(n, c_void_p * 4) for n in ("conv_weight", "conv_bias", "norm_weight", "norm_bias", "prelu_weight")]
 
 
+class EncoderParams(Structure):
+    _fields_ = ([(n, c_void_p) for n in ("conv1_weight", "conv1_bias", "norm1_weight", "norm1_bias", "prelu1_weight")]
+                + [("dense", DenseParams)]
+                + [(n, c_void_p) for n in ("conv2_weight", "conv2_bias", "norm2_weight", "norm2_bias", "prelu2_weight")])
+
+
+class DecoderParams(Structure):
+    _fields_ = ([("dense", DenseParams)]
+                + [(n, c_void_p) for n in ("sub_pixel_weight", "sub_pixel_bias", "conv_weight", "conv_bias",
+                                           "norm_weight", "norm_bias", "prelu_weight", "final_weight", "final_bias",
+                                           "prelu_out_weight")])
+
+
 class KernelTime(Structure):
     _fields_ = [("name", c_char_p), ("ms", c_float)]
 
@@ -94,6 +107,24 @@ SIGNATURES = {
                                           c_void_p, c_size_t, c_void_p]),
     "cmgan_dense_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DenseParams),
                                            c_void_p, POINTER(DenseParams), c_void_p, c_size_t, c_void_p]),
+    "cmgan_encoder_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "cmgan_encoder_train_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(EncoderParams), c_void_p,
+                                            c_void_p, c_size_t, c_void_p]),
+    "cmgan_encoder_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, POINTER(EncoderParams),
+                                             POINTER(EncoderParams), c_void_p, c_size_t, c_void_p]),
+    "cmgan_decoder_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "cmgan_decoder_train_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, POINTER(DecoderParams),
+                                            c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cmgan_decoder_train_backward": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                             POINTER(DecoderParams), c_void_p, POINTER(DecoderParams), c_void_p,
+                                             c_size_t, c_void_p]),
+    "cmgan_tscnet_prologue": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "cmgan_tscnet_epilogue_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                              c_void_p]),
+    "cmgan_tscnet_epilogue_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                               c_void_p, c_void_p]),
+    "cmgan_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
+                                    c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "cmgan_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float,
                                  c_float, c_float, c_float, c_int, c_void_p]),
     "cmgan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),

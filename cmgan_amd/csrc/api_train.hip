@@ -218,6 +218,136 @@ extern "C" int cmgan_dense_train_backward(cmgan_handle* h, const float* x, const
     return check_launch(h, "dense_train_backward");
 }
 
+// ---- DenseEncoder / MaskDecoder / ComplexDecoder -----------------------------------------------------------------
+static bool encoder_params_ok(const cmgan_encoder_params* p) {
+    return p && p->conv1_weight && p->conv1_bias && p->norm1_weight && p->norm1_bias && p->prelu1_weight &&
+           dense_params_ok(&p->dense) && p->conv2_weight && p->conv2_bias && p->norm2_weight && p->norm2_bias &&
+           p->prelu2_weight;
+}
+static EncoderTrainParams encoder_params(const cmgan_encoder_params* p) {
+    EncoderTrainParams e;
+    e.c1_w = p->conv1_weight; e.c1_b = p->conv1_bias; e.n1_w = p->norm1_weight; e.n1_b = p->norm1_bias; e.p1_w = p->prelu1_weight;
+    e.dense = dense_params(&p->dense);
+    e.c2_w = p->conv2_weight; e.c2_b = p->conv2_bias; e.n2_w = p->norm2_weight; e.n2_b = p->norm2_bias; e.p2_w = p->prelu2_weight;
+    return e;
+}
+
+extern "C" size_t cmgan_encoder_train_workspace_bytes(const cmgan_handle* h, int B, int T, int F) {
+    if (!h || B <= 0 || T <= 0 || F <= 0) return 0;
+    return encoder_train_ws_floats(B, T, F) * sizeof(float);
+}
+
+extern "C" int cmgan_encoder_train_forward(cmgan_handle* h, const float* xin, int B, int T, int F,
+                                           const cmgan_encoder_params* params, float* y, void* ws, size_t ws_bytes,
+                                           void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!xin || !y || B <= 0 || T <= 0 || F <= 0 || !encoder_params_ok(params))
+        return fail(h, CMGAN_E_BADARG, "cmgan_encoder_train_forward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, encoder_train_ws_floats(B, T, F) * sizeof(float))) return rc;
+    launch_encoder_train_forward(begin(h, stream), xin, B, T, F, encoder_params(params), y, (float*)ws);
+    return check_launch(h, "encoder_train_forward");
+}
+
+extern "C" int cmgan_encoder_train_backward(cmgan_handle* h, const float* xin, const float* dy, int B, int T, int F,
+                                            const cmgan_encoder_params* params, const cmgan_encoder_params* grads,
+                                            void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!xin || !dy || B <= 0 || T <= 0 || F <= 0 || !encoder_params_ok(params) || !encoder_params_ok(grads))
+        return fail(h, CMGAN_E_BADARG, "cmgan_encoder_train_backward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, encoder_train_ws_floats(B, T, F) * sizeof(float))) return rc;
+    launch_encoder_train_backward(begin(h, stream), xin, dy, B, T, F, encoder_params(params), encoder_params(grads),
+                                  (float*)ws);
+    return check_launch(h, "encoder_train_backward");
+}
+
+static bool decoder_params_ok(const cmgan_decoder_params* p, int kind) {
+    if (!p || !dense_params_ok(&p->dense) || !p->sub_pixel_weight || !p->sub_pixel_bias || !p->conv_weight ||
+        !p->conv_bias || !p->norm_weight || !p->norm_bias || !p->prelu_weight)
+        return false;
+    return kind == CMGAN_DECODER_COMPLEX || (p->final_weight && p->final_bias && p->prelu_out_weight);
+}
+static DecoderTrainParams decoder_params(const cmgan_decoder_params* p) {
+    DecoderTrainParams d;
+    d.dense = dense_params(&p->dense);
+    d.sp_w = p->sub_pixel_weight; d.sp_b = p->sub_pixel_bias; d.c_w = p->conv_weight; d.c_b = p->conv_bias;
+    d.n_w = p->norm_weight; d.n_b = p->norm_bias; d.p_w = p->prelu_weight;
+    d.f_w = p->final_weight; d.f_b = p->final_bias; d.po_w = p->prelu_out_weight;
+    return d;
+}
+
+extern "C" size_t cmgan_decoder_train_workspace_bytes(const cmgan_handle* h, int B, int T, int Fe) {
+    if (!h || B <= 0 || T <= 0 || Fe <= 0) return 0;
+    return decoder_train_ws_floats(B, T, Fe) * sizeof(float);
+}
+
+extern "C" int cmgan_decoder_train_forward(cmgan_handle* h, int kind, const float* x, int B, int T, int Fe,
+                                           const cmgan_decoder_params* params, float* out, void* ws, size_t ws_bytes,
+                                           void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if ((kind != CMGAN_DECODER_MASK && kind != CMGAN_DECODER_COMPLEX) || !x || !out || B <= 0 || T <= 0 || Fe <= 0 ||
+        !decoder_params_ok(params, kind))
+        return fail(h, CMGAN_E_BADARG, "cmgan_decoder_train_forward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, decoder_train_ws_floats(B, T, Fe) * sizeof(float))) return rc;
+    launch_decoder_train_forward(begin(h, stream), kind, x, B, T, Fe, decoder_params(params), out, (float*)ws);
+    return check_launch(h, "decoder_train_forward");
+}
+
+extern "C" int cmgan_decoder_train_backward(cmgan_handle* h, int kind, const float* x, const float* dout, int B, int T,
+                                            int Fe, const cmgan_decoder_params* params, float* dx,
+                                            const cmgan_decoder_params* grads, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if ((kind != CMGAN_DECODER_MASK && kind != CMGAN_DECODER_COMPLEX) || !x || !dout || !dx || B <= 0 || T <= 0 ||
+        Fe <= 0 || !decoder_params_ok(params, kind) || !decoder_params_ok(grads, kind))
+        return fail(h, CMGAN_E_BADARG, "cmgan_decoder_train_backward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, decoder_train_ws_floats(B, T, Fe) * sizeof(float))) return rc;
+    launch_decoder_train_backward(begin(h, stream), kind, x, dout, B, T, Fe, decoder_params(params), dx,
+                                  decoder_params(grads), (float*)ws);
+    return check_launch(h, "decoder_train_backward");
+}
+
+// ---- TSCNet.forward glue and the loss gradient ---------------------------------------------------------------------
+extern "C" int cmgan_tscnet_prologue(cmgan_handle* h, const float* spec, int B, int T, float* xin, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!spec || !xin || B <= 0 || T <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_tscnet_prologue: bad argument");
+    launch_tsc_prologue(begin(h, stream), spec, B, T, h->cfg.num_features, xin);
+    return check_launch(h, "tscnet_prologue");
+}
+
+extern "C" int cmgan_tscnet_epilogue_forward(cmgan_handle* h, const float* spec, const float* mask, const float* cplx,
+                                             int B, int T, float* est_real, float* est_imag, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!spec || !mask || !cplx || !est_real || !est_imag || B <= 0 || T <= 0)
+        return fail(h, CMGAN_E_BADARG, "cmgan_tscnet_epilogue_forward: bad argument");
+    launch_tsc_epilogue_forward(begin(h, stream), spec, mask, cplx, B, T, h->cfg.num_features, est_real, est_imag);
+    return check_launch(h, "tscnet_epilogue_forward");
+}
+
+extern "C" int cmgan_tscnet_epilogue_backward(cmgan_handle* h, const float* spec, const float* d_real,
+                                              const float* d_imag, int B, int T, float* dmask, float* dcplx,
+                                              void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!spec || !d_real || !d_imag || !dmask || !dcplx || B <= 0 || T <= 0)
+        return fail(h, CMGAN_E_BADARG, "cmgan_tscnet_epilogue_backward: bad argument");
+    launch_tsc_epilogue_backward(begin(h, stream), spec, d_real, d_imag, B, T, h->cfg.num_features, dmask, dcplx);
+    return check_launch(h, "tscnet_epilogue_backward");
+}
+
+extern "C" int cmgan_loss_backward(cmgan_handle* h, const float* est_real, const float* est_imag,
+                                   const float* clean_spec, int B, int T, const float* est_audio,
+                                   const float* clean_audio, float w_ri, float w_mag, float w_time, float* d_real,
+                                   float* d_imag, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!est_real || !est_imag || !clean_spec || !d_real || !d_imag || B <= 0 || T <= 1)
+        return fail(h, CMGAN_E_BADARG, "cmgan_loss_backward: bad argument");
+    if ((est_audio == nullptr) != (clean_audio == nullptr))
+        return fail(h, CMGAN_E_BADARG, "cmgan_loss_backward: the time term needs est_audio and clean_audio");
+    if (w_time != 0.f && !est_audio)
+        return fail(h, CMGAN_E_BADARG, "cmgan_loss_backward: w_time != 0 needs est_audio and clean_audio");
+    launch_loss_backward(begin(h, stream), est_real, est_imag, clean_spec, est_audio, clean_audio, B, T,
+                         h->cfg.num_features, h->cfg.n_fft, h->cfg.hop, w_ri, w_mag, w_time, d_real, d_imag);
+    return check_launch(h, "loss_backward");
+}
+
 extern "C" int cmgan_adamw_step(cmgan_handle* h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                 long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int step, void* stream) {

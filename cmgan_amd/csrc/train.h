@@ -67,6 +67,44 @@ void launch_dense_train_forward(LaunchCtx, const float* x, int B, int T, int F, 
                                 float* ws);
 void launch_dense_train_backward(LaunchCtx, const float* x, const float* dy, int B, int T, int F,
                                  const DenseTrainParams& p, float* dx, const DenseTrainParams& grad, float* ws);
+// training-mode DenseEncoder (generator.py:50-69): conv_1 (1x1, 3 -> 64) + IN + PReLU, DilatedDenseNet, conv_2
+// ((1,3), stride (1,2), padding (0,1)) + IN + PReLU; input [B,T,F,3] = (mag, re, im) per bin, output [B,T,F',64]
+struct EncoderTrainParams {
+    float *c1_w, *c1_b, *n1_w, *n1_b, *p1_w;      // conv_1.{0.weight [64,3,1,1], 0.bias, 1.weight, 1.bias, 2.weight}
+    DenseTrainParams dense;                       // dilated_dense.*
+    float *c2_w, *c2_b, *n2_w, *n2_b, *p2_w;      // conv_2.{0.weight [64,64,1,3], 0.bias, 1.weight, 1.bias, 2.weight}
+};
+size_t encoder_train_ws_floats(int B, int T, int F);
+void launch_encoder_train_forward(LaunchCtx, const float* xin, int B, int T, int F, const EncoderTrainParams& p, float* y,
+                                  float* ws);
+void launch_encoder_train_backward(LaunchCtx, const float* xin, const float* dy, int B, int T, int F,
+                                   const EncoderTrainParams& p, const EncoderTrainParams& grad, float* ws);
+// training-mode MaskDecoder (kind 0, generator.py:121-138) and ComplexDecoder (kind 1, generator.py:141-156):
+// DilatedDenseNet -> sub-pixel conv ((1,3), 64 -> 128, pixel shuffle x2 along frequency) -> head.
+//   kind 0: conv_1 (1,2) 64 -> 1, InstanceNorm2d(1) + PReLU(1), final_conv 1x1, PReLU(num_features)  -> [B,T,F]
+//   kind 1: InstanceNorm2d(64) + PReLU(64), conv (1,2) 64 -> 2                                        -> [B,T,F,2]
+struct DecoderTrainParams {
+    DenseTrainParams dense;          // dense_block.*
+    float *sp_w, *sp_b;              // sub_pixel.conv.{weight [128,64,1,3], bias [128]}
+    float *c_w, *c_b;                // conv_1 / conv: weight [NO,64,1,2], bias [NO]
+    float *n_w, *n_b, *p_w;          // norm.{weight,bias} and prelu.weight ([1] for kind 0, [64] for kind 1)
+    float *f_w, *f_b, *po_w;         // kind 0 only: final_conv.{weight [1,1,1,1], bias [1]}, prelu_out.weight [F]
+};
+size_t decoder_train_ws_floats(int B, int T, int Fe);
+void launch_decoder_train_forward(LaunchCtx, int kind, const float* x, int B, int T, int Fe, const DecoderTrainParams& p,
+                                  float* out, float* ws);
+void launch_decoder_train_backward(LaunchCtx, int kind, const float* x, const float* dout, int B, int T, int Fe,
+                                   const DecoderTrainParams& p, float* dx, const DecoderTrainParams& grad, float* ws);
+// TSCNet.forward glue (generator.py:176-201): spec [B,2,T,F] -> xin [B,T,F,3]; est = mask * spec + complex_out
+void launch_tsc_prologue(LaunchCtx, const float* spec, int B, int T, int F, float* xin);
+void launch_tsc_epilogue_forward(LaunchCtx, const float* spec, const float* mask, const float* cplx, int B, int T, int F,
+                                 float* est_real, float* est_imag);
+void launch_tsc_epilogue_backward(LaunchCtx, const float* spec, const float* d_real, const float* d_imag, int B, int T, int F,
+                                  float* dmask, float* dcplx);
+// gradient of w_ri loss_ri + w_mag loss_mag + w_time time_loss (train.py:133-148) with respect to est_real / est_imag
+void launch_loss_backward(LaunchCtx, const float* est_real, const float* est_imag, const float* clean_spec,
+                          const float* est_audio, const float* clean_audio, int B, int T, int F, int nfft, int hop, float w_ri,
+                          float w_mag, float w_time, float* d_real, float* d_imag);
 void launch_adamw(LaunchCtx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                   float eps, float wd, int step);
 

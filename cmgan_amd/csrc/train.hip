@@ -1806,3 +1806,757 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
     }
     hipMemcpyAsync(dx, ga(0), (size_t)M * 64 * sizeof(float), hipMemcpyDeviceToDevice, st);
 }
+
+// =====================================================================================
+// Encoder / decoder heads (generator.py:50-69, 102-156), training mode.
+//
+// "Row conv": Conv2d(64 -> 64 NG, kernel (1, KW), stride (1, SF), left padding PL) on channels-last planes, on the
+// per-position fp32-MFMA chain (tap images [kw][4 NG ob][4 kb]).  NG = 2 is the sub-pixel conv: its 128 output
+// channels are written pixel-shuffled, channel 64 r + c of position f -> channel c of position 2 f + r of a plane
+// that is twice as wide (SPConvTranspose2d, generator.py:102-119) - the shuffle is an index map, never a copy.
+// =====================================================================================
+struct RcGeom { int B, T, Fi, Fo, KW, SF, PL; };      // Fo = output positions per row (before the pixel shuffle)
+
+template <int NG>
+__global__ __launch_bounds__(256) void rc_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wimg,
+                                                     const float* __restrict__ bias, RcGeom gm, float* __restrict__ z) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long Mo = (long)gm.B * gm.T * gm.Fo;
+    const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (m0 >= Mo) return;
+    const long m = m0 + c;
+    const bool ok = m < Mo;
+    const long mm = ok ? m : Mo - 1;
+    const long bt = mm / gm.Fo;
+    const int fo = (int)(mm - bt * gm.Fo);
+    f32x4 acc[4 * NG];
+#pragma unroll
+    for (int ob = 0; ob < 4 * NG; ++ob) acc[ob] = ldg4(bias + 16 * ob + 4 * g);
+    for (int kw = 0; kw < gm.KW; ++kw) {
+        const int fi = fo * gm.SF - gm.PL + kw;
+        const bool inb = ok && fi >= 0 && fi < gm.Fi;
+        const long src = inb ? bt * gm.Fi + fi : 0;
+        f32x4 bfr[1][4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            bfr[0][kb] = ldg4(in + src * 64 + 16 * kb + 4 * g);
+            if (!inb) bfr[0][kb] = splat4(0.f);
+        }
+        const float* wp = wimg + ((long)kw * 4 * NG * 4) * 256 + lane * 4;
+#pragma unroll
+        for (int ob = 0; ob < 4 * NG; ++ob) {
+            f32x4 a1[1] = {acc[ob]};
+            lin_acc<4, 1>(wp + (long)ob * 4 * 256, bfr, a1);
+            acc[ob] = a1[0];
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int ob = 0; ob < 4 * NG; ++ob) {
+            const int r = ob >> 2;                                        // pixel-shuffle phase (0 when NG = 1)
+            const long orow = NG == 1 ? mm : (bt * gm.Fo + fo) * 2 + r;   // (b, t, 2 fo + r) of the 2 Fo wide plane
+            stg4(z + orow * 64 + 16 * (ob & 3) + 4 * g, acc[ob]);
+        }
+    }
+}
+
+// din[(b,t,fi)][ci] = sum_kw W_kw^T dz[(b,t,fo)] with fo SF - PL + kw = fi          images: [kw][4 ob(ci)][4 NG kb(co)]
+template <int NG>
+__global__ __launch_bounds__(256) void rc_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ wimgT,
+                                                       RcGeom gm, float* __restrict__ din) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const long Mi = (long)gm.B * gm.T * gm.Fi;
+    const long m0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+    if (m0 >= Mi) return;
+    const long m = m0 + c;
+    const bool ok = m < Mi;
+    const long mm = ok ? m : Mi - 1;
+    const long bt = mm / gm.Fi;
+    const int fi = (int)(mm - bt * gm.Fi);
+    f32x4 acc[4];
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) acc[ob] = splat4(0.f);
+    for (int kw = 0; kw < gm.KW; ++kw) {
+        const int num = fi + gm.PL - kw;
+        const int fo = num / gm.SF;
+        const bool inb = ok && num >= 0 && fo * gm.SF == num && fo < gm.Fo;
+        f32x4 bfr[1][4 * NG];
+#pragma unroll
+        for (int kb = 0; kb < 4 * NG; ++kb) {
+            const long srow = NG == 1 ? bt * gm.Fo + fo : (bt * gm.Fo + fo) * 2 + (kb >> 2);
+            bfr[0][kb] = ldg4(dz + (inb ? srow : 0) * 64 + 16 * (kb & 3) + 4 * g);
+            if (!inb) bfr[0][kb] = splat4(0.f);
+        }
+        const float* wp = wimgT + ((long)kw * 4 * 4 * NG) * 256 + lane * 4;
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x4 a1[1] = {acc[ob]};
+            lin_acc<4 * NG, 1>(wp + (long)ob * 4 * NG * 256, bfr, a1);
+            acc[ob] = a1[0];
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) stg4(din + mm * 64 + 16 * ob + 4 * g, acc[ob]);
+    }
+}
+
+// partial[kw][s][co][ci] = sum over the s-th range of output tokens of dz[.][co] * in[(b, t, fo SF - PL + kw)][ci]
+template <int NG>
+__global__ __launch_bounds__(256) void rc_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ in, RcGeom gm,
+                                                       int nsplit, float* __restrict__ partial) {
+    __shared__ float red[4][16 * 64];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int ib = blockIdx.x, kw = blockIdx.y, s = blockIdx.z;            // ib: output-channel block of 16
+    const long Mo = (long)gm.B * gm.T * gm.Fo;
+    const long steps = (Mo + 15) / 16, per = (steps + nsplit - 1) / nsplit;
+    const long st0 = (long)s * per, st1 = st0 + per < steps ? st0 + per : steps;
+    f32x4 acc[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) acc[jb] = splat4(0.f);
+    for (long st = st0 + wv; st < st1; st += 4) {
+        float av[4];
+        f32x4 bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = st * 16 + 4 * g + r;
+            const bool ok = m < Mo;
+            const long mm = ok ? m : Mo - 1;
+            const long bt = mm / gm.Fo;
+            const int fo = (int)(mm - bt * gm.Fo), fi = fo * gm.SF - gm.PL + kw;
+            const bool inb = ok && fi >= 0 && fi < gm.Fi;
+            const long src = inb ? bt * gm.Fi + fi : 0;
+            const long zrow = NG == 1 ? mm : (bt * gm.Fo + fo) * 2 + (ib >> 2);
+            av[r] = ok ? dz[zrow * 64 + 16 * (ib & 3) + c] : 0.f;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const float v = in[src * 64 + 16 * jb + c];
+                bv[jb][r] = inb ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[jb] = mfma16(av[r], bv[jb][r], acc[jb]);
+    }
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][(4 * g + r) * 64 + 16 * jb + c] = acc[jb][r];
+    __syncthreads();
+    const int Co = 64 * NG;
+    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        const int i = e >> 6, j = e & 63;
+        partial[(((long)kw * nsplit + s) * Co + 16 * ib + i) * 64 + j] = v;
+    }
+}
+
+// dW[co][ci][0][kw] = sum_s partial[kw][s][co][ci]                     (conv weight [Co, 64, 1, KW])
+__global__ void rc_wgrad_scatter_kernel(const float* __restrict__ partial, int nsplit, int Co, int KW,
+                                        float* __restrict__ dW) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= KW * Co * 64) return;
+    const int kw = idx / (Co * 64), e = idx - kw * Co * 64;               // e = co * 64 + ci
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[((long)kw * nsplit + k) * Co * 64 + e];
+    dW[(long)e * KW + kw] = s;
+}
+
+// tap images of a row conv: plain [kw][Co/16][4] and transposed [kw][4][Co/16]
+__global__ void rc_pack_kernel(const float* __restrict__ w, int Co, int KW, float* __restrict__ img, float* __restrict__ imgT) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = Co * 64;
+    if (e >= n) return;
+    const int kw = blockIdx.y;
+    const int r = e & 3, lane = (e >> 2) & 63, blk = e >> 8;
+    {   // plain: rows = co (Co), cols = ci (64): KB = 4
+        const int rb = blk >> 2, kb = blk & 3;
+        const int co = 16 * rb + (lane & 15), ci = 16 * kb + 4 * (lane >> 4) + r;
+        img[(long)kw * n + e] = w[((long)co * 64 + ci) * KW + kw];
+    }
+    {   // transposed: rows = ci (64), cols = co (Co): KB = Co / 16
+        const int KB = Co / 16, rb = blk / KB, kb = blk - rb * KB;
+        const int ci = 16 * rb + (lane & 15), co = 16 * kb + 4 * (lane >> 4) + r;
+        imgT[(long)kw * n + e] = w[((long)co * 64 + ci) * KW + kw];
+    }
+}
+
+// ---- conv_1 of the encoder: Conv2d(3 -> 64, 1x1) on the [mag, re, im] planes (generator.py:54) --------------------
+__global__ __launch_bounds__(256) void c1_fwd_kernel(const float* __restrict__ xin, long M, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ z) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < M * 64; i += (long)gridDim.x * 256) {
+        const long m = i >> 6;
+        const int co = (int)(i & 63);
+        z[i] = b[co] + w[co * 3] * xin[m * 3] + w[co * 3 + 1] * xin[m * 3 + 1] + w[co * 3 + 2] * xin[m * 3 + 2];
+    }
+}
+// partial[blk][co][ci] = sum over the block's positions of dz[m][co] * xin[m][ci]
+__global__ __launch_bounds__(256) void c1_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ xin, long M,
+                                                       float* __restrict__ partial) {
+    __shared__ float red[4][64][3];
+    const int co = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const long per = (M + gridDim.x - 1) / gridDim.x, m0 = (long)blockIdx.x * per, m1 = m0 + per < M ? m0 + per : M;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (long m = m0 + sub; m < m1; m += 4) {
+        const float d = dz[m * 64 + co];
+        s0 = fmaf(d, xin[m * 3], s0); s1 = fmaf(d, xin[m * 3 + 1], s1); s2 = fmaf(d, xin[m * 3 + 2], s2);
+    }
+    red[sub][co][0] = s0; red[sub][co][1] = s1; red[sub][co][2] = s2;
+    __syncthreads();
+    if (sub == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            partial[((long)blockIdx.x * 64 + co) * 3 + k] = (red[0][co][k] + red[1][co][k]) + (red[2][co][k] + red[3][co][k]);
+    }
+}
+
+// InstanceNorm2d(64, affine) + PReLU(64) on a channels-last plane: forward (statistics -> mean, rstd) ...
+static void in_prelu_forward(LaunchCtx ctx, const float* z, int B, int P, const float* gamma, const float* beta,
+                             const float* alpha, float* mean, float* rstd, float* part, float* a) {
+    hipStream_t st = ctx.stream;
+    LAUNCH(ctx, "in_prelu_train", (db_sums_kernel<0><<<dim3(B, DB_NCH), 256, 0, st>>>(z, nullptr, P, nullptr, nullptr, nullptr,
+                                                                                    nullptr, nullptr, part)));
+    LAUNCH(ctx, "in_prelu_train", (db_stats_finalize_kernel<<<(B * 64 + 255) / 256, 256, 0, st>>>(part, B, (double)P, mean, rstd)));
+    LAUNCH(ctx, "in_prelu_train", (db_norm_prelu_kernel<<<2048, 256, 0, st>>>(z, (long)B * P * 64, P, mean, rstd, gamma, beta,
+                                                                              alpha, a)));
+}
+// ... and backward: g holds dL/da on entry and dL/dz on exit; the three parameter gradients are written
+static void in_prelu_backward(LaunchCtx ctx, const float* z, float* g, int B, int P, const float* gamma, const float* beta,
+                              const float* alpha, const float* mean, const float* rstd, float* part, float* m1, float* m2,
+                              float* dgamma, float* dbeta, float* dalpha) {
+    hipStream_t st = ctx.stream;
+    LAUNCH(ctx, "in_prelu_train", (db_sums_kernel<1><<<dim3(B, DB_NCH), 256, 0, st>>>(z, g, P, mean, rstd, gamma, beta, alpha,
+                                                                                    part)));
+    LAUNCH(ctx, "in_prelu_train", (db_bwd_finalize_kernel<<<1, 64, 0, st>>>(part, B, (double)P, m1, m2, dgamma, dbeta, dalpha)));
+    LAUNCH(ctx, "in_prelu_train", (db_in_bwd_kernel<<<2048, 256, 0, st>>>(g, z, (long)B * P * 64, P, mean, rstd, gamma, m1, m2)));
+}
+
+template <int NG>
+static void rc_forward(LaunchCtx ctx, const float* in, const float* img, const float* bias, const RcGeom& gm, float* z) {
+    const long Mo = (long)gm.B * gm.T * gm.Fo;
+    LAUNCH(ctx, "rowconv_train", (rc_fwd_kernel<NG><<<(unsigned)((Mo + 63) / 64), 256, 0, ctx.stream>>>(in, img, bias, gm, z)));
+}
+template <int NG>
+static void rc_backward(LaunchCtx ctx, const float* dz, const float* in, const float* imgT, const RcGeom& gm, float* din,
+                        float* dW, float* wpart) {
+    hipStream_t st = ctx.stream;
+    const long Mi = (long)gm.B * gm.T * gm.Fi;
+    LAUNCH(ctx, "rowconv_train", (rc_wgrad_kernel<NG><<<dim3(4 * NG, gm.KW, FFN_WGRAD_SPLIT), 256, 0, st>>>(
+                                     dz, in, gm, FFN_WGRAD_SPLIT, wpart)));
+    const int nw = gm.KW * 64 * NG * 64;
+    LAUNCH(ctx, "rowconv_train", (rc_wgrad_scatter_kernel<<<(nw + 255) / 256, 256, 0, st>>>(wpart, FFN_WGRAD_SPLIT, 64 * NG,
+                                                                                            gm.KW, dW)));
+    if (din)
+        LAUNCH(ctx, "rowconv_train", (rc_dgrad_kernel<NG><<<(unsigned)((Mi + 63) / 64), 256, 0, st>>>(dz, imgT, gm, din)));
+}
+
+// ---- DenseEncoder (generator.py:50-69) --------------------------------------------------------------------------
+struct EncPlan { size_t img2, img2T, z1, a1, d, z2, g, st, part, m, wpart, cpart, dense, total; };
+static EncPlan enc_plan(int B, int T, int F) {
+    EncPlan p;
+    const size_t M = (size_t)B * T * F, F2 = (F - 1) / 2 + 1, M2 = (size_t)B * T * F2;
+    size_t cur = 0;
+    auto take = [&](size_t n) { const size_t o = cur; cur += (n + 63) & ~(size_t)63; return o; };
+    p.img2 = take(3 * 4096); p.img2T = take(3 * 4096);
+    p.z1 = take(M * 64); p.a1 = take(M * 64); p.d = take(M * 64); p.z2 = take(M2 * 64);
+    p.g = take(M * 64);                         // gradient plane (dd, then da1 / dz1)
+    p.st = take((size_t)4 * B * 64);            // mean1, rstd1, mean2, rstd2
+    p.part = take((size_t)B * DB_NCH * 64 * 3);
+    p.m = take((size_t)2 * B * 64);
+    p.wpart = take((size_t)3 * FFN_WGRAD_SPLIT * 4096);
+    p.cpart = take((size_t)FFN_COLSUM_BLOCKS * 256);
+    p.dense = take(dense_train_ws_floats(B, T, F));
+    p.total = cur;
+    return p;
+}
+size_t encoder_train_ws_floats(int B, int T, int F) { return enc_plan(B, T, F).total; }
+
+void launch_encoder_train_forward(LaunchCtx ctx, const float* xin, int B, int T, int F, const EncoderTrainParams& p,
+                                  float* y, float* ws) {
+    hipStream_t st = ctx.stream;
+    const EncPlan pl = enc_plan(B, T, F);
+    const long M = (long)B * T * F;
+    const int F2 = (F - 1) / 2 + 1;
+    const RcGeom g2{B, T, F, F2, 3, 2, 1};
+    LAUNCH(ctx, "encoder_train", (rc_pack_kernel<<<dim3(16, 3), 256, 0, st>>>(p.c2_w, 64, 3, ws + pl.img2, ws + pl.img2T)));
+    LAUNCH(ctx, "encoder_train", (c1_fwd_kernel<<<2048, 256, 0, st>>>(xin, M, p.c1_w, p.c1_b, ws + pl.z1)));
+    float* stt = ws + pl.st;
+    in_prelu_forward(ctx, ws + pl.z1, B, T * F, p.n1_w, p.n1_b, p.p1_w, stt, stt + B * 64, ws + pl.part, ws + pl.a1);
+    launch_dense_train_forward(ctx, ws + pl.a1, B, T, F, p.dense, ws + pl.d, ws + pl.dense);
+    rc_forward<1>(ctx, ws + pl.d, ws + pl.img2, p.c2_b, g2, ws + pl.z2);
+    in_prelu_forward(ctx, ws + pl.z2, B, T * F2, p.n2_w, p.n2_b, p.p2_w, stt + 2 * B * 64, stt + 3 * B * 64, ws + pl.part, y);
+}
+
+void launch_encoder_train_backward(LaunchCtx ctx, const float* xin, const float* dy, int B, int T, int F,
+                                   const EncoderTrainParams& p, const EncoderTrainParams& grad, float* ws) {
+    hipStream_t st = ctx.stream;
+    const EncPlan pl = enc_plan(B, T, F);
+    const long M = (long)B * T * F;
+    const int F2 = (F - 1) / 2 + 1;
+    const long M2 = (long)B * T * F2;
+    const RcGeom g2{B, T, F, F2, 3, 2, 1};
+    float* stt = ws + pl.st;
+    float* cpart = ws + pl.cpart;
+    LAUNCH(ctx, "encoder_train", (rc_pack_kernel<<<dim3(16, 3), 256, 0, st>>>(p.c2_w, 64, 3, ws + pl.img2, ws + pl.img2T)));
+    // conv_2 + IN + PReLU: dy -> dz2 (kept in the front of the [M,64] gradient plane)
+    float* dz2 = ws + pl.g;
+    hipMemcpyAsync(dz2, dy, (size_t)M2 * 64 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    in_prelu_backward(ctx, ws + pl.z2, dz2, B, T * F2, p.n2_w, p.n2_b, p.p2_w, stt + 2 * B * 64, stt + 3 * B * 64, ws + pl.part,
+                      ws + pl.m, ws + pl.m + B * 64, grad.n2_w, grad.n2_b, grad.p2_w);
+    LAUNCH(ctx, "encoder_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz2, M2, 64, cpart)));
+    LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<1, 256, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64, grad.c2_b)));
+    // the weight gradient reads conv_2's input d; only then is d overwritten by its own gradient dd
+    rc_backward<1>(ctx, dz2, ws + pl.d, ws + pl.img2T, g2, nullptr, grad.c2_w, ws + pl.wpart);
+    LAUNCH(ctx, "rowconv_train", (rc_dgrad_kernel<1><<<(unsigned)((M + 63) / 64), 256, 0, st>>>(dz2, ws + pl.img2T, g2,
+                                                                                               ws + pl.d)));
+    // dilated dense block: x = a1, dy = dd (in pl.d) -> da1 (into pl.g; dz2 is dead)
+    launch_dense_train_backward(ctx, ws + pl.a1, ws + pl.d, B, T, F, p.dense, ws + pl.g, grad.dense, ws + pl.dense);
+    // conv_1 + IN + PReLU
+    float* dz1 = ws + pl.g;
+    in_prelu_backward(ctx, ws + pl.z1, dz1, B, T * F, p.n1_w, p.n1_b, p.p1_w, stt, stt + B * 64, ws + pl.part, ws + pl.m,
+                      ws + pl.m + B * 64, grad.n1_w, grad.n1_b, grad.p1_w);
+    LAUNCH(ctx, "encoder_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz1, M, 64, cpart)));
+    LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<1, 256, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64, grad.c1_b)));
+    LAUNCH(ctx, "encoder_train", (c1_wgrad_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz1, xin, M, ws + pl.wpart)));
+    LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<1, 256, 0, st>>>(ws + pl.wpart, FFN_COLSUM_BLOCKS, 192, grad.c1_w)));
+}
+
+// ---- decoder tails: Conv2d(64 -> NO, (1,2)) with NO = 1 (mask head) or 2 (complex head) on a [R, W, 64] plane -------
+// out[(r, f)][o] = b[o] + sum_{kw, ci} w[o][ci][0][kw] in[(r, f + kw)][ci],  f < W - 1.       (generator.py:126,148)
+// 16 lanes share one output position: the 128-float window (two adjacent rows) is read once, coalesced.
+template <int NO>
+__global__ __launch_bounds__(256) void tail_fwd_kernel(const float* __restrict__ in, long R, int W, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ out) {
+    const int l = threadIdx.x & 15;
+    const long Mo = R * (W - 1);
+    float wv[NO][8];
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int j = 8 * l + e, kw = j >> 6, ci = j & 63;
+            wv[o][e] = w[(o * 64 + ci) * 2 + kw];
+        }
+    for (long m = (long)blockIdx.x * 16 + (threadIdx.x >> 4); m < Mo; m += (long)gridDim.x * 16) {
+        const long r = m / (W - 1);
+        const long base = (m + r) * 64;                         // position (r, f) of the W wide plane = m + r
+        const f32x4 v0 = ldg4(in + base + 8 * l), v1 = ldg4(in + base + 8 * l + 4);
+        float s[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a = fmaf(wv[o][e], v0[e], a); a = fmaf(wv[o][4 + e], v1[e], a); }
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) a += __shfl_xor(a, d, 16);
+            s[o] = a;
+        }
+        if (l == 0) {
+#pragma unroll
+            for (int o = 0; o < NO; ++o) out[m * NO + o] = s[o] + b[o];
+        }
+    }
+}
+// din[(r, fi)][ci] = sum_{kw, o} w[o][ci][0][kw] dz[(r, fi - kw)][o]
+template <int NO>
+__global__ __launch_bounds__(256) void tail_dgrad_kernel(const float* __restrict__ dz, long R, int W, const float* __restrict__ w,
+                                                         float* __restrict__ din) {
+    const long total = R * W * 64;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ci = (int)(i & 63);
+        const long pos = i >> 6, r = pos / W;
+        const int fi = (int)(pos - r * W);
+        float s = 0.f;
+#pragma unroll
+        for (int kw = 0; kw < 2; ++kw) {
+            const int f = fi - kw;
+            if (f < 0 || f >= W - 1) continue;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) s = fmaf(w[(o * 64 + ci) * 2 + kw], dz[(r * (W - 1) + f) * NO + o], s);
+        }
+        din[i] = s;
+    }
+}
+// partial[blk][o][ci][kw] = sum over the block's output positions of dz[m][o] in[(r, f + kw)][ci]
+template <int NO>
+__global__ __launch_bounds__(256) void tail_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ in, long R, int W,
+                                                         float* __restrict__ partial) {
+    __shared__ float red[4][NO * 128];
+    const int ci = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const long Mo = R * (W - 1);
+    const long per = (Mo + gridDim.x - 1) / gridDim.x, m0 = (long)blockIdx.x * per, m1 = m0 + per < Mo ? m0 + per : Mo;
+    float s[NO][2];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) s[o][0] = s[o][1] = 0.f;
+    for (long m = m0 + sub; m < m1; m += 4) {
+        const long r = m / (W - 1);
+        const float x0 = in[(m + r) * 64 + ci], x1 = in[(m + r + 1) * 64 + ci];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const float d = dz[m * NO + o];
+            s[o][0] = fmaf(d, x0, s[o][0]);
+            s[o][1] = fmaf(d, x1, s[o][1]);
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NO; ++o) { red[sub][(o * 64 + ci) * 2] = s[o][0]; red[sub][(o * 64 + ci) * 2 + 1] = s[o][1]; }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NO * 128; e += 256)
+        partial[(long)blockIdx.x * NO * 128 + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+}
+
+template <int NO>
+static void tail_forward(LaunchCtx ctx, const float* in, long R, int W, const float* w, const float* b, float* out) {
+    LAUNCH(ctx, "tail_train", (tail_fwd_kernel<NO><<<2048, 256, 0, ctx.stream>>>(in, R, W, w, b, out)));
+}
+// dW, db and the data gradient of a tail conv; wpart needs FFN_COLSUM_BLOCKS * NO * 128 floats, cpart FFN_COLSUM_BLOCKS * 256
+template <int NO>
+static void tail_backward(LaunchCtx ctx, const float* dz, const float* in, long R, int W, const float* w, float* din, float* dW,
+                          float* db, float* wpart, float* cpart) {
+    hipStream_t st = ctx.stream;
+    LAUNCH(ctx, "tail_train", (tail_wgrad_kernel<NO><<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz, in, R, W, wpart)));
+    LAUNCH(ctx, "tail_train", (reduce_partials_kernel<<<1, 256, 0, st>>>(wpart, FFN_COLSUM_BLOCKS, NO * 128, dW)));
+    LAUNCH(ctx, "tail_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz, R * (W - 1), NO, cpart)));
+    LAUNCH(ctx, "tail_train", (reduce_partials_kernel<<<1, 256, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, NO, db)));
+    LAUNCH(ctx, "tail_train", (tail_dgrad_kernel<NO><<<2048, 256, 0, st>>>(dz, R, W, w, din)));
+}
+
+// ---- mask head after conv_1: InstanceNorm2d(1, affine) + PReLU(1) + Conv2d(1,1,1x1) + PReLU(num_features) -----------
+//   n = gamma zhat + beta,  a = PReLU_alpha(n),  u = wf a + bf,  mask = PReLU_{alphaf[f]}(u)        (generator.py:127-138)
+struct MaskTailP { const float *gamma, *beta, *alpha, *wf, *bf, *alphaf; };
+struct MaskTailG { float *gamma, *beta, *alpha, *wf, *bf, *alphaf; };
+
+__global__ __launch_bounds__(256) void mt_stats_kernel(const float* __restrict__ t1, int P, float* __restrict__ partial) {
+    __shared__ float red[256][2];
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int per = (P + DB_NCH - 1) / DB_NCH, p0 = chunk * per, p1 = p0 + per < P ? p0 + per : P;
+    float s0 = 0.f, s1 = 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) { const float v = t1[(long)b * P + p]; s0 += v; s1 = fmaf(v, v, s1); }
+    red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d) { red[threadIdx.x][0] += red[threadIdx.x + d][0]; red[threadIdx.x][1] += red[threadIdx.x + d][1]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[((long)b * DB_NCH + chunk) * 2] = red[0][0]; partial[((long)b * DB_NCH + chunk) * 2 + 1] = red[0][1]; }
+}
+__global__ void mt_stats_finalize_kernel(const float* __restrict__ partial, int B, double count, float* __restrict__ mean,
+                                         float* __restrict__ rstd) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < DB_NCH; ++k) { s1 += (double)partial[((long)b * DB_NCH + k) * 2]; s2 += (double)partial[((long)b * DB_NCH + k) * 2 + 1]; }
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    mean[b] = (float)mu;
+    rstd[b] = (float)(1.0 / sqrt(var + 1e-5));
+}
+__global__ __launch_bounds__(256) void mt_apply_kernel(const float* __restrict__ t1, long total, int P, int F,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       MaskTailP p, float* __restrict__ mask) {
+    const float gm = p.gamma[0], bt = p.beta[0], al = p.alpha[0], wf = p.wf[0], bf = p.bf[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / P;
+        const int f = (int)(i % F);
+        const float n = (t1[i] - mean[b]) * rstd[b] * gm + bt;
+        const float a = n >= 0.f ? n : al * n;
+        const float u = fmaf(wf, a, bf);
+        mask[i] = u >= 0.f ? u : p.alphaf[f] * u;
+    }
+}
+// backward pass 1: g = dL/dmask on entry, dn on exit; partial[b][chunk][5] = (sum dn, sum dn zhat, sum da n [n<0],
+// sum du a, sum du)
+__global__ __launch_bounds__(256) void mt_bwd_sums_kernel(const float* __restrict__ t1, float* __restrict__ g, int P, int F,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          MaskTailP p, float* __restrict__ partial) {
+    __shared__ float red[256][5];
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int per = (P + DB_NCH - 1) / DB_NCH, p0 = chunk * per, p1 = p0 + per < P ? p0 + per : P;
+    const float gm = p.gamma[0], bt = p.beta[0], al = p.alpha[0], wf = p.wf[0], bf = p.bf[0], mu = mean[b], rs = rstd[b];
+    float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = p0 + threadIdx.x; q < p1; q += 256) {
+        const long i = (long)b * P + q;
+        const int f = q % F;
+        const float zh = (t1[i] - mu) * rs, n = zh * gm + bt, a = n >= 0.f ? n : al * n, u = fmaf(wf, a, bf);
+        const float du = u >= 0.f ? g[i] : g[i] * p.alphaf[f];
+        const float da = du * wf, dn = n >= 0.f ? da : da * al;
+        g[i] = dn;
+        s[0] += dn; s[1] = fmaf(dn, zh, s[1]); s[2] += n < 0.f ? da * n : 0.f; s[3] = fmaf(du, a, s[3]); s[4] += du;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) red[threadIdx.x][k] = s[k];
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if ((int)threadIdx.x < d)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) red[threadIdx.x][k] += red[threadIdx.x + d][k];
+        __syncthreads();
+    }
+    if (threadIdx.x < 5) partial[((long)b * DB_NCH + chunk) * 5 + threadIdx.x] = red[0][threadIdx.x];
+}
+__global__ void mt_bwd_finalize_kernel(const float* __restrict__ partial, int B, double count, float* __restrict__ m1,
+                                       float* __restrict__ m2, MaskTailG gr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double t[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < B; ++b) {
+        double s[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < DB_NCH; ++k)
+            for (int j = 0; j < 5; ++j) s[j] += (double)partial[((long)b * DB_NCH + k) * 5 + j];
+        m1[b] = (float)(s[0] / count);
+        m2[b] = (float)(s[1] / count);
+        for (int j = 0; j < 5; ++j) t[j] += s[j];
+    }
+    gr.beta[0] = (float)t[0]; gr.gamma[0] = (float)t[1]; gr.alpha[0] = (float)t[2]; gr.wf[0] = (float)t[3]; gr.bf[0] = (float)t[4];
+}
+// backward pass 2: dt1 = gamma rstd (dn - mean dn - zhat mean(dn zhat)), in place
+__global__ __launch_bounds__(256) void mt_in_bwd_kernel(float* __restrict__ g, const float* __restrict__ t1, long total, int P,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ m1,
+                                                        const float* __restrict__ m2) {
+    const float gm = gamma[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / P;
+        const float zh = (t1[i] - mean[b]) * rstd[b];
+        g[i] = gm * rstd[b] * (g[i] - m1[b] - zh * m2[b]);
+    }
+}
+// dalphaf[f] = sum_{b,t} dL/dmask u [u < 0]: one block per frequency, rows in (b, t) order
+__global__ __launch_bounds__(256) void mt_dalphaf_kernel(const float* __restrict__ t1, const float* __restrict__ dmask, int B,
+                                                         int T, int F, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, MaskTailP p, float* __restrict__ dalphaf) {
+    __shared__ float red[256];
+    const int f = blockIdx.x;
+    const float gm = p.gamma[0], bt = p.beta[0], al = p.alpha[0], wf = p.wf[0], bf = p.bf[0];
+    float s = 0.f;
+    for (long r = threadIdx.x; r < (long)B * T; r += 256) {
+        const long b = r / T, i = r * F + f;
+        const float n = (t1[i] - mean[b]) * rstd[b] * gm + bt, a = n >= 0.f ? n : al * n, u = fmaf(wf, a, bf);
+        s += u < 0.f ? dmask[i] * u : 0.f;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) dalphaf[f] = red[0];
+}
+
+// ---- MaskDecoder / ComplexDecoder (generator.py:121-156) ----------------------------------------------------------
+struct DecPlan { size_t img, imgT, d, s, a, t1, g, g2, st, part, m, wpart, cpart, dense, total; };
+static DecPlan dec_plan(int B, int T, int Fe) {
+    DecPlan p;
+    const size_t Me = (size_t)B * T * Fe, Ms = 2 * Me;
+    size_t cur = 0;
+    auto take = [&](size_t n) { const size_t o = cur; cur += (n + 63) & ~(size_t)63; return o; };
+    p.img = take(3 * 8192); p.imgT = take(3 * 8192);
+    p.d = take(Me * 64);                        // dense block output (sub-pixel input); later its gradient
+    p.s = take(Ms * 64);                        // sub-pixel output [B,T,2 Fe,64] (pre-norm for the complex head)
+    p.a = take(Ms * 64);                        // complex head: PReLU(IN(s))
+    p.t1 = take(Ms);                            // mask head: conv_1 output [B,T,2 Fe - 1]
+    p.g = take(Ms * 64);                        // gradient plane on the 2 Fe wide grid
+    p.g2 = take(Ms * 2);                        // gradient of the head output (dn / dt1, or a copy of dc)
+    p.st = take((size_t)2 * B * 64);
+    p.part = take((size_t)B * DB_NCH * 64 * 3);
+    p.m = take((size_t)2 * B * 64);
+    p.wpart = take((size_t)3 * FFN_WGRAD_SPLIT * 8192);
+    p.cpart = take((size_t)FFN_COLSUM_BLOCKS * 256);
+    p.dense = take(dense_train_ws_floats(B, T, Fe));
+    p.total = cur;
+    return p;
+}
+size_t decoder_train_ws_floats(int B, int T, int Fe) { return dec_plan(B, T, Fe).total; }
+
+static MaskTailP mask_tail_params(const DecoderTrainParams& p) { return {p.n_w, p.n_b, p.p_w, p.f_w, p.f_b, p.po_w}; }
+
+// kind 0: mask head -> out [B,T,2 Fe - 1];  kind 1: complex head -> out [B,T,2 Fe - 1,2]
+void launch_decoder_train_forward(LaunchCtx ctx, int kind, const float* x, int B, int T, int Fe, const DecoderTrainParams& p,
+                                  float* out, float* ws) {
+    hipStream_t st = ctx.stream;
+    const DecPlan pl = dec_plan(B, T, Fe);
+    const int W = 2 * Fe, F = W - 1;
+    const long R = (long)B * T;
+    const RcGeom gs{B, T, Fe, Fe, 3, 1, 1};
+    LAUNCH(ctx, "decoder_train", (rc_pack_kernel<<<dim3(32, 3), 256, 0, st>>>(p.sp_w, 128, 3, ws + pl.img, ws + pl.imgT)));
+    launch_dense_train_forward(ctx, x, B, T, Fe, p.dense, ws + pl.d, ws + pl.dense);
+    rc_forward<2>(ctx, ws + pl.d, ws + pl.img, p.sp_b, gs, ws + pl.s);
+    float* stt = ws + pl.st;
+    if (kind == 0) {
+        tail_forward<1>(ctx, ws + pl.s, R, W, p.c_w, p.c_b, ws + pl.t1);
+        LAUNCH(ctx, "decoder_train", (mt_stats_kernel<<<dim3(B, DB_NCH), 256, 0, st>>>(ws + pl.t1, T * F, ws + pl.part)));
+        LAUNCH(ctx, "decoder_train", (mt_stats_finalize_kernel<<<(B + 63) / 64, 64, 0, st>>>(ws + pl.part, B, (double)T * F, stt,
+                                                                                             stt + B)));
+        LAUNCH(ctx, "decoder_train", (mt_apply_kernel<<<1024, 256, 0, st>>>(ws + pl.t1, R * F, T * F, F, stt, stt + B,
+                                                                            mask_tail_params(p), out)));
+    } else {
+        in_prelu_forward(ctx, ws + pl.s, B, T * W, p.n_w, p.n_b, p.p_w, stt, stt + B * 64, ws + pl.part, ws + pl.a);
+        tail_forward<2>(ctx, ws + pl.a, R, W, p.c_w, p.c_b, out);
+    }
+}
+
+void launch_decoder_train_backward(LaunchCtx ctx, int kind, const float* x, const float* dout, int B, int T, int Fe,
+                                   const DecoderTrainParams& p, float* dx, const DecoderTrainParams& grad, float* ws) {
+    hipStream_t st = ctx.stream;
+    const DecPlan pl = dec_plan(B, T, Fe);
+    const int W = 2 * Fe, F = W - 1;
+    const long R = (long)B * T, Me = R * Fe;
+    const RcGeom gs{B, T, Fe, Fe, 3, 1, 1};
+    float* stt = ws + pl.st;
+    float* g = ws + pl.g;
+    float* g2 = ws + pl.g2;
+    LAUNCH(ctx, "decoder_train", (rc_pack_kernel<<<dim3(32, 3), 256, 0, st>>>(p.sp_w, 128, 3, ws + pl.img, ws + pl.imgT)));
+    if (kind == 0) {
+        const MaskTailP mp = mask_tail_params(p);
+        const MaskTailG mg{grad.n_w, grad.n_b, grad.p_w, grad.f_w, grad.f_b, grad.po_w};
+        LAUNCH(ctx, "decoder_train", (mt_dalphaf_kernel<<<F, 256, 0, st>>>(ws + pl.t1, dout, B, T, F, stt, stt + B, mp,
+                                                                          grad.po_w)));
+        hipMemcpyAsync(g2, dout, (size_t)R * F * sizeof(float), hipMemcpyDeviceToDevice, st);
+        LAUNCH(ctx, "decoder_train", (mt_bwd_sums_kernel<<<dim3(B, DB_NCH), 256, 0, st>>>(ws + pl.t1, g2, T * F, F, stt, stt + B,
+                                                                                        mp, ws + pl.part)));
+        LAUNCH(ctx, "decoder_train", (mt_bwd_finalize_kernel<<<1, 64, 0, st>>>(ws + pl.part, B, (double)T * F, ws + pl.m,
+                                                                              ws + pl.m + B, mg)));
+        LAUNCH(ctx, "decoder_train", (mt_in_bwd_kernel<<<1024, 256, 0, st>>>(g2, ws + pl.t1, R * F, T * F, stt, stt + B, p.n_w,
+                                                                             ws + pl.m, ws + pl.m + B)));
+        tail_backward<1>(ctx, g2, ws + pl.s, R, W, p.c_w, g, grad.c_w, grad.c_b, ws + pl.wpart, ws + pl.cpart);
+    } else {
+        tail_backward<2>(ctx, dout, ws + pl.a, R, W, p.c_w, g, grad.c_w, grad.c_b, ws + pl.wpart, ws + pl.cpart);
+        in_prelu_backward(ctx, ws + pl.s, g, B, T * W, p.n_w, p.n_b, p.p_w, stt, stt + B * 64, ws + pl.part, ws + pl.m,
+                          ws + pl.m + B * 64, grad.n_w, grad.n_b, grad.p_w);
+    }
+    // sub-pixel conv: g = dL/ds on the 2 Fe wide grid = [Me, 128] rows in conv-channel order (64 r + c)
+    LAUNCH(ctx, "decoder_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(g, Me, 128, ws + pl.cpart)));
+    LAUNCH(ctx, "decoder_train", (reduce_partials_kernel<<<1, 256, 0, st>>>(ws + pl.cpart, FFN_COLSUM_BLOCKS, 128, grad.sp_b)));
+    rc_backward<2>(ctx, g, ws + pl.d, ws + pl.imgT, gs, nullptr, grad.sp_w, ws + pl.wpart);
+    LAUNCH(ctx, "rowconv_train", (rc_dgrad_kernel<2><<<(unsigned)((Me + 63) / 64), 256, 0, st>>>(g, ws + pl.imgT, gs, ws + pl.d)));
+    launch_dense_train_backward(ctx, x, ws + pl.d, B, T, Fe, p.dense, dx, grad.dense, ws + pl.dense);
+}
+
+// ---- TSCNet.forward glue (generator.py:176-201) --------------------------------------------------------------------
+// prologue: spec [B,2,T,F] (compressed re, im) -> xin [B,T,F,3] = (|spec|, re, im), the encoder's channels-last input
+__global__ __launch_bounds__(256) void tsc_prologue_kernel(const float* __restrict__ spec, int B, long P, float* __restrict__ xin) {
+    const long total = (long)B * P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / P, q = i - b * P;
+        const float re = spec[(2 * b) * P + q], im = spec[(2 * b + 1) * P + q];
+        xin[i * 3] = sqrtf(re * re + im * im);
+        xin[i * 3 + 1] = re;
+        xin[i * 3 + 2] = im;
+    }
+}
+// epilogue: est = mask |spec| (cos, sin)(angle spec) + complex_out = mask (re, im) + complex_out     generator.py:192-199
+__global__ __launch_bounds__(256) void tsc_epilogue_fwd_kernel(const float* __restrict__ spec, const float* __restrict__ mask,
+                                                               const float* __restrict__ cplx, int B, long P,
+                                                               float* __restrict__ est_real, float* __restrict__ est_imag) {
+    const long total = (long)B * P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / P, q = i - b * P;
+        const float re = spec[(2 * b) * P + q], im = spec[(2 * b + 1) * P + q], m = mask[i];
+        est_real[i] = fmaf(m, re, cplx[2 * i]);
+        est_imag[i] = fmaf(m, im, cplx[2 * i + 1]);
+    }
+}
+__global__ __launch_bounds__(256) void tsc_epilogue_bwd_kernel(const float* __restrict__ spec, const float* __restrict__ d_real,
+                                                               const float* __restrict__ d_imag, int B, long P,
+                                                               float* __restrict__ dmask, float* __restrict__ dcplx) {
+    const long total = (long)B * P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / P, q = i - b * P;
+        const float re = spec[(2 * b) * P + q], im = spec[(2 * b + 1) * P + q], gr = d_real[i], gi = d_imag[i];
+        dmask[i] = fmaf(gr, re, gi * im);
+        dcplx[2 * i] = gr;
+        dcplx[2 * i + 1] = gi;
+    }
+}
+void launch_tsc_prologue(LaunchCtx ctx, const float* spec, int B, int T, int F, float* xin) {
+    LAUNCH(ctx, "tsc_glue_train", (tsc_prologue_kernel<<<1024, 256, 0, ctx.stream>>>(spec, B, (long)T * F, xin)));
+}
+void launch_tsc_epilogue_forward(LaunchCtx ctx, const float* spec, const float* mask, const float* cplx, int B, int T, int F,
+                                 float* est_real, float* est_imag) {
+    LAUNCH(ctx, "tsc_glue_train", (tsc_epilogue_fwd_kernel<<<1024, 256, 0, ctx.stream>>>(spec, mask, cplx, B, (long)T * F, est_real,
+                                                                                         est_imag)));
+}
+void launch_tsc_epilogue_backward(LaunchCtx ctx, const float* spec, const float* d_real, const float* d_imag, int B, int T, int F,
+                                  float* dmask, float* dcplx) {
+    LAUNCH(ctx, "tsc_glue_train", (tsc_epilogue_bwd_kernel<<<1024, 256, 0, ctx.stream>>>(spec, d_real, d_imag, B, (long)T * F, dmask,
+                                                                                         dcplx)));
+}
+
+// ---- gradient of the non-adversarial generator loss (train.py:100-112, 133-148) with respect to est_real / est_imag ---
+//   L = w_ri (mse(er, cr) + mse(ei, ci)) + w_mag mse(|e|, |c|) + w_time mean |istft(uncompress(e)) - clean|
+// Time term: dL/d audio = w_time sign(est - clean) / (B La); the adjoint of torch.istft (window, overlap-add, envelope
+// division, centre trim) followed by the adjoint of the one-sided inverse real DFT is a windowed forward real DFT of
+// the envelope-normalised gradient: gU[f] = (c_f / N) sum_k df[k] e^{-2 pi i f k / N}, c_f = 1 at DC / Nyquist, else 2.
+// Then the uncompress (utils.py:32-39) U = e |e|^(p-1), p = 1/0.3, in Cartesian form:
+//   dL/der = s gUr + (p-1) |e|^(p-3) er (er gUr + ei gUi),   s = |e|^(p-1)   (same for ei).
+__device__ __forceinline__ float hamming_periodic(int k, int n) { return 0.54f - 0.46f * cospif(2.0f * (float)k / (float)n); }
+
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ est_real, const float* __restrict__ est_imag,
+                                                       const float* __restrict__ clean_spec, const float* __restrict__ est_audio,
+                                                       const float* __restrict__ clean_audio, int B, int T, int F, int nfft,
+                                                       int hop, float w_ri, float w_mag, float w_time,
+                                                       float* __restrict__ d_real, float* __restrict__ d_imag) {
+    extern __shared__ float sm[];
+    float* df = sm;                 // [nfft] windowed, envelope-normalised audio gradient of this frame
+    float* tc = sm + nfft;          // [nfft] cos(2 pi j / nfft)
+    float* ts = sm + 2 * nfft;      // [nfft] sin(2 pi j / nfft)
+    const int b = blockIdx.x / T, t = blockIdx.x - b * T;
+    const long La = (long)hop * (T - 1);
+    const bool has_time = est_audio && clean_audio && w_time != 0.f;
+    if (has_time) {
+        const float ga = w_time / (float)((double)B * (double)La);
+        for (int k = threadIdx.x; k < nfft; k += 256) {
+            float sn, cs;
+            sincospif(2.0f * (float)k / (float)nfft, &sn, &cs);
+            tc[k] = cs; ts[k] = sn;
+            const long n = (long)t * hop + k;                   // index in the centre-padded signal
+            const long a = n - nfft / 2;                        // index in the returned audio
+            float v = 0.f;
+            if (a >= 0 && a < La) {
+                float env = 0.f;
+                int t0 = (int)((n - nfft + hop) / hop); if (t0 < 0) t0 = 0;
+                int t1 = (int)(n / hop); if (t1 > T - 1) t1 = T - 1;
+                for (int tt = t0; tt <= t1; ++tt) { const float w = hamming_periodic((int)(n - (long)tt * hop), nfft); env = fmaf(w, w, env); }
+                const float d = est_audio[b * La + a] - clean_audio[b * La + a];
+                const float sg = d > 0.f ? ga : (d < 0.f ? -ga : 0.f);
+                v = sg * hamming_periodic(k, nfft) / env;
+            }
+            df[k] = v;
+        }
+        __syncthreads();
+    }
+    const long P = (long)T * F;
+    const float invn = 1.0f / (float)((double)B * (double)P);
+    const float p = 1.0f / 0.3f;
+    for (int f = threadIdx.x; f < F; f += 256) {
+        const long i = (long)b * P + (long)t * F + f;
+        const float er = est_real[i], ei = est_imag[i];
+        const float cr = clean_spec[(2L * b) * P + (long)t * F + f], ci = clean_spec[(2L * b + 1) * P + (long)t * F + f];
+        const float me = sqrtf(er * er + ei * ei), mc = sqrtf(cr * cr + ci * ci);
+        float gr = 2.f * w_ri * invn * (er - cr), gi = 2.f * w_ri * invn * (ei - ci);
+        if (me > 0.f) {
+            const float q = 2.f * w_mag * invn * (me - mc) / me;
+            gr = fmaf(q, er, gr); gi = fmaf(q, ei, gi);
+        }
+        if (has_time) {
+            float sr = 0.f, si = 0.f;
+            int j = 0;                                          // (f k) mod nfft, advanced incrementally
+            for (int k = 0; k < nfft; ++k) {
+                sr = fmaf(df[k], tc[j], sr);
+                si = fmaf(df[k], ts[j], si);
+                j += f; if (j >= nfft) j -= nfft;
+            }
+            const float cf = (f == 0 || 2 * f == nfft) ? 1.f : 2.f;
+            const float gur = cf * sr / (float)nfft, gui = (f == 0 || 2 * f == nfft) ? 0.f : -cf * si / (float)nfft;
+            const float s = powf(me, p - 1.f), s3 = (p - 1.f) * powf(me, p - 3.f), dot = er * gur + ei * gui;
+            gr += s * gur + s3 * er * dot;
+            gi += s * gui + s3 * ei * dot;
+        }
+        d_real[i] = gr; d_imag[i] = gi;
+    }
+}
+void launch_loss_backward(LaunchCtx ctx, const float* est_real, const float* est_imag, const float* clean_spec,
+                          const float* est_audio, const float* clean_audio, int B, int T, int F, int nfft, int hop, float w_ri,
+                          float w_mag, float w_time, float* d_real, float* d_imag) {
+    LAUNCH(ctx, "loss_backward", (loss_bwd_kernel<<<B * T, 256, 3 * nfft * sizeof(float), ctx.stream>>>(
+                                     est_real, est_imag, clean_spec, est_audio, clean_audio, B, T, F, nfft, hop, w_ri, w_mag, w_time,
+                                     d_real, d_imag)));
+}

@@ -66,17 +66,22 @@ class FlatBucket:
     """Named tensors as views of ONE flat fp32 buffer - the shape the reference's DDP gives its gradient buckets
     (7.3 MB generator + 0.7 MB discriminator, src/train.py:68-69) and the shape that suits a fully connected xGMI
     mesh: a single all-reduce over the whole bucket instead of one per tensor (latency-bound at this size), and a
-    single optimiser launch over the same memory (cmgan_adamw_step).  Works on CPU tensors too (gloo tests)."""
+    single optimiser launch over the same memory (cmgan_adamw_step).  Works on CPU tensors too (gloo tests).
+    Every tensor starts on a 64-byte boundary (the kernels read parameters with 16-byte vector loads); the padding
+    floats are zero in the parameter, gradient and moment buckets alike and stay zero under all-reduce and AdamW."""
+
+    ALIGN = 16                              # floats
 
     def __init__(self, shapes: dict, device="cpu"):
         self.shapes = {k: tuple(v) for k, v in shapes.items()}
-        self.numel = sum(int(torch.Size(s).numel()) for s in self.shapes.values())
+        pad = lambda n: (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        sizes = {k: int(torch.Size(s).numel()) for k, s in self.shapes.items()}
+        self.numel = sum(pad(n) for n in sizes.values())
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.views, off = {}, 0
         for k, shp in self.shapes.items():
-            n = int(torch.Size(shp).numel())
-            self.views[k] = self.flat[off:off + n].view(shp)
-            off += n
+            self.views[k] = self.flat[off:off + sizes[k]].view(shp)
+            off += pad(sizes[k])
 
     def load(self, tensors: dict):
         for k, v in self.views.items():

@@ -153,3 +153,28 @@ def state_dict_shapes(num_features: int = 201) -> dict:
     if num_features not in _SHAPES:
         _SHAPES[num_features] = {k: tuple(v.shape) for k, v in make_state_dict(0, num_features).items()}
     return _SHAPES[num_features]
+
+
+def synthetic_dropout_masks(seed: int, B: int, T: int, Fe: int, p: float = 0.2, blocks: int = 4) -> list:
+    """Deterministic keep-masks (numpy float32, entries 0 or 1/(1-p)) for every Dropout of `blocks` two-stage conformer
+    blocks on a [B, T, Fe] grid: [(time, freq)] * blocks, each a dict ff1_1 / ff1_2 / attn / ff2_1 / ff2_2 of
+    [N, L, C] arrays (time: N = B Fe, L = T; freq: N = B T, L = Fe).  numpy's legacy RandomState stream is frozen,
+    so the fixture generator and the tests draw the same masks without storing them."""
+    rs = np.random.RandomState(seed)
+    out = []
+    for _ in range(blocks):
+        pair = []
+        for n, l in ((B * Fe, T), (B * T, Fe)):
+            d = {}
+            for name, c in (("ff1_1", 256), ("ff1_2", 64), ("attn", 64), ("ff2_1", 256), ("ff2_2", 64)):
+                d[name] = ((rs.random_sample((n, l, c)) >= p).astype(np.float32) / np.float32(1.0 - p)).astype(np.float32)
+            pair.append(d)
+        out.append(tuple(pair))
+    return out
+
+
+def sample_indices(numel: int, k: int = 256, seed: int = 1234) -> np.ndarray:
+    """k fixed flat indices into a tensor of `numel` elements (all of them when numel <= k)."""
+    if numel <= k:
+        return np.arange(numel)
+    return np.sort(np.random.RandomState(seed + numel % 9973).choice(numel, k, replace=False))

@@ -28,9 +28,19 @@
                              (conformer.py:54-72, 136-148, 211-212) in TRAIN mode: forward with the two Dropout layers
                              as explicit keep-masks, and the full backward (dL/dx and all six parameter gradients).
 
+* `DenseEncoderTrain`,
+  `DecoderTrain`           - DenseEncoder (generator.py:50-69), MaskDecoder / ComplexDecoder (generator.py:121-156) in
+                             train mode: strided / sub-pixel row convs on the fp32 MFMA chain, the (1,2) tail convs,
+                             InstanceNorm2d + PReLU heads, forward + full backward.
+* `GeneratorTrain`         - the WHOLE TSCNet (generator.py:159-201) in train mode from the pieces above: forward,
+                             backward, every learnable parameter and its gradient a view of ONE flat bucket.
+* `generator_train_step`   - one optimisation step of the generator on the non-adversarial loss (train.py:72-151,
+                             185-193 without the metric-discriminator term): STFT, forward, ISTFT, loss, loss gradient
+                             (incl. the ISTFT adjoint), backward, ONE gradient all-reduce, ONE AdamW launch.
+
 Everything numerical runs in libcmgan_hip (csrc/train.hip); this module only owns parameter tensors, draws the
-dropout masks with torch's generator (plumbing) and passes pointers.  The remaining backward kernels (attention,
-conv module, dense convs, InstanceNorm, STFT), the metric discriminator and the optimiser are not built.
+dropout masks with torch's generator (plumbing) and passes pointers.  The metric discriminator (and with it the
+adversarial loss term and the discriminator step) is not built.
 """
 from __future__ import annotations
 
@@ -39,11 +49,11 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from ._lib import AttnParams, ConvModParams, DenseParams, FfnParams, check
+from ._lib import AttnParams, ConvModParams, DecoderParams, DenseParams, EncoderParams, FfnParams, check
 from .dist import FlatBucket, allreduce_mean
 from .engine import Engine
 
-__all__ = ["DenseBlockTrain", "TSCBTrain", "ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
+__all__ = ["GeneratorTrain", "generator_train_step", "DenseEncoderTrain", "DecoderTrain", "DenseBlockTrain", "TSCBTrain", "ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
            "validation_step"]
 
 _KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.net.0.weight", "fn.fn.net.0.bias",
@@ -83,6 +93,14 @@ def _buckets(shapes: Dict[str, tuple], state, views, device):
     pb = FlatBucket(shapes, device).load({k: state[k].detach().to(device, torch.float32) for k in shapes})
     gb = FlatBucket(shapes, device)
     return pb, gb, pb.views, gb.views
+
+
+def _subviews(views, prefix: str):
+    """The (params, grads) view dictionaries of the sub-module `prefix`, keys relative to it."""
+    n = len(prefix) + 1
+    params, grads = views
+    return ({k[n:]: v for k, v in params.items() if k.startswith(prefix + ".")},
+            {k[n:]: v for k, v in grads.items() if k.startswith(prefix + ".")})
 
 
 class FeedForwardTrain:
@@ -249,6 +267,7 @@ class ConvModuleTrain:
         self.param_bucket, self.grad_bucket, self.params, self.grads = _buckets(self.SHAPES, state, views, dev)
         self.running_mean = state["net.5.running_mean"].detach().to(dev, torch.float32).clone()
         self.running_var = state["net.5.running_var"].detach().to(dev, torch.float32).clone()
+        self.num_batches_tracked = int(state.get("net.5.num_batches_tracked", 0))
         self._ws: Optional[torch.Tensor] = None
         self._shape = None
 
@@ -280,6 +299,8 @@ class ConvModuleTrain:
             check(eng._h, eng.lib.cmgan_convmod_train_forward(eng._h, x.data_ptr(), N, L, ctypes.byref(p), rm, rv,
                                                               y.data_ptr(), ws.data_ptr(), ws.numel(), eng._stream()))
         self._shape = (N, L)
+        if update_running_stats:
+            self.num_batches_tracked += 1
         return y
 
     def backward(self, x: torch.Tensor, dy: torch.Tensor) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
@@ -389,24 +410,12 @@ class ConformerBlockTrain:
     collective, `AdamW(block.engine, block.param_bucket, block.grad_bucket)` one optimiser launch."""
 
     def __init__(self, state: Dict[str, torch.Tensor], attn_dropout: float = 0.2, ff_dropout: float = 0.2,
-                 engine: Optional[Engine] = None, device=None):
+                 engine: Optional[Engine] = None, device=None, views=None):
         self.engine = eng = engine if engine is not None else Engine(device=device)
-        dev = eng.device
-        sub = {"ff1": FeedForwardTrain.SHAPES, "attn": AttentionTrain.shapes(eng.cfg.max_pos_emb),
-               "conv": ConvModuleTrain.SHAPES, "ff2": FeedForwardTrain.SHAPES,
-               "post_norm": {"weight": (64,), "bias": (64,)}}
-        shapes = {f"{p}.{k}": shp for p, d in sub.items() for k, shp in d.items()}
-        for k, shp in shapes.items():
-            if tuple(state[k].shape) != tuple(shp):
-                raise ValueError(f"{k}: shape {tuple(state[k].shape)}, expected {tuple(shp)}")
-        self.param_bucket = FlatBucket(shapes, dev).load({k: state[k].detach().to(dev, torch.float32) for k in shapes})
-        self.grad_bucket = FlatBucket(shapes, dev)
-        self.params, self.grads = self.param_bucket.views, self.grad_bucket.views
+        self.param_bucket, self.grad_bucket, self.params, self.grads = _buckets(
+            self.shapes(eng.cfg.max_pos_emb), state, views, eng.device)
 
-        def views(prefix):
-            n = len(prefix) + 1
-            return ({k[n:]: v for k, v in self.params.items() if k.startswith(prefix + ".")},
-                    {k[n:]: v for k, v in self.grads.items() if k.startswith(prefix + ".")})
+        views = lambda prefix: _subviews((self.params, self.grads), prefix)
         self.ff1 = FeedForwardTrain(dropout=ff_dropout, engine=eng, views=views("ff1"))
         self.attn = AttentionTrain(dropout=attn_dropout, engine=eng, views=views("attn"))
         self.conv = ConvModuleTrain({k[5:]: v for k, v in state.items() if k.startswith("conv.")}, engine=eng,
@@ -414,6 +423,13 @@ class ConformerBlockTrain:
         self.ff2 = FeedForwardTrain(dropout=ff_dropout, engine=eng, views=views("ff2"))
         self._saved = None
         self._lnws: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def shapes(max_pos_emb: int = 512) -> Dict[str, tuple]:
+        sub = {"ff1": FeedForwardTrain.SHAPES, "attn": AttentionTrain.shapes(max_pos_emb),
+               "conv": ConvModuleTrain.SHAPES, "ff2": FeedForwardTrain.SHAPES,
+               "post_norm": {"weight": (64,), "bias": (64,)}}
+        return {f"{p}.{k}": shp for p, d in sub.items() for k, shp in d.items()}
 
     def masks(self, N: int, L: int, generator: Optional[torch.Generator] = None) -> Dict[str, Optional[torch.Tensor]]:
         a1, a2 = self.ff1.masks(N * L, generator)
@@ -468,6 +484,8 @@ class ConformerBlockTrain:
         return d0, self.grads
 
     def allreduce_gradients(self) -> torch.Tensor:
+        if self.grad_bucket is None:
+            raise RuntimeError("this module's gradients are views of its parent's bucket: all-reduce the parent")
         return allreduce_mean(self.grad_bucket.flat)
 
 
@@ -477,12 +495,18 @@ class TSCBTrain:
     `x.permute(0, 2, 3, 1)`.  `state` = the block's slice of the generator state_dict (`time_conformer.*`,
     `freq_conformer.*`)."""
 
-    def __init__(self, state: Dict[str, torch.Tensor], engine: Optional[Engine] = None, device=None):
+    def __init__(self, state: Dict[str, torch.Tensor], engine: Optional[Engine] = None, device=None, views=None):
         self.engine = eng = engine if engine is not None else Engine(device=device)
         sub = lambda p: {k[len(p) + 1:]: v for k, v in state.items() if k.startswith(p + ".")}
-        self.time = ConformerBlockTrain(sub("time_conformer"), engine=eng)
-        self.freq = ConformerBlockTrain(sub("freq_conformer"), engine=eng)
+        vw = lambda p: None if views is None else _subviews(views, p)
+        self.time = ConformerBlockTrain(sub("time_conformer"), engine=eng, views=vw("time_conformer"))
+        self.freq = ConformerBlockTrain(sub("freq_conformer"), engine=eng, views=vw("freq_conformer"))
         self._shape = None
+
+    @staticmethod
+    def shapes(max_pos_emb: int = 512) -> Dict[str, tuple]:
+        blk = ConformerBlockTrain.shapes(max_pos_emb)
+        return {f"{p}.{k}": shp for p in ("time_conformer", "freq_conformer") for k, shp in blk.items()}
 
     def masks(self, B: int, T: int, F2: int, generator: Optional[torch.Generator] = None):
         return self.time.masks(B * F2, T, generator), self.freq.masks(B * T, F2, generator)
@@ -589,3 +613,302 @@ class DenseBlockTrain:
         if self.grad_bucket is None:
             raise RuntimeError("this module's gradients are views of its parent's bucket: all-reduce the parent")
         return allreduce_mean(self.grad_bucket.flat)
+
+
+def _dense_struct(tensors, prefix: str) -> DenseParams:
+    s = DenseParams()
+    for i in range(4):
+        s.conv_weight[i] = tensors[f"{prefix}conv{i + 1}.weight"].data_ptr()
+        s.conv_bias[i] = tensors[f"{prefix}conv{i + 1}.bias"].data_ptr()
+        s.norm_weight[i] = tensors[f"{prefix}norm{i + 1}.weight"].data_ptr()
+        s.norm_bias[i] = tensors[f"{prefix}norm{i + 1}.bias"].data_ptr()
+        s.prelu_weight[i] = tensors[f"{prefix}prelu{i + 1}.weight"].data_ptr()
+    return s
+
+
+class _WsModule:
+    """Common plumbing of the encoder / decoder wrappers: buckets (own or views) and a grow-only workspace."""
+
+    def __init__(self, shapes, state, engine, device, views):
+        self.engine = engine if engine is not None else Engine(device=device)
+        self.param_bucket, self.grad_bucket, self.params, self.grads = _buckets(shapes, state, views, self.engine.device)
+        self._ws: Optional[torch.Tensor] = None
+        self._shape = None
+
+    def _grow(self, need: int) -> torch.Tensor:
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.engine.device)
+        return self._ws
+
+    def allreduce_gradients(self) -> torch.Tensor:
+        if self.grad_bucket is None:
+            raise RuntimeError("this module's gradients are views of its parent's bucket: all-reduce the parent")
+        return allreduce_mean(self.grad_bucket.flat)
+
+
+class DenseEncoderTrain(_WsModule):
+    """`models.generator.DenseEncoder(in_channel=3, channels=64)` (generator.py:50-69) in train mode on the HIP
+    kernels.  Input `[B, T, F, 3]` channels-last (|spec|, re, im), output `[B, T, F', 64]`, F' = (F - 1) // 2 + 1.
+    `state`: the `dense_encoder.` slice of the generator state_dict.  The input carries no gradient."""
+
+    SHAPES = {"conv_1.0.weight": (64, 3, 1, 1), "conv_1.0.bias": (64,), "conv_1.1.weight": (64,), "conv_1.1.bias": (64,),
+              "conv_1.2.weight": (64,),
+              **{f"dilated_dense.{k}": v for k, v in DenseBlockTrain.SHAPES.items()},
+              "conv_2.0.weight": (64, 64, 1, 3), "conv_2.0.bias": (64,), "conv_2.1.weight": (64,), "conv_2.1.bias": (64,),
+              "conv_2.2.weight": (64,)}
+
+    def __init__(self, state=None, engine: Optional[Engine] = None, device=None, views=None):
+        super().__init__(self.SHAPES, state, engine, device, views)
+
+    def _struct(self, t) -> EncoderParams:
+        s = EncoderParams()
+        for i, pre in ((1, "conv_1"), (2, "conv_2")):
+            setattr(s, f"conv{i}_weight", t[pre + ".0.weight"].data_ptr())
+            setattr(s, f"conv{i}_bias", t[pre + ".0.bias"].data_ptr())
+            setattr(s, f"norm{i}_weight", t[pre + ".1.weight"].data_ptr())
+            setattr(s, f"norm{i}_bias", t[pre + ".1.bias"].data_ptr())
+            setattr(s, f"prelu{i}_weight", t[pre + ".2.weight"].data_ptr())
+        s.dense = _dense_struct(t, "dilated_dense.")
+        return s
+
+    def forward(self, xin: torch.Tensor) -> torch.Tensor:
+        eng = self.engine
+        xin = eng._in(xin, "xin")
+        B, T, F, C = xin.shape
+        if C != 3:
+            raise ValueError("expected channels-last [B, T, F, 3]")
+        ws = self._grow(eng.lib.cmgan_encoder_train_workspace_bytes(eng._h, B, T, F))
+        y = torch.empty(B, T, (F - 1) // 2 + 1, 64, dtype=torch.float32, device=eng.device)
+        p = self._struct(self.params)
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_encoder_train_forward(eng._h, xin.data_ptr(), B, T, F, ctypes.byref(p), y.data_ptr(),
+                                                              ws.data_ptr(), ws.numel(), eng._stream()))
+        self._shape = (B, T, F)
+        self._xin = xin
+        return y
+
+    def backward(self, dy: torch.Tensor) -> Dict[str, torch.Tensor]:
+        if self._shape is None:
+            raise RuntimeError("backward() needs a forward() first")
+        eng = self.engine
+        B, T, F = self._shape
+        dy = eng._in(dy, "dy")
+        if tuple(dy.shape) != (B, T, (F - 1) // 2 + 1, 64):
+            raise ValueError("dy does not match the forward() output")
+        p, g = self._struct(self.params), self._struct(self.grads)
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_encoder_train_backward(eng._h, self._xin.data_ptr(), dy.data_ptr(), B, T, F,
+                                                               ctypes.byref(p), ctypes.byref(g), self._ws.data_ptr(),
+                                                               self._ws.numel(), eng._stream()))
+        return self.grads
+
+
+class DecoderTrain(_WsModule):
+    """`MaskDecoder(num_features)` (kind "mask", generator.py:121-138) or `ComplexDecoder()` (kind "complex",
+    generator.py:141-156) in train mode on the HIP kernels.  Input `[B, T, F', 64]` channels-last; output `[B, T, F]`
+    (mask) or `[B, T, F, 2]` (complex), F = 2 F' - 1.  `state`: the `mask_decoder.` / `complex_decoder.` slice."""
+
+    KINDS = {"mask": 0, "complex": 1}
+
+    @staticmethod
+    def shapes(kind: str, num_features: int = 201) -> Dict[str, tuple]:
+        d = {f"dense_block.{k}": v for k, v in DenseBlockTrain.SHAPES.items()}
+        d.update({"sub_pixel.conv.weight": (128, 64, 1, 3), "sub_pixel.conv.bias": (128,)})
+        if kind == "mask":
+            d.update({"conv_1.weight": (1, 64, 1, 2), "conv_1.bias": (1,), "norm.weight": (1,), "norm.bias": (1,),
+                      "prelu.weight": (1,), "final_conv.weight": (1, 1, 1, 1), "final_conv.bias": (1,),
+                      "prelu_out.weight": (num_features,)})
+        else:
+            d.update({"prelu.weight": (64,), "norm.weight": (64,), "norm.bias": (64,), "conv.weight": (2, 64, 1, 2),
+                      "conv.bias": (2,)})
+        return d
+
+    def __init__(self, kind: str, state=None, num_features: Optional[int] = None, engine: Optional[Engine] = None,
+                 device=None, views=None):
+        if kind not in self.KINDS:
+            raise ValueError("kind must be 'mask' or 'complex'")
+        eng = engine if engine is not None else Engine(device=device)
+        self.kind = kind
+        self.num_features = int(num_features if num_features is not None else eng.cfg.num_features)
+        super().__init__(self.shapes(kind, self.num_features), state, eng, device, views)
+
+    def _struct(self, t) -> DecoderParams:
+        s = DecoderParams()
+        s.dense = _dense_struct(t, "dense_block.")
+        s.sub_pixel_weight = t["sub_pixel.conv.weight"].data_ptr()
+        s.sub_pixel_bias = t["sub_pixel.conv.bias"].data_ptr()
+        conv = "conv_1" if self.kind == "mask" else "conv"
+        s.conv_weight, s.conv_bias = t[conv + ".weight"].data_ptr(), t[conv + ".bias"].data_ptr()
+        s.norm_weight, s.norm_bias = t["norm.weight"].data_ptr(), t["norm.bias"].data_ptr()
+        s.prelu_weight = t["prelu.weight"].data_ptr()
+        if self.kind == "mask":
+            s.final_weight, s.final_bias = t["final_conv.weight"].data_ptr(), t["final_conv.bias"].data_ptr()
+            s.prelu_out_weight = t["prelu_out.weight"].data_ptr()
+        return s
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        eng = self.engine
+        x = eng._in(x, "x")
+        B, T, Fe, C = x.shape
+        if C != 64:
+            raise ValueError("expected channels-last [B, T, F', 64]")
+        F = 2 * Fe - 1
+        if self.kind == "mask" and F != self.num_features:
+            raise ValueError(f"2 F' - 1 = {F} does not match num_features = {self.num_features} (prelu_out)")
+        ws = self._grow(eng.lib.cmgan_decoder_train_workspace_bytes(eng._h, B, T, Fe))
+        out = torch.empty((B, T, F) if self.kind == "mask" else (B, T, F, 2), dtype=torch.float32, device=eng.device)
+        p = self._struct(self.params)
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_decoder_train_forward(eng._h, self.KINDS[self.kind], x.data_ptr(), B, T, Fe,
+                                                              ctypes.byref(p), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                              eng._stream()))
+        self._shape = (B, T, Fe)
+        self._x = x
+        return out
+
+    def backward(self, dout: torch.Tensor) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        if self._shape is None:
+            raise RuntimeError("backward() needs a forward() first")
+        eng = self.engine
+        B, T, Fe = self._shape
+        F = 2 * Fe - 1
+        dout = eng._in(dout, "dout")
+        if tuple(dout.shape) != ((B, T, F) if self.kind == "mask" else (B, T, F, 2)):
+            raise ValueError("dout does not match the forward() output")
+        dx = torch.empty_like(self._x)
+        p, g = self._struct(self.params), self._struct(self.grads)
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_decoder_train_backward(eng._h, self.KINDS[self.kind], self._x.data_ptr(),
+                                                               dout.data_ptr(), B, T, Fe, ctypes.byref(p), dx.data_ptr(),
+                                                               ctypes.byref(g), self._ws.data_ptr(), self._ws.numel(),
+                                                               eng._stream()))
+        return dx, self.grads
+
+
+class GeneratorTrain:
+    """`models.generator.TSCNet(num_channel=64, num_features)` (generator.py:159-201) in TRAIN mode on the HIP kernels.
+
+    `state` is the reference generator state_dict.  Every learnable tensor (`named_parameters()` of the reference
+    module) and its gradient is a view of ONE flat fp32 bucket (`param_bucket` / `grad_bucket`): the data-parallel
+    gradient mean is one all-reduce, the optimiser one launch.  BatchNorm running statistics are buffers of the conv
+    modules and are exported by `state_dict()`.  `forward` takes the compressed noisy spectrogram `[B, 2, T, F]`
+    (`Engine.stft_compress`) and returns `est_real, est_imag [B, 1, T, F]` like the reference module."""
+
+    BLOCKS = ("TSCB_1", "TSCB_2", "TSCB_3", "TSCB_4")
+
+    def __init__(self, state: Dict[str, torch.Tensor], engine: Optional[Engine] = None, device=None):
+        self.engine = eng = engine if engine is not None else Engine(device=device)
+        F = eng.cfg.num_features
+        shapes: Dict[str, tuple] = {}
+        shapes.update({f"dense_encoder.{k}": v for k, v in DenseEncoderTrain.SHAPES.items()})
+        for b in self.BLOCKS:
+            shapes.update({f"{b}.{k}": v for k, v in TSCBTrain.shapes(eng.cfg.max_pos_emb).items()})
+        shapes.update({f"mask_decoder.{k}": v for k, v in DecoderTrain.shapes("mask", F).items()})
+        shapes.update({f"complex_decoder.{k}": v for k, v in DecoderTrain.shapes("complex", F).items()})
+        self.param_bucket, self.grad_bucket, self.params, self.grads = _buckets(shapes, state, None, eng.device)
+        views = (self.params, self.grads)
+        sub = lambda p: {k[len(p) + 1:]: v for k, v in state.items() if k.startswith(p + ".")}
+        self.dense_encoder = DenseEncoderTrain(engine=eng, views=_subviews(views, "dense_encoder"))
+        self.blocks = [TSCBTrain(sub(b), engine=eng, views=_subviews(views, b)) for b in self.BLOCKS]
+        self.mask_decoder = DecoderTrain("mask", engine=eng, views=_subviews(views, "mask_decoder"))
+        self.complex_decoder = DecoderTrain("complex", engine=eng, views=_subviews(views, "complex_decoder"))
+        self._saved = None
+
+    def masks(self, B: int, T: int, generator: Optional[torch.Generator] = None):
+        """Keep-masks of every Dropout of the four TSCBs for a [B, 2, T, F] input: [(time, freq)] * 4."""
+        Fe = (self.engine.cfg.num_features - 1) // 2 + 1
+        return [blk.masks(B, T, Fe, generator) for blk in self.blocks]
+
+    def forward(self, spec: torch.Tensor, masks=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        eng = self.engine
+        spec = eng._in(spec, "spec")
+        B, two, T, F = spec.shape
+        if two != 2 or F != eng.cfg.num_features:
+            raise ValueError(f"expected [B, 2, T, {eng.cfg.num_features}]")
+        with torch.cuda.device(eng.device):
+            xin = torch.empty(B, T, F, 3, dtype=torch.float32, device=eng.device)
+            check(eng._h, eng.lib.cmgan_tscnet_prologue(eng._h, spec.data_ptr(), B, T, xin.data_ptr(), eng._stream()))
+            x = self.dense_encoder.forward(xin)                                     # generator.py:181
+            for i, blk in enumerate(self.blocks):                                   # :182-185
+                mt, mf = masks[i] if masks is not None else (None, None)
+                x = blk.forward(x, mt, mf)
+            mask = self.mask_decoder.forward(x)                                     # :187
+            cplx = self.complex_decoder.forward(x)                                  # :190
+            est_real = torch.empty(B, 1, T, F, dtype=torch.float32, device=eng.device)
+            est_imag = torch.empty_like(est_real)
+            check(eng._h, eng.lib.cmgan_tscnet_epilogue_forward(eng._h, spec.data_ptr(), mask.data_ptr(), cplx.data_ptr(),
+                                                                B, T, est_real.data_ptr(), est_imag.data_ptr(),
+                                                                eng._stream()))    # :188-199
+        self._saved = (spec, B, T, F)
+        return est_real, est_imag
+
+    def backward(self, d_real: torch.Tensor, d_imag: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """All parameter gradients (views of `grad_bucket`) for the last forward()."""
+        if self._saved is None:
+            raise RuntimeError("backward() needs a forward() first")
+        eng = self.engine
+        spec, B, T, F = self._saved
+        d_real, d_imag = eng._in(d_real, "d_real"), eng._in(d_imag, "d_imag")
+        if d_real.numel() != B * T * F or d_imag.numel() != B * T * F:
+            raise ValueError("gradients do not match the forward() outputs")
+        with torch.cuda.device(eng.device):
+            dmask = torch.empty(B, T, F, dtype=torch.float32, device=eng.device)
+            dcplx = torch.empty(B, T, F, 2, dtype=torch.float32, device=eng.device)
+            check(eng._h, eng.lib.cmgan_tscnet_epilogue_backward(eng._h, spec.data_ptr(), d_real.data_ptr(),
+                                                                 d_imag.data_ptr(), B, T, dmask.data_ptr(),
+                                                                 dcplx.data_ptr(), eng._stream()))
+            dx_m, _ = self.mask_decoder.backward(dmask)
+            dx_c, _ = self.complex_decoder.backward(dcplx)
+            dx = self.blocks[0].time._add(dx_m, dx_c)
+            for blk in reversed(self.blocks):
+                dx = blk.backward(dx)
+            self.dense_encoder.backward(dx)
+        return self.grads
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """The reference generator state_dict (copies): parameters + the BatchNorm buffers of the eight conv modules."""
+        out = {k: v.detach().clone() for k, v in self.params.items()}
+        for name, blk in zip(self.BLOCKS, self.blocks):
+            for ax, conf in (("time_conformer", blk.time), ("freq_conformer", blk.freq)):
+                out[f"{name}.{ax}.conv.net.5.running_mean"] = conf.conv.running_mean.clone()
+                out[f"{name}.{ax}.conv.net.5.running_var"] = conf.conv.running_var.clone()
+                out[f"{name}.{ax}.conv.net.5.num_batches_tracked"] = torch.tensor(
+                    conf.conv.num_batches_tracked, dtype=torch.int64)
+        return out
+
+    def allreduce_gradients(self) -> torch.Tensor:
+        return allreduce_mean(self.grad_bucket.flat)
+
+
+def generator_train_step(gen: GeneratorTrain, optimizer: "AdamW", clean: torch.Tensor, noisy: torch.Tensor,
+                         loss_weights=(0.1, 0.9, 0.2), generator: Optional[torch.Generator] = None, masks="draw",
+                         lr: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One optimisation step of the generator on the non-adversarial loss - Trainer.train_step's generator half
+    (train.py:153-193) with forward_generator_step (train.py:72-122) and calculate_generator_loss (train.py:124-151)
+    minus the metric-discriminator term: returns (loss, float32[4] terms) of THIS rank before the update.
+    clean, noisy: float32 [B, L] on the GPU, L a multiple of hop.  `masks="draw"` draws fresh dropout masks from
+    `generator`; pass `gen.masks(...)`-shaped masks to fix them, or None to disable dropout."""
+    eng = gen.engine
+    clean, noisy = eng._in(clean, "clean"), eng._in(noisy, "noisy")
+    B = noisy.shape[0]
+    c = eng.rms_scale(noisy)                                    # train.py:75
+    noisy_spec = eng.stft_compress(noisy, c)                    # train.py:76-95
+    clean_spec = eng.stft_compress(clean, c)                    # train.py:88-98
+    T = noisy_spec.shape[2]
+    if isinstance(masks, str):
+        masks = gen.masks(B, T, generator)
+    est_real, est_imag = gen.forward(noisy_spec, masks)         # train.py:100
+    est_audio = eng.uncompress_istft(est_real, est_imag)        # train.py:105-112
+    La = est_audio.shape[-1]
+    clean_cut = clean[:, :La].contiguous()                      # train.py:187: the time term sees the RAW clean batch
+    loss, terms = generator_loss_terms(eng, est_real, est_imag, clean_spec, est_audio, clean_cut, loss_weights)
+    d_real, d_imag = torch.empty_like(est_real), torch.empty_like(est_imag)
+    with torch.cuda.device(eng.device):
+        check(eng._h, eng.lib.cmgan_loss_backward(eng._h, est_real.data_ptr(), est_imag.data_ptr(), clean_spec.data_ptr(),
+                                                  B, T, est_audio.data_ptr(), clean_cut.data_ptr(),
+                                                  float(loss_weights[0]), float(loss_weights[1]), float(loss_weights[2]),
+                                                  d_real.data_ptr(), d_imag.data_ptr(), eng._stream()))
+    gen.backward(d_real, d_imag)                                # train.py:190 (loss.backward())
+    gen.allreduce_gradients()                                   # DDP's gradient mean, one collective
+    optimizer.step(lr)                                          # train.py:191
+    return loss, terms

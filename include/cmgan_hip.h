@@ -251,6 +251,72 @@ int cmgan_dense_train_backward(cmgan_handle* h, const float* x_dev, const float*
                                const cmgan_dense_params* params, float* dx_dev, const cmgan_dense_params* grads,
                                void* workspace_dev, size_t workspace_bytes, void* stream);
 
+/* Training-mode DenseEncoder with its backward (src/models/generator.py:50-69): conv_1 (1x1, 3 -> 64) +
+ * InstanceNorm2d(affine) + PReLU(64), the DilatedDenseNet above, conv_2 ((1,3), stride (1,2), padding (0,1)) +
+ * InstanceNorm2d(affine) + PReLU(64).  xin [B,T,F,3] is the channels-last x_in of TSCNet.forward
+ * (cmgan_tscnet_prologue); y [B,T,F',64] with F' = (F - 1) / 2 + 1.  x_in carries no gradient, so the backward only
+ * writes the thirty parameter gradients.  Same workspace contract as the dense block.                            */
+typedef struct cmgan_encoder_params {
+    float *conv1_weight, *conv1_bias, *norm1_weight, *norm1_bias, *prelu1_weight;   /* conv_1.{0.weight [64,3,1,1], 0.bias, 1.weight, 1.bias, 2.weight} */
+    cmgan_dense_params dense;                                                       /* dilated_dense.* */
+    float *conv2_weight, *conv2_bias, *norm2_weight, *norm2_bias, *prelu2_weight;   /* conv_2.{0.weight [64,64,1,3], ...} */
+} cmgan_encoder_params;
+size_t cmgan_encoder_train_workspace_bytes(const cmgan_handle* h, int B, int T, int F);
+int cmgan_encoder_train_forward(cmgan_handle* h, const float* xin_dev, int B, int T, int F,
+                                const cmgan_encoder_params* params, float* y_dev,
+                                void* workspace_dev, size_t workspace_bytes, void* stream);
+int cmgan_encoder_train_backward(cmgan_handle* h, const float* xin_dev, const float* dy_dev, int B, int T, int F,
+                                 const cmgan_encoder_params* params, const cmgan_encoder_params* grads,
+                                 void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* Training-mode MaskDecoder (kind CMGAN_DECODER_MASK, generator.py:121-138) and ComplexDecoder (kind
+ * CMGAN_DECODER_COMPLEX, generator.py:141-156) with their backward.  Both: DilatedDenseNet -> SPConvTranspose2d
+ * (pad 1/1, Conv2d(64 -> 128, (1,3)), pixel shuffle x2 along frequency, generator.py:102-119) -> head.
+ *   mask head:    conv_1 (1,2) 64 -> 1, InstanceNorm2d(1, affine), PReLU(1), final_conv 1x1, PReLU(num_features);
+ *                 out [B,T,F] (= the reference's [B,1,T,F])
+ *   complex head: InstanceNorm2d(64, affine), PReLU(64), conv (1,2) 64 -> 2;  out [B,T,F,2] (reference: [B,2,T,F])
+ * x [B,T,Fe,64] channels-last, F = 2 Fe - 1.  final_* / prelu_out_weight are ignored for the complex head.        */
+enum { CMGAN_DECODER_MASK = 0, CMGAN_DECODER_COMPLEX = 1 };
+typedef struct cmgan_decoder_params {
+    cmgan_dense_params dense;                         /* dense_block.* */
+    float *sub_pixel_weight, *sub_pixel_bias;         /* sub_pixel.conv.{weight [128,64,1,3], bias [128]} */
+    float *conv_weight, *conv_bias;                   /* conv_1 (mask) / conv (complex): [NO,64,1,2], [NO] */
+    float *norm_weight, *norm_bias, *prelu_weight;    /* norm.{weight,bias}, prelu.weight: [1] (mask) or [64] */
+    float *final_weight, *final_bias;                 /* mask only: final_conv.{weight [1,1,1,1], bias [1]} */
+    float *prelu_out_weight;                          /* mask only: prelu_out.weight [num_features] */
+} cmgan_decoder_params;
+size_t cmgan_decoder_train_workspace_bytes(const cmgan_handle* h, int B, int T, int Fe);
+int cmgan_decoder_train_forward(cmgan_handle* h, int kind, const float* x_dev, int B, int T, int Fe,
+                                const cmgan_decoder_params* params, float* out_dev,
+                                void* workspace_dev, size_t workspace_bytes, void* stream);
+int cmgan_decoder_train_backward(cmgan_handle* h, int kind, const float* x_dev, const float* dout_dev, int B, int T,
+                                 int Fe, const cmgan_decoder_params* params, float* dx_dev,
+                                 const cmgan_decoder_params* grads,
+                                 void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* The glue of TSCNet.forward (generator.py:176-201) for the training step, F = num_features of the handle:
+ *   prologue:  spec [B,2,T,F] -> xin [B,T,F,3] = (|spec|, re, im)                       generator.py:177-181
+ *   epilogue:  est = mask * |spec| * (cos, sin)(angle spec) + complex_out = mask * spec + complex_out
+ *              (mask [B,T,F], complex_out [B,T,F,2] -> est_real, est_imag [B,T,F])      generator.py:188-199
+ *   backward:  dmask = d_real re + d_imag im,  dcomplex = (d_real, d_imag); the noisy spectrogram is data.       */
+int cmgan_tscnet_prologue(cmgan_handle* h, const float* spec_dev, int B, int T, float* xin_dev, void* stream);
+int cmgan_tscnet_epilogue_forward(cmgan_handle* h, const float* spec_dev, const float* mask_dev,
+                                  const float* complex_dev, int B, int T, float* est_real_dev, float* est_imag_dev,
+                                  void* stream);
+int cmgan_tscnet_epilogue_backward(cmgan_handle* h, const float* spec_dev, const float* d_real_dev,
+                                   const float* d_imag_dev, int B, int T, float* dmask_dev, float* dcomplex_dev,
+                                   void* stream);
+
+/* Gradient of  w_ri * loss_ri + w_mag * loss_mag + w_time * time_loss  (the non-adversarial part of
+ * Trainer.calculate_generator_loss, src/train.py:133-148; same arguments as cmgan_loss_terms) with respect to
+ * est_real / est_imag [B,T,F].  The time term runs the adjoint of torch.istft (window, overlap-add, envelope
+ * division, centre trim; train.py:106-112) and of utils.power_uncompress (utils.py:32-39) in one kernel; est_audio /
+ * clean_audio [B, hop (T-1)] may both be NULL when w_time = 0.  n_fft / hop / F are the handle's.                 */
+int cmgan_loss_backward(cmgan_handle* h, const float* est_real_dev, const float* est_imag_dev,
+                        const float* clean_spec_dev, int B, int T, const float* est_audio_dev,
+                        const float* clean_audio_dev, float w_ri, float w_mag, float w_time,
+                        float* d_real_dev, float* d_imag_dev, void* stream);
+
 /* One torch.optim.AdamW step (src/train.py:63-66, 192-193; defaults betas (0.9, 0.999), eps 1e-8, weight_decay
  * 0.01) over a FLAT fp32 bucket of n parameters: params, grads and the two moment buffers are parallel device
  * arrays (the bucket the gradient all-reduce runs over), `step` = 1, 2, ... is the update count for the bias

@@ -377,3 +377,44 @@ def generator_loss(out: dict, clean: torch.Tensor, loss_weights=(0.1, 0.9, 0.2))
     time_loss = torch.mean(torch.abs(out["est_audio"] - clean))
     loss = loss_weights[0] * loss_ri + loss_weights[1] * loss_mag + loss_weights[2] * time_loss
     return loss, loss_ri, loss_mag, time_loss
+
+
+def tscnet_forward_train(sd, x, masks=None):
+    """TSCNet.forward in TRAIN mode (generator.py:176-201): `masks` = [(time, freq)] * 4 keep-mask dictionaries of
+    the four TSCBs (None = no dropout).  Differentiable."""
+    re, im = x[:, 0:1], x[:, 1:2]
+    mag = torch.sqrt(re * re + im * im)
+    phase = torch.atan2(im, re)
+    h = dense_encoder(sd, torch.cat([mag, x], dim=1))
+    for b in range(1, 5):
+        mt, mf = masks[b - 1] if masks is not None else (None, None)
+        h = tscb_train(sd, f"TSCB_{b}", h, mt, mf)
+    mask = mask_decoder(sd, h)
+    cplx = complex_decoder(sd, h)
+    out_mag = mask * mag
+    return out_mag * torch.cos(phase) + cplx[:, 0:1], out_mag * torch.sin(phase) + cplx[:, 1:2]
+
+
+def generator_step_gradients(sd, clean, noisy, masks=None, loss_weights=(0.1, 0.9, 0.2), n_fft: int = 400,
+                             hop: int = 100):
+    """The generator half of Trainer.train_step without the metric discriminator (train.py:72-151, 185-190):
+    forward in train mode, the three non-adversarial loss terms, autograd.  Returns a dict with `loss`, `terms`
+    (loss_ri, loss_mag, time_loss), `est_real`, `est_imag`, their gradients `d_real`, `d_imag`, and `grads`
+    {key: dL/dparam} for every floating-point tensor of `sd` that the loss depends on."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()
+            if v.is_floating_point() and "running_" not in k}
+    sdx = dict(sd)
+    sdx.update(leaf)
+    with torch.enable_grad():
+        c = rms_scale(noisy)
+        noisy_spec = stft_compress(noisy * c[:, None], n_fft, hop)
+        clean_spec = stft_compress(clean * c[:, None], n_fft, hop)
+        er, ei = tscnet_forward_train(sdx, noisy_spec, masks)
+        er.retain_grad(); ei.retain_grad()
+        audio = uncompress_istft(er, ei, n_fft, hop)
+        out = {"est_real": er, "est_imag": ei, "clean_spec": clean_spec, "est_audio": audio}
+        loss, l_ri, l_mag, l_time = generator_loss(out, clean[:, :audio.shape[-1]], loss_weights)
+        loss.backward()
+    return {"loss": loss.detach(), "terms": torch.stack([l_ri, l_mag, l_time]).detach(), "est_real": er.detach(),
+            "est_imag": ei.detach(), "d_real": er.grad.detach(), "d_imag": ei.grad.detach(),
+            "grads": {k: v.grad for k, v in leaf.items()}}

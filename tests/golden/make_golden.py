@@ -334,6 +334,118 @@ def main():
         dgr = {"grad_" + k.replace(".", "_"): v.grad.detach() for k, v in ddn.named_parameters()}
     save("dense_train.npz", x=xd.detach(), dy=dyd, y=yd.detach(), dx=xd.grad.detach(), **dgr)
 
+    # -- 16. DenseEncoder (generator.py:50-69): conv_1 (1x1, 3 -> 64) + IN + PReLU, the dilated dense block, conv_2
+    #        ((1,3), stride (1,2), padding (0,1)) + IN + PReLU, with autograd gradients of all parameters
+    from models.generator import DenseEncoder
+    with torch.enable_grad():
+        enc = DenseEncoder(in_channel=3, channels=64)
+        esd = {k[len("dense_encoder."):]: v for k, v in sd.items() if k.startswith("dense_encoder.")}
+        enc.load_state_dict(esd, strict=True)
+        enc.train()
+        xe = rnd((2, 3, 13, 21), 81)                       # [mag, re, im] planes, F = 21 -> F' = 11
+        dye = rnd((2, 64, 13, 11), 82)
+        ye = enc(xe)
+        ye.backward(dye)
+        egr = {"grad_" + k.replace(".", "_"): v.grad.detach() for k, v in enc.named_parameters()}
+    save("encoder_train.npz", x=xe, dy=dye, y=ye.detach(), **egr)
+
+    # -- 17/18. MaskDecoder(num_features = 21) and ComplexDecoder (generator.py:121-156) with autograd gradients:
+    #        dilated dense block, sub-pixel conv (pad, (1,3) conv to 128 channels, pixel shuffle x2 along F), heads
+    from models.generator import ComplexDecoder, MaskDecoder
+    with torch.enable_grad():
+        mdec = MaskDecoder(num_features=21, num_channel=64, out_channel=1)
+        msd = {k[len("mask_decoder."):]: v for k, v in sd.items() if k.startswith("mask_decoder.")}
+        msd["prelu_out.weight"] = msd["prelu_out.weight"][:21].clone()
+        mdec.load_state_dict(msd, strict=True)
+        mdec.train()
+        xm = rnd((2, 64, 13, 11), 91).requires_grad_(True)
+        dym = rnd((2, 1, 13, 21), 92)
+        ym = mdec(xm)
+        ym.backward(dym)
+        mgr = {"grad_" + k.replace(".", "_"): v.grad.detach() for k, v in mdec.named_parameters()}
+    save("maskdec_train.npz", x=xm.detach(), dy=dym, y=ym.detach(), dx=xm.grad.detach(), **mgr)
+    with torch.enable_grad():
+        cdec = ComplexDecoder(num_channel=64)
+        cdec.load_state_dict({k[len("complex_decoder."):]: v for k, v in sd.items() if k.startswith("complex_decoder.")},
+                             strict=True)
+        cdec.train()
+        xc = rnd((2, 64, 13, 11), 93).requires_grad_(True)
+        dyc = rnd((2, 2, 13, 21), 94)
+        yc = cdec(xc)
+        yc.backward(dyc)
+        cgr = {"grad_" + k.replace(".", "_"): v.grad.detach() for k, v in cdec.named_parameters()}
+    save("complexdec_train.npz", x=xc.detach(), dy=dyc, y=yc.detach(), dx=xc.grad.detach(), **cgr)
+
+    # -- 19. one generator optimisation step of the reference trainer without the metric discriminator:
+    #        Trainer.forward_generator_step (train.py:72-122) on the reference TSCNet in TRAIN mode (all 40 Dropout
+    #        layers replaced by the deterministic keep-masks of cmgan_amd.synth.synthetic_dropout_masks),
+    #        loss = 0.1 loss_ri + 0.9 loss_mag + 0.2 time_loss (train.py:133-148, the RAW clean batch in the time
+    #        term as train.py:187 does), loss.backward(), AdamW(lr 5e-4).step(), and the loss of a second forward.
+    #        Stored: the losses, est_real / est_imag and their gradients, per-parameter gradient digests (sum, l2,
+    #        and up to 256 fixed samples - the full set is 1.8 M floats), the running statistics of one BatchNorm.
+    from cmgan_amd.synth import sample_indices, synthetic_dropout_masks
+    with torch.enable_grad():
+        gmodel = TSCNet(num_channel=64, num_features=201)
+        gmodel.load_state_dict(sd, strict=True)
+        gmodel.train()
+        Bg, Lg = 2, 800
+        Tg, Feg = Lg // 100 + 1, 101
+        gm = synthetic_dropout_masks(77, Bg, Tg, Feg)
+        for bi, name in enumerate(("TSCB_1", "TSCB_2", "TSCB_3", "TSCB_4")):
+            for ai, ax in enumerate(("time_conformer", "freq_conformer")):
+                conf = getattr(getattr(gmodel, name), ax)
+                mk = {k: torch.from_numpy(v) for k, v in gm[bi][ai].items()}
+                conf.ff1.fn.fn.net[2], conf.ff1.fn.fn.net[4] = _Mask(mk["ff1_1"]), _Mask(mk["ff1_2"])
+                conf.attn.fn.dropout = _Mask(mk["attn"])
+                conf.ff2.fn.fn.net[2], conf.ff2.fn.fn.net[4] = _Mask(mk["ff2_1"]), _Mask(mk["ff2_2"])
+        gclean = synthetic_clips(Bg, Lg, seed=31)
+        gnoisy = gclean + 0.3 * synthetic_clips(Bg, Lg, seed=32)
+        win = torch.hamming_window(400)
+
+        def gen_step():
+            c = torch.sqrt(gnoisy.size(-1) / torch.sum(gnoisy ** 2.0, dim=-1))
+            noisy_s, clean_s = gnoisy * c[:, None], gclean * c[:, None]
+            nspec = torch.view_as_real(torch.stft(noisy_s, 400, 100, window=win, onesided=True, return_complex=True))
+            cspec = torch.view_as_real(torch.stft(clean_s, 400, 100, window=win, onesided=True, return_complex=True))
+            nspec = ref_utils.power_compress(nspec).permute(0, 1, 3, 2)
+            cspec = ref_utils.power_compress(cspec)
+            clean_real, clean_imag = cspec[:, 0:1], cspec[:, 1:2]
+            er0, ei0 = gmodel(nspec)                                   # [B,1,T,F]
+            if er0.requires_grad:
+                er0.retain_grad(); ei0.retain_grad()
+            er, ei = er0.permute(0, 1, 3, 2), ei0.permute(0, 1, 3, 2)
+            est_mag = torch.sqrt(er ** 2 + ei ** 2)
+            clean_mag = torch.sqrt(clean_real ** 2 + clean_imag ** 2)
+            unc = ref_utils.power_uncompress(er, ei).squeeze(1)
+            est_audio = torch.istft(torch.view_as_complex(unc.contiguous()), 400, 100, window=win, onesided=True)
+            F_ = torch.nn.functional
+            loss_mag = F_.mse_loss(est_mag, clean_mag)
+            loss_ri = F_.mse_loss(er, clean_real) + F_.mse_loss(ei, clean_imag)
+            time_loss = torch.mean(torch.abs(est_audio - gclean))
+            loss = 0.1 * loss_ri + 0.9 * loss_mag + 0.2 * time_loss
+            return loss, (loss_ri, loss_mag, time_loss), er0, ei0
+
+        opt = torch.optim.AdamW(gmodel.parameters(), lr=5e-4)
+        loss1, terms1, er0, ei0 = gen_step()
+        opt.zero_grad()
+        loss1.backward()
+        digest = {}
+        for k, v in gmodel.named_parameters():
+            gflat = v.grad.detach().reshape(-1)
+            idx = torch.from_numpy(sample_indices(gflat.numel()))
+            digest["gsum_" + k] = gflat.double().sum().float()
+            digest["gl2_" + k] = gflat.double().norm().float()
+            digest["gsmp_" + k] = gflat[idx].clone()
+        d_er, d_ei = er0.grad.detach().clone(), ei0.grad.detach().clone()
+        opt.step()
+        with torch.no_grad():
+            loss2, terms2, _, _ = gen_step()
+        bn = gmodel.TSCB_2.freq_conformer.conv.net[5]
+    save("generator_step.npz", clean=gclean, noisy=gnoisy, loss=loss1.detach(), terms=torch.stack(terms1).detach(),
+         est_real=er0.detach(), est_imag=ei0.detach(), d_real=d_er, d_imag=d_ei, loss2=loss2.detach(),
+         terms2=torch.stack(terms2).detach(), bn_mean=bn.running_mean.detach().clone(),
+         bn_var=bn.running_var.detach().clone(), **digest)
+
     save("ffn_train.npz", x=xt.detach(), dy=dy, mask1=m1, mask2=m2, y=yt.detach(), dx=xt.grad.detach(),
          y_nomask=y0.detach(), dx_nomask=x0.grad.detach(), **grads, **grads0)
 

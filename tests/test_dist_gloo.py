@@ -97,4 +97,7 @@ def test_flat_gradient_bucket_is_averaged_with_one_allreduce():
     mp.spawn(_bucket_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert ret["ok"] is True
     b = cdist.FlatBucket({"a": (3,), "b": (2, 2)}).load({"a": torch.arange(3.0), "b": torch.ones(2, 2)})
-    assert b.flat.tolist() == [0, 1, 2, 1, 1, 1, 1] and torch.equal(cdist.allreduce_mean(b.flat), b.flat)
+    # tensors start on 64-byte boundaries; the padding stays zero
+    assert b.numel == 32 and b.flat[:3].tolist() == [0, 1, 2] and b.flat[16:20].tolist() == [1, 1, 1, 1]
+    assert float(b.flat.sum()) == 7.0 and b["b"].data_ptr() - b["a"].data_ptr() == 64
+    assert torch.equal(cdist.allreduce_mean(b.flat), b.flat)

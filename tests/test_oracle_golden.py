@@ -2,6 +2,7 @@
 reference's own modules (tests/golden/make_golden.py).  CPU only."""
 import json
 import os
+import re
 
 import pytest
 import torch
@@ -237,6 +238,104 @@ def test_dense_block_gradients(sd):
             assert float(v.grad.abs().max()) < 1e-4 * float(g["grad_norm1_bias"].abs().max())
             continue
         assert rel_err(v.grad, want) < 5e-5, k
+
+
+def test_dense_encoder_gradients(sd):
+    g = load_golden("encoder_train.npz")
+    pre = "dense_encoder."
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith(pre)}
+    sdx = dict(sd)
+    sdx.update(leaf)
+    with torch.enable_grad():
+        y = O.dense_encoder(sdx, g["x"])
+        y.backward(g["dy"])
+    assert rel_err(y, g["y"]) < TOL
+    for k, v in leaf.items():
+        want = g["grad_" + k[len(pre):].replace(".", "_")]
+        if k.endswith(".0.bias") or re.search(r"\.conv\d\.bias$", k):          # conv biases in front of an InstanceNorm
+            assert float(v.grad.abs().max()) < 1e-4 * float(g["grad_conv_1_1_bias"].abs().max())
+            continue
+        assert rel_err(v.grad, want) < 5e-5, k
+
+
+def _decoder_case(sd, fixture, pre, fn, num_features=None):
+    g = load_golden(fixture)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith(pre)}
+    if num_features is not None:
+        leaf[pre + "prelu_out.weight"] = sd[pre + "prelu_out.weight"][:num_features].clone().requires_grad_(True)
+    sdx = dict(sd)
+    sdx.update(leaf)
+    x = g["x"].clone().requires_grad_(True)
+    with torch.enable_grad():
+        y = fn(sdx, x)
+        y.backward(g["dy"])
+    assert rel_err(y, g["y"]) < TOL
+    assert rel_err(x.grad, g["dx"]) < 5e-5
+    ref_scale = float(g["grad_norm_bias"].abs().max())
+    for k, v in leaf.items():
+        want = g["grad_" + k[len(pre):].replace(".", "_")]
+        zero = [r"\.conv\d\.bias$", r"sub_pixel\.conv\.bias$"] if "complex" in pre else [r"\.conv\d\.bias$", r"conv_1\.bias$"]
+        if any(re.search(z, k) for z in zero):
+            # a bias in front of an InstanceNorm: exactly zero gradient (rounding noise in both implementations)
+            assert float((v.grad - want).abs().max()) < 1e-4 * max(ref_scale, float(want.abs().max())), k
+            continue
+        assert rel_err(v.grad, want) < 5e-5, k
+
+
+def test_mask_decoder_gradients(sd):
+    _decoder_case(sd, "maskdec_train.npz", "mask_decoder.", O.mask_decoder, num_features=21)
+
+
+def test_complex_decoder_gradients(sd):
+    _decoder_case(sd, "complexdec_train.npz", "complex_decoder.", O.complex_decoder)
+
+
+def test_generator_step_gradients(sd):
+    """One generator optimisation step of the reference trainer minus the discriminator: loss terms, the gradients at
+    the network output and the digests of all 335 parameter gradients."""
+    from cmgan_amd.synth import sample_indices, synthetic_dropout_masks
+    g = load_golden("generator_step.npz")
+    masks = [tuple({k: torch.from_numpy(v) for k, v in d.items()} for d in pair)
+             for pair in synthetic_dropout_masks(77, 2, 9, 101)]
+    out = O.generator_step_gradients(sd, g["clean"], g["noisy"], masks)
+    assert abs(float(out["loss"]) - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+    assert rel_err(out["terms"], g["terms"]) < 2e-5
+    assert rel_err(out["est_real"], g["est_real"]) < 5e-5 and rel_err(out["est_imag"], g["est_imag"]) < 5e-5
+    assert rel_err(out["d_real"], g["d_real"]) < 5e-5 and rel_err(out["d_imag"], g["d_imag"]) < 5e-5
+    keys = [k[len("gsmp_"):] for k in g if k.startswith("gsmp_")]
+    assert len(keys) == 335 and set(keys) == set(out["grads"])
+    scale = max(float(g["gl2_" + k]) for k in keys)
+    for k in keys:
+        got = out["grads"][k].reshape(-1)
+        l2 = float(g["gl2_" + k])
+        smp = got[torch.from_numpy(sample_indices(got.numel()))]
+        tol = 1e-4 * l2 + 1e-7 * scale                                  # zero-gradient biases: absolute floor
+        assert float((smp - g["gsmp_" + k]).abs().max()) < tol + 1e-4 * float(g["gsmp_" + k].abs().max()), k
+        assert abs(float(got.double().norm()) - l2) < 1e-4 * l2 + 1e-7 * scale, k
+
+
+def test_generator_gradient_noise_floor(sd):
+    """How well-defined the whole-network gradient is: the same step through the oracle in fp64.  PReLU and |.| kinks
+    make single elements jump, so fp32 autograd (the reference's and any re-implementation) agrees with fp64 only to
+    ~2e-4 (median over tensors, relative to the tensor's max) and ~1e-2 (worst tensor) on this fixture; the GPU test
+    of the whole step uses this measured floor as its bar, the per-module tests stay at 1e-6."""
+    from cmgan_amd.synth import synthetic_dropout_masks
+    g = load_golden("generator_step.npz")
+    masks = [tuple({k: torch.from_numpy(v) for k, v in d.items()} for d in pair)
+             for pair in synthetic_dropout_masks(77, 2, 9, 101)]
+    o32 = O.generator_step_gradients(sd, g["clean"], g["noisy"], masks)
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    m64 = [tuple({k: v.double() for k, v in d.items()} for d in pair) for pair in masks]
+    o64 = O.generator_step_gradients(sd64, g["clean"].double(), g["noisy"].double(), m64)
+    scale = max(float(v.abs().max()) for v in o64["grads"].values())
+    errs = []
+    for k, v64 in o64["grads"].items():
+        den = float(v64.abs().max())
+        if den > 1e-6 * scale:
+            errs.append(float((o32["grads"][k].double() - v64).abs().max()) / den)
+    errs = sorted(errs)
+    print(f"[noise floor] fp32 vs fp64 autograd: median {errs[len(errs) // 2]:.2e}, worst {errs[-1]:.2e}")
+    assert 1e-5 < errs[len(errs) // 2] < 1e-3 and errs[-1] < 5e-2
 
 
 def test_validation_step_losses_match_the_reference(sd):
