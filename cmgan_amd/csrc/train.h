@@ -17,7 +17,7 @@ struct FfnTrainParams {
     float *w2, *b2;           // Linear(256, 64): weight [64,256], bias     conformer.py:143
 };
 #define FFN_WGRAD_SPLIT 64
-#define FFN_COLSUM_BLOCKS 128
+#define FFN_COLSUM_BLOCKS 512
 size_t ffn_train_ws_floats(long M);
 void launch_ffn_train_forward(LaunchCtx, const float* x, long M, const FfnTrainParams& p, const float* m1,
                               const float* m2, float* y, float* ws);

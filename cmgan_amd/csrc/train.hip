@@ -303,15 +303,24 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* __restr
     }
 }
 
-// column sums of X [M,C] over NB fixed row ranges -> partial [NB][C]
+// column sums of X [M,C] over NB fixed row ranges -> partial [NB][C]; four independent accumulators per thread keep
+// four loads in flight (the loop is latency-bound otherwise), combined in a fixed order
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long M, int C,
                                                              float* __restrict__ partial) {
     __shared__ float red[256];
     const int col = threadIdx.x % C, sub = threadIdx.x / C, nsub = 256 / C;     // C divides 256
     const long per = (M + gridDim.x - 1) / gridDim.x;
     const long m0 = (long)blockIdx.x * per, m1 = m0 + per < M ? m0 + per : M;
-    float s = 0.f;
-    for (long m = m0 + sub; m < m1; m += nsub) s += X[m * C + col];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long m = m0 + sub;
+    for (; m + 3L * nsub < m1; m += 4L * nsub) {
+        s0 += X[m * C + col];
+        s1 += X[(m + nsub) * C + col];
+        s2 += X[(m + 2L * nsub) * C + col];
+        s3 += X[(m + 3L * nsub) * C + col];
+    }
+    for (; m < m1; m += nsub) s0 += X[m * C + col];
+    float s = (s0 + s1) + (s2 + s3);
     red[threadIdx.x] = s;
     __syncthreads();
     if (sub == 0) {
@@ -320,13 +329,34 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     }
 }
 
-// out[e] = sum_s partial[s][e] in index order
+// out[e] = sum_s partial[s][e]: a block owns 64 consecutive outputs at a time, its blockDim / 64 thread groups each
+// add every G-th slab (four loads in flight), the groups are combined in group order - a fixed order for a given
+// launch shape, coalesced 256-byte reads.  Final column sums (n <= 256) are launched as <<<4, 1024>>>.
 __global__ void reduce_partials_kernel(const float* __restrict__ partial, int nsplit, long n, float* __restrict__ out) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[(long)k * n + e];
-    out[e] = s;
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6, G = blockDim.x >> 6;
+    for (long chunk = blockIdx.x; chunk * 64 < n; chunk += gridDim.x) {
+        const long e = chunk * 64 + col;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (e < n) {
+            int k = grp;
+            for (; k + 3 * G < nsplit; k += 4 * G) {
+                s0 += partial[(long)k * n + e];
+                s1 += partial[(long)(k + G) * n + e];
+                s2 += partial[(long)(k + 2 * G) * n + e];
+                s3 += partial[(long)(k + 3 * G) * n + e];
+            }
+            for (; k < nsplit; k += G) s0 += partial[(long)k * n + e];
+        }
+        red[grp][col] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (grp == 0 && e < n) {
+            float s = red[0][col];
+            for (int g = 1; g < G; ++g) s += red[g][col];
+            out[e] = s;
+        }
+        __syncthreads();
+    }
 }
 
 static FfnTrainImg ffn_pack_images(LaunchCtx ctx, const FfnTrainParams& p, float* img) {
@@ -372,7 +402,7 @@ void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, l
         {o.dh, 256, grad.b1}, {o.dz, 64, grad.b2}, {o.g1, 64, grad.gamma}, {o.dxn, 64, grad.beta}};
     for (auto& cs : sums) {
         LAUNCH(ctx, "ffn_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(cs.X, M, cs.C, cpart)));
-        LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<1, 256, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, cs.C, cs.out)));
+        LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, cs.C, cs.out)));
     }
 }
 
@@ -514,16 +544,29 @@ __global__ __launch_bounds__(256) void cm_depthwise_kernel(const float* __restri
 }
 
 // batch statistics of BatchNorm1d(128) in train mode (biased variance, eps 1e-5) from the per-block partial sums, in
-// fp64 and block order; running statistics updated like torch (momentum 0.1, unbiased variance)   conformer.py:168
-__global__ void cm_bn_finalize_kernel(const float* __restrict__ stats, long nblk, double count,
+// fp64: 64 blocks each add every 64-th slab of 256 floats (channel, {sum, sum of squares}), the finalize adds the 64
+// partials in order; running statistics updated like torch (momentum 0.1, unbiased variance)   conformer.py:168
+#define CM_BN_RED 64
+__global__ __launch_bounds__(256) void cm_bn_reduce_kernel(const float* __restrict__ stats, long nblk,
+                                                           double* __restrict__ part) {
+    double a0 = 0.0, a1 = 0.0;
+    long k = blockIdx.x;
+    for (; k + CM_BN_RED < nblk; k += 2 * CM_BN_RED) {
+        a0 += (double)stats[k * 256 + threadIdx.x];
+        a1 += (double)stats[(k + CM_BN_RED) * 256 + threadIdx.x];
+    }
+    if (k < nblk) a0 += (double)stats[k * 256 + threadIdx.x];
+    part[(long)blockIdx.x * 256 + threadIdx.x] = a0 + a1;
+}
+__global__ void cm_bn_finalize_kernel(const double* __restrict__ part, double count,
                                       const float* __restrict__ bn_w, const float* __restrict__ bn_b, CmStats st,
                                       float* __restrict__ running_mean, float* __restrict__ running_var) {
     const int ch = threadIdx.x;
     if (ch >= 128) return;
     double s1 = 0.0, s2 = 0.0;
-    for (long k = 0; k < nblk; ++k) {
-        s1 += (double)stats[(k * 128 + ch) * 2];
-        s2 += (double)stats[(k * 128 + ch) * 2 + 1];
+    for (int k = 0; k < CM_BN_RED; ++k) {
+        s1 += part[(long)k * 256 + ch * 2];
+        s2 += part[(long)k * 256 + ch * 2 + 1];
     }
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
@@ -614,36 +657,44 @@ __global__ __launch_bounds__(256) void cm_bn_bwd_kernel(float* __restrict__ ddn,
     }
 }
 
-// depthwise weight gradient: dw[ch][t] = sum_{n,l} dd[(n,l)][ch] u[(n, l + t - 15)][ch] -> partial [blk][128*31]
+// depthwise weight gradient: dw[ch][t] = sum_{n,l} dd[(n,l)][ch] u[(n, l + t - 15)][ch] -> partial [blk][128*31].
+// At most CM_DW_SLABS blocks walk the (sequence, 32-token tile) list with a fixed stride and keep their 31 taps in
+// registers across tiles, so the second-stage reduction reads a few hundred slabs instead of one per tile.
+#define CM_DW_SLABS 512
 __global__ __launch_bounds__(256) void cm_dw_wgrad_kernel(const float* __restrict__ dd, const float* __restrict__ u, int L,
-                                                          float* __restrict__ partial) {
+                                                          int ntile_l, long ntile, float* __restrict__ partial) {
     __shared__ float red[128 * 31];
     const int ch = threadIdx.x & 127, sub = threadIdx.x >> 7;
-    const int n = blockIdx.x, l0 = blockIdx.y * 32 + sub * 16;
-    const float* ub = u + (long)n * L * 128 + ch;
-    const float* db = dd + (long)n * L * 128 + ch;
-    // unconditional (clamped) loads + selects, and tap-major loops with compile-time indices only: the
-    // output-major form with `acc[kk - oo]` left the 46-step loop rolled and indexed registers dynamically
-    float g[16], uw[46];
-#pragma unroll
-    for (int oo = 0; oo < 16; ++oo) {
-        const int l = l0 + oo, lc = l < L ? l : L - 1;
-        const float v = db[(long)lc * 128];
-        g[oo] = l < L ? v : 0.f;
-    }
-#pragma unroll
-    for (int kk = 0; kk < 46; ++kk) {
-        const int l = l0 - 15 + kk, lc = l < 0 ? 0 : (l < L ? l : L - 1);
-        const float v = ub[(long)lc * 128];
-        uw[kk] = (l >= 0 && l < L) ? v : 0.f;
-    }
     float acc[31];
 #pragma unroll
-    for (int t = 0; t < 31; ++t) {
-        float a = 0.f;
+    for (int t = 0; t < 31; ++t) acc[t] = 0.f;
+    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const long n = tile / ntile_l;
+        const int l0 = (int)(tile - n * ntile_l) * 32 + sub * 16;
+        const float* ub = u + n * L * 128 + ch;
+        const float* db = dd + n * L * 128 + ch;
+        // unconditional (clamped) loads + selects, and tap-major loops with compile-time indices only: the
+        // output-major form with `acc[kk - oo]` left the 46-step loop rolled and indexed registers dynamically
+        float g[16], uw[46];
 #pragma unroll
-        for (int oo = 0; oo < 16; ++oo) a = fmaf(g[oo], uw[oo + t], a);
-        acc[t] = a;
+        for (int oo = 0; oo < 16; ++oo) {
+            const int l = l0 + oo, lc = l < L ? l : L - 1;
+            const float v = db[(long)lc * 128];
+            g[oo] = l < L ? v : 0.f;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 46; ++kk) {
+            const int l = l0 - 15 + kk, lc = l < 0 ? 0 : (l < L ? l : L - 1);
+            const float v = ub[(long)lc * 128];
+            uw[kk] = (l >= 0 && l < L) ? v : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 31; ++t) {
+            float a = acc[t];
+#pragma unroll
+            for (int oo = 0; oo < 16; ++oo) a = fmaf(g[oo], uw[oo + t], a);
+            acc[t] = a;
+        }
     }
     if (sub == 1) {
 #pragma unroll
@@ -651,9 +702,8 @@ __global__ __launch_bounds__(256) void cm_dw_wgrad_kernel(const float* __restric
     }
     __syncthreads();
     if (sub == 0) {
-        const long blk = (long)blockIdx.x * gridDim.y + blockIdx.y;
 #pragma unroll
-        for (int t = 0; t < 31; ++t) partial[blk * 3968 + ch * 31 + t] = acc[t] + red[ch * 31 + t];
+        for (int t = 0; t < 31; ++t) partial[(long)blockIdx.x * 3968 + ch * 31 + t] = acc[t] + red[ch * 31 + t];
     }
 }
 
@@ -727,7 +777,7 @@ __global__ __launch_bounds__(256) void cm_bwd2_kernel(const float* __restrict__ 
 
 // workspace layout (floats): images | u | d | stats (4 x 128) | bwd buffers | partials
 struct CmPlan {
-    size_t img, u, d, st, ddn, s, g2, du, dag, xn, g1, dxn, wpart, dwpart, bnpart, cpart, sums, total;
+    size_t img, u, d, st, ddn, s, g2, du, dag, xn, g1, dxn, wpart, dwpart, bnpart, bnred, cpart, sums, total;
 };
 static CmPlan cm_plan(int N, int L) {
     CmPlan p;
@@ -739,8 +789,9 @@ static CmPlan cm_plan(int N, int L) {
     p.ddn = take(M * 128); p.s = take(M * 128); p.g2 = take(M * 128); p.du = take(M * 128);
     p.dag = take(M * 256); p.xn = take(M * 64); p.g1 = take(M * 64); p.dxn = take(M * 64);
     p.wpart = take((size_t)FFN_WGRAD_SPLIT * 16384);
-    p.dwpart = take(nblk * 3968);
+    p.dwpart = take((size_t)CM_DW_SLABS * 3968);
     p.bnpart = take(nblk * 256);
+    p.bnred = take((size_t)CM_BN_RED * 256 * 2);        // doubles
     p.cpart = take((size_t)FFN_COLSUM_BLOCKS * 256);
     p.sums = take(256);
     p.total = cur;
@@ -770,9 +821,11 @@ void launch_convmod_train_forward(LaunchCtx ctx, const float* x, int N, int L, c
     LAUNCH(ctx, "convmod_train_fwd", (cm_pw1glu_kernel<<<grid, 256, 0, s>>>(x, M, im.w1, p, ws + pl.u)));
     LAUNCH(ctx, "convmod_train_fwd", (cm_depthwise_kernel<<<dgrid, 256, 0, s>>>(ws + pl.u, p.dw_w, p.dw_b, 0, L, ws + pl.d,
                                                                                 ws + pl.bnpart)));
-    LAUNCH(ctx, "convmod_train_fwd", (cm_bn_finalize_kernel<<<1, 128, 0, s>>>(ws + pl.bnpart, (long)dgrid.x * dgrid.y,
-                                                                              (double)M, p.bn_w, p.bn_b, st, running_mean,
-                                                                              running_var)));
+    double* bnred = (double*)(ws + pl.bnred);
+    LAUNCH(ctx, "convmod_train_fwd", (cm_bn_reduce_kernel<<<CM_BN_RED, 256, 0, s>>>(ws + pl.bnpart, (long)dgrid.x * dgrid.y,
+                                                                                    bnred)));
+    LAUNCH(ctx, "convmod_train_fwd", (cm_bn_finalize_kernel<<<1, 128, 0, s>>>(bnred, (double)M, p.bn_w, p.bn_b, st,
+                                                                              running_mean, running_var)));
     LAUNCH(ctx, "convmod_train_fwd", (cm_bn_swish_pw2_kernel<<<grid, 256, 0, s>>>(ws + pl.d, M, st, im.w2, p.pw2_b, y)));
 }
 
@@ -791,7 +844,7 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     float* sum_g2 = ws + pl.sums + 128;
     auto colsum = [&](const float* X, int C, float* out) {
         LAUNCH(ctx, "convmod_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(X, M, C, cpart)));
-        LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<1, 256, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, C, out)));
+        LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, C, out)));
     };
     LAUNCH(ctx, "convmod_train_bwd", (cm_bwd1_kernel<<<grid, 256, 0, s>>>(dy, ws + pl.d, M, st, im.w2t, ws + pl.ddn,
                                                                           ws + pl.s, ws + pl.g2)));
@@ -811,9 +864,10 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     float* dd = ws + pl.ddn;
     // depthwise: bias / weight gradients, then the data gradient (same kernel, flipped taps)
     colsum(dd, 128, grad.dw_b);
-    LAUNCH(ctx, "convmod_train_wgrad", (cm_dw_wgrad_kernel<<<dgrid, 256, 0, s>>>(dd, ws + pl.u, L, ws + pl.dwpart)));
-    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<16, 256, 0, s>>>(ws + pl.dwpart, (int)nblk, 3968,
-                                                                                   grad.dw_w)));
+    const int nslab = (int)(nblk < CM_DW_SLABS ? nblk : CM_DW_SLABS);
+    LAUNCH(ctx, "convmod_train_wgrad", (cm_dw_wgrad_kernel<<<nslab, 256, 0, s>>>(dd, ws + pl.u, L, (int)dgrid.y, nblk,
+                                                                                 ws + pl.dwpart)));
+    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<62, 1024, 0, s>>>(ws + pl.dwpart, nslab, 3968, grad.dw_w)));
     LAUNCH(ctx, "convmod_train_bwd", (cm_depthwise_kernel<<<dgrid, 256, 0, s>>>(dd, p.dw_w, nullptr, 1, L, ws + pl.du,
                                                                                 nullptr)));
     LAUNCH(ctx, "convmod_train_bwd", (cm_bwd2_kernel<<<grid, 256, 0, s>>>(x, ws + pl.du, M, im.w1, im.w1t, p, dx,
@@ -891,32 +945,70 @@ __device__ __forceinline__ float at_dot16(const float (&a)[16], const float* __r
     return s;
 }
 
-// forward core: one block per (sequence, head), one thread per query row (two passes over the keys)
-__global__ __launch_bounds__(256) void at_core_fwd_kernel(AtBufs b, const float* __restrict__ rel, int L, int max_pos) {
+// Work split of the four core kernels: a block owns one (sequence, head); its threads are QPB x KS with QPB = L rounded
+// up to a wave multiple and KS = blockDim / QPB.  Thread (iq, ks) owns row iq (a query, a key or a distance) and
+// every KS-th element of the reduction axis, so that a wave reads ONE K / V row (broadcast) and 64 consecutive
+// relative-position rows (conflict-free at pitch 17) per step.  The KS partial results of a row are merged through
+// LDS in ks order (the staged operands are dead by then) - deterministic, no atomics.
+struct AtSplit { int qpb, ks; };
+static AtSplit at_split(int L) {
+    AtSplit sp;
+    sp.qpb = (L + 63) / 64 * 64;
+    sp.ks = 1024 / sp.qpb;
+    if (sp.ks > 8) sp.ks = 8;
+    if (sp.ks < 1) sp.ks = 1;
+    return sp;
+}
+// LDS floats: the larger of the staged operands and the merge buffer [(ks - 1)][qpb][width]
+static size_t at_lds_bytes(size_t staged_floats, const AtSplit& sp, int width) {
+    const size_t merge = (size_t)(sp.ks - 1) * sp.qpb * width;
+    return (staged_floats > merge ? staged_floats : merge) * sizeof(float);
+}
+
+// forward core: online softmax over this thread's keys, then a log-sum-exp merge of the KS partial rows
+__global__ __launch_bounds__(1024) void at_core_fwd_kernel(AtBufs b, const float* __restrict__ rel, int L, int max_pos,
+                                                           int qpb) {
     extern __shared__ float sm[];
     float* K = sm;                        // [L][AT_P]
     float* V = K + L * AT_P;
     float* E = V + L * AT_P;              // [2L-1][AT_P]
     const int n = blockIdx.x, h = blockIdx.y;
     const long base = (long)n * L;
+    const int iq = threadIdx.x % qpb, ks = threadIdx.x / qpb, KS = blockDim.x / qpb;
     at_stage(K, b.qkv, 192, 64 + 16 * h, base, L);
     at_stage(V, b.qkv, 192, 128 + 16 * h, base, L);
     at_stage_rel(E, rel, L, max_pos);
     __syncthreads();
-    for (int i = threadIdx.x; i < L; i += blockDim.x) {
-        float q[16];
+    const bool act = iq < L;
+    const int i = act ? iq : L - 1;
+    float q[16], o[16];
 #pragma unroll
-        for (int d = 0; d < 16; ++d) q[d] = b.qkv[(base + i) * 192 + 16 * h + d] * 0.25f;     // scale = 16^-0.5
-        float m = -INFINITY;
-        for (int j = 0; j < L; ++j) m = fmaxf(m, at_dot16(q, K + j * AT_P) + at_dot16(q, E + (i - j + L - 1) * AT_P));
-        float l = 0.f, o[16];
+    for (int d = 0; d < 16; ++d) { q[d] = b.qkv[(base + i) * 192 + 16 * h + d] * 0.25f; o[d] = 0.f; }     // scale = 16^-0.5
+    float m = -1e30f, l = 0.f;
+    for (int j = ks; j < L; j += KS) {
+        const float sc = at_dot16(q, K + j * AT_P) + at_dot16(q, E + (i - j + L - 1) * AT_P);
+        const float mn = fmaxf(m, sc), c = __expf(m - mn), pj = __expf(sc - mn);
+        l = fmaf(l, c, pj);
 #pragma unroll
-        for (int d = 0; d < 16; ++d) o[d] = 0.f;
-        for (int j = 0; j < L; ++j) {
-            const float p = __expf(at_dot16(q, K + j * AT_P) + at_dot16(q, E + (i - j + L - 1) * AT_P) - m);
-            l += p;
+        for (int d = 0; d < 16; ++d) o[d] = fmaf(o[d], c, pj * V[j * AT_P + d]);
+        m = mn;
+    }
+    __syncthreads();                      // K / V / E are dead: reuse as the merge buffer [(KS-1)][qpb][18]
+    if (ks > 0) {
+        float* w = sm + ((long)(ks - 1) * qpb + iq) * 18;
+        w[0] = m; w[1] = l;
 #pragma unroll
-            for (int d = 0; d < 16; ++d) o[d] = fmaf(p, V[j * AT_P + d], o[d]);
+        for (int d = 0; d < 16; ++d) w[2 + d] = o[d];
+    }
+    __syncthreads();
+    if (ks == 0 && act) {
+        for (int k2 = 1; k2 < KS; ++k2) {
+            const float* w = sm + ((long)(k2 - 1) * qpb + iq) * 18;
+            const float m2 = w[0], mn = fmaxf(m, m2), c1 = __expf(m - mn), c2 = __expf(m2 - mn);
+            l = l * c1 + w[1] * c2;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) o[d] = o[d] * c1 + w[2 + d] * c2;
+            m = mn;
         }
         const float inv = 1.0f / l;
 #pragma unroll
@@ -991,44 +1083,67 @@ __device__ __forceinline__ AtPair at_pair(const float (&qs)[16], const float* __
     return r;
 }
 
-// dq: thread per query row                      dq_i = scale * sum_j ds_ij (k_j + E[i - j])
-__global__ __launch_bounds__(256) void at_core_bwd_dq_kernel(AtBufs b, const float* __restrict__ rel,
-                                                             const float* __restrict__ dO, const float* __restrict__ D,
-                                                             int L, int max_pos, float* __restrict__ dqkv) {
+// sum of the KS partial [W]-vectors of a row through LDS, in ks order; the result lands in acc of the ks = 0 thread
+template <int W>
+__device__ __forceinline__ void at_merge_sum(float* sm, float (&acc)[W], int iq, int ks, int KS, int qpb) {
+    __syncthreads();                      // the staged operands are dead
+    if (ks > 0) {
+        float* w = sm + ((long)(ks - 1) * qpb + iq) * W;
+#pragma unroll
+        for (int d = 0; d < W; ++d) w[d] = acc[d];
+    }
+    __syncthreads();
+    if (ks == 0) {
+        for (int k2 = 1; k2 < KS; ++k2) {
+            const float* w = sm + ((long)(k2 - 1) * qpb + iq) * W;
+#pragma unroll
+            for (int d = 0; d < W; ++d) acc[d] += w[d];
+        }
+    }
+}
+
+// dq: thread (query i, key subset)             dq_i = scale * sum_j ds_ij (k_j + E[i - j])
+__global__ __launch_bounds__(1024) void at_core_bwd_dq_kernel(AtBufs b, const float* __restrict__ rel,
+                                                              const float* __restrict__ dO, const float* __restrict__ D,
+                                                              int L, int max_pos, int qpb, float* __restrict__ dqkv) {
     extern __shared__ float sm[];
     float* K = sm;
     float* V = K + L * AT_P;
     float* E = V + L * AT_P;
     const int n = blockIdx.x, h = blockIdx.y;
     const long base = (long)n * L;
+    const int iq = threadIdx.x % qpb, ks = threadIdx.x / qpb, KS = blockDim.x / qpb;
     at_stage(K, b.qkv, 192, 64 + 16 * h, base, L);
     at_stage(V, b.qkv, 192, 128 + 16 * h, base, L);
     at_stage_rel(E, rel, L, max_pos);
     __syncthreads();
-    for (int i = threadIdx.x; i < L; i += blockDim.x) {
-        float qs[16], dOi[16], dq[16];
+    const bool act = iq < L;
+    const int i = act ? iq : L - 1;
+    float qs[16], dOi[16], dq[16];
 #pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            qs[d] = b.qkv[(base + i) * 192 + 16 * h + d] * 0.25f;
-            dOi[d] = dO[(base + i) * 64 + 16 * h + d];
-            dq[d] = 0.f;
-        }
-        const float lse = b.lse[((long)n * 4 + h) * L + i], Di = D[(base + i) * 4 + h];
-        for (int j = 0; j < L; ++j) {
-            const float* er = E + (i - j + L - 1) * AT_P;
-            const AtPair pr = at_pair(qs, K + j * AT_P, er, dOi, V + j * AT_P, lse, Di);
+    for (int d = 0; d < 16; ++d) {
+        qs[d] = b.qkv[(base + i) * 192 + 16 * h + d] * 0.25f;
+        dOi[d] = dO[(base + i) * 64 + 16 * h + d];
+        dq[d] = 0.f;
+    }
+    const float lse = b.lse[((long)n * 4 + h) * L + i], Di = D[(base + i) * 4 + h];
+    for (int j = ks; j < L; j += KS) {
+        const float* er = E + (i - j + L - 1) * AT_P;
+        const AtPair pr = at_pair(qs, K + j * AT_P, er, dOi, V + j * AT_P, lse, Di);
 #pragma unroll
-            for (int d = 0; d < 16; ++d) dq[d] = fmaf(pr.ds, K[j * AT_P + d] + er[d], dq[d]);
-        }
+        for (int d = 0; d < 16; ++d) dq[d] = fmaf(pr.ds, K[j * AT_P + d] + er[d], dq[d]);
+    }
+    at_merge_sum<16>(sm, dq, iq, ks, KS, qpb);
+    if (ks == 0 && act) {
 #pragma unroll
         for (int d = 0; d < 16; ++d) dqkv[(base + i) * 192 + 16 * h + d] = dq[d] * 0.25f;
     }
 }
 
-// dk, dv: thread per key                        dk_j = scale * sum_i ds_ij q_i,  dv_j = sum_i p_ij dO_i
-__global__ __launch_bounds__(256) void at_core_bwd_dkv_kernel(AtBufs b, const float* __restrict__ rel,
-                                                              const float* __restrict__ dO, const float* __restrict__ D,
-                                                              int L, int max_pos, float* __restrict__ dqkv) {
+// dk, dv: thread (key j, query subset)          dk_j = scale * sum_i ds_ij q_i,  dv_j = sum_i p_ij dO_i
+__global__ __launch_bounds__(1024) void at_core_bwd_dkv_kernel(AtBufs b, const float* __restrict__ rel,
+                                                               const float* __restrict__ dO, const float* __restrict__ D,
+                                                               int L, int max_pos, int qpb, float* __restrict__ dqkv) {
     extern __shared__ float sm[];
     float* Q = sm;                         // q * scale
     float* G = Q + L * AT_P;               // dO
@@ -1037,6 +1152,7 @@ __global__ __launch_bounds__(256) void at_core_bwd_dkv_kernel(AtBufs b, const fl
     float* Dl = lse + L;
     const int n = blockIdx.x, h = blockIdx.y;
     const long base = (long)n * L;
+    const int jq = threadIdx.x % qpb, ks = threadIdx.x / qpb, KS = blockDim.x / qpb;
     at_stage(Q, b.qkv, 192, 16 * h, base, L);
     at_stage(G, dO, 64, 16 * h, base, L);
     at_stage_rel(E, rel, L, max_pos);
@@ -1047,37 +1163,41 @@ __global__ __launch_bounds__(256) void at_core_bwd_dkv_kernel(AtBufs b, const fl
     __syncthreads();
     for (int i = threadIdx.x; i < L * 16; i += blockDim.x) Q[(i >> 4) * AT_P + (i & 15)] *= 0.25f;
     __syncthreads();
-    for (int j = threadIdx.x; j < L; j += blockDim.x) {
-        float kj[16], vj[16], dk[16], dv[16];
+    const bool act = jq < L;
+    const int j = act ? jq : L - 1;
+    float kj[16], vj[16], acc[32];         // acc = dk | dv
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        kj[d] = b.qkv[(base + j) * 192 + 64 + 16 * h + d];
+        vj[d] = b.qkv[(base + j) * 192 + 128 + 16 * h + d];
+        acc[d] = 0.f; acc[16 + d] = 0.f;
+    }
+    for (int i = ks; i < L; i += KS) {
+        float qs[16], dOi[16];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) { qs[d] = Q[i * AT_P + d]; dOi[d] = G[i * AT_P + d]; }
+        const AtPair pr = at_pair(qs, kj, E + (i - j + L - 1) * AT_P, dOi, vj, lse[i], Dl[i]);
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
-            kj[d] = b.qkv[(base + j) * 192 + 64 + 16 * h + d];
-            vj[d] = b.qkv[(base + j) * 192 + 128 + 16 * h + d];
-            dk[d] = 0.f; dv[d] = 0.f;
+            acc[d] = fmaf(pr.ds, qs[d], acc[d]);                  // qs already carries one factor of scale
+            acc[16 + d] = fmaf(pr.p, dOi[d], acc[16 + d]);
         }
-        for (int i = 0; i < L; ++i) {
-            float qs[16], dOi[16];
-#pragma unroll
-            for (int d = 0; d < 16; ++d) { qs[d] = Q[i * AT_P + d]; dOi[d] = G[i * AT_P + d]; }
-            const AtPair pr = at_pair(qs, kj, E + (i - j + L - 1) * AT_P, dOi, vj, lse[i], Dl[i]);
-#pragma unroll
-            for (int d = 0; d < 16; ++d) {
-                dk[d] = fmaf(pr.ds, qs[d], dk[d]);            // qs already carries one factor of scale
-                dv[d] = fmaf(pr.p, dOi[d], dv[d]);
-            }
-        }
+    }
+    at_merge_sum<32>(sm, acc, jq, ks, KS, qpb);
+    if (ks == 0 && act) {
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
-            dqkv[(base + j) * 192 + 64 + 16 * h + d] = dk[d];
-            dqkv[(base + j) * 192 + 128 + 16 * h + d] = dv[d];
+            dqkv[(base + j) * 192 + 64 + 16 * h + d] = acc[d];
+            dqkv[(base + j) * 192 + 128 + 16 * h + d] = acc[16 + d];
         }
     }
 }
 
-// dE window: thread per relative distance       dEwin[r] = scale * sum_{i - j = r - (L-1)} ds_ij q_i  -> partial [(n,h)][2L-1][16]
-__global__ __launch_bounds__(256) void at_core_bwd_de_kernel(AtBufs b, const float* __restrict__ rel,
-                                                             const float* __restrict__ dO, const float* __restrict__ D,
-                                                             int L, int max_pos, float* __restrict__ partial) {
+// dE window: thread (relative distance, diagonal subset)
+//   dEwin[r] = scale * sum_{i - j = r - (L-1)} ds_ij q_i  -> partial [(n,h)][2L-1][16]
+__global__ __launch_bounds__(1024) void at_core_bwd_de_kernel(AtBufs b, const float* __restrict__ rel,
+                                                              const float* __restrict__ dO, const float* __restrict__ D,
+                                                              int L, int max_pos, int qpb, float* __restrict__ partial) {
     extern __shared__ float sm[];
     float* Q = sm;                         // q * scale
     float* G = Q + L * AT_P;
@@ -1087,6 +1207,7 @@ __global__ __launch_bounds__(256) void at_core_bwd_de_kernel(AtBufs b, const flo
     float* Dl = lse + L;
     const int n = blockIdx.x, h = blockIdx.y;
     const long base = (long)n * L;
+    const int rq = threadIdx.x % qpb, ks = threadIdx.x / qpb, KS = blockDim.x / qpb;      // here qpb >= 2 L - 1
     at_stage(Q, b.qkv, 192, 16 * h, base, L);
     at_stage(K, b.qkv, 192, 64 + 16 * h, base, L);
     at_stage(V, b.qkv, 192, 128 + 16 * h, base, L);
@@ -1098,22 +1219,25 @@ __global__ __launch_bounds__(256) void at_core_bwd_de_kernel(AtBufs b, const flo
     __syncthreads();
     for (int i = threadIdx.x; i < L * 16; i += blockDim.x) Q[(i >> 4) * AT_P + (i & 15)] *= 0.25f;
     __syncthreads();
-    for (int r = threadIdx.x; r < 2 * L - 1; r += blockDim.x) {
-        const int dist = r - (L - 1);
-        int e = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
-        float er[16], acc[16];
+    const bool act = rq < 2 * L - 1;
+    const int r = act ? rq : 2 * L - 2;
+    const int dist = r - (L - 1);
+    const int e = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
+    float er[16], acc[16];
 #pragma unroll
-        for (int d = 0; d < 16; ++d) { er[d] = rel[(long)(e + max_pos) * 16 + d]; acc[d] = 0.f; }
-        const int i0 = dist > 0 ? dist : 0, i1 = dist > 0 ? L : L + dist;     // j = i - dist in [0, L)
-        for (int i = i0; i < i1; ++i) {
-            const int j = i - dist;
-            float qs[16], dOi[16];
+    for (int d = 0; d < 16; ++d) { er[d] = rel[(long)(e + max_pos) * 16 + d]; acc[d] = 0.f; }
+    const int i0 = dist > 0 ? dist : 0, i1 = dist > 0 ? L : L + dist;     // j = i - dist in [0, L)
+    for (int i = i0 + ks; i < i1; i += KS) {
+        const int j = i - dist;
+        float qs[16], dOi[16];
 #pragma unroll
-            for (int d = 0; d < 16; ++d) { qs[d] = Q[i * AT_P + d]; dOi[d] = G[i * AT_P + d]; }
-            const AtPair pr = at_pair(qs, K + j * AT_P, er, dOi, V + j * AT_P, lse[i], Dl[i]);
+        for (int d = 0; d < 16; ++d) { qs[d] = Q[i * AT_P + d]; dOi[d] = G[i * AT_P + d]; }
+        const AtPair pr = at_pair(qs, K + j * AT_P, er, dOi, V + j * AT_P, lse[i], Dl[i]);
 #pragma unroll
-            for (int d = 0; d < 16; ++d) acc[d] = fmaf(pr.ds, qs[d], acc[d]);
-        }
+        for (int d = 0; d < 16; ++d) acc[d] = fmaf(pr.ds, qs[d], acc[d]);
+    }
+    at_merge_sum<16>(sm, acc, rq, ks, KS, qpb);
+    if (ks == 0 && act) {
 #pragma unroll
         for (int d = 0; d < 16; ++d) partial[(((long)n * 4 + h) * (2 * L - 1) + r) * 16 + d] = acc[d];
     }
@@ -1196,7 +1320,7 @@ static void at_allow_lds(KernelT kernel, size_t bytes) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-struct AtPlan { size_t raw, wqkv, wqkvt, wo, wot, qkv, o, lse, dout, dO, D, dqkv, xn, g1, dxn, depart, wpart, cpart, total; };
+struct AtPlan { size_t raw, wqkv, wqkvt, wo, wot, qkv, o, lse, dout, dO, D, dqkv, xn, g1, dxn, depart, dewin, wpart, cpart, total; };
 static AtPlan at_plan(int N, int L) {
     AtPlan p;
     const size_t M = (size_t)N * L;
@@ -1207,6 +1331,7 @@ static AtPlan at_plan(int N, int L) {
     p.dout = take(M * 64); p.dO = take(M * 64); p.D = take(M * 4); p.dqkv = take(M * 192);
     p.xn = take(M * 64); p.g1 = take(M * 64); p.dxn = take(M * 64);
     p.depart = take((size_t)N * 4 * (2 * L - 1) * 16);
+    p.dewin = take((size_t)(2 * L - 1) * 16);
     p.wpart = take((size_t)FFN_WGRAD_SPLIT * 12288);
     p.cpart = take((size_t)FFN_COLSUM_BLOCKS * 256);
     p.total = cur;
@@ -1234,9 +1359,10 @@ void launch_attn_train_forward(LaunchCtx ctx, const float* x, int N, int L, cons
     const AtBufs b{ws + pl.qkv, ws + pl.o, ws + pl.lse};
     const unsigned grid = (unsigned)((M + 63) / 64);
     LAUNCH(ctx, "attn_train_fwd", (at_qkv_kernel<<<grid, 256, 0, s>>>(x, M, ws + pl.wqkv, p.ln_w, p.ln_b, b.qkv)));
-    const size_t shm = ((size_t)2 * L * AT_P + (size_t)(2 * L - 1) * AT_P) * sizeof(float);
+    const AtSplit sp = at_split(L);
+    const size_t shm = at_lds_bytes((size_t)2 * L * AT_P + (size_t)(2 * L - 1) * AT_P, sp, 18);
     at_allow_lds(at_core_fwd_kernel, shm);
-    LAUNCH(ctx, "attn_train_fwd", (at_core_fwd_kernel<<<dim3(N, 4), 256, shm, s>>>(b, p.rel, L, max_pos)));
+    LAUNCH(ctx, "attn_train_fwd", (at_core_fwd_kernel<<<dim3(N, 4), sp.qpb * sp.ks, shm, s>>>(b, p.rel, L, max_pos, sp.qpb)));
     LAUNCH(ctx, "attn_train_fwd", (at_out_kernel<<<grid, 256, 0, s>>>(b.o, M, ws + pl.wo, p.bo, mask, y)));
 }
 
@@ -1251,7 +1377,7 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     float* cpart = ws + pl.cpart;
     auto colsum = [&](const float* X, int C, float* out) {
         LAUNCH(ctx, "attn_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(X, M, C, cpart)));
-        LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<1, 256, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, C, out)));
+        LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, C, out)));
     };
     LAUNCH(ctx, "attn_train_bwd", (at_out_bwd_kernel<<<grid, 256, 0, s>>>(dy, mask, b.o, M, ws + pl.wot, ws + pl.dout,
                                                                           ws + pl.dO, ws + pl.D)));
@@ -1262,21 +1388,28 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
                                                                                 grad.wo)));
     colsum(ws + pl.dout, 64, grad.bo);
     // attention core: dq (rows), dk / dv (columns), dE (distances)
-    const size_t shm_q = ((size_t)2 * L * AT_P + (size_t)(2 * L - 1) * AT_P) * sizeof(float);
-    const size_t shm_kv = shm_q + (size_t)2 * L * sizeof(float);
-    const size_t shm_e = ((size_t)4 * L * AT_P + 2 * L) * sizeof(float);
+    const AtSplit sp = at_split(L), spe = at_split(2 * L - 1);
+    const size_t staged = (size_t)2 * L * AT_P + (size_t)(2 * L - 1) * AT_P;
+    const size_t shm_q = at_lds_bytes(staged, sp, 16);
+    const size_t shm_kv = at_lds_bytes(staged + 2 * L, sp, 32);
+    const size_t shm_e = at_lds_bytes((size_t)4 * L * AT_P + 2 * L, spe, 16);
     at_allow_lds(at_core_bwd_dq_kernel, shm_q);
     at_allow_lds(at_core_bwd_dkv_kernel, shm_kv);
     at_allow_lds(at_core_bwd_de_kernel, shm_e);
-    LAUNCH(ctx, "attn_train_bwd", (at_core_bwd_dq_kernel<<<dim3(N, 4), 256, shm_q, s>>>(b, p.rel, ws + pl.dO, ws + pl.D, L,
-                                                                                       max_pos, ws + pl.dqkv)));
-    LAUNCH(ctx, "attn_train_bwd", (at_core_bwd_dkv_kernel<<<dim3(N, 4), 256, shm_kv, s>>>(b, p.rel, ws + pl.dO, ws + pl.D, L,
-                                                                                         max_pos, ws + pl.dqkv)));
-    LAUNCH(ctx, "attn_train_bwd", (at_core_bwd_de_kernel<<<dim3(N, 4), 256, shm_e, s>>>(b, p.rel, ws + pl.dO, ws + pl.D, L,
-                                                                                       max_pos, ws + pl.depart)));
+    LAUNCH(ctx, "attn_train_bwd", (at_core_bwd_dq_kernel<<<dim3(N, 4), sp.qpb * sp.ks, shm_q, s>>>(
+                                      b, p.rel, ws + pl.dO, ws + pl.D, L, max_pos, sp.qpb, ws + pl.dqkv)));
+    LAUNCH(ctx, "attn_train_bwd", (at_core_bwd_dkv_kernel<<<dim3(N, 4), sp.qpb * sp.ks, shm_kv, s>>>(
+                                      b, p.rel, ws + pl.dO, ws + pl.D, L, max_pos, sp.qpb, ws + pl.dqkv)));
+    LAUNCH(ctx, "attn_train_bwd", (at_core_bwd_de_kernel<<<dim3(N, 4), spe.qpb * spe.ks, shm_e, s>>>(
+                                      b, p.rel, ws + pl.dO, ws + pl.D, L, max_pos, spe.qpb, ws + pl.depart)));
+    // rel_pos_emb gradient: sum the window partials over (n, h) first (grouped, coalesced), then fold the window rows
+    // onto the clamped table rows
+    const int win_elems = (2 * L - 1) * 16;
+    LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<(win_elems + 63) / 64, 1024, 0, s>>>(ws + pl.depart, N * 4,
+                                                                                                   win_elems, ws + pl.dewin)));
     const int rel_elems = (2 * max_pos + 1) * 16;
-    LAUNCH(ctx, "attn_train_reduce", (at_de_scatter_kernel<<<(rel_elems + 255) / 256, 256, 0, s>>>(ws + pl.depart, N * 4, L,
-                                                                                                  max_pos, grad.rel)));
+    LAUNCH(ctx, "attn_train_reduce", (at_de_scatter_kernel<<<(rel_elems + 255) / 256, 256, 0, s>>>(ws + pl.dewin, 1, L, max_pos,
+                                                                                                  grad.rel)));
     // projections + LayerNorm
     LAUNCH(ctx, "attn_train_bwd", (at_qkv_bwd_kernel<<<grid, 256, 0, s>>>(x, ws + pl.dqkv, M, ws + pl.wqkvt, p.ln_w, p.ln_b,
                                                                           dx, ws + pl.xn, ws + pl.g1, ws + pl.dxn)));
@@ -1367,9 +1500,9 @@ void launch_ln_train_backward(LaunchCtx ctx, const float* x, const float* dy, lo
     float* cpart = ws + (size_t)M * 64;
     LAUNCH(ctx, "ln_train", (ln_train_bwd_kernel<<<(unsigned)((M + 63) / 64), 256, 0, s>>>(x, dy, M, gamma, beta, dx, g1)));
     LAUNCH(ctx, "ln_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(g1, M, 64, cpart)));
-    LAUNCH(ctx, "ln_train", (reduce_partials_kernel<<<1, 256, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, 64, dgamma)));
+    LAUNCH(ctx, "ln_train", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, 64, dgamma)));
     LAUNCH(ctx, "ln_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(dy, M, 64, cpart)));
-    LAUNCH(ctx, "ln_train", (reduce_partials_kernel<<<1, 256, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, 64, dbeta)));
+    LAUNCH(ctx, "ln_train", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, 64, dbeta)));
 }
 
 // [B, A, C, 64] -> [B, C, A, 64]: the layout flip between the time-axis and frequency-axis sequences of a TSCB
@@ -1792,7 +1925,7 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
         LAUNCH(ctx, "dense_train_bwd", (db_in_bwd_kernel<<<2048, 256, 0, st>>>(g, z, M * 64, P, mean, rstd, p.norm_w[i],
                                                                                ws + pl.m1, ws + pl.m2)));
         LAUNCH(ctx, "dense_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(g, M, 64, cpart)));
-        LAUNCH(ctx, "dense_train_reduce", (reduce_partials_kernel<<<1, 256, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64,
+        LAUNCH(ctx, "dense_train_reduce", (reduce_partials_kernel<<<4, 1024, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64,
                                                                                      grad.conv_b[i])));
         const int dil = 1 << i, Cin = 64 * (i + 1);
         for (int s = 0; s <= i; ++s) {
@@ -2105,7 +2238,7 @@ void launch_encoder_train_backward(LaunchCtx ctx, const float* xin, const float*
     in_prelu_backward(ctx, ws + pl.z2, dz2, B, T * F2, p.n2_w, p.n2_b, p.p2_w, stt + 2 * B * 64, stt + 3 * B * 64, ws + pl.part,
                       ws + pl.m, ws + pl.m + B * 64, grad.n2_w, grad.n2_b, grad.p2_w);
     LAUNCH(ctx, "encoder_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz2, M2, 64, cpart)));
-    LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<1, 256, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64, grad.c2_b)));
+    LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64, grad.c2_b)));
     // the weight gradient reads conv_2's input d; only then is d overwritten by its own gradient dd
     rc_backward<1>(ctx, dz2, ws + pl.d, ws + pl.img2T, g2, nullptr, grad.c2_w, ws + pl.wpart);
     LAUNCH(ctx, "rowconv_train", (rc_dgrad_kernel<1><<<(unsigned)((M + 63) / 64), 256, 0, st>>>(dz2, ws + pl.img2T, g2,
@@ -2117,9 +2250,9 @@ void launch_encoder_train_backward(LaunchCtx ctx, const float* xin, const float*
     in_prelu_backward(ctx, ws + pl.z1, dz1, B, T * F, p.n1_w, p.n1_b, p.p1_w, stt, stt + B * 64, ws + pl.part, ws + pl.m,
                       ws + pl.m + B * 64, grad.n1_w, grad.n1_b, grad.p1_w);
     LAUNCH(ctx, "encoder_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz1, M, 64, cpart)));
-    LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<1, 256, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64, grad.c1_b)));
+    LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64, grad.c1_b)));
     LAUNCH(ctx, "encoder_train", (c1_wgrad_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz1, xin, M, ws + pl.wpart)));
-    LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<1, 256, 0, st>>>(ws + pl.wpart, FFN_COLSUM_BLOCKS, 192, grad.c1_w)));
+    LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(ws + pl.wpart, FFN_COLSUM_BLOCKS, 192, grad.c1_w)));
 }
 
 // ---- decoder tails: Conv2d(64 -> NO, (1,2)) with NO = 1 (mask head) or 2 (complex head) on a [R, W, 64] plane -------
@@ -2216,9 +2349,9 @@ static void tail_backward(LaunchCtx ctx, const float* dz, const float* in, long 
                           float* db, float* wpart, float* cpart) {
     hipStream_t st = ctx.stream;
     LAUNCH(ctx, "tail_train", (tail_wgrad_kernel<NO><<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz, in, R, W, wpart)));
-    LAUNCH(ctx, "tail_train", (reduce_partials_kernel<<<1, 256, 0, st>>>(wpart, FFN_COLSUM_BLOCKS, NO * 128, dW)));
+    LAUNCH(ctx, "tail_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(wpart, FFN_COLSUM_BLOCKS, NO * 128, dW)));
     LAUNCH(ctx, "tail_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz, R * (W - 1), NO, cpart)));
-    LAUNCH(ctx, "tail_train", (reduce_partials_kernel<<<1, 256, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, NO, db)));
+    LAUNCH(ctx, "tail_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, NO, db)));
     LAUNCH(ctx, "tail_train", (tail_dgrad_kernel<NO><<<2048, 256, 0, st>>>(dz, R, W, w, din)));
 }
 
@@ -2424,7 +2557,7 @@ void launch_decoder_train_backward(LaunchCtx ctx, int kind, const float* x, cons
     }
     // sub-pixel conv: g = dL/ds on the 2 Fe wide grid = [Me, 128] rows in conv-channel order (64 r + c)
     LAUNCH(ctx, "decoder_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(g, Me, 128, ws + pl.cpart)));
-    LAUNCH(ctx, "decoder_train", (reduce_partials_kernel<<<1, 256, 0, st>>>(ws + pl.cpart, FFN_COLSUM_BLOCKS, 128, grad.sp_b)));
+    LAUNCH(ctx, "decoder_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(ws + pl.cpart, FFN_COLSUM_BLOCKS, 128, grad.sp_b)));
     rc_backward<2>(ctx, g, ws + pl.d, ws + pl.imgT, gs, nullptr, grad.sp_w, ws + pl.wpart);
     LAUNCH(ctx, "rowconv_train", (rc_dgrad_kernel<2><<<(unsigned)((Me + 63) / 64), 256, 0, st>>>(g, ws + pl.imgT, gs, ws + pl.d)));
     launch_dense_train_backward(ctx, x, ws + pl.d, B, T, Fe, p.dense, dx, grad.dense, ws + pl.dense);

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Time one generator optimisation step (cmgan_amd.training.generator_train_step: STFT of both batches, train-mode
+TSCNet forward, ISTFT, loss, loss gradient, backward, gradient all-reduce (identity on one rank), AdamW) at the
+reference's training shape - 2 s clips (cut_len 32000, train.py:25), batch 4 per GPU (train.py:22) - and larger
+batches.  Prints one JSON line for profiles/ with the per-kernel-label split of the last step."""
+import argparse, collections, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cmgan_amd.synth import make_state_dict, synthetic_clips
+from cmgan_amd.training import AdamW, GeneratorTrain, generator_train_step
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batches", default="4,16")
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--cut-len", type=int, default=32000)
+args = ap.parse_args()
+
+gen = GeneratorTrain(make_state_dict(0), device="cuda:0")
+opt = AdamW(gen.engine, gen.param_bucket, gen.grad_bucket, lr=5e-4)
+tgen = torch.Generator(device="cuda:0").manual_seed(1)
+res = {}
+for B in [int(b) for b in args.batches.split(",")]:
+    clean = synthetic_clips(B, args.cut_len, seed=5).cuda()
+    noisy = (clean + 0.3 * synthetic_clips(B, args.cut_len, seed=6).cuda()).contiguous()
+    for _ in range(2):
+        loss, _ = generator_train_step(gen, opt, clean, noisy, generator=tgen)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = generator_train_step(gen, opt, clean, noisy, generator=tgen)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    gen.engine.set_profiling(True)
+    generator_train_step(gen, opt, clean, noisy, generator=tgen)
+    torch.cuda.synchronize()
+    split = collections.OrderedDict()
+    for name, ms in gen.engine.profile():
+        split[name] = split.get(name, 0.0) + ms
+    gen.engine.set_profiling(False)
+    top = sorted(split.items(), key=lambda kv: -kv[1])[:12]
+    res[f"batch{B}"] = {"ms_per_step": round(1e3 * dt, 2), "clips_per_s": round(B / dt, 2),
+                        "frames_per_s": round(B * (args.cut_len // 100 + 1) / dt, 1), "loss": round(float(loss), 4),
+                        "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2),
+                        "kernel_ms": {k: round(v, 2) for k, v in top}, "kernel_ms_total": round(sum(split.values()), 2)}
+print(json.dumps({"workload": f"generator train step, {args.cut_len}-sample clips, TSCNet(64,201) random-init, dropout 0.2, "
+                              "fp32 MFMA training kernels, 1 x MI355X", "results": res}))
