@@ -54,9 +54,9 @@ class TSCNet:
     def train(self, mode: bool = True):
         if mode:
             raise NotImplementedError(
-                "train-mode forward of the whole generator (Dropout 0.2, BatchNorm1d batch statistics, autograd; "
-                "src/train.py:72-122) is not built: cmgan_amd.training holds the pieces that are (loss terms, validation "
-                "step, FeedForward and ConformerConvModule forward/backward, AdamW)")
+                "this module is the inference path (packed split-f16 weights, no autograd); the train-mode generator - "
+                "Dropout masks, BatchNorm1d batch statistics, every module's backward, AdamW (src/train.py:72-193) - is "
+                "cmgan_amd.training.GeneratorTrain / generator_train_step")
         return self
 
     def load_state_dict(self, state_dict: dict, strict: bool = True):
