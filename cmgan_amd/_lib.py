@@ -66,6 +66,13 @@ class DecoderParams(Structure):
                                            "prelu_out_weight")])
 
 
+class DiscParams(Structure):
+    _fields_ = ([(n, c_void_p * 4) for n in ("conv_weight_orig", "conv_u", "conv_v", "norm_weight", "norm_bias",
+                                             "prelu_weight")]
+                + [(n, c_void_p) for n in ("fc1_weight_orig", "fc1_bias", "fc1_u", "fc1_v", "prelu5_weight",
+                                           "fc2_weight_orig", "fc2_bias", "fc2_u", "fc2_v", "slope")])
+
+
 class KernelTime(Structure):
     _fields_ = [("name", c_char_p), ("ms", c_float)]
 
@@ -125,6 +132,15 @@ SIGNATURES = {
                                                c_void_p, c_void_p]),
     "cmgan_loss_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
                                     c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "cmgan_disc_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "cmgan_disc_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(DiscParams), c_void_p, c_int, c_void_p,
+                                   c_void_p, c_size_t, c_void_p]),
+    "cmgan_disc_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(DiscParams), c_void_p, c_void_p,
+                                    POINTER(DiscParams), c_void_p, c_size_t, c_void_p]),
+    "cmgan_mag_pair": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "cmgan_mag_pair_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p,
+                                        c_void_p, c_void_p]),
+    "cmgan_score_mse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "cmgan_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float,
                                  c_float, c_float, c_float, c_int, c_void_p]),
     "cmgan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),

@@ -348,6 +348,86 @@ extern "C" int cmgan_loss_backward(cmgan_handle* h, const float* est_real, const
     return check_launch(h, "loss_backward");
 }
 
+// ---- metric discriminator --------------------------------------------------------------------------------------------
+static bool disc_params_ok(const cmgan_disc_params* p, bool need_uv) {
+    if (!p) return false;
+    for (int i = 0; i < 4; ++i) {
+        if (!p->conv_weight_orig[i] || !p->norm_weight[i] || !p->norm_bias[i] || !p->prelu_weight[i]) return false;
+        if (need_uv && (!p->conv_u[i] || !p->conv_v[i])) return false;
+    }
+    if (!p->fc1_weight_orig || !p->fc1_bias || !p->prelu5_weight || !p->fc2_weight_orig || !p->fc2_bias || !p->slope)
+        return false;
+    return !need_uv || (p->fc1_u && p->fc1_v && p->fc2_u && p->fc2_v);
+}
+static DiscParams disc_params(const cmgan_disc_params* p) {
+    DiscParams d;
+    for (int i = 0; i < 4; ++i) {
+        d.conv_w[i] = p->conv_weight_orig[i]; d.conv_u[i] = p->conv_u[i]; d.conv_v[i] = p->conv_v[i];
+        d.norm_w[i] = p->norm_weight[i]; d.norm_b[i] = p->norm_bias[i]; d.prelu_w[i] = p->prelu_weight[i];
+    }
+    d.fc1_w = p->fc1_weight_orig; d.fc1_b = p->fc1_bias; d.fc1_u = p->fc1_u; d.fc1_v = p->fc1_v;
+    d.prelu5_w = p->prelu5_weight;
+    d.fc2_w = p->fc2_weight_orig; d.fc2_b = p->fc2_bias; d.fc2_u = p->fc2_u; d.fc2_v = p->fc2_v;
+    d.slope = p->slope;
+    return d;
+}
+
+extern "C" size_t cmgan_disc_workspace_bytes(const cmgan_handle* h, int B, int T) {
+    if (!h || B <= 0 || !disc_shape_ok(T, h->cfg.num_features)) return 0;
+    return disc_ws_floats(B, T, h->cfg.num_features) * sizeof(float);
+}
+
+extern "C" int cmgan_mag_pair(cmgan_handle* h, const float* clean_spec, const float* est_real, const float* est_imag,
+                              int B, int T, float* xy, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!clean_spec || !xy || B <= 0 || T <= 0 || ((est_real == nullptr) != (est_imag == nullptr)))
+        return fail(h, CMGAN_E_BADARG, "cmgan_mag_pair: bad argument");
+    launch_mag_pair(begin(h, stream), clean_spec, est_real, est_imag, B, T, h->cfg.num_features, xy);
+    return check_launch(h, "mag_pair");
+}
+
+extern "C" int cmgan_mag_pair_backward(cmgan_handle* h, const float* est_real, const float* est_imag, const float* dxy,
+                                       int B, int T, float scale, float* d_real, float* d_imag, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!est_real || !est_imag || !dxy || !d_real || !d_imag || B <= 0 || T <= 0)
+        return fail(h, CMGAN_E_BADARG, "cmgan_mag_pair_backward: bad argument");
+    launch_mag_pair_backward(begin(h, stream), est_real, est_imag, dxy, B, T, h->cfg.num_features, scale, d_real, d_imag);
+    return check_launch(h, "mag_pair_backward");
+}
+
+extern "C" int cmgan_score_mse(cmgan_handle* h, const float* score, const float* target, int B, float scale, float* loss,
+                               float* dscore, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!score || !loss || B <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_score_mse: bad argument");
+    launch_score_mse(begin(h, stream), score, target, B, scale, loss, dscore);
+    return check_launch(h, "score_mse");
+}
+
+extern "C" int cmgan_disc_forward(cmgan_handle* h, const float* xy, int B, int T, const cmgan_disc_params* params,
+                                  const float* mask, int update_uv, float* score, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    const int F = h->cfg.num_features;
+    if (!xy || !score || B <= 0 || !disc_shape_ok(T, F) || !disc_params_ok(params, true))
+        return fail(h, CMGAN_E_BADARG, "cmgan_disc_forward: bad argument (T and F must be >= 16)");
+    if (int rc = check_ws(h, ws, ws_bytes, disc_ws_floats(B, T, F) * sizeof(float))) return rc;
+    launch_disc_forward(begin(h, stream), xy, B, T, F, disc_params(params), mask, update_uv, score, (float*)ws);
+    return check_launch(h, "disc_forward");
+}
+
+extern "C" int cmgan_disc_backward(cmgan_handle* h, const float* xy, const float* dscore, int B, int T,
+                                   const cmgan_disc_params* params, const float* mask, float* dxy,
+                                   const cmgan_disc_params* grads, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    const int F = h->cfg.num_features;
+    if (!xy || !dscore || B <= 0 || !disc_shape_ok(T, F) || !disc_params_ok(params, false) || !disc_params_ok(grads, false))
+        return fail(h, CMGAN_E_BADARG, "cmgan_disc_backward: bad argument");
+    if (int rc = check_ws(h, ws, ws_bytes, disc_ws_floats(B, T, F) * sizeof(float))) return rc;
+    launch_disc_backward(begin(h, stream), xy, dscore, B, T, F, disc_params(params), mask, dxy, disc_params(grads),
+                         (float*)ws);
+    return check_launch(h, "disc_backward");
+}
+
 extern "C" int cmgan_adamw_step(cmgan_handle* h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                 long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int step, void* stream) {

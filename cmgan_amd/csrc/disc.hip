@@ -1,0 +1,606 @@
+// disc.hip - the metric discriminator of the reference trainer (src/models/discriminator.py:29-64) with its backward,
+// for the adversarial term of the generator loss and the discriminator step (src/train.py:124-171, 185-205).
+//
+//   D(x, y):  cat -> 4 x [ spectral-norm Conv2d(4x4, stride 2, pad 1, no bias) -> InstanceNorm2d(affine) -> PReLU ]
+//             (2 -> 16 -> 32 -> 64 -> 128 channels) -> global max pool -> spectral-norm Linear(128, 64) -> Dropout(0.3)
+//             -> PReLU(64) -> spectral-norm Linear(64, 1) -> LearnableSigmoid(1)
+//
+// The network is 0.2 % of the generator's arithmetic (105 M MACs per clip), so the kernels are plain and correctness
+// first: channels-last activations [B, T', F', C] (the reference's [B, C, F', T'] with the two spatial axes swapped, so
+// tap (kt, kf) here is weight[co][ci][kh = kf][kw = kt]), direct convolutions with one thread per output element and
+// weights re-laid so that the fastest thread index is contiguous, split-K weight gradients into fixed-shape partial
+// slabs, fp32 everywhere, fixed reduction orders (deterministic).
+//
+// Spectral norm (torch.nn.utils.spectral_norm, the legacy hook the reference uses): every TRAIN-mode forward runs one
+// power iteration v <- normalize(W^T u), u <- normalize(W v) outside the graph and uses W / sigma, sigma = u^T W v.
+// The forward keeps the (u, v, sigma) it used in the workspace; the backward is
+//   dL/dW = (G - (sum G . W_eff) u v^T) / sigma,   G = dL/dW_eff.
+#include "train.h"
+
+#define DC_NCH 8             // position chunks of the InstanceNorm partial sums
+#define DC_SPLIT 32          // position chunks of the conv weight gradient
+
+// ---- spectral norm ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dc_block_sum(float v, float* red) {
+    const int t = threadIdx.x;
+    red[t] = v;
+    __syncthreads();
+    for (int d = blockDim.x >> 1; d >= 1; d >>= 1) {
+        if (t < d) red[t] += red[t + d];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// one block of 256 threads; W [out, K] row-major (out <= 128, K <= 1024)
+__global__ __launch_bounds__(256) void sn_power_kernel(const float* __restrict__ W, int out, int K, float* __restrict__ u_state,
+                                                       float* __restrict__ v_state, int update, float* __restrict__ u_used,
+                                                       float* __restrict__ v_used, float* __restrict__ sigma) {
+    __shared__ float su[128], sv[1024], swv[128], red[256];
+    const int t = threadIdx.x;
+    for (int o = t; o < out; o += 256) su[o] = u_state[o];
+    for (int k = t; k < K; k += 256) sv[k] = v_state[k];
+    __syncthreads();
+    if (update) {
+        float part = 0.f;
+        float mine[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = t + 256 * q;
+            float s = 0.f;
+            if (k < K)
+                for (int o = 0; o < out; ++o) s = fmaf(W[(long)o * K + k], su[o], s);
+            mine[q] = s;
+            part = fmaf(s, s, part);
+        }
+        const float nrm = sqrtf(dc_block_sum(part, red));
+        const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = t + 256 * q;
+            if (k < K) sv[k] = mine[q] * inv;
+        }
+        __syncthreads();
+    }
+    for (int o = 0; o < out; ++o) {
+        float s = 0.f;
+        for (int k = t; k < K; k += 256) s = fmaf(W[(long)o * K + k], sv[k], s);
+        const float r = dc_block_sum(s, red);
+        if (t == 0) swv[o] = r;
+    }
+    __syncthreads();
+    if (update) {
+        float part = 0.f;
+        for (int o = t; o < out; o += 256) part = fmaf(swv[o], swv[o], part);
+        const float nrm = sqrtf(dc_block_sum(part, red));
+        const float inv = 1.0f / fmaxf(nrm, 1e-12f);
+        for (int o = t; o < out; o += 256) su[o] = swv[o] * inv;
+        __syncthreads();
+    }
+    float part = 0.f;
+    for (int o = t; o < out; o += 256) part = fmaf(su[o], swv[o], part);
+    const float sg = dc_block_sum(part, red);
+    if (t == 0) sigma[0] = sg;
+    for (int o = t; o < out; o += 256) { u_used[o] = su[o]; if (update) u_state[o] = su[o]; }
+    for (int k = t; k < K; k += 256) { v_used[k] = sv[k]; if (update) v_state[k] = sv[k]; }
+}
+
+// effective conv weights W / sigma in the two thread-friendly layouts: wf [tap][ci][co], wb [tap][co][ci]
+__global__ void dc_pack_kernel(const float* __restrict__ W, int Co, int Ci, const float* __restrict__ sigma,
+                               float* __restrict__ wf, float* __restrict__ wb) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Co * Ci * 16) return;
+    const int kw = e & 3, kh = (e >> 2) & 3, ci = (e >> 4) % Ci, co = (e >> 4) / Ci;
+    const float v = W[e] / sigma[0];
+    const int tap = kw * 4 + kh;                             // (kt, kf) = (kw, kh)
+    wf[((long)tap * Ci + ci) * Co + co] = v;
+    wb[((long)tap * Co + co) * Ci + ci] = v;
+}
+
+// ---- 4x4 stride-2 pad-1 convolution ----------------------------------------------------------------------------------
+struct DcGeom { int B, Ti, Fi, Ci, To, Fo, Co; };
+
+__global__ __launch_bounds__(256) void dc_conv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wf, DcGeom gm,
+                                                          float* __restrict__ out) {
+    const long total = (long)gm.B * gm.To * gm.Fo * gm.Co;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int co = (int)(idx % gm.Co);
+        long pos = idx / gm.Co;
+        const int fo = (int)(pos % gm.Fo); pos /= gm.Fo;
+        const int to = (int)(pos % gm.To);
+        const int b = (int)(pos / gm.To);
+        float acc = 0.f;
+        for (int kt = 0; kt < 4; ++kt) {
+            const int ti = 2 * to - 1 + kt;
+            if (ti < 0 || ti >= gm.Ti) continue;
+            for (int kf = 0; kf < 4; ++kf) {
+                const int fi = 2 * fo - 1 + kf;
+                if (fi < 0 || fi >= gm.Fi) continue;
+                const float* ip = in + (((long)b * gm.Ti + ti) * gm.Fi + fi) * gm.Ci;
+                const float* wp = wf + ((long)(kt * 4 + kf) * gm.Ci) * gm.Co + co;
+                for (int ci = 0; ci < gm.Ci; ++ci) acc = fmaf(ip[ci], wp[(long)ci * gm.Co], acc);
+            }
+        }
+        out[idx] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void dc_conv_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ wb,
+                                                            DcGeom gm, float* __restrict__ din) {
+    const long total = (long)gm.B * gm.Ti * gm.Fi * gm.Ci;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ci = (int)(idx % gm.Ci);
+        long pos = idx / gm.Ci;
+        const int fi = (int)(pos % gm.Fi); pos /= gm.Fi;
+        const int ti = (int)(pos % gm.Ti);
+        const int b = (int)(pos / gm.Ti);
+        float acc = 0.f;
+        for (int kt = 0; kt < 4; ++kt) {
+            const int tn = ti + 1 - kt;
+            if (tn < 0 || (tn & 1)) continue;
+            const int to = tn >> 1;
+            if (to >= gm.To) continue;
+            for (int kf = 0; kf < 4; ++kf) {
+                const int fn = fi + 1 - kf;
+                if (fn < 0 || (fn & 1)) continue;
+                const int fo = fn >> 1;
+                if (fo >= gm.Fo) continue;
+                const float* op = dout + (((long)b * gm.To + to) * gm.Fo + fo) * gm.Co;
+                const float* wp = wb + ((long)(kt * 4 + kf) * gm.Co) * gm.Ci + ci;
+                for (int co = 0; co < gm.Co; ++co) acc = fmaf(op[co], wp[(long)co * gm.Ci], acc);
+            }
+        }
+        din[idx] = acc;
+    }
+}
+
+// partial[s][tap][ci][co] = sum over the s-th chunk of output positions of dout[pos][co] * in[pos shifted by tap][ci]
+__global__ __launch_bounds__(256) void dc_conv_wgrad_kernel(const float* __restrict__ dout, const float* __restrict__ in,
+                                                            DcGeom gm, float* __restrict__ partial) {
+    const int tap = blockIdx.x, kt = tap >> 2, kf = tap & 3, s = blockIdx.z;
+    const int pair = blockIdx.y * 256 + threadIdx.x;
+    if (pair >= gm.Ci * gm.Co) return;
+    const int ci = pair / gm.Co, co = pair - ci * gm.Co;
+    const long P = (long)gm.B * gm.To * gm.Fo;
+    const long per = (P + DC_SPLIT - 1) / DC_SPLIT, p0 = (long)s * per, p1 = p0 + per < P ? p0 + per : P;
+    float acc = 0.f;
+    for (long pos = p0; pos < p1; ++pos) {
+        const int fo = (int)(pos % gm.Fo);
+        const long r = pos / gm.Fo;
+        const int to = (int)(r % gm.To), b = (int)(r / gm.To);
+        const int ti = 2 * to - 1 + kt, fi = 2 * fo - 1 + kf;
+        if (ti < 0 || ti >= gm.Ti || fi < 0 || fi >= gm.Fi) continue;
+        acc = fmaf(dout[pos * gm.Co + co], in[(((long)b * gm.Ti + ti) * gm.Fi + fi) * gm.Ci + ci], acc);
+    }
+    partial[(((long)s * 16 + tap) * gm.Ci + ci) * gm.Co + co] = acc;
+}
+// G[e] = sum_s partial[s][e]
+__global__ void dc_reduce_kernel(const float* __restrict__ partial, int nsplit, long n, float* __restrict__ G) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += partial[(long)k * n + e];
+    G[e] = s;
+}
+// spectral-norm backward for a conv layer: G and W_eff in the [tap][ci][co] layout, dW in the parameter's layout
+__global__ __launch_bounds__(1024) void sn_conv_finish_kernel(const float* __restrict__ G, const float* __restrict__ wf, int Co,
+                                                              int Ci, const float* __restrict__ u, const float* __restrict__ v,
+                                                              const float* __restrict__ sigma, float* __restrict__ dW) {
+    __shared__ float red[1024];
+    const int n = Co * Ci * 16;
+    float part = 0.f;
+    for (int e = threadIdx.x; e < n; e += 1024) part = fmaf(G[e], wf[e], part);
+    const float dot = dc_block_sum(part, red);
+    const float inv = 1.0f / sigma[0];
+    for (int e = threadIdx.x; e < n; e += 1024) {                 // e in the PARAMETER layout [co][ci][kh][kw]
+        const int kw = e & 3, kh = (e >> 2) & 3, ci = (e >> 4) % Ci, co = (e >> 4) / Ci;
+        const int tap = kw * 4 + kh;
+        const float g = G[((long)tap * Ci + ci) * Co + co];
+        dW[e] = (g - dot * u[co] * v[e - co * Ci * 16]) * inv;
+    }
+}
+
+// ---- InstanceNorm2d(C, affine) + PReLU(C), C in {16, 32, 64, 128}, planes [B, P, C] ------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void gin_sums_kernel(const float* __restrict__ z, float* __restrict__ ga, int P, int C,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ alpha, float* __restrict__ partial) {
+    __shared__ float red[256][3];
+    const int c = threadIdx.x % C, sub = threadIdx.x / C, nsub = 256 / C;
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int per = (P + DC_NCH - 1) / DC_NCH, p0 = chunk * per, p1 = p0 + per < P ? p0 + per : P;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    float mu = 0.f, rs = 0.f, gm = 0.f, bt = 0.f, al = 0.f;
+    if (MODE == 1) { mu = mean[b * C + c]; rs = rstd[b * C + c]; gm = gamma[c]; bt = beta[c]; al = alpha[c]; }
+    for (int p = p0 + sub; p < p1; p += nsub) {
+        const long i = ((long)b * P + p) * C + c;
+        const float zv = z[i];
+        if (MODE == 0) {
+            s0 += zv;
+            s1 = fmaf(zv, zv, s1);
+        } else {
+            const float zh = (zv - mu) * rs, n = zh * gm + bt, gv = ga[i];
+            const float dn = n < 0.f ? gv * al : gv;
+            ga[i] = dn;
+            s0 += dn;
+            s1 = fmaf(dn, zh, s1);
+            s2 += n < 0.f ? gv * n : 0.f;
+        }
+    }
+    red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1; red[threadIdx.x][2] = s2;
+    __syncthreads();
+    if (sub == 0) {
+        for (int k = 1; k < nsub; ++k) { s0 += red[k * C + c][0]; s1 += red[k * C + c][1]; s2 += red[k * C + c][2]; }
+        const long o = (((long)b * DC_NCH + chunk) * C + c) * 3;
+        partial[o] = s0; partial[o + 1] = s1; partial[o + 2] = s2;
+    }
+}
+__global__ void gin_stats_finalize_kernel(const float* __restrict__ partial, int B, int C, double count, float* __restrict__ mean,
+                                          float* __restrict__ rstd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < DC_NCH; ++k) {
+        const long o = (((long)b * DC_NCH + k) * C + c) * 3;
+        s1 += (double)partial[o];
+        s2 += (double)partial[o + 1];
+    }
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
+    var = var > 0.0 ? var : 0.0;
+    mean[i] = (float)mu;
+    rstd[i] = (float)(1.0 / sqrt(var + 1e-5));
+}
+__global__ __launch_bounds__(256) void gin_norm_prelu_kernel(const float* __restrict__ z, long total, int P, int C,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ alpha, float* __restrict__ a) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long bc = (i / C) / P * C + c;
+        const float n = (z[i] - mean[bc]) * rstd[bc] * gamma[c] + beta[c];
+        a[i] = n >= 0.f ? n : alpha[c] * n;
+    }
+}
+__global__ void gin_bwd_finalize_kernel(const float* __restrict__ partial, int B, int C, double count, float* __restrict__ m1,
+                                        float* __restrict__ m2, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                        float* __restrict__ dalpha) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    double g = 0.0, bsum = 0.0, a = 0.0;
+    for (int b = 0; b < B; ++b) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < DC_NCH; ++k) {
+            const long o = (((long)b * DC_NCH + k) * C + c) * 3;
+            s0 += (double)partial[o]; s1 += (double)partial[o + 1]; s2 += (double)partial[o + 2];
+        }
+        m1[b * C + c] = (float)(s0 / count);
+        m2[b * C + c] = (float)(s1 / count);
+        bsum += s0; g += s1; a += s2;
+    }
+    dgamma[c] = (float)g; dbeta[c] = (float)bsum; dalpha[c] = (float)a;
+}
+__global__ __launch_bounds__(256) void gin_in_bwd_kernel(float* __restrict__ dn, const float* __restrict__ z, long total, int P,
+                                                         int C, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ m1,
+                                                         const float* __restrict__ m2) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const long bc = (i / C) / P * C + c;
+        const float zh = (z[i] - mean[bc]) * rstd[bc];
+        dn[i] = gamma[c] * rstd[bc] * (dn[i] - m1[bc] - zh * m2[bc]);
+    }
+}
+
+// ---- global max pool over the plane (AdaptiveMaxPool2d(1)), 128 channels ---------------------------------------------
+__global__ __launch_bounds__(128) void dc_maxpool_kernel(const float* __restrict__ a, int P, float* __restrict__ pooled,
+                                                         int* __restrict__ idx) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    float best = a[((long)b * P) * 128 + c];
+    int bi = 0;
+    for (int p = 1; p < P; ++p) {
+        const float v = a[((long)b * P + p) * 128 + c];
+        if (v > best) { best = v; bi = p; }
+    }
+    pooled[b * 128 + c] = best;
+    idx[b * 128 + c] = bi;
+}
+__global__ __launch_bounds__(128) void dc_maxpool_bwd_kernel(const float* __restrict__ dpool, const int* __restrict__ idx, int P,
+                                                             float* __restrict__ da) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    da[((long)b * P + idx[b * 128 + c]) * 128 + c] = dpool[b * 128 + c];
+}
+
+// ---- head: SN-Linear(128, 64) -> Dropout mask -> PReLU(64) -> SN-Linear(64, 1) -> sigmoid(slope .) --------------------
+struct DcHead {
+    const float *w1, *b1, *sig1, *alpha, *w2, *b2, *sig2, *slope;
+};
+__global__ __launch_bounds__(64) void dc_head_fwd_kernel(const float* __restrict__ pooled, DcHead hd, const float* __restrict__ mask,
+                                                         float* __restrict__ h1, float* __restrict__ x2, float* __restrict__ score) {
+    __shared__ float red[64];
+    const int b = blockIdx.x, j = threadIdx.x;
+    float s = 0.f;
+    for (int k = 0; k < 128; ++k) s = fmaf(hd.w1[j * 128 + k], pooled[b * 128 + k], s);
+    const float h = s / hd.sig1[0] + hd.b1[j];
+    h1[b * 64 + j] = h;
+    const float d5 = mask ? h * mask[b * 64 + j] : h;
+    const float a5 = d5 >= 0.f ? d5 : hd.alpha[j] * d5;
+    red[j] = hd.w2[j] * a5;
+    __syncthreads();
+    for (int d = 32; d >= 1; d >>= 1) { if (j < d) red[j] += red[j + d]; __syncthreads(); }
+    if (j == 0) {
+        const float x = red[0] / hd.sig2[0] + hd.b2[0];
+        x2[b] = x;
+        score[b] = 1.0f / (1.0f + __expf(-hd.slope[0] * x));
+    }
+}
+// per sample: dh1 [B,64], ds2 [B], dslope_b [B], da5n [B,64] (= da5 d5 [d5 < 0]) and dL/dpooled [B,128]
+__global__ __launch_bounds__(128) void dc_head_bwd_kernel(const float* __restrict__ pooled, const float* __restrict__ h1,
+                                                          const float* __restrict__ x2, const float* __restrict__ dscore, DcHead hd,
+                                                          const float* __restrict__ mask, float* __restrict__ dh1,
+                                                          float* __restrict__ ds2, float* __restrict__ dslope_b,
+                                                          float* __restrict__ dalpha_b, float* __restrict__ dpool) {
+    __shared__ float sdh[64];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float sl = hd.slope[0], x = x2[b];
+    const float y = 1.0f / (1.0f + __expf(-sl * x));
+    const float dy = dscore[b] * y * (1.0f - y);
+    const float s2 = dy * sl;
+    if (t == 0) { ds2[b] = s2; dslope_b[b] = dy * x; }
+    if (t < 64) {
+        const float mk = mask ? mask[b * 64 + t] : 1.0f;
+        const float d5 = h1[b * 64 + t] * mk;
+        const float da5 = s2 * hd.w2[t] / hd.sig2[0];
+        const float dd5 = d5 >= 0.f ? da5 : da5 * hd.alpha[t];
+        dalpha_b[b * 64 + t] = d5 < 0.f ? da5 * d5 : 0.f;
+        const float v = dd5 * mk;
+        dh1[b * 64 + t] = v;
+        sdh[t] = v;
+    }
+    __syncthreads();
+    float s = 0.f;
+    for (int j = 0; j < 64; ++j) s = fmaf(sdh[j], hd.w1[j * 128 + t], s);
+    dpool[b * 128 + t] = s / hd.sig1[0];
+}
+// sums over the batch (in sample order) + the spectral-norm backward of the two Linear layers; one block of 1024
+struct DcHeadGrads { float *w1, *b1, *alpha, *w2, *b2, *slope; };
+__global__ __launch_bounds__(1024) void dc_head_finish_kernel(const float* __restrict__ pooled, const float* __restrict__ h1,
+                                                              const float* __restrict__ dh1, const float* __restrict__ ds2,
+                                                              const float* __restrict__ dslope_b, const float* __restrict__ dalpha_b,
+                                                              const float* __restrict__ mask, int B, DcHead hd,
+                                                              const float* __restrict__ u1, const float* __restrict__ v1,
+                                                              const float* __restrict__ u2, const float* __restrict__ v2,
+                                                              DcHeadGrads gr) {
+    __shared__ float red[1024];
+    __shared__ float G2[64];
+    const int t = threadIdx.x;
+    // fc1: G1 [64,128] = sum_b dh1_b pooled_b^T
+    float g1[8];
+    float part = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = t + 1024 * q, j = e >> 7, k = e & 127;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s = fmaf(dh1[b * 64 + j], pooled[b * 128 + k], s);
+        g1[q] = s;
+        part = fmaf(s, hd.w1[e] / hd.sig1[0], part);
+    }
+    const float dot1 = dc_block_sum(part, red);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = t + 1024 * q, j = e >> 7, k = e & 127;
+        gr.w1[e] = (g1[q] - dot1 * u1[j] * v1[k]) / hd.sig1[0];
+    }
+    // fc2: G2 [1,64] = sum_b ds2_b a5_b^T ; biases, PReLU slope, LearnableSigmoid slope
+    float p2 = 0.f;
+    if (t < 64) {
+        float s = 0.f, sb = 0.f, sa = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float mk = mask ? mask[b * 64 + t] : 1.0f;
+            const float d5 = h1[b * 64 + t] * mk;
+            const float a5 = d5 >= 0.f ? d5 : hd.alpha[t] * d5;
+            s = fmaf(ds2[b], a5, s);
+            sb += dh1[b * 64 + t];
+            sa += dalpha_b[b * 64 + t];
+        }
+        G2[t] = s;
+        gr.b1[t] = sb;
+        gr.alpha[t] = sa;
+        p2 = s * hd.w2[t] / hd.sig2[0];
+    }
+    const float dot2 = dc_block_sum(p2, red);
+    if (t < 64) gr.w2[t] = (G2[t] - dot2 * u2[0] * v2[t]) / hd.sig2[0];
+    if (t == 0) {
+        float sb = 0.f, ss = 0.f;
+        for (int b = 0; b < B; ++b) { sb += ds2[b]; ss += dslope_b[b]; }
+        gr.b2[0] = sb;
+        gr.slope[0] = ss;
+    }
+}
+
+// ---- input / loss glue -------------------------------------------------------------------------------------------------
+// xy [B,T,F,2] = (|clean|, |est|); est = clean when est_real is NULL   (train.py:102-103, 126-128, 163-167)
+__global__ __launch_bounds__(256) void mag_pair_kernel(const float* __restrict__ clean_spec, const float* __restrict__ est_real,
+                                                       const float* __restrict__ est_imag, int B, long P, float* __restrict__ xy) {
+    const long total = (long)B * P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / P, q = i - b * P;
+        const float cr = clean_spec[(2 * b) * P + q], ci = clean_spec[(2 * b + 1) * P + q];
+        const float mc = sqrtf(cr * cr + ci * ci);
+        float me = mc;
+        if (est_real) { const float er = est_real[i], ei = est_imag[i]; me = sqrtf(er * er + ei * ei); }
+        xy[2 * i] = mc;
+        xy[2 * i + 1] = me;
+    }
+}
+// d_real / d_imag += scale * dxy[..., 1] * (er, ei) / |e|
+__global__ __launch_bounds__(256) void mag_pair_bwd_kernel(const float* __restrict__ est_real, const float* __restrict__ est_imag,
+                                                           const float* __restrict__ dxy, long total, float scale,
+                                                           float* __restrict__ d_real, float* __restrict__ d_imag) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const float er = est_real[i], ei = est_imag[i], me = sqrtf(er * er + ei * ei);
+        if (me > 0.f) {
+            const float q = scale * dxy[2 * i + 1] / me;
+            d_real[i] = fmaf(q, er, d_real[i]);
+            d_imag[i] = fmaf(q, ei, d_imag[i]);
+        }
+    }
+}
+// loss = mean (score - target)^2 (target = 1 when NULL), dscore = scale * 2 (score - target) / B      train.py:129-131, 168-170
+__global__ void score_mse_kernel(const float* __restrict__ score, const float* __restrict__ target, int B, float scale,
+                                 float* __restrict__ loss, float* __restrict__ dscore) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float d = score[b] - (target ? target[b] : 1.0f);
+        s += (double)d * d;
+        if (dscore) dscore[b] = scale * 2.0f * d / (float)B;
+    }
+    loss[0] = (float)(s / B);
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------
+struct DcLayer { int Ti, Fi, Ci, To, Fo, Co; };
+struct DcPlan {
+    DcLayer L[4];
+    size_t wf[4], wb[4], z[4], a[4], g[4], mean[4], rstd[4];
+    size_t uu[6], vv[6], sigma;                  // the (u, v, sigma) this forward used, per spectral-norm layer
+    size_t pooled, idx, h1, x2, dh1, ds2, dslope, dalpha, dpool, part, m12, wpart, G, total;
+};
+static DcPlan dc_plan(int B, int T, int F) {
+    DcPlan p;
+    const int ch[5] = {2, 16, 32, 64, 128};
+    int t = T, f = F;
+    size_t cur = 0;
+    auto take = [&](size_t n) { const size_t o = cur; cur += (n + 63) & ~(size_t)63; return o; };
+    size_t maxw = 0;
+    for (int i = 0; i < 4; ++i) {
+        p.L[i] = {t, f, ch[i], t / 2, f / 2, ch[i + 1]};
+        t /= 2; f /= 2;
+        const size_t nw = (size_t)16 * ch[i] * ch[i + 1], na = (size_t)B * p.L[i].To * p.L[i].Fo * ch[i + 1];
+        p.wf[i] = take(nw); p.wb[i] = take(nw);
+        p.z[i] = take(na); p.a[i] = take(na); p.g[i] = take(na);
+        p.mean[i] = take((size_t)B * ch[i + 1]); p.rstd[i] = take((size_t)B * ch[i + 1]);
+        p.uu[i] = take(ch[i + 1]); p.vv[i] = take((size_t)16 * ch[i]);
+        if (nw > maxw) maxw = nw;
+    }
+    p.uu[4] = take(64); p.vv[4] = take(128); p.uu[5] = take(1); p.vv[5] = take(64);
+    p.sigma = take(8);
+    p.pooled = take((size_t)B * 128); p.idx = take((size_t)B * 128);
+    p.h1 = take((size_t)B * 64); p.x2 = take(B);
+    p.dh1 = take((size_t)B * 64); p.ds2 = take(B); p.dslope = take(B); p.dalpha = take((size_t)B * 64);
+    p.dpool = take((size_t)B * 128);
+    p.part = take((size_t)B * DC_NCH * 128 * 3);
+    p.m12 = take((size_t)2 * B * 128);
+    p.wpart = take((size_t)DC_SPLIT * maxw);
+    p.G = take(maxw);
+    p.total = cur;
+    return p;
+}
+size_t disc_ws_floats(int B, int T, int F) { return dc_plan(B, T, F).total; }
+bool disc_shape_ok(int T, int F) { return T >= 16 && F >= 16; }
+
+static DcHead dc_head(const DiscParams& p, float* ws, const DcPlan& pl) {
+    return DcHead{p.fc1_w, p.fc1_b, ws + pl.sigma + 4, p.prelu5_w, p.fc2_w, p.fc2_b, ws + pl.sigma + 5, p.slope};
+}
+
+void launch_disc_forward(LaunchCtx ctx, const float* xy, int B, int T, int F, const DiscParams& p, const float* mask,
+                         int update_uv, float* score, float* ws) {
+    hipStream_t st = ctx.stream;
+    const DcPlan pl = dc_plan(B, T, F);
+    const float* in = xy;
+    for (int i = 0; i < 4; ++i) {
+        const DcLayer& L = pl.L[i];
+        const DcGeom gm{B, L.Ti, L.Fi, L.Ci, L.To, L.Fo, L.Co};
+        LAUNCH(ctx, "disc_spectral_norm", (sn_power_kernel<<<1, 256, 0, st>>>(p.conv_w[i], L.Co, L.Ci * 16, p.conv_u[i], p.conv_v[i],
+                                                                             update_uv, ws + pl.uu[i], ws + pl.vv[i],
+                                                                             ws + pl.sigma + i)));
+        const int nw = 16 * L.Ci * L.Co;
+        LAUNCH(ctx, "disc_spectral_norm", (dc_pack_kernel<<<(nw + 255) / 256, 256, 0, st>>>(p.conv_w[i], L.Co, L.Ci, ws + pl.sigma + i,
+                                                                                           ws + pl.wf[i], ws + pl.wb[i])));
+        const long total = (long)B * L.To * L.Fo * L.Co;
+        const int P = L.To * L.Fo;
+        const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        LAUNCH(ctx, "disc_conv_fwd", (dc_conv_fwd_kernel<<<grid, 256, 0, st>>>(in, ws + pl.wf[i], gm, ws + pl.z[i])));
+        LAUNCH(ctx, "disc_norm", (gin_sums_kernel<0><<<dim3(B, DC_NCH), 256, 0, st>>>(ws + pl.z[i], nullptr, P, L.Co, nullptr, nullptr,
+                                                                                     nullptr, nullptr, nullptr, ws + pl.part)));
+        LAUNCH(ctx, "disc_norm", (gin_stats_finalize_kernel<<<(B * L.Co + 255) / 256, 256, 0, st>>>(ws + pl.part, B, L.Co, (double)P,
+                                                                                                   ws + pl.mean[i], ws + pl.rstd[i])));
+        LAUNCH(ctx, "disc_norm", (gin_norm_prelu_kernel<<<grid, 256, 0, st>>>(ws + pl.z[i], total, P, L.Co, ws + pl.mean[i],
+                                                                              ws + pl.rstd[i], p.norm_w[i], p.norm_b[i],
+                                                                              p.prelu_w[i], ws + pl.a[i])));
+        in = ws + pl.a[i];
+    }
+    const int P4 = pl.L[3].To * pl.L[3].Fo;
+    LAUNCH(ctx, "disc_head", (dc_maxpool_kernel<<<B, 128, 0, st>>>(ws + pl.a[3], P4, ws + pl.pooled, (int*)(ws + pl.idx))));
+    LAUNCH(ctx, "disc_spectral_norm", (sn_power_kernel<<<1, 256, 0, st>>>(p.fc1_w, 64, 128, p.fc1_u, p.fc1_v, update_uv, ws + pl.uu[4],
+                                                                         ws + pl.vv[4], ws + pl.sigma + 4)));
+    LAUNCH(ctx, "disc_spectral_norm", (sn_power_kernel<<<1, 256, 0, st>>>(p.fc2_w, 1, 64, p.fc2_u, p.fc2_v, update_uv, ws + pl.uu[5],
+                                                                         ws + pl.vv[5], ws + pl.sigma + 5)));
+    LAUNCH(ctx, "disc_head", (dc_head_fwd_kernel<<<B, 64, 0, st>>>(ws + pl.pooled, dc_head(p, ws, pl), mask, ws + pl.h1, ws + pl.x2,
+                                                                  score)));
+}
+
+void launch_disc_backward(LaunchCtx ctx, const float* xy, const float* dscore, int B, int T, int F, const DiscParams& p,
+                          const float* mask, float* dxy, const DiscParams& grad, float* ws) {
+    hipStream_t st = ctx.stream;
+    const DcPlan pl = dc_plan(B, T, F);
+    const DcHead hd = dc_head(p, ws, pl);
+    LAUNCH(ctx, "disc_head", (dc_head_bwd_kernel<<<B, 128, 0, st>>>(ws + pl.pooled, ws + pl.h1, ws + pl.x2, dscore, hd, mask,
+                                                                   ws + pl.dh1, ws + pl.ds2, ws + pl.dslope, ws + pl.dalpha,
+                                                                   ws + pl.dpool)));
+    const DcHeadGrads hg{grad.fc1_w, grad.fc1_b, grad.prelu5_w, grad.fc2_w, grad.fc2_b, grad.slope};
+    LAUNCH(ctx, "disc_head", (dc_head_finish_kernel<<<1, 1024, 0, st>>>(ws + pl.pooled, ws + pl.h1, ws + pl.dh1, ws + pl.ds2,
+                                                                       ws + pl.dslope, ws + pl.dalpha, mask, B, hd, ws + pl.uu[4],
+                                                                       ws + pl.vv[4], ws + pl.uu[5], ws + pl.vv[5], hg)));
+    const int P4 = pl.L[3].To * pl.L[3].Fo;
+    hipMemsetAsync(ws + pl.g[3], 0, (size_t)B * P4 * 128 * sizeof(float), st);
+    LAUNCH(ctx, "disc_head", (dc_maxpool_bwd_kernel<<<B, 128, 0, st>>>(ws + pl.dpool, (const int*)(ws + pl.idx), P4, ws + pl.g[3])));
+    for (int i = 3; i >= 0; --i) {
+        const DcLayer& L = pl.L[i];
+        const DcGeom gm{B, L.Ti, L.Fi, L.Ci, L.To, L.Fo, L.Co};
+        const int P = L.To * L.Fo;
+        const long total = (long)B * P * L.Co;
+        const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        float* g = ws + pl.g[i];                                  // dL/da_i -> dn -> dz, in place
+        float* m1 = ws + pl.m12;
+        float* m2 = ws + pl.m12 + (size_t)B * 128;
+        LAUNCH(ctx, "disc_norm", (gin_sums_kernel<1><<<dim3(B, DC_NCH), 256, 0, st>>>(ws + pl.z[i], g, P, L.Co, ws + pl.mean[i],
+                                                                                     ws + pl.rstd[i], p.norm_w[i], p.norm_b[i],
+                                                                                     p.prelu_w[i], ws + pl.part)));
+        LAUNCH(ctx, "disc_norm", (gin_bwd_finalize_kernel<<<1, 128, 0, st>>>(ws + pl.part, B, L.Co, (double)P, m1, m2, grad.norm_w[i],
+                                                                            grad.norm_b[i], grad.prelu_w[i])));
+        LAUNCH(ctx, "disc_norm", (gin_in_bwd_kernel<<<grid, 256, 0, st>>>(g, ws + pl.z[i], total, P, L.Co, ws + pl.mean[i],
+                                                                          ws + pl.rstd[i], p.norm_w[i], m1, m2)));
+        const float* in = i == 0 ? xy : ws + pl.a[i - 1];
+        const int nw = 16 * L.Ci * L.Co;
+        LAUNCH(ctx, "disc_conv_wgrad", (dc_conv_wgrad_kernel<<<dim3(16, (L.Ci * L.Co + 255) / 256, DC_SPLIT), 256, 0, st>>>(
+                                           g, in, gm, ws + pl.wpart)));
+        LAUNCH(ctx, "disc_conv_wgrad", (dc_reduce_kernel<<<(nw + 255) / 256, 256, 0, st>>>(ws + pl.wpart, DC_SPLIT, nw, ws + pl.G)));
+        LAUNCH(ctx, "disc_spectral_norm", (sn_conv_finish_kernel<<<1, 1024, 0, st>>>(ws + pl.G, ws + pl.wf[i], L.Co, L.Ci, ws + pl.uu[i],
+                                                                                    ws + pl.vv[i], ws + pl.sigma + i, grad.conv_w[i])));
+        float* din = i == 0 ? dxy : ws + pl.g[i - 1];
+        if (din) {
+            const long tin = (long)B * L.Ti * L.Fi * L.Ci;
+            const unsigned gin = (unsigned)((tin + 255) / 256 < 4096 ? (tin + 255) / 256 : 4096);
+            LAUNCH(ctx, "disc_conv_bwd", (dc_conv_dgrad_kernel<<<gin, 256, 0, st>>>(g, ws + pl.wb[i], gm, din)));
+        }
+    }
+}
+
+void launch_mag_pair(LaunchCtx ctx, const float* clean_spec, const float* est_real, const float* est_imag, int B, int T, int F,
+                     float* xy) {
+    LAUNCH(ctx, "disc_glue", (mag_pair_kernel<<<1024, 256, 0, ctx.stream>>>(clean_spec, est_real, est_imag, B, (long)T * F, xy)));
+}
+void launch_mag_pair_backward(LaunchCtx ctx, const float* est_real, const float* est_imag, const float* dxy, int B, int T, int F,
+                              float scale, float* d_real, float* d_imag) {
+    LAUNCH(ctx, "disc_glue", (mag_pair_bwd_kernel<<<1024, 256, 0, ctx.stream>>>(est_real, est_imag, dxy, (long)B * T * F, scale, d_real,
+                                                                                d_imag)));
+}
+void launch_score_mse(LaunchCtx ctx, const float* score, const float* target, int B, float scale, float* loss, float* dscore) {
+    LAUNCH(ctx, "disc_glue", (score_mse_kernel<<<1, 64, 0, ctx.stream>>>(score, target, B, scale, loss, dscore)));
+}

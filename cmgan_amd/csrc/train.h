@@ -105,6 +105,30 @@ void launch_tsc_epilogue_backward(LaunchCtx, const float* spec, const float* d_r
 void launch_loss_backward(LaunchCtx, const float* est_real, const float* est_imag, const float* clean_spec,
                           const float* est_audio, const float* clean_audio, int B, int T, int F, int nfft, int hop, float w_ri,
                           float w_mag, float w_time, float* d_real, float* d_imag);
+// ------------------------------- disc.hip ----------------------------------------
+// the metric discriminator Discriminator(ndf=16) (src/models/discriminator.py:29-64) on RAW parameters
+struct DiscParams {
+    float *conv_w[4], *conv_u[4], *conv_v[4];     // layers.{0,3,6,9}.weight_orig [Co,Ci,4,4], weight_u [Co], weight_v [16 Ci]
+    float *norm_w[4], *norm_b[4], *prelu_w[4];    // layers.{1,4,7,10}.{weight,bias}, layers.{2,5,8,11}.weight
+    float *fc1_w, *fc1_b, *fc1_u, *fc1_v;         // layers.14.{weight_orig [64,128], bias, weight_u, weight_v}
+    float *prelu5_w;                              // layers.16.weight [64]
+    float *fc2_w, *fc2_b, *fc2_u, *fc2_v;         // layers.17.{weight_orig [1,64], bias, weight_u, weight_v}
+    float *slope;                                 // layers.18.slope [1]
+};
+size_t disc_ws_floats(int B, int T, int F);
+bool disc_shape_ok(int T, int F);
+// xy [B,T,F,2] = (|clean|, |est|) channels-last; score [B]; mask [B,64] = Dropout(0.3) keep-mask or NULL;
+// update_uv != 0: one power iteration per spectral norm, written back to the u / v buffers (train mode)
+void launch_disc_forward(LaunchCtx, const float* xy, int B, int T, int F, const DiscParams& p, const float* mask,
+                         int update_uv, float* score, float* ws);
+void launch_disc_backward(LaunchCtx, const float* xy, const float* dscore, int B, int T, int F, const DiscParams& p,
+                          const float* mask, float* dxy, const DiscParams& grad, float* ws);
+void launch_mag_pair(LaunchCtx, const float* clean_spec, const float* est_real, const float* est_imag, int B, int T, int F,
+                     float* xy);
+void launch_mag_pair_backward(LaunchCtx, const float* est_real, const float* est_imag, const float* dxy, int B, int T, int F,
+                              float scale, float* d_real, float* d_imag);
+void launch_score_mse(LaunchCtx, const float* score, const float* target, int B, float scale, float* loss, float* dscore);
+
 void launch_adamw(LaunchCtx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                   float eps, float wd, int step);
 

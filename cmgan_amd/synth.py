@@ -178,3 +178,35 @@ def sample_indices(numel: int, k: int = 256, seed: int = 1234) -> np.ndarray:
     if numel <= k:
         return np.arange(numel)
     return np.sort(np.random.RandomState(seed + numel % 9973).choice(numel, k, replace=False))
+
+
+def discriminator_state_dict(seed: int = 0, ndf: int = 16) -> dict:
+    """State dict of the reference metric discriminator `Discriminator(ndf=16)` (src/models/discriminator.py:29-64):
+    four spectral-norm 4x4 stride-2 convs (weight_orig + the power-iteration vectors weight_u / weight_v, both unit
+    norm like torch initialises them), InstanceNorm2d(affine) + PReLU after each, two spectral-norm Linear layers,
+    PReLU, LearnableSigmoid.  Keys as `Discriminator.state_dict()` returns them (34 entries)."""
+    s = _Stream(seed + 7919)
+    sd: dict = {}
+
+    def unit(n):
+        v = s.normal((n,), 0.0, 1.0).astype(np.float64)
+        return (v / max(float(np.linalg.norm(v)), 1e-12)).astype(np.float32)
+
+    chans = (2, ndf, 2 * ndf, 4 * ndf, 8 * ndf)
+    for i in range(4):
+        cin, cout = chans[i], chans[i + 1]
+        bound = 1.0 / np.sqrt(cin * 16)
+        sd[f"layers.{3 * i}.weight_orig"] = s.uniform((cout, cin, 4, 4), bound)
+        sd[f"layers.{3 * i}.weight_u"] = unit(cout)
+        sd[f"layers.{3 * i}.weight_v"] = unit(cin * 16)
+        _norm(s, sd, f"layers.{3 * i + 1}", cout)
+        _prelu(s, sd, f"layers.{3 * i + 2}", cout)
+    for idx, (out_f, in_f) in ((14, (4 * ndf, 8 * ndf)), (17, (1, 4 * ndf))):
+        bound = 1.0 / np.sqrt(in_f)
+        sd[f"layers.{idx}.weight_orig"] = s.uniform((out_f, in_f), bound)
+        sd[f"layers.{idx}.bias"] = s.uniform((out_f,), bound)
+        sd[f"layers.{idx}.weight_u"] = unit(out_f)
+        sd[f"layers.{idx}.weight_v"] = unit(in_f)
+    _prelu(s, sd, "layers.16", 4 * ndf)
+    sd["layers.18.slope"] = s.normal((1,), 1.0, 0.05)
+    return {k: _to_torch(v) for k, v in sd.items()}

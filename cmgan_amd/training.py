@@ -38,9 +38,14 @@
                              185-193 without the metric-discriminator term): STFT, forward, ISTFT, loss, loss gradient
                              (incl. the ISTFT adjoint), backward, ONE gradient all-reduce, ONE AdamW launch.
 
-Everything numerical runs in libcmgan_hip (csrc/train.hip); this module only owns parameter tensors, draws the
-dropout masks with torch's generator (plumbing) and passes pointers.  The metric discriminator (and with it the
-adversarial loss term and the discriminator step) is not built.
+* `DiscriminatorTrain`     - the metric discriminator (src/models/discriminator.py:29-64) with spectral-norm power
+                             iteration, forward + backward (csrc/disc.hip).
+* `adversarial_train_step` - Trainer.train_step (train.py:173-205): the generator step incl. the 0.05 * gen_loss_GAN
+                             term through the discriminator, then the discriminator step on GIVEN PESQ labels
+                             (batch_pesq itself is CPU code from the absent `pesq` wheel).
+
+Everything numerical runs in libcmgan_hip (csrc/train.hip, csrc/disc.hip); this module only owns parameter tensors,
+draws the dropout masks with torch's generator (plumbing) and passes pointers.
 """
 from __future__ import annotations
 
@@ -49,11 +54,12 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from ._lib import AttnParams, ConvModParams, DecoderParams, DenseParams, EncoderParams, FfnParams, check
+from ._lib import (AttnParams, ConvModParams, DecoderParams, DenseParams, DiscParams, EncoderParams, FfnParams,
+                   check)
 from .dist import FlatBucket, allreduce_mean
 from .engine import Engine
 
-__all__ = ["GeneratorTrain", "generator_train_step", "DenseEncoderTrain", "DecoderTrain", "DenseBlockTrain", "TSCBTrain", "ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
+__all__ = ["DiscriminatorTrain", "adversarial_train_step", "GeneratorTrain", "generator_train_step", "DenseEncoderTrain", "DecoderTrain", "DenseBlockTrain", "TSCBTrain", "ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
            "validation_step"]
 
 _KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.net.0.weight", "fn.fn.net.0.bias",
@@ -912,3 +918,199 @@ def generator_train_step(gen: GeneratorTrain, optimizer: "AdamW", clean: torch.T
     gen.allreduce_gradients()                                   # DDP's gradient mean, one collective
     optimizer.step(lr)                                          # train.py:191
     return loss, terms
+
+
+_DISC_CH = (2, 16, 32, 64, 128)
+
+
+class DiscriminatorTrain:
+    """`models.discriminator.Discriminator(ndf=16)` (discriminator.py:29-64) on the HIP kernels of csrc/disc.hip.
+
+    `state` is the module's state_dict (34 entries: `layers.N.weight_orig / weight_u / weight_v` of the six spectral
+    norms, InstanceNorm / PReLU / bias / slope tensors).  The 22 learnable tensors and their gradients are views of one
+    flat bucket each; the power-iteration vectors are buffers, updated in place by every train-mode forward like
+    torch's hook does.  Inputs are `xy [B, T, F, 2] = (|clean|, |est|)` from `pair()`.  Up to `slots` forwards can be
+    alive at once (the discriminator loss backpropagates through two of them, train.py:163-170)."""
+
+    @staticmethod
+    def shapes() -> Dict[str, tuple]:
+        d: Dict[str, tuple] = {}
+        for i in range(4):
+            d[f"layers.{3 * i}.weight_orig"] = (_DISC_CH[i + 1], _DISC_CH[i], 4, 4)
+            d[f"layers.{3 * i + 1}.weight"] = (_DISC_CH[i + 1],)
+            d[f"layers.{3 * i + 1}.bias"] = (_DISC_CH[i + 1],)
+            d[f"layers.{3 * i + 2}.weight"] = (_DISC_CH[i + 1],)
+        d.update({"layers.14.weight_orig": (64, 128), "layers.14.bias": (64,), "layers.16.weight": (64,),
+                  "layers.17.weight_orig": (1, 64), "layers.17.bias": (1,), "layers.18.slope": (1,)})
+        return d
+
+    _SN = ("layers.0", "layers.3", "layers.6", "layers.9", "layers.14", "layers.17")
+
+    def __init__(self, state: Dict[str, torch.Tensor], engine: Optional[Engine] = None, device=None, dropout: float = 0.3,
+                 slots: int = 2):
+        self.engine = eng = engine if engine is not None else Engine(device=device)
+        self.dropout = float(dropout)
+        self.param_bucket, self.grad_bucket, self.params, self.grads = _buckets(self.shapes(), state, None, eng.device)
+        self._scratch = FlatBucket(self.shapes(), eng.device)          # second graph's gradients before accumulation
+        self.buffers = {}
+        for p in self._SN:
+            for s in ("weight_u", "weight_v"):
+                self.buffers[f"{p}.{s}"] = state[f"{p}.{s}"].detach().to(eng.device, torch.float32).clone().contiguous()
+        self._ws = [None] * slots
+        self._saved = [None] * slots
+
+    def _struct(self, t, with_buffers: bool = True) -> DiscParams:
+        s = DiscParams()
+        for i in range(4):
+            s.conv_weight_orig[i] = t[f"layers.{3 * i}.weight_orig"].data_ptr()
+            s.norm_weight[i] = t[f"layers.{3 * i + 1}.weight"].data_ptr()
+            s.norm_bias[i] = t[f"layers.{3 * i + 1}.bias"].data_ptr()
+            s.prelu_weight[i] = t[f"layers.{3 * i + 2}.weight"].data_ptr()
+            if with_buffers:
+                s.conv_u[i] = self.buffers[f"layers.{3 * i}.weight_u"].data_ptr()
+                s.conv_v[i] = self.buffers[f"layers.{3 * i}.weight_v"].data_ptr()
+        s.fc1_weight_orig, s.fc1_bias = t["layers.14.weight_orig"].data_ptr(), t["layers.14.bias"].data_ptr()
+        s.prelu5_weight = t["layers.16.weight"].data_ptr()
+        s.fc2_weight_orig, s.fc2_bias = t["layers.17.weight_orig"].data_ptr(), t["layers.17.bias"].data_ptr()
+        s.slope = t["layers.18.slope"].data_ptr()
+        if with_buffers:
+            s.fc1_u, s.fc1_v = self.buffers["layers.14.weight_u"].data_ptr(), self.buffers["layers.14.weight_v"].data_ptr()
+            s.fc2_u, s.fc2_v = self.buffers["layers.17.weight_u"].data_ptr(), self.buffers["layers.17.weight_v"].data_ptr()
+        return s
+
+    def mask(self, B: int, generator: Optional[torch.Generator] = None) -> Optional[torch.Tensor]:
+        return dropout_mask((B, 64), self.dropout, self.engine.device, generator)
+
+    def pair(self, clean_spec: torch.Tensor, est_real: Optional[torch.Tensor] = None,
+             est_imag: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """xy [B, T, F, 2] = (|clean_spec|, |est|); without est: (|clean|, |clean|) (train.py:102-103, 166)."""
+        eng = self.engine
+        clean_spec = eng._in(clean_spec, "clean_spec")
+        B, _, T, F = clean_spec.shape
+        xy = torch.empty(B, T, F, 2, dtype=torch.float32, device=eng.device)
+        er = eng._in(est_real, "est_real").data_ptr() if est_real is not None else None
+        ei = eng._in(est_imag, "est_imag").data_ptr() if est_imag is not None else None
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_mag_pair(eng._h, clean_spec.data_ptr(), er, ei, B, T, xy.data_ptr(), eng._stream()))
+        return xy
+
+    def forward(self, xy: torch.Tensor, mask: Optional[torch.Tensor] = None, train: bool = True, slot: int = 0) -> torch.Tensor:
+        eng = self.engine
+        xy = eng._in(xy, "xy")
+        B, T, F, two = xy.shape
+        if two != 2 or F != eng.cfg.num_features:
+            raise ValueError(f"expected [B, T, {eng.cfg.num_features}, 2]")
+        need = eng.lib.cmgan_disc_workspace_bytes(eng._h, B, T)
+        if need == 0:
+            raise ValueError("the discriminator needs T >= 16 frames and F >= 16 bins")
+        if self._ws[slot] is None or self._ws[slot].numel() < need:
+            self._ws[slot] = torch.empty(need, dtype=torch.uint8, device=eng.device)
+        ws = self._ws[slot]
+        score = torch.empty(B, dtype=torch.float32, device=eng.device)
+        mp = eng._in(mask, "mask").data_ptr() if mask is not None else None
+        p = self._struct(self.params)
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_disc_forward(eng._h, xy.data_ptr(), B, T, ctypes.byref(p), mp, 1 if train else 0,
+                                                     score.data_ptr(), ws.data_ptr(), ws.numel(), eng._stream()))
+        self._saved[slot] = (xy, mask, B, T)
+        return score
+
+    def backward(self, dscore: torch.Tensor, slot: int = 0, need_input_grad: bool = True,
+                 accumulate: bool = False) -> Optional[torch.Tensor]:
+        """dL/dxy (or None) for the forward of `slot`; parameter gradients are written to (or, with `accumulate`,
+        added to) the gradient bucket."""
+        if self._saved[slot] is None:
+            raise RuntimeError("backward() needs the forward() of the same slot first")
+        eng = self.engine
+        xy, mask, B, T = self._saved[slot]
+        dscore = eng._in(dscore, "dscore")
+        dxy = torch.empty_like(xy) if need_input_grad else None
+        target = self._scratch.views if accumulate else self.grads
+        p, g = self._struct(self.params), self._struct(target, with_buffers=False)
+        mp = mask.data_ptr() if mask is not None else None
+        ws = self._ws[slot]
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_disc_backward(eng._h, xy.data_ptr(), dscore.data_ptr(), B, T, ctypes.byref(p), mp,
+                                                      dxy.data_ptr() if dxy is not None else None, ctypes.byref(g),
+                                                      ws.data_ptr(), ws.numel(), eng._stream()))
+            if accumulate:
+                gf, sf = self.grad_bucket.flat, self._scratch.flat
+                check(eng._h, eng.lib.cmgan_add(eng._h, gf.data_ptr(), sf.data_ptr(), gf.data_ptr(), gf.numel(), eng._stream()))
+        return dxy
+
+    def score_mse(self, score: torch.Tensor, target: Optional[torch.Tensor] = None, scale: float = 1.0):
+        """(mean((score - target)^2), scale * d/dscore); target None = ones (train.py:129-131, 168-170)."""
+        eng = self.engine
+        B = score.numel()
+        loss = torch.empty(1, dtype=torch.float32, device=eng.device)
+        dscore = torch.empty(B, dtype=torch.float32, device=eng.device)
+        tp = eng._in(target, "target").data_ptr() if target is not None else None
+        with torch.cuda.device(eng.device):
+            check(eng._h, eng.lib.cmgan_score_mse(eng._h, score.data_ptr(), tp, B, float(scale), loss.data_ptr(),
+                                                  dscore.data_ptr(), eng._stream()))
+        return loss[0], dscore
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        out = {k: v.detach().clone() for k, v in self.params.items()}
+        out.update({k: v.clone() for k, v in self.buffers.items()})
+        return out
+
+    def allreduce_gradients(self) -> torch.Tensor:
+        return allreduce_mean(self.grad_bucket.flat)
+
+
+def adversarial_train_step(gen: GeneratorTrain, disc: DiscriminatorTrain, opt_g: "AdamW", opt_d: "AdamW",
+                           clean: torch.Tensor, noisy: torch.Tensor, pesq_score: Optional[torch.Tensor],
+                           loss_weights=(0.1, 0.9, 0.2, 0.05), generator: Optional[torch.Generator] = None,
+                           masks="draw", disc_masks="draw", lr: Optional[float] = None):
+    """Trainer.train_step (train.py:173-205): the generator step on the FULL loss (train.py:124-151: RI, magnitude,
+    time and 0.05 x metric-discriminator terms), then the discriminator step (train.py:153-171) on `pesq_score`
+    [B] = (PESQ - 1) / 3.5 of (clean, est_audio) - the labels discriminator.batch_pesq computes on the CPU; None (a
+    silent clip made PESQ fail) skips the discriminator update like the reference.  Returns
+    (generator loss, float32[4] terms, gen_loss_GAN, discriminator loss or None) of this rank before the updates."""
+    eng = gen.engine
+    clean, noisy = eng._in(clean, "clean"), eng._in(noisy, "noisy")
+    B = noisy.shape[0]
+    c = eng.rms_scale(noisy)
+    noisy_spec = eng.stft_compress(noisy, c)
+    clean_spec = eng.stft_compress(clean, c)
+    T = noisy_spec.shape[2]
+    if isinstance(masks, str):
+        masks = gen.masks(B, T, generator)
+    if isinstance(disc_masks, str):
+        disc_masks = [disc.mask(B, generator) for _ in range(3)]
+    elif disc_masks is None:
+        disc_masks = [None, None, None]
+    est_real, est_imag = gen.forward(noisy_spec, masks)                       # train.py:100
+    est_audio = eng.uncompress_istft(est_real, est_imag)                      # train.py:105-112
+    La = est_audio.shape[-1]
+    clean_cut = clean[:, :La].contiguous()
+    base, terms = generator_loss_terms(eng, est_real, est_imag, clean_spec, est_audio, clean_cut, loss_weights[:3])
+    xy = disc.pair(clean_spec, est_real, est_imag)                            # (clean_mag, est_mag), train.py:102-103
+    score = disc.forward(xy, disc_masks[0], train=True, slot=0)               # train.py:126-128
+    gan, dscore = disc.score_mse(score, None, scale=float(loss_weights[3]))    # train.py:129-131
+    loss = base + float(loss_weights[3]) * gan
+    d_real, d_imag = torch.empty_like(est_real), torch.empty_like(est_imag)
+    with torch.cuda.device(eng.device):
+        check(eng._h, eng.lib.cmgan_loss_backward(eng._h, est_real.data_ptr(), est_imag.data_ptr(), clean_spec.data_ptr(),
+                                                  B, T, est_audio.data_ptr(), clean_cut.data_ptr(),
+                                                  float(loss_weights[0]), float(loss_weights[1]), float(loss_weights[2]),
+                                                  d_real.data_ptr(), d_imag.data_ptr(), eng._stream()))
+        dxy = disc.backward(dscore, slot=0, need_input_grad=True)
+        check(eng._h, eng.lib.cmgan_mag_pair_backward(eng._h, est_real.data_ptr(), est_imag.data_ptr(), dxy.data_ptr(), B, T,
+                                                      1.0, d_real.data_ptr(), d_imag.data_ptr(), eng._stream()))
+    gen.backward(d_real, d_imag)                                              # train.py:190
+    gen.allreduce_gradients()
+    opt_g.step(lr)                                                            # train.py:191
+    loss_d = None
+    if pesq_score is not None:                                                # train.py:194-201
+        s_enh = disc.forward(xy, disc_masks[1], train=True, slot=0)           # D(clean, est.detach()), :163-165
+        s_max = disc.forward(disc.pair(clean_spec), disc_masks[2], train=True, slot=1)   # D(clean, clean), :166-167
+        l_max, d_max = disc.score_mse(s_max, None)
+        l_enh, d_enh = disc.score_mse(s_enh, pesq_score)
+        loss_d = l_max + l_enh                                                # :168-170
+        disc.backward(d_enh, slot=0, need_input_grad=False)
+        disc.backward(d_max, slot=1, need_input_grad=False, accumulate=True)
+        disc.allreduce_gradients()
+        opt_d.step(None if lr is None else 2.0 * lr)                          # train.py:64-66: twice the generator's rate
+    return loss, terms, gan, loss_d

@@ -317,6 +317,43 @@ int cmgan_loss_backward(cmgan_handle* h, const float* est_real_dev, const float*
                         const float* clean_audio_dev, float w_ri, float w_mag, float w_time,
                         float* d_real_dev, float* d_imag_dev, void* stream);
 
+/* The metric discriminator Discriminator(ndf=16) of the reference trainer (src/models/discriminator.py:29-64) with its
+ * backward: four spectral-norm Conv2d(4x4, stride 2, pad 1, no bias) + InstanceNorm2d(affine) + PReLU stages
+ * (2 -> 16 -> 32 -> 64 -> 128), global max pool, spectral-norm Linear(128,64), Dropout(0.3), PReLU(64), spectral-norm
+ * Linear(64,1), LearnableSigmoid(1).  Parameters are the RAW state_dict tensors (weight_orig + the power-iteration
+ * buffers weight_u / weight_v of torch.nn.utils.spectral_norm).  xy [B,T,F,2] = (|clean|, |est|) channels-last is the
+ * reference's cat([clean_mag, est_mag], 1) [B,2,F,T] (cmgan_mag_pair builds it from the model-layout tensors);
+ * T, F >= 16.  update_uv != 0 is train mode: one power iteration per spectral norm before use, written back to the
+ * u / v buffers; mask [B,64] is the Dropout keep-mask (0 or 1/0.7) or NULL.  The backward needs the forward's workspace
+ * untouched (it holds the u, v, sigma that forward used), writes dL/dxy when dxy is not NULL and the 22 parameter
+ * gradients (the u / v fields of `grads` are ignored).                                                            */
+typedef struct cmgan_disc_params {
+    float *conv_weight_orig[4], *conv_u[4], *conv_v[4];   /* layers.{0,3,6,9}.weight_orig / weight_u / weight_v */
+    float *norm_weight[4], *norm_bias[4], *prelu_weight[4]; /* layers.{1,4,7,10}.{weight,bias}, layers.{2,5,8,11}.weight */
+    float *fc1_weight_orig, *fc1_bias, *fc1_u, *fc1_v;    /* layers.14.* */
+    float *prelu5_weight;                                 /* layers.16.weight */
+    float *fc2_weight_orig, *fc2_bias, *fc2_u, *fc2_v;    /* layers.17.* */
+    float *slope;                                         /* layers.18.slope */
+} cmgan_disc_params;
+size_t cmgan_disc_workspace_bytes(const cmgan_handle* h, int B, int T);
+int cmgan_disc_forward(cmgan_handle* h, const float* xy_dev, int B, int T, const cmgan_disc_params* params,
+                       const float* mask_dev, int update_uv, float* score_dev,
+                       void* workspace_dev, size_t workspace_bytes, void* stream);
+int cmgan_disc_backward(cmgan_handle* h, const float* xy_dev, const float* dscore_dev, int B, int T,
+                        const cmgan_disc_params* params, const float* mask_dev, float* dxy_dev,
+                        const cmgan_disc_params* grads, void* workspace_dev, size_t workspace_bytes, void* stream);
+/* xy [B,T,F,2] = (|clean_spec|, |est|) (train.py:102-103); est_* NULL -> (|clean|, |clean|) (train.py:166).
+ * Backward: d_real / d_imag += scale * dxy[...,1] * est / |est|  (the path of gen_loss_GAN into the generator).   */
+int cmgan_mag_pair(cmgan_handle* h, const float* clean_spec_dev, const float* est_real_dev, const float* est_imag_dev,
+                   int B, int T, float* xy_dev, void* stream);
+int cmgan_mag_pair_backward(cmgan_handle* h, const float* est_real_dev, const float* est_imag_dev,
+                            const float* dxy_dev, int B, int T, float scale, float* d_real_dev, float* d_imag_dev,
+                            void* stream);
+/* loss = mean((score - target)^2) with target = 1 when NULL (train.py:129-131, 168-170); dscore (may be NULL) =
+ * scale * d loss / d score.                                                                                       */
+int cmgan_score_mse(cmgan_handle* h, const float* score_dev, const float* target_dev, int B, float scale,
+                    float* loss_dev, float* dscore_dev, void* stream);
+
 /* One torch.optim.AdamW step (src/train.py:63-66, 192-193; defaults betas (0.9, 0.999), eps 1e-8, weight_decay
  * 0.01) over a FLAT fp32 bucket of n parameters: params, grads and the two moment buffers are parallel device
  * arrays (the bucket the gradient all-reduce runs over), `step` = 1, 2, ... is the update count for the bias

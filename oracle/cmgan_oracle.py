@@ -418,3 +418,72 @@ def generator_step_gradients(sd, clean, noisy, masks=None, loss_weights=(0.1, 0.
     return {"loss": loss.detach(), "terms": torch.stack([l_ri, l_mag, l_time]).detach(), "est_real": er.detach(),
             "est_imag": ei.detach(), "d_real": er.grad.detach(), "d_imag": ei.grad.detach(),
             "grads": {k: v.grad for k, v in leaf.items()}}
+
+
+# --------------------------------------------------------------------------- #
+# metric discriminator: src/models/discriminator.py:29-64
+# --------------------------------------------------------------------------- #
+def spectral_normed(w_orig, u, v, update: bool, eps: float = 1e-12):
+    """torch.nn.utils.spectral_norm's weight (one power iteration per training-mode forward, the iteration itself
+    outside the autograd graph): returns (w_orig / sigma, u', v').  discriminator.py:33-58."""
+    wm = w_orig.reshape(w_orig.shape[0], -1)
+    with torch.no_grad():
+        if update:
+            v = F.normalize(torch.mv(wm.t(), u), dim=0, eps=eps)
+            u = F.normalize(torch.mv(wm, v), dim=0, eps=eps)
+    sigma = torch.dot(u, torch.mv(wm, v))
+    return w_orig / sigma, u, v
+
+
+def discriminator(dsd, x, y, mask=None, train: bool = True):
+    """Discriminator(ndf=16).forward(x, y) (discriminator.py:61-64).  x, y: [B,1,F,T] magnitudes.  `mask` [B,64] is
+    the keep-mask of the Dropout(0.3) (None = no dropout).  Returns (score [B,1], {key: updated u / v})."""
+    h = torch.cat([x, y], dim=1)
+    new = {}
+    for i in range(4):
+        p = f"layers.{3 * i}"
+        w, u, v = spectral_normed(dsd[p + ".weight_orig"], dsd[p + ".weight_u"], dsd[p + ".weight_v"], train)
+        new[p + ".weight_u"], new[p + ".weight_v"] = u, v
+        h = F.conv2d(h, w, None, stride=(2, 2), padding=(1, 1))
+        h = F.instance_norm(h, weight=dsd[f"layers.{3 * i + 1}.weight"], bias=dsd[f"layers.{3 * i + 1}.bias"], eps=EPS)
+        h = F.prelu(h, dsd[f"layers.{3 * i + 2}.weight"])
+    h = torch.amax(h, dim=(2, 3))
+    w, u, v = spectral_normed(dsd["layers.14.weight_orig"], dsd["layers.14.weight_u"], dsd["layers.14.weight_v"], train)
+    new["layers.14.weight_u"], new["layers.14.weight_v"] = u, v
+    h = F.linear(h, w, dsd["layers.14.bias"])
+    if mask is not None:
+        h = h * mask
+    h = F.prelu(h, dsd["layers.16.weight"])
+    w, u, v = spectral_normed(dsd["layers.17.weight_orig"], dsd["layers.17.weight_u"], dsd["layers.17.weight_v"], train)
+    new["layers.17.weight_u"], new["layers.17.weight_v"] = u, v
+    h = F.linear(h, w, dsd["layers.17.bias"])
+    return torch.sigmoid(dsd["layers.18.slope"] * h), new
+
+
+def adversarial_generator_gradients(sd, dsd, clean, noisy, masks=None, disc_mask=None, loss_weights=(0.1, 0.9, 0.2, 0.05),
+                                    n_fft: int = 400, hop: int = 100):
+    """Generator half of Trainer.train_step with the metric-discriminator term (train.py:72-151, 185-190): like
+    generator_step_gradients plus `gan` = mse(D(clean_mag, est_mag), 1) through `discriminator` (one power iteration).
+    Returns loss, gan, est_*, d_real / d_imag, generator grads and the updated u / v of the discriminator."""
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()
+            if v.is_floating_point() and "running_" not in k}
+    sdx = dict(sd)
+    sdx.update(leaf)
+    with torch.enable_grad():
+        c = rms_scale(noisy)
+        noisy_spec = stft_compress(noisy * c[:, None], n_fft, hop)
+        clean_spec = stft_compress(clean * c[:, None], n_fft, hop)
+        er, ei = tscnet_forward_train(sdx, noisy_spec, masks)
+        er.retain_grad(); ei.retain_grad()
+        audio = uncompress_istft(er, ei, n_fft, hop)
+        out = {"est_real": er, "est_imag": ei, "clean_spec": clean_spec, "est_audio": audio}
+        base, l_ri, l_mag, l_time = generator_loss(out, clean[:, :audio.shape[-1]], loss_weights[:3])
+        est_mag = torch.sqrt(er ** 2 + ei ** 2).permute(0, 1, 3, 2)
+        clean_mag = torch.sqrt(clean_spec[:, 0:1] ** 2 + clean_spec[:, 1:2] ** 2).permute(0, 1, 3, 2)
+        score, new = discriminator(dsd, clean_mag, est_mag, disc_mask, train=True)
+        gan = F.mse_loss(score.flatten(), torch.ones(score.shape[0], dtype=score.dtype))
+        loss = base + loss_weights[3] * gan
+        loss.backward()
+    return {"loss": loss.detach(), "gan": gan.detach(), "est_real": er.detach(), "est_imag": ei.detach(),
+            "d_real": er.grad.detach(), "d_imag": ei.grad.detach(), "grads": {k: v.grad for k, v in leaf.items()},
+            "disc_buffers": new, "clean_spec": clean_spec}

@@ -446,6 +446,121 @@ def main():
          terms2=torch.stack(terms2).detach(), bn_mean=bn.running_mean.detach().clone(),
          bn_var=bn.running_var.detach().clone(), **digest)
 
+    # -- 20. the metric discriminator (src/models/discriminator.py:29-64) in TRAIN mode: one power iteration of every
+    #        spectral norm per forward (u / v buffers updated), Dropout(0.3) as an explicit keep-mask, autograd
+    #        gradients of the score with respect to both inputs and all parameters; plus the eval-mode score afterwards.
+    #        The module imports the `pesq` wheel (absent here) at the top for batch_pesq only: a stub module stands in.
+    import types
+    sys.modules.setdefault("pesq", types.SimpleNamespace(pesq=None))
+    from models.discriminator import Discriminator
+    from cmgan_amd.synth import discriminator_state_dict
+    dsd = discriminator_state_dict(0)
+    with torch.enable_grad():
+        disc = Discriminator(ndf=16)
+        disc.load_state_dict(dsd, strict=True)
+        xdm = rnd((2, 1, 201, 33), 101).abs()
+        ydm = rnd((2, 1, 201, 33), 102).abs()
+        disc.train()
+        mdm = (torch.rand(2, 64, generator=torch.Generator().manual_seed(103)) >= 0.3).float() / 0.7
+        disc.layers[15] = _Mask(mdm)
+        xdl, ydl = xdm.clone().requires_grad_(True), ydm.clone().requires_grad_(True)
+        score = disc(xdl, ydl)
+        dscore = rnd((2, 1), 104)
+        score.backward(dscore)
+        dgrads = {"grad_" + k.replace(".", "_"): v.grad.detach() for k, v in disc.named_parameters()}
+        duv = {"new_" + k.replace(".", "_"): v.detach().clone() for k, v in disc.state_dict().items()
+               if k.endswith("_u") or k.endswith("_v")}
+        disc.eval()                                   # eval mode: no power iteration (the UPDATED u / v), no dropout
+        disc.layers[15] = torch.nn.Identity()
+        with torch.no_grad():
+            score_eval = disc(xdm, ydm)
+    save("disc_train.npz", x=xdm, y=ydm, mask=mdm, score_eval=score_eval, score=score.detach(), dscore=dscore,
+         dx=xdl.grad.detach(), dy=ydl.grad.detach(), **dgrads, **duv)
+
+    # -- 21. one FULL adversarial training step of the reference trainer (train.py:153-205) at B = 2, L = 3200 (T = 33):
+    #        generator loss incl. 0.05 * gen_loss_GAN through the discriminator, AdamW(5e-4) on the generator, then the
+    #        discriminator loss mse(D(clean, clean), 1) + mse(D(clean, est.detach()), pesq) with GIVEN normalised PESQ
+    #        labels (the pesq wheel is absent; the labels are data as far as the device step is concerned),
+    #        AdamW(1e-3) on the discriminator; and the generator loss of a second step.  Dropout masks: generator
+    #        synthetic_dropout_masks(78), discriminator RandomState(79) keep-masks [3 calls][B, 64].
+    with torch.enable_grad():
+        amodel = TSCNet(num_channel=64, num_features=201)
+        amodel.load_state_dict(sd, strict=True)
+        amodel.train()
+        adisc = Discriminator(ndf=16)
+        adisc.load_state_dict(dsd, strict=True)
+        adisc.train()
+        Ba, La = 2, 3200
+        Ta = La // 100 + 1
+        am = synthetic_dropout_masks(78, Ba, Ta, 101)
+        for bi, name in enumerate(("TSCB_1", "TSCB_2", "TSCB_3", "TSCB_4")):
+            for ai, ax in enumerate(("time_conformer", "freq_conformer")):
+                conf = getattr(getattr(amodel, name), ax)
+                mk = {k: torch.from_numpy(v) for k, v in am[bi][ai].items()}
+                conf.ff1.fn.fn.net[2], conf.ff1.fn.fn.net[4] = _Mask(mk["ff1_1"]), _Mask(mk["ff1_2"])
+                conf.attn.fn.dropout = _Mask(mk["attn"])
+                conf.ff2.fn.fn.net[2], conf.ff2.fn.fn.net[4] = _Mask(mk["ff2_1"]), _Mask(mk["ff2_2"])
+        drs = np.random.RandomState(79)
+        dmasks = [torch.from_numpy(((drs.random_sample((Ba, 64)) >= 0.3).astype(np.float32) / np.float32(0.7)))
+                  for _ in range(6)]
+        aclean = synthetic_clips(Ba, La, seed=41)
+        anoisy = aclean + 0.3 * synthetic_clips(Ba, La, seed=42)
+        pesq_lab = torch.tensor([0.45, 0.8])
+        ones = torch.ones(Ba)
+        F_ = torch.nn.functional
+        dcall = [0]
+
+        def D(a, b_):
+            adisc.layers[15] = _Mask(dmasks[dcall[0]])
+            dcall[0] += 1
+            return adisc(a, b_)
+
+        def fwd_gen():
+            c = torch.sqrt(anoisy.size(-1) / torch.sum(anoisy ** 2.0, dim=-1))
+            noisy_s, clean_s = anoisy * c[:, None], aclean * c[:, None]
+            nspec = torch.view_as_real(torch.stft(noisy_s, 400, 100, window=win, onesided=True, return_complex=True))
+            cspec = torch.view_as_real(torch.stft(clean_s, 400, 100, window=win, onesided=True, return_complex=True))
+            nspec = ref_utils.power_compress(nspec).permute(0, 1, 3, 2)
+            cspec = ref_utils.power_compress(cspec)
+            clean_real, clean_imag = cspec[:, 0:1], cspec[:, 1:2]
+            er0, ei0 = amodel(nspec)
+            er, ei = er0.permute(0, 1, 3, 2), ei0.permute(0, 1, 3, 2)
+            est_mag = torch.sqrt(er ** 2 + ei ** 2)
+            clean_mag = torch.sqrt(clean_real ** 2 + clean_imag ** 2)
+            unc = ref_utils.power_uncompress(er, ei).squeeze(1)
+            est_audio = torch.istft(torch.view_as_complex(unc.contiguous()), 400, 100, window=win, onesided=True)
+            gan = F_.mse_loss(D(clean_mag, est_mag).flatten(), ones)
+            loss_mag = F_.mse_loss(est_mag, clean_mag)
+            loss_ri = F_.mse_loss(er, clean_real) + F_.mse_loss(ei, clean_imag)
+            time_loss = torch.mean(torch.abs(est_audio - aclean))
+            loss = 0.1 * loss_ri + 0.9 * loss_mag + 0.2 * time_loss + 0.05 * gan
+            return loss, gan, est_mag, clean_mag
+
+        opt_g = torch.optim.AdamW(amodel.parameters(), lr=5e-4)
+        opt_d = torch.optim.AdamW(adisc.parameters(), lr=1e-3)
+        loss_g, gan_g, est_mag, clean_mag = fwd_gen()
+        opt_g.zero_grad()
+        loss_g.backward()
+        adig = {}
+        for k, v in amodel.named_parameters():
+            gflat = v.grad.detach().reshape(-1)
+            idx = torch.from_numpy(sample_indices(gflat.numel()))
+            adig["gl2_" + k] = gflat.double().norm().float()
+            adig["gsmp_" + k] = gflat[idx].clone()
+        opt_g.step()
+        p_enh = D(clean_mag.detach(), est_mag.detach())
+        p_max = D(clean_mag.detach(), clean_mag.detach())
+        loss_d = F_.mse_loss(p_max.flatten(), ones) + F_.mse_loss(p_enh.flatten(), pesq_lab)
+        opt_d.zero_grad()
+        loss_d.backward()
+        ddig = {"dgrad_" + k.replace(".", "_"): v.grad.detach().clone() for k, v in adisc.named_parameters()}
+        opt_d.step()
+        with torch.no_grad():
+            loss_g2, gan_g2, _, _ = fwd_gen()
+    save("adversarial_step.npz", clean=aclean, noisy=anoisy, pesq=pesq_lab, loss=loss_g.detach(), gan=gan_g.detach(),
+         loss_d=loss_d.detach(), p_enh=p_enh.detach(), p_max=p_max.detach(), loss2=loss_g2.detach(),
+         gan2=gan_g2.detach(), **adig, **ddig)
+
     save("ffn_train.npz", x=xt.detach(), dy=dy, mask1=m1, mask2=m2, y=yt.detach(), dx=xt.grad.detach(),
          y_nomask=y0.detach(), dx_nomask=x0.grad.detach(), **grads, **grads0)
 

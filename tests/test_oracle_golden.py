@@ -338,6 +338,54 @@ def test_generator_gradient_noise_floor(sd):
     assert 1e-5 < errs[len(errs) // 2] < 1e-3 and errs[-1] < 5e-2
 
 
+def test_discriminator_forward_and_gradients():
+    """Metric discriminator in train mode: one spectral-norm power iteration, dropout mask, autograd vs the reference
+    module; then the eval-mode score with the updated u / v."""
+    from cmgan_amd.synth import discriminator_state_dict
+    g = load_golden("disc_train.npz")
+    dsd = discriminator_state_dict(0)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in dsd.items() if not (k.endswith("_u") or k.endswith("_v"))}
+    sdx = dict(dsd)
+    sdx.update(leaf)
+    x, y = g["x"].clone().requires_grad_(True), g["y"].clone().requires_grad_(True)
+    with torch.enable_grad():
+        score, new = O.discriminator(sdx, x, y, g["mask"], train=True)
+        score.backward(g["dscore"])
+    assert rel_err(score, g["score"]) < TOL
+    assert rel_err(x.grad, g["dx"]) < 5e-5 and rel_err(y.grad, g["dy"]) < 5e-5
+    for k, v in leaf.items():
+        assert rel_err(v.grad, g["grad_" + k.replace(".", "_")]) < 5e-5, k
+    for k, v in new.items():
+        assert rel_err(v, g["new_" + k.replace(".", "_")]) < TOL, k
+    sde = dict(dsd)
+    sde.update(new)
+    score_eval, _ = O.discriminator(sde, g["x"], g["y"], None, train=False)
+    assert rel_err(score_eval, g["score_eval"]) < TOL
+
+
+def test_adversarial_generator_gradients(sd):
+    """The generator half of the reference's full train step (loss incl. 0.05 x gen_loss_GAN through the metric
+    discriminator) at T = 33: loss, GAN term and the digests of all 335 parameter gradients."""
+    import numpy as np
+    from cmgan_amd.synth import discriminator_state_dict, sample_indices, synthetic_dropout_masks
+    g = load_golden("adversarial_step.npz")
+    masks = [tuple({k: torch.from_numpy(v) for k, v in d.items()} for d in pair)
+             for pair in synthetic_dropout_masks(78, 2, 33, 101)]
+    dmask = torch.from_numpy((np.random.RandomState(79).random_sample((2, 64)) >= 0.3).astype(np.float32) / np.float32(0.7))
+    out = O.adversarial_generator_gradients(sd, discriminator_state_dict(0), g["clean"], g["noisy"], masks, dmask)
+    assert abs(float(out["loss"]) - float(g["loss"])) < 2e-5 * float(g["loss"])
+    assert abs(float(out["gan"]) - float(g["gan"])) < 2e-5 * float(g["gan"])
+    errs = []
+    scale = max(float(g["gl2_" + k]) for k in out["grads"])
+    for k, v in out["grads"].items():
+        want = g["gsmp_" + k]
+        if float(g["gl2_" + k]) > 1e-4 * scale:
+            smp = v.reshape(-1)[torch.from_numpy(sample_indices(v.numel()))]
+            errs.append(float((smp - want).abs().max()) / float(want.abs().max()))
+    errs.sort()
+    assert errs[len(errs) // 2] < 2e-5 and errs[-1] < 3e-2
+
+
 def test_validation_step_losses_match_the_reference(sd):
     """Generator half of Trainer.test_step: forward_generator_step + the three non-adversarial loss terms."""
     g = load_golden("valstep.npz")
