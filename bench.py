@@ -232,6 +232,47 @@ def load_pmc_traffic(x3: bool, sh: Shape, workload: str):
     return None, None, why
 
 
+def train_leg(eng, sd, dev, rank, world, barrier, batch=4, cut_len=32000, steps=3):
+    """One data-parallel adversarial training step per rank (cmgan_amd.training.adversarial_train_step: generator on
+    RI + magnitude + time + GAN loss, metric discriminator on given PESQ labels; per step TWO gradient all-reduces over
+    the flat buckets - 7.3 MB generator, 0.7 MB discriminator - and two AdamW launches).  Timed like the main leg:
+    barrier + synchronize on both sides, MAX over ranks.  Any failure is reported in the line instead of losing it."""
+    try:
+        from cmgan_amd import dist as cdist
+        from cmgan_amd.synth import discriminator_state_dict, synthetic_clips
+        from cmgan_amd.training import AdamW, DiscriminatorTrain, GeneratorTrain, adversarial_train_step
+        gen = GeneratorTrain(sd, engine=eng)
+        disc = DiscriminatorTrain(discriminator_state_dict(0), engine=eng)
+        opt_g = AdamW(eng, gen.param_bucket, gen.grad_bucket, lr=5e-4)
+        opt_d = AdamW(eng, disc.param_bucket, disc.grad_bucket, lr=1e-3)
+        clean = synthetic_clips(batch, cut_len, seed=2000 + rank).to(dev)
+        noisy = (clean + 0.3 * synthetic_clips(batch, cut_len, seed=3000 + rank).to(dev)).contiguous()
+        pesq = torch.full((batch,), 0.5, device=dev)
+        tgen = torch.Generator(device=dev).manual_seed(rank)
+        run = lambda: adversarial_train_step(gen, disc, opt_g, opt_d, clean, noisy, pesq, generator=tgen)
+        run()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, _, gan, loss_d = run()
+        torch.cuda.synchronize()
+        barrier()
+        dt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+        ms = 1e3 * float(dt) / steps
+        return {"workload": f"configs[2]: adversarial train step, {batch} x {cut_len / 16000:g} s clips per GPU, dropout on, "
+                            "TSCNet(64,201) + Discriminator(16) random-init, synthetic PESQ labels",
+                "batch_per_gpu": batch, "steps": steps, "ms_per_step": round(ms, 2),
+                "clips_per_s": round(batch * world / (ms * 1e-3), 2), "dtype": "f32 (fp32 MFMA training kernels)",
+                "collectives_per_step": "2 all-reduces over flat buckets (generator %.1f MB, discriminator %.1f MB)"
+                                        % (gen.grad_bucket.numel * 4 / 2**20, disc.grad_bucket.numel * 4 / 2**20),
+                "loss": round(float(loss), 4), "gen_loss_GAN": round(float(gan), 4), "disc_loss": round(float(loss_d), 4)}
+    except Exception as e:                                      # noqa: BLE001 - the headline line must survive
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,6 +282,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the bit-exact fp32-MFMA mode leg of the line")
+    ap.add_argument("--no-train", action="store_true",
+                    help="skip the training-step leg (BASELINE configs[2]: one adversarial train step per rank at the "
+                         "reference's batch 4 with the gradient all-reduces over the flat buckets)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--mfma-mode", choices=["f16x3", "f32"], default="f16x3",
                     help="f16x3: fp32-accurate 3-term split products on the f16 matrix pipe (default); "
@@ -426,8 +470,22 @@ def main():
                                                                      FP32_MFMA_PEAK_TF, 4),
                                 "roofline": roof32}
             del m32, e32
+        # ---- BASELINE configs[2]: the reference's training step (train.py:173-205), batch 4 per GPU, data parallel ----
+        if not args.no_train and args.workload == "16k" and x3:
+            tr = train_leg(eng, sd, dev, rank, world, barrier)
+            if rank == 0:
+                line["train_step"] = tr
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(sd, sh)
+    elif not args.no_train:
+        # launcher self-test of the same collective shape: a flat gradient bucket averaged over the gloo ranks
+        b = cdist.FlatBucket({"w": (1000,), "b": (7,)})
+        b.flat.fill_(float(rank + 1))
+        cdist.allreduce_mean(b.flat)
+        want = sum(range(1, world + 1)) / world
+        if rank == 0:
+            line["train_step"] = {"stub": True, "grad_mean_ok": bool(abs(float(b["w"][0]) - want) < 1e-6),
+                                  "bucket_floats": int(b.numel)}
 
     if rank == 0:
         print(json.dumps(line), flush=True)

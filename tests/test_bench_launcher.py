@@ -24,6 +24,8 @@ def test_gpus_2_launches_two_ranks_and_reports_them():
     assert len(lines) == 1, r.stdout                       # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["stub"] is True
+    # the training leg's collective shape (a flat gradient bucket averaged over the ranks) ran on both ranks
+    assert d["train_step"]["stub"] is True and d["train_step"]["grad_mean_ok"] is True
     assert d["collective"]["ranks_seen"] == 2 and d["collective"]["backend"] == "gloo"
     assert len(d["per_rank_frames_per_s"]) == 2
     assert d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
