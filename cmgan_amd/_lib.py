@@ -143,6 +143,8 @@ SIGNATURES = {
     "cmgan_score_mse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "cmgan_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_float, c_float,
                                  c_float, c_float, c_float, c_int, c_void_p]),
+    "cmgan_adamw_step_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_float,
+                                     c_float, c_float, c_float, c_void_p]),
     "cmgan_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "cmgan_rms_scale": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "cmgan_num_frames": (c_int, [c_void_p, c_int]),

@@ -428,6 +428,17 @@ extern "C" int cmgan_disc_backward(cmgan_handle* h, const float* xy, const float
     return check_launch(h, "disc_backward");
 }
 
+extern "C" int cmgan_adamw_step_dev(cmgan_handle* h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                                    long long n, float* state, float beta1, float beta2, float eps, float weight_decay,
+                                    void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !state || n <= 0 || !(beta1 >= 0.f && beta1 < 1.f) ||
+        !(beta2 >= 0.f && beta2 < 1.f))
+        return fail(h, CMGAN_E_BADARG, "cmgan_adamw_step_dev: bad argument");
+    launch_adamw_dev(begin(h, stream), params, grads, exp_avg, exp_avg_sq, (long)n, state, beta1, beta2, eps, weight_decay);
+    return check_launch(h, "adamw_step_dev");
+}
+
 extern "C" int cmgan_adamw_step(cmgan_handle* h, float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                 long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
                                 int step, void* stream) {

@@ -129,6 +129,8 @@ void launch_mag_pair_backward(LaunchCtx, const float* est_real, const float* est
                               float scale, float* d_real, float* d_imag);
 void launch_score_mse(LaunchCtx, const float* score, const float* target, int B, float scale, float* loss, float* dscore);
 
+void launch_adamw_dev(LaunchCtx, float* p, const float* g, float* m, float* v, long n, float* state, float b1, float b2,
+                      float eps, float wd);
 void launch_adamw(LaunchCtx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                   float eps, float wd, int step);
 

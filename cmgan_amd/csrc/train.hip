@@ -359,9 +359,11 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int ns
     }
 }
 
-static FfnTrainImg ffn_pack_images(LaunchCtx ctx, const FfnTrainParams& p, float* img) {
+// pack = false: the images the forward of the SAME parameters left in the workspace are reused (backward passes)
+static FfnTrainImg ffn_pack_images(LaunchCtx ctx, const FfnTrainParams& p, float* img, bool pack = true) {
     hipStream_t s = ctx.stream;
     float *w1 = img, *w2 = img + 16384, *w2t = img + 2 * 16384, *w1t = img + 3 * 16384;
+    if (!pack) return FfnTrainImg{w1, w2, w2t, w1t, p.gamma, p.beta, p.b1, p.b2};
     LAUNCH(ctx, "ffn_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.w1, 256, 64, 64, 0, w1)));     // rows = hidden
     LAUNCH(ctx, "ffn_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.w2, 64, 256, 256, 0, w2)));    // rows = out
     LAUNCH(ctx, "ffn_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.w2, 256, 64, 256, 1, w2t)));   // rows = hidden
@@ -383,7 +385,7 @@ void launch_ffn_train_forward(LaunchCtx ctx, const float* x, long M, const FfnTr
 void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, long M, const FfnTrainParams& p,
                                const float* m1, const float* m2, float* dx, const FfnTrainParams& grad, float* ws) {
     hipStream_t s = ctx.stream;
-    const FfnTrainImg w = ffn_pack_images(ctx, p, ws);
+    const FfnTrainImg w = ffn_pack_images(ctx, p, ws, false);
     float* act = ws + 4 * 16384;
     FfnBwdBufs o{act, act + M * 64, act + M * 320, act + M * 576, act + M * 640, act + M * 704};
     float* part = act + M * 768;                                  // [SPLIT][16384] x 2, then colsum slabs
@@ -430,6 +432,38 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// the same update with the step counter and the learning rate in device memory (state[0] = lr, state[1] = update count
+// as a float), so that the launch can be replayed from a captured hipGraph: a one-thread kernel advances the count,
+// the update kernel derives the bias corrections from it
+__global__ void adamw_tick_kernel(float* __restrict__ state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) state[1] += 1.0f;
+}
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, long n,
+                                                        const float* __restrict__ state, float b1, float b2, float eps,
+                                                        float wd) {
+    const float lr = state[0];
+    const double t = (double)state[1];
+    const float bc1 = (float)(1.0 - pow((double)b1, t));
+    const float rsqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)b2, t)));
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i];
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        const float denom = sqrtf(vi) * rsqrt_bc2 + eps;
+        pi -= step_size * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+void launch_adamw_dev(LaunchCtx ctx, float* p, const float* g, float* m, float* v, long n, float* state, float b1, float b2,
+                      float eps, float wd) {
+    const long want = (n + 255) / 256;
+    const unsigned grid = (unsigned)(want < 2048 ? (want > 0 ? want : 1) : 2048);
+    LAUNCH(ctx, "adamw", (adamw_tick_kernel<<<1, 64, 0, ctx.stream>>>(state)));
+    LAUNCH(ctx, "adamw", (adamw_dev_kernel<<<grid, 256, 0, ctx.stream>>>(p, g, m, v, n, state, b1, b2, eps, wd)));
+}
 void launch_adamw(LaunchCtx ctx, float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                   float eps, float wd, int step) {
     const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
@@ -799,9 +833,10 @@ static CmPlan cm_plan(int N, int L) {
 }
 size_t convmod_train_ws_floats(int N, int L) { return cm_plan(N, L).total; }
 
-static CmImg cm_pack_images(LaunchCtx ctx, const ConvModTrainParams& p, float* img) {
+static CmImg cm_pack_images(LaunchCtx ctx, const ConvModTrainParams& p, float* img, bool pack = true) {
     hipStream_t s = ctx.stream;
     float *w1 = img, *w1t = img + 16384, *w2 = img + 32768, *w2t = img + 32768 + 8192;
+    if (!pack) return CmImg{w1, w1t, w2, w2t};
     LAUNCH(ctx, "convmod_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.pw1_w, 256, 64, 64, 0, w1)));
     LAUNCH(ctx, "convmod_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.pw1_w, 64, 256, 64, 1, w1t)));
     LAUNCH(ctx, "convmod_train_pack", (pack_fm_kernel<<<32, 256, 0, s>>>(p.pw2_w, 64, 128, 128, 0, w2)));
@@ -834,7 +869,7 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     hipStream_t s = ctx.stream;
     const CmPlan pl = cm_plan(N, L);
     const long M = (long)N * L;
-    const CmImg im = cm_pack_images(ctx, p, ws + pl.img);          // (the optimiser may have run since the forward's pack)
+    const CmImg im = cm_pack_images(ctx, p, ws + pl.img, false);   // the forward's images (same parameters)
     const CmStats st{ws + pl.st, ws + pl.st + 128, ws + pl.st + 256, ws + pl.st + 384};
     const unsigned grid = (unsigned)((M + 63) / 64);
     const dim3 dgrid(N, (L + 31) / 32);
@@ -1340,7 +1375,8 @@ static AtPlan at_plan(int N, int L) {
 size_t attn_train_ws_floats(int N, int L) { return at_plan(N, L).total; }
 int attn_train_max_len() { return AT_MAX_L; }
 
-static void at_pack_images(LaunchCtx ctx, const AttnTrainParams& p, float* ws, const AtPlan& pl) {
+static void at_pack_images(LaunchCtx ctx, const AttnTrainParams& p, float* ws, const AtPlan& pl, bool pack = true) {
+    if (!pack) return;
     hipStream_t s = ctx.stream;
     hipMemcpyAsync(ws + pl.raw, p.wq, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);            // rows 0..63
     hipMemcpyAsync(ws + pl.raw + 4096, p.wkv, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);    // rows 64..191
@@ -1371,7 +1407,7 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     hipStream_t s = ctx.stream;
     const AtPlan pl = at_plan(N, L);
     const long M = (long)N * L;
-    at_pack_images(ctx, p, ws, pl);
+    at_pack_images(ctx, p, ws, pl, false);
     const AtBufs b{ws + pl.qkv, ws + pl.o, ws + pl.lse};
     const unsigned grid = (unsigned)((M + 63) / 64);
     float* cpart = ws + pl.cpart;
@@ -1850,7 +1886,8 @@ __global__ void db_pack_layer_kernel(const float* __restrict__ w, int i, float* 
     (blockIdx.z ? imgT : img)[(long)st * 4096 + e] = v;
 }
 
-static void db_pack_images(LaunchCtx ctx, const DenseTrainParams& p, float* ws, const DbPlan& pl) {
+static void db_pack_images(LaunchCtx ctx, const DenseTrainParams& p, float* ws, const DbPlan& pl, bool pack = true) {
+    if (!pack) return;
     for (int i = 0; i < 4; ++i) {
         const long off = (long)db_img_index(i, 0) * 4096;
         LAUNCH(ctx, "dense_train_pack", (db_pack_layer_kernel<<<dim3(16, 6 * (i + 1), 2), 256, 0, ctx.stream>>>(
@@ -1905,7 +1942,7 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
     const DbPlan pl = db_plan(B, T, F);
     const long M = (long)B * T * F;
     const int P = T * F;
-    db_pack_images(ctx, p, ws, pl);
+    db_pack_images(ctx, p, ws, pl, false);
     auto ga = [&](int s) { return ws + pl.ga + (size_t)s * M * 64; };
     auto aslot = [&](int s) -> const float* { return s == 0 ? x : ws + pl.a + (size_t)(s - 1) * M * 64; };
     hipMemsetAsync(ws + pl.ga, 0, (size_t)4 * M * 64 * sizeof(float), st);                       // ga_0 .. ga_3
@@ -2231,7 +2268,6 @@ void launch_encoder_train_backward(LaunchCtx ctx, const float* xin, const float*
     const RcGeom g2{B, T, F, F2, 3, 2, 1};
     float* stt = ws + pl.st;
     float* cpart = ws + pl.cpart;
-    LAUNCH(ctx, "encoder_train", (rc_pack_kernel<<<dim3(16, 3), 256, 0, st>>>(p.c2_w, 64, 3, ws + pl.img2, ws + pl.img2T)));
     // conv_2 + IN + PReLU: dy -> dz2 (kept in the front of the [M,64] gradient plane)
     float* dz2 = ws + pl.g;
     hipMemcpyAsync(dz2, dy, (size_t)M2 * 64 * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -2536,7 +2572,6 @@ void launch_decoder_train_backward(LaunchCtx ctx, int kind, const float* x, cons
     float* stt = ws + pl.st;
     float* g = ws + pl.g;
     float* g2 = ws + pl.g2;
-    LAUNCH(ctx, "decoder_train", (rc_pack_kernel<<<dim3(32, 3), 256, 0, st>>>(p.sp_w, 128, 3, ws + pl.img, ws + pl.imgT)));
     if (kind == 0) {
         const MaskTailP mp = mask_tail_params(p);
         const MaskTailG mg{grad.n_w, grad.n_b, grad.p_w, grad.f_w, grad.f_b, grad.po_w};

@@ -59,7 +59,7 @@ from ._lib import (AttnParams, ConvModParams, DecoderParams, DenseParams, DiscPa
 from .dist import FlatBucket, allreduce_mean
 from .engine import Engine
 
-__all__ = ["DiscriminatorTrain", "adversarial_train_step", "GeneratorTrain", "generator_train_step", "DenseEncoderTrain", "DecoderTrain", "DenseBlockTrain", "TSCBTrain", "ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
+__all__ = ["GraphedTrainStep", "DiscriminatorTrain", "adversarial_train_step", "GeneratorTrain", "generator_train_step", "DenseEncoderTrain", "DecoderTrain", "DenseBlockTrain", "TSCBTrain", "ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
            "validation_step"]
 
 _KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.net.0.weight", "fn.fn.net.0.bias",
@@ -81,8 +81,20 @@ def generator_loss_terms(engine: Engine, est_real, est_imag, clean_spec, est_aud
     """(weighted loss without the GAN term, float32[4] = {loss_ri, loss_mag, time_loss, time_mse}) on the device.
     loss = w0 loss_ri + w1 loss_mag + w2 time_loss   (train.py:143-148; default weights train.py:28)."""
     terms = engine.loss_terms(est_real, est_imag, clean_spec, est_audio, clean_audio)
-    w = torch.tensor(list(loss_weights) + [0.0], dtype=torch.float32, device=terms.device)
-    return (terms * w).sum(), terms
+    return (terms * _loss_w(loss_weights, terms.device)).sum(), terms
+
+
+_LOSS_W: Dict[tuple, torch.Tensor] = {}
+
+
+def _loss_w(loss_weights, device) -> torch.Tensor:
+    """[w_ri, w_mag, w_time, 0] on the device, created once per (weights, device): no host -> device copy inside a
+    step, which keeps the step graph-capturable."""
+    key = (tuple(float(x) for x in loss_weights[:3]), str(device))
+    w = _LOSS_W.get(key)
+    if w is None:
+        w = _LOSS_W[key] = torch.tensor(list(key[0]) + [0.0], dtype=torch.float32, device=device)
+    return w
 
 
 def _buckets(shapes: Dict[str, tuple], state, views, device):
@@ -195,29 +207,41 @@ def step_lr(epoch: int, init_lr: float = 5e-4, decay_epoch: int = 30, gamma: flo
 
 
 class AdamW:
-    """torch.optim.AdamW(params, lr=init_lr) of src/train.py:63 on a FlatBucket pair: one cmgan_adamw_step launch
-    updates every parameter of the bucket.  Defaults are torch's (betas (0.9, 0.999), eps 1e-8, weight_decay 1e-2)."""
+    """torch.optim.AdamW(params, lr=init_lr) of src/train.py:63 on a FlatBucket pair: one launch updates every
+    parameter of the bucket.  Defaults are torch's (betas (0.9, 0.999), eps 1e-8, weight_decay 1e-2).  The learning
+    rate and the update count live in device memory (`state`), so the launch carries no step-dependent host scalars
+    and a captured training step can be replayed (`GraphedTrainStep`); `set_lr` is the schedule's hook."""
 
     def __init__(self, engine: Engine, params: FlatBucket, grads: FlatBucket, lr: float = 5e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2):
         if params.numel != grads.numel:
             raise ValueError("parameter and gradient buckets differ in size")
         self.engine, self.params, self.grads = engine, params, grads
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(params.flat)
         self.exp_avg_sq = torch.zeros_like(params.flat)
-        self.t = 0
+        self.state = torch.tensor([self.lr, 0.0], dtype=torch.float32, device=engine.device)   # lr, update count
+
+    @property
+    def t(self) -> int:
+        return int(self.state[1].item())
+
+    def set_lr(self, lr: float):
+        """Not capturable (host -> device copy): call it between replays, like StepLR.step() between epochs."""
+        if float(lr) != self.lr:
+            self.lr = float(lr)
+            self.state[0:1].copy_(torch.tensor([self.lr], dtype=torch.float32))
 
     def step(self, lr: Optional[float] = None):
         eng = self.engine
-        self.t += 1
+        if lr is not None:
+            self.set_lr(lr)
         p, g = eng._in(self.params.flat, "params"), eng._in(self.grads.flat, "grads")
         with torch.cuda.device(eng.device):
-            check(eng._h, eng.lib.cmgan_adamw_step(eng._h, p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
-                                                   self.exp_avg_sq.data_ptr(), self.params.numel,
-                                                   float(self.lr if lr is None else lr), float(self.betas[0]),
-                                                   float(self.betas[1]), float(self.eps), float(self.weight_decay),
-                                                   self.t, eng._stream()))
+            check(eng._h, eng.lib.cmgan_adamw_step_dev(eng._h, p.data_ptr(), g.data_ptr(), self.exp_avg.data_ptr(),
+                                                       self.exp_avg_sq.data_ptr(), self.params.numel,
+                                                       self.state.data_ptr(), float(self.betas[0]), float(self.betas[1]),
+                                                       float(self.eps), float(self.weight_decay), eng._stream()))
 
 
 @torch.no_grad()
@@ -823,7 +847,27 @@ class GeneratorTrain:
     def masks(self, B: int, T: int, generator: Optional[torch.Generator] = None):
         """Keep-masks of every Dropout of the four TSCBs for a [B, 2, T, F] input: [(time, freq)] * 4."""
         Fe = (self.engine.cfg.num_features - 1) // 2 + 1
-        return [blk.masks(B, T, Fe, generator) for blk in self.blocks]
+        ps = {m.p for blk in self.blocks for c in (blk.time, blk.freq) for m in (c.ff1, c.attn, c.ff2)}
+        if len(ps) != 1 or next(iter(ps)) <= 0.0:
+            return [blk.masks(B, T, Fe, generator) for blk in self.blocks]
+        # all forty masks from ONE uniform draw (three launches instead of 160): views of a single buffer
+        p = next(iter(ps))
+        widths = (("ff1_1", 256), ("ff1_2", 64), ("attn", 64), ("ff2_1", 256), ("ff2_2", 64))
+        tokens = B * T * Fe
+        per_axis = tokens * sum(w for _, w in widths)
+        buf = torch.rand(len(self.blocks) * 2 * per_axis, device=self.engine.device, generator=generator)
+        buf.ge_(p).mul_(1.0 / (1.0 - p))
+        out, off = [], 0
+        for _ in self.blocks:
+            pair = []
+            for n, l in ((B * Fe, T), (B * T, Fe)):
+                d = {}
+                for name, w in widths:
+                    d[name] = buf[off:off + tokens * w].view(n, l, w)
+                    off += tokens * w
+                pair.append(d)
+            out.append(tuple(pair))
+        return out
 
     def forward(self, spec: torch.Tensor, masks=None) -> Tuple[torch.Tensor, torch.Tensor]:
         eng = self.engine
@@ -1114,3 +1158,76 @@ def adversarial_train_step(gen: GeneratorTrain, disc: DiscriminatorTrain, opt_g:
         disc.allreduce_gradients()
         opt_d.step(None if lr is None else 2.0 * lr)                          # train.py:64-66: twice the generator's rate
     return loss, terms, gan, loss_d
+
+
+class GraphedTrainStep:
+    """A training step captured once as hipGraphs and replayed: the eager step is bound by its ~1 500 kernel launches
+    (62 of 72 ms at batch 4 are spent enqueueing), a replay by the kernels.
+
+    Two graphs per step with the gradient all-reduce between them, so that the collective stays an ordinary
+    `torch.distributed` call: (A) STFTs, train-mode forward, losses, backward [+ the discriminator passes], (B) the
+    AdamW launches.  Inputs are copied into static buffers; dropout masks are drawn INSIDE graph A from torch's default
+    CUDA generator (graph-safe Philox offsets), so every replay sees fresh masks.  `dropout=False` captures the step
+    without dropout (deterministic: used by the parity test against the eager step).  With a discriminator the step is
+    `adversarial_train_step` and needs PESQ labels at every call."""
+
+    def __init__(self, gen: GeneratorTrain, opt_g: AdamW, batch: int, length: int, disc: Optional[DiscriminatorTrain] = None,
+                 opt_d: Optional[AdamW] = None, loss_weights=(0.1, 0.9, 0.2, 0.05), dropout: bool = True):
+        if (disc is None) != (opt_d is None):
+            raise ValueError("pass both the discriminator and its optimiser, or neither")
+        self.gen, self.disc, self.opt_g, self.opt_d = gen, disc, opt_g, opt_d
+        eng = gen.engine
+        dev = eng.device
+        self.clean = torch.zeros(batch, length, dtype=torch.float32, device=dev)
+        self.noisy = torch.ones(batch, length, dtype=torch.float32, device=dev)       # non-zero: the RMS scale divides
+        self.pesq = torch.full((batch,), 0.5, dtype=torch.float32, device=dev) if disc is not None else None
+        w3 = tuple(float(x) for x in loss_weights[:3])
+        _loss_w(w3, dev)                                                # host -> device copies happen before capture
+        self._convs = [c.conv for blk in gen.blocks for c in (blk.time, blk.freq)]
+        masks = "draw" if dropout else None
+        torch.cuda.synchronize(dev)
+        self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        opts = [o for o in (opt_g, opt_d) if o is not None]
+        real_steps = [o.step for o in opts]
+        try:
+            for o in opts:
+                o.step = lambda lr=None: None                           # graph A ends where the optimisers would run
+            reduce_g, gen.allreduce_gradients = gen.allreduce_gradients, (lambda: None)
+            reduce_d = None
+            if disc is not None:
+                reduce_d, disc.allreduce_gradients = disc.allreduce_gradients, (lambda: None)
+            with torch.cuda.graph(self.graph_a):
+                if disc is None:
+                    self.out = generator_train_step(gen, opt_g, self.clean, self.noisy, w3, masks=masks)
+                else:
+                    self.out = adversarial_train_step(gen, disc, opt_g, opt_d, self.clean, self.noisy, self.pesq,
+                                                      loss_weights, masks=masks, disc_masks=masks)
+        finally:
+            for o, f in zip(opts, real_steps):
+                o.step = f
+            gen.allreduce_gradients = reduce_g
+            if disc is not None:
+                disc.allreduce_gradients = reduce_d
+        with torch.cuda.graph(self.graph_b):
+            for o in opts:
+                o.step()
+        # capturing executes nothing: the BatchNorm update counters advanced by the traced forward are rolled back
+        for c in self._convs:
+            c.num_batches_tracked -= 1
+
+    def __call__(self, clean: torch.Tensor, noisy: torch.Tensor, pesq_score: Optional[torch.Tensor] = None):
+        self.clean.copy_(clean)
+        self.noisy.copy_(noisy)
+        if self.disc is not None:
+            if pesq_score is None:
+                raise ValueError("the captured adversarial step needs PESQ labels; use adversarial_train_step for a "
+                                 "batch whose PESQ failed")
+            self.pesq.copy_(pesq_score)
+        self.graph_a.replay()
+        for c in self._convs:
+            c.num_batches_tracked += 1
+        self.gen.allreduce_gradients()
+        if self.disc is not None:
+            self.disc.allreduce_gradients()
+        self.graph_b.replay()
+        return self.out

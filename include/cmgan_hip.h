@@ -362,6 +362,14 @@ int cmgan_adamw_step(cmgan_handle* h, float* params_dev, const float* grads_dev,
                      float* exp_avg_sq_dev, long long n, float lr, float beta1, float beta2, float eps,
                      float weight_decay, int step, void* stream);
 
+/* The same update with the optimiser's scalars in device memory: state_dev[0] = learning rate, state_dev[1] = update
+ * count (a float, advanced by one by this call before it is used for the bias corrections).  Nothing in the launch
+ * depends on host values that change from step to step, so it can be captured in a hipGraph and replayed; a learning
+ * rate schedule writes state_dev[0] between replays.                                                               */
+int cmgan_adamw_step_dev(cmgan_handle* h, float* params_dev, const float* grads_dev, float* exp_avg_dev,
+                         float* exp_avg_sq_dev, long long n, float* state_dev, float beta1, float beta2, float eps,
+                         float weight_decay, void* stream);
+
 /* utils.power_compress (src/utils.py:20-29): x[B,F,T,2] -> y[B,2,F,T].          */
 int cmgan_power_compress(cmgan_handle* h, const float* x_dev, int B, int F, int T,
                          float* y_dev, void* stream);

@@ -704,3 +704,41 @@ def test_full_loss_gradient_at_the_network_output_vs_oracle_autograd():
     assert _report("full-loss d_imag vs oracle autograd", rel_err(d_imag, want["d_imag"])) < GRAD_TOL
     for k, v in disc.buffers.items():
         assert rel_err(v, want["disc_buffers"][k]) < GRAD_TOL, k
+
+
+def test_graphed_train_step_is_bit_identical_to_the_eager_step():
+    """The adversarial step captured as two hipGraphs (forward/backward, optimisers; device-resident AdamW step count)
+    and replayed twice leaves exactly the parameters the eager step leaves (dropout off so that both see the same
+    arithmetic), and the BatchNorm counters advance per replay."""
+    from cmgan_amd.synth import discriminator_state_dict, synthetic_clips
+    from cmgan_amd.training import (AdamW, DiscriminatorTrain, GeneratorTrain, GraphedTrainStep,
+                                    adversarial_train_step)
+    from oracle.weights import make_state_dict
+    sd, dsd = make_state_dict(seed=0), discriminator_state_dict(0)
+    B, L = 2, 3200
+    clean = synthetic_clips(B, L, seed=5).to(DEV)
+    noisy = (clean + 0.3 * synthetic_clips(B, L, seed=6).to(DEV)).contiguous()
+    pesq = torch.tensor([0.4, 0.7], device=DEV)
+
+    def fresh():
+        gen = GeneratorTrain(sd, device=DEV)
+        disc = DiscriminatorTrain(dsd, engine=gen.engine)
+        return (gen, disc, AdamW(gen.engine, gen.param_bucket, gen.grad_bucket, lr=5e-4),
+                AdamW(gen.engine, disc.param_bucket, disc.grad_bucket, lr=1e-3))
+    gen, disc, og, od = fresh()
+    for _ in range(2):
+        want = adversarial_train_step(gen, disc, og, od, clean, noisy, pesq, masks=None, disc_masks=None)
+    gen2, disc2, og2, od2 = fresh()
+    step = GraphedTrainStep(gen2, og2, B, L, disc2, od2, dropout=False)
+    assert og2.t == 0 and gen2.blocks[0].time.conv.num_batches_tracked == 100     # capturing executed nothing
+    for _ in range(2):
+        got = step(clean, noisy, pesq)
+    assert torch.equal(gen.param_bucket.flat, gen2.param_bucket.flat)
+    assert torch.equal(disc.param_bucket.flat, disc2.param_bucket.flat)
+    assert float(want[0]) == float(got[0]) and float(want[3]) == float(got[3])
+    assert og2.t == 2 and od2.t == 2 and gen2.blocks[3].freq.conv.num_batches_tracked == 102
+    # masks drawn inside the graph differ from replay to replay
+    step_d = GraphedTrainStep(gen2, og2, B, L, disc2, od2)
+    l1 = float(step_d(clean, noisy, pesq)[0])
+    l2 = float(step_d(clean, noisy, pesq)[0])
+    assert l1 != l2
