@@ -974,10 +974,16 @@ __device__ __forceinline__ void at_stage_rel(float* lds, const float* __restrict
     }
 }
 __device__ __forceinline__ float at_dot16(const float (&a)[16], const float* __restrict__ b) {
-    float s = 0.f;
+    // four independent chains: a single 16-deep fmaf chain per score was the critical path of every core kernel
+    float s0 = a[0] * b[0], s1 = a[1] * b[1], s2 = a[2] * b[2], s3 = a[3] * b[3];
 #pragma unroll
-    for (int d = 0; d < 16; ++d) s = fmaf(a[d], b[d], s);
-    return s;
+    for (int d = 4; d < 16; d += 4) {
+        s0 = fmaf(a[d], b[d], s0);
+        s1 = fmaf(a[d + 1], b[d + 1], s1);
+        s2 = fmaf(a[d + 2], b[d + 2], s2);
+        s3 = fmaf(a[d + 3], b[d + 3], s3);
+    }
+    return (s0 + s1) + (s2 + s3);
 }
 
 // Work split of the four core kernels: a block owns one (sequence, head); its threads are QPB x KS with QPB = L rounded

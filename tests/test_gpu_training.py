@@ -742,3 +742,47 @@ def test_graphed_train_step_is_bit_identical_to_the_eager_step():
     l1 = float(step_d(clean, noisy, pesq)[0])
     l2 = float(step_d(clean, noisy, pesq)[0])
     assert l1 != l2
+
+
+def test_generator_train_step_at_48_khz_vs_oracle_autograd():
+    """BASELINE configs[3] shape for the training path: n_fft 1200 / hop 300 (F = 601, F' = 301), one clip of 8 hops:
+    outputs, loss terms, the output gradients incl. the ISTFT adjoint at N = 1200, and all parameter gradients against
+    autograd through the oracle (dropout masks fixed)."""
+    from cmgan_amd.engine import Engine
+    from cmgan_amd.synth import synthetic_clips, synthetic_dropout_masks
+    from cmgan_amd.training import AdamW, GeneratorTrain, generator_train_step
+    from oracle.weights import make_state_dict
+    sd = make_state_dict(seed=0, num_features=601)
+    B, L = 1, 2400
+    T, Fe = L // 300 + 1, 301
+    clean = synthetic_clips(B, L, seed=61)
+    noisy = clean + 0.3 * synthetic_clips(B, L, seed=62)
+    npm = synthetic_dropout_masks(81, B, T, Fe)
+    want = O.generator_step_gradients(
+        sd, clean, noisy, [tuple({k: torch.from_numpy(v) for k, v in d.items()} for d in pair) for pair in npm],
+        n_fft=1200, hop=300)
+    gen = GeneratorTrain(sd, engine=Engine(n_fft=1200, hop=300, device=DEV))
+    opt = AdamW(gen.engine, gen.param_bucket, gen.grad_bucket, lr=5e-4)
+    masks = [tuple({k: torch.from_numpy(v).to(DEV) for k, v in d.items()} for d in pair) for pair in npm]
+    eng = gen.engine
+    nz = noisy.to(DEV)
+    er, ei = gen.forward(eng.stft_compress(nz, eng.rms_scale(nz)), masks)
+    assert _report("48 kHz train forward est_real", rel_err(er, want["est_real"])) < GRAD_TOL
+    assert _report("48 kHz train forward est_imag", rel_err(ei, want["est_imag"])) < GRAD_TOL
+    gen2 = GeneratorTrain(sd, engine=eng)
+    opt = AdamW(eng, gen2.param_bucket, gen2.grad_bucket, lr=5e-4)
+    loss, terms = generator_train_step(gen2, opt, clean.to(DEV), nz, masks=masks)
+    assert _report("48 kHz loss", abs(float(loss) - float(want["loss"])) / float(want["loss"])) < GRAD_TOL
+    assert _report("48 kHz loss terms", rel_err(terms[:3], want["terms"])) < GRAD_TOL
+    scale = max(float(v.abs().max()) for v in want["grads"].values())
+    groups = {}
+    for k, v in want["grads"].items():
+        den = float(v.abs().max())
+        if den > 1e-6 * scale:
+            e = float((gen2.grads[k].cpu() - v).abs().max()) / den
+            assert e < 3e-2, (k, e)
+            groups.setdefault(k.split(".")[0], []).append(e)
+    for name, v in groups.items():
+        _report(f"48 kHz gradient error, median over the tensors of {name}", float(np.median(v)))
+    allv = [e for v in groups.values() for e in v]
+    assert float(np.median(allv)) < 2e-3 and min(float(np.median(v)) for v in groups.values()) < 2e-5
