@@ -1006,35 +1006,39 @@ static size_t at_lds_bytes(size_t staged_floats, const AtSplit& sp, int width) {
     return (staged_floats > merge ? staged_floats : merge) * sizeof(float);
 }
 
-// forward core: online softmax over this thread's keys, then a log-sum-exp merge of the KS partial rows
+// forward core: online softmax over this thread's keys, then a log-sum-exp merge of the KS partial rows.
+// K and V rows are the same for every lane of a wave (the key index depends only on the wave's ks), so they are read
+// through wave-uniform addresses (scalar loads, operands straight from SGPRs) instead of 32 broadcast LDS reads per
+// step: the LDS pipe, which bounded these kernels, only serves the per-lane relative-position rows.
 __global__ __launch_bounds__(1024) void at_core_fwd_kernel(AtBufs b, const float* __restrict__ rel, int L, int max_pos,
                                                            int qpb) {
     extern __shared__ float sm[];
-    float* K = sm;                        // [L][AT_P]
-    float* V = K + L * AT_P;
-    float* E = V + L * AT_P;              // [2L-1][AT_P]
+    float* E = sm;                        // [2L-1][AT_P]
+    const float* __restrict__ qkv = b.qkv;
     const int n = blockIdx.x, h = blockIdx.y;
     const long base = (long)n * L;
-    const int iq = threadIdx.x % qpb, ks = threadIdx.x / qpb, KS = blockDim.x / qpb;
-    at_stage(K, b.qkv, 192, 64 + 16 * h, base, L);
-    at_stage(V, b.qkv, 192, 128 + 16 * h, base, L);
+    const int iq = threadIdx.x % qpb;
+    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x / qpb), KS = blockDim.x / qpb;     // wave-uniform
     at_stage_rel(E, rel, L, max_pos);
     __syncthreads();
     const bool act = iq < L;
     const int i = act ? iq : L - 1;
     float q[16], o[16];
 #pragma unroll
-    for (int d = 0; d < 16; ++d) { q[d] = b.qkv[(base + i) * 192 + 16 * h + d] * 0.25f; o[d] = 0.f; }     // scale = 16^-0.5
+    for (int d = 0; d < 16; ++d) { q[d] = qkv[(base + i) * 192 + 16 * h + d] * 0.25f; o[d] = 0.f; }     // scale = 16^-0.5
     float m = -1e30f, l = 0.f;
+#pragma unroll 2                          // two steps' scalar loads in flight (measured: 325 -> 285 us)
     for (int j = ks; j < L; j += KS) {
-        const float sc = at_dot16(q, K + j * AT_P) + at_dot16(q, E + (i - j + L - 1) * AT_P);
+        const float* __restrict__ kr = qkv + (base + j) * 192 + 64 + 16 * h;      // uniform
+        const float* __restrict__ vr = kr + 64;
+        const float sc = at_dot16(q, kr) + at_dot16(q, E + (i - j + L - 1) * AT_P);
         const float mn = fmaxf(m, sc), c = __expf(m - mn), pj = __expf(sc - mn);
         l = fmaf(l, c, pj);
 #pragma unroll
-        for (int d = 0; d < 16; ++d) o[d] = fmaf(o[d], c, pj * V[j * AT_P + d]);
+        for (int d = 0; d < 16; ++d) o[d] = fmaf(o[d], c, pj * vr[d]);
         m = mn;
     }
-    __syncthreads();                      // K / V / E are dead: reuse as the merge buffer [(KS-1)][qpb][18]
+    __syncthreads();                      // E is dead: reuse as the merge buffer [(KS-1)][qpb][18]
     if (ks > 0) {
         float* w = sm + ((long)(ks - 1) * qpb + iq) * 18;
         w[0] = m; w[1] = l;
@@ -1113,14 +1117,22 @@ __global__ __launch_bounds__(256) void at_out_bwd_kernel(const float* __restrict
     }
 }
 
-// p_ij and ds_ij of one (query i, key j) pair from staged operands; scores are recomputed, never stored
+// p_ij and ds_ij of one (query i, key j) pair; scores are recomputed, never stored.  q is the RAW query row (the
+// 16^-0.5 scale is applied to the score), so that rows can come straight from wave-uniform scalar loads.
 struct AtPair { float p, ds; };
-__device__ __forceinline__ AtPair at_pair(const float (&qs)[16], const float* __restrict__ kj, const float* __restrict__ er,
-                                          const float (&dOi)[16], const float* __restrict__ vj, float lse, float Di) {
-    const float s = at_dot16(qs, kj) + at_dot16(qs, er);            // qs = q * scale
+__device__ __forceinline__ AtPair at_pair(const float* __restrict__ q, const float* __restrict__ kj, const float* __restrict__ er,
+                                          const float* __restrict__ dOi, const float* __restrict__ vj, float lse, float Di) {
+    float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 16; d += 2) {
+        s0 = fmaf(q[d], kj[d] + er[d], s0);
+        s1 = fmaf(q[d + 1], kj[d + 1] + er[d + 1], s1);
+        t0 = fmaf(dOi[d], vj[d], t0);
+        t1 = fmaf(dOi[d + 1], vj[d + 1], t1);
+    }
     AtPair r;
-    r.p = __expf(s - lse);
-    r.ds = r.p * (at_dot16(dOi, vj) - Di);
+    r.p = __expf((s0 + s1) * 0.25f - lse);
+    r.ds = r.p * ((t0 + t1) - Di);
     return r;
 }
 
@@ -1143,36 +1155,38 @@ __device__ __forceinline__ void at_merge_sum(float* sm, float (&acc)[W], int iq,
     }
 }
 
+// In the three backward cores the operands of the reduction axis (the key row in dq; the query row, its dO row, lse
+// and D in dk / dv and dE) are wave-uniform and come from scalar loads; LDS holds only what differs per lane.
+
 // dq: thread (query i, key subset)             dq_i = scale * sum_j ds_ij (k_j + E[i - j])
 __global__ __launch_bounds__(1024) void at_core_bwd_dq_kernel(AtBufs b, const float* __restrict__ rel,
                                                               const float* __restrict__ dO, const float* __restrict__ D,
                                                               int L, int max_pos, int qpb, float* __restrict__ dqkv) {
     extern __shared__ float sm[];
-    float* K = sm;
-    float* V = K + L * AT_P;
-    float* E = V + L * AT_P;
+    float* E = sm;
+    const float* __restrict__ qkv = b.qkv;
     const int n = blockIdx.x, h = blockIdx.y;
     const long base = (long)n * L;
-    const int iq = threadIdx.x % qpb, ks = threadIdx.x / qpb, KS = blockDim.x / qpb;
-    at_stage(K, b.qkv, 192, 64 + 16 * h, base, L);
-    at_stage(V, b.qkv, 192, 128 + 16 * h, base, L);
+    const int iq = threadIdx.x % qpb;
+    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x / qpb), KS = blockDim.x / qpb;
     at_stage_rel(E, rel, L, max_pos);
     __syncthreads();
     const bool act = iq < L;
     const int i = act ? iq : L - 1;
-    float qs[16], dOi[16], dq[16];
+    float q[16], dOi[16], dq[16];
 #pragma unroll
     for (int d = 0; d < 16; ++d) {
-        qs[d] = b.qkv[(base + i) * 192 + 16 * h + d] * 0.25f;
+        q[d] = qkv[(base + i) * 192 + 16 * h + d];
         dOi[d] = dO[(base + i) * 64 + 16 * h + d];
         dq[d] = 0.f;
     }
     const float lse = b.lse[((long)n * 4 + h) * L + i], Di = D[(base + i) * 4 + h];
     for (int j = ks; j < L; j += KS) {
+        const float* __restrict__ kr = qkv + (base + j) * 192 + 64 + 16 * h;      // uniform
         const float* er = E + (i - j + L - 1) * AT_P;
-        const AtPair pr = at_pair(qs, K + j * AT_P, er, dOi, V + j * AT_P, lse, Di);
+        const AtPair pr = at_pair(q, kr, er, dOi, kr + 64, lse, Di);
 #pragma unroll
-        for (int d = 0; d < 16; ++d) dq[d] = fmaf(pr.ds, K[j * AT_P + d] + er[d], dq[d]);
+        for (int d = 0; d < 16; ++d) dq[d] = fmaf(pr.ds, kr[d] + er[d], dq[d]);
     }
     at_merge_sum<16>(sm, dq, iq, ks, KS, qpb);
     if (ks == 0 && act) {
@@ -1186,49 +1200,40 @@ __global__ __launch_bounds__(1024) void at_core_bwd_dkv_kernel(AtBufs b, const f
                                                                const float* __restrict__ dO, const float* __restrict__ D,
                                                                int L, int max_pos, int qpb, float* __restrict__ dqkv) {
     extern __shared__ float sm[];
-    float* Q = sm;                         // q * scale
-    float* G = Q + L * AT_P;               // dO
-    float* E = G + L * AT_P;
-    float* lse = E + (2 * L - 1) * AT_P;
-    float* Dl = lse + L;
+    float* E = sm;
+    const float* __restrict__ qkv = b.qkv;
+    const float* __restrict__ lse = b.lse + ((long)blockIdx.x * 4 + blockIdx.y) * L;
     const int n = blockIdx.x, h = blockIdx.y;
     const long base = (long)n * L;
-    const int jq = threadIdx.x % qpb, ks = threadIdx.x / qpb, KS = blockDim.x / qpb;
-    at_stage(Q, b.qkv, 192, 16 * h, base, L);
-    at_stage(G, dO, 64, 16 * h, base, L);
+    const int jq = threadIdx.x % qpb;
+    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x / qpb), KS = blockDim.x / qpb;
     at_stage_rel(E, rel, L, max_pos);
-    for (int i = threadIdx.x; i < L; i += blockDim.x) {
-        lse[i] = b.lse[((long)n * 4 + h) * L + i];
-        Dl[i] = D[(base + i) * 4 + h];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < L * 16; i += blockDim.x) Q[(i >> 4) * AT_P + (i & 15)] *= 0.25f;
     __syncthreads();
     const bool act = jq < L;
     const int j = act ? jq : L - 1;
     float kj[16], vj[16], acc[32];         // acc = dk | dv
 #pragma unroll
     for (int d = 0; d < 16; ++d) {
-        kj[d] = b.qkv[(base + j) * 192 + 64 + 16 * h + d];
-        vj[d] = b.qkv[(base + j) * 192 + 128 + 16 * h + d];
+        kj[d] = qkv[(base + j) * 192 + 64 + 16 * h + d];
+        vj[d] = qkv[(base + j) * 192 + 128 + 16 * h + d];
         acc[d] = 0.f; acc[16 + d] = 0.f;
     }
+#pragma unroll 2
     for (int i = ks; i < L; i += KS) {
-        float qs[16], dOi[16];
-#pragma unroll
-        for (int d = 0; d < 16; ++d) { qs[d] = Q[i * AT_P + d]; dOi[d] = G[i * AT_P + d]; }
-        const AtPair pr = at_pair(qs, kj, E + (i - j + L - 1) * AT_P, dOi, vj, lse[i], Dl[i]);
+        const float* __restrict__ qr = qkv + (base + i) * 192 + 16 * h;           // uniform
+        const float* __restrict__ gr = dO + (base + i) * 64 + 16 * h;             // uniform
+        const AtPair pr = at_pair(qr, kj, E + (i - j + L - 1) * AT_P, gr, vj, lse[i], D[(base + i) * 4 + h]);
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
-            acc[d] = fmaf(pr.ds, qs[d], acc[d]);                  // qs already carries one factor of scale
-            acc[16 + d] = fmaf(pr.p, dOi[d], acc[16 + d]);
+            acc[d] = fmaf(pr.ds, qr[d], acc[d]);
+            acc[16 + d] = fmaf(pr.p, gr[d], acc[16 + d]);
         }
     }
     at_merge_sum<32>(sm, acc, jq, ks, KS, qpb);
     if (ks == 0 && act) {
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
-            dqkv[(base + j) * 192 + 64 + 16 * h + d] = acc[d];
+            dqkv[(base + j) * 192 + 64 + 16 * h + d] = acc[d] * 0.25f;
             dqkv[(base + j) * 192 + 128 + 16 * h + d] = acc[16 + d];
         }
     }
@@ -1240,25 +1245,16 @@ __global__ __launch_bounds__(1024) void at_core_bwd_de_kernel(AtBufs b, const fl
                                                               const float* __restrict__ dO, const float* __restrict__ D,
                                                               int L, int max_pos, int qpb, float* __restrict__ partial) {
     extern __shared__ float sm[];
-    float* Q = sm;                         // q * scale
-    float* G = Q + L * AT_P;
-    float* K = G + L * AT_P;
+    float* K = sm;
     float* V = K + L * AT_P;
-    float* lse = V + L * AT_P;
-    float* Dl = lse + L;
+    const float* __restrict__ qkv = b.qkv;
+    const float* __restrict__ lse = b.lse + ((long)blockIdx.x * 4 + blockIdx.y) * L;
     const int n = blockIdx.x, h = blockIdx.y;
     const long base = (long)n * L;
-    const int rq = threadIdx.x % qpb, ks = threadIdx.x / qpb, KS = blockDim.x / qpb;      // here qpb >= 2 L - 1
-    at_stage(Q, b.qkv, 192, 16 * h, base, L);
+    const int rq = threadIdx.x % qpb;                             // here qpb >= 2 L - 1
+    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x / qpb), KS = blockDim.x / qpb;
     at_stage(K, b.qkv, 192, 64 + 16 * h, base, L);
     at_stage(V, b.qkv, 192, 128 + 16 * h, base, L);
-    at_stage(G, dO, 64, 16 * h, base, L);
-    for (int i = threadIdx.x; i < L; i += blockDim.x) {
-        lse[i] = b.lse[((long)n * 4 + h) * L + i];
-        Dl[i] = D[(base + i) * 4 + h];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < L * 16; i += blockDim.x) Q[(i >> 4) * AT_P + (i & 15)] *= 0.25f;
     __syncthreads();
     const bool act = rq < 2 * L - 1;
     const int r = act ? rq : 2 * L - 2;
@@ -1267,20 +1263,26 @@ __global__ __launch_bounds__(1024) void at_core_bwd_de_kernel(AtBufs b, const fl
     float er[16], acc[16];
 #pragma unroll
     for (int d = 0; d < 16; ++d) { er[d] = rel[(long)(e + max_pos) * 16 + d]; acc[d] = 0.f; }
-    const int i0 = dist > 0 ? dist : 0, i1 = dist > 0 ? L : L + dist;     // j = i - dist in [0, L)
-    for (int i = i0 + ks; i < i1; i += KS) {
+    // the loop is wave-uniform (the query rows are scalar operands) over the union of the wave's 64 consecutive
+    // diagonals' query ranges; pairs outside a lane's own diagonal contribute nothing
+    const int r_lo = __builtin_amdgcn_readfirstlane(rq);                          // the wave's first distance row
+    const int d_lo = r_lo - (L - 1), d_hi = (r_lo + 63 < 2 * L - 2 ? r_lo + 63 : 2 * L - 2) - (L - 1);
+    const int i_begin = d_lo > 0 ? d_lo : 0, i_end = d_hi < 0 ? L + d_hi : L;
+    for (int i = i_begin + ks; i < i_end; i += KS) {
         const int j = i - dist;
-        float qs[16], dOi[16];
+        const bool in = j >= 0 && j < L;
+        const int jc = in ? j : 0;
+        const float* __restrict__ qr = qkv + (base + i) * 192 + 16 * h;           // uniform
+        const float* __restrict__ gr = dO + (base + i) * 64 + 16 * h;             // uniform
+        const AtPair pr = at_pair(qr, K + jc * AT_P, er, gr, V + jc * AT_P, lse[i], D[(base + i) * 4 + h]);
+        const float ds = in ? pr.ds : 0.f;
 #pragma unroll
-        for (int d = 0; d < 16; ++d) { qs[d] = Q[i * AT_P + d]; dOi[d] = G[i * AT_P + d]; }
-        const AtPair pr = at_pair(qs, K + j * AT_P, er, dOi, V + j * AT_P, lse[i], Dl[i]);
-#pragma unroll
-        for (int d = 0; d < 16; ++d) acc[d] = fmaf(pr.ds, qs[d], acc[d]);
+        for (int d = 0; d < 16; ++d) acc[d] = fmaf(ds, qr[d], acc[d]);
     }
     at_merge_sum<16>(sm, acc, rq, ks, KS, qpb);
     if (ks == 0 && act) {
 #pragma unroll
-        for (int d = 0; d < 16; ++d) partial[(((long)n * 4 + h) * (2 * L - 1) + r) * 16 + d] = acc[d];
+        for (int d = 0; d < 16; ++d) partial[(((long)n * 4 + h) * (2 * L - 1) + r) * 16 + d] = acc[d] * 0.25f;
     }
 }
 
@@ -1402,7 +1404,7 @@ void launch_attn_train_forward(LaunchCtx ctx, const float* x, int N, int L, cons
     const unsigned grid = (unsigned)((M + 63) / 64);
     LAUNCH(ctx, "attn_train_fwd", (at_qkv_kernel<<<grid, 256, 0, s>>>(x, M, ws + pl.wqkv, p.ln_w, p.ln_b, b.qkv)));
     const AtSplit sp = at_split(L);
-    const size_t shm = at_lds_bytes((size_t)2 * L * AT_P + (size_t)(2 * L - 1) * AT_P, sp, 18);
+    const size_t shm = at_lds_bytes((size_t)(2 * L - 1) * AT_P, sp, 18);
     at_allow_lds(at_core_fwd_kernel, shm);
     LAUNCH(ctx, "attn_train_fwd", (at_core_fwd_kernel<<<dim3(N, 4), sp.qpb * sp.ks, shm, s>>>(b, p.rel, L, max_pos, sp.qpb)));
     LAUNCH(ctx, "attn_train_fwd", (at_out_kernel<<<grid, 256, 0, s>>>(b.o, M, ws + pl.wo, p.bo, mask, y)));
@@ -1431,10 +1433,10 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     colsum(ws + pl.dout, 64, grad.bo);
     // attention core: dq (rows), dk / dv (columns), dE (distances)
     const AtSplit sp = at_split(L), spe = at_split(2 * L - 1);
-    const size_t staged = (size_t)2 * L * AT_P + (size_t)(2 * L - 1) * AT_P;
-    const size_t shm_q = at_lds_bytes(staged, sp, 16);
-    const size_t shm_kv = at_lds_bytes(staged + 2 * L, sp, 32);
-    const size_t shm_e = at_lds_bytes((size_t)4 * L * AT_P + 2 * L, spe, 16);
+    const size_t rel_rows = (size_t)(2 * L - 1) * AT_P;
+    const size_t shm_q = at_lds_bytes(rel_rows, sp, 16);
+    const size_t shm_kv = at_lds_bytes(rel_rows, sp, 32);
+    const size_t shm_e = at_lds_bytes((size_t)2 * L * AT_P, spe, 16);
     at_allow_lds(at_core_bwd_dq_kernel, shm_q);
     at_allow_lds(at_core_bwd_dkv_kernel, shm_kv);
     at_allow_lds(at_core_bwd_de_kernel, shm_e);
