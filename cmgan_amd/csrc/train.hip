@@ -1582,7 +1582,9 @@ void launch_swap_axes(LaunchCtx ctx, const float* in, float* out, int B, int A, 
 // its backward sums are per-(clip, channel) two-pass reductions in fp64.  A conv bias in front of an InstanceNorm
 // has an exactly zero gradient; it is still computed (column sum of dz) so that the ten "bias" tensors are written.
 // =====================================================================================
-#define DB_NCH 32                      // position chunks per clip of the per-(b, c) reductions
+#define DB_NCH 256                     // position chunks per clip of the per-(b, c) reductions: B x 256 blocks fill the chip
+                                       // (32 chunks = 128 blocks at batch 4 ran these streaming sums at 0.2 TB/s)
+#define MT_NCH 32                      // the single-channel mask head's planes are 64 x smaller
 
 // strided fragment-major pack: out[rb][kb][lane][r] = w[row * rs + col * cs]  (row/col swapped when transpose)
 __global__ void pack_fm_strided_kernel(const float* __restrict__ w, int R, int K, long rs, long cs, int transpose,
@@ -1695,23 +1697,34 @@ __global__ __launch_bounds__(256) void db_sums_kernel(const float* __restrict__ 
     }
 }
 
-// forward statistics: mean, rstd per (b, c) from the chunk partials (fp64, chunk order)
-__global__ void db_stats_finalize_kernel(const float* __restrict__ partial, int B, double count, float* __restrict__ mean,
-                                         float* __restrict__ rstd) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * 64) return;
-    const int b = i >> 6, c = i & 63;
-    double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < DB_NCH; ++k) {
-        const long o = (((long)b * DB_NCH + k) * 64 + c) * 3;
-        s1 += (double)partial[o];
-        s2 += (double)partial[o + 1];
+// fp64 sum of up to 256 chunk partials per thread block: thread k holds chunk k, fixed-shape tree
+__device__ __forceinline__ double db_tree_sum(double v, double* red) {
+    const int t = threadIdx.x;
+    red[t] = v;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+        if (t < d) red[t] += red[t + d];
+        __syncthreads();
     }
-    const double mu = s1 / count;
-    double var = s2 / count - mu * mu;
-    var = var > 0.0 ? var : 0.0;
-    mean[i] = (float)mu;
-    rstd[i] = (float)(1.0 / sqrt(var + 1e-5));
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+// forward statistics: one block per (b, c) adds the DB_NCH chunk partials in fp64 -> mean, rstd
+__global__ __launch_bounds__(256) void db_stats_finalize_kernel(const float* __restrict__ partial, int B, double count,
+                                                                float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ double red[256];
+    const int i = blockIdx.x, b = i >> 6, c = i & 63, k = threadIdx.x;
+    const long o = (((long)b * DB_NCH + k) * 64 + c) * 3;
+    const double s1 = db_tree_sum(k < DB_NCH ? (double)partial[o] : 0.0, red);
+    const double s2 = db_tree_sum(k < DB_NCH ? (double)partial[o + 1] : 0.0, red);
+    if (k == 0) {
+        const double mu = s1 / count;
+        double var = s2 / count - mu * mu;
+        var = var > 0.0 ? var : 0.0;
+        mean[i] = (float)mu;
+        rstd[i] = (float)(1.0 / sqrt(var + 1e-5));
+    }
 }
 
 // a = PReLU(InstanceNorm(z))
@@ -1727,24 +1740,27 @@ __global__ __launch_bounds__(256) void db_norm_prelu_kernel(const float* __restr
     }
 }
 
-// backward means per (b, c) and the per-channel parameter gradients (summed over clips in clip order)
-__global__ void db_bwd_finalize_kernel(const float* __restrict__ partial, int B, double count, float* __restrict__ m1,
-                                       float* __restrict__ m2, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ dalpha) {
-    const int c = threadIdx.x;
-    if (c >= 64) return;
+// backward means per (b, c) and the per-channel parameter gradients (summed over clips in clip order): one block per
+// channel, the chunk partials of each clip added by the fp64 tree
+__global__ __launch_bounds__(256) void db_bwd_finalize_kernel(const float* __restrict__ partial, int B, double count,
+                                                              float* __restrict__ m1, float* __restrict__ m2,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ dalpha) {
+    __shared__ double red[256];
+    const int c = blockIdx.x, k = threadIdx.x;
     double g = 0.0, bsum = 0.0, a = 0.0;
     for (int b = 0; b < B; ++b) {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < DB_NCH; ++k) {
-            const long o = (((long)b * DB_NCH + k) * 64 + c) * 3;
-            s0 += (double)partial[o]; s1 += (double)partial[o + 1]; s2 += (double)partial[o + 2];
+        const long o = (((long)b * DB_NCH + k) * 64 + c) * 3;
+        const double s0 = db_tree_sum(k < DB_NCH ? (double)partial[o] : 0.0, red);
+        const double s1 = db_tree_sum(k < DB_NCH ? (double)partial[o + 1] : 0.0, red);
+        const double s2 = db_tree_sum(k < DB_NCH ? (double)partial[o + 2] : 0.0, red);
+        if (k == 0) {
+            m1[b * 64 + c] = (float)(s0 / count);
+            m2[b * 64 + c] = (float)(s1 / count);
         }
-        m1[b * 64 + c] = (float)(s0 / count);
-        m2[b * 64 + c] = (float)(s1 / count);
         bsum += s0; g += s1; a += s2;
     }
-    dgamma[c] = (float)g; dbeta[c] = (float)bsum; dalpha[c] = (float)a;
+    if (k == 0) { dgamma[c] = (float)g; dbeta[c] = (float)bsum; dalpha[c] = (float)a; }
 }
 
 // dz = gamma rstd (dn - mean(dn) - zhat mean(dn zhat)), in place on dn
@@ -1936,7 +1952,7 @@ void launch_dense_train_forward(LaunchCtx ctx, const float* x, int B, int T, int
         LAUNCH(ctx, "dense_train_fwd", (db_sums_kernel<0><<<dim3(B, DB_NCH), 256, 0, st>>>(z, nullptr, P, nullptr, nullptr,
                                                                                          nullptr, nullptr, nullptr,
                                                                                          ws + pl.part)));
-        LAUNCH(ctx, "dense_train_fwd", (db_stats_finalize_kernel<<<(B * 64 + 255) / 256, 256, 0, st>>>(ws + pl.part, B,
+        LAUNCH(ctx, "dense_train_fwd", (db_stats_finalize_kernel<<<B * 64, 256, 0, st>>>(ws + pl.part, B,
                                                                                                        (double)P, mean, rstd)));
         LAUNCH(ctx, "dense_train_fwd", (db_norm_prelu_kernel<<<2048, 256, 0, st>>>(z, M * 64, P, mean, rstd, p.norm_w[i],
                                                                                    p.norm_b[i], p.prelu_w[i], a)));
@@ -1964,7 +1980,7 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
         LAUNCH(ctx, "dense_train_bwd", (db_sums_kernel<1><<<dim3(B, DB_NCH), 256, 0, st>>>(z, g, P, mean, rstd, p.norm_w[i],
                                                                                          p.norm_b[i], p.prelu_w[i],
                                                                                          ws + pl.part)));
-        LAUNCH(ctx, "dense_train_bwd", (db_bwd_finalize_kernel<<<1, 64, 0, st>>>(ws + pl.part, B, (double)P, ws + pl.m1,
+        LAUNCH(ctx, "dense_train_bwd", (db_bwd_finalize_kernel<<<64, 256, 0, st>>>(ws + pl.part, B, (double)P, ws + pl.m1,
                                                                                 ws + pl.m2, grad.norm_w[i], grad.norm_b[i],
                                                                                 grad.prelu_w[i])));
         LAUNCH(ctx, "dense_train_bwd", (db_in_bwd_kernel<<<2048, 256, 0, st>>>(g, z, M * 64, P, mean, rstd, p.norm_w[i],
@@ -2195,7 +2211,7 @@ static void in_prelu_forward(LaunchCtx ctx, const float* z, int B, int P, const 
     hipStream_t st = ctx.stream;
     LAUNCH(ctx, "in_prelu_train", (db_sums_kernel<0><<<dim3(B, DB_NCH), 256, 0, st>>>(z, nullptr, P, nullptr, nullptr, nullptr,
                                                                                     nullptr, nullptr, part)));
-    LAUNCH(ctx, "in_prelu_train", (db_stats_finalize_kernel<<<(B * 64 + 255) / 256, 256, 0, st>>>(part, B, (double)P, mean, rstd)));
+    LAUNCH(ctx, "in_prelu_train", (db_stats_finalize_kernel<<<B * 64, 256, 0, st>>>(part, B, (double)P, mean, rstd)));
     LAUNCH(ctx, "in_prelu_train", (db_norm_prelu_kernel<<<2048, 256, 0, st>>>(z, (long)B * P * 64, P, mean, rstd, gamma, beta,
                                                                               alpha, a)));
 }
@@ -2206,7 +2222,7 @@ static void in_prelu_backward(LaunchCtx ctx, const float* z, float* g, int B, in
     hipStream_t st = ctx.stream;
     LAUNCH(ctx, "in_prelu_train", (db_sums_kernel<1><<<dim3(B, DB_NCH), 256, 0, st>>>(z, g, P, mean, rstd, gamma, beta, alpha,
                                                                                     part)));
-    LAUNCH(ctx, "in_prelu_train", (db_bwd_finalize_kernel<<<1, 64, 0, st>>>(part, B, (double)P, m1, m2, dgamma, dbeta, dalpha)));
+    LAUNCH(ctx, "in_prelu_train", (db_bwd_finalize_kernel<<<64, 256, 0, st>>>(part, B, (double)P, m1, m2, dgamma, dbeta, dalpha)));
     LAUNCH(ctx, "in_prelu_train", (db_in_bwd_kernel<<<2048, 256, 0, st>>>(g, z, (long)B * P * 64, P, mean, rstd, gamma, m1, m2)));
 }
 
@@ -2407,7 +2423,7 @@ struct MaskTailG { float *gamma, *beta, *alpha, *wf, *bf, *alphaf; };
 __global__ __launch_bounds__(256) void mt_stats_kernel(const float* __restrict__ t1, int P, float* __restrict__ partial) {
     __shared__ float red[256][2];
     const int b = blockIdx.x, chunk = blockIdx.y;
-    const int per = (P + DB_NCH - 1) / DB_NCH, p0 = chunk * per, p1 = p0 + per < P ? p0 + per : P;
+    const int per = (P + MT_NCH - 1) / MT_NCH, p0 = chunk * per, p1 = p0 + per < P ? p0 + per : P;
     float s0 = 0.f, s1 = 0.f;
     for (int p = p0 + threadIdx.x; p < p1; p += 256) { const float v = t1[(long)b * P + p]; s0 += v; s1 = fmaf(v, v, s1); }
     red[threadIdx.x][0] = s0; red[threadIdx.x][1] = s1;
@@ -2416,14 +2432,14 @@ __global__ __launch_bounds__(256) void mt_stats_kernel(const float* __restrict__
         if ((int)threadIdx.x < d) { red[threadIdx.x][0] += red[threadIdx.x + d][0]; red[threadIdx.x][1] += red[threadIdx.x + d][1]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { partial[((long)b * DB_NCH + chunk) * 2] = red[0][0]; partial[((long)b * DB_NCH + chunk) * 2 + 1] = red[0][1]; }
+    if (threadIdx.x == 0) { partial[((long)b * MT_NCH + chunk) * 2] = red[0][0]; partial[((long)b * MT_NCH + chunk) * 2 + 1] = red[0][1]; }
 }
 __global__ void mt_stats_finalize_kernel(const float* __restrict__ partial, int B, double count, float* __restrict__ mean,
                                          float* __restrict__ rstd) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < DB_NCH; ++k) { s1 += (double)partial[((long)b * DB_NCH + k) * 2]; s2 += (double)partial[((long)b * DB_NCH + k) * 2 + 1]; }
+    for (int k = 0; k < MT_NCH; ++k) { s1 += (double)partial[((long)b * MT_NCH + k) * 2]; s2 += (double)partial[((long)b * MT_NCH + k) * 2 + 1]; }
     const double mu = s1 / count;
     double var = s2 / count - mu * mu;
     var = var > 0.0 ? var : 0.0;
@@ -2450,7 +2466,7 @@ __global__ __launch_bounds__(256) void mt_bwd_sums_kernel(const float* __restric
                                                           MaskTailP p, float* __restrict__ partial) {
     __shared__ float red[256][5];
     const int b = blockIdx.x, chunk = blockIdx.y;
-    const int per = (P + DB_NCH - 1) / DB_NCH, p0 = chunk * per, p1 = p0 + per < P ? p0 + per : P;
+    const int per = (P + MT_NCH - 1) / MT_NCH, p0 = chunk * per, p1 = p0 + per < P ? p0 + per : P;
     const float gm = p.gamma[0], bt = p.beta[0], al = p.alpha[0], wf = p.wf[0], bf = p.bf[0], mu = mean[b], rs = rstd[b];
     float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     for (int q = p0 + threadIdx.x; q < p1; q += 256) {
@@ -2471,7 +2487,7 @@ __global__ __launch_bounds__(256) void mt_bwd_sums_kernel(const float* __restric
             for (int k = 0; k < 5; ++k) red[threadIdx.x][k] += red[threadIdx.x + d][k];
         __syncthreads();
     }
-    if (threadIdx.x < 5) partial[((long)b * DB_NCH + chunk) * 5 + threadIdx.x] = red[0][threadIdx.x];
+    if (threadIdx.x < 5) partial[((long)b * MT_NCH + chunk) * 5 + threadIdx.x] = red[0][threadIdx.x];
 }
 __global__ void mt_bwd_finalize_kernel(const float* __restrict__ partial, int B, double count, float* __restrict__ m1,
                                        float* __restrict__ m2, MaskTailG gr) {
@@ -2479,8 +2495,8 @@ __global__ void mt_bwd_finalize_kernel(const float* __restrict__ partial, int B,
     double t[5] = {0, 0, 0, 0, 0};
     for (int b = 0; b < B; ++b) {
         double s[5] = {0, 0, 0, 0, 0};
-        for (int k = 0; k < DB_NCH; ++k)
-            for (int j = 0; j < 5; ++j) s[j] += (double)partial[((long)b * DB_NCH + k) * 5 + j];
+        for (int k = 0; k < MT_NCH; ++k)
+            for (int j = 0; j < 5; ++j) s[j] += (double)partial[((long)b * MT_NCH + k) * 5 + j];
         m1[b] = (float)(s[0] / count);
         m2[b] = (float)(s[1] / count);
         for (int j = 0; j < 5; ++j) t[j] += s[j];
@@ -2559,7 +2575,7 @@ void launch_decoder_train_forward(LaunchCtx ctx, int kind, const float* x, int B
     float* stt = ws + pl.st;
     if (kind == 0) {
         tail_forward<1>(ctx, ws + pl.s, R, W, p.c_w, p.c_b, ws + pl.t1);
-        LAUNCH(ctx, "decoder_train", (mt_stats_kernel<<<dim3(B, DB_NCH), 256, 0, st>>>(ws + pl.t1, T * F, ws + pl.part)));
+        LAUNCH(ctx, "decoder_train", (mt_stats_kernel<<<dim3(B, MT_NCH), 256, 0, st>>>(ws + pl.t1, T * F, ws + pl.part)));
         LAUNCH(ctx, "decoder_train", (mt_stats_finalize_kernel<<<(B + 63) / 64, 64, 0, st>>>(ws + pl.part, B, (double)T * F, stt,
                                                                                              stt + B)));
         LAUNCH(ctx, "decoder_train", (mt_apply_kernel<<<1024, 256, 0, st>>>(ws + pl.t1, R * F, T * F, F, stt, stt + B,
@@ -2586,7 +2602,7 @@ void launch_decoder_train_backward(LaunchCtx ctx, int kind, const float* x, cons
         LAUNCH(ctx, "decoder_train", (mt_dalphaf_kernel<<<F, 256, 0, st>>>(ws + pl.t1, dout, B, T, F, stt, stt + B, mp,
                                                                           grad.po_w)));
         hipMemcpyAsync(g2, dout, (size_t)R * F * sizeof(float), hipMemcpyDeviceToDevice, st);
-        LAUNCH(ctx, "decoder_train", (mt_bwd_sums_kernel<<<dim3(B, DB_NCH), 256, 0, st>>>(ws + pl.t1, g2, T * F, F, stt, stt + B,
+        LAUNCH(ctx, "decoder_train", (mt_bwd_sums_kernel<<<dim3(B, MT_NCH), 256, 0, st>>>(ws + pl.t1, g2, T * F, F, stt, stt + B,
                                                                                         mp, ws + pl.part)));
         LAUNCH(ctx, "decoder_train", (mt_bwd_finalize_kernel<<<1, 64, 0, st>>>(ws + pl.part, B, (double)T * F, ws + pl.m,
                                                                               ws + pl.m + B, mg)));
