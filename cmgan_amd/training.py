@@ -850,13 +850,13 @@ class GeneratorTrain:
         ps = {m.p for blk in self.blocks for c in (blk.time, blk.freq) for m in (c.ff1, c.attn, c.ff2)}
         if len(ps) != 1 or next(iter(ps)) <= 0.0:
             return [blk.masks(B, T, Fe, generator) for blk in self.blocks]
-        # all forty masks from ONE uniform draw (three launches instead of 160): views of a single buffer
+        # all forty masks from ONE Bernoulli draw (two launches instead of 160): views of a single buffer
         p = next(iter(ps))
         widths = (("ff1_1", 256), ("ff1_2", 64), ("attn", 64), ("ff2_1", 256), ("ff2_2", 64))
         tokens = B * T * Fe
         per_axis = tokens * sum(w for _, w in widths)
-        buf = torch.rand(len(self.blocks) * 2 * per_axis, device=self.engine.device, generator=generator)
-        buf.ge_(p).mul_(1.0 / (1.0 - p))
+        buf = torch.empty(len(self.blocks) * 2 * per_axis, dtype=torch.float32, device=self.engine.device)
+        buf.bernoulli_(1.0 - p, generator=generator).mul_(1.0 / (1.0 - p))
         out, off = [], 0
         for _ in self.blocks:
             pair = []
