@@ -1,5 +1,7 @@
-"""Pieces of the reference's training step (src/train.py) that are built on the HIP path so far
-(SURVEY.md N2 - a bounded slice, not the whole trainer):
+"""The reference's training step (src/train.py:72-205) on the HIP path: every module of the generator
+and the metric discriminator with forward + backward, the losses and their gradients, AdamW and the data-parallel
+gradient mean.  Not here: the epoch loop, logging, checkpoint files and `batch_pesq` (CPU code of the absent `pesq`
+wheel - PESQ labels are an input).
 
 * `generator_loss_terms`   - the non-adversarial terms of Trainer.calculate_generator_loss (train.py:124-151) as one
                              deterministic device reduction; the per-rank scalars a data-parallel step all-reduces.
@@ -932,12 +934,13 @@ class GeneratorTrain:
 
 def generator_train_step(gen: GeneratorTrain, optimizer: "AdamW", clean: torch.Tensor, noisy: torch.Tensor,
                          loss_weights=(0.1, 0.9, 0.2), generator: Optional[torch.Generator] = None, masks="draw",
-                         lr: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                         lr: Optional[float] = None, update: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """One optimisation step of the generator on the non-adversarial loss - Trainer.train_step's generator half
     (train.py:153-193) with forward_generator_step (train.py:72-122) and calculate_generator_loss (train.py:124-151)
     minus the metric-discriminator term: returns (loss, float32[4] terms) of THIS rank before the update.
     clean, noisy: float32 [B, L] on the GPU, L a multiple of hop.  `masks="draw"` draws fresh dropout masks from
-    `generator`; pass `gen.masks(...)`-shaped masks to fix them, or None to disable dropout."""
+    `generator`; pass `gen.masks(...)`-shaped masks to fix them, or None to disable dropout.  `update=False` stops
+    after the backward pass (gradients in the bucket; no all-reduce, no optimiser launch)."""
     eng = gen.engine
     clean, noisy = eng._in(clean, "clean"), eng._in(noisy, "noisy")
     B = noisy.shape[0]
@@ -959,8 +962,9 @@ def generator_train_step(gen: GeneratorTrain, optimizer: "AdamW", clean: torch.T
                                                   float(loss_weights[0]), float(loss_weights[1]), float(loss_weights[2]),
                                                   d_real.data_ptr(), d_imag.data_ptr(), eng._stream()))
     gen.backward(d_real, d_imag)                                # train.py:190 (loss.backward())
-    gen.allreduce_gradients()                                   # DDP's gradient mean, one collective
-    optimizer.step(lr)                                          # train.py:191
+    if update:                                                  # False: stop after the backward (GraphedTrainStep)
+        gen.allreduce_gradients()                               # DDP's gradient mean, one collective
+        optimizer.step(lr)                                      # train.py:191
     return loss, terms
 
 
@@ -1106,12 +1110,15 @@ class DiscriminatorTrain:
 def adversarial_train_step(gen: GeneratorTrain, disc: DiscriminatorTrain, opt_g: "AdamW", opt_d: "AdamW",
                            clean: torch.Tensor, noisy: torch.Tensor, pesq_score: Optional[torch.Tensor],
                            loss_weights=(0.1, 0.9, 0.2, 0.05), generator: Optional[torch.Generator] = None,
-                           masks="draw", disc_masks="draw", lr: Optional[float] = None):
+                           masks="draw", disc_masks="draw", lr: Optional[float] = None, update: bool = True):
     """Trainer.train_step (train.py:173-205): the generator step on the FULL loss (train.py:124-151: RI, magnitude,
     time and 0.05 x metric-discriminator terms), then the discriminator step (train.py:153-171) on `pesq_score`
     [B] = (PESQ - 1) / 3.5 of (clean, est_audio) - the labels discriminator.batch_pesq computes on the CPU; None (a
     silent clip made PESQ fail) skips the discriminator update like the reference.  Returns
-    (generator loss, float32[4] terms, gen_loss_GAN, discriminator loss or None) of this rank before the updates."""
+    (generator loss, float32[4] terms, gen_loss_GAN, discriminator loss or None) of this rank before the updates.
+    `update=False` leaves both gradient buckets filled and skips the all-reduces and optimiser launches; note that the
+    reference updates the generator BEFORE the discriminator forwards, which does not change the discriminator's
+    inputs (est is detached), so deferring both updates gives the same gradients."""
     eng = gen.engine
     clean, noisy = eng._in(clean, "clean"), eng._in(noisy, "noisy")
     B = noisy.shape[0]
@@ -1144,8 +1151,9 @@ def adversarial_train_step(gen: GeneratorTrain, disc: DiscriminatorTrain, opt_g:
         check(eng._h, eng.lib.cmgan_mag_pair_backward(eng._h, est_real.data_ptr(), est_imag.data_ptr(), dxy.data_ptr(), B, T,
                                                       1.0, d_real.data_ptr(), d_imag.data_ptr(), eng._stream()))
     gen.backward(d_real, d_imag)                                              # train.py:190
-    gen.allreduce_gradients()
-    opt_g.step(lr)                                                            # train.py:191
+    if update:
+        gen.allreduce_gradients()
+        opt_g.step(lr)                                                        # train.py:191
     loss_d = None
     if pesq_score is not None:                                                # train.py:194-201
         s_enh = disc.forward(xy, disc_masks[1], train=True, slot=0)           # D(clean, est.detach()), :163-165
@@ -1155,8 +1163,9 @@ def adversarial_train_step(gen: GeneratorTrain, disc: DiscriminatorTrain, opt_g:
         loss_d = l_max + l_enh                                                # :168-170
         disc.backward(d_enh, slot=0, need_input_grad=False)
         disc.backward(d_max, slot=1, need_input_grad=False, accumulate=True)
-        disc.allreduce_gradients()
-        opt_d.step(None if lr is None else 2.0 * lr)                          # train.py:64-66: twice the generator's rate
+        if update:
+            disc.allreduce_gradients()
+            opt_d.step(None if lr is None else 2.0 * lr)                      # train.py:64-66: twice the generator's rate
     return loss, terms, gan, loss_d
 
 
@@ -1188,26 +1197,12 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         opts = [o for o in (opt_g, opt_d) if o is not None]
-        real_steps = [o.step for o in opts]
-        try:
-            for o in opts:
-                o.step = lambda lr=None: None                           # graph A ends where the optimisers would run
-            reduce_g, gen.allreduce_gradients = gen.allreduce_gradients, (lambda: None)
-            reduce_d = None
-            if disc is not None:
-                reduce_d, disc.allreduce_gradients = disc.allreduce_gradients, (lambda: None)
-            with torch.cuda.graph(self.graph_a):
-                if disc is None:
-                    self.out = generator_train_step(gen, opt_g, self.clean, self.noisy, w3, masks=masks)
-                else:
-                    self.out = adversarial_train_step(gen, disc, opt_g, opt_d, self.clean, self.noisy, self.pesq,
-                                                      loss_weights, masks=masks, disc_masks=masks)
-        finally:
-            for o, f in zip(opts, real_steps):
-                o.step = f
-            gen.allreduce_gradients = reduce_g
-            if disc is not None:
-                disc.allreduce_gradients = reduce_d
+        with torch.cuda.graph(self.graph_a):                            # ends where the all-reduces / optimisers start
+            if disc is None:
+                self.out = generator_train_step(gen, opt_g, self.clean, self.noisy, w3, masks=masks, update=False)
+            else:
+                self.out = adversarial_train_step(gen, disc, opt_g, opt_d, self.clean, self.noisy, self.pesq,
+                                                  loss_weights, masks=masks, disc_masks=masks, update=False)
         with torch.cuda.graph(self.graph_b):
             for o in opts:
                 o.step()
