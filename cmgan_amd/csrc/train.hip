@@ -359,6 +359,72 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int ns
     }
 }
 
+// Several column sums over the SAME M rows in two launches instead of two per sum (a conformer block's backward has
+// twenty of them): blockIdx.y selects the job, each job has its own 512-slab region of `cpart`.
+#define COLSUM_MAX_JOBS 4
+struct ColsumJobs {
+    const float* X[COLSUM_MAX_JOBS];
+    float* out[COLSUM_MAX_JOBS];
+    int C[COLSUM_MAX_JOBS];
+};
+__global__ __launch_bounds__(256) void colsum_multi_partial_kernel(ColsumJobs jobs, long M, float* __restrict__ cpart) {
+    __shared__ float red[256];
+    const int job = blockIdx.y;
+    const float* __restrict__ X = jobs.X[job];
+    const int C = jobs.C[job];
+    float* partial = cpart + (size_t)job * FFN_COLSUM_BLOCKS * 256;
+    const int col = threadIdx.x % C, sub = threadIdx.x / C, nsub = 256 / C;
+    const long per = (M + gridDim.x - 1) / gridDim.x;
+    const long m0 = (long)blockIdx.x * per, m1 = m0 + per < M ? m0 + per : M;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long m = m0 + sub;
+    for (; m + 3L * nsub < m1; m += 4L * nsub) {
+        s0 += X[m * C + col];
+        s1 += X[(m + nsub) * C + col];
+        s2 += X[(m + 2L * nsub) * C + col];
+        s3 += X[(m + 3L * nsub) * C + col];
+    }
+    for (; m < m1; m += nsub) s0 += X[m * C + col];
+    float sum = (s0 + s1) + (s2 + s3);
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    if (sub == 0) {
+        for (int k = 1; k < nsub; ++k) sum += red[k * C + col];
+        partial[(long)blockIdx.x * C + col] = sum;
+    }
+}
+__global__ __launch_bounds__(1024) void colsum_multi_reduce_kernel(ColsumJobs jobs, const float* __restrict__ cpart) {
+    __shared__ float red[16][64];
+    const int job = blockIdx.y, n = jobs.C[job];
+    const float* partial = cpart + (size_t)job * FFN_COLSUM_BLOCKS * 256;
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + col;
+    if ((long)blockIdx.x * 64 >= n) return;                               // block-uniform
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < n) {
+        int k = grp;
+        for (; k + 48 < FFN_COLSUM_BLOCKS; k += 64) {
+            s0 += partial[(long)k * n + e];
+            s1 += partial[(long)(k + 16) * n + e];
+            s2 += partial[(long)(k + 32) * n + e];
+            s3 += partial[(long)(k + 48) * n + e];
+        }
+        for (; k < FFN_COLSUM_BLOCKS; k += 16) s0 += partial[(long)k * n + e];
+    }
+    red[grp][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && e < n) {
+        float sum = red[0][col];
+        for (int g = 1; g < 16; ++g) sum += red[g][col];
+        jobs.out[job][e] = sum;
+    }
+}
+// cpart must hold njobs * FFN_COLSUM_BLOCKS * 256 floats
+static void colsum_batch(LaunchCtx ctx, const char* label, const ColsumJobs& jobs, int njobs, long M, float* cpart) {
+    LAUNCH(ctx, label, (colsum_multi_partial_kernel<<<dim3(FFN_COLSUM_BLOCKS, njobs), 256, 0, ctx.stream>>>(jobs, M, cpart)));
+    LAUNCH(ctx, label, (colsum_multi_reduce_kernel<<<dim3(4, njobs), 1024, 0, ctx.stream>>>(jobs, cpart)));
+}
+
 // pack = false: the images the forward of the SAME parameters left in the workspace are reused (backward passes)
 static FfnTrainImg ffn_pack_images(LaunchCtx ctx, const FfnTrainParams& p, float* img, bool pack = true) {
     hipStream_t s = ctx.stream;
@@ -372,7 +438,8 @@ static FfnTrainImg ffn_pack_images(LaunchCtx ctx, const FfnTrainParams& p, float
 }
 
 size_t ffn_train_ws_floats(long M) {
-    return (size_t)4 * 16384 + (size_t)M * 768 + (size_t)FFN_WGRAD_SPLIT * 16384 * 2 + (size_t)FFN_COLSUM_BLOCKS * 256;
+    return (size_t)4 * 16384 + (size_t)M * 768 + (size_t)FFN_WGRAD_SPLIT * 16384 * 2 +
+           (size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256;
 }
 
 void launch_ffn_train_forward(LaunchCtx ctx, const float* x, long M, const FfnTrainParams& p, const float* m1,
@@ -400,12 +467,8 @@ void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, l
     LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<64, 256, 0, s>>>(part, FFN_WGRAD_SPLIT, 16384, grad.w2)));
     LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<64, 256, 0, s>>>(part + (size_t)FFN_WGRAD_SPLIT * 16384,
                                                                                FFN_WGRAD_SPLIT, 16384, grad.w1)));
-    struct { const float* X; int C; float* out; } sums[4] = {
-        {o.dh, 256, grad.b1}, {o.dz, 64, grad.b2}, {o.g1, 64, grad.gamma}, {o.dxn, 64, grad.beta}};
-    for (auto& cs : sums) {
-        LAUNCH(ctx, "ffn_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(cs.X, M, cs.C, cpart)));
-        LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, cs.C, cs.out)));
-    }
+    const ColsumJobs jobs{{o.dh, o.dz, o.g1, o.dxn}, {grad.b1, grad.b2, grad.gamma, grad.beta}, {256, 64, 64, 64}};
+    colsum_batch(ctx, "ffn_train_reduce", jobs, 4, M, cpart);
 }
 
 // ---------------------------------------------------------------------------------
@@ -826,7 +889,7 @@ static CmPlan cm_plan(int N, int L) {
     p.dwpart = take((size_t)CM_DW_SLABS * 3968);
     p.bnpart = take(nblk * 256);
     p.bnred = take((size_t)CM_BN_RED * 256 * 2);        // doubles
-    p.cpart = take((size_t)FFN_COLSUM_BLOCKS * 256);
+    p.cpart = take((size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256);
     p.sums = take(256);
     p.total = cur;
     return p;
@@ -888,10 +951,11 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
                                            dy, ws + pl.s, M, 64, 128, FFN_WGRAD_SPLIT, ws + pl.wpart)));
     LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<32, 256, 0, s>>>(ws + pl.wpart, FFN_WGRAD_SPLIT, 8192,
                                                                                    grad.pw2_w)));
-    colsum(dy, 64, grad.pw2_b);
-    // BatchNorm: dbeta = sum ddn, dgamma = sum ddn dhat; then dd in place
-    colsum(ws + pl.ddn, 128, sum_ddn);
-    colsum(ws + pl.g2, 128, sum_g2);
+    // BatchNorm: dbeta = sum ddn, dgamma = sum ddn dhat; then dd in place   (+ db_pw2 = colsum dy in the same pair of launches)
+    {
+        const ColsumJobs jobs{{dy, ws + pl.ddn, ws + pl.g2}, {grad.pw2_b, sum_ddn, sum_g2}, {64, 128, 128}};
+        colsum_batch(ctx, "convmod_train_reduce", jobs, 3, M, cpart);
+    }
     hipMemcpyAsync(grad.bn_b, sum_ddn, 128 * sizeof(float), hipMemcpyDeviceToDevice, s);
     hipMemcpyAsync(grad.bn_w, sum_g2, 128 * sizeof(float), hipMemcpyDeviceToDevice, s);
     LAUNCH(ctx, "convmod_train_bwd", (cm_bn_bwd_kernel<<<2048, 256, 0, s>>>(ws + pl.ddn, ws + pl.d, M * 128, st, sum_ddn,
@@ -913,9 +977,8 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
                                            ws + pl.dag, ws + pl.xn, M, 256, 64, FFN_WGRAD_SPLIT, ws + pl.wpart)));
     LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<64, 256, 0, s>>>(ws + pl.wpart, FFN_WGRAD_SPLIT, 16384,
                                                                                    grad.pw1_w)));
-    colsum(ws + pl.dag, 256, grad.pw1_b);
-    colsum(ws + pl.g1, 64, grad.ln_w);
-    colsum(ws + pl.dxn, 64, grad.ln_b);
+    const ColsumJobs jobs{{ws + pl.dag, ws + pl.g1, ws + pl.dxn}, {grad.pw1_b, grad.ln_w, grad.ln_b}, {256, 64, 64}};
+    colsum_batch(ctx, "convmod_train_reduce", jobs, 3, M, cpart);
 }
 
 // =====================================================================================
@@ -1376,7 +1439,7 @@ static AtPlan at_plan(int N, int L) {
     p.depart = take((size_t)N * 4 * (2 * L - 1) * 16);
     p.dewin = take((size_t)(2 * L - 1) * 16);
     p.wpart = take((size_t)FFN_WGRAD_SPLIT * 12288);
-    p.cpart = take((size_t)FFN_COLSUM_BLOCKS * 256);
+    p.cpart = take((size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256);
     p.total = cur;
     return p;
 }
@@ -1419,10 +1482,6 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     const AtBufs b{ws + pl.qkv, ws + pl.o, ws + pl.lse};
     const unsigned grid = (unsigned)((M + 63) / 64);
     float* cpart = ws + pl.cpart;
-    auto colsum = [&](const float* X, int C, float* out) {
-        LAUNCH(ctx, "attn_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(X, M, C, cpart)));
-        LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, C, out)));
-    };
     LAUNCH(ctx, "attn_train_bwd", (at_out_bwd_kernel<<<grid, 256, 0, s>>>(dy, mask, b.o, M, ws + pl.wot, ws + pl.dout,
                                                                           ws + pl.dO, ws + pl.D)));
     // to_out gradients: dWo [64,64] = dout^T O, dbo = colsum dout
@@ -1430,7 +1489,6 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
                                         ws + pl.dout, b.o, M, 64, 64, FFN_WGRAD_SPLIT, ws + pl.wpart)));
     LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<16, 256, 0, s>>>(ws + pl.wpart, FFN_WGRAD_SPLIT, 4096,
                                                                                 grad.wo)));
-    colsum(ws + pl.dout, 64, grad.bo);
     // attention core: dq (rows), dk / dv (columns), dE (distances)
     const AtSplit sp = at_split(L), spe = at_split(2 * L - 1);
     const size_t rel_rows = (size_t)(2 * L - 1) * AT_P;
@@ -1463,8 +1521,8 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
                                                                                 ws + pl.raw)));      // [192,64], then split
     hipMemcpyAsync(grad.wq, ws + pl.raw, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);
     hipMemcpyAsync(grad.wkv, ws + pl.raw + 4096, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);
-    colsum(ws + pl.g1, 64, grad.ln_w);
-    colsum(ws + pl.dxn, 64, grad.ln_b);
+    const ColsumJobs jobs{{ws + pl.dout, ws + pl.g1, ws + pl.dxn}, {grad.bo, grad.ln_w, grad.ln_b}, {64, 64, 64}};
+    colsum_batch(ctx, "attn_train_reduce", jobs, 3, M, cpart);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1531,7 +1589,7 @@ __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float* __restri
     }
 }
 
-size_t ln_train_ws_floats(long M) { return (size_t)M * 64 + (size_t)FFN_COLSUM_BLOCKS * 256; }
+size_t ln_train_ws_floats(long M) { return (size_t)M * 64 + (size_t)2 * FFN_COLSUM_BLOCKS * 256; }
 
 void launch_ln_train_forward(LaunchCtx ctx, const float* x, long M, const float* gamma, const float* beta, float* y) {
     LAUNCH(ctx, "ln_train", (ln_train_fwd_kernel<<<(unsigned)((M + 63) / 64), 256, 0, ctx.stream>>>(x, M, gamma, beta, y)));
@@ -1543,10 +1601,8 @@ void launch_ln_train_backward(LaunchCtx ctx, const float* x, const float* dy, lo
     float* g1 = ws;
     float* cpart = ws + (size_t)M * 64;
     LAUNCH(ctx, "ln_train", (ln_train_bwd_kernel<<<(unsigned)((M + 63) / 64), 256, 0, s>>>(x, dy, M, gamma, beta, dx, g1)));
-    LAUNCH(ctx, "ln_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(g1, M, 64, cpart)));
-    LAUNCH(ctx, "ln_train", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, 64, dgamma)));
-    LAUNCH(ctx, "ln_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(dy, M, 64, cpart)));
-    LAUNCH(ctx, "ln_train", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, 64, dbeta)));
+    const ColsumJobs jobs{{g1, dy}, {dgamma, dbeta}, {64, 64}};
+    colsum_batch(ctx, "ln_train", jobs, 2, M, cpart);
 }
 
 // [B, A, C, 64] -> [B, C, A, 64]: the layout flip between the time-axis and frequency-axis sequences of a TSCB
@@ -1888,7 +1944,7 @@ static DbPlan db_plan(int B, int T, int F) {
     p.part = take((size_t)B * DB_NCH * 64 * 3);
     p.m1 = take((size_t)B * 64); p.m2 = take((size_t)B * 64);
     p.wpart = take((size_t)6 * FFN_WGRAD_SPLIT * 4096);
-    p.cpart = take((size_t)FFN_COLSUM_BLOCKS * 256);
+    p.cpart = take((size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256);
     p.total = cur;
     return p;
 }
@@ -1985,9 +2041,6 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
                                                                                 grad.prelu_w[i])));
         LAUNCH(ctx, "dense_train_bwd", (db_in_bwd_kernel<<<2048, 256, 0, st>>>(g, z, M * 64, P, mean, rstd, p.norm_w[i],
                                                                                ws + pl.m1, ws + pl.m2)));
-        LAUNCH(ctx, "dense_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(g, M, 64, cpart)));
-        LAUNCH(ctx, "dense_train_reduce", (reduce_partials_kernel<<<4, 1024, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64,
-                                                                                     grad.conv_b[i])));
         const int dil = 1 << i, Cin = 64 * (i + 1);
         for (int s = 0; s <= i; ++s) {
             LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_kernel<<<dim3(4, 6, FFN_WGRAD_SPLIT), 256, 0, st>>>(
@@ -1998,6 +2051,10 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
                                                g, ws + pl.imgT + (long)db_img_index(i, s) * 4096, B, T, F, dil, ga(s))));
         }
     }
+    // the four conv-bias gradients (column sums of the layers' dz planes, which stay untouched once written) in one batch
+    const ColsumJobs jobs{{ga(1), ga(2), ga(3), ga(4)}, {grad.conv_b[0], grad.conv_b[1], grad.conv_b[2], grad.conv_b[3]},
+                          {64, 64, 64, 64}};
+    colsum_batch(ctx, "dense_train_reduce", jobs, 4, M, cpart);
     hipMemcpyAsync(dx, ga(0), (size_t)M * 64 * sizeof(float), hipMemcpyDeviceToDevice, st);
 }
 
@@ -2259,7 +2316,7 @@ static EncPlan enc_plan(int B, int T, int F) {
     p.part = take((size_t)B * DB_NCH * 64 * 3);
     p.m = take((size_t)2 * B * 64);
     p.wpart = take((size_t)3 * FFN_WGRAD_SPLIT * 4096);
-    p.cpart = take((size_t)FFN_COLSUM_BLOCKS * 256);
+    p.cpart = take((size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256);
     p.dense = take(dense_train_ws_floats(B, T, F));
     p.total = cur;
     return p;
@@ -2552,7 +2609,7 @@ static DecPlan dec_plan(int B, int T, int Fe) {
     p.part = take((size_t)B * DB_NCH * 64 * 3);
     p.m = take((size_t)2 * B * 64);
     p.wpart = take((size_t)3 * FFN_WGRAD_SPLIT * 8192);
-    p.cpart = take((size_t)FFN_COLSUM_BLOCKS * 256);
+    p.cpart = take((size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256);
     p.dense = take(dense_train_ws_floats(B, T, Fe));
     p.total = cur;
     return p;
