@@ -61,7 +61,7 @@ from ._lib import (AttnParams, ConvModParams, DecoderParams, DenseParams, DiscPa
 from .dist import FlatBucket, allreduce_mean
 from .engine import Engine
 
-__all__ = ["GraphedTrainStep", "DiscriminatorTrain", "adversarial_train_step", "GeneratorTrain", "generator_train_step", "DenseEncoderTrain", "DecoderTrain", "DenseBlockTrain", "TSCBTrain", "ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
+__all__ = ["Trainer", "batch_pesq", "GraphedTrainStep", "DiscriminatorTrain", "adversarial_train_step", "GeneratorTrain", "generator_train_step", "DenseEncoderTrain", "DecoderTrain", "DenseBlockTrain", "TSCBTrain", "ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
            "validation_step"]
 
 _KEYS = ("fn.norm.weight", "fn.norm.bias", "fn.fn.net.0.weight", "fn.fn.net.0.bias",
@@ -1114,7 +1114,9 @@ def adversarial_train_step(gen: GeneratorTrain, disc: DiscriminatorTrain, opt_g:
     """Trainer.train_step (train.py:173-205): the generator step on the FULL loss (train.py:124-151: RI, magnitude,
     time and 0.05 x metric-discriminator terms), then the discriminator step (train.py:153-171) on `pesq_score`
     [B] = (PESQ - 1) / 3.5 of (clean, est_audio) - the labels discriminator.batch_pesq computes on the CPU; None (a
-    silent clip made PESQ fail) skips the discriminator update like the reference.  Returns
+    silent clip made PESQ fail) skips the discriminator update like the reference; a callable
+    `pesq_score(clean [B, La], est_audio [B, La]) -> tensor | None` is evaluated where the reference calls batch_pesq
+    (after the generator update).  Returns
     (generator loss, float32[4] terms, gen_loss_GAN, discriminator loss or None) of this rank before the updates.
     `update=False` leaves both gradient buckets filled and skips the all-reduces and optimiser launches; note that the
     reference updates the generator BEFORE the discriminator forwards, which does not change the discriminator's
@@ -1155,6 +1157,8 @@ def adversarial_train_step(gen: GeneratorTrain, disc: DiscriminatorTrain, opt_g:
         gen.allreduce_gradients()
         opt_g.step(lr)                                                        # train.py:191
     loss_d = None
+    if callable(pesq_score):                                                  # discriminator.batch_pesq's place in the step
+        pesq_score = pesq_score(clean_cut, est_audio)
     if pesq_score is not None:                                                # train.py:194-201
         s_enh = disc.forward(xy, disc_masks[1], train=True, slot=0)           # D(clean, est.detach()), :163-165
         s_max = disc.forward(disc.pair(clean_spec), disc_masks[2], train=True, slot=1)   # D(clean, clean), :166-167
@@ -1226,3 +1230,108 @@ class GraphedTrainStep:
             self.disc.allreduce_gradients()
         self.graph_b.replay()
         return self.out
+
+
+def batch_pesq(clean: torch.Tensor, est: torch.Tensor, sr: int = 16000) -> Optional[torch.Tensor]:
+    """discriminator.batch_pesq (src/models/discriminator.py:9-26): wide-band PESQ of every (clean, estimate) pair on the
+    CPU, normalised to (PESQ - 1) / 3.5 on the inputs' device; None when any pair fails (silent clips).  Needs the
+    `pesq` wheel the reference depends on: without it there are no labels, and None is returned (the discriminator
+    update is then skipped, exactly what the reference does for a failed batch)."""
+    from .metrics import _default_pesq
+    fn = _default_pesq()
+    if fn is None:
+        return None
+    scores = []
+    for c, e in zip(clean.detach().cpu().numpy(), est.detach().cpu().numpy()):
+        try:
+            scores.append(float(fn(sr, c, e)))
+        except Exception:                                      # noqa: BLE001 - "error can happen due to silent period"
+            return None
+    return ((torch.tensor(scores, dtype=torch.float32) - 1.0) / 3.5).to(clean.device)
+
+
+class Trainer:
+    """`Trainer` of src/train.py:47-275 on the HIP path: `train_step`, `test_step`, `test`, `train` with the reference's
+    optimisers (AdamW 5e-4 / 1e-3), StepLR(decay_epoch, 0.5) for both, per-epoch validation and the generator checkpoint
+    `CMGAN_epoch_<e>_<loss>` (a plain `state_dict`, loadable by the reference's evaluation.py and by `cmgan_amd.TSCNet`).
+    One instance per process / GPU (train.py:277-297 spawns them); gradients are averaged over the initialised
+    process group.  `train_ds` / `test_ds` are the loaders of `cmgan_amd.data.load_data`; `pesq_fn` defaults to
+    `batch_pesq` (labels need the `pesq` wheel; without it every discriminator update is skipped)."""
+
+    def __init__(self, train_ds, test_ds, generator_state: Dict[str, torch.Tensor],
+                 discriminator_state: Dict[str, torch.Tensor], device=None, init_lr: float = 5e-4, decay_epoch: int = 30,
+                 loss_weights=(0.1, 0.9, 0.2, 0.05), n_fft: int = 400, hop: int = 100, pesq_fn=batch_pesq,
+                 log_interval: int = 500, log=print):
+        from .generator import TSCNet
+        self.train_ds, self.test_ds = train_ds, test_ds
+        self.engine = eng = Engine(n_fft=n_fft, hop=hop, device=device)
+        self.gen = GeneratorTrain(generator_state, engine=eng)                            # train.py:52
+        self.disc = DiscriminatorTrain(discriminator_state, engine=eng)                   # train.py:58
+        self.optimizer = AdamW(eng, self.gen.param_bucket, self.gen.grad_bucket, lr=init_lr)           # train.py:63
+        self.optimizer_disc = AdamW(eng, self.disc.param_bucket, self.disc.grad_bucket, lr=2 * init_lr)    # :64-66
+        self.init_lr, self.decay_epoch, self.loss_weights = init_lr, decay_epoch, tuple(loss_weights)
+        self.pesq_fn, self.log_interval, self.log = pesq_fn, log_interval, log
+        self.epoch = 0
+        # eval-mode twin of the generator for test(): the inference path on the CURRENT parameters
+        self._eval_model = TSCNet(64, eng.cfg.num_features, n_fft=n_fft, hop=hop, device=eng.device)
+
+    def _batches(self, loader):
+        from .data import DevicePrefetcher
+        return DevicePrefetcher(loader, self.engine.device)
+
+    def train_step(self, clean: torch.Tensor, noisy: torch.Tensor) -> Tuple[float, float]:
+        """train.py:173-205: (generator loss, discriminator loss or 0.0 when PESQ gave no labels)."""
+        lr = step_lr(self.epoch, self.init_lr, self.decay_epoch)
+        loss, _, _, loss_d = adversarial_train_step(self.gen, self.disc, self.optimizer, self.optimizer_disc, clean, noisy,
+                                                    self.pesq_fn, self.loss_weights, lr=lr)
+        return float(loss), (float(loss_d) if loss_d is not None else 0.0)
+
+    @torch.no_grad()
+    def test_step(self, clean: torch.Tensor, noisy: torch.Tensor) -> Tuple[float, float]:
+        """train.py:207-227 in eval mode: the full generator loss (incl. the metric term) and the discriminator loss."""
+        eng = self.engine
+        out = forward_generator_step(self._eval_model, clean, noisy)
+        La = out["est_audio"].shape[-1]
+        clean_cut = clean[:, :La].contiguous()
+        base, _ = generator_loss_terms(eng, out["est_real"], out["est_imag"], out["clean_spec"], out["est_audio"], clean_cut,
+                                       self.loss_weights[:3])
+        xy = self.disc.pair(out["clean_spec"], out["est_real"], out["est_imag"])
+        gan, _ = self.disc.score_mse(self.disc.forward(xy, None, train=False, slot=0), None)
+        loss = float(base) + self.loss_weights[3] * float(gan)
+        labels = self.pesq_fn(clean_cut, out["est_audio"]) if self.pesq_fn is not None else None
+        loss_d = 0.0
+        if labels is not None:
+            s_enh = self.disc.forward(xy, None, train=False, slot=0)
+            s_max = self.disc.forward(self.disc.pair(out["clean_spec"]), None, train=False, slot=1)
+            loss_d = float(self.disc.score_mse(s_max, None)[0]) + float(self.disc.score_mse(s_enh, labels)[0])
+        return loss, loss_d
+
+    def test(self) -> float:
+        """train.py:229-245: mean generator loss over the validation set with the networks in eval mode."""
+        self._eval_model.load_state_dict(self.gen.state_dict()).eval()
+        gen_total = disc_total = 0.0
+        steps = 0
+        for clean, noisy, _ in self._batches(self.test_ds):
+            loss, loss_d = self.test_step(clean, noisy)
+            gen_total, disc_total, steps = gen_total + loss, disc_total + loss_d, steps + 1
+        steps = max(steps, 1)
+        self.log(f"GPU: {self.engine.device}, Generator loss: {gen_total / steps}, Discriminator loss: {disc_total / steps}")
+        return gen_total / steps
+
+    def train(self, epochs: int, save_model_dir: Optional[str] = None, rank: int = 0) -> list:
+        """train.py:247-275.  Returns the per-epoch validation losses; rank 0 writes the generator checkpoints."""
+        import os
+        history = []
+        for _ in range(epochs):
+            for idx, (clean, noisy, _) in enumerate(self._batches(self.train_ds)):
+                loss, loss_d = self.train_step(clean, noisy)
+                if (idx + 1) % self.log_interval == 0:
+                    self.log(f"GPU: {self.engine.device}, Epoch {self.epoch}, Step {idx + 1}, loss: {loss}, disc_loss: {loss_d}")
+            gen_loss = self.test()
+            history.append(gen_loss)
+            if save_model_dir is not None and rank == 0:
+                os.makedirs(save_model_dir, exist_ok=True)
+                torch.save({k: v.cpu() for k, v in self.gen.state_dict().items()},
+                           os.path.join(save_model_dir, "CMGAN_epoch_" + str(self.epoch) + "_" + str(gen_loss)[:5]))
+            self.epoch += 1                                                     # scheduler_G.step(); scheduler_D.step()
+        return history
