@@ -156,6 +156,8 @@ SIGNATURES = {
     "cmgan_power_uncompress": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cmgan_conformer_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "cmgan_conformer_forward": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cmgan_conformer_forward_masked": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_size_t, c_void_p]),
     "cmgan_tscnet_forward_taps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(Taps), c_void_p, c_size_t, c_void_p]),
     "cmgan_selftest_mfma": (c_int, [c_void_p, POINTER(c_float)]),
     "cmgan_selftest_mfma_x3": (c_int, [c_void_p, POINTER(c_float)]),

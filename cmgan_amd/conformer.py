@@ -1,5 +1,5 @@
 """Drop-in for ``models.conformer.ConformerBlock`` (reference: src/models/conformer.py:182-222)
-in eval mode: ``forward(x[N,L,64]) -> [N,L,64]`` on the HIP kernels.  Only the configuration
+in eval mode: ``forward(x[N,L,64], mask=None) -> [N,L,64]`` on the HIP kernels.  Only the configuration
 CMGAN instantiates (generator.py:75-90) is supported."""
 from __future__ import annotations
 
@@ -30,9 +30,9 @@ class ConformerBlock:
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, mask=None):
-        if mask is not None:
-            raise NotImplementedError("CMGAN never passes an attention mask (generator.py:95,97)")
-        return self.engine.conformer_forward(0, x)
+        """x [N, L, 64]; mask [N, L] bool as in the reference (conformer.py:216-217, 113-126): it only gates the
+        attention scores (pairs of two kept positions keep theirs), every other sub-module sees all rows."""
+        return self.engine.conformer_forward(0, x, mask=mask)
 
     __call__ = forward
 

@@ -551,8 +551,23 @@ extern "C" size_t cmgan_conformer_workspace_bytes(const cmgan_handle* h, int N, 
     return plan_conf(N, L).total * sizeof(float);
 }
 
+static int conformer_forward_impl(cmgan_handle* h, int index, const float* x, int N, int L, const unsigned char* mask,
+                                  float* y, float* taps, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int cmgan_conformer_forward(cmgan_handle* h, int index, const float* x, int N, int L, float* y,
                                        float* taps, void* ws, size_t ws_bytes, void* stream) {
+    return conformer_forward_impl(h, index, x, N, L, nullptr, y, taps, ws, ws_bytes, stream);
+}
+
+extern "C" int cmgan_conformer_forward_masked(cmgan_handle* h, int index, const float* x, int N, int L,
+                                              const unsigned char* mask, float* y, float* taps, void* ws,
+                                              size_t ws_bytes, void* stream) {
+    if (h && !mask) return fail(h, CMGAN_E_BADARG, "cmgan_conformer_forward_masked: mask is null");
+    return conformer_forward_impl(h, index, x, N, L, mask, y, taps, ws, ws_bytes, stream);
+}
+
+static int conformer_forward_impl(cmgan_handle* h, int index, const float* x, int N, int L, const unsigned char* mask,
+                                  float* y, float* taps, void* ws, size_t ws_bytes, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !y || N <= 0 || L <= 0 || index < 0 || index >= 8) return fail(h, CMGAN_E_BADARG, "cmgan_conformer_forward: bad argument");
     const ConfPlan p = plan_conf(N, L);
@@ -568,9 +583,9 @@ extern "C" int cmgan_conformer_forward(cmgan_handle* h, int index, const float* 
     if (h->cfg.mfma_mode == CMGAN_MFMA_F16X3) {
         ConfWeightsX3 w16;
         if (!conf_weights_x3(h, index, w16)) return CMGAN_E_WEIGHTS;
-        conformer_forward_x3(begin(h, stream), w, w16, b, seq, (long)M, taps, false);
+        conformer_forward_x3(begin(h, stream), w, w16, b, seq, (long)M, taps, false, mask);
     } else {
-        conformer_forward(begin(h, stream), w, b, seq, (long)M, taps, false);
+        conformer_forward(begin(h, stream), w, b, seq, (long)M, taps, false, mask);
     }
     HIPCHK(h, hipMemcpyAsync(y, b.xa, M * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return check_launch(h, "conformer_forward");

@@ -202,24 +202,26 @@ struct AttnState {
 // add or subtract: p = exp2(K q + E q - m_ref).
 #define ATTN_HI 12.0f
 #define ATTN_LO -4.0f
-template <bool FULL>
-__device__ __forceinline__ void attn_softmax(f32x4 (&s)[4], int c, int g, int j0, int nb, int L, AttnState& st) {
+// MASK: the [b, n] mask of ConformerBlock.forward(x, mask) (conformer.py:113-126), see att_softmax in conformer_x3.hip.
+template <bool FULL, bool MASK = false>
+__device__ __forceinline__ void attn_softmax(f32x4 (&s)[4], int c, int g, int j0, int nb, int L, AttnState& st,
+                                             const unsigned char* __restrict__ mk = nullptr, bool qvalid = true) {
     float mx = -INFINITY;
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
         if (FULL || jb < nb) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (!FULL) {
-                    const int key = j0 + 16 * jb + 4 * g + r;
-                    s[jb][r] = key < L ? s[jb][r] : -INFINITY;
-                }
+                const int key = j0 + 16 * jb + 4 * g + r;
+                if (!FULL) s[jb][r] = key < L ? s[jb][r] : -INFINITY;
+                if (MASK && (FULL || key < L)) s[jb][r] = qvalid ? (mk[key] ? s[jb][r] : -INFINITY) : 0.f;
                 mx = fmaxf(mx, s[jb][r]);
             }
         }
     }
     const float run = fmaxf(st.run, red_g_max(mx));
-    const bool drift = run > ATTN_HI || run < ATTN_LO;
+    const bool dead = MASK && run == -INFINITY;           // every key so far was masked for this (unmasked) query
+    const bool drift = !dead && (run > ATTN_HI || run < ATTN_LO);
     float psum = 0.f;
     if (__any(drift)) {
         const float alpha = st.l > 0.f ? __builtin_amdgcn_exp2f(-run) : 1.0f;
@@ -228,7 +230,7 @@ __device__ __forceinline__ void attn_softmax(f32x4 (&s)[4], int c, int g, int j0
             if (FULL || jb < nb) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(s[jb][r] - run);
+                    const float p = dead ? 0.f : __builtin_amdgcn_exp2f(s[jb][r] - run);
                     s[jb][r] = p;
                     psum += p;
                 }
@@ -238,8 +240,10 @@ __device__ __forceinline__ void attn_softmax(f32x4 (&s)[4], int c, int g, int j0
         }
         st.l *= alpha;
         st.o = st.o * splat4(alpha);
-        st.m += run;
-        st.run = 0.f;
+        if (!dead) {
+            st.m += run;
+            st.run = 0.f;
+        }
     } else {
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
@@ -263,9 +267,10 @@ struct AttnCtx {
     const float *qp, *kp, *vp, *rel;
     float *RA, *RB;
     int Lb, L, max_pos, c, g, lane;
+    const unsigned char* mk;          // this sequence's attention mask row (MASK variant only)
 };
 
-template <bool FULL>
+template <bool FULL, bool MASK = false>
 __device__ __forceinline__ void attn_chunk(const AttnCtx& a, int ibA, int j0, const f32x4& qA, const f32x4& qB,
                                            AttnState& sa, AttnState& sb) {
     const int nb = FULL ? 4 : ((a.L - j0 + 15) >> 4);
@@ -319,8 +324,15 @@ __device__ __forceinline__ void attn_chunk(const AttnCtx& a, int ibA, int j0, co
             sB[jb] = splat4(0.f);
         }
     }
-    attn_softmax<FULL>(sA, c, g, j0, nb, a.L, sa);
-    attn_softmax<FULL>(sB, c, g, j0, nb, a.L, sb);
+    if (MASK) {
+        const int ibB = ibA + 1 < a.Lb ? ibA + 1 : a.Lb - 1;
+        const int la = ibA * 16 + c, lb = ibB * 16 + c;
+        attn_softmax<FULL, true>(sA, c, g, j0, nb, a.L, sa, a.mk, a.mk[la < a.L ? la : a.L - 1] != 0);
+        attn_softmax<FULL, true>(sB, c, g, j0, nb, a.L, sb, a.mk, a.mk[lb < a.L ? lb : a.L - 1] != 0);
+    } else {
+        attn_softmax<FULL>(sA, c, g, j0, nb, a.L, sa);
+        attn_softmax<FULL>(sB, c, g, j0, nb, a.L, sb);
+    }
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
         if (FULL || jb < nb) {
@@ -334,10 +346,11 @@ __device__ __forceinline__ void attn_chunk(const AttnCtx& a, int ibA, int j0, co
     }
 }
 
+template <bool MASK>
 __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                    const float* __restrict__ v, const float* __restrict__ rel,
                                                    int max_pos, float* __restrict__ o, int L, int Lb, int npairs,
-                                                   long total) {
+                                                   long total, const unsigned char* __restrict__ mask) {
     __shared__ float rbuf[4][2][80 * RSTRIDE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long item = (long)blockIdx.x * 4 + wv;          // (n*4 + h) * npairs + pair
@@ -349,6 +362,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
     a.lane = lane; a.c = lane & 15; a.g = lane >> 4;
     a.RA = rbuf[wv][0]; a.RB = rbuf[wv][1];
     a.Lb = Lb; a.L = L; a.max_pos = max_pos; a.rel = rel;
+    a.mk = MASK ? mask + (nh >> 2) * L : nullptr;
     a.qp = q + nh * Lb * 256 + lane * 4;
     a.kp = k + nh * Lb * 256 + lane * 4;
     a.vp = v + nh * Lb * 256 + lane * 4;
@@ -358,8 +372,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ q, 
     sa.m = sb.m = 0.f; sa.run = sb.run = -INFINITY; sa.l = sb.l = 0.f; sa.o = sb.o = splat4(0.f);
     const int nfull = L >> 6;
 #pragma unroll 1
-    for (int ch = 0; ch < nfull; ++ch) attn_chunk<true>(a, ibA, ch * 64, qA, qB, sa, sb);
-    if (L & 63) attn_chunk<false>(a, ibA, nfull * 64, qA, qB, sa, sb);
+    for (int ch = 0; ch < nfull; ++ch) attn_chunk<true, MASK>(a, ibA, ch * 64, qA, qB, sa, sb);
+    if (L & 63) attn_chunk<false, MASK>(a, ibA, nfull * 64, qA, qB, sa, sb);
 
     stg4(o + (nh * Lb + ibA) * 256 + lane * 4, sa.o * splat4(__builtin_amdgcn_rcpf(sa.l)));
     if (ibA + 1 < Lb) stg4(o + (nh * Lb + ibA + 1) * 256 + lane * 4, sb.o * splat4(__builtin_amdgcn_rcpf(sb.l)));
@@ -588,7 +602,7 @@ void launch_dwconv(LaunchCtx ctx, const float* u, float* out, const float* dw_w,
 }
 
 void conformer_forward(LaunchCtx ctx, const ConfWeights& w, const ConfBuffers& b, const TokMap& seq, long M,
-                       float* taps, bool outer_residual) {
+                       float* taps, bool outer_residual, const unsigned char* mask) {
     const TokMap flat = make_flat_map(M);
     const int N = seq.nblocks / seq.Lb;
     hipStream_t s = ctx.stream;
@@ -603,8 +617,12 @@ void conformer_forward(LaunchCtx ctx, const ConfWeights& w, const ConfBuffers& b
                                                                                   b.q, b.k, b.v)));
     const int npairs = (seq.Lb + 1) / 2;
     const long items = (long)N * 4 * npairs;
-    LAUNCH(ctx, "attn", (attn_kernel<<<(unsigned)((items + 3) / 4), 256, 0, s>>>(b.q, b.k, b.v, w.rel, w.max_pos,
-                                                                                  b.o, seq.L, seq.Lb, npairs, items)));
+    if (mask)
+        LAUNCH(ctx, "attn", (attn_kernel<true><<<(unsigned)((items + 3) / 4), 256, 0, s>>>(
+                                b.q, b.k, b.v, w.rel, w.max_pos, b.o, seq.L, seq.Lb, npairs, items, mask)));
+    else
+        LAUNCH(ctx, "attn", (attn_kernel<false><<<(unsigned)((items + 3) / 4), 256, 0, s>>>(
+                                b.q, b.k, b.v, w.rel, w.max_pos, b.o, seq.L, seq.Lb, npairs, items, nullptr)));
     LAUNCH(ctx, "outproj",
            (outproj_kernel<<<grid_for_blocks(seq.nblocks), 256, 0, s>>>(b.xb, seq, b.o, w.wo, w.bo)));
     if (taps) hipMemcpyAsync(taps + (size_t)M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);

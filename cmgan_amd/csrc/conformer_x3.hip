@@ -280,24 +280,30 @@ struct AttState {
 // Scaling an empty accumulator is skipped (0 * exp2(+big) would be NaN).
 #define ATT_HI 12.0f
 #define ATT_LO -4.0f
-template <bool FULL>
-__device__ __forceinline__ void att_softmax(f32x4 (&s)[4], int c, int g, int j0, int nb, int L, AttState& st) {
+// MASK (ConformerBlock.forward(x, mask), conformer.py:113-126): mk = the sequence's [L] byte mask, qvalid = this lane's
+// query is unmasked.  A pair keeps its score only if query AND key are unmasked; the reference fills every other score
+// with -finfo.max, so an unmasked query ignores masked keys (p = 0) and a masked query attends uniformly to all L keys
+// (all its scores equal: 0 here).  A query whose keys so far were all masked has run = -inf ("dead"): it contributes
+// p = 0 and keeps its reference level untouched.
+template <bool FULL, bool MASK = false>
+__device__ __forceinline__ void att_softmax(f32x4 (&s)[4], int c, int g, int j0, int nb, int L, AttState& st,
+                                            const unsigned char* __restrict__ mk = nullptr, bool qvalid = true) {
     float mx = -INFINITY;
 #pragma unroll
     for (int jb = 0; jb < 4; ++jb) {
         if (FULL || jb < nb) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (!FULL) {
-                    const int key = j0 + 16 * jb + 4 * g + r;
-                    s[jb][r] = key < L ? s[jb][r] : -INFINITY;          // select, no branch
-                }
+                const int key = j0 + 16 * jb + 4 * g + r;
+                if (!FULL) s[jb][r] = key < L ? s[jb][r] : -INFINITY;   // select, no branch
+                if (MASK && (FULL || key < L)) s[jb][r] = qvalid ? (mk[key] ? s[jb][r] : -INFINITY) : 0.f;
                 mx = fmaxf(mx, s[jb][r]);
             }
         }
     }
     const float run = fmaxf(st.run, red_g_max(mx));
-    const bool drift = run > ATT_HI || run < ATT_LO;
+    const bool dead = MASK && run == -INFINITY;
+    const bool drift = !dead && (run > ATT_HI || run < ATT_LO);
     float psum = 0.f;
     if (__any(drift)) {                                  // rare: re-reference this query block to its running maximum
         const float alpha = st.l > 0.f ? __builtin_amdgcn_exp2f(-run) : 1.0f;
@@ -306,7 +312,7 @@ __device__ __forceinline__ void att_softmax(f32x4 (&s)[4], int c, int g, int j0,
             if (FULL || jb < nb) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(s[jb][r] - run);
+                    const float p = dead ? 0.f : __builtin_amdgcn_exp2f(s[jb][r] - run);
                     s[jb][r] = p;
                     psum += p;
                 }
@@ -316,8 +322,10 @@ __device__ __forceinline__ void att_softmax(f32x4 (&s)[4], int c, int g, int j0,
         }
         st.l *= alpha;
         st.o = st.o * splat4(alpha);
-        st.m += run;
-        st.run = 0.f;
+        if (!dead) {
+            st.m += run;
+            st.run = 0.f;
+        }
     } else {
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) {
@@ -341,12 +349,13 @@ struct AttCtx {
     const _Float16 *qbase, *kbase, *vbase, *ebase;
     float *RA, *RB;
     int qoff1, qoff2, nblk16, Lb, Lb2, L, max_pos, c, g;
+    const unsigned char* mk;          // this sequence's attention mask row (MASK variants only)
 };
 
 // one 64-key chunk for the wave's (up to) four query blocks; FULL = all 64 keys exist; HASB = the second block of
 // the pair exists (false only for the last pair of a sequence with an odd number of 16-token blocks - L = 321 -> 21,
 // L = 101 -> 7: one of 8 query-block slots of a frequency-axis sequence - whose B half is then not computed at all)
-template <bool FULL, bool HASB = true>
+template <bool FULL, bool HASB = true, bool MASK = false>
 __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttState (&st)[ATT_NQ]) {
     const int nb = FULL ? 4 : ((a.L - j0 + 15) >> 4);     // live 16-key blocks (tail chunk: 1..4)
     const int c = a.c, g = a.g;
@@ -428,8 +437,14 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb)
             if (FULL || jb < nb) { sA[jb] = mfma32l(kf[jb], qA2, sA[jb]); if (HASB) sB[jb] = mfma32l(kf[jb], qB2, sB[jb]); }
-        att_softmax<FULL>(sA, c, g, j0, nb, a.L, sa);
-        if (HASB) att_softmax<FULL>(sB, c, g, j0, nb, a.L, sb);
+        if (MASK) {
+            const int la = ibA * 16 + c, lb = qB * 16 + c;
+            att_softmax<FULL, true>(sA, c, g, j0, nb, a.L, sa, a.mk, a.mk[la < a.L ? la : a.L - 1] != 0);
+            if (HASB) att_softmax<FULL, true>(sB, c, g, j0, nb, a.L, sb, a.mk, a.mk[lb < a.L ? lb : a.L - 1] != 0);
+        } else {
+            att_softmax<FULL>(sA, c, g, j0, nb, a.L, sa);
+            if (HASB) att_softmax<FULL>(sB, c, g, j0, nb, a.L, sb);
+        }
 #pragma unroll
         for (int mp = 0; mp < 2; ++mp) {
             if (FULL || 2 * mp < nb) {
@@ -470,6 +485,7 @@ __global__ __launch_bounds__(256, ATT_WAVES) void attn_x3_kernel(QkvOut io, cons
     a.vbase = io.vimg + nh * Lb2 * 1024 + lane * 8;
     a.ebase = eimg + a.g * 8;
     a.qoff1 = ((a.g & 1) * 16 + a.c) * 8; a.qoff2 = ((2 + (a.g & 1)) * 16 + a.c) * 8;
+    a.mk = nullptr;
 
     AttState st[ATT_NQ];
 #pragma unroll
@@ -500,11 +516,12 @@ __global__ __launch_bounds__(256, ATT_WAVES) void attn_x3_kernel(QkvOut io, cons
 // Blocks run in XCD-contiguous order: the query pairs of a sequence follow each other on one XCD, so the
 // K / V images of its four heads are fetched into that L2 once.
 // ---------------------------------------------------------------------------------
+template <bool MASK>
 __global__ __launch_bounds__(256, ATT_WAVES) void attn_out_x3_kernel(QkvOut io, const _Float16* __restrict__ eimg,
                                                              int max_pos, float* __restrict__ x, TokMap m,
                                                              const _Float16* __restrict__ woi,
                                                              const float* __restrict__ bo, int Lb2, int nqg,
-                                                             long nblocks) {
+                                                             long nblocks, const unsigned char* __restrict__ mask) {
     __shared__ __attribute__((aligned(16))) float rbuf[4][2][80 * RSTRIDE_X + 4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long lblk = XCD_ORDER ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
@@ -522,6 +539,7 @@ __global__ __launch_bounds__(256, ATT_WAVES) void attn_out_x3_kernel(QkvOut io, 
     a.vbase = io.vimg + nh * Lb2 * 1024 + lane * 8;
     a.ebase = eimg + a.g * 8;
     a.qoff1 = ((a.g & 1) * 16 + a.c) * 8; a.qoff2 = ((2 + (a.g & 1)) * 16 + a.c) * 8;
+    a.mk = MASK ? mask + (long)n * L : nullptr;
 
     AttState st[ATT_NQ];
 #pragma unroll
@@ -531,12 +549,12 @@ __global__ __launch_bounds__(256, ATT_WAVES) void attn_out_x3_kernel(QkvOut io, 
     const int nfull = L >> 6;
     if (!ATT_SKIP_DEAD || ibb + 1 < Lb) {                  // block-uniform: both query blocks of the pair exist
 #pragma unroll 1
-        for (int ch = 0; ch < nfull; ++ch) att_chunk<true, true>(a, ibb, ch * 64, st);
-        if (L & 63) att_chunk<false, true>(a, ibb, nfull * 64, st);
+        for (int ch = 0; ch < nfull; ++ch) att_chunk<true, true, MASK>(a, ibb, ch * 64, st);
+        if (L & 63) att_chunk<false, true, MASK>(a, ibb, nfull * 64, st);
     } else {
 #pragma unroll 1
-        for (int ch = 0; ch < nfull; ++ch) att_chunk<true, false>(a, ibb, ch * 64, st);
-        if (L & 63) att_chunk<false, false>(a, ibb, nfull * 64, st);
+        for (int ch = 0; ch < nfull; ++ch) att_chunk<true, false, MASK>(a, ibb, ch * 64, st);
+        if (L & 63) att_chunk<false, false, MASK>(a, ibb, nfull * 64, st);
         st[1].l = 1.f;                                     // never accumulated: keep the (unused) stash finite
     }
 
@@ -987,7 +1005,7 @@ static int ffn_grid(int ntiles) {                         // one persistent Feed
 }
 
 void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeightsX3& w16, const ConfBuffers& b,
-                          const TokMap& seq, long M, float* taps, bool outer_residual) {
+                          const TokMap& seq, long M, float* taps, bool outer_residual, const unsigned char* mask) {
     hipStream_t s = ctx.stream;
     const int N = seq.nblocks / seq.Lb;
     const int Lb2 = (seq.Lb + 1) / 2;
@@ -1011,8 +1029,13 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
 #if ATTN_FUSE_OUT
         static_assert(ATT_NQ == 2, "the fused to_out epilogue stashes one pair of O tiles per head");
         const long nb = (long)N * nqg;
-        LAUNCH(ctx, "attn_out", (attn_out_x3_kernel<<<XCD_ORDER ? (unsigned)(((nb + 7) / 8) * 8) : (unsigned)nb, 256, 0, s>>>(
-                                    io, w16.rel_img, w.max_pos, b.xb, seq, w16.wo, w.bo, Lb2, nqg, nb)));
+        const unsigned agrid = XCD_ORDER ? (unsigned)(((nb + 7) / 8) * 8) : (unsigned)nb;
+        if (mask)
+            LAUNCH(ctx, "attn_out", (attn_out_x3_kernel<true><<<agrid, 256, 0, s>>>(io, w16.rel_img, w.max_pos, b.xb, seq, w16.wo,
+                                                                                  w.bo, Lb2, nqg, nb, mask)));
+        else
+            LAUNCH(ctx, "attn_out", (attn_out_x3_kernel<false><<<agrid, 256, 0, s>>>(io, w16.rel_img, w.max_pos, b.xb, seq, w16.wo,
+                                                                                   w.bo, Lb2, nqg, nb, nullptr)));
     }
 #else
         const long waves = (long)N * 4 * nqg;

@@ -108,8 +108,9 @@ TokMap make_seq_map(int N, int L, int inner, long outer, long istride, long lstr
 size_t conf_qkv_floats(int N, int L);   // floats of one of q/k/v/o for N sequences of length L (Lb rounded up to even)
 // one ConformerBlock on the residual stream in bufs.xa (in place); taps (may be NULL) -> 4 x [M,64].
 // outer_residual: add the block's input again after post_norm (what TSCB does, generator.py:95,97).
+// mask (may be NULL): [N, L] bytes, non-zero = keep - ConformerBlock.forward(x, mask), conformer.py:113-126, 217.
 void conformer_forward(LaunchCtx, const ConfWeights&, const ConfBuffers&, const TokMap& seq, long M, float* taps,
-                       bool outer_residual);
+                       bool outer_residual, const unsigned char* mask = nullptr);
 
 // --------------------------- x3 mode (f16 split products) ------------------------
 struct ConfWeightsX3 {
@@ -117,7 +118,7 @@ struct ConfWeightsX3 {
     const _Float16* rel_img;    // [2*max_pos+1][hi 16 | lo 16] halfs
 };
 void conformer_forward_x3(LaunchCtx, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&, const TokMap& seq,
-                          long M, float* taps, bool outer_residual);
+                          long M, float* taps, bool outer_residual, const unsigned char* mask = nullptr);
 void launch_dwconv(LaunchCtx, const float* u, float* out, const float* dw_w, const float* dw_b, const TokMap& seq);
 int  conv3x_ntiles(int T, int F, int cout);
 void launch_conv3_x3(LaunchCtx, const ConvArgs&, const void* w16, int B, int time_taps, int cout);

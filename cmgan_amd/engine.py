@@ -227,7 +227,8 @@ class Engine:
         return real, imag, st
 
     @_on_device
-    def conformer_forward(self, index: int, x: torch.Tensor, taps: bool = False):
+    def conformer_forward(self, index: int, x: torch.Tensor, taps: bool = False, mask: Optional[torch.Tensor] = None):
+        """mask: [N, L] bool (or any integer / float tensor, non-zero = keep) - ConformerBlock.forward(x, mask)."""
         self._need_weights()
         x = self._in(x, "x")
         N, L, C = x.shape
@@ -236,9 +237,19 @@ class Engine:
         ws = self._conf_workspace(N, L)
         y = torch.empty_like(x)
         tp = torch.empty(4, N, L, 64, dtype=torch.float32, device=x.device) if taps else None
-        check(self._h, self.lib.cmgan_conformer_forward(self._h, index, x.data_ptr(), N, L, y.data_ptr(),
-                                                        tp.data_ptr() if taps else None, ws.data_ptr(),
-                                                        ws.numel(), self._stream()))
+        if mask is None:
+            check(self._h, self.lib.cmgan_conformer_forward(self._h, index, x.data_ptr(), N, L, y.data_ptr(),
+                                                            tp.data_ptr() if taps else None, ws.data_ptr(),
+                                                            ws.numel(), self._stream()))
+        else:
+            if tuple(mask.shape) != (N, L):
+                raise ValueError(f"mask must be [N, L] = [{N}, {L}], got {tuple(mask.shape)}")
+            if mask.device != x.device:
+                raise ValueError(f"mask is on {mask.device}, x on {x.device}")
+            mk = (mask != 0).to(torch.uint8).contiguous()
+            check(self._h, self.lib.cmgan_conformer_forward_masked(self._h, index, x.data_ptr(), N, L, mk.data_ptr(),
+                                                                   y.data_ptr(), tp.data_ptr() if taps else None,
+                                                                   ws.data_ptr(), ws.numel(), self._stream()))
         return (y, tp) if taps else y
 
     @_on_device

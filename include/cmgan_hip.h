@@ -387,6 +387,14 @@ size_t cmgan_conformer_workspace_bytes(const cmgan_handle* h, int N, int L);
 int cmgan_conformer_forward(cmgan_handle* h, int index, const float* x_dev, int N, int L,
                             float* y_dev, float* taps_dev,
                             void* workspace_dev, size_t workspace_bytes, void* stream);
+/* The same with the attention mask of ConformerBlock.forward(x, mask) (conformer.py:113-126, 217):
+ * mask_dev [N, L] bytes, non-zero = keep.  A (query i, key j) pair keeps its score only when both are kept; every
+ * other score is the reference's -finfo.max, i.e. kept queries ignore masked keys and a masked query attends
+ * uniformly to all L keys.  Only the attention uses the mask (feed-forward, conv module and norms see every row),
+ * exactly like the reference.  CMGAN itself never passes one (generator.py:95,97).                              */
+int cmgan_conformer_forward_masked(cmgan_handle* h, int index, const float* x_dev, int N, int L,
+                                   const unsigned char* mask_dev, float* y_dev, float* taps_dev,
+                                   void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Stage taps of TSCNet.forward for parity tests (NCHW like the reference so the
  * tests read like the reference's module outputs); any pointer may be NULL:

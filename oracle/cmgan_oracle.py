@@ -110,8 +110,10 @@ def feed_forward_train(sd, p, x, mask1=None, mask2=None):
     return 0.5 * h
 
 
-def attention(sd, p, x, heads: int = 4, max_pos: int = 512):
+def attention(sd, p, x, heads: int = 4, max_pos: int = 512, mask=None):
     """PreNorm(Attention) with Shaw relative positions (conformer.py:75-133).
+    `mask` [b, n] bool (conformer.py:113-126): pairs (i, j) with mask_i AND mask_j keep their score, every other
+    score becomes -finfo.max - so a masked QUERY row attends uniformly to all n keys, like in the reference.
     bias[i,j] = q_i . E[clamp(i-j, +-512) + 512]; the reference materialises
     E[dist] as [n, n, d]; here q E^T is formed once ([.., n, 1025]) and gathered
     along the relative index - the same sums, a Toeplitz read."""
@@ -130,7 +132,11 @@ def attention(sd, p, x, heads: int = 4, max_pos: int = 512):
     rel = (idx[:, None] - idx[None, :]).clamp(-max_pos, max_pos) + max_pos   # [n, n]
     qe = torch.matmul(q, emb.t())                                           # b h n 1025
     pos = torch.gather(qe, -1, rel.expand(q.shape[0], heads, n, n)) * scale
-    attn = torch.softmax(dots + pos, dim=-1)
+    dots = dots + pos
+    if mask is not None:
+        pair = mask[:, None, :, None] & mask[:, None, None, :]
+        dots = dots.masked_fill(~pair, -torch.finfo(dots.dtype).max)
+    attn = torch.softmax(dots, dim=-1)
     out = torch.matmul(attn, v).transpose(1, 2).reshape(x.shape[0], n, heads * d)
     return F.linear(out, sd[p + ".fn.to_out.weight"], sd[p + ".fn.to_out.bias"])
 
@@ -182,13 +188,13 @@ def conv_module_train(sd, p, x, running: dict | None = None, kernel: int = 31):
     return h.transpose(1, 2)
 
 
-def conformer_block(sd, p, x, stages: dict | None = None):
+def conformer_block(sd, p, x, stages: dict | None = None, mask=None):
     """ConformerBlock.forward (conformer.py:216-222).  x: [N, L, 64].
     ``stages`` (optional dict) receives the residual stream after each sub-module."""
     pre = (p + ".") if p else ""
     x = feed_forward(sd, pre + "ff1", x) + x
     if stages is not None: stages["ff1"] = x
-    x = attention(sd, pre + "attn", x) + x
+    x = attention(sd, pre + "attn", x, mask=mask) + x
     if stages is not None: stages["attn"] = x
     x = conv_module(sd, pre + "conv", x) + x
     if stages is not None: stages["conv"] = x

@@ -116,6 +116,17 @@ def main():
     assert torch.equal(out, blk(x))
     save("conformer.npz", x=x, ff1=s1, attn=s2, conv=s3, ff2=s4, out=out)
 
+    # -- 2b. ConformerBlock.forward(x, mask) (conformer.py:216-217, 113-126): ragged lengths as a [b, n] bool mask, plus
+    #        an arbitrary (non-prefix) mask; masked query rows attend uniformly, as the reference's masked_fill makes them
+    xm = rnd((4, 83, 64), 14)
+    mk = torch.zeros(4, 83, dtype=torch.bool)
+    for row, n_valid in enumerate((83, 40, 7)):
+        mk[row, :n_valid] = True
+    mk[3] = torch.rand(83, generator=torch.Generator().manual_seed(15)) > 0.4
+    mk[3, :70] &= (torch.arange(70) % 64 != 63)              # ... and a fully masked stretch inside one 64-key chunk
+    mk[3, 64:83] = False
+    save("conformer_mask.npz", x=xm, mask=mk.to(torch.uint8), out=blk(xm, mask=mk), attn=blk.attn(blk.ff1(xm) + xm, mask=mk))
+
     # -- 3. attention beyond max_pos_emb (clamp active, n = 600) ---------------
     xl = rnd((1, 600, 64), 12)
     save("attention_long.npz", x=xl, out=blk.attn(xl))

@@ -156,6 +156,31 @@ def test_conformer_matches_oracle_over_lengths(conf, n, l):
     assert _report(f"conformer[{n}x{l}].out", rel_err(y, want)) < STAGE
 
 
+def test_conformer_attention_mask_matches_reference_golden(conf):
+    """ConformerBlock.forward(x, mask) (conformer.py:216-217, 113-126): ragged lengths and an arbitrary pattern with
+    masked query rows (uniform attention) and a chunk whose keys are all masked for some queries."""
+    g = load_golden("conformer_mask.npz")
+    y = conf(g["x"].to(DEV), mask=g["mask"].bool().to(DEV))
+    _check("conformer(x, mask) vs golden", y, g["out"], gate=STAGE)
+    # the unmasked call is untouched by the masked variant, and an all-True mask equals no mask bit for bit
+    y0 = conf(g["x"].to(DEV))
+    assert torch.equal(conf(g["x"].to(DEV), mask=torch.ones(4, 83, dtype=torch.bool, device=DEV)), y0)
+
+
+@pytest.mark.parametrize("n,l,seed", [(3, 321, 1), (5, 101, 2), (2, 130, 3)])
+def test_conformer_attention_mask_over_lengths_vs_oracle(conf, n, l, seed):
+    """random masks at the path's own sequence lengths, incl. sequences whose first 64-key chunk is fully masked."""
+    csd = conformer_state_dict(seed=3)
+    rng = np.random.Generator(np.random.PCG64(500 + seed))
+    x = torch.from_numpy(rng.standard_normal((n, l, 64)).astype(np.float32))
+    mask = torch.from_numpy(rng.random((n, l)) > 0.3)
+    mask[0, :min(l, 70)] = False                      # dead first chunk for the kept queries of sequence 0
+    mask[0, -1] = True
+    want = O.conformer_block(csd, "", x, mask=mask)
+    y = conf(x.to(DEV), mask=mask.to(DEV))
+    assert _report(f"conformer[{n}x{l}](x, mask)", rel_err(y, want)) < STAGE
+
+
 def test_conformer_rel_pos_clamp_beyond_512(conf):
     """n = 600 > max_pos_emb: distances saturate at +-512 (conformer.py:108)."""
     g = load_golden("attention_long.npz")

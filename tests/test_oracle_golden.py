@@ -386,6 +386,15 @@ def test_adversarial_generator_gradients(sd):
     assert errs[len(errs) // 2] < 2e-5 and errs[-1] < 3e-2
 
 
+def test_conformer_block_with_attention_mask():
+    """ConformerBlock.forward(x, mask): the [b, n] bool mask of conformer.py:113-126 (ragged lengths and an arbitrary
+    pattern incl. fully masked query rows)."""
+    g = load_golden("conformer_mask.npz")
+    csd = conformer_state_dict(seed=3)
+    out = O.conformer_block(csd, "", g["x"], mask=g["mask"].bool())
+    assert rel_err(out, g["out"]) < TOL
+
+
 def test_validation_step_losses_match_the_reference(sd):
     """Generator half of Trainer.test_step: forward_generator_step + the three non-adversarial loss terms."""
     g = load_golden("valstep.npz")
