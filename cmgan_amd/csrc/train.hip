@@ -303,6 +303,78 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* __restr
     }
 }
 
+// The same contraction with a 64 x 64 output tile per block (all four 16-row blocks of a 64-row band): the 16 x 64
+// version re-read Q once per row block and P once per column block - 664 MB of L2 / HBM reads for the 166 MB of
+// operands of one FeedForward weight gradient, which is what bounded it (83 us at 8 TB/s of cache traffic).  Here a
+// wave-step loads 16 + 16 operand dwords for 64 MFMAs; the four waves' tiles are combined through 32 KB of LDS in a
+// fixed order.  Grid (R / 64, C / 64, WG_SPLIT).
+#define WG_SPLIT 256
+__global__ __launch_bounds__(256) void wgrad_partial64_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                              long M, int R, int C, float* __restrict__ partial) {
+    __shared__ float red[2][64 * 64];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int ic = blockIdx.x, jc = blockIdx.y, s = blockIdx.z;
+    const long steps = (M + 15) / 16, per = (steps + WG_SPLIT - 1) / WG_SPLIT;
+    const long st0 = (long)s * per, st1 = st0 + per < steps ? st0 + per : steps;
+    f32x4 acc[4][4];                                  // [ib][jb]
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = splat4(0.f);
+    for (long st = st0 + wv; st < st1; st += 4) {
+        f32x4 a[4], b[4];                             // [ib][r], [jb][r]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long m = st * 16 + 4 * g + r;
+            const bool ok = m < M;
+            const long mm = ok ? m : M - 1;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) a[ib][r] = ok ? P[mm * R + 64 * ic + 16 * ib + c] : 0.f;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) b[jb][r] = ok ? Q[mm * C + 64 * jc + 16 * jb + c] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma16(a[ib][r], b[jb][r], acc[ib][jb]);
+    }
+    // (wave 2 + wave 0), (wave 3 + wave 1), then (wave 1 + wave 0): element (row 16 ib + 4 g + r, col 16 jb + c)
+    auto put = [&](float* dst) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(16 * ib + 4 * g + r) * 64 + 16 * jb + c] = acc[ib][jb][r];
+    };
+    auto add = [&](const float* src) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ib][jb][r] += src[(16 * ib + 4 * g + r) * 64 + 16 * jb + c];
+    };
+    if (wv >= 2) put(red[wv - 2]);
+    __syncthreads();
+    if (wv < 2) add(red[wv]);
+    __syncthreads();
+    if (wv == 1) put(red[0]);
+    __syncthreads();
+    if (wv == 0) {
+        add(red[0]);
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    partial[((long)s * R + 64 * ic + 16 * ib + 4 * g + r) * C + 64 * jc + 16 * jb + c] = acc[ib][jb][r];
+    }
+}
+
 // column sums of X [M,C] over NB fixed row ranges -> partial [NB][C]; four independent accumulators per thread keep
 // four loads in flight (the loop is latency-bound otherwise), combined in a fixed order
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ X, long M, int C,
@@ -438,7 +510,7 @@ static FfnTrainImg ffn_pack_images(LaunchCtx ctx, const FfnTrainParams& p, float
 }
 
 size_t ffn_train_ws_floats(long M) {
-    return (size_t)4 * 16384 + (size_t)M * 768 + (size_t)FFN_WGRAD_SPLIT * 16384 * 2 +
+    return (size_t)4 * 16384 + (size_t)M * 768 + (size_t)WG_SPLIT * 16384 * 2 +
            (size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256;
 }
 
@@ -456,17 +528,16 @@ void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, l
     float* act = ws + 4 * 16384;
     FfnBwdBufs o{act, act + M * 64, act + M * 320, act + M * 576, act + M * 640, act + M * 704};
     float* part = act + M * 768;                                  // [SPLIT][16384] x 2, then colsum slabs
-    float* cpart = part + (size_t)FFN_WGRAD_SPLIT * 16384 * 2;
+    float* cpart = part + (size_t)WG_SPLIT * 16384 * 2;
     const unsigned grid = (unsigned)((M + 63) / 64);
     LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_kernel<<<grid, 256, 0, s>>>(x, dy, M, w, m1, m2, dx, o)));
     // dW2 [64,256] = dz^T d1 ; dW1 [256,64] = dh^T xn
-    LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial_kernel<<<dim3(4, 4, FFN_WGRAD_SPLIT), 256, 0, s>>>(
-                                       o.dz, o.d1, M, 64, 256, FFN_WGRAD_SPLIT, part)));
-    LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial_kernel<<<dim3(16, 1, FFN_WGRAD_SPLIT), 256, 0, s>>>(
-                                       o.dh, o.xn, M, 256, 64, FFN_WGRAD_SPLIT, part + (size_t)FFN_WGRAD_SPLIT * 16384)));
-    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<64, 256, 0, s>>>(part, FFN_WGRAD_SPLIT, 16384, grad.w2)));
-    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<64, 256, 0, s>>>(part + (size_t)FFN_WGRAD_SPLIT * 16384,
-                                                                               FFN_WGRAD_SPLIT, 16384, grad.w1)));
+    LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 4, WG_SPLIT), 256, 0, s>>>(o.dz, o.d1, M, 64, 256, part)));
+    LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial64_kernel<<<dim3(4, 1, WG_SPLIT), 256, 0, s>>>(o.dh, o.xn, M, 256, 64,
+                                                                                              part + (size_t)WG_SPLIT * 16384)));
+    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part, WG_SPLIT, 16384, grad.w2)));
+    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part + (size_t)WG_SPLIT * 16384, WG_SPLIT, 16384,
+                                                                                 grad.w1)));
     const ColsumJobs jobs{{o.dh, o.dz, o.g1, o.dxn}, {grad.b1, grad.b2, grad.gamma, grad.beta}, {256, 64, 64, 64}};
     colsum_batch(ctx, "ffn_train_reduce", jobs, 4, M, cpart);
 }
@@ -885,7 +956,7 @@ static CmPlan cm_plan(int N, int L) {
     p.u = take(M * 128); p.d = take(M * 128); p.st = take(512);
     p.ddn = take(M * 128); p.s = take(M * 128); p.g2 = take(M * 128); p.du = take(M * 128);
     p.dag = take(M * 256); p.xn = take(M * 64); p.g1 = take(M * 64); p.dxn = take(M * 64);
-    p.wpart = take((size_t)FFN_WGRAD_SPLIT * 16384);
+    p.wpart = take((size_t)WG_SPLIT * 16384);
     p.dwpart = take((size_t)CM_DW_SLABS * 3968);
     p.bnpart = take(nblk * 256);
     p.bnred = take((size_t)CM_BN_RED * 256 * 2);        // doubles
@@ -947,9 +1018,9 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     LAUNCH(ctx, "convmod_train_bwd", (cm_bwd1_kernel<<<grid, 256, 0, s>>>(dy, ws + pl.d, M, st, im.w2t, ws + pl.ddn,
                                                                           ws + pl.s, ws + pl.g2)));
     // pointwise-2 gradients: dW_pw2 [64,128] = dy^T s, db_pw2 = colsum dy
-    LAUNCH(ctx, "convmod_train_wgrad", (wgrad_partial_kernel<<<dim3(4, 2, FFN_WGRAD_SPLIT), 256, 0, s>>>(
-                                           dy, ws + pl.s, M, 64, 128, FFN_WGRAD_SPLIT, ws + pl.wpart)));
-    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<32, 256, 0, s>>>(ws + pl.wpart, FFN_WGRAD_SPLIT, 8192,
+    LAUNCH(ctx, "convmod_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 2, WG_SPLIT), 256, 0, s>>>(dy, ws + pl.s, M, 64, 128,
+                                                                                                  ws + pl.wpart)));
+    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<128, 1024, 0, s>>>(ws + pl.wpart, WG_SPLIT, 8192,
                                                                                    grad.pw2_w)));
     // BatchNorm: dbeta = sum ddn, dgamma = sum ddn dhat; then dd in place   (+ db_pw2 = colsum dy in the same pair of launches)
     {
@@ -973,9 +1044,9 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
                                                                           ws + pl.dag, ws + pl.xn, ws + pl.g1,
                                                                           ws + pl.dxn)));
     // pointwise-1 and LayerNorm gradients
-    LAUNCH(ctx, "convmod_train_wgrad", (wgrad_partial_kernel<<<dim3(16, 1, FFN_WGRAD_SPLIT), 256, 0, s>>>(
-                                           ws + pl.dag, ws + pl.xn, M, 256, 64, FFN_WGRAD_SPLIT, ws + pl.wpart)));
-    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<64, 256, 0, s>>>(ws + pl.wpart, FFN_WGRAD_SPLIT, 16384,
+    LAUNCH(ctx, "convmod_train_wgrad", (wgrad_partial64_kernel<<<dim3(4, 1, WG_SPLIT), 256, 0, s>>>(ws + pl.dag, ws + pl.xn, M, 256,
+                                                                                                  64, ws + pl.wpart)));
+    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(ws + pl.wpart, WG_SPLIT, 16384,
                                                                                    grad.pw1_w)));
     const ColsumJobs jobs{{ws + pl.dag, ws + pl.g1, ws + pl.dxn}, {grad.pw1_b, grad.ln_w, grad.ln_b}, {256, 64, 64}};
     colsum_batch(ctx, "convmod_train_reduce", jobs, 3, M, cpart);
@@ -1438,7 +1509,7 @@ static AtPlan at_plan(int N, int L) {
     p.xn = take(M * 64); p.g1 = take(M * 64); p.dxn = take(M * 64);
     p.depart = take((size_t)N * 4 * (2 * L - 1) * 16);
     p.dewin = take((size_t)(2 * L - 1) * 16);
-    p.wpart = take((size_t)FFN_WGRAD_SPLIT * 12288);
+    p.wpart = take((size_t)WG_SPLIT * 12288);
     p.cpart = take((size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256);
     p.total = cur;
     return p;
@@ -1485,9 +1556,9 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     LAUNCH(ctx, "attn_train_bwd", (at_out_bwd_kernel<<<grid, 256, 0, s>>>(dy, mask, b.o, M, ws + pl.wot, ws + pl.dout,
                                                                           ws + pl.dO, ws + pl.D)));
     // to_out gradients: dWo [64,64] = dout^T O, dbo = colsum dout
-    LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial_kernel<<<dim3(4, 1, FFN_WGRAD_SPLIT), 256, 0, s>>>(
-                                        ws + pl.dout, b.o, M, 64, 64, FFN_WGRAD_SPLIT, ws + pl.wpart)));
-    LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<16, 256, 0, s>>>(ws + pl.wpart, FFN_WGRAD_SPLIT, 4096,
+    LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 1, WG_SPLIT), 256, 0, s>>>(ws + pl.dout, b.o, M, 64, 64,
+                                                                                               ws + pl.wpart)));
+    LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<64, 1024, 0, s>>>(ws + pl.wpart, WG_SPLIT, 4096,
                                                                                 grad.wo)));
     // attention core: dq (rows), dk / dv (columns), dE (distances)
     const AtSplit sp = at_split(L), spe = at_split(2 * L - 1);
@@ -1515,9 +1586,9 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     // projections + LayerNorm
     LAUNCH(ctx, "attn_train_bwd", (at_qkv_bwd_kernel<<<grid, 256, 0, s>>>(x, ws + pl.dqkv, M, ws + pl.wqkvt, p.ln_w, p.ln_b,
                                                                           dx, ws + pl.xn, ws + pl.g1, ws + pl.dxn)));
-    LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial_kernel<<<dim3(12, 1, FFN_WGRAD_SPLIT), 256, 0, s>>>(
-                                        ws + pl.dqkv, ws + pl.xn, M, 192, 64, FFN_WGRAD_SPLIT, ws + pl.wpart)));
-    LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<48, 256, 0, s>>>(ws + pl.wpart, FFN_WGRAD_SPLIT, 12288,
+    LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial64_kernel<<<dim3(3, 1, WG_SPLIT), 256, 0, s>>>(ws + pl.dqkv, ws + pl.xn, M, 192,
+                                                                                               64, ws + pl.wpart)));
+    LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<192, 1024, 0, s>>>(ws + pl.wpart, WG_SPLIT, 12288,
                                                                                 ws + pl.raw)));      // [192,64], then split
     hipMemcpyAsync(grad.wq, ws + pl.raw, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);
     hipMemcpyAsync(grad.wkv, ws + pl.raw + 4096, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);
