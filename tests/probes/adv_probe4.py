@@ -1,7 +1,7 @@
 """Stage-by-stage check of the complex decoder's backward through its workspace planes (debug probe)."""
 import sys, numpy as np, torch
 import torch.nn.functional as F
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from oracle import cmgan_oracle as O
 from oracle.weights import make_state_dict
 from cmgan_amd.training import DecoderTrain

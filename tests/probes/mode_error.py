@@ -3,7 +3,7 @@
 2 x 2 s synthetic clips and on the three real-recording goldens - used once to quote the error of the
 single-product fp16 experiment (cmgan_amd.build variant "x1") next to the shipped f16x3 mode."""
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from cmgan_amd import TSCNet

@@ -643,7 +643,7 @@ def test_adversarial_train_step_matches_the_reference_trainer():
     for name, v in groups.items():
         _report(f"adversarial step: gradient error, median over the tensors of {name}", float(np.median(v)))
     _report("adversarial step: generator gradients, median error relative to each tensor's max", float(np.median(errs)))
-    # Measured with tools/probes/adv_probe4.py: the HIP forward is 1e-6 from torch's, which is enough to put ~1 of the
+    # Measured with tests/probes/adv_probe4.py: the HIP forward is 1e-6 from torch's, which is enough to put ~1 of the
     # 853 k InstanceNorm outputs in front of a decoder's PReLU on the other side of zero.  That single element changes
     # dL/ds there by O(1) and every gradient UPSTREAM of it by 1e-4 .. 1e-3 of the tensor's max (seen here: the complex
     # decoder's head, so everything but the mask decoder sits at 3.6e-4; the mask decoder, which shares all kernels,
