@@ -99,6 +99,23 @@ def test_product_package_never_imports_the_oracle():
             assert not re.search(r"import_module\(|__import__\(|sys\.path", src), fn
 
 
+def test_only_the_allowed_places_touch_the_oracle():
+    """Outside tests/, only bench.py's cpu_baseline leg and __graft_entry__.smoke() may import oracle/: tools/ never,
+    and the two root scripts only inside those two functions."""
+    tools = os.path.join(ROOT, "tools")
+    for dirpath, _, files in os.walk(tools):
+        for fn in files:
+            if fn.endswith((".py", ".sh")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(dirpath, fn)
+    for script, func in (("bench.py", "cpu_baseline"), ("__graft_entry__.py", "smoke")):
+        src = open(os.path.join(ROOT, script)).read()
+        for m in re.finditer(r"^\s*(from|import)\s+oracle\b", src, re.M):
+            head = src[:m.start()]
+            owner = re.findall(r"^def\s+(\w+)\(", head, re.M)[-1]       # the enclosing top-level function
+            assert owner == func, (script, owner)
+
+
 def test_engine_fails_loudly_without_gpu():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
