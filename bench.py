@@ -237,8 +237,10 @@ def train_leg(eng, sd, dev, rank, world, barrier, batch=4, cut_len=32000, steps=
     RI + magnitude + time + GAN loss, metric discriminator on given PESQ labels; per step TWO gradient all-reduces over
     the flat buckets - 7.3 MB generator, 0.7 MB discriminator - and two AdamW launches).  Timed like the main leg:
     barrier + synchronize on both sides, MAX over ranks.  Any failure is reported in the line instead of losing it."""
+    # phase 1 - no collectives: build both networks on every rank, then agree (one MIN all-reduce) that all of them
+    # succeeded before any rank enters a step with gradient all-reduces, so a rank-local failure cannot strand the others
+    err = None
     try:
-        from cmgan_amd import dist as cdist
         from cmgan_amd.synth import discriminator_state_dict, synthetic_clips
         from cmgan_amd.training import AdamW, DiscriminatorTrain, GeneratorTrain, adversarial_train_step
         gen = GeneratorTrain(sd, engine=eng)
@@ -250,6 +252,14 @@ def train_leg(eng, sd, dev, rank, world, barrier, batch=4, cut_len=32000, steps=
         pesq = torch.full((batch,), 0.5, device=dev)
         tgen = torch.Generator(device=dev).manual_seed(rank)
         run = lambda: adversarial_train_step(gen, disc, opt_g, opt_d, clean, noisy, pesq, generator=tgen)
+    except Exception as e:                                      # noqa: BLE001 - the headline line must survive
+        err = f"{type(e).__name__}: {e}"[:300]
+    ready = torch.tensor([0.0 if err else 1.0], device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(ready, op=torch.distributed.ReduceOp.MIN)
+    if float(ready) < 1.0:
+        return {"error": err or "another rank failed to set the training leg up"}
+    try:
         run()
         torch.cuda.synchronize()
         barrier()
