@@ -1941,64 +1941,108 @@ __global__ __launch_bounds__(256) void db_conv_dgrad_kernel(const float* __restr
     }
 }
 
-// partial[tap][s][co][ci] = sum over the s-th token range of dz[m][co] * a_slot[m shifted by tap][ci]
+// partial[tap][s][co][ci] = sum over the s-th range of tokens of dz[m][co] * a[m shifted by tap][ci]
+// One block per (tap, token range) computes the whole 64 x 64 tile (every operand row is loaded once per tap instead
+// of once per 16 output channels), and the (clip, t, f) coordinates of a lane's four tokens come from ONE 32-bit
+// division per step plus carries - the first version spent as many VALU cycles on 64-bit divisions as the matrix pipe
+// spent on the products.
+#define DB_WG_SPLIT 128
 __global__ __launch_bounds__(256) void db_conv_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ a, int B,
-                                                            int T, int F, int dil, int nsplit,
-                                                            float* __restrict__ partial) {
-    __shared__ float red[4][16 * 64];
+                                                            int T, int F, int dil, float* __restrict__ partial) {
+    __shared__ float red[2][64 * 64];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-    const int ib = blockIdx.x, tap = blockIdx.y, s = blockIdx.z;
+    const int tap = blockIdx.x, s = blockIdx.y;
     const int kt = tap / 3, kf = tap - 3 * kt, dt = (kt - 1) * dil, df = kf - 1;
-    const long M = (long)B * T * F, tf = (long)T * F;
-    const long steps = (M + 15) / 16, per = (steps + nsplit - 1) / nsplit;
-    const long st0 = (long)s * per, st1 = st0 + per < steps ? st0 + per : steps;
-    f32x4 acc[4];
+    const unsigned M = (unsigned)B * T * F, tf = (unsigned)T * F;
+    const unsigned steps = (M + 15) / 16, per = (steps + DB_WG_SPLIT - 1) / DB_WG_SPLIT;
+    const unsigned st0 = s * per, st1 = st0 + per < steps ? st0 + per : steps;
+    f32x4 acc[4][4];                                  // [ib][jb]
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb) acc[jb] = splat4(0.f);
-    for (long st = st0 + wv; st < st1; st += 4) {
-        float av[4];
-        f32x4 bv[4];
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = splat4(0.f);
+    for (unsigned st = st0 + wv; st < st1; st += 4) {
+        const unsigned m0 = st * 16 + 4 * g;
+        unsigned bb = m0 / tf;
+        const unsigned rem = m0 - bb * tf;
+        int t = (int)(rem / (unsigned)F), f = (int)(rem - (unsigned)t * F);
+        f32x4 av[4], bv[4];                           // [ib][r], [jb][r]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long m = st * 16 + 4 * g + r;
+            const unsigned m = m0 + r;
             const bool ok = m < M;
+            const int ts = t + dt, fs = f + df;
+            const bool inb = ok && ts >= 0 && ts < T && fs >= 0 && fs < F;
+            const long src = inb ? ((long)bb * T + ts) * F + fs : 0;
             const long mm = ok ? m : M - 1;
-            const int b = (int)(mm / tf), rem = (int)(mm - (long)b * tf), t = rem / F + dt, f = rem % F + df;
-            const bool inb = ok && t >= 0 && t < T && f >= 0 && f < F;
-            const long src = inb ? ((long)b * T + t) * F + f : 0;
-            av[r] = ok ? dz[mm * 64 + 16 * ib + c] : 0.f;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) av[ib][r] = ok ? dz[mm * 64 + 16 * ib + c] : 0.f;
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) {
                 const float v = a[src * 64 + 16 * jb + c];
                 bv[jb][r] = inb ? v : 0.f;
             }
+            if (++f == F) { f = 0; if (++t == T) { t = 0; ++bb; } }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb) acc[jb] = mfma16(av[r], bv[jb][r], acc[jb]);
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma16(av[ib][r], bv[jb][r], acc[ib][jb]);
     }
+    auto put = [&](float* dst) {
 #pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
+        for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wv][(4 * g + r) * 64 + 16 * jb + c] = acc[jb][r];
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(16 * ib + 4 * g + r) * 64 + 16 * jb + c] = acc[ib][jb][r];
+    };
+    auto add = [&](const float* src) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ib][jb][r] += src[(16 * ib + 4 * g + r) * 64 + 16 * jb + c];
+    };
+    if (wv >= 2) put(red[wv - 2]);
     __syncthreads();
-    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
-        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-        const int i = e >> 6, j = e & 63;
-        partial[(((long)tap * nsplit + s) * 64 + 16 * ib + i) * 64 + j] = v;
+    if (wv < 2) add(red[wv]);
+    __syncthreads();
+    if (wv == 1) put(red[0]);
+    __syncthreads();
+    if (wv == 0) {
+        add(red[0]);
+        float* out = partial + ((long)tap * DB_WG_SPLIT + s) * 4096;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(16 * ib + 4 * g + r) * 64 + 16 * jb + c] = acc[ib][jb][r];
     }
 }
-
-// dW[co][cbase + ci][kt][kf] = sum_s partial[tap][s][co][ci]        (conv weight [64, Cin, 2, 3], tap = kt 3 + kf)
-__global__ void db_wgrad_scatter_kernel(const float* __restrict__ partial, int nsplit, int Cin, int cbase,
-                                        float* __restrict__ dW) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 6 * 4096) return;
-    const int tap = idx / 4096, e = idx - tap * 4096, co = e >> 6, ci = e & 63;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[((long)tap * nsplit + k) * 4096 + e];
-    dW[((long)co * Cin + cbase + ci) * 6 + tap] = s;
+// dW[co][cbase + ci][tap] = sum_s partial[tap][s][co][ci]: a block owns 64 consecutive (co, ci) of one tap, its four
+// thread groups add every fourth slab (coalesced), combined in group order
+__global__ __launch_bounds__(256) void db_wgrad_scatter_kernel(const float* __restrict__ partial, int Cin, int cbase,
+                                                               float* __restrict__ dW) {
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int tap = blockIdx.x >> 6, e = (blockIdx.x & 63) * 64 + col;
+    float s0 = 0.f, s1 = 0.f;
+    for (int k = grp; k < DB_WG_SPLIT; k += 8) {
+        s0 += partial[((long)tap * DB_WG_SPLIT + k) * 4096 + e];
+        s1 += partial[((long)tap * DB_WG_SPLIT + k + 4) * 4096 + e];
+    }
+    red[grp][col] = s0 + s1;
+    __syncthreads();
+    if (grp == 0) {
+        const float sum = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        const int co = e >> 6, ci = e & 63;
+        dW[((long)co * Cin + cbase + ci) * 6 + tap] = sum;
+    }
 }
 
 struct DbPlan { size_t img, imgT, a, z, ga, mean, rstd, part, m1, m2, wpart, cpart, total; };
@@ -2014,7 +2058,7 @@ static DbPlan db_plan(int B, int T, int F) {
     p.mean = take((size_t)4 * B * 64); p.rstd = take((size_t)4 * B * 64);
     p.part = take((size_t)B * DB_NCH * 64 * 3);
     p.m1 = take((size_t)B * 64); p.m2 = take((size_t)B * 64);
-    p.wpart = take((size_t)6 * FFN_WGRAD_SPLIT * 4096);
+    p.wpart = take((size_t)6 * DB_WG_SPLIT * 4096);
     p.cpart = take((size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256);
     p.total = cur;
     return p;
@@ -2114,10 +2158,10 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
                                                                                ws + pl.m1, ws + pl.m2)));
         const int dil = 1 << i, Cin = 64 * (i + 1);
         for (int s = 0; s <= i; ++s) {
-            LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_kernel<<<dim3(4, 6, FFN_WGRAD_SPLIT), 256, 0, st>>>(
-                                                 g, aslot(s), B, T, F, dil, FFN_WGRAD_SPLIT, ws + pl.wpart)));
-            LAUNCH(ctx, "dense_train_reduce", (db_wgrad_scatter_kernel<<<96, 256, 0, st>>>(ws + pl.wpart, FFN_WGRAD_SPLIT, Cin,
-                                                                                           64 * (i - s), grad.conv_w[i])));
+            LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_kernel<<<dim3(6, DB_WG_SPLIT), 256, 0, st>>>(
+                                                 g, aslot(s), B, T, F, dil, ws + pl.wpart)));
+            LAUNCH(ctx, "dense_train_reduce", (db_wgrad_scatter_kernel<<<6 * 64, 256, 0, st>>>(ws + pl.wpart, Cin, 64 * (i - s),
+                                                                                               grad.conv_w[i])));
             LAUNCH(ctx, "dense_train_bwd", (db_conv_dgrad_kernel<<<(unsigned)((M + 63) / 64), 256, 0, st>>>(
                                                g, ws + pl.imgT + (long)db_img_index(i, s) * 4096, B, T, F, dil, ga(s))));
         }
