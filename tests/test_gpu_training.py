@@ -257,10 +257,11 @@ def test_attention_train_matches_reference_autograd():
         assert_close(grads[k], want, rtol=1e-3, atol_rel=2e-4, name=k)
 
 
-@pytest.mark.parametrize("n,l", [(2, 321), (3, 101)])
+@pytest.mark.parametrize("n,l", [(2, 321), (3, 101), (1, 512), (2, 7), (1, 65)])
 def test_attention_train_full_length_sequences_vs_oracle_autograd(n, l):
-    """the two sequence lengths of the 2 s training clip (time axis T = 321: 87 KB of LDS per block; frequency axis
-    F' = 101), no dropout."""
+    """the two sequence lengths of the 2 s training clip (time axis T = 321, frequency axis F' = 101), the longest
+    supported sequence (512: every thread-split / LDS-merge configuration at its limit), and two short ones whose
+    row x reduction-subset split has more subsets than keys per subset; no dropout."""
     from cmgan_amd.training import AttentionTrain
     csd = conformer_state_dict(seed=3)
     at = AttentionTrain({k: csd["attn." + k] for k in AT_KEYS})
