@@ -36,25 +36,25 @@ static FfnTrainParams ffn_params(const cmgan_ffn_params* p) {
 }
 
 extern "C" int cmgan_ffn_train_forward(cmgan_handle* h, const float* x, long long M, const cmgan_ffn_params* params,
-                                       const float* mask1, const float* mask2, float* y, void* ws, size_t ws_bytes,
-                                       void* stream) {
+                                       const unsigned char* mask1, const unsigned char* mask2, float mask_scale,
+                                       float* y, void* ws, size_t ws_bytes, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !y || M <= 0 || !ffn_params_ok(params)) return fail(h, CMGAN_E_BADARG, "cmgan_ffn_train_forward: bad argument");
     if (int rc = check_ws(h, ws, ws_bytes, ffn_train_ws_floats((long)M) * sizeof(float))) return rc;
-    launch_ffn_train_forward(begin(h, stream), x, (long)M, ffn_params(params), mask1, mask2, y, (float*)ws);
+    launch_ffn_train_forward(begin(h, stream), x, (long)M, ffn_params(params), mask1, mask2, mask_scale, y, (float*)ws);
     return check_launch(h, "ffn_train_forward");
 }
 
 extern "C" int cmgan_ffn_train_backward(cmgan_handle* h, const float* x, const float* dy, long long M,
-                                        const cmgan_ffn_params* params, const float* mask1, const float* mask2,
-                                        float* dx, const cmgan_ffn_params* grads, void* ws, size_t ws_bytes,
-                                        void* stream) {
+                                        const cmgan_ffn_params* params, const unsigned char* mask1,
+                                        const unsigned char* mask2, float mask_scale, float* dx,
+                                        const cmgan_ffn_params* grads, void* ws, size_t ws_bytes, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !dy || !dx || M <= 0 || !ffn_params_ok(params) || !ffn_params_ok(grads))
         return fail(h, CMGAN_E_BADARG, "cmgan_ffn_train_backward: bad argument");
     if (int rc = check_ws(h, ws, ws_bytes, ffn_train_ws_floats((long)M) * sizeof(float))) return rc;
-    launch_ffn_train_backward(begin(h, stream), x, dy, (long)M, ffn_params(params), mask1, mask2, dx, ffn_params(grads),
-                              (float*)ws);
+    launch_ffn_train_backward(begin(h, stream), x, dy, (long)M, ffn_params(params), mask1, mask2, mask_scale, dx,
+                              ffn_params(grads), (float*)ws);
     return check_launch(h, "ffn_train_backward");
 }
 
@@ -112,27 +112,30 @@ static AttnTrainParams attn_params(const cmgan_attn_params* p) {
 }
 
 extern "C" int cmgan_attn_train_forward(cmgan_handle* h, const float* x, int N, int L, const cmgan_attn_params* params,
-                                        const float* mask, float* y, void* ws, size_t ws_bytes, void* stream) {
+                                        const unsigned char* mask, float mask_scale, float* y, void* ws,
+                                        size_t ws_bytes, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !y || N <= 0 || L <= 0 || !attn_params_ok(params))
         return fail(h, CMGAN_E_BADARG, "cmgan_attn_train_forward: bad argument");
     if (L > attn_train_max_len())
         return fail(h, CMGAN_E_UNSUPPORTED, "cmgan_attn_train: sequences up to %d positions (got %d)", attn_train_max_len(), L);
     if (int rc = check_ws(h, ws, ws_bytes, attn_train_ws_floats(N, L) * sizeof(float))) return rc;
-    launch_attn_train_forward(begin(h, stream), x, N, L, attn_params(params), h->cfg.max_pos_emb, mask, y, (float*)ws);
+    launch_attn_train_forward(begin(h, stream), x, N, L, attn_params(params), h->cfg.max_pos_emb, mask, mask_scale, y,
+                              (float*)ws);
     return check_launch(h, "attn_train_forward");
 }
 
 extern "C" int cmgan_attn_train_backward(cmgan_handle* h, const float* x, const float* dy, int N, int L,
-                                         const cmgan_attn_params* params, const float* mask, float* dx,
-                                         const cmgan_attn_params* grads, void* ws, size_t ws_bytes, void* stream) {
+                                         const cmgan_attn_params* params, const unsigned char* mask, float mask_scale,
+                                         float* dx, const cmgan_attn_params* grads, void* ws, size_t ws_bytes,
+                                         void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !dy || !dx || N <= 0 || L <= 0 || !attn_params_ok(params) || !attn_params_ok(grads))
         return fail(h, CMGAN_E_BADARG, "cmgan_attn_train_backward: bad argument");
     if (L > attn_train_max_len())
         return fail(h, CMGAN_E_UNSUPPORTED, "cmgan_attn_train: sequences up to %d positions (got %d)", attn_train_max_len(), L);
     if (int rc = check_ws(h, ws, ws_bytes, attn_train_ws_floats(N, L) * sizeof(float))) return rc;
-    launch_attn_train_backward(begin(h, stream), x, dy, N, L, attn_params(params), h->cfg.max_pos_emb, mask, dx,
+    launch_attn_train_backward(begin(h, stream), x, dy, N, L, attn_params(params), h->cfg.max_pos_emb, mask, mask_scale, dx,
                                attn_params(grads), (float*)ws);
     return check_launch(h, "attn_train_backward");
 }

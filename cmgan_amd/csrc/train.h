@@ -19,10 +19,12 @@ struct FfnTrainParams {
 #define FFN_WGRAD_SPLIT 64
 #define FFN_COLSUM_BLOCKS 512
 size_t ffn_train_ws_floats(long M);
-void launch_ffn_train_forward(LaunchCtx, const float* x, long M, const FfnTrainParams& p, const float* m1,
-                              const float* m2, float* y, float* ws);
+// dropout keep-masks: bytes (non-zero = keep), kept values scaled by mask_scale = 1 / (1 - p); NULL = no dropout
+void launch_ffn_train_forward(LaunchCtx, const float* x, long M, const FfnTrainParams& p, const unsigned char* m1,
+                              const unsigned char* m2, float mask_scale, float* y, float* ws);
 void launch_ffn_train_backward(LaunchCtx, const float* x, const float* dy, long M, const FfnTrainParams& p,
-                               const float* m1, const float* m2, float* dx, const FfnTrainParams& grad, float* ws);
+                               const unsigned char* m1, const unsigned char* m2, float mask_scale, float* dx,
+                               const FfnTrainParams& grad, float* ws);
 
 // training-mode ConformerConvModule (BatchNorm1d on batch statistics) forward + backward on raw parameters
 struct ConvModTrainParams {
@@ -47,9 +49,10 @@ struct AttnTrainParams {
 size_t attn_train_ws_floats(int N, int L);
 int attn_train_max_len();
 void launch_attn_train_forward(LaunchCtx, const float* x, int N, int L, const AttnTrainParams& p, int max_pos,
-                               const float* mask, float* y, float* ws);
+                               const unsigned char* mask, float mask_scale, float* y, float* ws);
 void launch_attn_train_backward(LaunchCtx, const float* x, const float* dy, int N, int L, const AttnTrainParams& p,
-                                int max_pos, const float* mask, float* dx, const AttnTrainParams& grad, float* ws);
+                                int max_pos, const unsigned char* mask, float mask_scale, float* dx,
+                                const AttnTrainParams& grad, float* ws);
 void launch_swap_axes(LaunchCtx, const float* in, float* out, int B, int A, int C);
 void launch_add(LaunchCtx, const float* a, const float* b, float* out, long n);
 size_t ln_train_ws_floats(long M);

@@ -120,6 +120,18 @@ __global__ void pack_fm_kernel(const float* __restrict__ w, int R, int K, int ld
     out[i] = transpose ? w[(long)col * ldw + row] : w[(long)row * ldw + col];
 }
 
+// Dropout keep-masks are BYTES (non-zero = keep; the kept values are scaled by `ms` = 1 / (1 - p)): a quarter of the
+// traffic of float masks - per conformer block and token 704 mask values are read in the forward and again in the backward
+__device__ __forceinline__ f32x4 mask4(const unsigned char* __restrict__ m, long idx, float ms) {
+    const unsigned v = *reinterpret_cast<const unsigned*>(m + idx);          // idx is a multiple of 4
+    f32x4 r;
+    r[0] = (v & 0x000000ffu) ? ms : 0.f;
+    r[1] = (v & 0x0000ff00u) ? ms : 0.f;
+    r[2] = (v & 0x00ff0000u) ? ms : 0.f;
+    r[3] = (v & 0xff000000u) ? ms : 0.f;
+    return r;
+}
+
 struct FfnTrainImg {
     const float *w1, *w2, *w2t, *w1t;     // fm [16][4], [4][16], [16][4], [4][16]
     const float *gamma, *beta, *b1, *b2;
@@ -145,8 +157,9 @@ __device__ __forceinline__ bool ffn_load_norm(const float* __restrict__ x, long 
 }
 
 __global__ __launch_bounds__(256) void ffn_train_fwd_kernel(const float* __restrict__ x, long M, FfnTrainImg w,
-                                                            const float* __restrict__ m1,
-                                                            const float* __restrict__ m2, float* __restrict__ y) {
+                                                            const unsigned char* __restrict__ m1,
+                                                            const unsigned char* __restrict__ m2, float ms,
+                                                            float* __restrict__ y) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (t0 >= M) return;
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(256) void ffn_train_fwd_kernel(const float* __restr
         f32x4 s;
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[r] = swishf(h[0][r]);
-        if (m1) s = s * ldg4(m1 + row * 256 + 16 * hb + 4 * g);
+        if (m1) s = s * mask4(m1, row * 256 + 16 * hb + 4 * g, ms);
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {
             const f32x4 a = ldg4(w.w2 + ((long)ob * 16 + hb) * 256 + lane * 4);
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(256) void ffn_train_fwd_kernel(const float* __restr
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {
             f32x4 v = acc[ob] * splat4(0.5f);
-            if (m2) v = v * ldg4(m2 + row * 64 + 16 * ob + 4 * g);
+            if (m2) v = v * mask4(m2, row * 64 + 16 * ob + 4 * g, ms);
             stg4(y + row * 64 + 16 * ob + 4 * g, v);
         }
     }
@@ -187,8 +200,9 @@ struct FfnBwdBufs {
 };
 
 __global__ __launch_bounds__(256) void ffn_train_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                            long M, FfnTrainImg w, const float* __restrict__ m1,
-                                                            const float* __restrict__ m2, float* __restrict__ dx,
+                                                            long M, FfnTrainImg w, const unsigned char* __restrict__ m1,
+                                                            const unsigned char* __restrict__ m2, float ms,
+                                                            float* __restrict__ dx,
                                                             FfnBwdBufs o) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(256) void ffn_train_bwd_kernel(const float* __restr
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
         f32x4 v = ldg4(dy + row * 64 + 16 * ob + 4 * g) * splat4(0.5f);
-        if (m2) v = v * ldg4(m2 + row * 64 + 16 * ob + 4 * g);
+        if (m2) v = v * mask4(m2, row * 64 + 16 * ob + 4 * g, ms);
         if (!ok) v = splat4(0.f);                       // padding tokens of the last block contribute nothing
         dz[0][ob] = v;
         if (ok) {
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(256) void ffn_train_bwd_kernel(const float* __restr
         f32x4 dd1[1] = {splat4(0.f)};
         lin_acc<4, 1>(w.w2t + (long)hb * 4 * 256 + lane * 4, dz, dd1);
         f32x4 mk = splat4(1.f);
-        if (m1) mk = ldg4(m1 + row * 256 + 16 * hb + 4 * g);
+        if (m1) mk = mask4(m1, row * 256 + 16 * hb + 4 * g, ms);
         f32x4 d1v, dhv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -514,15 +528,16 @@ size_t ffn_train_ws_floats(long M) {
            (size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256;
 }
 
-void launch_ffn_train_forward(LaunchCtx ctx, const float* x, long M, const FfnTrainParams& p, const float* m1,
-                              const float* m2, float* y, float* ws) {
+void launch_ffn_train_forward(LaunchCtx ctx, const float* x, long M, const FfnTrainParams& p, const unsigned char* m1,
+                              const unsigned char* m2, float ms, float* y, float* ws) {
     const FfnTrainImg w = ffn_pack_images(ctx, p, ws);
     const unsigned grid = (unsigned)((M + 63) / 64);
-    LAUNCH(ctx, "ffn_train_fwd", (ffn_train_fwd_kernel<<<grid, 256, 0, ctx.stream>>>(x, M, w, m1, m2, y)));
+    LAUNCH(ctx, "ffn_train_fwd", (ffn_train_fwd_kernel<<<grid, 256, 0, ctx.stream>>>(x, M, w, m1, m2, ms, y)));
 }
 
 void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, long M, const FfnTrainParams& p,
-                               const float* m1, const float* m2, float* dx, const FfnTrainParams& grad, float* ws) {
+                               const unsigned char* m1, const unsigned char* m2, float ms, float* dx,
+                               const FfnTrainParams& grad, float* ws) {
     hipStream_t s = ctx.stream;
     const FfnTrainImg w = ffn_pack_images(ctx, p, ws, false);
     float* act = ws + 4 * 16384;
@@ -530,7 +545,7 @@ void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, l
     float* part = act + M * 768;                                  // [SPLIT][16384] x 2, then colsum slabs
     float* cpart = part + (size_t)WG_SPLIT * 16384 * 2;
     const unsigned grid = (unsigned)((M + 63) / 64);
-    LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_kernel<<<grid, 256, 0, s>>>(x, dy, M, w, m1, m2, dx, o)));
+    LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_kernel<<<grid, 256, 0, s>>>(x, dy, M, w, m1, m2, ms, dx, o)));
     // dW2 [64,256] = dz^T d1 ; dW1 [256,64] = dh^T xn
     LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 4, WG_SPLIT), 256, 0, s>>>(o.dz, o.d1, M, 64, 256, part)));
     LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial64_kernel<<<dim3(4, 1, WG_SPLIT), 256, 0, s>>>(o.dh, o.xn, M, 256, 64,
@@ -1198,7 +1213,7 @@ __global__ __launch_bounds__(1024) void at_core_fwd_kernel(AtBufs b, const float
 
 // y = mask * (Wo O + bo)
 __global__ __launch_bounds__(256) void at_out_kernel(const float* __restrict__ o, long M, const float* __restrict__ wofm,
-                                                     const float* __restrict__ bo, const float* __restrict__ mask,
+                                                     const float* __restrict__ bo, const unsigned char* __restrict__ mask, float ms,
                                                      float* __restrict__ y) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
@@ -1213,13 +1228,13 @@ __global__ __launch_bounds__(256) void at_out_kernel(const float* __restrict__ o
     for (int ob = 0; ob < 4; ++ob) {
         f32x4 acc[1] = {ldg4(bo + 16 * ob + 4 * g)};
         lin_acc<4, 1>(wofm + (long)ob * 4 * 256 + lane * 4, of, acc);
-        if (mask) acc[0] = acc[0] * ldg4(mask + row * 64 + 16 * ob + 4 * g);
+        if (mask) acc[0] = acc[0] * mask4(mask, row * 64 + 16 * ob + 4 * g, ms);
         if (ok) stg4(y + row * 64 + 16 * ob + 4 * g, acc[0]);
     }
 }
 
 // backward of to_out: dout = mask dy (kept for dWo / dbo), dO = Wo^T dout, D[token][head] = sum_d dO O
-__global__ __launch_bounds__(256) void at_out_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ mask,
+__global__ __launch_bounds__(256) void at_out_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ mask, float ms,
                                                          const float* __restrict__ o, long M,
                                                          const float* __restrict__ wotfm, float* __restrict__ dout,
                                                          float* __restrict__ dO, float* __restrict__ D) {
@@ -1233,7 +1248,7 @@ __global__ __launch_bounds__(256) void at_out_bwd_kernel(const float* __restrict
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
         f32x4 v = ldg4(dy + row * 64 + 16 * ob + 4 * g);
-        if (mask) v = v * ldg4(mask + row * 64 + 16 * ob + 4 * g);
+        if (mask) v = v * mask4(mask, row * 64 + 16 * ob + 4 * g, ms);
         dyf[0][ob] = v;
         if (ok) stg4(dout + row * 64 + 16 * ob + 4 * g, v);
     }
@@ -1529,7 +1544,7 @@ static void at_pack_images(LaunchCtx ctx, const AttnTrainParams& p, float* ws, c
 }
 
 void launch_attn_train_forward(LaunchCtx ctx, const float* x, int N, int L, const AttnTrainParams& p, int max_pos,
-                               const float* mask, float* y, float* ws) {
+                               const unsigned char* mask, float ms, float* y, float* ws) {
     hipStream_t s = ctx.stream;
     const AtPlan pl = at_plan(N, L);
     const long M = (long)N * L;
@@ -1541,11 +1556,12 @@ void launch_attn_train_forward(LaunchCtx ctx, const float* x, int N, int L, cons
     const size_t shm = at_lds_bytes((size_t)(2 * L - 1) * AT_P, sp, 18);
     at_allow_lds(at_core_fwd_kernel, shm);
     LAUNCH(ctx, "attn_train_fwd", (at_core_fwd_kernel<<<dim3(N, 4), sp.qpb * sp.ks, shm, s>>>(b, p.rel, L, max_pos, sp.qpb)));
-    LAUNCH(ctx, "attn_train_fwd", (at_out_kernel<<<grid, 256, 0, s>>>(b.o, M, ws + pl.wo, p.bo, mask, y)));
+    LAUNCH(ctx, "attn_train_fwd", (at_out_kernel<<<grid, 256, 0, s>>>(b.o, M, ws + pl.wo, p.bo, mask, ms, y)));
 }
 
 void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, int N, int L, const AttnTrainParams& p,
-                                int max_pos, const float* mask, float* dx, const AttnTrainParams& grad, float* ws) {
+                                int max_pos, const unsigned char* mask, float ms, float* dx, const AttnTrainParams& grad,
+                                float* ws) {
     hipStream_t s = ctx.stream;
     const AtPlan pl = at_plan(N, L);
     const long M = (long)N * L;
@@ -1553,7 +1569,7 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     const AtBufs b{ws + pl.qkv, ws + pl.o, ws + pl.lse};
     const unsigned grid = (unsigned)((M + 63) / 64);
     float* cpart = ws + pl.cpart;
-    LAUNCH(ctx, "attn_train_bwd", (at_out_bwd_kernel<<<grid, 256, 0, s>>>(dy, mask, b.o, M, ws + pl.wot, ws + pl.dout,
+    LAUNCH(ctx, "attn_train_bwd", (at_out_bwd_kernel<<<grid, 256, 0, s>>>(dy, mask, ms, b.o, M, ws + pl.wot, ws + pl.dout,
                                                                           ws + pl.dO, ws + pl.D)));
     // to_out gradients: dWo [64,64] = dout^T O, dbo = colsum dout
     LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 1, WG_SPLIT), 256, 0, s>>>(ws + pl.dout, b.o, M, 64, 64,

@@ -71,11 +71,28 @@ _SHAPES = ((64,), (64,), (256, 64), (256,), (64, 256), (64,))
 
 
 def dropout_mask(shape, p: float, device, generator: Optional[torch.Generator] = None) -> Optional[torch.Tensor]:
-    """Keep-mask of nn.Dropout(p) in train mode: Bernoulli(1-p) / (1-p), float32 (None when p == 0)."""
+    """Keep-mask of nn.Dropout(p) in train mode as BYTES: Bernoulli(1 - p) flags, uint8 (None when p == 0).  The kernels
+    multiply kept values by 1 / (1 - p) themselves; bytes because the masks are the step's largest per-token traffic."""
     if p <= 0.0:
         return None
-    keep = torch.rand(shape, device=device, generator=generator) >= p
-    return keep.to(torch.float32) / (1.0 - p)
+    return torch.empty(shape, dtype=torch.uint8, device=device).bernoulli_(1.0 - p, generator=generator)
+
+
+def _keep_mask(mask: Optional[torch.Tensor], shape, p: float, device, name: str) -> Optional[torch.Tensor]:
+    """The byte keep-mask the kernels take, from either form a caller may hold: uint8 / bool keep flags, or the float
+    mask of F.dropout's arithmetic (entries 0 or 1 / (1 - p), as the reference-derived fixtures store them)."""
+    if mask is None:
+        return None
+    if mask.device != torch.device(device):
+        raise ValueError(f"{name} is on {mask.device}, the engine on {device}")
+    if mask.is_floating_point():
+        if p <= 0.0:
+            raise ValueError(f"{name}: a float dropout mask needs the module's dropout probability to be > 0")
+        kept = mask[mask != 0]
+        if kept.numel() and float((kept - 1.0 / (1.0 - p)).abs().max()) > 1e-5:
+            raise ValueError(f"{name}: float mask entries must be 0 or 1/(1-p) = {1.0 / (1.0 - p):.6f}")
+        mask = mask != 0
+    return mask.reshape(shape).to(torch.uint8).contiguous()
 
 
 def generator_loss_terms(engine: Engine, est_real, est_imag, clean_spec, est_audio, clean_audio,
@@ -153,6 +170,9 @@ class FeedForwardTrain:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.engine.device)
         return self._ws
 
+    def _scale(self) -> float:
+        return 1.0 / (1.0 - self.p) if self.p > 0.0 else 1.0
+
     def masks(self, M: int, generator: Optional[torch.Generator] = None):
         """Fresh keep-masks for the two Dropout layers (conformer.py:142,144)."""
         dev = self.engine.device
@@ -165,15 +185,16 @@ class FeedForwardTrain:
         shape = x.shape
         x2 = eng._in(x.reshape(-1, 64), "x")
         M = x2.size(0)
-        m1 = eng._in(mask1.reshape(M, 256), "mask1") if mask1 is not None else None
-        m2 = eng._in(mask2.reshape(M, 64), "mask2") if mask2 is not None else None
+        m1 = _keep_mask(mask1, (M, 256), self.p, eng.device, "mask1")
+        m2 = _keep_mask(mask2, (M, 64), self.p, eng.device, "mask2")
         y = torch.empty_like(x2)
         ws = self._workspace(M)
         p = self._struct(self.params)
         with torch.cuda.device(eng.device):
             check(eng._h, eng.lib.cmgan_ffn_train_forward(
                 eng._h, x2.data_ptr(), M, ctypes.byref(p), m1.data_ptr() if m1 is not None else None,
-                m2.data_ptr() if m2 is not None else None, y.data_ptr(), ws.data_ptr(), ws.numel(), eng._stream()))
+                m2.data_ptr() if m2 is not None else None, self._scale(), y.data_ptr(), ws.data_ptr(), ws.numel(),
+                eng._stream()))
         return y.reshape(shape)
 
     def backward(self, x: torch.Tensor, dy: torch.Tensor, mask1: Optional[torch.Tensor] = None,
@@ -183,16 +204,16 @@ class FeedForwardTrain:
         shape = x.shape
         x2, dy2 = eng._in(x.reshape(-1, 64), "x"), eng._in(dy.reshape(-1, 64), "dy")
         M = x2.size(0)
-        m1 = eng._in(mask1.reshape(M, 256), "mask1") if mask1 is not None else None
-        m2 = eng._in(mask2.reshape(M, 64), "mask2") if mask2 is not None else None
+        m1 = _keep_mask(mask1, (M, 256), self.p, eng.device, "mask1")
+        m2 = _keep_mask(mask2, (M, 64), self.p, eng.device, "mask2")
         dx = torch.empty_like(x2)
         ws = self._workspace(M)
         p, g = self._struct(self.params), self._struct(self.grads)
         with torch.cuda.device(eng.device):
             check(eng._h, eng.lib.cmgan_ffn_train_backward(
                 eng._h, x2.data_ptr(), dy2.data_ptr(), M, ctypes.byref(p), m1.data_ptr() if m1 is not None else None,
-                m2.data_ptr() if m2 is not None else None, dx.data_ptr(), ctypes.byref(g), ws.data_ptr(), ws.numel(),
-                eng._stream()))
+                m2.data_ptr() if m2 is not None else None, self._scale(), dx.data_ptr(), ctypes.byref(g), ws.data_ptr(),
+                ws.numel(), eng._stream()))
         return dx.reshape(shape), self.grads
 
     def allreduce_gradients(self) -> torch.Tensor:
@@ -403,13 +424,14 @@ class AttentionTrain:
         N, L, C = x.shape
         if C != 64:
             raise ValueError("conformer dim must be 64")
-        m = eng._in(mask.reshape(N, L, 64), "mask") if mask is not None else None
+        m = _keep_mask(mask, (N, L, 64), self.p, eng.device, "mask")
         ws = self._workspace(N, L)
         y = torch.empty_like(x)
         p = self._struct(self.params)
+        scale = 1.0 / (1.0 - self.p) if self.p > 0.0 else 1.0
         with torch.cuda.device(eng.device):
             check(eng._h, eng.lib.cmgan_attn_train_forward(eng._h, x.data_ptr(), N, L, ctypes.byref(p),
-                                                           m.data_ptr() if m is not None else None, y.data_ptr(),
+                                                           m.data_ptr() if m is not None else None, scale, y.data_ptr(),
                                                            ws.data_ptr(), ws.numel(), eng._stream()))
         self._shape = (N, L)
         return y
@@ -420,13 +442,14 @@ class AttentionTrain:
         N, L, _ = x.shape
         if self._shape != (N, L) or dy.shape != x.shape:
             raise RuntimeError("backward() needs the forward() of the same [N, L, 64] input first")
-        m = eng._in(mask.reshape(N, L, 64), "mask") if mask is not None else None
+        m = _keep_mask(mask, (N, L, 64), self.p, eng.device, "mask")
         ws = self._workspace(N, L)
         dx = torch.empty_like(x)
         p, g = self._struct(self.params), self._struct(self.grads)
+        scale = 1.0 / (1.0 - self.p) if self.p > 0.0 else 1.0
         with torch.cuda.device(eng.device):
             check(eng._h, eng.lib.cmgan_attn_train_backward(eng._h, x.data_ptr(), dy.data_ptr(), N, L, ctypes.byref(p),
-                                                            m.data_ptr() if m is not None else None, dx.data_ptr(),
+                                                            m.data_ptr() if m is not None else None, scale, dx.data_ptr(),
                                                             ctypes.byref(g), ws.data_ptr(), ws.numel(), eng._stream()))
         return dx, self.grads
 
@@ -852,13 +875,13 @@ class GeneratorTrain:
         ps = {m.p for blk in self.blocks for c in (blk.time, blk.freq) for m in (c.ff1, c.attn, c.ff2)}
         if len(ps) != 1 or next(iter(ps)) <= 0.0:
             return [blk.masks(B, T, Fe, generator) for blk in self.blocks]
-        # all forty masks from ONE Bernoulli draw (two launches instead of 160): views of a single buffer
+        # all forty byte masks from ONE Bernoulli draw (one launch instead of 160): views of a single buffer
         p = next(iter(ps))
         widths = (("ff1_1", 256), ("ff1_2", 64), ("attn", 64), ("ff2_1", 256), ("ff2_2", 64))
         tokens = B * T * Fe
         per_axis = tokens * sum(w for _, w in widths)
-        buf = torch.empty(len(self.blocks) * 2 * per_axis, dtype=torch.float32, device=self.engine.device)
-        buf.bernoulli_(1.0 - p, generator=generator).mul_(1.0 / (1.0 - p))
+        buf = torch.empty(len(self.blocks) * 2 * per_axis, dtype=torch.uint8, device=self.engine.device)
+        buf.bernoulli_(1.0 - p, generator=generator)
         out, off = [], 0
         for _ in self.blocks:
             pair = []
@@ -1027,7 +1050,9 @@ class DiscriminatorTrain:
         return s
 
     def mask(self, B: int, generator: Optional[torch.Generator] = None) -> Optional[torch.Tensor]:
-        return dropout_mask((B, 64), self.dropout, self.engine.device, generator)
+        """Float keep-mask [B, 64] (0 or 1 / 0.7) of the Dropout(0.3): 256 bytes per clip, not worth a byte form."""
+        keep = dropout_mask((B, 64), self.dropout, self.engine.device, generator)
+        return None if keep is None else keep.to(torch.float32) / (1.0 - self.dropout)
 
     def pair(self, clean_spec: torch.Tensor, est_real: Optional[torch.Tensor] = None,
              est_imag: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -156,8 +156,9 @@ int cmgan_loss_terms(cmgan_handle* h, const float* est_real_dev, const float* es
  * Parameters are the RAW tensors of the reference state_dict for one ff{1,2} branch (row-major, device):
  *   ln_weight/ln_bias [64] = ff.fn.norm.{weight,bias};  w1 [256,64], b1 [256] = ff.fn.fn.net.0;
  *   w2 [64,256], b2 [64] = ff.fn.fn.net.3.
- * x, y, dy, dx are [M,64].  mask1 [M,256] / mask2 [M,64] are the keep-masks of the two nn.Dropout layers
- * (0 or 1/(1-p)); NULL = no dropout (p = 0 or eval).  The backward recomputes the hidden activations from x,
+ * x, y, dy, dx are [M,64].  mask1 [M,256] / mask2 [M,64] are the keep-masks of the two nn.Dropout layers as BYTES
+ * (non-zero = keep; a kept value is multiplied by mask_scale = 1/(1-p)); NULL = no dropout (p = 0 or eval) - bytes
+ * because the masks are the largest per-token traffic of the step.  The backward recomputes the hidden activations from x,
  * writes dL/dx to dx and dL/dparam to the six tensors of *grads (overwritten, not accumulated), with
  * fixed-order reductions (bit-reproducible).  Workspace: cmgan_ffn_train_workspace_bytes(h, M).            */
 typedef struct cmgan_ffn_params {
@@ -165,11 +166,12 @@ typedef struct cmgan_ffn_params {
 } cmgan_ffn_params;
 size_t cmgan_ffn_train_workspace_bytes(const cmgan_handle* h, long long M);
 int cmgan_ffn_train_forward(cmgan_handle* h, const float* x_dev, long long M, const cmgan_ffn_params* params,
-                            const float* mask1_dev, const float* mask2_dev, float* y_dev,
-                            void* workspace_dev, size_t workspace_bytes, void* stream);
+                            const unsigned char* mask1_dev, const unsigned char* mask2_dev, float mask_scale,
+                            float* y_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 int cmgan_ffn_train_backward(cmgan_handle* h, const float* x_dev, const float* dy_dev, long long M,
-                             const cmgan_ffn_params* params, const float* mask1_dev, const float* mask2_dev,
-                             float* dx_dev, const cmgan_ffn_params* grads,
+                             const cmgan_ffn_params* params, const unsigned char* mask1_dev,
+                             const unsigned char* mask2_dev, float mask_scale, float* dx_dev,
+                             const cmgan_ffn_params* grads,
                              void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Training-mode ConformerConvModule with its backward - second slice of the training step:
@@ -198,7 +200,8 @@ int cmgan_convmod_train_backward(cmgan_handle* h, const float* x_dev, const floa
 /* Training-mode PreNorm(Attention) with its backward - third slice of the training step:
  *   y = mask * to_out(softmax((q k^T + q E[clamp(i - j, +-max_pos)]^T) / 4) v),  q = to_q(LN(x)), k|v = to_kv(LN(x))
  * (src/models/conformer.py:54-72, 75-133; 4 heads of 16; the residual add of :218 stays with the caller).  `mask`
- * [N,L,64] is the keep-mask of the nn.Dropout on the to_out output (conformer.py:133; NULL = none).  Parameters are
+ * [N,L,64] is the byte keep-mask (non-zero = keep, kept values x mask_scale) of the nn.Dropout on the to_out output
+ * (conformer.py:133; NULL = none).  Parameters are
  * the RAW tensors attn.norm.{weight,bias}, attn.fn.to_q.weight [64,64], attn.fn.to_kv.weight [128,64],
  * attn.fn.to_out.{weight [64,64], bias}, attn.fn.rel_pos_emb.weight [2 max_pos + 1, 16].  L <= 512 in this slice
  * (CMGAN_E_UNSUPPORTED beyond).  The forward keeps q|k|v, the attention output and the row log-sum-exp in the
@@ -209,11 +212,11 @@ typedef struct cmgan_attn_params {
 } cmgan_attn_params;
 size_t cmgan_attn_train_workspace_bytes(const cmgan_handle* h, int N, int L);
 int cmgan_attn_train_forward(cmgan_handle* h, const float* x_dev, int N, int L, const cmgan_attn_params* params,
-                             const float* mask_dev, float* y_dev,
+                             const unsigned char* mask_dev, float mask_scale, float* y_dev,
                              void* workspace_dev, size_t workspace_bytes, void* stream);
 int cmgan_attn_train_backward(cmgan_handle* h, const float* x_dev, const float* dy_dev, int N, int L,
-                              const cmgan_attn_params* params, const float* mask_dev, float* dx_dev,
-                              const cmgan_attn_params* grads,
+                              const cmgan_attn_params* params, const unsigned char* mask_dev, float mask_scale,
+                              float* dx_dev, const cmgan_attn_params* grads,
                               void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Glue of ConformerBlock.forward in train mode (src/models/conformer.py:216-222): out = a + b over n floats (the

@@ -52,12 +52,14 @@ def test_feed_forward_train_ragged_token_count_and_determinism(ff):
     x = torch.from_numpy(rng.standard_normal((1000, 64)).astype(np.float32))
     dy = torch.from_numpy(rng.standard_normal((1000, 64)).astype(np.float32))
     gen = torch.Generator(device=DEV).manual_seed(3)
-    m1, m2 = ff.masks(1000, gen)
-    assert set(torch.unique(m1).tolist()) == {0.0, 1.25} and m2.shape == (1000, 64)
+    m1, m2 = ff.masks(1000, gen)                          # byte keep flags; F.dropout's arithmetic is flag / (1 - p)
+    assert m1.dtype == torch.uint8 and set(torch.unique(m1).tolist()) == {0, 1} and m2.shape == (1000, 64)
+    assert 0.7 < float(m1.float().mean()) < 0.9
+    f1, f2 = m1.float().cpu() * 1.25, m2.float().cpu() * 1.25
     leaf = {"ff1." + k: csd["ff1." + k].clone().requires_grad_(True) for k in KEYS}
     xr = x.clone().requires_grad_(True)
     with torch.enable_grad():
-        want_y = O.feed_forward_train(leaf, "ff1", xr, m1.cpu(), m2.cpu())
+        want_y = O.feed_forward_train(leaf, "ff1", xr, f1, f2)
         want_y.backward(dy)
     y = ff.forward(x.to(DEV), m1, m2)
     assert _report("ffn train forward M=1000", rel_err(y, want_y.detach())) < GRAD_TOL
@@ -168,7 +170,7 @@ def test_three_adamw_steps_of_the_feed_forward_branch_match_torch():
         opt.step(step_lr(0))
         ref_opt.zero_grad()
         with torch.enable_grad():
-            yr = O.feed_forward_train(leaf, "ff1", x, m1.cpu(), m2.cpu())
+            yr = O.feed_forward_train(leaf, "ff1", x, m1.float().cpu() * 1.25, m2.float().cpu() * 1.25)
             torch.mean((yr - tgt) ** 2).backward()
         ref_opt.step()
     for k in KEYS:
