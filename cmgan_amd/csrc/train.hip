@@ -95,8 +95,9 @@ void launch_loss_terms(LaunchCtx ctx, const float* est_real, const float* est_im
 // Training-mode FeedForward (first backward slice of SURVEY.md N2).
 //   y = 0.5 * m2 * (W2 (m1 * Swish(W1 LN(x) + b1)) + b2)
 // = Scale(0.5, PreNorm(dim, FeedForward(dim, mult=4, dropout)))(x) of src/models/conformer.py:54-72,136-148,211 in
-// TRAIN mode, with the two nn.Dropout layers expressed as caller-supplied keep-masks m1 [M,256], m2 [M,64] (entries 0
-// or 1/(1-p); NULL = no dropout) so that the result is reproducible and comparable with autograd on the oracle.
+// TRAIN mode, with the two nn.Dropout layers expressed as caller-supplied byte keep-masks m1 [M,256], m2 [M,64]
+// (non-zero = keep, kept values scaled by 1/(1-p); NULL = no dropout) so that the result is reproducible and comparable
+// with autograd on the oracle.
 // The residual add of ConformerBlock.forward (conformer.py:217) stays with the caller (dx_total = dy + dx).
 //
 // Same per-token transposed MFMA chain as the inference kernels (out^T = W x^T on v_mfma_f32_16x16x4_f32, a wave owns
