@@ -10,6 +10,9 @@ needs, with a numerical contract that can be stated against the reference:
 
 `W` = window, `C` = context (look-back / look-ahead "state", re-computed rather than cached: the conformers
 attend over the whole window, so a KV cache would change the result, which is why the contract is per window).
+`lookahead` (default = C) is the right-hand context alone: `lookahead=0` is the causal-chunk form - window k then
+needs no sample beyond (k+1) W, so the algorithmic latency is one window - under the same per-window contract
+(window k covers [k W - C, (k+1) W + lookahead)).
 All windows have the same shape [1, W + 2C], so the ~250 kernel launches are captured once into a hipGraph
 (`Engine.enhance_graphed`-style) and replayed per window; several windows can be batched per replay.
 """
@@ -26,20 +29,22 @@ __all__ = ["enhance_windows"]
 
 @torch.no_grad()
 def enhance_windows(model: TSCNet, noisy: torch.Tensor, window: int = 40000, context: int = 4000,
-                    batch: int = 4, graph: bool = True) -> torch.Tensor:
-    """noisy: float32 [1, L] on the GPU -> enhanced [L].  window and context must be multiples of hop."""
+                    batch: int = 4, graph: bool = True, lookahead: int | None = None) -> torch.Tensor:
+    """noisy: float32 [1, L] on the GPU -> enhanced [L].  window, context and lookahead must be multiples of hop;
+    lookahead (right-hand context) defaults to `context`, 0 = no sample beyond the window's end is used."""
     if noisy.dim() != 2 or noisy.size(0) != 1:
         raise ValueError("expected a mono track shaped [1, L]")
     eng = model.engine
     hop = eng.cfg.hop
-    if window <= 0 or window % hop or context < 0 or context % hop:
-        raise ValueError("window and context must be non-negative multiples of hop")
+    ahead = context if lookahead is None else lookahead
+    if window <= 0 or window % hop or context < 0 or context % hop or ahead < 0 or ahead % hop:
+        raise ValueError("window, context and lookahead must be non-negative multiples of hop")
     noisy = noisy.to(dtype=torch.float32).contiguous()
     L = noisy.size(-1)
     c = eng.rms_scale(noisy)                                   # file-level scale, as evaluation.py:21
     nwin = int(math.ceil(L / window))
-    span = window + 2 * context
-    padded = torch.zeros(nwin * window + 2 * context, device=noisy.device, dtype=torch.float32)
+    span = window + context + ahead
+    padded = torch.zeros(nwin * window + context + ahead, device=noisy.device, dtype=torch.float32)
     padded[context:context + L] = noisy[0] * c
     rows = padded.unfold(0, span, window).contiguous()         # [nwin, span], window k starts at k*W - C
     out = torch.empty(nwin, window, device=noisy.device, dtype=torch.float32)

@@ -370,6 +370,22 @@ def test_windowed_inference_matches_the_per_window_contract(model, sd, graph):
         assert torch.equal(got, eager)
 
 
+def test_windowed_inference_without_lookahead(model, sd):
+    """lookahead = 0 (causal chunks: the rows the oracle sees end at (k+1) W, so window k uses nothing beyond its own
+    end): the same per-window contract."""
+    from cmgan_amd.streaming import enhance_windows
+    W, C, L = 8000, 2400, 19000
+    noisy = synthetic_clips(1, L, seed=61)
+    got = enhance_windows(model, noisy.to(DEV), window=W, context=C, batch=2, graph=True, lookahead=0)
+    c = O.rms_scale(noisy)
+    padded = torch.zeros(3 * W + C)
+    padded[C:C + L] = noisy[0] * c
+    rows = padded.unfold(0, W + C, W)
+    est = O.uncompress_istft(*O.tscnet_forward(sd, O.stft_compress(rows)))
+    want = est[:, C:C + W].reshape(-1)[:L] / c
+    assert _report("enhance_windows (lookahead 0) vs oracle windows", rel_err(got, want)) < GATE
+
+
 # ------------------------------------------------------------------ real recordings, full-size rows, 48 kHz
 @pytest.mark.parametrize("tag", ["a", "b", "silence"])
 def test_real_recordings_match_reference_golden(model, tag):
