@@ -1080,7 +1080,10 @@ class DiscriminatorTrain:
             self._ws[slot] = torch.empty(need, dtype=torch.uint8, device=eng.device)
         ws = self._ws[slot]
         score = torch.empty(B, dtype=torch.float32, device=eng.device)
-        mp = eng._in(mask, "mask").data_ptr() if mask is not None else None
+        mask = eng._in(mask, "mask") if mask is not None else None        # float32, contiguous; kept for the backward
+        if mask is not None and tuple(mask.shape) != (B, 64):
+            raise ValueError(f"mask must be [B, 64] = [{B}, 64]")
+        mp = mask.data_ptr() if mask is not None else None
         p = self._struct(self.params)
         with torch.cuda.device(eng.device):
             check(eng._h, eng.lib.cmgan_disc_forward(eng._h, xy.data_ptr(), B, T, ctypes.byref(p), mp, 1 if train else 0,
