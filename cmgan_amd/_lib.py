@@ -90,23 +90,25 @@ SIGNATURES = {
                                  c_void_p, c_void_p]),
     "cmgan_ffn_train_workspace_bytes": (c_size_t, [c_void_p, c_longlong]),
     "cmgan_ffn_train_forward": (c_int, [c_void_p, c_void_p, c_longlong, POINTER(FfnParams), c_void_p, c_void_p, c_float,
-                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+                                        c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cmgan_ffn_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, POINTER(FfnParams), c_void_p,
-                                         c_void_p, c_float, c_void_p, POINTER(FfnParams), c_void_p, c_size_t, c_void_p]),
+                                         c_void_p, c_float, c_void_p, c_void_p, POINTER(FfnParams), c_void_p, c_size_t,
+                                         c_void_p]),
     "cmgan_convmod_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "cmgan_convmod_train_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(ConvModParams), c_void_p,
-                                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cmgan_convmod_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(ConvModParams),
-                                             c_void_p, POINTER(ConvModParams), c_void_p, c_size_t, c_void_p]),
+                                             c_void_p, c_void_p, POINTER(ConvModParams), c_void_p, c_size_t, c_void_p]),
     "cmgan_attn_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "cmgan_attn_train_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(AttnParams), c_void_p, c_float,
-                                         c_void_p, c_void_p, c_size_t, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cmgan_attn_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, POINTER(AttnParams), c_void_p,
-                                          c_float, c_void_p, POINTER(AttnParams), c_void_p, c_size_t, c_void_p]),
-    "cmgan_swap_axes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+                                          c_float, c_void_p, c_void_p, POINTER(AttnParams), c_void_p, c_size_t, c_void_p]),
+    "cmgan_swap_axes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cmgan_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),
     "cmgan_layernorm_train_workspace_bytes": (c_size_t, [c_void_p, c_longlong]),
-    "cmgan_layernorm_train_forward": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "cmgan_layernorm_train_forward": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p,
+                                              c_void_p]),
     "cmgan_layernorm_train_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cmgan_dense_train_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),

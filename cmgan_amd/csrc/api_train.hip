@@ -37,24 +37,26 @@ static FfnTrainParams ffn_params(const cmgan_ffn_params* p) {
 
 extern "C" int cmgan_ffn_train_forward(cmgan_handle* h, const float* x, long long M, const cmgan_ffn_params* params,
                                        const unsigned char* mask1, const unsigned char* mask2, float mask_scale,
-                                       float* y, void* ws, size_t ws_bytes, void* stream) {
+                                       const float* residual, float* y, void* ws, size_t ws_bytes, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !y || M <= 0 || !ffn_params_ok(params)) return fail(h, CMGAN_E_BADARG, "cmgan_ffn_train_forward: bad argument");
     if (int rc = check_ws(h, ws, ws_bytes, ffn_train_ws_floats((long)M) * sizeof(float))) return rc;
-    launch_ffn_train_forward(begin(h, stream), x, (long)M, ffn_params(params), mask1, mask2, mask_scale, y, (float*)ws);
+    launch_ffn_train_forward(begin(h, stream), x, (long)M, ffn_params(params), mask1, mask2, mask_scale, residual, y,
+                             (float*)ws);
     return check_launch(h, "ffn_train_forward");
 }
 
 extern "C" int cmgan_ffn_train_backward(cmgan_handle* h, const float* x, const float* dy, long long M,
                                         const cmgan_ffn_params* params, const unsigned char* mask1,
-                                        const unsigned char* mask2, float mask_scale, float* dx,
-                                        const cmgan_ffn_params* grads, void* ws, size_t ws_bytes, void* stream) {
+                                        const unsigned char* mask2, float mask_scale, const float* dresidual,
+                                        float* dx, const cmgan_ffn_params* grads, void* ws, size_t ws_bytes,
+                                        void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !dy || !dx || M <= 0 || !ffn_params_ok(params) || !ffn_params_ok(grads))
         return fail(h, CMGAN_E_BADARG, "cmgan_ffn_train_backward: bad argument");
     if (int rc = check_ws(h, ws, ws_bytes, ffn_train_ws_floats((long)M) * sizeof(float))) return rc;
-    launch_ffn_train_backward(begin(h, stream), x, dy, (long)M, ffn_params(params), mask1, mask2, mask_scale, dx,
-                              ffn_params(grads), (float*)ws);
+    launch_ffn_train_backward(begin(h, stream), x, dy, (long)M, ffn_params(params), mask1, mask2, mask_scale,
+                              dresidual, dx, ffn_params(grads), (float*)ws);
     return check_launch(h, "ffn_train_backward");
 }
 
@@ -74,26 +76,27 @@ static ConvModTrainParams convmod_params(const cmgan_convmod_params* p) {
 
 extern "C" int cmgan_convmod_train_forward(cmgan_handle* h, const float* x, int N, int L,
                                            const cmgan_convmod_params* params, float* running_mean,
-                                           float* running_var, float* y, void* ws, size_t ws_bytes, void* stream) {
+                                           float* running_var, const float* residual, float* y, void* ws,
+                                           size_t ws_bytes, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !y || N <= 0 || L <= 0 || !convmod_params_ok(params) || (!running_mean != !running_var))
         return fail(h, CMGAN_E_BADARG, "cmgan_convmod_train_forward: bad argument");
     if (int rc = check_ws(h, ws, ws_bytes, convmod_train_ws_floats(N, L) * sizeof(float))) return rc;
-    launch_convmod_train_forward(begin(h, stream), x, N, L, convmod_params(params), running_mean, running_var, y,
-                                 (float*)ws);
+    launch_convmod_train_forward(begin(h, stream), x, N, L, convmod_params(params), running_mean, running_var,
+                                 residual, y, (float*)ws);
     return check_launch(h, "convmod_train_forward");
 }
 
 extern "C" int cmgan_convmod_train_backward(cmgan_handle* h, const float* x, const float* dy, int N, int L,
-                                            const cmgan_convmod_params* params, float* dx,
+                                            const cmgan_convmod_params* params, const float* dresidual, float* dx,
                                             const cmgan_convmod_params* grads, void* ws, size_t ws_bytes,
                                             void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !dy || !dx || N <= 0 || L <= 0 || !convmod_params_ok(params) || !convmod_params_ok(grads))
         return fail(h, CMGAN_E_BADARG, "cmgan_convmod_train_backward: bad argument");
     if (int rc = check_ws(h, ws, ws_bytes, convmod_train_ws_floats(N, L) * sizeof(float))) return rc;
-    launch_convmod_train_backward(begin(h, stream), x, dy, N, L, convmod_params(params), dx, convmod_params(grads),
-                                  (float*)ws);
+    launch_convmod_train_backward(begin(h, stream), x, dy, N, L, convmod_params(params), dresidual, dx,
+                                  convmod_params(grads), (float*)ws);
     return check_launch(h, "convmod_train_backward");
 }
 
@@ -112,38 +115,40 @@ static AttnTrainParams attn_params(const cmgan_attn_params* p) {
 }
 
 extern "C" int cmgan_attn_train_forward(cmgan_handle* h, const float* x, int N, int L, const cmgan_attn_params* params,
-                                        const unsigned char* mask, float mask_scale, float* y, void* ws,
-                                        size_t ws_bytes, void* stream) {
+                                        const unsigned char* mask, float mask_scale, const float* residual, float* y,
+                                        void* ws, size_t ws_bytes, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !y || N <= 0 || L <= 0 || !attn_params_ok(params))
         return fail(h, CMGAN_E_BADARG, "cmgan_attn_train_forward: bad argument");
     if (L > attn_train_max_len())
         return fail(h, CMGAN_E_UNSUPPORTED, "cmgan_attn_train: sequences up to %d positions (got %d)", attn_train_max_len(), L);
     if (int rc = check_ws(h, ws, ws_bytes, attn_train_ws_floats(N, L) * sizeof(float))) return rc;
-    launch_attn_train_forward(begin(h, stream), x, N, L, attn_params(params), h->cfg.max_pos_emb, mask, mask_scale, y,
-                              (float*)ws);
+    launch_attn_train_forward(begin(h, stream), x, N, L, attn_params(params), h->cfg.max_pos_emb, mask, mask_scale,
+                              residual, y, (float*)ws);
     return check_launch(h, "attn_train_forward");
 }
 
 extern "C" int cmgan_attn_train_backward(cmgan_handle* h, const float* x, const float* dy, int N, int L,
                                          const cmgan_attn_params* params, const unsigned char* mask, float mask_scale,
-                                         float* dx, const cmgan_attn_params* grads, void* ws, size_t ws_bytes,
-                                         void* stream) {
+                                         const float* dresidual, float* dx, const cmgan_attn_params* grads, void* ws,
+                                         size_t ws_bytes, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !dy || !dx || N <= 0 || L <= 0 || !attn_params_ok(params) || !attn_params_ok(grads))
         return fail(h, CMGAN_E_BADARG, "cmgan_attn_train_backward: bad argument");
     if (L > attn_train_max_len())
         return fail(h, CMGAN_E_UNSUPPORTED, "cmgan_attn_train: sequences up to %d positions (got %d)", attn_train_max_len(), L);
     if (int rc = check_ws(h, ws, ws_bytes, attn_train_ws_floats(N, L) * sizeof(float))) return rc;
-    launch_attn_train_backward(begin(h, stream), x, dy, N, L, attn_params(params), h->cfg.max_pos_emb, mask, mask_scale, dx,
-                               attn_params(grads), (float*)ws);
+    launch_attn_train_backward(begin(h, stream), x, dy, N, L, attn_params(params), h->cfg.max_pos_emb, mask, mask_scale,
+                               dresidual, dx, attn_params(grads), (float*)ws);
     return check_launch(h, "attn_train_backward");
 }
 
-extern "C" int cmgan_swap_axes(cmgan_handle* h, const float* in, float* out, int B, int A, int C, void* stream) {
+extern "C" int cmgan_swap_axes(cmgan_handle* h, const float* in, const float* add, float* out, int B, int A, int C,
+                               void* stream) {
     if (!h) return CMGAN_E_BADARG;
-    if (!in || !out || in == out || B <= 0 || A <= 0 || C <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_swap_axes: bad argument");
-    launch_swap_axes(begin(h, stream), in, out, B, A, C);
+    if (!in || !out || in == out || add == out || B <= 0 || A <= 0 || C <= 0)
+        return fail(h, CMGAN_E_BADARG, "cmgan_swap_axes: bad argument");
+    launch_swap_axes(begin(h, stream), in, add, out, B, A, C);
     return check_launch(h, "swap_axes");
 }
 
@@ -160,10 +165,10 @@ extern "C" size_t cmgan_layernorm_train_workspace_bytes(const cmgan_handle* h, l
 }
 
 extern "C" int cmgan_layernorm_train_forward(cmgan_handle* h, const float* x, long long M, const float* weight,
-                                             const float* bias, float* y, void* stream) {
+                                             const float* bias, const float* residual, float* y, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !y || !weight || !bias || M <= 0) return fail(h, CMGAN_E_BADARG, "cmgan_layernorm_train_forward: bad argument");
-    launch_ln_train_forward(begin(h, stream), x, (long)M, weight, bias, y);
+    launch_ln_train_forward(begin(h, stream), x, (long)M, weight, bias, residual, y);
     return check_launch(h, "layernorm_train_forward");
 }
 

@@ -19,12 +19,14 @@ struct FfnTrainParams {
 #define FFN_WGRAD_SPLIT 64
 #define FFN_COLSUM_BLOCKS 512
 size_t ffn_train_ws_floats(long M);
-// dropout keep-masks: bytes (non-zero = keep), kept values scaled by mask_scale = 1 / (1 - p); NULL = no dropout
+// dropout keep-masks: bytes (non-zero = keep), kept values scaled by mask_scale = 1 / (1 - p); NULL = no dropout.
+// res / dres (here and in the two modules below): optional [M,64] tensor added in the final store, i.e. the residual
+// connection of conformer.py:216-219 fused into the branch (y = res + f(x); dx = dres + f'(dy)); NULL = none.
 void launch_ffn_train_forward(LaunchCtx, const float* x, long M, const FfnTrainParams& p, const unsigned char* m1,
-                              const unsigned char* m2, float mask_scale, float* y, float* ws);
+                              const unsigned char* m2, float mask_scale, const float* res, float* y, float* ws);
 void launch_ffn_train_backward(LaunchCtx, const float* x, const float* dy, long M, const FfnTrainParams& p,
-                               const unsigned char* m1, const unsigned char* m2, float mask_scale, float* dx,
-                               const FfnTrainParams& grad, float* ws);
+                               const unsigned char* m1, const unsigned char* m2, float mask_scale, const float* dres,
+                               float* dx, const FfnTrainParams& grad, float* ws);
 
 // training-mode ConformerConvModule (BatchNorm1d on batch statistics) forward + backward on raw parameters
 struct ConvModTrainParams {
@@ -36,9 +38,10 @@ struct ConvModTrainParams {
 };
 size_t convmod_train_ws_floats(int N, int L);
 void launch_convmod_train_forward(LaunchCtx, const float* x, int N, int L, const ConvModTrainParams& p,
-                                  float* running_mean, float* running_var, float* y, float* ws);
+                                  float* running_mean, float* running_var, const float* res, float* y, float* ws);
 void launch_convmod_train_backward(LaunchCtx, const float* x, const float* dy, int N, int L,
-                                   const ConvModTrainParams& p, float* dx, const ConvModTrainParams& grad, float* ws);
+                                   const ConvModTrainParams& p, const float* dres, float* dx,
+                                   const ConvModTrainParams& grad, float* ws);
 // training-mode PreNorm(Attention) forward + backward on raw parameters
 struct AttnTrainParams {
     float *ln_w, *ln_b;       // attn.norm               LayerNorm(64)          conformer.py:68
@@ -49,14 +52,15 @@ struct AttnTrainParams {
 size_t attn_train_ws_floats(int N, int L);
 int attn_train_max_len();
 void launch_attn_train_forward(LaunchCtx, const float* x, int N, int L, const AttnTrainParams& p, int max_pos,
-                               const unsigned char* mask, float mask_scale, float* y, float* ws);
+                               const unsigned char* mask, float mask_scale, const float* res, float* y, float* ws);
 void launch_attn_train_backward(LaunchCtx, const float* x, const float* dy, int N, int L, const AttnTrainParams& p,
-                                int max_pos, const unsigned char* mask, float mask_scale, float* dx,
+                                int max_pos, const unsigned char* mask, float mask_scale, const float* dres, float* dx,
                                 const AttnTrainParams& grad, float* ws);
-void launch_swap_axes(LaunchCtx, const float* in, float* out, int B, int A, int C);
+void launch_swap_axes(LaunchCtx, const float* in, const float* add, float* out, int B, int A, int C);
 void launch_add(LaunchCtx, const float* a, const float* b, float* out, long n);
 size_t ln_train_ws_floats(long M);
-void launch_ln_train_forward(LaunchCtx, const float* x, long M, const float* gamma, const float* beta, float* y);
+void launch_ln_train_forward(LaunchCtx, const float* x, long M, const float* gamma, const float* beta, const float* res,
+                             float* y);
 void launch_ln_train_backward(LaunchCtx, const float* x, const float* dy, long M, const float* gamma, const float* beta,
                               float* dx, float* dgamma, float* dbeta, float* ws);
 // training-mode DilatedDenseNet (generator.py:6-47) forward + backward on raw parameters, channels-last [B,T,F,64]

@@ -160,7 +160,7 @@ __device__ __forceinline__ bool ffn_load_norm(const float* __restrict__ x, long 
 __global__ __launch_bounds__(256) void ffn_train_fwd_kernel(const float* __restrict__ x, long M, FfnTrainImg w,
                                                             const unsigned char* __restrict__ m1,
                                                             const unsigned char* __restrict__ m2, float ms,
-                                                            float* __restrict__ y) {
+                                                            const float* __restrict__ res, float* __restrict__ y) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (t0 >= M) return;
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void ffn_train_fwd_kernel(const float* __restr
         for (int ob = 0; ob < 4; ++ob) {
             f32x4 v = acc[ob] * splat4(0.5f);
             if (m2) v = v * mask4(m2, row * 64 + 16 * ob + 4 * g, ms);
+            if (res) v = v + ldg4(res + row * 64 + 16 * ob + 4 * g);      // the block's residual add, fused
             stg4(y + row * 64 + 16 * ob + 4 * g, v);
         }
     }
@@ -203,7 +204,7 @@ struct FfnBwdBufs {
 __global__ __launch_bounds__(256) void ffn_train_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             long M, FfnTrainImg w, const unsigned char* __restrict__ m1,
                                                             const unsigned char* __restrict__ m2, float ms,
-                                                            float* __restrict__ dx,
+                                                            const float* __restrict__ dres, float* __restrict__ dx,
                                                             FfnBwdBufs o) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
@@ -269,7 +270,9 @@ __global__ __launch_bounds__(256) void ffn_train_bwd_kernel(const float* __restr
     if (ok) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            stg4(dx + row * 64 + 16 * kb + 4 * g, (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd));
+            f32x4 dv = (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd);
+            if (dres) dv = dv + ldg4(dres + row * 64 + 16 * kb + 4 * g);   // + the gradient of the residual path
+            stg4(dx + row * 64 + 16 * kb + 4 * g, dv);
             stg4(o.g1 + row * 64 + 16 * kb + 4 * g, dxn[kb] * xh[kb]);
             stg4(o.dxn + row * 64 + 16 * kb + 4 * g, dxn[kb]);
         }
@@ -530,14 +533,14 @@ size_t ffn_train_ws_floats(long M) {
 }
 
 void launch_ffn_train_forward(LaunchCtx ctx, const float* x, long M, const FfnTrainParams& p, const unsigned char* m1,
-                              const unsigned char* m2, float ms, float* y, float* ws) {
+                              const unsigned char* m2, float ms, const float* res, float* y, float* ws) {
     const FfnTrainImg w = ffn_pack_images(ctx, p, ws);
     const unsigned grid = (unsigned)((M + 63) / 64);
-    LAUNCH(ctx, "ffn_train_fwd", (ffn_train_fwd_kernel<<<grid, 256, 0, ctx.stream>>>(x, M, w, m1, m2, ms, y)));
+    LAUNCH(ctx, "ffn_train_fwd", (ffn_train_fwd_kernel<<<grid, 256, 0, ctx.stream>>>(x, M, w, m1, m2, ms, res, y)));
 }
 
 void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, long M, const FfnTrainParams& p,
-                               const unsigned char* m1, const unsigned char* m2, float ms, float* dx,
+                               const unsigned char* m1, const unsigned char* m2, float ms, const float* dres, float* dx,
                                const FfnTrainParams& grad, float* ws) {
     hipStream_t s = ctx.stream;
     const FfnTrainImg w = ffn_pack_images(ctx, p, ws, false);
@@ -546,7 +549,7 @@ void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, l
     float* part = act + M * 768;                                  // [SPLIT][16384] x 2, then colsum slabs
     float* cpart = part + (size_t)WG_SPLIT * 16384 * 2;
     const unsigned grid = (unsigned)((M + 63) / 64);
-    LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_kernel<<<grid, 256, 0, s>>>(x, dy, M, w, m1, m2, ms, dx, o)));
+    LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_kernel<<<grid, 256, 0, s>>>(x, dy, M, w, m1, m2, ms, dres, dx, o)));
     // dW2 [64,256] = dz^T d1 ; dW1 [256,64] = dh^T xn
     LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 4, WG_SPLIT), 256, 0, s>>>(o.dz, o.d1, M, 64, 256, part)));
     LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial64_kernel<<<dim3(4, 1, WG_SPLIT), 256, 0, s>>>(o.dh, o.xn, M, 256, 64,
@@ -770,7 +773,8 @@ __global__ void cm_bn_finalize_kernel(const double* __restrict__ part, double co
 // BatchNorm apply -> Swish -> pointwise 128 -> 64 + bias
 __global__ __launch_bounds__(256) void cm_bn_swish_pw2_kernel(const float* __restrict__ d, long M, CmStats st,
                                                               const float* __restrict__ w2fm,
-                                                              const float* __restrict__ b2, float* __restrict__ y) {
+                                                              const float* __restrict__ b2, const float* __restrict__ res,
+                                                              float* __restrict__ y) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (t0 >= M) return;
@@ -789,6 +793,7 @@ __global__ __launch_bounds__(256) void cm_bn_swish_pw2_kernel(const float* __res
     for (int ob = 0; ob < 4; ++ob) {
         f32x4 acc[1] = {ldg4(b2 + 16 * ob + 4 * g)};
         lin_acc<8, 1>(w2fm + (long)ob * 8 * 256 + lane * 4, s, acc);
+        if (res) acc[0] = acc[0] + ldg4(res + row * 64 + 16 * ob + 4 * g);
         if (ok) stg4(y + row * 64 + 16 * ob + 4 * g, acc[0]);
     }
 }
@@ -894,9 +899,10 @@ __global__ __launch_bounds__(256) void cm_dw_wgrad_kernel(const float* __restric
 // backward, part 2 (per token): GLU backward with a, g recomputed from x, dxn = pw1^T [da; dg], LayerNorm backward
 __global__ __launch_bounds__(256) void cm_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ du, long M,
                                                       const float* __restrict__ w1fm, const float* __restrict__ w1tfm,
-                                                      ConvModTrainParams p, float* __restrict__ dx,
-                                                      float* __restrict__ dag, float* __restrict__ xn_out,
-                                                      float* __restrict__ g1, float* __restrict__ dxn_out) {
+                                                      ConvModTrainParams p, const float* __restrict__ dres,
+                                                      float* __restrict__ dx, float* __restrict__ dag,
+                                                      float* __restrict__ xn_out, float* __restrict__ g1,
+                                                      float* __restrict__ dxn_out) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (t0 >= M) return;
@@ -951,7 +957,9 @@ __global__ __launch_bounds__(256) void cm_bwd2_kernel(const float* __restrict__ 
     if (ok) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            stg4(dx + row * 64 + 16 * kb + 4 * g, (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd));
+            f32x4 dv = (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd);
+            if (dres) dv = dv + ldg4(dres + row * 64 + 16 * kb + 4 * g);
+            stg4(dx + row * 64 + 16 * kb + 4 * g, dv);
             stg4(xn_out + row * 64 + 16 * kb + 4 * g, xn[0][kb]);
             stg4(g1 + row * 64 + 16 * kb + 4 * g, dxn[kb] * xh[kb]);
             stg4(dxn_out + row * 64 + 16 * kb + 4 * g, dxn[kb]);
@@ -995,7 +1003,7 @@ static CmImg cm_pack_images(LaunchCtx ctx, const ConvModTrainParams& p, float* i
 }
 
 void launch_convmod_train_forward(LaunchCtx ctx, const float* x, int N, int L, const ConvModTrainParams& p,
-                                  float* running_mean, float* running_var, float* y, float* ws) {
+                                  float* running_mean, float* running_var, const float* res, float* y, float* ws) {
     hipStream_t s = ctx.stream;
     const CmPlan pl = cm_plan(N, L);
     const long M = (long)N * L;
@@ -1011,11 +1019,12 @@ void launch_convmod_train_forward(LaunchCtx ctx, const float* x, int N, int L, c
                                                                                     bnred)));
     LAUNCH(ctx, "convmod_train_fwd", (cm_bn_finalize_kernel<<<1, 128, 0, s>>>(bnred, (double)M, p.bn_w, p.bn_b, st,
                                                                               running_mean, running_var)));
-    LAUNCH(ctx, "convmod_train_fwd", (cm_bn_swish_pw2_kernel<<<grid, 256, 0, s>>>(ws + pl.d, M, st, im.w2, p.pw2_b, y)));
+    LAUNCH(ctx, "convmod_train_fwd", (cm_bn_swish_pw2_kernel<<<grid, 256, 0, s>>>(ws + pl.d, M, st, im.w2, p.pw2_b, res, y)));
 }
 
 void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* dy, int N, int L,
-                                   const ConvModTrainParams& p, float* dx, const ConvModTrainParams& grad, float* ws) {
+                                   const ConvModTrainParams& p, const float* dres, float* dx,
+                                   const ConvModTrainParams& grad, float* ws) {
     hipStream_t s = ctx.stream;
     const CmPlan pl = cm_plan(N, L);
     const long M = (long)N * L;
@@ -1056,7 +1065,7 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<62, 1024, 0, s>>>(ws + pl.dwpart, nslab, 3968, grad.dw_w)));
     LAUNCH(ctx, "convmod_train_bwd", (cm_depthwise_kernel<<<dgrid, 256, 0, s>>>(dd, p.dw_w, nullptr, 1, L, ws + pl.du,
                                                                                 nullptr)));
-    LAUNCH(ctx, "convmod_train_bwd", (cm_bwd2_kernel<<<grid, 256, 0, s>>>(x, ws + pl.du, M, im.w1, im.w1t, p, dx,
+    LAUNCH(ctx, "convmod_train_bwd", (cm_bwd2_kernel<<<grid, 256, 0, s>>>(x, ws + pl.du, M, im.w1, im.w1t, p, dres, dx,
                                                                           ws + pl.dag, ws + pl.xn, ws + pl.g1,
                                                                           ws + pl.dxn)));
     // pointwise-1 and LayerNorm gradients
@@ -1215,7 +1224,7 @@ __global__ __launch_bounds__(1024) void at_core_fwd_kernel(AtBufs b, const float
 // y = mask * (Wo O + bo)
 __global__ __launch_bounds__(256) void at_out_kernel(const float* __restrict__ o, long M, const float* __restrict__ wofm,
                                                      const float* __restrict__ bo, const unsigned char* __restrict__ mask, float ms,
-                                                     float* __restrict__ y) {
+                                                     const float* __restrict__ res, float* __restrict__ y) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (t0 >= M) return;
@@ -1230,6 +1239,7 @@ __global__ __launch_bounds__(256) void at_out_kernel(const float* __restrict__ o
         f32x4 acc[1] = {ldg4(bo + 16 * ob + 4 * g)};
         lin_acc<4, 1>(wofm + (long)ob * 4 * 256 + lane * 4, of, acc);
         if (mask) acc[0] = acc[0] * mask4(mask, row * 64 + 16 * ob + 4 * g, ms);
+        if (res) acc[0] = acc[0] + ldg4(res + row * 64 + 16 * ob + 4 * g);
         if (ok) stg4(y + row * 64 + 16 * ob + 4 * g, acc[0]);
     }
 }
@@ -1461,9 +1471,9 @@ __global__ void at_de_scatter_kernel(const float* __restrict__ partial, int NH, 
 // backward of the projections: dxn = [to_q ; to_kv]^T dqkv (A image [4][12]), LayerNorm backward
 __global__ __launch_bounds__(256) void at_qkv_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dqkv, long M,
                                                          const float* __restrict__ wtfm, const float* __restrict__ ln_w,
-                                                         const float* __restrict__ ln_b, float* __restrict__ dx,
-                                                         float* __restrict__ xn_out, float* __restrict__ g1,
-                                                         float* __restrict__ dxn_out) {
+                                                         const float* __restrict__ ln_b, const float* __restrict__ dres,
+                                                         float* __restrict__ dx, float* __restrict__ xn_out,
+                                                         float* __restrict__ g1, float* __restrict__ dxn_out) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (t0 >= M) return;
@@ -1499,7 +1509,9 @@ __global__ __launch_bounds__(256) void at_qkv_bwd_kernel(const float* __restrict
     if (ok) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            stg4(dx + row * 64 + 16 * kb + 4 * g, (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd));
+            f32x4 dv = (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd);
+            if (dres) dv = dv + ldg4(dres + row * 64 + 16 * kb + 4 * g);
+            stg4(dx + row * 64 + 16 * kb + 4 * g, dv);
             stg4(xn_out + row * 64 + 16 * kb + 4 * g, xn[0][kb]);
             stg4(g1 + row * 64 + 16 * kb + 4 * g, dxn[kb] * xh[kb]);
             stg4(dxn_out + row * 64 + 16 * kb + 4 * g, dxn[kb]);
@@ -1545,7 +1557,7 @@ static void at_pack_images(LaunchCtx ctx, const AttnTrainParams& p, float* ws, c
 }
 
 void launch_attn_train_forward(LaunchCtx ctx, const float* x, int N, int L, const AttnTrainParams& p, int max_pos,
-                               const unsigned char* mask, float ms, float* y, float* ws) {
+                               const unsigned char* mask, float ms, const float* res, float* y, float* ws) {
     hipStream_t s = ctx.stream;
     const AtPlan pl = at_plan(N, L);
     const long M = (long)N * L;
@@ -1557,12 +1569,12 @@ void launch_attn_train_forward(LaunchCtx ctx, const float* x, int N, int L, cons
     const size_t shm = at_lds_bytes((size_t)(2 * L - 1) * AT_P, sp, 18);
     at_allow_lds(at_core_fwd_kernel, shm);
     LAUNCH(ctx, "attn_train_fwd", (at_core_fwd_kernel<<<dim3(N, 4), sp.qpb * sp.ks, shm, s>>>(b, p.rel, L, max_pos, sp.qpb)));
-    LAUNCH(ctx, "attn_train_fwd", (at_out_kernel<<<grid, 256, 0, s>>>(b.o, M, ws + pl.wo, p.bo, mask, ms, y)));
+    LAUNCH(ctx, "attn_train_fwd", (at_out_kernel<<<grid, 256, 0, s>>>(b.o, M, ws + pl.wo, p.bo, mask, ms, res, y)));
 }
 
 void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, int N, int L, const AttnTrainParams& p,
-                                int max_pos, const unsigned char* mask, float ms, float* dx, const AttnTrainParams& grad,
-                                float* ws) {
+                                int max_pos, const unsigned char* mask, float ms, const float* dres, float* dx,
+                                const AttnTrainParams& grad, float* ws) {
     hipStream_t s = ctx.stream;
     const AtPlan pl = at_plan(N, L);
     const long M = (long)N * L;
@@ -1602,7 +1614,7 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
                                                                                                   grad.rel)));
     // projections + LayerNorm
     LAUNCH(ctx, "attn_train_bwd", (at_qkv_bwd_kernel<<<grid, 256, 0, s>>>(x, ws + pl.dqkv, M, ws + pl.wqkvt, p.ln_w, p.ln_b,
-                                                                          dx, ws + pl.xn, ws + pl.g1, ws + pl.dxn)));
+                                                                          dres, dx, ws + pl.xn, ws + pl.g1, ws + pl.dxn)));
     LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial64_kernel<<<dim3(3, 1, WG_SPLIT), 256, 0, s>>>(ws + pl.dqkv, ws + pl.xn, M, 192,
                                                                                                64, ws + pl.wpart)));
     LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<192, 1024, 0, s>>>(ws + pl.wpart, WG_SPLIT, 12288,
@@ -1630,7 +1642,8 @@ void launch_add(LaunchCtx ctx, const float* a, const float* b, float* out, long 
 
 __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restrict__ x, long M,
                                                            const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float* __restrict__ y) {
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ res, float* __restrict__ y) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (t0 >= M) return;
@@ -1640,7 +1653,11 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restri
     const bool ok = cm_load_norm(x, M, t0, c, g, gamma, beta, xh, xn, rstd, row);
     if (ok) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) stg4(y + row * 64 + 16 * kb + 4 * g, xn[0][kb]);
+        for (int kb = 0; kb < 4; ++kb) {
+            f32x4 v = xn[0][kb];
+            if (res) v = v + ldg4(res + row * 64 + 16 * kb + 4 * g);
+            stg4(y + row * 64 + 16 * kb + 4 * g, v);
+        }
     }
 }
 
@@ -1679,8 +1696,9 @@ __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float* __restri
 
 size_t ln_train_ws_floats(long M) { return (size_t)M * 64 + (size_t)2 * FFN_COLSUM_BLOCKS * 256; }
 
-void launch_ln_train_forward(LaunchCtx ctx, const float* x, long M, const float* gamma, const float* beta, float* y) {
-    LAUNCH(ctx, "ln_train", (ln_train_fwd_kernel<<<(unsigned)((M + 63) / 64), 256, 0, ctx.stream>>>(x, M, gamma, beta, y)));
+void launch_ln_train_forward(LaunchCtx ctx, const float* x, long M, const float* gamma, const float* beta,
+                             const float* res, float* y) {
+    LAUNCH(ctx, "ln_train", (ln_train_fwd_kernel<<<(unsigned)((M + 63) / 64), 256, 0, ctx.stream>>>(x, M, gamma, beta, res, y)));
 }
 
 void launch_ln_train_backward(LaunchCtx ctx, const float* x, const float* dy, long M, const float* gamma,
@@ -1694,9 +1712,10 @@ void launch_ln_train_backward(LaunchCtx ctx, const float* x, const float* dy, lo
 }
 
 // [B, A, C, 64] -> [B, C, A, 64]: the layout flip between the time-axis and frequency-axis sequences of a TSCB
-// (the reference's permute(...).contiguous(), generator.py:94,96) on channels-last rows of 256 B
-__global__ __launch_bounds__(256) void swap_axes_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int C,
-                                                        long total4) {
+// (the reference's permute(...).contiguous(), generator.py:94,96) on channels-last rows of 256 B; `add` (optional, laid
+// out like `in`) is summed in on the way: the residual `x_t = time_conformer(x_t) + x_t` of :95 rides on the flip of :96
+__global__ __launch_bounds__(256) void swap_axes_kernel(const float* __restrict__ in, const float* __restrict__ add,
+                                                        float* __restrict__ out, int A, int C, long total4) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
         const int q = (int)(i & 15);
         long r = i >> 4;                       // output row (b, c, a)
@@ -1704,13 +1723,16 @@ __global__ __launch_bounds__(256) void swap_axes_kernel(const float* __restrict_
         r /= A;
         const int c = (int)(r % C);
         const long b = r / C;
-        stg4(out + 4 * i, ldg4(in + ((((b * A + a) * C + c) << 4) + q) * 4));
+        const long src = ((((b * A + a) * C + c) << 4) + q) * 4;
+        f32x4 v = ldg4(in + src);
+        if (add) v = v + ldg4(add + src);
+        stg4(out + 4 * i, v);
     }
 }
-void launch_swap_axes(LaunchCtx ctx, const float* in, float* out, int B, int A, int C) {
+void launch_swap_axes(LaunchCtx ctx, const float* in, const float* add, float* out, int B, int A, int C) {
     const long total4 = (long)B * A * C * 16, want = (total4 + 255) / 256;
     LAUNCH(ctx, "swap_axes", (swap_axes_kernel<<<(unsigned)(want < 8192 ? (want > 0 ? want : 1) : 8192), 256, 0, ctx.stream>>>(
-                                 in, out, A, C, total4)));
+                                 in, add, out, A, C, total4)));
 }
 
 // =====================================================================================

@@ -78,6 +78,15 @@ def dropout_mask(shape, p: float, device, generator: Optional[torch.Generator] =
     return torch.empty(shape, dtype=torch.uint8, device=device).bernoulli_(1.0 - p, generator=generator)
 
 
+def _same_shape(eng, t: Optional[torch.Tensor], like: torch.Tensor, name: str) -> Optional[int]:
+    """Device pointer of the optional fused residual `t` (must have `like`'s element count, fp32, contiguous) or None."""
+    if t is None:
+        return None
+    if t.numel() != like.numel() or not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor of {tuple(like.shape)}")
+    return eng._in(t, name).data_ptr()
+
+
 def _keep_mask(mask: Optional[torch.Tensor], shape, p: float, device, name: str) -> Optional[torch.Tensor]:
     """The byte keep-mask the kernels take, from either form a caller may hold: uint8 / bool keep flags, or the float
     mask of F.dropout's arithmetic (entries 0 or 1 / (1 - p), as the reference-derived fixtures store them)."""
@@ -179,12 +188,14 @@ class FeedForwardTrain:
         return dropout_mask((M, 256), self.p, dev, generator), dropout_mask((M, 64), self.p, dev, generator)
 
     def forward(self, x: torch.Tensor, mask1: Optional[torch.Tensor] = None,
-                mask2: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x [..., 64] -> 0.5 * FeedForward(LayerNorm(x)) with the given dropout masks (add the residual yourself)."""
+                mask2: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [..., 64] -> 0.5 * FeedForward(LayerNorm(x)) with the given dropout masks, plus `residual` (same shape)
+        when given - the `+ x` of conformer.py:216 fused into the kernel's final store."""
         eng = self.engine
         shape = x.shape
         x2 = eng._in(x.reshape(-1, 64), "x")
         M = x2.size(0)
+        r = _same_shape(eng, residual, x2, "residual")
         m1 = _keep_mask(mask1, (M, 256), self.p, eng.device, "mask1")
         m2 = _keep_mask(mask2, (M, 64), self.p, eng.device, "mask2")
         y = torch.empty_like(x2)
@@ -193,17 +204,20 @@ class FeedForwardTrain:
         with torch.cuda.device(eng.device):
             check(eng._h, eng.lib.cmgan_ffn_train_forward(
                 eng._h, x2.data_ptr(), M, ctypes.byref(p), m1.data_ptr() if m1 is not None else None,
-                m2.data_ptr() if m2 is not None else None, self._scale(), y.data_ptr(), ws.data_ptr(), ws.numel(),
+                m2.data_ptr() if m2 is not None else None, self._scale(), r, y.data_ptr(), ws.data_ptr(), ws.numel(),
                 eng._stream()))
         return y.reshape(shape)
 
     def backward(self, x: torch.Tensor, dy: torch.Tensor, mask1: Optional[torch.Tensor] = None,
-                 mask2: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-        """(dL/dx of the branch, {key: dL/dparam}) for upstream gradient dy; masks must be the forward's."""
+                 mask2: Optional[torch.Tensor] = None, dresidual: Optional[torch.Tensor] = None
+                 ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """(dL/dx of the branch [+ dresidual], {key: dL/dparam}) for upstream gradient dy; masks must be the forward's.
+        `dresidual=dy` gives the gradient of `ff(x) + x` in one pass."""
         eng = self.engine
         shape = x.shape
         x2, dy2 = eng._in(x.reshape(-1, 64), "x"), eng._in(dy.reshape(-1, 64), "dy")
         M = x2.size(0)
+        r = _same_shape(eng, dresidual, x2, "dresidual")
         m1 = _keep_mask(mask1, (M, 256), self.p, eng.device, "mask1")
         m2 = _keep_mask(mask2, (M, 64), self.p, eng.device, "mask2")
         dx = torch.empty_like(x2)
@@ -212,8 +226,8 @@ class FeedForwardTrain:
         with torch.cuda.device(eng.device):
             check(eng._h, eng.lib.cmgan_ffn_train_backward(
                 eng._h, x2.data_ptr(), dy2.data_ptr(), M, ctypes.byref(p), m1.data_ptr() if m1 is not None else None,
-                m2.data_ptr() if m2 is not None else None, self._scale(), dx.data_ptr(), ctypes.byref(g), ws.data_ptr(),
-                ws.numel(), eng._stream()))
+                m2.data_ptr() if m2 is not None else None, self._scale(), r, dx.data_ptr(), ctypes.byref(g),
+                ws.data_ptr(), ws.numel(), eng._stream()))
         return dx.reshape(shape), self.grads
 
     def allreduce_gradients(self) -> torch.Tensor:
@@ -336,10 +350,12 @@ class ConvModuleTrain:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.engine.device)
         return self._ws
 
-    def forward(self, x: torch.Tensor, update_running_stats: bool = True) -> torch.Tensor:
-        """x [N, L, 64] -> ConformerConvModule(x) in train mode (add the residual yourself)."""
+    def forward(self, x: torch.Tensor, update_running_stats: bool = True,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x [N, L, 64] -> ConformerConvModule(x) in train mode [+ residual, fused: conformer.py:218]."""
         eng = self.engine
         x = eng._in(x, "x")
+        r = _same_shape(eng, residual, x, "residual")
         N, L, C = x.shape
         if C != 64:
             raise ValueError("conformer dim must be 64")
@@ -350,16 +366,19 @@ class ConvModuleTrain:
         rv = self.running_var.data_ptr() if update_running_stats else None
         with torch.cuda.device(eng.device):
             check(eng._h, eng.lib.cmgan_convmod_train_forward(eng._h, x.data_ptr(), N, L, ctypes.byref(p), rm, rv,
-                                                              y.data_ptr(), ws.data_ptr(), ws.numel(), eng._stream()))
+                                                              r, y.data_ptr(), ws.data_ptr(), ws.numel(), eng._stream()))
         self._shape = (N, L)
         if update_running_stats:
             self.num_batches_tracked += 1
         return y
 
-    def backward(self, x: torch.Tensor, dy: torch.Tensor) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-        """(dL/dx, {key: dL/dparam}) for upstream gradient dy; uses the activations the last forward left behind."""
+    def backward(self, x: torch.Tensor, dy: torch.Tensor, dresidual: Optional[torch.Tensor] = None
+                 ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """(dL/dx [+ dresidual], {key: dL/dparam}) for upstream gradient dy; uses the activations the last forward
+        left behind."""
         eng = self.engine
         x, dy = eng._in(x, "x"), eng._in(dy, "dy")
+        r = _same_shape(eng, dresidual, x, "dresidual")
         N, L, _ = x.shape
         if self._shape != (N, L) or dy.shape != x.shape:
             raise RuntimeError("backward() needs the forward() of the same [N, L, 64] input first")
@@ -368,7 +387,7 @@ class ConvModuleTrain:
         p, g = self._struct(self.params), self._struct(self.grads)
         with torch.cuda.device(eng.device):
             check(eng._h, eng.lib.cmgan_convmod_train_backward(eng._h, x.data_ptr(), dy.data_ptr(), N, L, ctypes.byref(p),
-                                                               dx.data_ptr(), ctypes.byref(g), ws.data_ptr(),
+                                                               r, dx.data_ptr(), ctypes.byref(g), ws.data_ptr(),
                                                                ws.numel(), eng._stream()))
         return dx, self.grads
 
@@ -418,9 +437,11 @@ class AttentionTrain:
     def mask(self, N: int, L: int, generator: Optional[torch.Generator] = None):
         return dropout_mask((N, L, 64), self.p, self.engine.device, generator)
 
-    def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
         eng = self.engine
         x = eng._in(x, "x")
+        r = _same_shape(eng, residual, x, "residual")
         N, L, C = x.shape
         if C != 64:
             raise ValueError("conformer dim must be 64")
@@ -431,14 +452,16 @@ class AttentionTrain:
         scale = 1.0 / (1.0 - self.p) if self.p > 0.0 else 1.0
         with torch.cuda.device(eng.device):
             check(eng._h, eng.lib.cmgan_attn_train_forward(eng._h, x.data_ptr(), N, L, ctypes.byref(p),
-                                                           m.data_ptr() if m is not None else None, scale, y.data_ptr(),
-                                                           ws.data_ptr(), ws.numel(), eng._stream()))
+                                                           m.data_ptr() if m is not None else None, scale, r,
+                                                           y.data_ptr(), ws.data_ptr(), ws.numel(), eng._stream()))
         self._shape = (N, L)
         return y
 
-    def backward(self, x: torch.Tensor, dy: torch.Tensor, mask: Optional[torch.Tensor] = None):
+    def backward(self, x: torch.Tensor, dy: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                 dresidual: Optional[torch.Tensor] = None):
         eng = self.engine
         x, dy = eng._in(x, "x"), eng._in(dy, "dy")
+        r = _same_shape(eng, dresidual, x, "dresidual")
         N, L, _ = x.shape
         if self._shape != (N, L) or dy.shape != x.shape:
             raise RuntimeError("backward() needs the forward() of the same [N, L, 64] input first")
@@ -449,8 +472,9 @@ class AttentionTrain:
         scale = 1.0 / (1.0 - self.p) if self.p > 0.0 else 1.0
         with torch.cuda.device(eng.device):
             check(eng._h, eng.lib.cmgan_attn_train_backward(eng._h, x.data_ptr(), dy.data_ptr(), N, L, ctypes.byref(p),
-                                                            m.data_ptr() if m is not None else None, scale, dx.data_ptr(),
-                                                            ctypes.byref(g), ws.data_ptr(), ws.numel(), eng._stream()))
+                                                            m.data_ptr() if m is not None else None, scale, r,
+                                                            dx.data_ptr(), ctypes.byref(g), ws.data_ptr(), ws.numel(),
+                                                            eng._stream()))
         return dx, self.grads
 
     def allreduce_gradients(self) -> torch.Tensor:
@@ -498,20 +522,23 @@ class ConformerBlockTrain:
         check(eng._h, eng.lib.cmgan_add(eng._h, a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), eng._stream()))
         return out
 
-    def forward(self, x: torch.Tensor, masks: Optional[Dict[str, Optional[torch.Tensor]]] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, masks: Optional[Dict[str, Optional[torch.Tensor]]] = None,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ConformerBlock(x) [+ residual, fused into the post_norm store: the `+ x` of generator.py:95,97]."""
         eng = self.engine
         m = masks or {}
         x0 = eng._in(x, "x")
+        r = _same_shape(eng, residual, x0, "residual")
         with torch.cuda.device(eng.device):
-            x1 = self._add(self.ff1.forward(x0, m.get("ff1_1"), m.get("ff1_2")), x0)
-            x2 = self._add(self.attn.forward(x1, m.get("attn")), x1)
-            x3 = self._add(self.conv.forward(x2), x2)
-            x4 = self._add(self.ff2.forward(x3, m.get("ff2_1"), m.get("ff2_2")), x3)
+            x1 = self.ff1.forward(x0, m.get("ff1_1"), m.get("ff1_2"), residual=x0)      # the `+ x` of :216-219 is
+            x2 = self.attn.forward(x1, m.get("attn"), residual=x1)                       # fused into each branch's
+            x3 = self.conv.forward(x2, residual=x2)                                      # last kernel
+            x4 = self.ff2.forward(x3, m.get("ff2_1"), m.get("ff2_2"), residual=x3)
             y = torch.empty_like(x4)
             check(eng._h, eng.lib.cmgan_layernorm_train_forward(eng._h, x4.data_ptr(), x4.numel() // 64,
                                                                 self.params["post_norm.weight"].data_ptr(),
-                                                                self.params["post_norm.bias"].data_ptr(), y.data_ptr(),
-                                                                eng._stream()))
+                                                                self.params["post_norm.bias"].data_ptr(), r,
+                                                                y.data_ptr(), eng._stream()))
         self._saved = (x0, x1, x2, x3, x4, m)
         return y
 
@@ -532,10 +559,10 @@ class ConformerBlockTrain:
                 eng._h, x4.data_ptr(), dy.data_ptr(), M, self.params["post_norm.weight"].data_ptr(),
                 self.params["post_norm.bias"].data_ptr(), d4.data_ptr(), self.grads["post_norm.weight"].data_ptr(),
                 self.grads["post_norm.bias"].data_ptr(), self._lnws.data_ptr(), self._lnws.numel(), eng._stream()))
-            d3 = self._add(self.ff2.backward(x3, d4, m.get("ff2_1"), m.get("ff2_2"))[0], d4)
-            d2 = self._add(self.conv.backward(x2, d3)[0], d3)
-            d1 = self._add(self.attn.backward(x1, d2, m.get("attn"))[0], d2)
-            d0 = self._add(self.ff1.backward(x0, d1, m.get("ff1_1"), m.get("ff1_2"))[0], d1)
+            d3 = self.ff2.backward(x3, d4, m.get("ff2_1"), m.get("ff2_2"), dresidual=d4)[0]
+            d2 = self.conv.backward(x2, d3, dresidual=d3)[0]
+            d1 = self.attn.backward(x1, d2, m.get("attn"), dresidual=d2)[0]
+            d0 = self.ff1.backward(x0, d1, m.get("ff1_1"), m.get("ff1_2"), dresidual=d1)[0]
         return d0, self.grads
 
     def allreduce_gradients(self) -> torch.Tensor:
@@ -566,10 +593,12 @@ class TSCBTrain:
     def masks(self, B: int, T: int, F2: int, generator: Optional[torch.Generator] = None):
         return self.time.masks(B * F2, T, generator), self.freq.masks(B * T, F2, generator)
 
-    def _swap(self, x: torch.Tensor, B: int, A: int, C: int) -> torch.Tensor:
+    def _swap(self, x: torch.Tensor, B: int, A: int, C: int, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[B, A, C, 64] -> [B, C, A, 64] of x (+ add, same layout as x: a residual riding on the flip)."""
         eng = self.engine
         out = torch.empty(B, C, A, 64, dtype=torch.float32, device=x.device)
-        check(eng._h, eng.lib.cmgan_swap_axes(eng._h, x.data_ptr(), out.data_ptr(), B, A, C, eng._stream()))
+        check(eng._h, eng.lib.cmgan_swap_axes(eng._h, x.data_ptr(), add.data_ptr() if add is not None else None,
+                                              out.data_ptr(), B, A, C, eng._stream()))
         return out
 
     def forward(self, x: torch.Tensor, masks_time=None, masks_freq=None) -> torch.Tensor:
@@ -580,9 +609,9 @@ class TSCBTrain:
             raise ValueError("expected channels-last [B, T, F', 64]")
         with torch.cuda.device(eng.device):
             xt = self._swap(x, B, T, F2).view(B * F2, T, 64)                       # generator.py:94
-            xt = self.time._add(self.time.forward(xt, masks_time), xt)             # :95
-            xf = self._swap(xt, B, F2, T).view(B * T, F2, 64)                      # :96
-            xf = self.freq._add(self.freq.forward(xf, masks_freq), xf)             # :97
+            yt = self.time.forward(xt, masks_time)                                 # :95, its `+ x_t` rides on
+            xf = self._swap(yt, B, F2, T, add=xt).view(B * T, F2, 64)              # the flip of :96
+            xf = self.freq.forward(xf, masks_freq, residual=xf)                    # :97
         self._shape = (B, T, F2)
         return xf.view(B, T, F2, 64)
 
@@ -594,10 +623,8 @@ class TSCBTrain:
         B, T, F2 = self._shape
         dy = eng._in(dy, "dy").view(B * T, F2, 64)
         with torch.cuda.device(eng.device):
-            dxf = self.freq._add(self.freq.backward(dy)[0], dy)
-            dxt2 = self._swap(dxf, B, T, F2).view(B * F2, T, 64)
-            dxt = self.time._add(self.time.backward(dxt2)[0], dxt2)
-            return self._swap(dxt, B, F2, T)
+            dxt2 = self._swap(self.freq.backward(dy)[0], B, T, F2, add=dy).view(B * F2, T, 64)
+            return self._swap(self.time.backward(dxt2)[0], B, F2, T, add=dxt2)
 
 
 class DenseBlockTrain:

@@ -152,7 +152,10 @@ int cmgan_loss_terms(cmgan_handle* h, const float* est_real_dev, const float* es
 /* Training-mode FeedForward branch of a ConformerBlock with its backward - the first slice of the training
  * step:  y = Scale(0.5, PreNorm(64, FeedForward(64, mult=4, dropout)))(x)
  *                         = 0.5 * m2 * (W2 (m1 * Swish(W1 LayerNorm(x) + b1)) + b2)
- * (src/models/conformer.py:54-72, 136-148, 211-212; the residual add of :217 stays with the caller).
+ * (src/models/conformer.py:54-72, 136-148, 211-212).  The residual add of :216/:219 is fused on request:
+ * residual_dev [M,64] (NULL = none) is added to y in the final store, dresidual_dev [M,64] (NULL = none; usually dy
+ * itself) to dx, so that `x = ff(x) + x` and its backward cost no extra pass over the sequence.  The same pair of
+ * optional pointers exists on the conv-module and attention entry points below.
  * Parameters are the RAW tensors of the reference state_dict for one ff{1,2} branch (row-major, device):
  *   ln_weight/ln_bias [64] = ff.fn.norm.{weight,bias};  w1 [256,64], b1 [256] = ff.fn.fn.net.0;
  *   w2 [64,256], b2 [64] = ff.fn.fn.net.3.
@@ -167,16 +170,17 @@ typedef struct cmgan_ffn_params {
 size_t cmgan_ffn_train_workspace_bytes(const cmgan_handle* h, long long M);
 int cmgan_ffn_train_forward(cmgan_handle* h, const float* x_dev, long long M, const cmgan_ffn_params* params,
                             const unsigned char* mask1_dev, const unsigned char* mask2_dev, float mask_scale,
-                            float* y_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+                            const float* residual_dev, float* y_dev, void* workspace_dev, size_t workspace_bytes,
+                            void* stream);
 int cmgan_ffn_train_backward(cmgan_handle* h, const float* x_dev, const float* dy_dev, long long M,
                              const cmgan_ffn_params* params, const unsigned char* mask1_dev,
-                             const unsigned char* mask2_dev, float mask_scale, float* dx_dev,
-                             const cmgan_ffn_params* grads,
+                             const unsigned char* mask2_dev, float mask_scale, const float* dresidual_dev,
+                             float* dx_dev, const cmgan_ffn_params* grads,
                              void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Training-mode ConformerConvModule with its backward - second slice of the training step:
  *   y = Conv1d(128,64,1)(Swish(BatchNorm1d(DepthWiseConv1d_31(GLU(Conv1d(64,256,1)(LayerNorm(x)))))))
- * (src/models/conformer.py:151-176; the residual add of :219 stays with the caller; the module's Dropout has
+ * (src/models/conformer.py:151-176; residual_dev / dresidual_dev fuse the residual add of :218; the module's Dropout has
  * p = conv_dropout = 0).  TRAIN semantics: BatchNorm1d normalises with the statistics of this batch (biased
  * variance over all N*L positions, eps 1e-5) and updates running_mean / running_var in place (momentum 0.1, unbiased
  * variance) when both pointers are non-NULL.  x, y, dy, dx: contiguous sequences [N, L, 64].  Parameters are the
@@ -190,16 +194,16 @@ typedef struct cmgan_convmod_params {
 } cmgan_convmod_params;
 size_t cmgan_convmod_train_workspace_bytes(const cmgan_handle* h, int N, int L);
 int cmgan_convmod_train_forward(cmgan_handle* h, const float* x_dev, int N, int L, const cmgan_convmod_params* params,
-                                float* running_mean_dev, float* running_var_dev, float* y_dev,
-                                void* workspace_dev, size_t workspace_bytes, void* stream);
+                                float* running_mean_dev, float* running_var_dev, const float* residual_dev,
+                                float* y_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 int cmgan_convmod_train_backward(cmgan_handle* h, const float* x_dev, const float* dy_dev, int N, int L,
-                                 const cmgan_convmod_params* params, float* dx_dev,
+                                 const cmgan_convmod_params* params, const float* dresidual_dev, float* dx_dev,
                                  const cmgan_convmod_params* grads,
                                  void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Training-mode PreNorm(Attention) with its backward - third slice of the training step:
  *   y = mask * to_out(softmax((q k^T + q E[clamp(i - j, +-max_pos)]^T) / 4) v),  q = to_q(LN(x)), k|v = to_kv(LN(x))
- * (src/models/conformer.py:54-72, 75-133; 4 heads of 16; the residual add of :218 stays with the caller).  `mask`
+ * (src/models/conformer.py:54-72, 75-133; 4 heads of 16; residual_dev / dresidual_dev fuse the residual add of :217).  `mask`
  * [N,L,64] is the byte keep-mask (non-zero = keep, kept values x mask_scale) of the nn.Dropout on the to_out output
  * (conformer.py:133; NULL = none).  Parameters are
  * the RAW tensors attn.norm.{weight,bias}, attn.fn.to_q.weight [64,64], attn.fn.to_kv.weight [128,64],
@@ -212,23 +216,27 @@ typedef struct cmgan_attn_params {
 } cmgan_attn_params;
 size_t cmgan_attn_train_workspace_bytes(const cmgan_handle* h, int N, int L);
 int cmgan_attn_train_forward(cmgan_handle* h, const float* x_dev, int N, int L, const cmgan_attn_params* params,
-                             const unsigned char* mask_dev, float mask_scale, float* y_dev,
-                             void* workspace_dev, size_t workspace_bytes, void* stream);
+                             const unsigned char* mask_dev, float mask_scale, const float* residual_dev,
+                             float* y_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
 int cmgan_attn_train_backward(cmgan_handle* h, const float* x_dev, const float* dy_dev, int N, int L,
                               const cmgan_attn_params* params, const unsigned char* mask_dev, float mask_scale,
-                              float* dx_dev, const cmgan_attn_params* grads,
+                              const float* dresidual_dev, float* dx_dev, const cmgan_attn_params* grads,
                               void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Glue of ConformerBlock.forward in train mode (src/models/conformer.py:216-222): out = a + b over n floats (the
  * residual adds; n % 4 == 0), and the closing post_norm = nn.LayerNorm(64) (eps 1e-5) on [M,64] rows with its backward
  * (dL/dx, dL/dweight, dL/dbias; fixed-order reductions).                                                          */
 /* in [B, A, C, 64] -> out [B, C, A, 64] (out != in): the time-axis <-> frequency-axis layout flip of a TSCB on
- * channels-last activations (src/models/generator.py:94,96 permute + contiguous).                                */
-int cmgan_swap_axes(cmgan_handle* h, const float* in_dev, float* out_dev, int B, int A, int C, void* stream);
+ * channels-last activations (src/models/generator.py:94,96 permute + contiguous).  add_dev (optional, laid out like
+ * in_dev; NULL = none) is summed in before the flip: out = flip(in + add), which carries the residual add of
+ * generator.py:95 (and of the backward) without a pass of its own.  cmgan_layernorm_train_forward's residual_dev
+ * [M,64] (NULL = none) does the same for generator.py:97: y = LayerNorm(x) + residual.                            */
+int cmgan_swap_axes(cmgan_handle* h, const float* in_dev, const float* add_dev, float* out_dev, int B, int A, int C,
+                    void* stream);
 int cmgan_add(cmgan_handle* h, const float* a_dev, const float* b_dev, float* out_dev, long long n, void* stream);
 size_t cmgan_layernorm_train_workspace_bytes(const cmgan_handle* h, long long M);
 int cmgan_layernorm_train_forward(cmgan_handle* h, const float* x_dev, long long M, const float* weight_dev,
-                                  const float* bias_dev, float* y_dev, void* stream);
+                                  const float* bias_dev, const float* residual_dev, float* y_dev, void* stream);
 int cmgan_layernorm_train_backward(cmgan_handle* h, const float* x_dev, const float* dy_dev, long long M,
                                    const float* weight_dev, const float* bias_dev, float* dx_dev,
                                    float* dweight_dev, float* dbias_dev,

@@ -259,6 +259,35 @@ def test_attention_train_matches_reference_autograd():
         assert_close(grads[k], want, rtol=1e-3, atol_rel=2e-4, name=k)
 
 
+def test_fused_residual_pointers_equal_a_separate_add(ff):
+    """`x = branch(x) + x` (conformer.py:216-219) and its backward ride on each branch's last kernel through the optional
+    residual / dresidual pointers: same values as the un-fused call plus a torch add (one extra fp32 rounding at most),
+    identical parameter gradients, on a ragged token count."""
+    from cmgan_amd.training import AttentionTrain, ConvModuleTrain
+    csd = conformer_state_dict(seed=3)
+    rng = np.random.Generator(np.random.PCG64(11))
+    t = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).to(DEV)
+    x, r, dy, dr = t(3, 37, 64), t(3, 37, 64), t(3, 37, 64), t(3, 37, 64)
+    close = lambda a, b: float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    at = AttentionTrain({k: csd["attn." + k] for k in AT_KEYS})
+    cm = ConvModuleTrain({k: csd["conv." + k] for k in CM_ALL})
+    m1, m2 = ff.masks(3 * 37, torch.Generator(device=DEV).manual_seed(1))
+    am = at.mask(3, 37, torch.Generator(device=DEV).manual_seed(2))
+    cases = (("ffn", lambda **k: ff.forward(x, m1, m2, **k), lambda **k: ff.backward(x, dy, m1, m2, **k)),
+             ("attn", lambda **k: at.forward(x, am, **k), lambda **k: at.backward(x, dy, am, **k)),
+             ("conv", lambda **k: cm.forward(x, update_running_stats=False, **k), lambda **k: cm.backward(x, dy, **k)))
+    for name, fwd, bwd in cases:
+        plain = fwd()
+        assert close(fwd(residual=r), plain + r), name
+        dx0, g0 = bwd()
+        g0 = {k: v.clone() for k, v in g0.items()}
+        dx1, g1 = bwd(dresidual=dr)
+        assert close(dx1, dx0 + dr), name
+        assert all(torch.equal(g0[k], g1[k]) for k in g0), name
+    with pytest.raises(ValueError, match="residual"):
+        ff.forward(x, m1, m2, residual=r[:, :5])
+
+
 @pytest.mark.parametrize("n,l", [(2, 321), (3, 101), (1, 512), (2, 7), (1, 65)])
 def test_attention_train_full_length_sequences_vs_oracle_autograd(n, l):
     """the two sequence lengths of the 2 s training clip (time axis T = 321, frequency axis F' = 101), the longest
