@@ -1082,14 +1082,11 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
 //   LayerNorm -> to_q / to_kv (no bias) -> per head softmax((q k^T + q E[clamp(i - j)]^T) / 4) v -> to_out + bias
 //   -> Dropout (keep-mask on the [M,64] output)
 // on contiguous sequences x [N, L, 64], L <= AT_MAX_L.  The projections are the per-token fp32-MFMA chain; the
-// attention core of THIS slice is a correctness-first row / column-parallel form (one block per (sequence, head),
-// K, V or Q, dO and the relative-position window in LDS, one thread per query row - forward, dq - or per key - dk,
-// dv - or per relative distance - dE), each recomputing the scores from q, k, E and the saved row log-sum-exp, so no
-// thread ever accumulates into another thread's output and every sum has a fixed order.  (The inference kernel of
-// conformer_x3.hip is the MFMA form; a flash-style MFMA backward is future work.)
+// attention core runs on the fp32 matrix pipe, one wave per (sequence, head, 16-row block) task (see below), each
+// backward core recomputing the probabilities from q, k, E and the saved row log-sum-exp, so no task ever accumulates
+// into another task's output and every sum has a fixed order.
 // =====================================================================================
 #define AT_MAX_L 512
-#define AT_P 17                       // LDS row pitch (floats) of the 16-wide per-head rows: conflict-free per-thread rows
 
 struct AtBufs {
     float *qkv;      // [M,192]  q | k | v  (features 16 h + d inside each 64)
@@ -1116,108 +1113,129 @@ __global__ __launch_bounds__(256) void at_qkv_kernel(const float* __restrict__ x
     }
 }
 
-// rows of the per-head operand `which` (0 q, 1 k, 2 v; 3 = rows of a [M,64] tensor) of sequence n into LDS [L][AT_P]
-__device__ __forceinline__ void at_stage(float* lds, const float* __restrict__ src, int stride, int off, long base, int L) {
-    for (int i = threadIdx.x; i < L * 16; i += blockDim.x) {
-        const int l = i >> 4, d = i & 15;
-        lds[l * AT_P + d] = src[(base + l) * stride + off + d];
-    }
+// ---------------------------------------------------------------------------------
+// Attention cores on the fp32 matrix pipe (v_mfma_f32_16x16x4_f32), one WAVE per task, no block barriers:
+//   forward  task (n, h, query block)  : S^T = K q^T, E q^T -> skew -> online softmax down the key blocks -> o^T += V^T P^T
+//   dq       task (n, h, query block)  : recompute P^T, dS^T;  dq += dS K + unskew(dS) E_band
+//   dk / dv  task (n, h, key block)    : recompute P, dS;      dk += dS^T q, dv += P^T dO
+//   dE       task (n, h, tile diagonal): recompute dS;         dE_band += unskew(dS)^T q   (all tiles of a diagonal
+//                                        share their 31 distances, so the band stays in registers)
+// A 16 x 16 tile of (query, key) pairs costs 4 MFMAs for q.k, 8 for the relative-position term (the 31 distances of
+// the tile, as q . E_band^T) and 4 for dO.v; the band result is turned into the tile ("skew": R[i][j] =
+// QE[i][15 + i - j]) through a wave-private LDS patch, and dS goes back the same way for the two E-side products.
+// Operand fragments (common.hip.h convention, lane = (g, c)):
+//   "A-type" XA[s] = X[row0 + c][4g + s]   one float4 per lane: at_dot(XA, YA)[r] = sum_d X[4g + r][d] Y[c][d]
+//   "row-type" XB[r] = X[row0 + 4g + r][c] : B operand of a product that contracts over the 16 rows of the tile
+// and an accumulator f32x4 holds D[4g + r][c].  Choosing which of the two operands of at_dot is the key side gives
+// the tile (S) or its transpose (S^T) without any data movement, and the accumulator layout of one product is the
+// A-operand layout of the next: dS^T feeds dq, dS feeds dk, P^T feeds o^T, P feeds dv straight from registers.
+// Every sum has a fixed order (a task owns its outputs; dE partial slabs are reduced in (n, h) order afterwards).
+// ---------------------------------------------------------------------------------
+#define AT_PA 20                      // LDS pitch of the [32][16] band patch (E q^T) and of the [16][16] dS patch
+#define AT_PB 36                      // LDS pitch of the [16][32] band patch (q E^T): conflict-free writes, <= 2-way reads
+
+struct AtTask { int nh, blk; };
+// blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of tasks so that the waves sharing one
+// (n, h)'s q / k / v / dO rows sit behind the same L2
+__device__ __forceinline__ bool at_task(long ntask, int nb, AtTask& t) {
+    const long per = (gridDim.x + 7) / 8;
+    const long blk = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const long task = blk * 4 + (threadIdx.x >> 6);
+    if (task >= ntask) return false;
+    t.nh = (int)(task / nb);
+    t.blk = (int)(task - (long)t.nh * nb);
+    return true;
 }
-// relative-position window: row r <-> distance r - (L - 1) = i - j, table row clamp(distance, +-max_pos) + max_pos
-__device__ __forceinline__ void at_stage_rel(float* lds, const float* __restrict__ rel, int L, int max_pos) {
-    for (int i = threadIdx.x; i < (2 * L - 1) * 16; i += blockDim.x) {
-        const int r = i >> 4, d = i & 15;
-        int dist = r - (L - 1);
-        dist = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
-        lds[r * AT_P + d] = rel[(long)(dist + max_pos) * 16 + d];
-    }
-}
-__device__ __forceinline__ float at_dot16(const float (&a)[16], const float* __restrict__ b) {
-    // four independent chains: a single 16-deep fmaf chain per score was the critical path of every core kernel
-    float s0 = a[0] * b[0], s1 = a[1] * b[1], s2 = a[2] * b[2], s3 = a[3] * b[3];
+__device__ __forceinline__ f32x4 at_dot(const f32x4& a, const f32x4& b) {
+    f32x4 acc = splat4(0.f);
 #pragma unroll
-    for (int d = 4; d < 16; d += 4) {
-        s0 = fmaf(a[d], b[d], s0);
-        s1 = fmaf(a[d + 1], b[d + 1], s1);
-        s2 = fmaf(a[d + 2], b[d + 2], s2);
-        s3 = fmaf(a[d + 3], b[d + 3], s3);
+    for (int s = 0; s < 4; ++s) acc = mfma16(a[s], b[s], acc);
+    return acc;
+}
+__device__ __forceinline__ int at_row(int r, int L) { return r < L ? r : L - 1; }           // readable (clamped) row
+__device__ __forceinline__ const float* at_erow(const float* __restrict__ rel, int dist, int max_pos) {
+    dist = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
+    return rel + (long)(dist + max_pos) * 16;
+}
+// A-type fragments of the two 16-distance halves of the band that starts at distance d0
+__device__ __forceinline__ void at_band(const float* __restrict__ rel, int d0, int max_pos, int c, int g, f32x4& e0, f32x4& e1) {
+    e0 = ldg4(at_erow(rel, d0 + c, max_pos) + 4 * g);
+    e1 = ldg4(at_erow(rel, d0 + 16 + c, max_pos) + 4 * g);
+}
+// band^T [32 distances][16 queries] (two accumulators) -> R^T[key 4g + r][query c] = band[15 + c - (4g + r)][c]
+__device__ __forceinline__ f32x4 at_skew_t(float* buf, const f32x4& eq0, const f32x4& eq1, int c, int g) {
+    wave_lds_fence();                     // the previous tile's reads of the patch are done
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        buf[(4 * g + r) * AT_PA + c] = eq0[r];
+        buf[(16 + 4 * g + r) * AT_PA + c] = eq1[r];
     }
-    return (s0 + s1) + (s2 + s3);
+    wave_lds_fence();
+    f32x4 rt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rt[r] = buf[(15 + c - 4 * g - r) * AT_PA + c];
+    return rt;
+}
+// band [16 queries][32 distances] -> R[query 4g + r][key c] = band[4g + r][15 + 4g + r - c]
+__device__ __forceinline__ f32x4 at_skew(float* buf, const f32x4& qe0, const f32x4& qe1, int c, int g) {
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        buf[(4 * g + r) * AT_PB + c] = qe0[r];
+        buf[(4 * g + r) * AT_PB + 16 + c] = qe1[r];
+    }
+    wave_lds_fence();
+    f32x4 rr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rr[r] = buf[(4 * g + r) * AT_PB + 15 + 4 * g + r - c];
+    return rr;
 }
 
-// Work split of the four core kernels: a block owns one (sequence, head); its threads are QPB x KS with QPB = L rounded
-// up to a wave multiple and KS = blockDim / QPB.  Thread (iq, ks) owns row iq (a query, a key or a distance) and
-// every KS-th element of the reduction axis, so that a wave reads ONE K / V row (broadcast) and 64 consecutive
-// relative-position rows (conflict-free at pitch 17) per step.  The KS partial results of a row are merged through
-// LDS in ks order (the staged operands are dead by then) - deterministic, no atomics.
-struct AtSplit { int qpb, ks; };
-static AtSplit at_split(int L) {
-    AtSplit sp;
-    sp.qpb = (L + 63) / 64 * 64;
-    sp.ks = 1024 / sp.qpb;
-    if (sp.ks > 8) sp.ks = 8;
-    if (sp.ks < 1) sp.ks = 1;
-    return sp;
-}
-// LDS floats: the larger of the staged operands and the merge buffer [(ks - 1)][qpb][width]
-static size_t at_lds_bytes(size_t staged_floats, const AtSplit& sp, int width) {
-    const size_t merge = (size_t)(sp.ks - 1) * sp.qpb * width;
-    return (staged_floats > merge ? staged_floats : merge) * sizeof(float);
-}
-
-// forward core: online softmax over this thread's keys, then a log-sum-exp merge of the KS partial rows.
-// K and V rows are the same for every lane of a wave (the key index depends only on the wave's ks), so they are read
-// through wave-uniform addresses (scalar loads, operands straight from SGPRs) instead of 32 broadcast LDS reads per
-// step: the LDS pipe, which bounded these kernels, only serves the per-lane relative-position rows.
-__global__ __launch_bounds__(1024) void at_core_fwd_kernel(AtBufs b, const float* __restrict__ rel, int L, int max_pos,
-                                                           int qpb) {
-    extern __shared__ float sm[];
-    float* E = sm;                        // [2L-1][AT_P]
+// forward: o = softmax((q k^T + q E^T) / 4) v and the row log-sum-exp, online over the key blocks.  Everything a query
+// owns (running max, denominator, its o^T column) lives in the lanes with c = its index: the rescale needs no transpose.
+__global__ __launch_bounds__(256) void at_fwd_kernel(AtBufs b, const float* __restrict__ rel, int L, int max_pos, int nb,
+                                                     long ntask) {
+    __shared__ float sm[4][32 * AT_PA];
+    AtTask t;
+    if (!at_task(ntask, nb, t)) return;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    float* buf = sm[threadIdx.x >> 6];
     const float* __restrict__ qkv = b.qkv;
-    const int n = blockIdx.x, h = blockIdx.y;
-    const long base = (long)n * L;
-    const int iq = threadIdx.x % qpb;
-    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x / qpb), KS = blockDim.x / qpb;     // wave-uniform
-    at_stage_rel(E, rel, L, max_pos);
-    __syncthreads();
-    const bool act = iq < L;
-    const int i = act ? iq : L - 1;
-    float q[16], o[16];
-#pragma unroll
-    for (int d = 0; d < 16; ++d) { q[d] = qkv[(base + i) * 192 + 16 * h + d] * 0.25f; o[d] = 0.f; }     // scale = 16^-0.5
+    const int h = t.nh & 3, I0 = 16 * t.blk;
+    const long base = (long)(t.nh >> 2) * L;
+    const f32x4 qa = ldg4(qkv + (base + at_row(I0 + c, L)) * 192 + 16 * h + 4 * g) * splat4(0.25f);     // scale = 16^-0.5
+    f32x4 ot = splat4(0.f);               // o^T[d = 4g + r][query c]
     float m = -1e30f, l = 0.f;
-#pragma unroll 2                          // two steps' scalar loads in flight (measured: 325 -> 285 us)
-    for (int j = ks; j < L; j += KS) {
-        const float* __restrict__ kr = qkv + (base + j) * 192 + 64 + 16 * h;      // uniform
-        const float* __restrict__ vr = kr + 64;
-        const float sc = at_dot16(q, kr) + at_dot16(q, E + (i - j + L - 1) * AT_P);
-        const float mn = fmaxf(m, sc), c = __expf(m - mn), pj = __expf(sc - mn);
-        l = fmaf(l, c, pj);
+    for (int jb = 0; jb < nb; ++jb) {
+        const int J0 = 16 * jb;
+        const f32x4 ka = ldg4(qkv + (base + at_row(J0 + c, L)) * 192 + 64 + 16 * h + 4 * g);
+        f32x4 vb, e0, e1;
 #pragma unroll
-        for (int d = 0; d < 16; ++d) o[d] = fmaf(o[d], c, pj * vr[d]);
-        m = mn;
-    }
-    __syncthreads();                      // E is dead: reuse as the merge buffer [(KS-1)][qpb][18]
-    if (ks > 0) {
-        float* w = sm + ((long)(ks - 1) * qpb + iq) * 18;
-        w[0] = m; w[1] = l;
+        for (int r = 0; r < 4; ++r) vb[r] = qkv[(base + at_row(J0 + 4 * g + r, L)) * 192 + 128 + 16 * h + c];
+        at_band(rel, I0 - J0 - 15, max_pos, c, g, e0, e1);
+        const f32x4 st = at_dot(ka, qa);
+        const f32x4 rt = at_skew_t(buf, at_dot(e0, qa), at_dot(e1, qa), c, g);
+        f32x4 sc;
+        float mx = -1e30f;
 #pragma unroll
-        for (int d = 0; d < 16; ++d) w[2 + d] = o[d];
-    }
-    __syncthreads();
-    if (ks == 0 && act) {
-        for (int k2 = 1; k2 < KS; ++k2) {
-            const float* w = sm + ((long)(k2 - 1) * qpb + iq) * 18;
-            const float m2 = w[0], mn = fmaxf(m, m2), c1 = __expf(m - mn), c2 = __expf(m2 - mn);
-            l = l * c1 + w[1] * c2;
-#pragma unroll
-            for (int d = 0; d < 16; ++d) o[d] = o[d] * c1 + w[2 + d] * c2;
-            m = mn;
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = J0 + 4 * g + r < L ? st[r] + rt[r] : -1e30f;
+            mx = fmaxf(mx, sc[r]);
         }
-        const float inv = 1.0f / l;
+        const float mn = fmaxf(m, red_g_max(mx)), corr = __expf(m - mn);
+        f32x4 p;
+        float ps = 0.f;
 #pragma unroll
-        for (int d = 0; d < 16; ++d) b.o[(base + i) * 64 + 16 * h + d] = o[d] * inv;
-        b.lse[((long)n * 4 + h) * L + i] = m + __logf(l);
+        for (int r = 0; r < 4; ++r) { p[r] = __expf(sc[r] - mn); ps += p[r]; }
+        l = fmaf(l, corr, red_g_sum(ps));
+        ot = ot * splat4(corr);
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot = mfma16(vb[r], p[r], ot);
+    }
+    if (I0 + c < L) {
+        stg4(b.o + (base + I0 + c) * 64 + 16 * h + 4 * g, ot * splat4(1.0f / l));
+        if (g == 0) b.lse[(long)t.nh * L + I0 + c] = m + __logf(l);
     }
 }
 
@@ -1279,194 +1297,212 @@ __global__ __launch_bounds__(256) void at_out_bwd_kernel(const float* __restrict
 
 // p_ij and ds_ij of one (query i, key j) pair; scores are recomputed, never stored.  q is the RAW query row (the
 // 16^-0.5 scale is applied to the score), so that rows can come straight from wave-uniform scalar loads.
-struct AtPair { float p, ds; };
-__device__ __forceinline__ AtPair at_pair(const float* __restrict__ q, const float* __restrict__ kj, const float* __restrict__ er,
-                                          const float* __restrict__ dOi, const float* __restrict__ vj, float lse, float Di) {
-    float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
+// dq: task (n, h, query block); P^T / dS^T tiles (key 4g + r, query c).   dq_i = scale sum_j ds_ij (k_j + E[i - j])
+__global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __restrict__ rel, const float* __restrict__ dO,
+                                                    const float* __restrict__ D, int L, int max_pos, int nb, long ntask,
+                                                    float* __restrict__ dqkv) {
+    __shared__ float sm[4][48 * AT_PA];
+    AtTask t;
+    if (!at_task(ntask, nb, t)) return;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    float* buf = sm[threadIdx.x >> 6];
+    float* buf2 = buf + 32 * AT_PA;       // dS patch [query][key]
+    const float* __restrict__ qkv = b.qkv;
+    const int h = t.nh & 3, I0 = 16 * t.blk;
+    const long base = (long)(t.nh >> 2) * L;
+    const int ri = at_row(I0 + c, L);
+    const bool vi = I0 + c < L;
+    const f32x4 qa = ldg4(qkv + (base + ri) * 192 + 16 * h + 4 * g) * splat4(0.25f);
+    const f32x4 ga = ldg4(dO + (base + ri) * 64 + 16 * h + 4 * g);
+    const float lse = b.lse[(long)t.nh * L + ri], Di = D[(base + ri) * 4 + h];
+    f32x4 dq = splat4(0.f);               // dq[query 4g + r][d = c]
+    for (int jb = 0; jb < nb; ++jb) {
+        const int J0 = 16 * jb, d0 = I0 - J0 - 15;
+        const long rj = (base + at_row(J0 + c, L)) * 192 + 16 * h + 4 * g;
+        const f32x4 ka = ldg4(qkv + rj + 64), va = ldg4(qkv + rj + 128);
+        f32x4 kb, e0, e1;
+        float eb[8];
 #pragma unroll
-    for (int d = 0; d < 16; d += 2) {
-        s0 = fmaf(q[d], kj[d] + er[d], s0);
-        s1 = fmaf(q[d + 1], kj[d + 1] + er[d + 1], s1);
-        t0 = fmaf(dOi[d], vj[d], t0);
-        t1 = fmaf(dOi[d + 1], vj[d + 1], t1);
+        for (int r = 0; r < 4; ++r) kb[r] = qkv[(base + at_row(J0 + 4 * g + r, L)) * 192 + 64 + 16 * h + c];
+        at_band(rel, d0, max_pos, c, g, e0, e1);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) eb[s] = at_erow(rel, d0 + 4 * s + g, max_pos)[c];
+        const f32x4 st = at_dot(ka, qa), dpt = at_dot(va, ga);
+        const f32x4 rt = at_skew_t(buf, at_dot(e0, qa), at_dot(e1, qa), c, g);
+        f32x4 ds;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = (vi && J0 + 4 * g + r < L) ? __expf(st[r] + rt[r] - lse) : 0.f;
+            ds[r] = p * (dpt[r] - Di);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dq = mfma16(ds[r], kb[r], dq);
+        // unskew: dSE[query c][distance 4s + g] = dS[c][15 + c - (4s + g)]
+        wave_lds_fence();
+        *reinterpret_cast<f32x4*>(buf2 + c * AT_PA + 4 * g) = ds;
+        wave_lds_fence();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int jl = 15 + c - 4 * s - g;
+            const float a = (unsigned)jl < 16u ? buf2[c * AT_PA + jl] : 0.f;
+            dq = mfma16(a, eb[s], dq);
+        }
     }
-    AtPair r;
-    r.p = __expf((s0 + s1) * 0.25f - lse);
-    r.ds = r.p * ((t0 + t1) - Di);
-    return r;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (I0 + 4 * g + r < L) dqkv[(base + I0 + 4 * g + r) * 192 + 16 * h + c] = dq[r] * 0.25f;
 }
 
-// sum of the KS partial [W]-vectors of a row through LDS, in ks order; the result lands in acc of the ks = 0 thread
-template <int W>
-__device__ __forceinline__ void at_merge_sum(float* sm, float (&acc)[W], int iq, int ks, int KS, int qpb) {
-    __syncthreads();                      // the staged operands are dead
-    if (ks > 0) {
-        float* w = sm + ((long)(ks - 1) * qpb + iq) * W;
+// one tile in the (query 4g + r, key c) orientation: P and dS.  lse / D are per query ROW here (four per lane).
+__device__ __forceinline__ void at_tile_pds(float* buf, const f32x4& qa, const f32x4& ga, const f32x4& ka, const f32x4& va,
+                                            const f32x4& e0, const f32x4& e1, const f32x4& lse, const f32x4& Dr, int I0,
+                                            bool vj, int L, int c, int g, f32x4& p, f32x4& ds) {
+    const f32x4 sc = at_dot(qa, ka), dp = at_dot(ga, va);
+    const f32x4 rr = at_skew(buf, at_dot(qa, e0), at_dot(qa, e1), c, g);
 #pragma unroll
-        for (int d = 0; d < W; ++d) w[d] = acc[d];
+    for (int r = 0; r < 4; ++r) {
+        p[r] = (vj && I0 + 4 * g + r < L) ? __expf(sc[r] + rr[r] - lse[r]) : 0.f;
+        ds[r] = p[r] * (dp[r] - Dr[r]);
     }
-    __syncthreads();
-    if (ks == 0) {
-        for (int k2 = 1; k2 < KS; ++k2) {
-            const float* w = sm + ((long)(k2 - 1) * qpb + iq) * W;
+}
+
+// dk, dv: task (n, h, key block).          dk_j = scale sum_i ds_ij q_i,  dv_j = sum_i p_ij dO_i
+__global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __restrict__ rel, const float* __restrict__ dO,
+                                                     const float* __restrict__ D, int L, int max_pos, int nb, long ntask,
+                                                     float* __restrict__ dqkv) {
+    __shared__ float sm[4][16 * AT_PB];
+    AtTask t;
+    if (!at_task(ntask, nb, t)) return;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    float* buf = sm[threadIdx.x >> 6];
+    const float* __restrict__ qkv = b.qkv;
+    const float* __restrict__ lsep = b.lse + (long)t.nh * L;
+    const int h = t.nh & 3, J0 = 16 * t.blk;
+    const long base = (long)(t.nh >> 2) * L;
+    const bool vj = J0 + c < L;
+    const long rj = (base + at_row(J0 + c, L)) * 192 + 16 * h + 4 * g;
+    const f32x4 ka = ldg4(qkv + rj + 64), va = ldg4(qkv + rj + 128);
+    f32x4 dk = splat4(0.f), dv = splat4(0.f);        // [key 4g + r][d = c]
+    for (int ib = 0; ib < nb; ++ib) {
+        const int I0 = 16 * ib;
+        const int ri = at_row(I0 + c, L);
+        const f32x4 qa = ldg4(qkv + (base + ri) * 192 + 16 * h + 4 * g) * splat4(0.25f);
+        const f32x4 ga = ldg4(dO + (base + ri) * 64 + 16 * h + 4 * g);
+        f32x4 qb, gb, lse, Dr, e0, e1, p, ds;
 #pragma unroll
-            for (int d = 0; d < W; ++d) acc[d] += w[d];
+        for (int r = 0; r < 4; ++r) {
+            const int rr = at_row(I0 + 4 * g + r, L);
+            qb[r] = qkv[(base + rr) * 192 + 16 * h + c];
+            gb[r] = dO[(base + rr) * 64 + 16 * h + c];
+            lse[r] = lsep[rr];
+            Dr[r] = D[(base + rr) * 4 + h];
+        }
+        at_band(rel, I0 - J0 - 15, max_pos, c, g, e0, e1);
+        at_tile_pds(buf, qa, ga, ka, va, e0, e1, lse, Dr, I0, vj, L, c, g, p, ds);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dk = mfma16(ds[r], qb[r], dk);
+            dv = mfma16(p[r], gb[r], dv);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (J0 + 4 * g + r < L) {
+            dqkv[(base + J0 + 4 * g + r) * 192 + 64 + 16 * h + c] = dk[r] * 0.25f;
+            dqkv[(base + J0 + 4 * g + r) * 192 + 128 + 16 * h + c] = dv[r];
+        }
+}
+
+// dE: task (n, h, t) walks tile diagonal delta = t (nb - t tiles) and then delta = t - nb (t tiles): nb tiles per task.
+// All tiles of a diagonal cover the same 31 distances 16 delta - 15 .. 16 delta + 15, so the band gradient
+//   dEband[dist][:] = scale sum_{i - j = dist} ds_ij q_i
+// stays in two accumulators and is written once per diagonal: slab [(n, h)][delta + nb - 1][32][16].
+__global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __restrict__ rel, const float* __restrict__ dO,
+                                                    const float* __restrict__ D, int L, int max_pos, int nb, long ntask,
+                                                    float* __restrict__ partial) {
+    __shared__ float sm[4][16 * AT_PB + 16 * AT_PA];
+    AtTask t;
+    if (!at_task(ntask, nb, t)) return;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    float* buf = sm[threadIdx.x >> 6];
+    float* buf2 = buf + 16 * AT_PB;       // dS patch [query][key]
+    const float* __restrict__ qkv = b.qkv;
+    const float* __restrict__ lsep = b.lse + (long)t.nh * L;
+    const int h = t.nh & 3;
+    const long base = (long)(t.nh >> 2) * L;
+    for (int seg = 0; seg < 2; ++seg) {
+        if (seg == 1 && t.blk == 0) break;
+        const int delta = seg == 0 ? t.blk : t.blk - nb;
+        const int ntile = seg == 0 ? nb - t.blk : t.blk;
+        const int ib0 = seg == 0 ? t.blk : 0, jb0 = seg == 0 ? 0 : nb - t.blk;
+        f32x4 e0, e1;
+        at_band(rel, 16 * delta - 15, max_pos, c, g, e0, e1);
+        f32x4 de0 = splat4(0.f), de1 = splat4(0.f);  // [distance 16 blk + 4g + r][d = c]
+        for (int k = 0; k < ntile; ++k) {
+            const int I0 = 16 * (ib0 + k), J0 = 16 * (jb0 + k);
+            const int ri = at_row(I0 + c, L);
+            const long rj = (base + at_row(J0 + c, L)) * 192 + 16 * h + 4 * g;
+            const f32x4 qa = ldg4(qkv + (base + ri) * 192 + 16 * h + 4 * g) * splat4(0.25f);
+            const f32x4 ga = ldg4(dO + (base + ri) * 64 + 16 * h + 4 * g);
+            const f32x4 ka = ldg4(qkv + rj + 64), va = ldg4(qkv + rj + 128);
+            f32x4 qb, lse, Dr, p, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = at_row(I0 + 4 * g + r, L);
+                qb[r] = qkv[(base + rr) * 192 + 16 * h + c];
+                lse[r] = lsep[rr];
+                Dr[r] = D[(base + rr) * 4 + h];
+            }
+            at_tile_pds(buf, qa, ga, ka, va, e0, e1, lse, Dr, I0, J0 + c < L, L, c, g, p, ds);
+            // unskew: dSE^T[distance 16 blk + c][query 4g + r] = dS[4g + r][15 + 4g + r - 16 blk - c]
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf2[(4 * g + r) * AT_PA + c] = ds[r];
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j0 = 15 + 4 * g + r - c, j1 = j0 - 16;
+                const float a0 = (unsigned)j0 < 16u ? buf2[(4 * g + r) * AT_PA + j0] : 0.f;
+                const float a1 = (unsigned)j1 < 16u ? buf2[(4 * g + r) * AT_PA + j1] : 0.f;
+                de0 = mfma16(a0, qb[r], de0);
+                de1 = mfma16(a1, qb[r], de1);
+            }
+        }
+        float* out = partial + ((long)t.nh * (2 * nb - 1) + (delta + nb - 1)) * 512;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            out[(4 * g + r) * 16 + c] = de0[r] * 0.25f;
+            out[(16 + 4 * g + r) * 16 + c] = de1[r] * 0.25f;
         }
     }
 }
 
-// In the three backward cores the operands of the reduction axis (the key row in dq; the query row, its dO row, lse
-// and D in dk / dv and dE) are wave-uniform and come from scalar loads; LDS holds only what differs per lane.
-
-// dq: thread (query i, key subset)             dq_i = scale * sum_j ds_ij (k_j + E[i - j])
-__global__ __launch_bounds__(1024) void at_core_bwd_dq_kernel(AtBufs b, const float* __restrict__ rel,
-                                                              const float* __restrict__ dO, const float* __restrict__ D,
-                                                              int L, int max_pos, int qpb, float* __restrict__ dqkv) {
-    extern __shared__ float sm[];
-    float* E = sm;
-    const float* __restrict__ qkv = b.qkv;
-    const int n = blockIdx.x, h = blockIdx.y;
-    const long base = (long)n * L;
-    const int iq = threadIdx.x % qpb;
-    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x / qpb), KS = blockDim.x / qpb;
-    at_stage_rel(E, rel, L, max_pos);
-    __syncthreads();
-    const bool act = iq < L;
-    const int i = act ? iq : L - 1;
-    float q[16], dOi[16], dq[16];
-#pragma unroll
-    for (int d = 0; d < 16; ++d) {
-        q[d] = qkv[(base + i) * 192 + 16 * h + d];
-        dOi[d] = dO[(base + i) * 64 + 16 * h + d];
-        dq[d] = 0.f;
-    }
-    const float lse = b.lse[((long)n * 4 + h) * L + i], Di = D[(base + i) * 4 + h];
-    for (int j = ks; j < L; j += KS) {
-        const float* __restrict__ kr = qkv + (base + j) * 192 + 64 + 16 * h;      // uniform
-        const float* er = E + (i - j + L - 1) * AT_P;
-        const AtPair pr = at_pair(q, kr, er, dOi, kr + 64, lse, Di);
-#pragma unroll
-        for (int d = 0; d < 16; ++d) dq[d] = fmaf(pr.ds, kr[d] + er[d], dq[d]);
-    }
-    at_merge_sum<16>(sm, dq, iq, ks, KS, qpb);
-    if (ks == 0 && act) {
-#pragma unroll
-        for (int d = 0; d < 16; ++d) dqkv[(base + i) * 192 + 16 * h + d] = dq[d] * 0.25f;
-    }
-}
-
-// dk, dv: thread (key j, query subset)          dk_j = scale * sum_i ds_ij q_i,  dv_j = sum_i p_ij dO_i
-__global__ __launch_bounds__(1024) void at_core_bwd_dkv_kernel(AtBufs b, const float* __restrict__ rel,
-                                                               const float* __restrict__ dO, const float* __restrict__ D,
-                                                               int L, int max_pos, int qpb, float* __restrict__ dqkv) {
-    extern __shared__ float sm[];
-    float* E = sm;
-    const float* __restrict__ qkv = b.qkv;
-    const float* __restrict__ lse = b.lse + ((long)blockIdx.x * 4 + blockIdx.y) * L;
-    const int n = blockIdx.x, h = blockIdx.y;
-    const long base = (long)n * L;
-    const int jq = threadIdx.x % qpb;
-    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x / qpb), KS = blockDim.x / qpb;
-    at_stage_rel(E, rel, L, max_pos);
-    __syncthreads();
-    const bool act = jq < L;
-    const int j = act ? jq : L - 1;
-    float kj[16], vj[16], acc[32];         // acc = dk | dv
-#pragma unroll
-    for (int d = 0; d < 16; ++d) {
-        kj[d] = qkv[(base + j) * 192 + 64 + 16 * h + d];
-        vj[d] = qkv[(base + j) * 192 + 128 + 16 * h + d];
-        acc[d] = 0.f; acc[16 + d] = 0.f;
-    }
-#pragma unroll 2
-    for (int i = ks; i < L; i += KS) {
-        const float* __restrict__ qr = qkv + (base + i) * 192 + 16 * h;           // uniform
-        const float* __restrict__ gr = dO + (base + i) * 64 + 16 * h;             // uniform
-        const AtPair pr = at_pair(qr, kj, E + (i - j + L - 1) * AT_P, gr, vj, lse[i], D[(base + i) * 4 + h]);
-#pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            acc[d] = fmaf(pr.ds, qr[d], acc[d]);
-            acc[16 + d] = fmaf(pr.p, gr[d], acc[16 + d]);
-        }
-    }
-    at_merge_sum<32>(sm, acc, jq, ks, KS, qpb);
-    if (ks == 0 && act) {
-#pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            dqkv[(base + j) * 192 + 64 + 16 * h + d] = acc[d] * 0.25f;
-            dqkv[(base + j) * 192 + 128 + 16 * h + d] = acc[16 + d];
-        }
-    }
-}
-
-// dE window: thread (relative distance, diagonal subset)
-//   dEwin[r] = scale * sum_{i - j = r - (L-1)} ds_ij q_i  -> partial [(n,h)][2L-1][16]
-__global__ __launch_bounds__(1024) void at_core_bwd_de_kernel(AtBufs b, const float* __restrict__ rel,
-                                                              const float* __restrict__ dO, const float* __restrict__ D,
-                                                              int L, int max_pos, int qpb, float* __restrict__ partial) {
-    extern __shared__ float sm[];
-    float* K = sm;
-    float* V = K + L * AT_P;
-    const float* __restrict__ qkv = b.qkv;
-    const float* __restrict__ lse = b.lse + ((long)blockIdx.x * 4 + blockIdx.y) * L;
-    const int n = blockIdx.x, h = blockIdx.y;
-    const long base = (long)n * L;
-    const int rq = threadIdx.x % qpb;                             // here qpb >= 2 L - 1
-    const int ks = __builtin_amdgcn_readfirstlane(threadIdx.x / qpb), KS = blockDim.x / qpb;
-    at_stage(K, b.qkv, 192, 64 + 16 * h, base, L);
-    at_stage(V, b.qkv, 192, 128 + 16 * h, base, L);
-    __syncthreads();
-    const bool act = rq < 2 * L - 1;
-    const int r = act ? rq : 2 * L - 2;
-    const int dist = r - (L - 1);
-    const int e = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
-    float er[16], acc[16];
-#pragma unroll
-    for (int d = 0; d < 16; ++d) { er[d] = rel[(long)(e + max_pos) * 16 + d]; acc[d] = 0.f; }
-    // the loop is wave-uniform (the query rows are scalar operands) over the union of the wave's 64 consecutive
-    // diagonals' query ranges; pairs outside a lane's own diagonal contribute nothing
-    const int r_lo = __builtin_amdgcn_readfirstlane(rq);                          // the wave's first distance row
-    const int d_lo = r_lo - (L - 1), d_hi = (r_lo + 63 < 2 * L - 2 ? r_lo + 63 : 2 * L - 2) - (L - 1);
-    const int i_begin = d_lo > 0 ? d_lo : 0, i_end = d_hi < 0 ? L + d_hi : L;
-    for (int i = i_begin + ks; i < i_end; i += KS) {
-        const int j = i - dist;
-        const bool in = j >= 0 && j < L;
-        const int jc = in ? j : 0;
-        const float* __restrict__ qr = qkv + (base + i) * 192 + 16 * h;           // uniform
-        const float* __restrict__ gr = dO + (base + i) * 64 + 16 * h;             // uniform
-        const AtPair pr = at_pair(qr, K + jc * AT_P, er, gr, V + jc * AT_P, lse[i], D[(base + i) * 4 + h]);
-        const float ds = in ? pr.ds : 0.f;
-#pragma unroll
-        for (int d = 0; d < 16; ++d) acc[d] = fmaf(ds, qr[d], acc[d]);
-    }
-    at_merge_sum<16>(sm, acc, rq, ks, KS, qpb);
-    if (ks == 0 && act) {
-#pragma unroll
-        for (int d = 0; d < 16; ++d) partial[(((long)n * 4 + h) * (2 * L - 1) + r) * 16 + d] = acc[d] * 0.25f;
-    }
-}
-
-// rel_pos_emb gradient [2 max_pos + 1][16]: row e sums, in (n, h) then distance order, every window row that maps to it
-__global__ void at_de_scatter_kernel(const float* __restrict__ partial, int NH, int L, int max_pos,
-                                     float* __restrict__ drel) {
+// rel_pos_emb gradient [2 max_pos + 1][16] from the (n, h)-summed diagonal slabs [2 nb - 1][32][16]: row e sums, in
+// distance then diagonal order, every band row whose clamped distance is e - max_pos (a distance lies in the bands of
+// one or two neighbouring diagonals)
+__global__ void at_de_scatter_kernel(const float* __restrict__ slabs, int L, int nb, int max_pos, float* __restrict__ drel) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int rows = 2 * max_pos + 1;
     if (idx >= rows * 16) return;
     const int e = idx >> 4, d = idx & 15;
     const int dist = e - max_pos;
-    // window rows r (distance r - (L-1)) whose clamped distance is `dist`
-    int r0 = dist + (L - 1), r1 = r0;
-    if (dist == -max_pos) r0 = 0;                          // every distance <= -max_pos
-    if (dist == max_pos) r1 = 2 * L - 2;                   // every distance >= +max_pos
+    int lo = dist, hi = dist;
+    if (dist == -max_pos) lo = -(L - 1);                  // every distance <= -max_pos
+    if (dist == max_pos) hi = L - 1;                      // every distance >= +max_pos
+    lo = lo < -(L - 1) ? -(L - 1) : lo;
+    hi = hi > L - 1 ? L - 1 : hi;
     float s = 0.f;
-    if (r1 >= 0 && r0 <= 2 * L - 2) {
-        r0 = r0 < 0 ? 0 : r0;
-        r1 = r1 > 2 * L - 2 ? 2 * L - 2 : r1;
-        for (int nh = 0; nh < NH; ++nh)
-            for (int r = r0; r <= r1; ++r) s += partial[((long)nh * (2 * L - 1) + r) * 16 + d];
+    for (int dd = lo; dd <= hi; ++dd) {
+        // diagonals delta with 16 delta - 15 <= dd <= 16 delta + 15
+        int d_lo = (dd - 15 + 16 * nb + 15) / 16 - nb, d_hi = (dd + 15 + 16 * nb) / 16 - nb;    // ceil / floor, shifted positive
+        d_lo = d_lo < -(nb - 1) ? -(nb - 1) : d_lo;
+        d_hi = d_hi > nb - 1 ? nb - 1 : d_hi;
+        for (int delta = d_lo; delta <= d_hi; ++delta)
+            s += slabs[((long)(delta + nb - 1) * 32 + (dd - (16 * delta - 15))) * 16 + d];
     }
     drel[idx] = s;
 }
+
 
 // backward of the projections: dxn = [to_q ; to_kv]^T dqkv (A image [4][12]), LayerNorm backward
 __global__ __launch_bounds__(256) void at_qkv_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dqkv, long M,
@@ -1520,11 +1556,9 @@ __global__ __launch_bounds__(256) void at_qkv_bwd_kernel(const float* __restrict
 }
 
 // dynamic LDS above the 64 KB default needs an explicit opt-in per kernel
-template <class KernelT>
-static void at_allow_lds(KernelT kernel, size_t bytes) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-}
-
+static int at_blocks(int L) { return (L + 15) / 16; }
+// launch width of the core kernels: four one-wave tasks per block, blocks rounded up to a multiple of the 8 XCDs
+static unsigned at_core_grid(long ntask) { return (unsigned)(((ntask + 3) / 4 + 7) / 8 * 8); }
 struct AtPlan { size_t raw, wqkv, wqkvt, wo, wot, qkv, o, lse, dout, dO, D, dqkv, xn, g1, dxn, depart, dewin, wpart, cpart, total; };
 static AtPlan at_plan(int N, int L) {
     AtPlan p;
@@ -1535,8 +1569,9 @@ static AtPlan at_plan(int N, int L) {
     p.qkv = take(M * 192); p.o = take(M * 64); p.lse = take((size_t)N * 4 * L);
     p.dout = take(M * 64); p.dO = take(M * 64); p.D = take(M * 4); p.dqkv = take(M * 192);
     p.xn = take(M * 64); p.g1 = take(M * 64); p.dxn = take(M * 64);
-    p.depart = take((size_t)N * 4 * (2 * L - 1) * 16);
-    p.dewin = take((size_t)(2 * L - 1) * 16);
+    const size_t slabs = (size_t)(2 * at_blocks(L) - 1) * 512;       // dE band slabs [2 nb - 1][32][16]
+    p.depart = take((size_t)N * 4 * slabs);
+    p.dewin = take(slabs);
     p.wpart = take((size_t)WG_SPLIT * 12288);
     p.cpart = take((size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256);
     p.total = cur;
@@ -1565,10 +1600,9 @@ void launch_attn_train_forward(LaunchCtx ctx, const float* x, int N, int L, cons
     const AtBufs b{ws + pl.qkv, ws + pl.o, ws + pl.lse};
     const unsigned grid = (unsigned)((M + 63) / 64);
     LAUNCH(ctx, "attn_train_fwd", (at_qkv_kernel<<<grid, 256, 0, s>>>(x, M, ws + pl.wqkv, p.ln_w, p.ln_b, b.qkv)));
-    const AtSplit sp = at_split(L);
-    const size_t shm = at_lds_bytes((size_t)(2 * L - 1) * AT_P, sp, 18);
-    at_allow_lds(at_core_fwd_kernel, shm);
-    LAUNCH(ctx, "attn_train_fwd", (at_core_fwd_kernel<<<dim3(N, 4), sp.qpb * sp.ks, shm, s>>>(b, p.rel, L, max_pos, sp.qpb)));
+    const int nb = at_blocks(L);
+    const long ntask = (long)N * 4 * nb;
+    LAUNCH(ctx, "attn_train_fwd", (at_fwd_kernel<<<at_core_grid(ntask), 256, 0, s>>>(b, p.rel, L, max_pos, nb, ntask)));
     LAUNCH(ctx, "attn_train_fwd", (at_out_kernel<<<grid, 256, 0, s>>>(b.o, M, ws + pl.wo, p.bo, mask, ms, res, y)));
 }
 
@@ -1589,28 +1623,23 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
                                                                                                ws + pl.wpart)));
     LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<64, 1024, 0, s>>>(ws + pl.wpart, WG_SPLIT, 4096,
                                                                                 grad.wo)));
-    // attention core: dq (rows), dk / dv (columns), dE (distances)
-    const AtSplit sp = at_split(L), spe = at_split(2 * L - 1);
-    const size_t rel_rows = (size_t)(2 * L - 1) * AT_P;
-    const size_t shm_q = at_lds_bytes(rel_rows, sp, 16);
-    const size_t shm_kv = at_lds_bytes(rel_rows, sp, 32);
-    const size_t shm_e = at_lds_bytes((size_t)2 * L * AT_P, spe, 16);
-    at_allow_lds(at_core_bwd_dq_kernel, shm_q);
-    at_allow_lds(at_core_bwd_dkv_kernel, shm_kv);
-    at_allow_lds(at_core_bwd_de_kernel, shm_e);
-    LAUNCH(ctx, "attn_train_bwd", (at_core_bwd_dq_kernel<<<dim3(N, 4), sp.qpb * sp.ks, shm_q, s>>>(
-                                      b, p.rel, ws + pl.dO, ws + pl.D, L, max_pos, sp.qpb, ws + pl.dqkv)));
-    LAUNCH(ctx, "attn_train_bwd", (at_core_bwd_dkv_kernel<<<dim3(N, 4), sp.qpb * sp.ks, shm_kv, s>>>(
-                                      b, p.rel, ws + pl.dO, ws + pl.D, L, max_pos, sp.qpb, ws + pl.dqkv)));
-    LAUNCH(ctx, "attn_train_bwd", (at_core_bwd_de_kernel<<<dim3(N, 4), spe.qpb * spe.ks, shm_e, s>>>(
-                                      b, p.rel, ws + pl.dO, ws + pl.D, L, max_pos, spe.qpb, ws + pl.depart)));
-    // rel_pos_emb gradient: sum the window partials over (n, h) first (grouped, coalesced), then fold the window rows
-    // onto the clamped table rows
-    const int win_elems = (2 * L - 1) * 16;
-    LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<(win_elems + 63) / 64, 1024, 0, s>>>(ws + pl.depart, N * 4,
-                                                                                                   win_elems, ws + pl.dewin)));
+    // attention core: dq (query blocks), dk / dv (key blocks), dE (tile diagonals)
+    const int nb = at_blocks(L);
+    const long ntask = (long)N * 4 * nb;
+    const unsigned cgrid = at_core_grid(ntask);
+    LAUNCH(ctx, "attn_train_bwd", (at_dq_kernel<<<cgrid, 256, 0, s>>>(b, p.rel, ws + pl.dO, ws + pl.D, L, max_pos, nb, ntask,
+                                                                      ws + pl.dqkv)));
+    LAUNCH(ctx, "attn_train_bwd", (at_dkv_kernel<<<cgrid, 256, 0, s>>>(b, p.rel, ws + pl.dO, ws + pl.D, L, max_pos, nb, ntask,
+                                                                       ws + pl.dqkv)));
+    LAUNCH(ctx, "attn_train_bwd", (at_de_kernel<<<cgrid, 256, 0, s>>>(b, p.rel, ws + pl.dO, ws + pl.D, L, max_pos, nb, ntask,
+                                                                      ws + pl.depart)));
+    // rel_pos_emb gradient: sum the band slabs over (n, h) first (grouped, coalesced), then fold the band rows onto
+    // the clamped table rows
+    const int slab_elems = (2 * nb - 1) * 512;
+    LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<(slab_elems + 63) / 64, 1024, 0, s>>>(ws + pl.depart, N * 4,
+                                                                                                    slab_elems, ws + pl.dewin)));
     const int rel_elems = (2 * max_pos + 1) * 16;
-    LAUNCH(ctx, "attn_train_reduce", (at_de_scatter_kernel<<<(rel_elems + 255) / 256, 256, 0, s>>>(ws + pl.dewin, 1, L, max_pos,
+    LAUNCH(ctx, "attn_train_reduce", (at_de_scatter_kernel<<<(rel_elems + 255) / 256, 256, 0, s>>>(ws + pl.dewin, L, nb, max_pos,
                                                                                                   grad.rel)));
     // projections + LayerNorm
     LAUNCH(ctx, "attn_train_bwd", (at_qkv_bwd_kernel<<<grid, 256, 0, s>>>(x, ws + pl.dqkv, M, ws + pl.wqkvt, p.ln_w, p.ln_b,
