@@ -2,6 +2,7 @@
 // generator forward path: the non-adversarial loss terms of Trainer.calculate_generator_loss (train.py:124-151)
 // as deterministic reductions (the scalars the data-parallel step all-reduces over RCCL).
 #include "train.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------
 // loss_ri  = mse(est_real, clean_real) + mse(est_imag, clean_imag)        train.py:135-137
@@ -1131,10 +1132,13 @@ __global__ __launch_bounds__(256) void at_qkv_kernel(const float* __restrict__ x
 // A-operand layout of the next: dS^T feeds dq, dS feeds dk, P^T feeds o^T, P feeds dv straight from registers.
 // Every sum has a fixed order (a task owns its outputs; dE partial slabs are reduced in (n, h) order afterwards).
 // ---------------------------------------------------------------------------------
-#define AT_PA 20                      // LDS pitch of the [32][16] band patch (E q^T) and of the [16][16] dS patch
+#define AT_PA 20                      // LDS pitch of the [32][16] band patch (E q^T)
 #define AT_PB 36                      // LDS pitch of the [16][32] band patch (q E^T): conflict-free writes, <= 2-way reads
+#define AT_PS 48                      // dS patch row: [16 zeros | 16 keys | 16 zeros] - out-of-tile reads of the unskew are 0
+#define AT_LOG2E 1.4426950408889634f  // scores are kept in log2 units: p = v_exp_f32(s - lse) without a multiply
+#define AT_QSCALE (0.25f * AT_LOG2E)  // dim_head^-0.5 * log2(e), folded into the q fragment of every score product
 
-struct AtTask { int nh, blk; };
+struct AtTask { int nh, blk; };       // wave-uniform (SGPRs)
 // blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of tasks so that the waves sharing one
 // (n, h)'s q / k / v / dO rows sit behind the same L2
 __device__ __forceinline__ bool at_task(long ntask, int nb, AtTask& t) {
@@ -1142,8 +1146,9 @@ __device__ __forceinline__ bool at_task(long ntask, int nb, AtTask& t) {
     const long blk = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
     const long task = blk * 4 + (threadIdx.x >> 6);
     if (task >= ntask) return false;
-    t.nh = (int)(task / nb);
-    t.blk = (int)(task - (long)t.nh * nb);
+    const int nh = (int)(task / nb);
+    t.nh = __builtin_amdgcn_readfirstlane(nh);
+    t.blk = __builtin_amdgcn_readfirstlane((int)(task - (long)nh * nb));
     return true;
 }
 __device__ __forceinline__ f32x4 at_dot(const f32x4& a, const f32x4& b) {
@@ -1152,15 +1157,25 @@ __device__ __forceinline__ f32x4 at_dot(const f32x4& a, const f32x4& b) {
     for (int s = 0; s < 4; ++s) acc = mfma16(a[s], b[s], acc);
     return acc;
 }
-__device__ __forceinline__ int at_row(int r, int L) { return r < L ? r : L - 1; }           // readable (clamped) row
-__device__ __forceinline__ const float* at_erow(const float* __restrict__ rel, int dist, int max_pos) {
-    dist = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
-    return rel + (long)(dist + max_pos) * 16;
+// lane offsets (floats) of the fragments of the 16 rows that start at row R0 of a sequence of L rows, relative to row
+// R0: rows past the end read row L - 1 (finite; masked or never stored).  Full blocks use the affine forms
+// c * stride + 4g / (4g + r) * stride + c, which cost no VALU inside the loops (uniform row pointer + immediates).
+__device__ __forceinline__ unsigned at_off_a(int R0, int L, int stride, int c, int g) {
+    const int r = R0 + c < L ? c : L - 1 - R0;
+    return (unsigned)(r * stride + 4 * g);
 }
-// A-type fragments of the two 16-distance halves of the band that starts at distance d0
-__device__ __forceinline__ void at_band(const float* __restrict__ rel, int d0, int max_pos, int c, int g, f32x4& e0, f32x4& e1) {
-    e0 = ldg4(at_erow(rel, d0 + c, max_pos) + 4 * g);
-    e1 = ldg4(at_erow(rel, d0 + 16 + c, max_pos) + 4 * g);
+__device__ __forceinline__ unsigned at_off_b(int R0, int L, int stride, int c, int g, int r) {
+    const int rr = R0 + 4 * g + r < L ? 4 * g + r : L - 1 - R0;
+    return (unsigned)(rr * stride + c);
+}
+// relative-position window: row w <-> distance w - W (W = 16 nb + 16 covers every band a tile can ask for), table row
+// clamp(distance, +-max_pos) + max_pos - the clamp of conformer.py:104 is applied once here, the cores index affinely
+__global__ void at_window_kernel(const float* __restrict__ rel, int W, int max_pos, float* __restrict__ ewin) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (2 * W + 1) * 16) return;
+    int dist = (idx >> 4) - W;
+    dist = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
+    ewin[idx] = rel[(long)(dist + max_pos) * 16 + (idx & 15)];
 }
 // band^T [32 distances][16 queries] (two accumulators) -> R^T[key 4g + r][query c] = band[15 + c - (4g + r)][c]
 __device__ __forceinline__ f32x4 at_skew_t(float* buf, const f32x4& eq0, const f32x4& eq1, int c, int g) {
@@ -1173,7 +1188,7 @@ __device__ __forceinline__ f32x4 at_skew_t(float* buf, const f32x4& eq0, const f
     wave_lds_fence();
     f32x4 rt;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rt[r] = buf[(15 + c - 4 * g - r) * AT_PA + c];
+    for (int r = 0; r < 4; ++r) rt[r] = buf[(15 + c - 4 * g) * AT_PA + c - r * AT_PA];
     return rt;
 }
 // band [16 queries][32 distances] -> R[query 4g + r][key c] = band[4g + r][15 + 4g + r - c]
@@ -1187,55 +1202,66 @@ __device__ __forceinline__ f32x4 at_skew(float* buf, const f32x4& qe0, const f32
     wave_lds_fence();
     f32x4 rr;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rr[r] = buf[(4 * g + r) * AT_PB + 15 + 4 * g + r - c];
+    for (int r = 0; r < 4; ++r) rr[r] = buf[4 * g * (AT_PB + 1) + 15 - c + r * (AT_PB + 1)];
     return rr;
+}
+__device__ __forceinline__ void at_zero_pads(float* patch, int lane) {
+    for (int i = lane; i < 16 * 32; i += 64) patch[(i >> 5) * AT_PS + ((i & 31) < 16 ? (i & 31) : 16 + (i & 31))] = 0.f;
 }
 
 // forward: o = softmax((q k^T + q E^T) / 4) v and the row log-sum-exp, online over the key blocks.  Everything a query
 // owns (running max, denominator, its o^T column) lives in the lanes with c = its index: the rescale needs no transpose.
-__global__ __launch_bounds__(256) void at_fwd_kernel(AtBufs b, const float* __restrict__ rel, int L, int max_pos, int nb,
-                                                     long ntask) {
+// The band product of a tile's upper 16 distances is the lower one of the previous key block: 4 new MFMAs per tile.
+__global__ __launch_bounds__(256) void at_fwd_kernel(AtBufs b, const float* __restrict__ ewin, int L, int nb, long ntask) {
     __shared__ float sm[4][32 * AT_PA];
     AtTask t;
     if (!at_task(ntask, nb, t)) return;
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     float* buf = sm[threadIdx.x >> 6];
-    const float* __restrict__ qkv = b.qkv;
-    const int h = t.nh & 3, I0 = 16 * t.blk;
+    const int h = t.nh & 3, I0 = 16 * t.blk, W = 16 * nb + 16, nfull = L >> 4;
     const long base = (long)(t.nh >> 2) * L;
-    const f32x4 qa = ldg4(qkv + (base + at_row(I0 + c, L)) * 192 + 16 * h + 4 * g) * splat4(0.25f);     // scale = 16^-0.5
+    const float* __restrict__ qh = b.qkv + base * 192 + 16 * h;                    // uniform: this head's q | k | v rows
+    const float* __restrict__ e_blk = ewin + (long)(I0 - 15 + W) * 16;             // band of key block 0; block jb: - 256 jb
+    const f32x4 qa = ldg4(qh + (long)I0 * 192 + at_off_a(I0, L, 192, c, g)) * splat4(AT_QSCALE);
+    const unsigned la = c * 192 + 4 * g, lb = 4 * g * 192 + c, le = c * 16 + 4 * g;
+    const unsigned la_t = at_off_a(16 * nfull, L, 192, c, g);
+    unsigned lb_t[4];
+    bool vt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { lb_t[r] = at_off_b(16 * nfull, L, 192, c, g, r); vt[r] = 16 * nfull + 4 * g + r < L; }
     f32x4 ot = splat4(0.f);               // o^T[d = 4g + r][query c]
     float m = -1e30f, l = 0.f;
-    for (int jb = 0; jb < nb; ++jb) {
-        const int J0 = 16 * jb;
-        const f32x4 ka = ldg4(qkv + (base + at_row(J0 + c, L)) * 192 + 64 + 16 * h + 4 * g);
-        f32x4 vb, e0, e1;
+    f32x4 eq1 = at_dot(ldg4(e_blk + 256 + le), qa);
+    auto tile = [&](auto tail, int jb) {
+        constexpr bool TAIL = decltype(tail)::value;
+        const float* __restrict__ kp = qh + 64 + (long)jb * (16 * 192);
+        const f32x4 ka = ldg4(kp + (TAIL ? la_t : la));
+        f32x4 vb;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vb[r] = qkv[(base + at_row(J0 + 4 * g + r, L)) * 192 + 128 + 16 * h + c];
-        at_band(rel, I0 - J0 - 15, max_pos, c, g, e0, e1);
+        for (int r = 0; r < 4; ++r) vb[r] = kp[64 + (TAIL ? lb_t[r] : lb + r * 192)];
+        const f32x4 eq0 = at_dot(ldg4(e_blk - (long)jb * 256 + le), qa);
         const f32x4 st = at_dot(ka, qa);
-        const f32x4 rt = at_skew_t(buf, at_dot(e0, qa), at_dot(e1, qa), c, g);
+        const f32x4 rt = at_skew_t(buf, eq0, eq1, c, g);
+        eq1 = eq0;
         f32x4 sc;
-        float mx = -1e30f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            sc[r] = J0 + 4 * g + r < L ? st[r] + rt[r] : -1e30f;
-            mx = fmaxf(mx, sc[r]);
-        }
-        const float mn = fmaxf(m, red_g_max(mx)), corr = __expf(m - mn);
+        for (int r = 0; r < 4; ++r) sc[r] = (!TAIL || vt[r]) ? st[r] + rt[r] : -1e30f;
+        const float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        const float mn = fmaxf(m, red_g_max(mx)), corr = __builtin_amdgcn_exp2f(m - mn);
         f32x4 p;
-        float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { p[r] = __expf(sc[r] - mn); ps += p[r]; }
-        l = fmaf(l, corr, red_g_sum(ps));
+        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(sc[r] - mn);
+        l = fmaf(l, corr, red_g_sum((p[0] + p[1]) + (p[2] + p[3])));
         ot = ot * splat4(corr);
         m = mn;
 #pragma unroll
         for (int r = 0; r < 4; ++r) ot = mfma16(vb[r], p[r], ot);
-    }
+    };
+    for (int jb = 0; jb < nfull; ++jb) tile(std::false_type{}, jb);
+    if (nfull < nb) tile(std::true_type{}, nfull);
     if (I0 + c < L) {
-        stg4(b.o + (base + I0 + c) * 64 + 16 * h + 4 * g, ot * splat4(1.0f / l));
-        if (g == 0) b.lse[(long)t.nh * L + I0 + c] = m + __logf(l);
+        stg4(b.o + (base + I0 + c) * 64 + 16 * h + 4 * g, ot * splat4(__builtin_amdgcn_rcpf(l)));
+        if (g == 0) b.lse[(long)t.nh * L + I0 + c] = (m + __log2f(l)) * 0.6931471805599453f;
     }
 }
 
@@ -1298,113 +1324,142 @@ __global__ __launch_bounds__(256) void at_out_bwd_kernel(const float* __restrict
 // p_ij and ds_ij of one (query i, key j) pair; scores are recomputed, never stored.  q is the RAW query row (the
 // 16^-0.5 scale is applied to the score), so that rows can come straight from wave-uniform scalar loads.
 // dq: task (n, h, query block); P^T / dS^T tiles (key 4g + r, query c).   dq_i = scale sum_j ds_ij (k_j + E[i - j])
-__global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __restrict__ rel, const float* __restrict__ dO,
-                                                    const float* __restrict__ D, int L, int max_pos, int nb, long ntask,
+__global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ dO,
+                                                    const float* __restrict__ D, int L, int nb, long ntask,
                                                     float* __restrict__ dqkv) {
-    __shared__ float sm[4][48 * AT_PA];
+    __shared__ float sm[4][32 * AT_PA + 16 * AT_PS];
     AtTask t;
     if (!at_task(ntask, nb, t)) return;
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     float* buf = sm[threadIdx.x >> 6];
-    float* buf2 = buf + 32 * AT_PA;       // dS patch [query][key]
-    const float* __restrict__ qkv = b.qkv;
-    const int h = t.nh & 3, I0 = 16 * t.blk;
+    float* buf2 = buf + 32 * AT_PA;       // dS patch [query][16 + key]
+    at_zero_pads(buf2, lane);
+    const int h = t.nh & 3, I0 = 16 * t.blk, W = 16 * nb + 16, nfull = L >> 4;
     const long base = (long)(t.nh >> 2) * L;
-    const int ri = at_row(I0 + c, L);
-    const bool vi = I0 + c < L;
-    const f32x4 qa = ldg4(qkv + (base + ri) * 192 + 16 * h + 4 * g) * splat4(0.25f);
+    const float* __restrict__ qh = b.qkv + base * 192 + 16 * h;
+    const float* __restrict__ e_blk = ewin + (long)(I0 - 15 + W) * 16;
+    const int ri = I0 + c < L ? I0 + c : L - 1;
+    const f32x4 qa = ldg4(qh + (long)ri * 192 + 4 * g) * splat4(AT_QSCALE);
     const f32x4 ga = ldg4(dO + (base + ri) * 64 + 16 * h + 4 * g);
-    const float lse = b.lse[(long)t.nh * L + ri], Di = D[(base + ri) * 4 + h];
+    const float lse = b.lse[(long)t.nh * L + ri] * AT_LOG2E, Di = D[(base + ri) * 4 + h];
+    const unsigned la = c * 192 + 4 * g, lb = 4 * g * 192 + c, le = c * 16 + 4 * g, lg = g * 16 + c;
+    const unsigned la_t = at_off_a(16 * nfull, L, 192, c, g);
+    unsigned lb_t[4];
+    bool vt[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { lb_t[r] = at_off_b(16 * nfull, L, 192, c, g, r); vt[r] = 16 * nfull + 4 * g + r < L; }
     f32x4 dq = splat4(0.f);               // dq[query 4g + r][d = c]
-    for (int jb = 0; jb < nb; ++jb) {
-        const int J0 = 16 * jb, d0 = I0 - J0 - 15;
-        const long rj = (base + at_row(J0 + c, L)) * 192 + 16 * h + 4 * g;
-        const f32x4 ka = ldg4(qkv + rj + 64), va = ldg4(qkv + rj + 128);
-        f32x4 kb, e0, e1;
-        float eb[8];
+    f32x4 eq1 = at_dot(ldg4(e_blk + 256 + le), qa);
+    f32x4 eb_prev;                        // E rows of the previous key block's lower 16 distances = this block's upper 16
 #pragma unroll
-        for (int r = 0; r < 4; ++r) kb[r] = qkv[(base + at_row(J0 + 4 * g + r, L)) * 192 + 64 + 16 * h + c];
-        at_band(rel, d0, max_pos, c, g, e0, e1);
+    for (int s = 0; s < 4; ++s) eb_prev[s] = e_blk[256 + lg + 64 * s];
+    auto tile = [&](auto tail, int jb) {
+        constexpr bool TAIL = decltype(tail)::value;
+        const float* __restrict__ kp = qh + 64 + (long)jb * (16 * 192);
+        const float* __restrict__ ep = e_blk - (long)jb * 256;
+        const f32x4 ka = ldg4(kp + (TAIL ? la_t : la)), va = ldg4(kp + 64 + (TAIL ? la_t : la));
+        f32x4 kb, eb_lo;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) eb[s] = at_erow(rel, d0 + 4 * s + g, max_pos)[c];
+        for (int r = 0; r < 4; ++r) kb[r] = kp[TAIL ? lb_t[r] : lb + r * 192];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) eb_lo[s] = ep[lg + 64 * s];
+        const f32x4 eq0 = at_dot(ldg4(ep + le), qa);
         const f32x4 st = at_dot(ka, qa), dpt = at_dot(va, ga);
-        const f32x4 rt = at_skew_t(buf, at_dot(e0, qa), at_dot(e1, qa), c, g);
+        const f32x4 rt = at_skew_t(buf, eq0, eq1, c, g);
+        eq1 = eq0;
         f32x4 ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float p = (vi && J0 + 4 * g + r < L) ? __expf(st[r] + rt[r] - lse) : 0.f;
+            const float p = (!TAIL || vt[r]) ? __builtin_amdgcn_exp2f(st[r] + rt[r] - lse) : 0.f;
             ds[r] = p * (dpt[r] - Di);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) dq = mfma16(ds[r], kb[r], dq);
-        // unskew: dSE[query c][distance 4s + g] = dS[c][15 + c - (4s + g)]
+        // unskew: dSE[query c][distance 4s + g] = dS[c][15 + c - (4s + g)], zero outside the tile (the pads)
         wave_lds_fence();
-        *reinterpret_cast<f32x4*>(buf2 + c * AT_PA + 4 * g) = ds;
+        *reinterpret_cast<f32x4*>(buf2 + c * AT_PS + 16 + 4 * g) = ds;
         wave_lds_fence();
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int jl = 15 + c - 4 * s - g;
-            const float a = (unsigned)jl < 16u ? buf2[c * AT_PA + jl] : 0.f;
-            dq = mfma16(a, eb[s], dq);
+            const float a = buf2[c * (AT_PS + 1) + 3 - g + 4 * (7 - s)];
+            dq = mfma16(a, s < 4 ? eb_lo[s] : eb_prev[s - 4], dq);
         }
-    }
+        eb_prev = eb_lo;
+    };
+    for (int jb = 0; jb < nfull; ++jb) tile(std::false_type{}, jb);
+    if (nfull < nb) tile(std::true_type{}, nfull);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (I0 + 4 * g + r < L) dqkv[(base + I0 + 4 * g + r) * 192 + 16 * h + c] = dq[r] * 0.25f;
 }
 
-// one tile in the (query 4g + r, key c) orientation: P and dS.  lse / D are per query ROW here (four per lane).
+// one tile in the (query 4g + r, key c) orientation: P and dS.  lse (log2 units) / D are per query ROW here.
 __device__ __forceinline__ void at_tile_pds(float* buf, const f32x4& qa, const f32x4& ga, const f32x4& ka, const f32x4& va,
-                                            const f32x4& e0, const f32x4& e1, const f32x4& lse, const f32x4& Dr, int I0,
-                                            bool vj, int L, int c, int g, f32x4& p, f32x4& ds) {
+                                            const f32x4& e0, const f32x4& e1, const f32x4& lse, const f32x4& Dr, int c, int g,
+                                            f32x4& p, f32x4& ds) {
     const f32x4 sc = at_dot(qa, ka), dp = at_dot(ga, va);
     const f32x4 rr = at_skew(buf, at_dot(qa, e0), at_dot(qa, e1), c, g);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        p[r] = (vj && I0 + 4 * g + r < L) ? __expf(sc[r] + rr[r] - lse[r]) : 0.f;
+        p[r] = __builtin_amdgcn_exp2f(sc[r] + rr[r] - lse[r]);
         ds[r] = p[r] * (dp[r] - Dr[r]);
     }
 }
 
 // dk, dv: task (n, h, key block).          dk_j = scale sum_i ds_ij q_i,  dv_j = sum_i p_ij dO_i
-__global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __restrict__ rel, const float* __restrict__ dO,
-                                                     const float* __restrict__ D, int L, int max_pos, int nb, long ntask,
+// (key columns past the end of the sequence only feed their own, never stored, rows: no mask for them)
+__global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ dO,
+                                                     const float* __restrict__ D, int L, int nb, long ntask,
                                                      float* __restrict__ dqkv) {
     __shared__ float sm[4][16 * AT_PB];
     AtTask t;
     if (!at_task(ntask, nb, t)) return;
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     float* buf = sm[threadIdx.x >> 6];
-    const float* __restrict__ qkv = b.qkv;
-    const float* __restrict__ lsep = b.lse + (long)t.nh * L;
-    const int h = t.nh & 3, J0 = 16 * t.blk;
+    const int h = t.nh & 3, J0 = 16 * t.blk, W = 16 * nb + 16, nfull = L >> 4;
     const long base = (long)(t.nh >> 2) * L;
-    const bool vj = J0 + c < L;
-    const long rj = (base + at_row(J0 + c, L)) * 192 + 16 * h + 4 * g;
-    const f32x4 ka = ldg4(qkv + rj + 64), va = ldg4(qkv + rj + 128);
+    const float* __restrict__ qh = b.qkv + base * 192 + 16 * h;
+    const float* __restrict__ gh = dO + base * 64 + 16 * h;
+    const float* __restrict__ lh = b.lse + (long)t.nh * L;
+    const float* __restrict__ Dh = D + base * 4 + h;
+    const float* __restrict__ e_blk = ewin + (long)(W - J0 - 15) * 16;             // band of query block 0; block ib: + 256 ib
+    const long rj = (long)J0 * 192 + at_off_a(J0, L, 192, c, g);
+    const f32x4 ka = ldg4(qh + 64 + rj), va = ldg4(qh + 128 + rj);
+    const unsigned le = c * 16 + 4 * g;
     f32x4 dk = splat4(0.f), dv = splat4(0.f);        // [key 4g + r][d = c]
-    for (int ib = 0; ib < nb; ++ib) {
+    f32x4 e0 = ldg4(e_blk + le);
+    auto tile = [&](auto tail, int ib) {
+        constexpr bool TAIL = decltype(tail)::value;
         const int I0 = 16 * ib;
-        const int ri = at_row(I0 + c, L);
-        const f32x4 qa = ldg4(qkv + (base + ri) * 192 + 16 * h + 4 * g) * splat4(0.25f);
-        const f32x4 ga = ldg4(dO + (base + ri) * 64 + 16 * h + 4 * g);
-        f32x4 qb, gb, lse, Dr, e0, e1, p, ds;
+        const float* __restrict__ qp = qh + (long)ib * (16 * 192);
+        const float* __restrict__ gp = gh + (long)ib * (16 * 64);
+        const f32x4 qa = ldg4(qp + (TAIL ? at_off_a(I0, L, 192, c, g) : c * 192 + 4 * g)) * splat4(AT_QSCALE);
+        const f32x4 ga = ldg4(gp + (TAIL ? at_off_a(I0, L, 64, c, g) : c * 64 + 4 * g));
+        const f32x4 e1 = ldg4(e_blk + (long)ib * 256 + 256 + le);
+        f32x4 qb, gb, lse, Dr, p, ds;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int rr = at_row(I0 + 4 * g + r, L);
-            qb[r] = qkv[(base + rr) * 192 + 16 * h + c];
-            gb[r] = dO[(base + rr) * 64 + 16 * h + c];
-            lse[r] = lsep[rr];
-            Dr[r] = D[(base + rr) * 4 + h];
+            const int rr = TAIL ? (I0 + 4 * g + r < L ? 4 * g + r : L - 1 - I0) : 4 * g + r;
+            qb[r] = qp[rr * 192 + c];
+            gb[r] = gp[rr * 64 + c];
+            lse[r] = lh[I0 + rr] * AT_LOG2E;
+            Dr[r] = Dh[(long)(I0 + rr) * 4];
         }
-        at_band(rel, I0 - J0 - 15, max_pos, c, g, e0, e1);
-        at_tile_pds(buf, qa, ga, ka, va, e0, e1, lse, Dr, I0, vj, L, c, g, p, ds);
+        at_tile_pds(buf, qa, ga, ka, va, e0, e1, lse, Dr, c, g, p, ds);
+        e0 = e1;
+        if (TAIL) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (I0 + 4 * g + r >= L) { p[r] = 0.f; ds[r] = 0.f; }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             dk = mfma16(ds[r], qb[r], dk);
             dv = mfma16(p[r], gb[r], dv);
         }
-    }
+    };
+    for (int ib = 0; ib < nfull; ++ib) tile(std::false_type{}, ib);
+    if (nfull < nb) tile(std::true_type{}, nfull);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (J0 + 4 * g + r < L) {
@@ -1417,56 +1472,70 @@ __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __re
 // All tiles of a diagonal cover the same 31 distances 16 delta - 15 .. 16 delta + 15, so the band gradient
 //   dEband[dist][:] = scale sum_{i - j = dist} ds_ij q_i
 // stays in two accumulators and is written once per diagonal: slab [(n, h)][delta + nb - 1][32][16].
-__global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __restrict__ rel, const float* __restrict__ dO,
-                                                    const float* __restrict__ D, int L, int max_pos, int nb, long ntask,
+__global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ dO,
+                                                    const float* __restrict__ D, int L, int nb, long ntask,
                                                     float* __restrict__ partial) {
-    __shared__ float sm[4][16 * AT_PB + 16 * AT_PA];
+    __shared__ float sm[4][16 * AT_PB + 16 * AT_PS];
     AtTask t;
     if (!at_task(ntask, nb, t)) return;
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     float* buf = sm[threadIdx.x >> 6];
-    float* buf2 = buf + 16 * AT_PB;       // dS patch [query][key]
-    const float* __restrict__ qkv = b.qkv;
-    const float* __restrict__ lsep = b.lse + (long)t.nh * L;
-    const int h = t.nh & 3;
+    float* buf2 = buf + 16 * AT_PB;       // dS patch [query][16 + key]
+    at_zero_pads(buf2, lane);
+    const int h = t.nh & 3, W = 16 * nb + 16, nfull = L >> 4;
     const long base = (long)(t.nh >> 2) * L;
+    const float* __restrict__ qh = b.qkv + base * 192 + 16 * h;
+    const float* __restrict__ gh = dO + base * 64 + 16 * h;
+    const float* __restrict__ lh = b.lse + (long)t.nh * L;
+    const float* __restrict__ Dh = D + base * 4 + h;
+    const unsigned le = c * 16 + 4 * g;
     for (int seg = 0; seg < 2; ++seg) {
         if (seg == 1 && t.blk == 0) break;
         const int delta = seg == 0 ? t.blk : t.blk - nb;
         const int ntile = seg == 0 ? nb - t.blk : t.blk;
         const int ib0 = seg == 0 ? t.blk : 0, jb0 = seg == 0 ? 0 : nb - t.blk;
-        f32x4 e0, e1;
-        at_band(rel, 16 * delta - 15, max_pos, c, g, e0, e1);
+        const float* __restrict__ ep = ewin + (long)(16 * delta - 15 + W) * 16;
+        const f32x4 e0 = ldg4(ep + le), e1 = ldg4(ep + 256 + le);
         f32x4 de0 = splat4(0.f), de1 = splat4(0.f);  // [distance 16 blk + 4g + r][d = c]
-        for (int k = 0; k < ntile; ++k) {
+        auto tile = [&](auto tail, int k) {
+            constexpr bool TAIL = decltype(tail)::value;
             const int I0 = 16 * (ib0 + k), J0 = 16 * (jb0 + k);
-            const int ri = at_row(I0 + c, L);
-            const long rj = (base + at_row(J0 + c, L)) * 192 + 16 * h + 4 * g;
-            const f32x4 qa = ldg4(qkv + (base + ri) * 192 + 16 * h + 4 * g) * splat4(0.25f);
-            const f32x4 ga = ldg4(dO + (base + ri) * 64 + 16 * h + 4 * g);
-            const f32x4 ka = ldg4(qkv + rj + 64), va = ldg4(qkv + rj + 128);
+            const float* __restrict__ qp = qh + (long)I0 * 192;
+            const float* __restrict__ gp = gh + (long)I0 * 64;
+            const float* __restrict__ kp = qh + 64 + (long)J0 * 192;
+            const f32x4 qa = ldg4(qp + (TAIL ? at_off_a(I0, L, 192, c, g) : c * 192 + 4 * g)) * splat4(AT_QSCALE);
+            const f32x4 ga = ldg4(gp + (TAIL ? at_off_a(I0, L, 64, c, g) : c * 64 + 4 * g));
+            const unsigned oj = TAIL ? at_off_a(J0, L, 192, c, g) : c * 192 + 4 * g;
+            const f32x4 ka = ldg4(kp + oj), va = ldg4(kp + 64 + oj);
             f32x4 qb, lse, Dr, p, ds;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int rr = at_row(I0 + 4 * g + r, L);
-                qb[r] = qkv[(base + rr) * 192 + 16 * h + c];
-                lse[r] = lsep[rr];
-                Dr[r] = D[(base + rr) * 4 + h];
+                const int rr = TAIL ? (I0 + 4 * g + r < L ? 4 * g + r : L - 1 - I0) : 4 * g + r;
+                qb[r] = qp[rr * 192 + c];
+                lse[r] = lh[I0 + rr] * AT_LOG2E;
+                Dr[r] = Dh[(long)(I0 + rr) * 4];
             }
-            at_tile_pds(buf, qa, ga, ka, va, e0, e1, lse, Dr, I0, J0 + c < L, L, c, g, p, ds);
-            // unskew: dSE^T[distance 16 blk + c][query 4g + r] = dS[4g + r][15 + 4g + r - 16 blk - c]
+            at_tile_pds(buf, qa, ga, ka, va, e0, e1, lse, Dr, c, g, p, ds);
+            if (TAIL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (I0 + 4 * g + r >= L || J0 + c >= L) ds[r] = 0.f;
+            }
+            // unskew: dSE^T[distance 16 blk + c][query 4g + r] = dS[4g + r][15 + 4g + r - 16 blk - c], zero outside
             wave_lds_fence();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) buf2[(4 * g + r) * AT_PA + c] = ds[r];
+            for (int r = 0; r < 4; ++r) buf2[(4 * g + r) * AT_PS + 16 + c] = ds[r];
             wave_lds_fence();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int j0 = 15 + 4 * g + r - c, j1 = j0 - 16;
-                const float a0 = (unsigned)j0 < 16u ? buf2[(4 * g + r) * AT_PA + j0] : 0.f;
-                const float a1 = (unsigned)j1 < 16u ? buf2[(4 * g + r) * AT_PA + j1] : 0.f;
-                de0 = mfma16(a0, qb[r], de0);
-                de1 = mfma16(a1, qb[r], de1);
+                const float* row = buf2 + 4 * g * (AT_PS + 1) + 15 - c + r * (AT_PS + 1);
+                de0 = mfma16(row[16], qb[r], de0);
+                de1 = mfma16(row[0], qb[r], de1);
             }
+        };
+        for (int k = 0; k < ntile; ++k) {
+            if (ib0 + k >= nfull || jb0 + k >= nfull) tile(std::true_type{}, k);
+            else tile(std::false_type{}, k);
         }
         float* out = partial + ((long)t.nh * (2 * nb - 1) + (delta + nb - 1)) * 512;
 #pragma unroll
@@ -1557,15 +1626,17 @@ __global__ __launch_bounds__(256) void at_qkv_bwd_kernel(const float* __restrict
 
 // dynamic LDS above the 64 KB default needs an explicit opt-in per kernel
 static int at_blocks(int L) { return (L + 15) / 16; }
+static int at_window(int L) { return 16 * at_blocks(L) + 16; }      // half-width W of the relative-position window
 // launch width of the core kernels: four one-wave tasks per block, blocks rounded up to a multiple of the 8 XCDs
 static unsigned at_core_grid(long ntask) { return (unsigned)(((ntask + 3) / 4 + 7) / 8 * 8); }
-struct AtPlan { size_t raw, wqkv, wqkvt, wo, wot, qkv, o, lse, dout, dO, D, dqkv, xn, g1, dxn, depart, dewin, wpart, cpart, total; };
+struct AtPlan { size_t raw, wqkv, wqkvt, wo, wot, ewin, qkv, o, lse, dout, dO, D, dqkv, xn, g1, dxn, depart, dewin, wpart, cpart, total; };
 static AtPlan at_plan(int N, int L) {
     AtPlan p;
     const size_t M = (size_t)N * L;
     size_t cur = 0;
     auto take = [&](size_t n) { const size_t o = cur; cur += (n + 63) & ~(size_t)63; return o; };
     p.raw = take(12288); p.wqkv = take(12288); p.wqkvt = take(12288); p.wo = take(4096); p.wot = take(4096);
+    p.ewin = take((size_t)(2 * at_window(L) + 1) * 16);
     p.qkv = take(M * 192); p.o = take(M * 64); p.lse = take((size_t)N * 4 * L);
     p.dout = take(M * 64); p.dO = take(M * 64); p.D = take(M * 4); p.dqkv = take(M * 192);
     p.xn = take(M * 64); p.g1 = take(M * 64); p.dxn = take(M * 64);
@@ -1602,7 +1673,9 @@ void launch_attn_train_forward(LaunchCtx ctx, const float* x, int N, int L, cons
     LAUNCH(ctx, "attn_train_fwd", (at_qkv_kernel<<<grid, 256, 0, s>>>(x, M, ws + pl.wqkv, p.ln_w, p.ln_b, b.qkv)));
     const int nb = at_blocks(L);
     const long ntask = (long)N * 4 * nb;
-    LAUNCH(ctx, "attn_train_fwd", (at_fwd_kernel<<<at_core_grid(ntask), 256, 0, s>>>(b, p.rel, L, max_pos, nb, ntask)));
+    const int W = at_window(L);
+    LAUNCH(ctx, "attn_train_pack", (at_window_kernel<<<((2 * W + 1) * 16 + 255) / 256, 256, 0, s>>>(p.rel, W, max_pos, ws + pl.ewin)));
+    LAUNCH(ctx, "attn_train_fwd", (at_fwd_kernel<<<at_core_grid(ntask), 256, 0, s>>>(b, ws + pl.ewin, L, nb, ntask)));
     LAUNCH(ctx, "attn_train_fwd", (at_out_kernel<<<grid, 256, 0, s>>>(b.o, M, ws + pl.wo, p.bo, mask, ms, res, y)));
 }
 
@@ -1627,11 +1700,11 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     const int nb = at_blocks(L);
     const long ntask = (long)N * 4 * nb;
     const unsigned cgrid = at_core_grid(ntask);
-    LAUNCH(ctx, "attn_train_bwd", (at_dq_kernel<<<cgrid, 256, 0, s>>>(b, p.rel, ws + pl.dO, ws + pl.D, L, max_pos, nb, ntask,
+    LAUNCH(ctx, "attn_train_bwd", (at_dq_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.D, L, nb, ntask,
                                                                       ws + pl.dqkv)));
-    LAUNCH(ctx, "attn_train_bwd", (at_dkv_kernel<<<cgrid, 256, 0, s>>>(b, p.rel, ws + pl.dO, ws + pl.D, L, max_pos, nb, ntask,
+    LAUNCH(ctx, "attn_train_bwd", (at_dkv_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.D, L, nb, ntask,
                                                                        ws + pl.dqkv)));
-    LAUNCH(ctx, "attn_train_bwd", (at_de_kernel<<<cgrid, 256, 0, s>>>(b, p.rel, ws + pl.dO, ws + pl.D, L, max_pos, nb, ntask,
+    LAUNCH(ctx, "attn_train_bwd", (at_de_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.D, L, nb, ntask,
                                                                       ws + pl.depart)));
     // rel_pos_emb gradient: sum the band slabs over (n, h) first (grouped, coalesced), then fold the band rows onto
     // the clamped table rows
