@@ -1232,33 +1232,54 @@ __global__ __launch_bounds__(256) void at_fwd_kernel(AtBufs b, const float* __re
     f32x4 ot = splat4(0.f);               // o^T[d = 4g + r][query c]
     float m = -1e30f, l = 0.f;
     f32x4 eq1 = at_dot(ldg4(e_blk + 256 + le), qa);
-    auto tile = [&](auto tail, int jb) {
+    struct Frag { f32x4 ka, vb, ea; };
+    auto load = [&](auto tail, int jb) {
         constexpr bool TAIL = decltype(tail)::value;
         const float* __restrict__ kp = qh + 64 + (long)jb * (16 * 192);
-        const f32x4 ka = ldg4(kp + (TAIL ? la_t : la));
-        f32x4 vb;
+        Frag f;
+        f.ka = ldg4(kp + (TAIL ? la_t : la));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) vb[r] = kp[64 + (TAIL ? lb_t[r] : lb + r * 192)];
-        const f32x4 eq0 = at_dot(ldg4(e_blk - (long)jb * 256 + le), qa);
-        const f32x4 st = at_dot(ka, qa);
+        for (int r = 0; r < 4; ++r) f.vb[r] = kp[64 + (TAIL ? lb_t[r] : lb + r * 192)];
+        f.ea = ldg4(e_blk - (long)jb * 256 + le);
+        return f;
+    };
+    auto tile = [&](auto tail, const Frag& f) {
+        constexpr bool TAIL = decltype(tail)::value;
+        const f32x4 eq0 = at_dot(f.ea, qa);
+        const f32x4 st = at_dot(f.ka, qa);
         const f32x4 rt = at_skew_t(buf, eq0, eq1, c, g);
         eq1 = eq0;
         f32x4 sc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sc[r] = (!TAIL || vt[r]) ? st[r] + rt[r] : -1e30f;
-        const float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
-        const float mn = fmaxf(m, red_g_max(mx)), corr = __builtin_amdgcn_exp2f(m - mn);
+        const float mx = red_g_max(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
+        if (__builtin_amdgcn_ballot_w64(mx > m) != 0) {   // some query's running maximum moves (rare after the first blocks)
+            const float mn = fmaxf(m, mx), corr = __builtin_amdgcn_exp2f(m - mn);
+            l *= corr;
+            ot = ot * splat4(corr);
+            m = mn;
+        }
         f32x4 p;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(sc[r] - mn);
-        l = fmaf(l, corr, red_g_sum((p[0] + p[1]) + (p[2] + p[3])));
-        ot = ot * splat4(corr);
-        m = mn;
+        for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(sc[r] - m);
+        l += (p[0] + p[1]) + (p[2] + p[3]);               // this lane's four keys; the four lane groups are summed at the end
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ot = mfma16(vb[r], p[r], ot);
+        for (int r = 0; r < 4; ++r) ot = mfma16(f.vb[r], p[r], ot);
     };
-    for (int jb = 0; jb < nfull; ++jb) tile(std::false_type{}, jb);
-    if (nfull < nb) tile(std::true_type{}, nfull);
+    if (nfull > 0) {
+        // two blocks per trip: the other block's operands are in flight while one is being worked on
+        Frag fa = load(std::false_type{}, 0), fb;
+        int jb = 0;
+        for (; jb + 1 < nfull; jb += 2) {
+            fb = load(std::false_type{}, jb + 1);
+            tile(std::false_type{}, fa);
+            fa = load(std::false_type{}, jb + 2 < nfull ? jb + 2 : jb + 1);
+            tile(std::false_type{}, fb);
+        }
+        if (jb < nfull) tile(std::false_type{}, fa);
+    }
+    if (nfull < nb) tile(std::true_type{}, load(std::true_type{}, nfull));
+    l = red_g_sum(l);
     if (I0 + c < L) {
         stg4(b.o + (base + I0 + c) * 64 + 16 * h + 4 * g, ot * splat4(__builtin_amdgcn_rcpf(l)));
         if (g == 0) b.lse[(long)t.nh * L + I0 + c] = (m + __log2f(l)) * 0.6931471805599453f;
@@ -1353,18 +1374,26 @@ __global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __res
     f32x4 eb_prev;                        // E rows of the previous key block's lower 16 distances = this block's upper 16
 #pragma unroll
     for (int s = 0; s < 4; ++s) eb_prev[s] = e_blk[256 + lg + 64 * s];
-    auto tile = [&](auto tail, int jb) {
+    struct Frag { f32x4 ka, va, kb, ea, eb; };
+    auto load = [&](auto tail, int jb) {
         constexpr bool TAIL = decltype(tail)::value;
         const float* __restrict__ kp = qh + 64 + (long)jb * (16 * 192);
         const float* __restrict__ ep = e_blk - (long)jb * 256;
-        const f32x4 ka = ldg4(kp + (TAIL ? la_t : la)), va = ldg4(kp + 64 + (TAIL ? la_t : la));
-        f32x4 kb, eb_lo;
+        Frag f;
+        f.ka = ldg4(kp + (TAIL ? la_t : la));
+        f.va = ldg4(kp + 64 + (TAIL ? la_t : la));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) kb[r] = kp[TAIL ? lb_t[r] : lb + r * 192];
+        for (int r = 0; r < 4; ++r) f.kb[r] = kp[TAIL ? lb_t[r] : lb + r * 192];
+        f.ea = ldg4(ep + le);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) eb_lo[s] = ep[lg + 64 * s];
-        const f32x4 eq0 = at_dot(ldg4(ep + le), qa);
-        const f32x4 st = at_dot(ka, qa), dpt = at_dot(va, ga);
+        for (int s = 0; s < 4; ++s) f.eb[s] = ep[lg + 64 * s];
+        return f;
+    };
+    auto tile = [&](auto tail, const Frag& f) {
+        constexpr bool TAIL = decltype(tail)::value;
+        const f32x4 &kb = f.kb, &eb_lo = f.eb;
+        const f32x4 eq0 = at_dot(f.ea, qa);
+        const f32x4 st = at_dot(f.ka, qa), dpt = at_dot(f.va, ga);
         const f32x4 rt = at_skew_t(buf, eq0, eq1, c, g);
         eq1 = eq0;
         f32x4 ds;
@@ -1386,8 +1415,19 @@ __global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __res
         }
         eb_prev = eb_lo;
     };
-    for (int jb = 0; jb < nfull; ++jb) tile(std::false_type{}, jb);
-    if (nfull < nb) tile(std::true_type{}, nfull);
+    if (nfull > 0) {
+        // two blocks per trip: the other block's operands are in flight while one is being worked on
+        Frag fa = load(std::false_type{}, 0), fb;
+        int jb = 0;
+        for (; jb + 1 < nfull; jb += 2) {
+            fb = load(std::false_type{}, jb + 1);
+            tile(std::false_type{}, fa);
+            fa = load(std::false_type{}, jb + 2 < nfull ? jb + 2 : jb + 1);
+            tile(std::false_type{}, fb);
+        }
+        if (jb < nfull) tile(std::false_type{}, fa);
+    }
+    if (nfull < nb) tile(std::true_type{}, load(std::true_type{}, nfull));
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (I0 + 4 * g + r < L) dqkv[(base + I0 + 4 * g + r) * 192 + 16 * h + c] = dq[r] * 0.25f;
@@ -1428,25 +1468,34 @@ __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __re
     const unsigned le = c * 16 + 4 * g;
     f32x4 dk = splat4(0.f), dv = splat4(0.f);        // [key 4g + r][d = c]
     f32x4 e0 = ldg4(e_blk + le);
-    auto tile = [&](auto tail, int ib) {
+    struct Frag { f32x4 qa, ga, e1, qb, gb, lse, Dr; int I0; };
+    auto load = [&](auto tail, int ib) {
         constexpr bool TAIL = decltype(tail)::value;
         const int I0 = 16 * ib;
         const float* __restrict__ qp = qh + (long)ib * (16 * 192);
         const float* __restrict__ gp = gh + (long)ib * (16 * 64);
-        const f32x4 qa = ldg4(qp + (TAIL ? at_off_a(I0, L, 192, c, g) : c * 192 + 4 * g)) * splat4(AT_QSCALE);
-        const f32x4 ga = ldg4(gp + (TAIL ? at_off_a(I0, L, 64, c, g) : c * 64 + 4 * g));
-        const f32x4 e1 = ldg4(e_blk + (long)ib * 256 + 256 + le);
-        f32x4 qb, gb, lse, Dr, p, ds;
+        Frag f;
+        f.I0 = I0;
+        f.qa = ldg4(qp + (TAIL ? at_off_a(I0, L, 192, c, g) : c * 192 + 4 * g));
+        f.ga = ldg4(gp + (TAIL ? at_off_a(I0, L, 64, c, g) : c * 64 + 4 * g));
+        f.e1 = ldg4(e_blk + (long)ib * 256 + 256 + le);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rr = TAIL ? (I0 + 4 * g + r < L ? 4 * g + r : L - 1 - I0) : 4 * g + r;
-            qb[r] = qp[rr * 192 + c];
-            gb[r] = gp[rr * 64 + c];
-            lse[r] = lh[I0 + rr] * AT_LOG2E;
-            Dr[r] = Dh[(long)(I0 + rr) * 4];
+            f.qb[r] = qp[rr * 192 + c];
+            f.gb[r] = gp[rr * 64 + c];
+            f.lse[r] = lh[I0 + rr];
+            f.Dr[r] = Dh[(long)(I0 + rr) * 4];
         }
-        at_tile_pds(buf, qa, ga, ka, va, e0, e1, lse, Dr, c, g, p, ds);
-        e0 = e1;
+        return f;
+    };
+    auto tile = [&](auto tail, const Frag& f) {
+        constexpr bool TAIL = decltype(tail)::value;
+        const int I0 = f.I0;
+        const f32x4 &qb = f.qb, &gb = f.gb;
+        f32x4 p, ds;
+        at_tile_pds(buf, f.qa * splat4(AT_QSCALE), f.ga, ka, va, e0, f.e1, f.lse * splat4(AT_LOG2E), f.Dr, c, g, p, ds);
+        e0 = f.e1;
         if (TAIL) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -1458,8 +1507,19 @@ __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __re
             dv = mfma16(p[r], gb[r], dv);
         }
     };
-    for (int ib = 0; ib < nfull; ++ib) tile(std::false_type{}, ib);
-    if (nfull < nb) tile(std::true_type{}, nfull);
+    if (nfull > 0) {
+        // two blocks per trip: the other block's operands are in flight while one is being worked on
+        Frag fa = load(std::false_type{}, 0), fb;
+        int ib = 0;
+        for (; ib + 1 < nfull; ib += 2) {
+            fb = load(std::false_type{}, ib + 1);
+            tile(std::false_type{}, fa);
+            fa = load(std::false_type{}, ib + 2 < nfull ? ib + 2 : ib + 1);
+            tile(std::false_type{}, fb);
+        }
+        if (ib < nfull) tile(std::false_type{}, fa);
+    }
+    if (nfull < nb) tile(std::true_type{}, load(std::true_type{}, nfull));
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (J0 + 4 * g + r < L) {
@@ -1497,25 +1557,35 @@ __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __res
         const float* __restrict__ ep = ewin + (long)(16 * delta - 15 + W) * 16;
         const f32x4 e0 = ldg4(ep + le), e1 = ldg4(ep + 256 + le);
         f32x4 de0 = splat4(0.f), de1 = splat4(0.f);  // [distance 16 blk + 4g + r][d = c]
-        auto tile = [&](auto tail, int k) {
+        struct Frag { f32x4 qa, ga, ka, va, qb, lse, Dr; int I0, J0; };
+        auto load = [&](auto tail, int k) {
             constexpr bool TAIL = decltype(tail)::value;
             const int I0 = 16 * (ib0 + k), J0 = 16 * (jb0 + k);
             const float* __restrict__ qp = qh + (long)I0 * 192;
             const float* __restrict__ gp = gh + (long)I0 * 64;
             const float* __restrict__ kp = qh + 64 + (long)J0 * 192;
-            const f32x4 qa = ldg4(qp + (TAIL ? at_off_a(I0, L, 192, c, g) : c * 192 + 4 * g)) * splat4(AT_QSCALE);
-            const f32x4 ga = ldg4(gp + (TAIL ? at_off_a(I0, L, 64, c, g) : c * 64 + 4 * g));
+            Frag f;
+            f.I0 = I0; f.J0 = J0;
+            f.qa = ldg4(qp + (TAIL ? at_off_a(I0, L, 192, c, g) : c * 192 + 4 * g));
+            f.ga = ldg4(gp + (TAIL ? at_off_a(I0, L, 64, c, g) : c * 64 + 4 * g));
             const unsigned oj = TAIL ? at_off_a(J0, L, 192, c, g) : c * 192 + 4 * g;
-            const f32x4 ka = ldg4(kp + oj), va = ldg4(kp + 64 + oj);
-            f32x4 qb, lse, Dr, p, ds;
+            f.ka = ldg4(kp + oj);
+            f.va = ldg4(kp + 64 + oj);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rr = TAIL ? (I0 + 4 * g + r < L ? 4 * g + r : L - 1 - I0) : 4 * g + r;
-                qb[r] = qp[rr * 192 + c];
-                lse[r] = lh[I0 + rr] * AT_LOG2E;
-                Dr[r] = Dh[(long)(I0 + rr) * 4];
+                f.qb[r] = qp[rr * 192 + c];
+                f.lse[r] = lh[I0 + rr];
+                f.Dr[r] = Dh[(long)(I0 + rr) * 4];
             }
-            at_tile_pds(buf, qa, ga, ka, va, e0, e1, lse, Dr, c, g, p, ds);
+            return f;
+        };
+        auto tile = [&](auto tail, const Frag& f) {
+            constexpr bool TAIL = decltype(tail)::value;
+            const int I0 = f.I0, J0 = f.J0;
+            const f32x4& qb = f.qb;
+            f32x4 p, ds;
+            at_tile_pds(buf, f.qa * splat4(AT_QSCALE), f.ga, f.ka, f.va, e0, e1, f.lse * splat4(AT_LOG2E), f.Dr, c, g, p, ds);
             if (TAIL) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -1533,10 +1603,21 @@ __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __res
                 de1 = mfma16(row[0], qb[r], de1);
             }
         };
-        for (int k = 0; k < ntile; ++k) {
-            if (ib0 + k >= nfull || jb0 + k >= nfull) tile(std::true_type{}, k);
-            else tile(std::false_type{}, k);
+        // a diagonal's tiles are full except (when L is not a multiple of 16) its last one
+        const int nfl = (ib0 + ntile > nfull || jb0 + ntile > nfull) ? ntile - 1 : ntile;
+        if (nfl > 0) {
+            // two blocks per trip: the other block's operands are in flight while one is being worked on
+            Frag fa = load(std::false_type{}, 0), fb;
+            int k = 0;
+            for (; k + 1 < nfl; k += 2) {
+                fb = load(std::false_type{}, k + 1);
+                tile(std::false_type{}, fa);
+                fa = load(std::false_type{}, k + 2 < nfl ? k + 2 : k + 1);
+                tile(std::false_type{}, fb);
+            }
+            if (k < nfl) tile(std::false_type{}, fa);
         }
+        if (nfl < ntile) tile(std::true_type{}, load(std::true_type{}, nfl));
         float* out = partial + ((long)t.nh * (2 * nb - 1) + (delta + nb - 1)) * 512;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
