@@ -1087,7 +1087,7 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
 // backward core recomputing the probabilities from q, k, E and the saved row log-sum-exp, so no task ever accumulates
 // into another task's output and every sum has a fixed order.
 // =====================================================================================
-#define AT_MAX_L 512
+#define AT_MAX_L 4096                 // a workspace-size bound only: the cores have no length-dependent resource
 
 struct AtBufs {
     float *qkv;      // [M,192]  q | k | v  (features 16 h + d inside each 64)

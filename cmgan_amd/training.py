@@ -402,7 +402,7 @@ _AT_FIELDS = ("ln_weight", "ln_bias", "to_q_weight", "to_kv_weight", "to_out_wei
 
 class AttentionTrain:
     """`attn` branch (PreNorm + Attention) of one ConformerBlock in train mode on the HIP kernels (csrc/train.hip).
-    `state` holds the branch's tensors under the reference's key names relative to `attn.`.  Sequences of up to 512
+    `state` holds the branch's tensors under the reference's key names relative to `attn.`.  Sequences of up to 4096
     positions; `backward` must follow the `forward` of the same x (it reads q|k|v, O and the row log-sum-exp)."""
 
     @staticmethod
@@ -429,7 +429,7 @@ class AttentionTrain:
     def _workspace(self, N: int, L: int) -> torch.Tensor:
         need = self.engine.lib.cmgan_attn_train_workspace_bytes(self.engine._h, N, L)
         if need == 0:
-            raise ValueError(f"unsupported attention shape N={N}, L={L} (L <= 512)")
+            raise ValueError(f"unsupported attention shape N={N}, L={L} (L <= 4096)")
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.engine.device)
         return self._ws

@@ -207,8 +207,8 @@ int cmgan_convmod_train_backward(cmgan_handle* h, const float* x_dev, const floa
  * [N,L,64] is the byte keep-mask (non-zero = keep, kept values x mask_scale) of the nn.Dropout on the to_out output
  * (conformer.py:133; NULL = none).  Parameters are
  * the RAW tensors attn.norm.{weight,bias}, attn.fn.to_q.weight [64,64], attn.fn.to_kv.weight [128,64],
- * attn.fn.to_out.{weight [64,64], bias}, attn.fn.rel_pos_emb.weight [2 max_pos + 1, 16].  L <= 512 in this slice
- * (CMGAN_E_UNSUPPORTED beyond).  The forward keeps q|k|v, the attention output and the row log-sum-exp in the
+ * attn.fn.to_out.{weight [64,64], bias}, attn.fn.rel_pos_emb.weight [2 max_pos + 1, 16].  L <= 4096
+ * (CMGAN_E_UNSUPPORTED beyond; distances past +-max_pos share the table's end rows, as in the reference).  The forward keeps q|k|v, the attention output and the row log-sum-exp in the
  * workspace; the backward needs the SAME workspace untouched and writes dL/dx and the seven parameter gradients
  * (the embedding-table gradient is dense [2 max_pos + 1, 16], rows of unused distances are zero).                 */
 typedef struct cmgan_attn_params {

@@ -288,11 +288,12 @@ def test_fused_residual_pointers_equal_a_separate_add(ff):
         ff.forward(x, m1, m2, residual=r[:, :5])
 
 
-@pytest.mark.parametrize("n,l", [(2, 321), (3, 101), (1, 512), (2, 7), (1, 65)])
+@pytest.mark.parametrize("n,l", [(2, 321), (3, 101), (1, 512), (2, 7), (1, 65), (1, 600)])
 def test_attention_train_full_length_sequences_vs_oracle_autograd(n, l):
-    """the two sequence lengths of the 2 s training clip (time axis T = 321, frequency axis F' = 101), the longest
-    supported sequence (512: every thread-split / LDS-merge configuration at its limit), and two short ones whose
-    row x reduction-subset split has more subsets than keys per subset; no dropout."""
+    """the two sequence lengths of the 2 s training clip (time axis T = 321, frequency axis F' = 101), a multiple of the
+    16-row tile (512: no ragged block anywhere), two short ones (7: a single ragged block; 65: one row in the last
+    block) and one longer than max_pos_emb (600: distances beyond +-512 share the end rows of the embedding table,
+    in the scores and in its gradient); no dropout."""
     from cmgan_amd.training import AttentionTrain
     csd = conformer_state_dict(seed=3)
     at = AttentionTrain({k: csd["attn." + k] for k in AT_KEYS})
@@ -311,7 +312,7 @@ def test_attention_train_full_length_sequences_vs_oracle_autograd(n, l):
     for k in AT_KEYS:
         assert _report(f"attention dL/d[{k}] [{n}x{l}]", rel_err(grads[k], leaf["attn." + k].grad)) < GRAD_TOL, k
     with pytest.raises(ValueError):
-        at.forward(torch.zeros(1, 600, 64, device=DEV))
+        at.forward(torch.zeros(1, 4097, 64, device=DEV))
 
 
 def test_whole_conformer_block_trains_like_the_reference():
