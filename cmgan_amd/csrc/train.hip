@@ -124,6 +124,17 @@ __global__ void pack_fm_kernel(const float* __restrict__ w, int R, int K, int ld
 
 // Dropout keep-masks are BYTES (non-zero = keep; the kept values are scaled by `ms` = 1 / (1 - p)): a quarter of the
 // traffic of float masks - per conformer block and token 704 mask values are read in the forward and again in the backward
+__device__ __forceinline__ unsigned mask_word(const unsigned char* __restrict__ m, long idx) {   // idx % 4 == 0
+    return *reinterpret_cast<const unsigned*>(m + idx);
+}
+__device__ __forceinline__ f32x4 mask4w(unsigned v, float ms) {
+    f32x4 r;
+    r[0] = (v & 0x000000ffu) ? ms : 0.f;
+    r[1] = (v & 0x0000ff00u) ? ms : 0.f;
+    r[2] = (v & 0x00ff0000u) ? ms : 0.f;
+    r[3] = (v & 0xff000000u) ? ms : 0.f;
+    return r;
+}
 __device__ __forceinline__ f32x4 mask4(const unsigned char* __restrict__ m, long idx, float ms) {
     const unsigned v = *reinterpret_cast<const unsigned*>(m + idx);          // idx is a multiple of 4
     f32x4 r;
@@ -158,6 +169,30 @@ __device__ __forceinline__ bool ffn_load_norm(const float* __restrict__ x, long 
     return ok;
 }
 
+// four weight fragments = the A operands of 16 MFMAs.  rows: fragments [blk][0..3] of an image whose k-blocks are
+// contiguous (W1 [16][4], W2^T [16][4]); cols: fragments [0..3][blk] of an image with 16 k-blocks per row (W2, W1^T [4][16])
+struct FfnFrag { f32x4 a[4]; };
+__device__ __forceinline__ FfnFrag ffn_frag_rows(const float* __restrict__ img, int blk, int lane) {
+    FfnFrag f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) f.a[kb] = ldg4(img + ((long)blk * 4 + kb) * 256 + lane * 4);
+    return f;
+}
+__device__ __forceinline__ FfnFrag ffn_frag_cols(const float* __restrict__ img, int blk, int lane) {
+    FfnFrag f;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) f.a[ob] = ldg4(img + ((long)ob * 16 + blk) * 256 + lane * 4);
+    return f;
+}
+// acc + sum_kb frag[kb] x xf[kb]: one output block of a per-token linear layer (lin_acc<4, 1> on prefetched fragments)
+__device__ __forceinline__ f32x4 ffn_frag_mma(const FfnFrag& f, const f32x4 (&xf)[4], f32x4 acc) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma16(f.a[kb][r], xf[kb][r], acc);
+    return acc;
+}
+
 __global__ __launch_bounds__(256) void ffn_train_fwd_kernel(const float* __restrict__ x, long M, FfnTrainImg w,
                                                             const unsigned char* __restrict__ m1,
                                                             const unsigned char* __restrict__ m2, float ms,
@@ -172,19 +207,28 @@ __global__ __launch_bounds__(256) void ffn_train_fwd_kernel(const float* __restr
     f32x4 acc[4];
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) acc[ob] = ldg4(w.b2 + 16 * ob + 4 * g);
-#pragma unroll 2
+    // the weight fragments of the NEXT 16 MFMAs are fetched while the current 16 run (as written by the compiler, every
+    // group of 4 MFMAs waited for its own fragment: the kernel ran at L1 latency, not at the matrix rate)
+    // (loads retire in order: the small mask / bias loads of a block are issued BEFORE the fragment loads that are
+    // still in flight when they are needed)
+    unsigned mw = m1 ? mask_word(m1, row * 256 + 4 * g) : 0u;
+    f32x4 b1v = ldg4(w.b1 + 4 * g);
+    FfnFrag g1 = ffn_frag_rows(w.w1, 0, lane), g2;
     for (int hb = 0; hb < 16; ++hb) {
-        f32x4 h[1] = {ldg4(w.b1 + 16 * hb + 4 * g)};
-        lin_acc<4, 1>(w.w1 + (long)hb * 4 * 256 + lane * 4, xn, h);
+        g2 = ffn_frag_cols(w.w2, hb, lane);
+        const f32x4 h = ffn_frag_mma(g1, xn[0], b1v);
+        const f32x4 mk = m1 ? mask4w(mw, ms) : splat4(1.f);
+        const int hn = hb < 15 ? hb + 1 : 15;
+        if (m1) mw = mask_word(m1, row * 256 + 16 * hn + 4 * g);
+        b1v = ldg4(w.b1 + 16 * hn + 4 * g);
+        g1 = ffn_frag_rows(w.w1, hn, lane);
         f32x4 s;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[r] = swishf(h[0][r]);
-        if (m1) s = s * mask4(m1, row * 256 + 16 * hb + 4 * g, ms);
+        for (int r = 0; r < 4; ++r) s[r] = swishf(h[r]) * mk[r];
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {
-            const f32x4 a = ldg4(w.w2 + ((long)ob * 16 + hb) * 256 + lane * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[ob] = mfma16(a[r], s[r], acc[ob]);
+            for (int r = 0; r < 4; ++r) acc[ob] = mfma16(g2.a[ob][r], s[r], acc[ob]);
         }
     }
     if (ok) {
@@ -229,20 +273,27 @@ __global__ __launch_bounds__(256) void ffn_train_bwd_kernel(const float* __restr
     f32x4 dxn[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) dxn[kb] = splat4(0.f);
-#pragma unroll 2
+    // three groups of 16 MFMAs per hidden block (W1 recompute, W2^T, W1^T); the next group's fragments are in flight
+    // while one runs
+    unsigned mw = m1 ? mask_word(m1, row * 256 + 4 * g) : 0u;
+    f32x4 b1v = ldg4(w.b1 + 4 * g);
+    FfnFrag g1 = ffn_frag_rows(w.w1, 0, lane), g2, g3;
     for (int hb = 0; hb < 16; ++hb) {
-        f32x4 h[1] = {ldg4(w.b1 + 16 * hb + 4 * g)};
-        lin_acc<4, 1>(w.w1 + (long)hb * 4 * 256 + lane * 4, xn, h);
-        f32x4 dd1[1] = {splat4(0.f)};
-        lin_acc<4, 1>(w.w2t + (long)hb * 4 * 256 + lane * 4, dz, dd1);
-        f32x4 mk = splat4(1.f);
-        if (m1) mk = mask4(m1, row * 256 + 16 * hb + 4 * g, ms);
+        g2 = ffn_frag_rows(w.w2t, hb, lane);
+        const f32x4 h = ffn_frag_mma(g1, xn[0], b1v);
+        g3 = ffn_frag_cols(w.w1t, hb, lane);
+        const f32x4 dd1 = ffn_frag_mma(g2, dz[0], splat4(0.f));
+        const f32x4 mk = m1 ? mask4w(mw, ms) : splat4(1.f);
+        const int hn = hb < 15 ? hb + 1 : 15;
+        if (m1) mw = mask_word(m1, row * 256 + 16 * hn + 4 * g);
+        b1v = ldg4(w.b1 + 16 * hn + 4 * g);
+        g1 = ffn_frag_rows(w.w1, hn, lane);
         f32x4 d1v, dhv;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float hv = h[0][r], sg = sigmoidf_fast(hv);
+            const float hv = h[r], sg = sigmoidf_fast(hv);
             d1v[r] = hv * sg * mk[r];
-            dhv[r] = dd1[0][r] * mk[r] * (sg * (1.f + hv * (1.f - sg)));
+            dhv[r] = dd1[r] * mk[r] * (sg * (1.f + hv * (1.f - sg)));
         }
         if (ok) {
             stg4(o.d1 + row * 256 + 16 * hb + 4 * g, d1v);
@@ -250,9 +301,8 @@ __global__ __launch_bounds__(256) void ffn_train_bwd_kernel(const float* __restr
         }
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            const f32x4 a = ldg4(w.w1t + ((long)kb * 16 + hb) * 256 + lane * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dxn[kb] = mfma16(a[r], dhv[r], dxn[kb]);
+            for (int r = 0; r < 4; ++r) dxn[kb] = mfma16(g3.a[kb][r], dhv[r], dxn[kb]);
         }
     }
     // LayerNorm backward (per token: the 64 channels live in the 4 lanes c, c+16, c+32, c+48)
