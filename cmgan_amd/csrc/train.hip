@@ -377,37 +377,72 @@ __global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* __restr
 // operands of one FeedForward weight gradient, which is what bounded it (83 us at 8 TB/s of cache traffic).  Here a
 // wave-step loads 16 + 16 operand dwords for 64 MFMAs; the four waves' tiles are combined through 32 KB of LDS in a
 // fixed order.  Grid (R / 64, C / 64, WG_SPLIT).
-#define WG_SPLIT 256
+#define WG_SPLIT 256                  // largest split (sizes the slab buffers); a launch uses wg_split(tiles) <= WG_SPLIT
 __global__ __launch_bounds__(256) void wgrad_partial64_kernel(const float* __restrict__ P, const float* __restrict__ Q,
                                                               long M, int R, int C, float* __restrict__ partial) {
     __shared__ float red[2][64 * 64];
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ic = blockIdx.x, jc = blockIdx.y, s = blockIdx.z;
-    const long steps = (M + 15) / 16, per = (steps + WG_SPLIT - 1) / WG_SPLIT;
-    const long st0 = (long)s * per, st1 = st0 + per < steps ? st0 + per : steps;
+    const int nsplit = gridDim.z;
+    const long full = M / 16, per = (full + nsplit - 1) / nsplit;            // full 16-row steps, dealt to the splits
+    const long st0 = (long)s * per, st1 = st0 + per < full ? st0 + per : full;
     f32x4 acc[4][4];                                  // [ib][jb]
 #pragma unroll
     for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
         for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = splat4(0.f);
-    for (long st = st0 + wv; st < st1; st += 4) {
-        f32x4 a[4], b[4];                             // [ib][r], [jb][r]
+    // two steps per trip: the 32 operand dwords of the other step are in flight while the 64 MFMAs of one run (a wave
+    // that waited for its own loads before every step spent more time on HBM / L2 latency than on products)
+    unsigned oa[4], ob[4];                            // lane offsets of row 4g + r inside a step (P: + 16 ib, Q: + 16 jb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        oa[r] = (unsigned)((4 * g + r) * R + 64 * ic + c);
+        ob[r] = (unsigned)((4 * g + r) * C + 64 * jc + c);
+    }
+    auto load = [&](long st, f32x4 (&a)[4], f32x4 (&b)[4]) {       // [ib][r], [jb][r]; a full step (16 rows < M)
+        const float* __restrict__ Pp = P + st * 16 * R;             // uniform
+        const float* __restrict__ Qp = Q + st * 16 * C;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long m = st * 16 + 4 * g + r;
-            const bool ok = m < M;
-            const long mm = ok ? m : M - 1;
+            const float* __restrict__ pa = Pp + oa[r];              // + 16 ib / + 16 jb are instruction immediates
+            const float* __restrict__ qa = Qp + ob[r];
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) a[ib][r] = ok ? P[mm * R + 64 * ic + 16 * ib + c] : 0.f;
+            for (int ib = 0; ib < 4; ++ib) a[ib][r] = pa[16 * ib];
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb) b[jb][r] = ok ? Q[mm * C + 64 * jc + 16 * jb + c] : 0.f;
+            for (int jb = 0; jb < 4; ++jb) b[jb][r] = qa[16 * jb];
         }
+    };
+    auto mma = [&](const f32x4 (&a)[4], const f32x4 (&b)[4]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib)
 #pragma unroll
                 for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma16(a[ib][r], b[jb][r], acc[ib][jb]);
+    };
+    f32x4 a0[4], b0[4], a1[4], b1[4];
+    long st = st0 + wv;
+    if (st < st1) load(st, a0, b0);
+    while (st < st1) {
+        const long sn = st + 4;
+        if (sn < st1) load(sn, a1, b1);
+        mma(a0, b0);
+        st = sn + 4;
+        if (st < st1) load(st, a0, b0);
+        if (sn < st1) mma(a1, b1);
+    }
+    if ((M & 15) && s == nsplit - 1 && wv == 0) {   // the one ragged step of the tensor: rows past M contribute zeros
+        const float* __restrict__ Pp = P + full * 16 * R;
+        const float* __restrict__ Qp = Q + full * 16 * C;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = full * 16 + 4 * g + r < M;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) a0[ib][r] = ok ? Pp[oa[r] + 16 * ib] : 0.f;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) b0[jb][r] = ok ? Qp[ob[r] + 16 * jb] : 0.f;
+        }
+        mma(a0, b0);
     }
     // (wave 2 + wave 0), (wave 3 + wave 1), then (wave 1 + wave 0): element (row 16 ib + 4 g + r, col 16 jb + c)
     auto put = [&](float* dst) {
@@ -443,6 +478,9 @@ __global__ __launch_bounds__(256) void wgrad_partial64_kernel(const float* __res
                     partial[((long)s * R + 64 * ic + 16 * ib + 4 * g + r) * C + 64 * jc + 16 * jb + c] = acc[ib][jb][r];
     }
 }
+// the kernel holds two steps of operands next to its 64 x 64 accumulators: 184 registers, two waves per SIMD.  The
+// split is chosen so that one launch is at most those 2048 waves (tiles x split x 4), i.e. a single round
+static int wg_split(int tiles) { return tiles >= 3 ? 128 : 256; }
 
 // column sums of X [M,C] over NB fixed row ranges -> partial [NB][C]; four independent accumulators per thread keep
 // four loads in flight (the loop is latency-bound otherwise), combined in a fixed order
@@ -602,11 +640,11 @@ void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, l
     const unsigned grid = (unsigned)((M + 63) / 64);
     LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_kernel<<<grid, 256, 0, s>>>(x, dy, M, w, m1, m2, ms, dres, dx, o)));
     // dW2 [64,256] = dz^T d1 ; dW1 [256,64] = dh^T xn
-    LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 4, WG_SPLIT), 256, 0, s>>>(o.dz, o.d1, M, 64, 256, part)));
-    LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial64_kernel<<<dim3(4, 1, WG_SPLIT), 256, 0, s>>>(o.dh, o.xn, M, 256, 64,
+    LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 4, wg_split(4)), 256, 0, s>>>(o.dz, o.d1, M, 64, 256, part)));
+    LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial64_kernel<<<dim3(4, 1, wg_split(4)), 256, 0, s>>>(o.dh, o.xn, M, 256, 64,
                                                                                               part + (size_t)WG_SPLIT * 16384)));
-    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part, WG_SPLIT, 16384, grad.w2)));
-    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part + (size_t)WG_SPLIT * 16384, WG_SPLIT, 16384,
+    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part, wg_split(4), 16384, grad.w2)));
+    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part + (size_t)WG_SPLIT * 16384, wg_split(4), 16384,
                                                                                  grad.w1)));
     const ColsumJobs jobs{{o.dh, o.dz, o.g1, o.dxn}, {grad.b1, grad.b2, grad.gamma, grad.beta}, {256, 64, 64, 64}};
     colsum_batch(ctx, "ffn_train_reduce", jobs, 4, M, cpart);
@@ -1094,9 +1132,9 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     LAUNCH(ctx, "convmod_train_bwd", (cm_bwd1_kernel<<<grid, 256, 0, s>>>(dy, ws + pl.d, M, st, im.w2t, ws + pl.ddn,
                                                                           ws + pl.s, ws + pl.g2)));
     // pointwise-2 gradients: dW_pw2 [64,128] = dy^T s, db_pw2 = colsum dy
-    LAUNCH(ctx, "convmod_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 2, WG_SPLIT), 256, 0, s>>>(dy, ws + pl.s, M, 64, 128,
+    LAUNCH(ctx, "convmod_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 2, wg_split(2)), 256, 0, s>>>(dy, ws + pl.s, M, 64, 128,
                                                                                                   ws + pl.wpart)));
-    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<128, 1024, 0, s>>>(ws + pl.wpart, WG_SPLIT, 8192,
+    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<128, 1024, 0, s>>>(ws + pl.wpart, wg_split(2), 8192,
                                                                                    grad.pw2_w)));
     // BatchNorm: dbeta = sum ddn, dgamma = sum ddn dhat; then dd in place   (+ db_pw2 = colsum dy in the same pair of launches)
     {
@@ -1120,9 +1158,9 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
                                                                           ws + pl.dag, ws + pl.xn, ws + pl.g1,
                                                                           ws + pl.dxn)));
     // pointwise-1 and LayerNorm gradients
-    LAUNCH(ctx, "convmod_train_wgrad", (wgrad_partial64_kernel<<<dim3(4, 1, WG_SPLIT), 256, 0, s>>>(ws + pl.dag, ws + pl.xn, M, 256,
+    LAUNCH(ctx, "convmod_train_wgrad", (wgrad_partial64_kernel<<<dim3(4, 1, wg_split(4)), 256, 0, s>>>(ws + pl.dag, ws + pl.xn, M, 256,
                                                                                                   64, ws + pl.wpart)));
-    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(ws + pl.wpart, WG_SPLIT, 16384,
+    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(ws + pl.wpart, wg_split(4), 16384,
                                                                                    grad.pw1_w)));
     const ColsumJobs jobs{{ws + pl.dag, ws + pl.g1, ws + pl.dxn}, {grad.pw1_b, grad.ln_w, grad.ln_b}, {256, 64, 64}};
     colsum_batch(ctx, "convmod_train_reduce", jobs, 3, M, cpart);
@@ -1823,9 +1861,9 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     LAUNCH(ctx, "attn_train_bwd", (at_out_bwd_kernel<<<grid, 256, 0, s>>>(dy, mask, ms, b.o, M, ws + pl.wot, ws + pl.dout,
                                                                           ws + pl.dO, ws + pl.D)));
     // to_out gradients: dWo [64,64] = dout^T O, dbo = colsum dout
-    LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 1, WG_SPLIT), 256, 0, s>>>(ws + pl.dout, b.o, M, 64, 64,
+    LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 1, wg_split(1)), 256, 0, s>>>(ws + pl.dout, b.o, M, 64, 64,
                                                                                                ws + pl.wpart)));
-    LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<64, 1024, 0, s>>>(ws + pl.wpart, WG_SPLIT, 4096,
+    LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<64, 1024, 0, s>>>(ws + pl.wpart, wg_split(1), 4096,
                                                                                 grad.wo)));
     // attention core: dq (query blocks), dk / dv (key blocks), dE (tile diagonals)
     const int nb = at_blocks(L);
@@ -1848,9 +1886,9 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     // projections + LayerNorm
     LAUNCH(ctx, "attn_train_bwd", (at_qkv_bwd_kernel<<<grid, 256, 0, s>>>(x, ws + pl.dqkv, M, ws + pl.wqkvt, p.ln_w, p.ln_b,
                                                                           dres, dx, ws + pl.xn, ws + pl.g1, ws + pl.dxn)));
-    LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial64_kernel<<<dim3(3, 1, WG_SPLIT), 256, 0, s>>>(ws + pl.dqkv, ws + pl.xn, M, 192,
+    LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial64_kernel<<<dim3(3, 1, wg_split(3)), 256, 0, s>>>(ws + pl.dqkv, ws + pl.xn, M, 192,
                                                                                                64, ws + pl.wpart)));
-    LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<192, 1024, 0, s>>>(ws + pl.wpart, WG_SPLIT, 12288,
+    LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<192, 1024, 0, s>>>(ws + pl.wpart, wg_split(3), 12288,
                                                                                 ws + pl.raw)));      // [192,64], then split
     hipMemcpyAsync(grad.wq, ws + pl.raw, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);
     hipMemcpyAsync(grad.wkv, ws + pl.raw + 4096, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);
