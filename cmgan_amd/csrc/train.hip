@@ -176,12 +176,14 @@ __device__ __forceinline__ FfnFrag ffn_frag_rows(const float* __restrict__ img, 
     FfnFrag f;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) f.a[kb] = ldg4(img + ((long)blk * 4 + kb) * 256 + lane * 4);
+    __builtin_amdgcn_sched_barrier(0);    // keep the loads HERE: the scheduler otherwise sinks them next to their use
     return f;
 }
 __device__ __forceinline__ FfnFrag ffn_frag_cols(const float* __restrict__ img, int blk, int lane) {
     FfnFrag f;
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) f.a[ob] = ldg4(img + ((long)ob * 16 + blk) * 256 + lane * 4);
+    __builtin_amdgcn_sched_barrier(0);
     return f;
 }
 // acc + sum_kb frag[kb] x xf[kb]: one output block of a per-token linear layer (lin_acc<4, 1> on prefetched fragments)
@@ -758,14 +760,20 @@ __global__ __launch_bounds__(256) void cm_pw1glu_kernel(const float* __restrict_
     float rstd;
     long row;
     const bool ok = cm_load_norm(x, M, t0, c, g, p.ln_w, p.ln_b, xh, xn, rstd, row);
-#pragma unroll 2
+    // value half, then gate half of an output block; the other half's weight fragments are in flight meanwhile
+    f32x4 ba = ldg4(p.pw1_b + 4 * g), bg = ldg4(p.pw1_b + 128 + 4 * g);
+    FfnFrag fa = ffn_frag_rows(w1fm, 0, lane), fg;
     for (int ob = 0; ob < 8; ++ob) {
-        f32x4 a[1] = {ldg4(p.pw1_b + 16 * ob + 4 * g)}, gt[1] = {ldg4(p.pw1_b + 128 + 16 * ob + 4 * g)};
-        lin_acc<4, 1>(w1fm + (long)ob * 4 * 256 + lane * 4, xn, a);
-        lin_acc<4, 1>(w1fm + (long)(ob + 8) * 4 * 256 + lane * 4, xn, gt);
+        fg = ffn_frag_rows(w1fm, ob + 8, lane);
+        const f32x4 a = ffn_frag_mma(fa, xn[0], ba);
+        const int on = ob < 7 ? ob + 1 : 7;
+        ba = ldg4(p.pw1_b + 16 * on + 4 * g);
+        fa = ffn_frag_rows(w1fm, on, lane);
+        const f32x4 gt = ffn_frag_mma(fg, xn[0], bg);
+        bg = ldg4(p.pw1_b + 128 + 16 * on + 4 * g);
         f32x4 r;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = a[0][e] * sigmoidf_fast(gt[0][e]);
+        for (int e = 0; e < 4; ++e) r[e] = a[e] * sigmoidf_fast(gt[e]);
         if (ok) stg4(u + row * 128 + 16 * ob + 4 * g, r);
     }
 }
@@ -1002,34 +1010,42 @@ __global__ __launch_bounds__(256) void cm_bwd2_kernel(const float* __restrict__ 
     f32x4 dxn[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) dxn[kb] = splat4(0.f);
-#pragma unroll 2
+    // four groups of 16 MFMAs per output block (value, gate, and their two transposed products); the fragments of a
+    // group are fetched while the previous groups run
+    f32x4 ba = ldg4(p.pw1_b + 4 * g), bg = ldg4(p.pw1_b + 128 + 4 * g), dun = ldg4(du + row * 128 + 4 * g);
+    FfnFrag fa = ffn_frag_rows(w1fm, 0, lane), fg, ta, tg;
     for (int ob = 0; ob < 8; ++ob) {
-        f32x4 a[1] = {ldg4(p.pw1_b + 16 * ob + 4 * g)}, gt[1] = {ldg4(p.pw1_b + 128 + 16 * ob + 4 * g)};
-        lin_acc<4, 1>(w1fm + (long)ob * 4 * 256 + lane * 4, xn, a);
-        lin_acc<4, 1>(w1fm + (long)(ob + 8) * 4 * 256 + lane * 4, xn, gt);
-        f32x4 duv = ldg4(du + row * 128 + 16 * ob + 4 * g);
+        fg = ffn_frag_rows(w1fm, ob + 8, lane);
+        const f32x4 a = ffn_frag_mma(fa, xn[0], ba);
+        ta = ffn_frag_cols(w1tfm, ob, lane);
+        const f32x4 gt = ffn_frag_mma(fg, xn[0], bg);
+        tg = ffn_frag_cols(w1tfm, ob + 8, lane);
+        f32x4 duv = dun;
         if (!ok) duv = splat4(0.f);
+        const int on = ob < 7 ? ob + 1 : 7;
+        ba = ldg4(p.pw1_b + 16 * on + 4 * g);
+        bg = ldg4(p.pw1_b + 128 + 16 * on + 4 * g);
+        dun = ldg4(du + row * 128 + 16 * on + 4 * g);
         f32x4 da, dg;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float sg = sigmoidf_fast(gt[0][e]);
+            const float sg = sigmoidf_fast(gt[e]);
             da[e] = duv[e] * sg;
-            dg[e] = duv[e] * a[0][e] * sg * (1.f - sg);
+            dg[e] = duv[e] * a[e] * sg * (1.f - sg);
         }
         if (ok) {
             stg4(dag + row * 256 + 16 * ob + 4 * g, da);
             stg4(dag + row * 256 + 128 + 16 * ob + 4 * g, dg);
         }
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const f32x4 wa = ldg4(w1tfm + ((long)kb * 16 + ob) * 256 + lane * 4);
-            const f32x4 wg = ldg4(w1tfm + ((long)kb * 16 + ob + 8) * 256 + lane * 4);
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dxn[kb] = mfma16(wa[r], da[r], dxn[kb]);
-                dxn[kb] = mfma16(wg[r], dg[r], dxn[kb]);
-            }
-        }
+            for (int r = 0; r < 4; ++r) dxn[kb] = mfma16(ta.a[kb][r], da[r], dxn[kb]);
+        fa = ffn_frag_rows(w1fm, on, lane);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dxn[kb] = mfma16(tg.a[kb][r], dg[r], dxn[kb]);
     }
     f32x4 dxh[4];
     float s1 = 0.f, s2 = 0.f;
@@ -1194,11 +1210,14 @@ __global__ __launch_bounds__(256) void at_qkv_kernel(const float* __restrict__ x
     float rstd;
     long row;
     const bool ok = cm_load_norm(x, M, t0, c, g, ln_w, ln_b, xh, xn, rstd, row);
-#pragma unroll 4
-    for (int ob = 0; ob < 12; ++ob) {
-        f32x4 acc[1] = {splat4(0.f)};
-        lin_acc<4, 1>(wfm + (long)ob * 4 * 256 + lane * 4, xn, acc);
-        if (ok) stg4(qkv + row * 192 + 16 * ob + 4 * g, acc[0]);
+    FfnFrag f0 = ffn_frag_rows(wfm, 0, lane), f1;     // the next output block's fragments in flight
+    for (int ob = 0; ob < 12; ob += 2) {
+        f1 = ffn_frag_rows(wfm, ob + 1, lane);
+        const f32x4 q0 = ffn_frag_mma(f0, xn[0], splat4(0.f));
+        if (ok) stg4(qkv + row * 192 + 16 * ob + 4 * g, q0);
+        f0 = ffn_frag_rows(wfm, ob + 2 < 12 ? ob + 2 : 11, lane);
+        const f32x4 q1 = ffn_frag_mma(f1, xn[0], splat4(0.f));
+        if (ok) stg4(qkv + row * 192 + 16 * (ob + 1) + 4 * g, q1);
     }
 }
 
@@ -1762,11 +1781,25 @@ __global__ __launch_bounds__(256) void at_qkv_bwd_kernel(const float* __restrict
         if (!ok) df[0][kb] = splat4(0.f);
     }
     f32x4 dxn[4];
+    // 12 groups of 4 fragments (image [4 row blocks][12 k-blocks] = group index rb * 3 + third); next group in flight
+    {
+        FfnFrag f0 = ffn_frag_rows(wtfm, 0, lane), f1;
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-        f32x4 acc[1] = {splat4(0.f)};
-        lin_acc<12, 1>(wtfm + (long)rb * 12 * 256 + lane * 4, df, acc);
-        dxn[rb] = acc[0];
+        for (int rb = 0; rb < 4; ++rb) {
+            f32x4 acc = splat4(0.f);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int gi = rb * 3 + t;
+                FfnFrag& cur = (gi & 1) ? f1 : f0;
+                FfnFrag& nxt = (gi & 1) ? f0 : f1;
+                nxt = ffn_frag_rows(wtfm, gi + 1 < 12 ? gi + 1 : 11, lane);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = mfma16(cur.a[kb][r], df[0][4 * t + kb][r], acc);
+            }
+            dxn[rb] = acc;
+        }
     }
     f32x4 dxh[4];
     float s1 = 0.f, s2 = 0.f;
