@@ -121,6 +121,23 @@ __global__ void pack_fm_kernel(const float* __restrict__ w, int R, int K, int ld
     const int row = 16 * rb + (lane & 15), col = 16 * kb + 4 * (lane >> 4) + r;
     out[i] = transpose ? w[(long)col * ldw + row] : w[(long)row * ldw + col];
 }
+// the four images of one module in ONE launch (blockIdx.y = image): a training step re-packs 128 images
+struct PackJob { const float* w; int R, K, ldw, transpose; float* out; };
+struct PackJobs { PackJob j[4]; };
+__global__ void pack_fm4_kernel(PackJobs jobs) {
+    const PackJob& q = jobs.j[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q.R * q.K) return;
+    const int r = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+    const int KB = q.K / 16, rb = blk / KB, kb = blk - rb * KB;
+    const int row = 16 * rb + (lane & 15), col = 16 * kb + 4 * (lane >> 4) + r;
+    q.out[i] = q.transpose ? q.w[(long)col * q.ldw + row] : q.w[(long)row * q.ldw + col];
+}
+static void launch_pack4(LaunchCtx ctx, const char* label, const PackJobs& jobs) {
+    int most = 0;
+    for (int k = 0; k < 4; ++k) most = jobs.j[k].R * jobs.j[k].K > most ? jobs.j[k].R * jobs.j[k].K : most;
+    LAUNCH(ctx, label, (pack_fm4_kernel<<<dim3((most + 255) / 256, 4), 256, 0, ctx.stream>>>(jobs)));
+}
 
 // Dropout keep-masks are BYTES (non-zero = keep; the kept values are scaled by `ms` = 1 / (1 - p)): a quarter of the
 // traffic of float masks - per conformer block and token 704 mask values are read in the forward and again in the backward
@@ -611,10 +628,10 @@ static FfnTrainImg ffn_pack_images(LaunchCtx ctx, const FfnTrainParams& p, float
     hipStream_t s = ctx.stream;
     float *w1 = img, *w2 = img + 16384, *w2t = img + 2 * 16384, *w1t = img + 3 * 16384;
     if (!pack) return FfnTrainImg{w1, w2, w2t, w1t, p.gamma, p.beta, p.b1, p.b2};
-    LAUNCH(ctx, "ffn_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.w1, 256, 64, 64, 0, w1)));     // rows = hidden
-    LAUNCH(ctx, "ffn_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.w2, 64, 256, 256, 0, w2)));    // rows = out
-    LAUNCH(ctx, "ffn_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.w2, 256, 64, 256, 1, w2t)));   // rows = hidden
-    LAUNCH(ctx, "ffn_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.w1, 64, 256, 64, 1, w1t)));    // rows = in
+    launch_pack4(ctx, "ffn_train_pack", PackJobs{{{p.w1, 256, 64, 64, 0, w1},       // rows = hidden
+                                                  {p.w2, 64, 256, 256, 0, w2},      // rows = out
+                                                  {p.w2, 256, 64, 256, 1, w2t},     // rows = hidden
+                                                  {p.w1, 64, 256, 64, 1, w1t}}});   // rows = in
     return FfnTrainImg{w1, w2, w2t, w1t, p.gamma, p.beta, p.b1, p.b2};
 }
 
@@ -1100,10 +1117,8 @@ static CmImg cm_pack_images(LaunchCtx ctx, const ConvModTrainParams& p, float* i
     hipStream_t s = ctx.stream;
     float *w1 = img, *w1t = img + 16384, *w2 = img + 32768, *w2t = img + 32768 + 8192;
     if (!pack) return CmImg{w1, w1t, w2, w2t};
-    LAUNCH(ctx, "convmod_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.pw1_w, 256, 64, 64, 0, w1)));
-    LAUNCH(ctx, "convmod_train_pack", (pack_fm_kernel<<<64, 256, 0, s>>>(p.pw1_w, 64, 256, 64, 1, w1t)));
-    LAUNCH(ctx, "convmod_train_pack", (pack_fm_kernel<<<32, 256, 0, s>>>(p.pw2_w, 64, 128, 128, 0, w2)));
-    LAUNCH(ctx, "convmod_train_pack", (pack_fm_kernel<<<32, 256, 0, s>>>(p.pw2_w, 128, 64, 128, 1, w2t)));
+    launch_pack4(ctx, "convmod_train_pack", PackJobs{{{p.pw1_w, 256, 64, 64, 0, w1}, {p.pw1_w, 64, 256, 64, 1, w1t},
+                                                      {p.pw2_w, 64, 128, 128, 0, w2}, {p.pw2_w, 128, 64, 128, 1, w2t}}});
     return CmImg{w1, w1t, w2, w2t};
 }
 
@@ -1858,10 +1873,9 @@ static void at_pack_images(LaunchCtx ctx, const AttnTrainParams& p, float* ws, c
     hipStream_t s = ctx.stream;
     hipMemcpyAsync(ws + pl.raw, p.wq, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);            // rows 0..63
     hipMemcpyAsync(ws + pl.raw + 4096, p.wkv, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);    // rows 64..191
-    LAUNCH(ctx, "attn_train_pack", (pack_fm_kernel<<<48, 256, 0, s>>>(ws + pl.raw, 192, 64, 64, 0, ws + pl.wqkv)));
-    LAUNCH(ctx, "attn_train_pack", (pack_fm_kernel<<<48, 256, 0, s>>>(ws + pl.raw, 64, 192, 64, 1, ws + pl.wqkvt)));
-    LAUNCH(ctx, "attn_train_pack", (pack_fm_kernel<<<16, 256, 0, s>>>(p.wo, 64, 64, 64, 0, ws + pl.wo)));
-    LAUNCH(ctx, "attn_train_pack", (pack_fm_kernel<<<16, 256, 0, s>>>(p.wo, 64, 64, 64, 1, ws + pl.wot)));
+    launch_pack4(ctx, "attn_train_pack", PackJobs{{{ws + pl.raw, 192, 64, 64, 0, ws + pl.wqkv},
+                                                   {ws + pl.raw, 64, 192, 64, 1, ws + pl.wqkvt},
+                                                   {p.wo, 64, 64, 64, 0, ws + pl.wo}, {p.wo, 64, 64, 64, 1, ws + pl.wot}}});
 }
 
 void launch_attn_train_forward(LaunchCtx ctx, const float* x, int N, int L, const AttnTrainParams& p, int max_pos,
