@@ -113,15 +113,8 @@ void launch_loss_terms(LaunchCtx ctx, const float* est_real, const float* est_im
 // Weight gradients are token-contractions (K = M): split-K MFMA products into fixed-shape partial slabs that a
 // second kernel adds in a fixed order - deterministic, no atomics.
 // =====================================================================================
-__global__ void pack_fm_kernel(const float* __restrict__ w, int R, int K, int ldw, int transpose, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R * K) return;
-    const int r = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
-    const int KB = K / 16, rb = blk / KB, kb = blk - rb * KB;
-    const int row = 16 * rb + (lane & 15), col = 16 * kb + 4 * (lane >> 4) + r;
-    out[i] = transpose ? w[(long)col * ldw + row] : w[(long)row * ldw + col];
-}
-// the four images of one module in ONE launch (blockIdx.y = image): a training step re-packs 128 images
+// row-major W [R, K] (leading dimension ldw; transpose = 1: the image of W^T) -> fragment-major image [R/16][K/16][64][4]
+// (common.hip.h); the four images of one module in ONE launch (blockIdx.y = image): a training step re-packs 128 images
 struct PackJob { const float* w; int R, K, ldw, transpose; float* out; };
 struct PackJobs { PackJob j[4]; };
 __global__ void pack_fm4_kernel(PackJobs jobs) {
@@ -349,50 +342,9 @@ __global__ __launch_bounds__(256) void ffn_train_bwd_kernel(const float* __restr
     }
 }
 
-// out_partial[s][i][j] = sum over the s-th token range of P[m][i] * Q[m][j]   (P [M,R], Q [M,C], row-major);
-// block = (16 rows i, 64 columns j, split s); its 4 waves take interleaved 16-token steps, combined through LDS.
-__global__ __launch_bounds__(256) void wgrad_partial_kernel(const float* __restrict__ P, const float* __restrict__ Q,
-                                                            long M, int R, int C, int nsplit,
-                                                            float* __restrict__ partial) {
-    __shared__ float red[4][16 * 64];
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-    const int ib = blockIdx.x, jc = blockIdx.y, s = blockIdx.z;
-    const long steps = (M + 15) / 16, per = (steps + nsplit - 1) / nsplit;
-    const long st0 = (long)s * per, st1 = st0 + per < steps ? st0 + per : steps;
-    f32x4 acc[4];
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb) acc[jb] = splat4(0.f);
-    for (long st = st0 + wv; st < st1; st += 4) {
-        float a[4];
-        f32x4 b[4];                                   // b[jb][r]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long m = st * 16 + 4 * g + r;
-            const bool ok = m < M;
-            const long mm = ok ? m : M - 1;
-            a[r] = ok ? P[mm * R + 16 * ib + c] : 0.f;
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) b[jb][r] = ok ? Q[mm * C + 64 * jc + 16 * jb + c] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int jb = 0; jb < 4; ++jb) acc[jb] = mfma16(a[r], b[jb][r], acc[jb]);
-    }
-#pragma unroll
-    for (int jb = 0; jb < 4; ++jb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wv][(4 * g + r) * 64 + 16 * jb + c] = acc[jb][r];
-    __syncthreads();
-    for (int e = threadIdx.x; e < 16 * 64; e += 256) {
-        const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-        const int i = e >> 6, j = e & 63;
-        partial[((long)s * R + 16 * ib + i) * C + 64 * jc + j] = v;
-    }
-}
-
-// The same contraction with a 64 x 64 output tile per block (all four 16-row blocks of a 64-row band): the 16 x 64
-// version re-read Q once per row block and P once per column block - 664 MB of L2 / HBM reads for the 166 MB of
+// out_partial[s][i][j] = sum over the s-th token range of P[m][i] * Q[m][j]   (P [M,R], Q [M,C], row-major), a 64 x 64
+// output tile per block (all four 16-row blocks of a 64-row band): a first version with 16 x 64 tiles
+// re-read Q once per row block and P once per column block - 664 MB of L2 / HBM reads for the 166 MB of
 // operands of one FeedForward weight gradient, which is what bounded it (83 us at 8 TB/s of cache traffic).  Here a
 // wave-step loads 16 + 16 operand dwords for 64 MFMAs; the four waves' tiles are combined through 32 KB of LDS in a
 // fixed order.  Grid (R / 64, C / 64, WG_SPLIT).
@@ -2069,17 +2021,6 @@ void launch_swap_axes(LaunchCtx ctx, const float* in, const float* add, float* o
 #define DB_NCH 256                     // position chunks per clip of the per-(b, c) reductions: B x 256 blocks fill the chip
                                        // (32 chunks = 128 blocks at batch 4 ran these streaming sums at 0.2 TB/s)
 #define MT_NCH 32                      // the single-channel mask head's planes are 64 x smaller
-
-// strided fragment-major pack: out[rb][kb][lane][r] = w[row * rs + col * cs]  (row/col swapped when transpose)
-__global__ void pack_fm_strided_kernel(const float* __restrict__ w, int R, int K, long rs, long cs, int transpose,
-                                       float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= R * K) return;
-    const int r = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
-    const int KB = K / 16, rb = blk / KB, kb = blk - rb * KB;
-    const int row = 16 * rb + (lane & 15), col = 16 * kb + 4 * (lane >> 4) + r;
-    out[i] = transpose ? w[(long)col * rs + (long)row * cs] : w[(long)row * rs + (long)col * cs];
-}
 
 struct DbSlots { const float* p[5]; };
 
