@@ -304,6 +304,17 @@ static int build_x3_images(const float* payload, const std::map<uint32_t, WEntry
                     for (int d = 0; d < 16; ++d) img.push_back(hi[d]);
                     for (int d = 0; d < 16; ++d) img.push_back(lo[d]);
                 }
+                // attn32_x3.hip: four planes [hi d 0..7 | hi d 8..15 | lo d 0..7 | lo d 8..15] of [rows][8 halfs], rows in
+                // REVERSED distance order (row r' = max_pos - distance), so that the 32 consecutive - descending -
+                // distances an MFMA operand tile needs are 32 consecutive 16-byte units: a coalesced fetch
+                pad(); d16[id | 0x4000] = img.size();
+                for (int plane = 0; plane < 4; ++plane)
+                    for (size_t r = 0; r < rows; ++r)
+                        for (int e = 0; e < 8; ++e) {
+                            _Float16 hi1, lo1;
+                            split_h(src[(rows - 1 - r) * 16 + 8 * (plane & 1) + e], hi1, lo1);
+                            img.push_back(plane < 2 ? hi1 : lo1);
+                        }
             }
         } else if (grp == G_DB_E || grp == G_DB_M || grp == G_DB_C) {
             if (item % 4 == 0) { pad(); d16[id] = img.size(); x3_conv_image(src, 4 * (item / 4 + 1), 6, 4, img); }
@@ -399,6 +410,7 @@ static bool conf_weights_x3(cmgan_handle* h, int index, ConfWeightsX3& w) {
     w.pw1_w = W16(h, WID(g, CF_PW1_W), ok);   w.pw2_w = W16(h, WID(g, CF_PW2_W), ok);
     w.ff2_w1 = W16(h, WID(g, CF_FF2_W1), ok); w.ff2_w2 = W16(h, WID(g, CF_FF2_W2), ok);
     w.rel_img = W16(h, WID(g, CF_REL), ok);
+    w.rel_planes = W16(h, WID(g, CF_REL) | 0x4000, ok);
     return ok;
 }
 

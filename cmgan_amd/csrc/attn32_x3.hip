@@ -1,0 +1,609 @@
+// attn32_x3.hip - Shaw relative-position attention of the ConformerBlock (conformer.py:100-133) on
+// v_mfma_f32_32x32x16_f16 (8-pass MFMAs, three split-f16 products per contraction), fused with to_out + bias +
+// residual (conformer.py:131-132, 218).  x3 mode only; replaces the 16x16x32 kernels of conformer_x3.hip
+// (attn_out_x3_kernel / qkv_x3_kernel, kept there for A/B builds with -DATTN32=0).
+//
+// Why this shape.  The 16x16x32 kernel was bound by instruction ISSUE, not by the matrix pipe (25 % busy): per
+// 2048 scores it issued 48 four-pass MFMAs (which leave no issue slots for other instructions on their SIMD,
+// tools/micro), ~200 VALU and 72 LDS instructions, and started every 64-key chunk with a cold load of its K / V /
+// E operands.  Here:
+//   * the contraction of an 8-pass 32x32x16 MFMA is exactly the head dimension d = 16, so a product costs three
+//     MFMAs (hi.hi + hi.lo + lo.hi) instead of the four terms of the [hi | lo]-packed 16x16x32 form: 23 MFMAs
+//     per 32-query x 64-key chunk (9 E q, 6 K q, 8 P V), each leaving ~5 issue slots for the softmax VALU;
+//   * scores are computed transposed (S^T = K Q^T, rows = keys, columns = queries), so a lane owns ONE query
+//     (column = lane & 31) and 16 keys of every 32-key tile: the row maximum / sum are in-lane plus one
+//     v_permlane32_swap, and exp2(S) converted to fp16 hi / lo IS the B operand of O^T += [V_hi ; V_lo]^T P -
+//     no data movement between the two products;
+//   * the operands of chunk n + 1 are requested right after their last use in chunk n (E after the E q MFMAs,
+//     K after the K q MFMAs, V after the P V MFMAs) into the same registers: the L2 latency is covered by the
+//     rest of the chunk at no register cost.
+// The relative-position term is the same Toeplitz skew as before, through a wave-private LDS window: R[w][q] =
+// E[i0 - w] . q_q for the 96 distances w = j - q a chunk can see (three 32x32 MFMA tiles), written row-major
+// (32 floats per distance, bank = query: conflict-free) and read back with per-lane base (32 + 4 hh - q) rows +
+// compile-time row offsets straight into the score accumulators, on which K q then accumulates.
+//
+// Register images (all lane-linear 1 KiB fragments, written by qkv32_x3_kernel):
+//   Q, K : per (sequence, head, 32-token tile)  [hi | lo][64 lanes][8 halfs], lane (token = lane & 31, hh = lane >> 5)
+//          holds d = 8 hh .. 8 hh + 7        (A operand rows = keys / B operand columns = queries)
+//   V    : per (sequence, head, 16-key group)   [64 lanes][8 halfs], lane (row = lane & 31, hh): rows 0..15 = hi of
+//          V[key][d = row], rows 16..31 = lo of V[key][d = row - 16]; slot e <-> key 16 grp + 8 (e >> 2) + 4 hh + (e & 3)
+//          (= the key a lane's score register v = 8 (grp & 1) + e belongs to), so O^T[(hi | lo) d][query] accumulates
+//          V_hi P_hi + V_hi P_lo (rows 0..15) and V_lo P_hi + V_lo P_lo (rows 16..31) in two MFMAs per group.
+#include "kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mfma3216(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma3216l(f16x8 a, f16x8 b, f32x16 c) {      // a term with a lo operand
+    return X3_TERMS == 3 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0) : c;
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+// Cycle stamps (measurement builds only, -DA32_STAMP): per-phase s_memtime deltas of every wave, summed into a
+// device array that tools/probes/attn_stamps.py reads through cmgan_dbg_a32_stamps (phase names there); entries
+// 16 / 17 = waves / chunks; entries 32.. are the same for sequences shorter than 200 positions.
+#ifdef A32_STAMP
+__device__ unsigned long long g_a32_stamp[64];
+struct A32Stamp {
+    unsigned long long t, acc[16];
+    int chunks;
+};
+#define A32_STAMP_ARG , A32Stamp& sp
+#define A32_STAMP_PASS , sp
+#define A32_STAMP_PTR , A32Stamp* spp
+#define A32_STAMP_PTRPASS , &sp
+#define A32_MARK(ph)                                            \
+    do {                                                        \
+        __builtin_amdgcn_sched_barrier(0);                      \
+        const unsigned long long _t = __builtin_readcyclecounter(); \
+        sp.acc[ph] += _t - sp.t;                                \
+        sp.t = _t;                                              \
+        __builtin_amdgcn_sched_barrier(0);                      \
+    } while (0)
+#else
+#define A32_STAMP_ARG
+#define A32_STAMP_PASS
+#define A32_STAMP_PTR
+#define A32_STAMP_PTRPASS
+#define A32_MARK(ph) do { } while (0)
+#endif
+
+// max / sum over the two lanes (l, l + 32) that share a query column
+__device__ __forceinline__ float red_h_max(float v) {
+    float b;
+    const float a = xchg32(v, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float red_h_sum(float v) {
+    float b;
+    const float a = xchg32(v, b);
+    return a + b;
+}
+
+#ifndef XCD_ORDER
+#define XCD_ORDER 1
+#endif
+#define XNTB 2
+#define XWAVES 8
+
+__device__ __forceinline__ void ln_split32(const f32x4 (&x)[4], f16x8 (&bh)[2], f16x8 (&bl)[2]) {
+    float mean, rstd;
+    ln_stats(x, mean, rstd);
+    f32x4 xh[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) xh[kb] = (x[kb] - splat4(mean)) * splat4(rstd);
+    split8(xh[0], xh[1], bh[0], bl[0]);
+    split8(xh[2], xh[3], bh[1], bl[1]);
+}
+
+// ---------------------------------------------------------------------------------
+// LN -> q (x 0.25 log2 e folded), k, v in the 32-token tile images described above.  Same per-token chain as
+// qkv_x3_kernel (a wave owns 32 consecutive positions of one sequence as two 16-token MFMA column blocks); only
+// the store patterns differ.  LDS: weight image [12][2] = 48 KB + a 32 x 17 float transposition patch per wave.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void qkv32_x3_kernel(const float* __restrict__ x, TokMap m, int Lt,
+                                                       const _Float16* __restrict__ wi, const float* __restrict__ b,
+                                                       _Float16* __restrict__ qimg, _Float16* __restrict__ kimg,
+                                                       _Float16* __restrict__ vimg, int ntiles) {
+    __shared__ __attribute__((aligned(16))) _Float16 wlds[24576];              // 48 KB image
+    __shared__ float scratch[XWAVES * 32 * 17];                                // 17 KB
+    __shared__ __attribute__((aligned(16))) float bias_l[192];
+    stage_lds16<3072, 512>(wi, wlds);
+    for (int i = threadIdx.x; i < 192; i += blockDim.x) bias_l[i] = b[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int row32 = lane & 31, hh = lane >> 5;
+    float* T = scratch + wv * (32 * 17);
+
+#pragma unroll 1
+    for (int tile = blockIdx.x * XWAVES + wv; tile < ntiles; tile += gridDim.x * XWAVES) {
+        const int n = tile / Lt, it = tile - n * Lt;
+        f16x8 xbh[XNTB][2], xbl[XNTB][2];
+#pragma unroll
+        for (int tb = 0; tb < XNTB; ++tb) {
+            int l = it * 32 + tb * 16 + c;
+            if (l >= m.L) l = m.L - 1;
+            const long row = (long)(n / m.inner) * m.outer + (long)(n % m.inner) * m.istride + (long)l * m.lstride;
+            f32x4 xr[4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) xr[kb] = ldg4(x + row * 64 + 16 * kb + 4 * g);
+            ln_split32(xr, xbh[tb], xbl[tb]);
+        }
+#pragma unroll 2
+        for (int ob = 0; ob < 12; ++ob) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(&bias_l[16 * ob + 4 * g]);
+            f32x4 acc[XNTB];
+#pragma unroll
+            for (int tb = 0; tb < XNTB; ++tb) acc[tb] = bias;
+            lin_acc_x3<2, XNTB>(wlds + ob * 2048 + lane * 8, xbh, xbl, acc);
+            const int which = ob >> 2, h = ob & 3;
+            const long nh = (long)n * 4 + h;
+            if (which < 2) {
+                // lane (token c of block tb, g) holds d = 4 g .. 4 g + 3  ->  image lane (token 16 tb + c, hh = g >> 1),
+                // slots 4 (g & 1) .. + 3: one 8-byte store per half
+                _Float16* img = (which == 0 ? qimg : kimg) + (nh * Lt + it) * 1024;
+#pragma unroll
+                for (int tb = 0; tb < XNTB; ++tb) {
+                    f16x4 hi, lo;
+                    split4(acc[tb], hi, lo);
+                    _Float16* p = img + ((g >> 1) * 32 + 16 * tb + c) * 8 + 4 * (g & 1);
+                    *reinterpret_cast<f16x4*>(p) = hi;
+                    *reinterpret_cast<f16x4*>(p + 512) = lo;
+                }
+            } else {
+                wave_lds_fence();                           // the previous head's reads of T are done
+#pragma unroll
+                for (int tb = 0; tb < XNTB; ++tb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[(16 * tb + c) * 17 + 4 * g + r] = acc[tb][r];     // T[token][d]
+                wave_lds_fence();
+#pragma unroll
+                for (int grp = 0; grp < 2; ++grp) {
+                    f32x4 va, vb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        va[r] = T[(16 * grp + 4 * hh + r) * 17 + (row32 & 15)];
+                        vb[r] = T[(16 * grp + 8 + 4 * hh + r) * 17 + (row32 & 15)];
+                    }
+                    f16x8 vh, vl;
+                    split8(va, vb, vh, vl);
+                    const f16x8 out = row32 < 16 ? vh : vl;
+                    *reinterpret_cast<f16x8*>(vimg + ((nh * Lt + it) * 2 + grp) * 512 + lane * 8) = out;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// attention core
+// ---------------------------------------------------------------------------------
+#ifndef A32_OCC
+#define A32_OCC 2            // blocks per CU = waves per SIMD the register allocation is sized for (LDS: 48 KB / block)
+#endif
+#ifndef A32_RSEQ
+#define A32_RSEQ 1
+#endif
+#define A32_HI 12.0f         // the stale-reference band of the online softmax, see att_softmax in conformer_x3.hip
+#define A32_LO -4.0f
+#define A32_RFL (96 * 32)    // floats of one wave's distance window
+
+struct A32State {
+    float m, run, l;         // reference level, running maximum relative to it, this lane's part of the denominator
+};
+
+// Operand fetches are raw buffer loads: a wave-uniform descriptor (SGPRs) + a 32-bit per-lane byte offset + a scalar
+// tile offset.  With plain pointers the compiler keeps one 64-bit VGPR address pair per operand and tile (it
+// spilled them); here the only per-lane address state is lane * 16 and three distance-row offsets per chunk.
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t a32_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f16x8 buf_h8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+struct A32Ctx {
+    __amdgpu_buffer_rsrc_t qr, kr, vr, er;   // Q / K / V tile images of this (sequence, head); the distance planes
+    unsigned lane16, eoff, eplane2;          // lane * 16 bytes; hh * plane bytes; 2 * plane bytes (hi -> lo plane)
+    float* R;                                // the wave's distance window
+    int wbase, rbase;                        // float offsets of this lane's first write / read row
+    int Lt, L, max_pos, i0, a, hh;           // a = lane & 31 (operand row / query column)
+    const unsigned char* mk;                 // mask row of the sequence (MASK variants)
+    const char* xbase;                       // residual rows of this wave's to_out output block (uniform base)
+    const char* bo;                          // to_out bias of that block (uniform; the lane adds 16 * (lane >> 4))
+};
+
+// E rows of window tile t of chunk n of the query tile at i0: distance i0 - 64 n + 32 - 32 t - a, clamped to the
+// table (conformer.py:109).  The table is stored as four planes [hi d 0..7 | hi d 8..15 | lo d 0..7 | lo d 8..15] of
+// 16-byte rows in REVERSED distance order (row = max_pos - distance): the 32 lanes of one half read 32 consecutive
+// rows = 512 contiguous bytes (as a 64-byte [hi | lo] row gather these six fetches took most of the CU's
+// address-coalescer time).
+__device__ __forceinline__ void a32_load_e(const A32Ctx& c, int i0, int n, int t, f16x8& eh, f16x8& el) {
+    int row = c.max_pos - (i0 - 64 * n + 32 - 32 * t) + c.a;
+#ifdef A32_FAKEE
+    row = c.max_pos - 32 + 32 * t + c.a;                 // timing probe: always the same (L1-resident) table rows
+#endif
+    row = row < 0 ? 0 : (row > 2 * c.max_pos ? 2 * c.max_pos : row);
+    const unsigned off = (unsigned)row * 16u + c.eoff;
+    eh = buf_h8(c.er, off, 0);
+    el = buf_h8(c.er, off, c.eplane2);
+}
+__device__ __forceinline__ void a32_load_k(const A32Ctx& c, int n, int jt, f16x8& kh, f16x8& kl) {
+    int kt = 2 * n + jt;
+    kt = kt < c.Lt ? kt : c.Lt - 1;
+#ifdef A32_FAKEKV
+    kt = jt;                                             // timing probe: always the same (L1-resident) tiles
+#endif
+    kh = buf_h8(c.kr, c.lane16, (unsigned)kt * 2048u);
+    kl = buf_h8(c.kr, c.lane16 + 1024u, (unsigned)kt * 2048u);
+}
+__device__ __forceinline__ f16x8 a32_load_v(const A32Ctx& c, int n, int grp4) {
+    int gr = 4 * n + grp4;
+    gr = gr < 2 * c.Lt ? gr : 2 * c.Lt - 1;
+#ifdef A32_FAKEKV
+    gr = grp4 & 1;
+#endif
+    return buf_h8(c.vr, c.lane16, (unsigned)gr * 1024u);
+}
+
+// Online softmax of one chunk for the lane's query (see att_softmax in conformer_x3.hip for the stale-reference
+// scheme and the mask semantics; same arithmetic, one query per lane).  On return s holds p = exp2(s - m).
+template <int NKT, bool FULL, bool MASK>
+__device__ __forceinline__ void a32_softmax(f32x16 (&s)[2], const A32Ctx& c, int j0, A32State& st, f32x16& o,
+                                            bool qvalid A32_STAMP_PTR) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < NKT; ++jt) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            float xv = s[jt][v] - st.m;
+            const int key = j0 + 32 * jt + 8 * (v >> 2) + 4 * c.hh + (v & 3);
+            if (!FULL) xv = key < c.L ? xv : -INFINITY;
+            if (MASK && (FULL || key < c.L)) xv = qvalid ? (c.mk[key] ? xv : -INFINITY) : 0.f;
+            s[jt][v] = xv;
+            mx = fmaxf(mx, xv);
+        }
+    }
+    const float run = fmaxf(st.run, red_h_max(mx));
+#ifdef A32_STAMP
+    if (spp) { A32Stamp& sp = *spp; A32_MARK(11); }      // wait for the K q results + subtract / max
+#endif
+    const bool dead = MASK && run == -INFINITY;
+    const bool drift = !dead && (run > A32_HI || run < A32_LO);
+    float runk = run;
+    if (__any(drift)) {                                  // rare: re-reference the query to its running maximum
+        const float shift = dead ? 0.f : run;            // (every live lane of the wave re-references, as before)
+        const float alpha = st.l > 0.f ? __builtin_amdgcn_exp2f(-shift) : 1.0f;
+#pragma unroll
+        for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) s[jt][v] -= shift;
+        st.l *= alpha;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[v] *= alpha;
+        st.m += shift;
+        if (!dead) runk = 0.f;
+    }
+    st.run = runk;
+    float psum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const float p = __builtin_amdgcn_exp2f(s[jt][v]);      // exp2(-inf) = 0 for masked / non-existent keys
+            s[jt][v] = p;
+            psum += p;
+        }
+    st.l += psum;
+}
+
+// One 64-key chunk n for the wave's 32 queries.  NKT = live 32-key tiles (2, or 1 in a short tail chunk), FULL =
+// every key of the chunk exists, LAST = the tile's last chunk.  While this chunk computes, the operands of the NEXT
+// unit of work - chunk nn of the query tile at i0n (the next chunk of this tile, or chunk 0 of the block's next
+// tile, then together with that tile's Q) - are requested into the registers this chunk has just finished with.
+template <int NKT, bool FULL, bool LAST, bool MASK>
+__device__ __forceinline__ void a32_chunk(const A32Ctx& c, int n, int i0n, int nn, f16x8& qh, f16x8& ql, f16x8 (&eh)[3], f16x8 (&el)[3],
+                                          f16x8 (&kh)[2], f16x8 (&kl)[2], f16x8 (&va)[4], A32State& st, f32x16& o,
+                                          bool qvalid, const unsigned (&xo)[2], f32x4 (&xold)[2], f32x4& bias
+                                          A32_STAMP_ARG) {
+    constexpr int NT = NKT + 1;                          // window tiles the live key tiles read
+    // ---- R = E q for the distance window, written row-major to the wave's LDS window ----
+    // (A32_NO_* = timing-only ablation builds, never shipped: they drop one phase to measure what it costs)
+#ifndef A32_NO_R
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        f32x16 r = mfma3216(eh[t], qh, zero16());
+        if (t == 0) A32_MARK(8);                          // (stamp builds) the wait for the E operands
+        r = mfma3216l(eh[t], ql, r);
+        r = mfma3216l(el[t], qh, r);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) c.R[c.wbase + (32 * t + 8 * (v >> 2) + (v & 3)) * 32] = r[v];
+        if (A32_RSEQ && (t & 1)) __builtin_amdgcn_sched_barrier(0);     // at most two window tiles in flight (registers)
+    }
+#ifndef A32_NO_LD
+#pragma unroll
+    for (int t = 0; t < 3; ++t) a32_load_e(c, i0n, nn, t, eh[t], el[t]);
+#endif
+#endif
+    A32_MARK(1);
+    wave_lds_fence();
+    // ---- S^T = skewed R + K q ----
+    f32x16 s[2];
+#ifndef A32_NO_R
+#pragma unroll
+    for (int jt = 0; jt < NKT; ++jt) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) s[jt][v] = c.R[c.rbase + (32 * jt + 8 * (v >> 2) + (v & 3)) * 32];
+    }
+#else
+    s[0] = zero16(); s[1] = zero16();
+#endif
+    wave_lds_fence();                                    // the next chunk's window writes come after these reads
+    A32_MARK(9);                                         // (stamp builds) window reads returned
+#pragma unroll
+    for (int jt = 0; jt < NKT; ++jt) {
+        s[jt] = mfma3216(kh[jt], qh, s[jt]);
+        s[jt] = mfma3216l(kh[jt], ql, s[jt]);
+        s[jt] = mfma3216l(kl[jt], qh, s[jt]);
+    }
+#ifndef A32_NO_LD
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) a32_load_k(c, nn, jt, kh[jt], kl[jt]);
+    if (LAST) {                                          // last chunk of the tile: q is free, fetch the next tile's
+        const int itn = (i0n >> 5) < c.Lt ? (i0n >> 5) : c.Lt - 1;
+        qh = buf_h8(c.qr, c.lane16, (unsigned)itn * 2048u);
+        ql = buf_h8(c.qr, c.lane16 + 1024u, (unsigned)itn * 2048u);
+    }
+#endif
+    A32_MARK(2);
+#ifndef A32_NO_SM
+    a32_softmax<NKT, FULL, MASK>(s, c, 64 * n, st, o, qvalid A32_STAMP_PTRPASS);
+#else
+    st.l += s[0][0] + s[1][5];
+#endif
+    A32_MARK(3);
+    if (LAST) {                                          // the epilogue's residual rows and bias: hidden behind P V
+#pragma unroll
+        for (int i = 0; i < 2; ++i) xold[i] = *reinterpret_cast<const f32x4*>(c.xbase + xo[i]);
+        bias = *reinterpret_cast<const f32x4*>(c.bo + (c.lane16 >> 8) * 16u);
+    }
+    // ---- O^T += [V_hi ; V_lo] P ----
+#ifdef A32_NO_PV
+#pragma unroll
+    for (int v = 0; v < 16; ++v) o[v] += s[0][v] + s[1][v];
+#else
+#pragma unroll
+    for (int jt = 0; jt < NKT; ++jt) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 pa, pb;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pa[r] = s[jt][8 * half + r];
+                pb[r] = s[jt][8 * half + 4 + r];
+            }
+            f16x8 ph, pl;
+            split8(pa, pb, ph, pl);
+            o = mfma3216(va[2 * jt + half], ph, o);
+            if (jt == 0 && half == 0) A32_MARK(10);       // (stamp builds) first split + the wait for the V operands
+            o = mfma3216l(va[2 * jt + half], pl, o);
+        }
+    }
+#endif
+#ifndef A32_NO_LD
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) va[g4] = a32_load_v(c, nn, g4);
+#endif
+    A32_MARK(4);
+#ifdef A32_STAMP
+    ++sp.chunks;
+#endif
+}
+
+// Block = the four heads (one per wave) of up to A32_TPB consecutive 32-query tiles of one sequence, walked in
+// order: only the first tile of a block starts cold - while a tile's last chunk computes, chunk 0 of the next tile
+// is already being fetched, and the next tile's Q and residual rows are requested before the epilogue.
+// Epilogue of a tile: each wave parks its normalised O tile in the stash (double-buffered, so ONE barrier per
+// tile) in the 16x16 C-fragment form the to_out product consumes (the B fragment of k-block h); after the barrier
+// wave w evaluates output block w of x += Wo . concat_h(O_h) + bo for the tile's 32 tokens, exactly as
+// attn_out_x3_kernel does.
+#ifndef A32_TPB
+#define A32_TPB 6
+#endif
+template <bool MASK>
+__global__ __launch_bounds__(256, MASK ? 1 : A32_OCC) void attn32_out_x3_kernel(const _Float16* __restrict__ qimg,
+                                                                     const _Float16* __restrict__ kimg,
+                                                                     const _Float16* __restrict__ vimg,
+                                                                     const _Float16* __restrict__ eimg, int max_pos,
+                                                                     float* __restrict__ x, TokMap m,
+                                                                     const _Float16* __restrict__ woi,
+                                                                     const float* __restrict__ bo, int Lt, int tpb,
+                                                                     int bps, long nblocks,
+                                                                     const unsigned char* __restrict__ mask) {
+    __shared__ __attribute__((aligned(16))) float rbuf[4][A32_RFL];
+    __shared__ __attribute__((aligned(16))) f32x4 stash[2][4][2][64];      // [parity][head][16-token block][16x16 lane]
+    __shared__ __attribute__((aligned(16))) _Float16 wo_l[8192];           // to_out image [ob][m][hi | lo][64][8]: 16 KB
+                                                                           // (80 KB per block in all: two blocks per CU)
+#ifdef A32_LONE
+    __shared__ float lone_pad[8192];                      // measurement builds: 96 KB per block = one block per CU
+    if (max_pos < 0) lone_pad[threadIdx.x] = 1.f;
+#endif
+#ifdef A32_STAMP
+    A32Stamp sp;
+    sp.t = __builtin_readcyclecounter();
+    sp.chunks = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sp.acc[i] = 0;
+#endif
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long lblk = XCD_ORDER ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+    if (lblk >= nblocks) return;                          // padding blocks of the rounded-up grid (block-uniform)
+    stage_lds16<1024, 256>(woi, wo_l);                    // visible to every wave after the first tile's barrier
+    // (integer division runs on the VALU: readfirstlane moves the - uniform - results back to SGPRs, so that every
+    // pointer derived from them is a scalar base instead of a VGPR pair)
+    const int n = __builtin_amdgcn_readfirstlane((int)((unsigned)lblk / (unsigned)bps));   // sequence; bps blocks of tpb tiles each
+    const int it0 = ((int)lblk - n * bps) * tpb, it1 = it0 + tpb < Lt ? it0 + tpb : Lt;
+    const long nh = (long)n * 4 + wv;                     // this wave's head (wave-uniform: operand bases stay in SGPRs)
+    const int L = m.L;
+    A32Ctx c;
+    c.a = lane & 31; c.hh = lane >> 5;
+    c.R = rbuf[wv];
+    c.wbase = 4 * c.hh * 32 + c.a;
+    c.rbase = (32 + 4 * c.hh - c.a) * 32 + c.a;
+    c.Lt = Lt; c.L = L; c.max_pos = max_pos;
+    c.kr = a32_rsrc(kimg + nh * Lt * 1024, (unsigned)Lt * 2048u);
+    c.vr = a32_rsrc(vimg + nh * Lt * 1024, (unsigned)Lt * 2048u);
+    c.er = a32_rsrc(eimg, (unsigned)(2 * max_pos + 1) * 64u);
+    c.qr = a32_rsrc(qimg + nh * Lt * 1024, (unsigned)Lt * 2048u);
+    c.lane16 = (unsigned)lane * 16u;
+    c.eoff = (unsigned)c.hh * (unsigned)(2 * max_pos + 1) * 16u;
+    c.eplane2 = (unsigned)(2 * max_pos + 1) * 32u;
+    c.mk = MASK ? mask + (long)n * L : nullptr;
+    const int c16 = lane & 15, g16 = lane >> 4;
+    // residual rows of this wave's output block: uniform base + 32-bit lane offsets (a sequence spans < 4 GB)
+    const int nq = __builtin_amdgcn_readfirstlane(n / m.inner);
+    char* xbase = reinterpret_cast<char*>(x + ((long)nq * m.outer + (long)(n - nq * m.inner) * m.istride) * 64 + 16 * wv);
+    const unsigned xstride = (unsigned)m.lstride * 256u, xlane = (unsigned)g16 * 16u;
+
+    c.xbase = xbase;
+    c.bo = reinterpret_cast<const char*>(bo + 16 * wv);   // to_out bias of this wave's output block
+    f16x8 qh = buf_h8(c.qr, c.lane16, (unsigned)it0 * 2048u), ql = buf_h8(c.qr, c.lane16 + 1024u, (unsigned)it0 * 2048u);
+    f16x8 eh[3], el[3], kh[2], kl[2], va[4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) a32_load_e(c, 32 * it0, 0, t, eh[t], el[t]);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) a32_load_k(c, 0, jt, kh[jt], kl[jt]);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) va[g4] = a32_load_v(c, 0, g4);
+    const int nfull = L >> 6, tail = L & 63;
+    A32_MARK(0);
+
+#pragma unroll 1
+    for (int it = it0; it < it1; ++it) {
+        c.i0 = 32 * it;
+        bool qvalid = true;
+        if (MASK) {
+            const int lq = c.i0 + c.a;
+            qvalid = c.mk[lq < L ? lq : L - 1] != 0;
+        }
+        A32State st;
+        st.m = 0.f; st.run = -INFINITY; st.l = 0.f;
+        f32x16 o = zero16();
+        const int i0x = c.i0 + 32;                        // the unit of work after this tile's last chunk
+        // residual rows of this wave's output block (and the bias): requested inside the tile's last chunk
+        unsigned xo[2];
+        f32x4 xold[2], bias;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int l = c.i0 + 16 * i + c16;
+            xo[i] = (unsigned)(l < L ? l : L - 1) * xstride + xlane;
+        }
+#define A32_ARGS qh, ql, eh, el, kh, kl, va, st, o, qvalid, xo, xold, bias A32_STAMP_PASS
+        if (tail) {
+#pragma unroll 1
+            for (int ch = 0; ch < nfull; ++ch) a32_chunk<2, true, false, MASK>(c, ch, c.i0, ch + 1, A32_ARGS);
+            if (tail > 32) a32_chunk<2, false, true, MASK>(c, nfull, i0x, 0, A32_ARGS);
+            else a32_chunk<1, false, true, MASK>(c, nfull, i0x, 0, A32_ARGS);
+        } else {
+#pragma unroll 1
+            for (int ch = 0; ch + 1 < nfull; ++ch) a32_chunk<2, true, false, MASK>(c, ch, c.i0, ch + 1, A32_ARGS);
+            a32_chunk<2, true, true, MASK>(c, nfull - 1, i0x, 0, A32_ARGS);
+        }
+#undef A32_ARGS
+        // O[query a][d = 8 (v >> 2) + 4 hh + (v & 3)] = (hi rows + lo rows) / l: two float4s per lane, which are the
+        // C-fragment entries of 16x16 lanes (c = a & 15, g = hh) and (c, g = 2 + hh) of token block a >> 4
+        const float inv = __builtin_amdgcn_rcpf(red_h_sum(st.l));
+        f32x4 oa, ob;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            oa[r] = (o[r] + o[8 + r]) * inv;
+            ob[r] = (o[4 + r] + o[12 + r]) * inv;
+        }
+#ifdef A32_NO_EPI
+        if (c.i0 + c16 < L) *reinterpret_cast<f32x4*>(xbase + xo[0]) = oa + ob + xold[0] + xold[1] + bias;
+        continue;
+#endif
+        const int par = (it - it0) & 1;
+        const _Float16* wp = wo_l + wv * 2048 + lane * 8;  // this wave's output block of the to_out image
+        stash[par][wv][c.a >> 4][c.hh * 16 + (c.a & 15)] = oa;
+        stash[par][wv][c.a >> 4][(2 + c.hh) * 16 + (c.a & 15)] = ob;
+        A32_MARK(5);
+#ifndef A32_NO_BAR
+        __syncthreads();
+#endif
+        A32_MARK(6);
+        const f16x8 ah0 = *reinterpret_cast<const f16x8*>(wp), al0 = *reinterpret_cast<const f16x8*>(wp + 512);
+        const f16x8 ah1 = *reinterpret_cast<const f16x8*>(wp + 1024), al1 = *reinterpret_cast<const f16x8*>(wp + 1536);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f16x8 bh0, bl0, bh1, bl1;
+            split8(stash[par][0][i][lane], stash[par][1][i][lane], bh0, bl0);
+            split8(stash[par][2][i][lane], stash[par][3][i][lane], bh1, bl1);
+            f32x4 acc = bias;                              // same product order as lin_acc_x3 / outproj_x3_kernel
+            acc = mfma32h(ah0, bh0, acc);
+            acc = mfma32l(ah0, bl0, acc);
+            acc = mfma32l(al0, bh0, acc);
+            acc = mfma32h(ah1, bh1, acc);
+            acc = mfma32l(ah1, bl1, acc);
+            acc = mfma32l(al1, bh1, acc);
+            if (c.i0 + 16 * i + c16 < L) *reinterpret_cast<f32x4*>(xbase + xo[i]) = xold[i] + acc;
+        }
+        A32_MARK(7);
+    }
+#ifdef A32_STAMP
+    if (lane == 0) {
+        const int b = L < 200 ? 32 : 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_a32_stamp[b + i], sp.acc[i]);
+        atomicAdd(&g_a32_stamp[b + 16], 1ull);
+        atomicAdd(&g_a32_stamp[b + 17], (unsigned long long)sp.chunks);
+    }
+#endif
+}
+
+#ifdef A32_STAMP
+extern "C" int cmgan_dbg_a32_stamps(unsigned long long* out, int reset) {
+    hipDeviceSynchronize();
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a32_stamp), sizeof(unsigned long long) * 64);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[64] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_a32_stamp), z, sizeof z);
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
+
+// ---------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------
+void launch_qkv32_x3(LaunchCtx ctx, const float* x, const TokMap& seq, const _Float16* wi, const float* b,
+                     _Float16* qimg, _Float16* kimg, _Float16* vimg) {
+    const int N = seq.nblocks / seq.Lb, Lt = (seq.L + 31) / 32;
+    const int ntiles = N * Lt;
+    const int want = (ntiles + XWAVES - 1) / XWAVES;
+    const int grid = want < 512 ? (want > 0 ? want : 1) : 512;       // two persistent blocks per CU
+    LAUNCH(ctx, "qkv", (qkv32_x3_kernel<<<grid, 512, 0, ctx.stream>>>(x, seq, Lt, wi, b, qimg, kimg, vimg, ntiles)));
+}
+
+void launch_attn32_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* kimg, const _Float16* vimg,
+                          const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
+                          const float* bo, const unsigned char* mask) {
+    const int N = seq.nblocks / seq.Lb, Lt = (seq.L + 31) / 32;
+    const int bps = (Lt + A32_TPB - 1) / A32_TPB;          // blocks per sequence, tiles spread evenly over them
+    const int tpb = (Lt + bps - 1) / bps;
+    const long nb = (long)N * bps;
+    const unsigned grid = XCD_ORDER ? (unsigned)(((nb + 7) / 8) * 8) : (unsigned)nb;
+    if (mask)
+        LAUNCH(ctx, "attn_out", (attn32_out_x3_kernel<true><<<grid, 256, 0, ctx.stream>>>(
+                                    qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, bps, nb, mask)));
+    else
+        LAUNCH(ctx, "attn_out", (attn32_out_x3_kernel<false><<<grid, 256, 0, ctx.stream>>>(
+                                    qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, bps, nb, nullptr)));
+}

@@ -244,6 +244,9 @@ __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x
 #ifndef ATTN_FUSE_OUT
 #define ATTN_FUSE_OUT 1      // attention + to_out + residual in one kernel (0 = attn_x3_kernel, then outproj_x3_kernel)
 #endif
+#ifndef ATTN32
+#define ATTN32 0             // 1 = attention on 32x32x16 MFMAs (attn32_x3.hip, measured 3-6 % slower: DESIGN.md section 7c); 0 = the 16x16x32 kernels below
+#endif
 #ifndef DWPW2_SLIDE
 #define DWPW2_SLIDE 1        // sliding-window depthwise + pointwise kernel (0 = one block per 32-position tile)
 #endif
@@ -1021,6 +1024,10 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
                            b.xa, b.xb, nullptr, nullptr, w16.ff1_w1, w.ff1_b1, w16.ff1_w2, w.ff1_b2, M, flat_tiles)));
     if (taps) hipMemcpyAsync(taps, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
 
+#if ATTN32
+    launch_qkv32_x3(ctx, b.xb, seq, w16.qkv_w, w.qkv_b, io.qimg, io.kimg, io.vimg);
+    launch_attn32_out_x3(ctx, io.qimg, io.kimg, io.vimg, w16.rel_planes, w.max_pos, b.xb, seq, w16.wo, w.bo, mask);
+#else
     const int qtiles = N * Lb2;
     LAUNCH(ctx, "qkv", (qkv_x3_kernel<<<persistent_grid(qtiles, 2), 512, 0, s>>>(
                            b.xb, seq, Lb2, w16.qkv_w, w.qkv_b, io, qtiles)));
@@ -1046,6 +1053,7 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
     const int otiles = (seq.nblocks + XNTB - 1) / XNTB;
     LAUNCH(ctx, "outproj", (outproj_x3_kernel<<<persistent_grid(otiles, 2), 512, 0, s>>>(b.xb, seq, b.o, w16.wo,
                                                                                            w.bo, otiles)));
+#endif
 #endif
     if (taps) hipMemcpyAsync(taps + (size_t)M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
 

@@ -116,10 +116,17 @@ void conformer_forward(LaunchCtx, const ConfWeights&, const ConfBuffers&, const 
 struct ConfWeightsX3 {
     const _Float16 *ff1_w1, *ff1_w2, *qkv_w, *wo, *pw1_w, *pw2_w, *ff2_w1, *ff2_w2;
     const _Float16* rel_img;    // [2*max_pos+1][hi 16 | lo 16] halfs
+    const _Float16* rel_planes; // 4 x [2*max_pos+1 rows, reversed][8 halfs]: hi d0-7 | hi d8-15 | lo d0-7 | lo d8-15 (attn32_x3.hip)
 };
 void conformer_forward_x3(LaunchCtx, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&, const TokMap& seq,
                           long M, float* taps, bool outer_residual, const unsigned char* mask = nullptr);
 void launch_dwconv(LaunchCtx, const float* u, float* out, const float* dw_w, const float* dw_b, const TokMap& seq);
+// attn32_x3.hip: the x3 attention on 32x32x16 MFMAs (32-token Q / K / V tile images) + to_out + residual
+void launch_qkv32_x3(LaunchCtx, const float* x, const TokMap& seq, const _Float16* wi, const float* b,
+                     _Float16* qimg, _Float16* kimg, _Float16* vimg);
+void launch_attn32_out_x3(LaunchCtx, const _Float16* qimg, const _Float16* kimg, const _Float16* vimg,
+                          const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
+                          const float* bo, const unsigned char* mask);
 int  conv3x_ntiles(int T, int F, int cout);
 void launch_conv3_x3(LaunchCtx, const ConvArgs&, const void* w16, int B, int time_taps, int cout);
 void launch_selftest_x3(hipStream_t, const void* a_img, const float* b_fm, float* d, int M32);

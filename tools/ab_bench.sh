@@ -4,12 +4,12 @@
 # every other round) and prints
 # ms/step plus the per-kernel table, so box-to-box clock differences cancel out.
 OUT=gpurun_out; mkdir -p $OUT
-for round in 1 2 3 4; do
+for round in $(seq 1 ${AB_ROUNDS:-4}); do
   # order alternates between rounds: the first process of a round tends to run ~1 % slower than the last
   if [ $((round % 2)) = 1 ]; then order="default $*"; else order="$(echo default "$@" | tr ' ' '\n' | tac | tr '\n' ' ')"; fi
   for v in $order; do
     if [ "$v" = default ]; then unset CMGAN_HIP_LIB; else export CMGAN_HIP_LIB=$PWD/cmgan_amd/lib/variants/$v/libcmgan_hip.so; fi
-    timeout 300 python bench.py --no-cpu-baseline --no-f32 --steps 10 --warmup 3 > $OUT/ab_${v}_$round.json 2>/dev/null
+    timeout 300 python bench.py --no-cpu-baseline --no-f32 --no-train --steps 10 --warmup 3 > $OUT/ab_${v}_$round.json 2>/dev/null
     python - "$v" "$round" "$OUT/ab_${v}_$round.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[3]))
