@@ -348,8 +348,20 @@ __device__ __forceinline__ void att_softmax(f32x4 (&s)[4], int c, int g, int j0,
     st.l += red_g_sum(psum);
 }
 
+// Operand fetches are raw buffer loads (wave-uniform descriptor in SGPRs + 32-bit lane offset + scalar block offset):
+// no 64-bit VGPR address arithmetic per fetch.  The distance table is read from its four-plane image (kernels.h:
+// rel_planes; plane g = lane group g's slice, rows in reversed distance order), so the 16 consecutive distances of an
+// operand block are 256 contiguous bytes per lane group instead of a gather over 64-byte rows.
+typedef unsigned att_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t att_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f16x8 att_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
 struct AttCtx {
-    const _Float16 *qbase, *kbase, *vbase, *ebase;
+    __amdgpu_buffer_rsrc_t qr, kr, vr, er;
+    unsigned lane16, eoff;            // lane * 16 bytes; g * plane bytes
     float *RA, *RB;
     int qoff1, qoff2, nblk16, Lb, Lb2, L, max_pos, c, g;
     const unsigned char* mk;          // this sequence's attention mask row (MASK variants only)
@@ -367,26 +379,26 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
     for (int jb = 0; jb < 4; ++jb) {
         int kb = (j0 >> 4) + jb;
         if (!FULL) kb = kb < a.nblk16 ? kb : a.nblk16 - 1;
-        kf[jb] = *reinterpret_cast<const f16x8*>(a.kbase + (long)kb * 512);
+        kf[jb] = att_ld(a.kr, a.lane16, (unsigned)kb * 1024u);
     }
 #pragma unroll
     for (int mp = 0; mp < 2; ++mp) {
         int pr = (j0 >> 5) + mp;
         if (!FULL) pr = pr < a.Lb2 ? pr : a.Lb2 - 1;
-        vh[mp] = *reinterpret_cast<const f16x8*>(a.vbase + (long)pr * 1024);
-        vl[mp] = *reinterpret_cast<const f16x8*>(a.vbase + (long)pr * 1024 + 512);
+        vh[mp] = att_ld(a.vr, a.lane16, (unsigned)pr * 2048u);
+        vl[mp] = att_ld(a.vr, a.lane16 + 1024u, (unsigned)pr * 2048u);
     }
 #pragma unroll
     for (int pair = 0; pair < ATT_NQ / 2; ++pair) {
         const int ibA = ibb + 2 * pair;
         if (ibA >= a.Lb) break;
         const int qB = ibA + 1 < a.Lb ? ibA + 1 : a.Lb - 1;
-        const f16x8 qA1 = *reinterpret_cast<const f16x8*>(a.qbase + ibA * 512 + a.qoff1);
-        const f16x8 qA2 = *reinterpret_cast<const f16x8*>(a.qbase + ibA * 512 + a.qoff2);
+        const f16x8 qA1 = att_ld(a.qr, (unsigned)a.qoff1 * 2u, (unsigned)ibA * 1024u);
+        const f16x8 qA2 = att_ld(a.qr, (unsigned)a.qoff2 * 2u, (unsigned)ibA * 1024u);
         f16x8 qB1 = qA1, qB2 = qA2;
         if (HASB) {
-            qB1 = *reinterpret_cast<const f16x8*>(a.qbase + qB * 512 + a.qoff1);
-            qB2 = *reinterpret_cast<const f16x8*>(a.qbase + qB * 512 + a.qoff2);
+            qB1 = att_ld(a.qr, (unsigned)a.qoff1 * 2u, (unsigned)qB * 1024u);
+            qB2 = att_ld(a.qr, (unsigned)a.qoff2 * 2u, (unsigned)qB * 1024u);
         }
         // relative-position window of the pair: 6 row blocks starting at rminA = 16 ibA - j0 - 63;
         // block A uses window blocks 0..4 as its cb 0..4, block B (16 queries later) blocks 1..5
@@ -394,9 +406,9 @@ __device__ __forceinline__ void att_chunk(const AttCtx& a, int ibb, int j0, AttS
         const int rminA = ibA * 16 - j0 - 63;
 #pragma unroll
         for (int we = 0; we < 6; ++we) {
-            int rl = rminA + 16 * we + c;
-            rl = rl < -a.max_pos ? -a.max_pos : (rl > a.max_pos ? a.max_pos : rl);
-            ef[we] = *reinterpret_cast<const f16x8*>(a.ebase + (long)(rl + a.max_pos) * 32);
+            int rw = a.max_pos - (rminA + 16 * we + c);                    // row of the reversed-order planes
+            rw = rw < 0 ? 0 : (rw > 2 * a.max_pos ? 2 * a.max_pos : rw);
+            ef[we] = att_ld(a.er, (unsigned)rw * 16u + a.eoff, 0);
         }
         AttState& sa = st[2 * pair];
         AttState& sb = st[2 * pair + 1];
@@ -470,23 +482,25 @@ __global__ __launch_bounds__(256, ATT_WAVES) void attn_x3_kernel(QkvOut io, cons
                                                          long total) {
     __shared__ float rbuf[4][2][80 * RSTRIDE_X + 4];   // +4: keeps RA/RB 1604 dwords apart, which no ds_read2* form can span, so each skew read
                                                        // lands directly in its accumulator register (paired A/B reads cost a v_mov per value)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Workgroup b runs on XCD b % 8 (each XCD has its own L2).  The query-block waves of one (sequence, head)
     // read the same K / V images, so every XCD walks a CONTIGUOUS range of work items: the grid is a multiple
     // of 8 blocks and block b takes logical block (b % 8) * (grid / 8) + b / 8.
     const long lblk = XCD_ORDER ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
     const long item = lblk * 4 + wv;
     if (item >= total) return;                            // no block-level synchronisation below
-    const long nh = item / nqg;
-    const int ibb = (int)(item % nqg) * ATT_NQ;           // first query block of this wave
+    const int nh = __builtin_amdgcn_readfirstlane((int)((unsigned)item / (unsigned)nqg));   // wave-uniform: SGPR bases
+    const int ibb = ((int)item - nh * nqg) * ATT_NQ;      // first query block of this wave
     AttCtx a;
     a.c = lane & 15; a.g = lane >> 4;
     a.RA = rbuf[wv][0]; a.RB = rbuf[wv][1];
     a.nblk16 = 2 * Lb2; a.Lb = Lb; a.Lb2 = Lb2; a.L = L; a.max_pos = max_pos;
-    a.qbase = io.qimg + nh * a.nblk16 * 512;
-    a.kbase = io.kimg + nh * a.nblk16 * 512 + lane * 8;
-    a.vbase = io.vimg + nh * Lb2 * 1024 + lane * 8;
-    a.ebase = eimg + a.g * 8;
+    a.qr = att_rsrc(io.qimg + (long)nh * a.nblk16 * 512, (unsigned)a.nblk16 * 1024u);
+    a.kr = att_rsrc(io.kimg + (long)nh * a.nblk16 * 512, (unsigned)a.nblk16 * 1024u);
+    a.vr = att_rsrc(io.vimg + (long)nh * Lb2 * 1024, (unsigned)Lb2 * 2048u);
+    a.er = att_rsrc(eimg, (unsigned)(2 * max_pos + 1) * 64u);
+    a.lane16 = (unsigned)lane * 16u;
+    a.eoff = (unsigned)a.g * (unsigned)(2 * max_pos + 1) * 16u;
     a.qoff1 = ((a.g & 1) * 16 + a.c) * 8; a.qoff2 = ((2 + (a.g & 1)) * 16 + a.c) * 8;
     a.mk = nullptr;
 
@@ -526,21 +540,25 @@ __global__ __launch_bounds__(256, ATT_WAVES) void attn_out_x3_kernel(QkvOut io, 
                                                              const float* __restrict__ bo, int Lb2, int nqg,
                                                              long nblocks, const unsigned char* __restrict__ mask) {
     __shared__ __attribute__((aligned(16))) float rbuf[4][2][80 * RSTRIDE_X + 4];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long lblk = XCD_ORDER ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
     if (lblk >= nblocks) return;                          // padding blocks of the rounded-up grid (block-uniform)
-    const int n = (int)(lblk / nqg);
-    const int ibb = (int)(lblk - (long)n * nqg) * ATT_NQ; // first query block of the pair
+    // (the division runs on the VALU; readfirstlane returns the - uniform - quotient to an SGPR so that every base
+    // derived from it stays scalar)
+    const int n = __builtin_amdgcn_readfirstlane((int)((unsigned)lblk / (unsigned)nqg));
+    const int ibb = ((int)lblk - n * nqg) * ATT_NQ;       // first query block of the pair
     const long nh = (long)n * 4 + wv;                     // this wave's head
     const int L = m.L, Lb = m.Lb;
     AttCtx a;
     a.c = lane & 15; a.g = lane >> 4;
     a.RA = rbuf[wv][0]; a.RB = rbuf[wv][1];
     a.nblk16 = 2 * Lb2; a.Lb = Lb; a.Lb2 = Lb2; a.L = L; a.max_pos = max_pos;
-    a.qbase = io.qimg + nh * a.nblk16 * 512;
-    a.kbase = io.kimg + nh * a.nblk16 * 512 + lane * 8;
-    a.vbase = io.vimg + nh * Lb2 * 1024 + lane * 8;
-    a.ebase = eimg + a.g * 8;
+    a.qr = att_rsrc(io.qimg + nh * a.nblk16 * 512, (unsigned)a.nblk16 * 1024u);
+    a.kr = att_rsrc(io.kimg + nh * a.nblk16 * 512, (unsigned)a.nblk16 * 1024u);
+    a.vr = att_rsrc(io.vimg + nh * Lb2 * 1024, (unsigned)Lb2 * 2048u);
+    a.er = att_rsrc(eimg, (unsigned)(2 * max_pos + 1) * 64u);
+    a.lane16 = (unsigned)lane * 16u;
+    a.eoff = (unsigned)a.g * (unsigned)(2 * max_pos + 1) * 16u;
     a.qoff1 = ((a.g & 1) * 16 + a.c) * 8; a.qoff2 = ((2 + (a.g & 1)) * 16 + a.c) * 8;
     a.mk = MASK ? mask + (long)n * L : nullptr;
 
@@ -1038,17 +1056,17 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
         const long nb = (long)N * nqg;
         const unsigned agrid = XCD_ORDER ? (unsigned)(((nb + 7) / 8) * 8) : (unsigned)nb;
         if (mask)
-            LAUNCH(ctx, "attn_out", (attn_out_x3_kernel<true><<<agrid, 256, 0, s>>>(io, w16.rel_img, w.max_pos, b.xb, seq, w16.wo,
+            LAUNCH(ctx, "attn_out", (attn_out_x3_kernel<true><<<agrid, 256, 0, s>>>(io, w16.rel_planes, w.max_pos, b.xb, seq, w16.wo,
                                                                                   w.bo, Lb2, nqg, nb, mask)));
         else
-            LAUNCH(ctx, "attn_out", (attn_out_x3_kernel<false><<<agrid, 256, 0, s>>>(io, w16.rel_img, w.max_pos, b.xb, seq, w16.wo,
+            LAUNCH(ctx, "attn_out", (attn_out_x3_kernel<false><<<agrid, 256, 0, s>>>(io, w16.rel_planes, w.max_pos, b.xb, seq, w16.wo,
                                                                                    w.bo, Lb2, nqg, nb, nullptr)));
     }
 #else
         const long waves = (long)N * 4 * nqg;
         const unsigned ablk = (unsigned)((waves + 3) / 4);
         LAUNCH(ctx, "attn", (attn_x3_kernel<<<XCD_ORDER ? ((ablk + 7) / 8) * 8 : ablk, 256, 0, s>>>(
-                                io, w16.rel_img, w.max_pos, b.o, seq.L, seq.Lb, Lb2, nqg, waves)));
+                                io, w16.rel_planes, w.max_pos, b.o, seq.L, seq.Lb, Lb2, nqg, waves)));
     }
     const int otiles = (seq.nblocks + XNTB - 1) / XNTB;
     LAUNCH(ctx, "outproj", (outproj_x3_kernel<<<persistent_grid(otiles, 2), 512, 0, s>>>(b.xb, seq, b.o, w16.wo,
