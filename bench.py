@@ -232,10 +232,11 @@ def load_pmc_traffic(x3: bool, sh: Shape, workload: str):
     return None, None, why
 
 
-def train_leg(eng, sd, dev, rank, world, barrier, batch=4, cut_len=32000, steps=3):
-    """One data-parallel adversarial training step per rank (cmgan_amd.training.adversarial_train_step: generator on
-    RI + magnitude + time + GAN loss, metric discriminator on given PESQ labels; per step TWO gradient all-reduces over
-    the flat buckets - 7.3 MB generator, 0.7 MB discriminator - and two AdamW launches).  Timed like the main leg:
+def train_leg(eng, sd, dev, rank, world, barrier, batch=32, cut_len=32000, steps=5):
+    """BASELINE configs[2] at its own size: "batch=256 x 2 s clips data-parallel across 8 GPUs" = 32 clips per GPU and
+    step.  One data-parallel adversarial training step per rank (cmgan_amd.training.adversarial_train_step: generator
+    on RI + magnitude + time + GAN loss, metric discriminator on given PESQ labels; per step TWO gradient all-reduces
+    over the flat buckets - 7.3 MB generator, 0.7 MB discriminator - and two AdamW launches).  Timed like the main leg:
     barrier + synchronize on both sides, MAX over ranks.  Any failure is reported in the line instead of losing it."""
     # phase 1 - no collectives: build both networks on every rank, then agree (one MIN all-reduce) that all of them
     # succeeded before any rank enters a step with gradient all-reduces, so a rank-local failure cannot strand the others
@@ -260,6 +261,7 @@ def train_leg(eng, sd, dev, rank, world, barrier, batch=4, cut_len=32000, steps=
     if float(ready) < 1.0:
         return {"error": err or "another rank failed to set the training leg up"}
     try:
+        torch.cuda.reset_peak_memory_stats(dev)
         run()
         torch.cuda.synchronize()
         barrier()
@@ -274,13 +276,61 @@ def train_leg(eng, sd, dev, rank, world, barrier, batch=4, cut_len=32000, steps=
         ms = 1e3 * float(dt) / steps
         return {"workload": f"configs[2]: adversarial train step, {batch} x {cut_len / 16000:g} s clips per GPU, dropout on, "
                             "TSCNet(64,201) + Discriminator(16) random-init, synthetic PESQ labels",
-                "batch_per_gpu": batch, "steps": steps, "ms_per_step": round(ms, 2),
+                "batch_per_gpu": batch, "global_batch": batch * world, "steps": steps, "ms_per_step": round(ms, 2),
                 "clips_per_s": round(batch * world / (ms * 1e-3), 2), "dtype": "f32 (fp32 MFMA training kernels)",
+                "peak_device_GB": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
                 "collectives_per_step": "2 all-reduces over flat buckets (generator %.1f MB, discriminator %.1f MB)"
                                         % (gen.grad_bucket.numel * 4 / 2**20, disc.grad_bucket.numel * 4 / 2**20),
                 "loss": round(float(loss), 4), "gen_loss_GAN": round(float(gan), 4), "disc_loss": round(float(loss_d), 4)}
     except Exception as e:                                      # noqa: BLE001 - the headline line must survive
         return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def stream_leg(model, dev, reps=5):
+    """BASELINE configs[4]: one 10 s 16 kHz clip as 400-frame windows (40 000 samples + 4 000 samples of recomputed
+    context on each side, cmgan_amd.streaming.enhance_windows) replayed from ONE captured hipGraph.  The network has
+    no exact state carry (InstanceNorm over the window and bidirectional attention), so the
+    contract is per window and the context is recomputed."""
+    from cmgan_amd.streaming import enhance_windows
+    from cmgan_amd.synth import synthetic_clips
+    noisy = synthetic_clips(1, 160000, seed=3).to(dev)
+    out = {}
+    for name, kw in (("windows_per_replay_1", dict(batch=1)), ("windows_per_replay_4", dict(batch=4)),
+                     ("windows_per_replay_1_no_lookahead", dict(batch=1, lookahead=0))):
+        fn = lambda: enhance_windows(model, noisy, 40000, 4000, graph=True, **kw)
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out[name] = {"ms_per_10s_clip": round(1e3 * dt, 3), "frames_per_s": round(1601 / dt, 1),
+                     "real_time_factor": round(10.0 / dt, 1)}
+    return {"workload": "configs[4]: 10 s 16 kHz clip, 400-frame windows (W = 40000 samples, context 4000 each side, "
+                        "recomputed - no exact state carry exists for this network), one hipGraph per window shape",
+            "results": out}
+
+
+def workload_48k_leg(dev, mfma_mode, steps=5):
+    """BASELINE configs[3]: the 48 kHz super-wideband variant (n_fft 1200, F = 601) at batch 8, wav -> wav."""
+    from cmgan_amd import TSCNet
+    from cmgan_amd.synth import make_state_dict, synthetic_clips
+    sh = Shape(WORKLOADS["48k"])
+    m = TSCNet(64, sh.F, n_fft=sh.n_fft, hop=sh.hop, device=dev, mfma_mode=mfma_mode)
+    m.load_state_dict(make_state_dict(seed=0, num_features=sh.F)).eval()
+    wav = synthetic_clips(sh.B, sh.L, seed=7).to(dev)
+    for _ in range(2):
+        m.engine.enhance_graphed(wav)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m.engine.enhance_graphed(wav)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"workload": WORKLOADS["48k"]["name"], "ms_per_step": round(1e3 * dt, 3), "steps": steps,
+            "value": round(sh.B * sh.T / dt, 1), "unit": "frames/s", "frames_per_clip": sh.T, "launch": "hipGraph replay"}
 
 
 def main():
@@ -293,8 +343,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the bit-exact fp32-MFMA mode leg of the line")
     ap.add_argument("--no-train", action="store_true",
-                    help="skip the training-step leg (BASELINE configs[2]: one adversarial train step per rank at the "
-                         "reference's batch 4 with the gradient all-reduces over the flat buckets)")
+                    help="skip the training-step leg (BASELINE configs[2]: adversarial train steps at 32 clips per GPU "
+                         "with the gradient all-reduces over the flat buckets)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the configs[3] (48 kHz) and configs[4] (10 s clip in 400-frame windows) legs of the line")
+    ap.add_argument("--train-batch", type=int, default=32, help="clips per GPU of the training-step leg (configs[2]: 32)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--mfma-mode", choices=["f16x3", "f32"], default="f16x3",
                     help="f16x3: fp32-accurate 3-term split products on the f16 matrix pipe (default); "
@@ -480,9 +533,20 @@ def main():
                                                                      FP32_MFMA_PEAK_TF, 4),
                                 "roofline": roof32}
             del m32, e32
-        # ---- BASELINE configs[2]: the reference's training step (train.py:173-205), batch 4 per GPU, data parallel ----
+        # ---- BASELINE configs[4] and [3] in the same line (N = 1 only; each takes about a second) ----------------
+        if world == 1 and x3 and args.workload == "16k" and not args.no_extra:
+            for key, fn in (("stream_config5", lambda: stream_leg(model, dev)),
+                            ("workload_48k", lambda: workload_48k_leg(dev, args.mfma_mode))):
+                try:
+                    line[key] = fn()
+                except Exception as e:                          # noqa: BLE001 - the headline line must survive
+                    line[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.empty_cache()
+        # ---- BASELINE configs[2]: the reference's training step (train.py:173-205), 32 clips per GPU, data parallel ----
         if not args.no_train and args.workload == "16k" and x3:
-            tr = train_leg(eng, sd, dev, rank, world, barrier)
+            eng._graphs.clear()                                 # the inference graphs' workspace is not needed any more
+            torch.cuda.empty_cache()
+            tr = train_leg(eng, sd, dev, rank, world, barrier, batch=args.train_batch)
             if rank == 0:
                 line["train_step"] = tr
         if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1904,10 +1904,21 @@ __global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, c
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
         stg4(out + 4 * i, ldg4(a + 4 * i) + ldg4(b + 4 * i));
 }
+// acc += b: the accumulate form (out == a).  Its own kernel because add_kernel promises the compiler that its three
+// pointers do not alias (__restrict__), which an in-place call would break.
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* acc, const float* __restrict__ b, long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+        stg4(acc + 4 * i, ldg4(acc + 4 * i) + ldg4(b + 4 * i));
+}
 void launch_add(LaunchCtx ctx, const float* a, const float* b, float* out, long n) {
     const long n4 = n / 4, want = (n4 + 255) / 256;
-    LAUNCH(ctx, "residual_add", (add_kernel<<<(unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096), 256, 0, ctx.stream>>>(
-                                    a, b, out, n4)));
+    const unsigned grid = (unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096);
+    if (a == out)
+        LAUNCH(ctx, "residual_add", (add_inplace_kernel<<<grid, 256, 0, ctx.stream>>>(out, b, n4)));
+    else if (b == out)
+        LAUNCH(ctx, "residual_add", (add_inplace_kernel<<<grid, 256, 0, ctx.stream>>>(out, a, n4)));
+    else
+        LAUNCH(ctx, "residual_add", (add_kernel<<<grid, 256, 0, ctx.stream>>>(a, b, out, n4)));
 }
 
 __global__ __launch_bounds__(256) void ln_train_fwd_kernel(const float* __restrict__ x, long M,

@@ -99,3 +99,34 @@ def allreduce_mean(flat: torch.Tensor) -> torch.Tensor:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat /= dist.get_world_size()
     return flat
+
+
+def _multi() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def broadcast_from_rank0(tensors) -> None:
+    """In-place broadcast of rank 0's values: what DistributedDataParallel does with the parameters AND buffers at
+    construction (src/train.py:68-69) and, with `broadcast_buffers=True` (its default), with the buffers before every
+    forward.  `tensors`: a tensor or an iterable of tensors; identity in a single process."""
+    if not _multi():
+        return
+    if isinstance(tensors, torch.Tensor):
+        tensors = [tensors]
+    for t in tensors:
+        dist.broadcast(t, src=0)
+
+
+def all_agree(flag: bool, device="cpu") -> bool:
+    """True only if `flag` is true on EVERY rank (one MIN all-reduce of a single element).  Used to decide collectively
+    whether a step that contains collectives runs: a rank-local decision (e.g. 'PESQ returned no labels here', the
+    reference's src/train.py:194) would let one rank skip an all-reduce the others enter."""
+    if not _multi():
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
+def get_rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0

@@ -58,7 +58,7 @@ import torch
 
 from ._lib import (AttnParams, ConvModParams, DecoderParams, DenseParams, DiscParams, EncoderParams, FfnParams,
                    check)
-from .dist import FlatBucket, allreduce_mean
+from .dist import FlatBucket, all_agree, allreduce_mean, broadcast_from_rank0, get_rank
 from .engine import Engine
 
 __all__ = ["Trainer", "batch_pesq", "GraphedTrainStep", "DiscriminatorTrain", "adversarial_train_step", "GeneratorTrain", "generator_train_step", "DenseEncoderTrain", "DecoderTrain", "DenseBlockTrain", "TSCBTrain", "ConformerBlockTrain", "FeedForwardTrain", "ConvModuleTrain", "AttentionTrain", "AdamW", "step_lr", "generator_loss_terms", "dropout_mask", "forward_generator_step",
@@ -1162,20 +1162,11 @@ class DiscriminatorTrain:
         return allreduce_mean(self.grad_bucket.flat)
 
 
-def adversarial_train_step(gen: GeneratorTrain, disc: DiscriminatorTrain, opt_g: "AdamW", opt_d: "AdamW",
-                           clean: torch.Tensor, noisy: torch.Tensor, pesq_score: Optional[torch.Tensor],
-                           loss_weights=(0.1, 0.9, 0.2, 0.05), generator: Optional[torch.Generator] = None,
-                           masks="draw", disc_masks="draw", lr: Optional[float] = None, update: bool = True):
-    """Trainer.train_step (train.py:173-205): the generator step on the FULL loss (train.py:124-151: RI, magnitude,
-    time and 0.05 x metric-discriminator terms), then the discriminator step (train.py:153-171) on `pesq_score`
-    [B] = (PESQ - 1) / 3.5 of (clean, est_audio) - the labels discriminator.batch_pesq computes on the CPU; None (a
-    silent clip made PESQ fail) skips the discriminator update like the reference; a callable
-    `pesq_score(clean [B, La], est_audio [B, La]) -> tensor | None` is evaluated where the reference calls batch_pesq
-    (after the generator update).  Returns
-    (generator loss, float32[4] terms, gen_loss_GAN, discriminator loss or None) of this rank before the updates.
-    `update=False` leaves both gradient buckets filled and skips the all-reduces and optimiser launches; note that the
-    reference updates the generator BEFORE the discriminator forwards, which does not change the discriminator's
-    inputs (est is detached), so deferring both updates gives the same gradients."""
+def _adversarial_generator_half(gen: GeneratorTrain, disc: DiscriminatorTrain, clean: torch.Tensor, noisy: torch.Tensor,
+                                loss_weights, generator, masks, disc_masks):
+    """train.py:100-151, 188-190: STFTs, train-mode generator forward, the full generator loss (RI, magnitude, time and
+    the 0.05 x metric-discriminator term) and its backward.  Leaves the generator's gradient bucket filled and returns
+    (loss, terms, gan, ctx); ctx carries what the discriminator half needs (est is 'detached' there: only values)."""
     eng = gen.engine
     clean, noisy = eng._in(clean, "clean"), eng._in(noisy, "noisy")
     B = noisy.shape[0]
@@ -1208,20 +1199,58 @@ def adversarial_train_step(gen: GeneratorTrain, disc: DiscriminatorTrain, opt_g:
         check(eng._h, eng.lib.cmgan_mag_pair_backward(eng._h, est_real.data_ptr(), est_imag.data_ptr(), dxy.data_ptr(), B, T,
                                                       1.0, d_real.data_ptr(), d_imag.data_ptr(), eng._stream()))
     gen.backward(d_real, d_imag)                                              # train.py:190
+    ctx = dict(xy=xy, clean_spec=clean_spec, est_audio=est_audio, clean_cut=clean_cut, disc_masks=disc_masks)
+    return loss, terms, gan, ctx
+
+
+def _adversarial_discriminator_half(disc: DiscriminatorTrain, ctx, pesq_score: torch.Tensor):
+    """train.py:153-171, 194-199: D(clean, est.detach()) against the PESQ labels + D(clean, clean) against 1, and the
+    backward of their sum.  Leaves the discriminator's gradient bucket filled; returns the discriminator loss."""
+    dm = ctx["disc_masks"]
+    s_enh = disc.forward(ctx["xy"], dm[1], train=True, slot=0)                # D(clean, est.detach()), :163-165
+    s_max = disc.forward(disc.pair(ctx["clean_spec"]), dm[2], train=True, slot=1)   # D(clean, clean), :166-167
+    l_max, d_max = disc.score_mse(s_max, None)
+    l_enh, d_enh = disc.score_mse(s_enh, pesq_score)
+    disc.backward(d_enh, slot=0, need_input_grad=False)
+    disc.backward(d_max, slot=1, need_input_grad=False, accumulate=True)
+    return l_max + l_enh                                                      # :168-170
+
+
+def _agree_on_labels(pesq_score, device):
+    """The labels if EVERY rank has them, else None on every rank (see adversarial_train_step)."""
+    return pesq_score if all_agree(pesq_score is not None, device) else None
+
+
+def adversarial_train_step(gen: GeneratorTrain, disc: DiscriminatorTrain, opt_g: "AdamW", opt_d: "AdamW",
+                           clean: torch.Tensor, noisy: torch.Tensor, pesq_score: Optional[torch.Tensor],
+                           loss_weights=(0.1, 0.9, 0.2, 0.05), generator: Optional[torch.Generator] = None,
+                           masks="draw", disc_masks="draw", lr: Optional[float] = None, update: bool = True):
+    """Trainer.train_step (train.py:173-205): the generator step on the FULL loss (train.py:124-151: RI, magnitude,
+    time and 0.05 x metric-discriminator terms), then the discriminator step (train.py:153-171) on `pesq_score`
+    [B] = (PESQ - 1) / 3.5 of (clean, est_audio) - the labels discriminator.batch_pesq computes on the CPU; None (a
+    silent clip made PESQ fail) skips the discriminator update like the reference; a callable
+    `pesq_score(clean [B, La], est_audio [B, La]) -> tensor | None` is evaluated where the reference calls batch_pesq
+    (after the generator update).  Returns
+    (generator loss, float32[4] terms, gen_loss_GAN, discriminator loss or None) of this rank before the updates.
+    `update=False` leaves both gradient buckets filled and skips the all-reduces and optimiser launches; note that the
+    reference updates the generator BEFORE the discriminator forwards, which does not change the discriminator's
+    inputs (est is detached), so deferring both updates gives the same gradients.
+    Multi-rank: whether the discriminator step (which contains a collective) runs is decided by ALL ranks together - a
+    batch whose labels are missing on any rank is skipped on every rank (one MIN all-reduce of a flag); a rank-local
+    decision would let one rank's next generator all-reduce pair with the others' discriminator all-reduce (the
+    reference has this hazard through DDP, train.py:194-201)."""
+    eng = gen.engine
+    loss, terms, gan, ctx = _adversarial_generator_half(gen, disc, clean, noisy, loss_weights, generator, masks, disc_masks)
     if update:
         gen.allreduce_gradients()
         opt_g.step(lr)                                                        # train.py:191
     loss_d = None
     if callable(pesq_score):                                                  # discriminator.batch_pesq's place in the step
-        pesq_score = pesq_score(clean_cut, est_audio)
+        pesq_score = pesq_score(ctx["clean_cut"], ctx["est_audio"])
+    if update:
+        pesq_score = _agree_on_labels(pesq_score, eng.device)
     if pesq_score is not None:                                                # train.py:194-201
-        s_enh = disc.forward(xy, disc_masks[1], train=True, slot=0)           # D(clean, est.detach()), :163-165
-        s_max = disc.forward(disc.pair(clean_spec), disc_masks[2], train=True, slot=1)   # D(clean, clean), :166-167
-        l_max, d_max = disc.score_mse(s_max, None)
-        l_enh, d_enh = disc.score_mse(s_enh, pesq_score)
-        loss_d = l_max + l_enh                                                # :168-170
-        disc.backward(d_enh, slot=0, need_input_grad=False)
-        disc.backward(d_max, slot=1, need_input_grad=False, accumulate=True)
+        loss_d = _adversarial_discriminator_half(disc, ctx, pesq_score)
         if update:
             disc.allreduce_gradients()
             opt_d.step(None if lr is None else 2.0 * lr)                      # train.py:64-66: twice the generator's rate
@@ -1232,12 +1261,18 @@ class GraphedTrainStep:
     """A training step captured once as hipGraphs and replayed: the eager step is bound by its ~1 500 kernel launches
     (62 of 72 ms at batch 4 are spent enqueueing), a replay by the kernels.
 
-    Two graphs per step with the gradient all-reduce between them, so that the collective stays an ordinary
-    `torch.distributed` call: (A) STFTs, train-mode forward, losses, backward [+ the discriminator passes], (B) the
-    AdamW launches.  Inputs are copied into static buffers; dropout masks are drawn INSIDE graph A from torch's default
-    CUDA generator (graph-safe Philox offsets), so every replay sees fresh masks.  `dropout=False` captures the step
-    without dropout (deterministic: used by the parity test against the eager step).  With a discriminator the step is
-    `adversarial_train_step` and needs PESQ labels at every call."""
+    The collectives and the host-side PESQ stay OUTSIDE the graphs, in the reference's order (train.py:173-205):
+      graph A1  STFTs, train-mode generator forward, the full generator loss incl. the D(clean, est) term, backward
+      -> generator gradient all-reduce, graph B_g (generator AdamW)
+      -> PESQ labels of THIS step's est_audio: `pesq_score` may be a tensor or - like `adversarial_train_step` - a
+         callable `fn(clean_cut, est_audio)` evaluated here, after A1 has produced est_audio (the reference computes the
+         labels from the current forward, train.py:156-162); None / a failed batch on ANY rank skips the rest
+      graph A2  the two discriminator forwards + backward on those labels
+      -> discriminator gradient all-reduce, graph B_d (discriminator AdamW).
+    Inputs are copied into static buffers; dropout masks are drawn INSIDE the graphs from torch's default CUDA generator
+    (graph-safe Philox offsets), so every replay sees fresh masks.  `dropout=False` captures the step without dropout
+    (deterministic: used by the parity test against the eager step).  Without a discriminator the step is
+    `generator_train_step` (graph A1 + B_g)."""
 
     def __init__(self, gen: GeneratorTrain, opt_g: AdamW, batch: int, length: int, disc: Optional[DiscriminatorTrain] = None,
                  opt_d: Optional[AdamW] = None, loss_weights=(0.1, 0.9, 0.2, 0.05), dropout: bool = True):
@@ -1255,36 +1290,47 @@ class GraphedTrainStep:
         masks = "draw" if dropout else None
         torch.cuda.synchronize(dev)
         self.graph_a, self.graph_b = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        opts = [o for o in (opt_g, opt_d) if o is not None]
-        with torch.cuda.graph(self.graph_a):                            # ends where the all-reduces / optimisers start
+        self.graph_a2 = self.graph_bd = None
+        self._ctx = None
+        with torch.cuda.graph(self.graph_a):                            # ends where the all-reduce / optimiser starts
             if disc is None:
                 self.out = generator_train_step(gen, opt_g, self.clean, self.noisy, w3, masks=masks, update=False)
             else:
-                self.out = adversarial_train_step(gen, disc, opt_g, opt_d, self.clean, self.noisy, self.pesq,
-                                                  loss_weights, masks=masks, disc_masks=masks, update=False)
+                loss, terms, gan, self._ctx = _adversarial_generator_half(gen, disc, self.clean, self.noisy, loss_weights,
+                                                                          None, masks, masks)
+                self.out = (loss, terms, gan)
         with torch.cuda.graph(self.graph_b):
-            for o in opts:
-                o.step()
+            opt_g.step()
+        if disc is not None:
+            self.graph_a2, self.graph_bd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_a2):
+                self.loss_d = _adversarial_discriminator_half(disc, self._ctx, self.pesq)
+            with torch.cuda.graph(self.graph_bd):
+                opt_d.step()
         # capturing executes nothing: the BatchNorm update counters advanced by the traced forward are rolled back
         for c in self._convs:
             c.num_batches_tracked -= 1
 
-    def __call__(self, clean: torch.Tensor, noisy: torch.Tensor, pesq_score: Optional[torch.Tensor] = None):
+    def __call__(self, clean: torch.Tensor, noisy: torch.Tensor, pesq_score=None):
         self.clean.copy_(clean)
         self.noisy.copy_(noisy)
-        if self.disc is not None:
-            if pesq_score is None:
-                raise ValueError("the captured adversarial step needs PESQ labels; use adversarial_train_step for a "
-                                 "batch whose PESQ failed")
-            self.pesq.copy_(pesq_score)
         self.graph_a.replay()
         for c in self._convs:
             c.num_batches_tracked += 1
         self.gen.allreduce_gradients()
-        if self.disc is not None:
-            self.disc.allreduce_gradients()
         self.graph_b.replay()
-        return self.out
+        if self.disc is None:
+            return self.out
+        if callable(pesq_score):                                        # labels of THIS step's est_audio
+            pesq_score = pesq_score(self._ctx["clean_cut"], self._ctx["est_audio"])
+        pesq_score = _agree_on_labels(pesq_score, self.gen.engine.device)
+        if pesq_score is None:
+            return (*self.out, None)
+        self.pesq.copy_(pesq_score)
+        self.graph_a2.replay()
+        self.disc.allreduce_gradients()
+        self.graph_bd.replay()
+        return (*self.out, self.loss_d)
 
 
 def batch_pesq(clean: torch.Tensor, est: torch.Tensor, sr: int = 16000) -> Optional[torch.Tensor]:
@@ -1327,6 +1373,10 @@ class Trainer:
         self.init_lr, self.decay_epoch, self.loss_weights = init_lr, decay_epoch, tuple(loss_weights)
         self.pesq_fn, self.log_interval, self.log = pesq_fn, log_interval, log
         self.epoch = 0
+        # DistributedDataParallel's start-up semantics (train.py:68-69): every rank continues from rank 0's parameters
+        # and buffers, whatever state dict it was handed
+        broadcast_from_rank0([self.gen.param_bucket.flat, self.disc.param_bucket.flat])
+        self.sync_buffers()
         # eval-mode twin of the generator for test(): the inference path on the CURRENT parameters
         self._eval_model = TSCNet(64, eng.cfg.num_features, n_fft=n_fft, hop=hop, device=eng.device)
 
@@ -1334,9 +1384,26 @@ class Trainer:
         from .data import DevicePrefetcher
         return DevicePrefetcher(loader, self.engine.device)
 
+    def buffers(self) -> list:
+        """Every non-parameter state tensor of the two networks: the BatchNorm1d running statistics of the sixteen
+        conv modules and the power-iteration vectors of the six spectral norms."""
+        out = []
+        for blk in self.gen.blocks:
+            for c in (blk.time, blk.freq):
+                out += [c.conv.running_mean, c.conv.running_var]
+        out += [self.disc.buffers[k] for k in sorted(self.disc.buffers)]
+        return out
+
+    def sync_buffers(self):
+        """DDP(broadcast_buffers=True) - the reference's setting, train.py:68-69 - overwrites every rank's buffers with
+        rank 0's before each forward, so the spectral-norm u / v (hence the effective discriminator weights W / sigma)
+        and the running statistics are the same on all ranks.  ~20 small broadcasts; identity in a single process."""
+        broadcast_from_rank0(self.buffers())
+
     def train_step(self, clean: torch.Tensor, noisy: torch.Tensor) -> Tuple[float, float]:
         """train.py:173-205: (generator loss, discriminator loss or 0.0 when PESQ gave no labels)."""
         lr = step_lr(self.epoch, self.init_lr, self.decay_epoch)
+        self.sync_buffers()
         loss, _, _, loss_d = adversarial_train_step(self.gen, self.disc, self.optimizer, self.optimizer_disc, clean, noisy,
                                                     self.pesq_fn, self.loss_weights, lr=lr)
         return float(loss), (float(loss_d) if loss_d is not None else 0.0)
@@ -1373,9 +1440,12 @@ class Trainer:
         self.log(f"GPU: {self.engine.device}, Generator loss: {gen_total / steps}, Discriminator loss: {disc_total / steps}")
         return gen_total / steps
 
-    def train(self, epochs: int, save_model_dir: Optional[str] = None, rank: int = 0) -> list:
-        """train.py:247-275.  Returns the per-epoch validation losses; rank 0 writes the generator checkpoints."""
+    def train(self, epochs: int, save_model_dir: Optional[str] = None, rank: Optional[int] = None) -> list:
+        """train.py:247-275.  Returns the per-epoch validation losses; rank 0 (of the initialised process group unless
+        `rank` is given, like the reference's `gpu_id == 0`) writes the generator checkpoints."""
         import os
+        if rank is None:
+            rank = get_rank()
         history = []
         for _ in range(epochs):
             for idx, (clean, noisy, _) in enumerate(self._batches(self.train_ds)):

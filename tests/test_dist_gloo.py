@@ -101,3 +101,48 @@ def test_flat_gradient_bucket_is_averaged_with_one_allreduce():
     assert b.numel == 32 and b.flat[:3].tolist() == [0, 1, 2] and b.flat[16:20].tolist() == [1, 1, 1, 1]
     assert float(b.flat.sum()) == 7.0 and b["b"].data_ptr() - b["a"].data_ptr() == 64
     assert torch.equal(cdist.allreduce_mean(b.flat), b.flat)
+
+
+def _ddp_semantics_worker(rank, world, port, ret):
+    """The collective schedule of Trainer.train_step over three steps when PESQ fails on rank 1 only in step 1
+    (src/train.py:173-205 under DDP): start-up broadcast of parameters and buffers, per-step buffer broadcast, generator
+    gradient all-reduce, the labels-present agreement, discriminator gradient all-reduce."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    cdist.init_from_env("gloo")
+    from cmgan_amd.training import _agree_on_labels
+    gen_p = cdist.FlatBucket({"w": (1000, 64)})             # stand-ins of different sizes, like 7.3 MB vs 0.7 MB
+    disc_p = cdist.FlatBucket({"w": (300,)})
+    gen_g, disc_g = cdist.FlatBucket({"w": (1000, 64)}), cdist.FlatBucket({"w": (300,)})
+    buffers = [torch.full((128,), float(rank + 5)), torch.full((16,), float(rank - 3))]
+    gen_p.flat.fill_(float(rank + 1))                       # every rank was handed a DIFFERENT state dict
+    disc_p.flat.fill_(float(10 * rank + 2))
+    cdist.broadcast_from_rank0([gen_p.flat, disc_p.flat])   # Trainer.__init__
+    cdist.broadcast_from_rank0(buffers)
+    ok = float(gen_p.flat[0]) == 1.0 and float(disc_p.flat[7]) == 2.0 and float(buffers[0][3]) == 5.0
+    disc_steps = 0
+    for step in range(3):
+        buffers[0] += rank                                  # running statistics drift apart between steps ...
+        cdist.broadcast_from_rank0(buffers)                 # ... and are re-synchronised before the forward
+        ok = ok and float(buffers[0][0]) == 5.0
+        gen_g.flat.fill_(float(rank + step))
+        cdist.allreduce_mean(gen_g.flat)
+        ok = ok and abs(float(gen_g.flat[0]) - (step + 0.5)) < 1e-6
+        labels = None if (rank == 1 and step == 1) else torch.ones(4)
+        labels = _agree_on_labels(labels, "cpu")            # without it rank 0 would enter the 300-float all-reduce
+        if labels is not None:                              # while rank 1 is already in the next 64 000-float one
+            disc_g.flat.fill_(float(rank))
+            cdist.allreduce_mean(disc_g.flat)
+            ok = ok and abs(float(disc_g.flat[0]) - 0.5) < 1e-6
+            disc_steps += 1
+    ret[rank] = (ok, disc_steps, cdist.get_rank())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_trainer_collective_schedule_with_a_one_sided_pesq_failure():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ddp_semantics_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[0] == (True, 2, 0) and ret[1] == (True, 2, 1)       # step 1's discriminator update skipped on BOTH ranks
+    assert cdist.all_agree(True) is True and cdist.all_agree(False) is False and cdist.get_rank() == 0

@@ -770,6 +770,22 @@ def test_graphed_train_step_is_bit_identical_to_the_eager_step():
     assert torch.equal(disc.param_bucket.flat, disc2.param_bucket.flat)
     assert float(want[0]) == float(got[0]) and float(want[3]) == float(got[3])
     assert og2.t == 2 and od2.t == 2 and gen2.blocks[3].freq.conv.num_batches_tracked == 102
+    # labels computed by a callable from THIS step's est_audio, where the reference calls batch_pesq (train.py:156-162):
+    # the eager step and the replay (graph A1 -> host callable -> graph A2) see the same audio and agree bit for bit;
+    # a step whose labels are missing updates the generator only
+    seen = []
+
+    def labels(clean_cut, est_audio):
+        seen.append(float(est_audio.abs().sum()))
+        return torch.sigmoid(est_audio.abs().mean(1) * 40.0)
+    want3 = adversarial_train_step(gen, disc, og, od, clean, noisy, labels, masks=None, disc_masks=None)
+    got3 = step(clean, noisy, labels)
+    assert seen[0] == seen[1] and float(want3[3]) == float(got3[3])
+    assert torch.equal(gen.param_bucket.flat, gen2.param_bucket.flat)
+    assert torch.equal(disc.param_bucket.flat, disc2.param_bucket.flat)
+    before = disc2.param_bucket.flat.clone()
+    got4 = step(clean, noisy, None)
+    assert got4[3] is None and od2.t == 3 and og2.t == 4 and torch.equal(before, disc2.param_bucket.flat)
     # masks drawn inside the graph differ from replay to replay
     step_d = GraphedTrainStep(gen2, og2, B, L, disc2, od2)
     l1 = float(step_d(clean, noisy, pesq)[0])
