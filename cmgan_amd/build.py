@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcmgan_hip.so")
 SOURCES = ["api.hip", "api_train.hip", "conformer.hip", "conformer_x3.hip", "attn32_x3.hip", "conv.hip", "conv_x3.hip",
-           "stft.hip", "train.hip", "disc.hip"]
+           "stft.hip", "train.hip", "train_x3.hip", "disc.hip"]
 HEADERS = ["common.hip.h", "kernels.h", "weights.h", "api_internal.h", "train.h",
            os.path.join("..", "..", "include", "cmgan_hip.h")]
 # the generator FORWARD path: what bench.py measures and what the PMC evidence under profiles/ was collected on.  The

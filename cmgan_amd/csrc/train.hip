@@ -575,6 +575,28 @@ static void colsum_batch(LaunchCtx ctx, const char* label, const ColsumJobs& job
     LAUNCH(ctx, label, (colsum_multi_reduce_kernel<<<dim3(4, njobs), 1024, 0, ctx.stream>>>(jobs, cpart)));
 }
 
+#ifndef TRAIN_X3
+#define TRAIN_X3 1          // 1: FeedForward forward / backward and the token-contraction weight gradients on split-f16
+#endif                      //    products (train_x3.hip); 0: the fp32-MFMA kernels of this file
+// train_x3.hip
+void ffn_x3_pack(LaunchCtx, const FfnTrainParams& p, float* img);
+void ffn_x3_forward(LaunchCtx, const float* x, long M, const FfnTrainParams& p, const float* img, const unsigned char* m1,
+                    const unsigned char* m2, float ms, const float* res, float* y);
+void ffn_x3_backward(LaunchCtx, const float* x, const float* dy, long M, const FfnTrainParams& p, const float* img,
+                     const unsigned char* m1, const unsigned char* m2, float ms, const float* dres, float* dx, float* o_dz,
+                     float* o_d1, float* o_dh, float* o_xn, float* o_g1, float* o_dxn, float* dhmax);
+void launch_wgrad_partial64_x3(LaunchCtx, const char* label, const float* P, const float* Q, long M, int R, int C,
+                               float* partial, int nsplit);
+// the token-contraction weight gradient in either mode: grid (R / 64, C / 64, nsplit)
+static void wgrad_partial64(LaunchCtx ctx, const char* label, const float* P, const float* Q, long M, int R, int C,
+                            float* partial, int nsplit) {
+#if TRAIN_X3
+    launch_wgrad_partial64_x3(ctx, label, P, Q, M, R, C, partial, nsplit);
+#else
+    LAUNCH(ctx, label, (wgrad_partial64_kernel<<<dim3(R / 64, C / 64, nsplit), 256, 0, ctx.stream>>>(P, Q, M, R, C, partial)));
+#endif
+}
+
 // pack = false: the images the forward of the SAME parameters left in the workspace are reused (backward passes)
 static FfnTrainImg ffn_pack_images(LaunchCtx ctx, const FfnTrainParams& p, float* img, bool pack = true) {
     hipStream_t s = ctx.stream;
@@ -594,9 +616,14 @@ size_t ffn_train_ws_floats(long M) {
 
 void launch_ffn_train_forward(LaunchCtx ctx, const float* x, long M, const FfnTrainParams& p, const unsigned char* m1,
                               const unsigned char* m2, float ms, const float* res, float* y, float* ws) {
+#if TRAIN_X3
+    ffn_x3_pack(ctx, p, ws);
+    ffn_x3_forward(ctx, x, M, p, ws, m1, m2, ms, res, y);
+#else
     const FfnTrainImg w = ffn_pack_images(ctx, p, ws);
     const unsigned grid = (unsigned)((M + 63) / 64);
     LAUNCH(ctx, "ffn_train_fwd", (ffn_train_fwd_kernel<<<grid, 256, 0, ctx.stream>>>(x, M, w, m1, m2, ms, res, y)));
+#endif
 }
 
 void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, long M, const FfnTrainParams& p,
@@ -608,12 +635,17 @@ void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, l
     FfnBwdBufs o{act, act + M * 64, act + M * 320, act + M * 576, act + M * 640, act + M * 704};
     float* part = act + M * 768;                                  // [SPLIT][16384] x 2, then colsum slabs
     float* cpart = part + (size_t)WG_SPLIT * 16384 * 2;
+#if TRAIN_X3
+    (void)w;
+    ffn_x3_backward(ctx, x, dy, M, p, ws, m1, m2, ms, dres, dx, o.dz, o.d1, o.dh, o.xn, o.g1, o.dxn,
+                    cpart);                                       // per-tile |dh| maxima: the column-sum slabs are free until colsum_batch
+#else
     const unsigned grid = (unsigned)((M + 63) / 64);
     LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_kernel<<<grid, 256, 0, s>>>(x, dy, M, w, m1, m2, ms, dres, dx, o)));
+#endif
     // dW2 [64,256] = dz^T d1 ; dW1 [256,64] = dh^T xn
-    LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 4, wg_split(4)), 256, 0, s>>>(o.dz, o.d1, M, 64, 256, part)));
-    LAUNCH(ctx, "ffn_train_wgrad", (wgrad_partial64_kernel<<<dim3(4, 1, wg_split(4)), 256, 0, s>>>(o.dh, o.xn, M, 256, 64,
-                                                                                              part + (size_t)WG_SPLIT * 16384)));
+    wgrad_partial64(ctx, "ffn_train_wgrad", o.dz, o.d1, M, 64, 256, part, wg_split(4));
+    wgrad_partial64(ctx, "ffn_train_wgrad", o.dh, o.xn, M, 256, 64, part + (size_t)WG_SPLIT * 16384, wg_split(4));
     LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part, wg_split(4), 16384, grad.w2)));
     LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part + (size_t)WG_SPLIT * 16384, wg_split(4), 16384,
                                                                                  grad.w1)));
@@ -1115,8 +1147,7 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     LAUNCH(ctx, "convmod_train_bwd", (cm_bwd1_kernel<<<grid, 256, 0, s>>>(dy, ws + pl.d, M, st, im.w2t, ws + pl.ddn,
                                                                           ws + pl.s, ws + pl.g2)));
     // pointwise-2 gradients: dW_pw2 [64,128] = dy^T s, db_pw2 = colsum dy
-    LAUNCH(ctx, "convmod_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 2, wg_split(2)), 256, 0, s>>>(dy, ws + pl.s, M, 64, 128,
-                                                                                                  ws + pl.wpart)));
+    wgrad_partial64(ctx, "convmod_train_wgrad", dy, ws + pl.s, M, 64, 128, ws + pl.wpart, wg_split(2));
     LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<128, 1024, 0, s>>>(ws + pl.wpart, wg_split(2), 8192,
                                                                                    grad.pw2_w)));
     // BatchNorm: dbeta = sum ddn, dgamma = sum ddn dhat; then dd in place   (+ db_pw2 = colsum dy in the same pair of launches)
@@ -1141,8 +1172,7 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
                                                                           ws + pl.dag, ws + pl.xn, ws + pl.g1,
                                                                           ws + pl.dxn)));
     // pointwise-1 and LayerNorm gradients
-    LAUNCH(ctx, "convmod_train_wgrad", (wgrad_partial64_kernel<<<dim3(4, 1, wg_split(4)), 256, 0, s>>>(ws + pl.dag, ws + pl.xn, M, 256,
-                                                                                                  64, ws + pl.wpart)));
+    wgrad_partial64(ctx, "convmod_train_wgrad", ws + pl.dag, ws + pl.xn, M, 256, 64, ws + pl.wpart, wg_split(4));
     LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(ws + pl.wpart, wg_split(4), 16384,
                                                                                    grad.pw1_w)));
     const ColsumJobs jobs{{ws + pl.dag, ws + pl.g1, ws + pl.dxn}, {grad.pw1_b, grad.ln_w, grad.ln_b}, {256, 64, 64}};
@@ -1860,8 +1890,7 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     LAUNCH(ctx, "attn_train_bwd", (at_out_bwd_kernel<<<grid, 256, 0, s>>>(dy, mask, ms, b.o, M, ws + pl.wot, ws + pl.dout,
                                                                           ws + pl.dO, ws + pl.D)));
     // to_out gradients: dWo [64,64] = dout^T O, dbo = colsum dout
-    LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial64_kernel<<<dim3(1, 1, wg_split(1)), 256, 0, s>>>(ws + pl.dout, b.o, M, 64, 64,
-                                                                                               ws + pl.wpart)));
+    wgrad_partial64(ctx, "attn_train_wgrad", ws + pl.dout, b.o, M, 64, 64, ws + pl.wpart, wg_split(1));
     LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<64, 1024, 0, s>>>(ws + pl.wpart, wg_split(1), 4096,
                                                                                 grad.wo)));
     // attention core: dq (query blocks), dk / dv (key blocks), dE (tile diagonals)
@@ -1885,8 +1914,7 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     // projections + LayerNorm
     LAUNCH(ctx, "attn_train_bwd", (at_qkv_bwd_kernel<<<grid, 256, 0, s>>>(x, ws + pl.dqkv, M, ws + pl.wqkvt, p.ln_w, p.ln_b,
                                                                           dres, dx, ws + pl.xn, ws + pl.g1, ws + pl.dxn)));
-    LAUNCH(ctx, "attn_train_wgrad", (wgrad_partial64_kernel<<<dim3(3, 1, wg_split(3)), 256, 0, s>>>(ws + pl.dqkv, ws + pl.xn, M, 192,
-                                                                                               64, ws + pl.wpart)));
+    wgrad_partial64(ctx, "attn_train_wgrad", ws + pl.dqkv, ws + pl.xn, M, 192, 64, ws + pl.wpart, wg_split(3));
     LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<192, 1024, 0, s>>>(ws + pl.wpart, wg_split(3), 12288,
                                                                                 ws + pl.raw)));      // [192,64], then split
     hipMemcpyAsync(grad.wq, ws + pl.raw, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);

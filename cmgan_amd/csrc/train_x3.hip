@@ -1,0 +1,578 @@
+// train_x3.hip - the training-mode FeedForward and the token-contraction weight gradient on the f16 matrix pipe with
+// 3-term split products (common.hip.h "x3": hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_f16, fp32 accumulation, ~2^-21
+// per product) instead of v_mfma_f32_16x16x4_f32, which runs at 1/16 of that pipe's rate.  Same mathematics, same
+// C ABI, same workspace layout as the fp32 kernels of train.hip (kept there; -DTRAIN_X3=0 selects them).
+//
+//   forward    y = res + 0.5 m2 (W2 (m1 Swish(W1 LN(x) + b1)) + b2)          conformer.py:54-72,136-148,211
+//   backward   dz = 0.5 m2 dy;  dd1 = W2^T dz;  dh = m1 dd1 Swish'(h);  dxn = W1^T dh;  LayerNorm backward
+//   wgrad      dW[i][j] = sum_m P[m][i] Q[m][j]  (token contraction, split-K partial slabs)
+//
+// Structure follows the inference kernel ffn_x3_kernel (conformer_x3.hip): persistent 768-thread blocks with the
+// weight images resident in LDS (the fp32 training kernels streamed 8 KB of weight fragments per token from L1 / L2),
+// two 16-token blocks per wave, the per-token chain in registers.  The backward is two kernels because its three
+// weight images (W1, W2^T, W1^T: 192 KB) do not fit one CU's LDS: A holds W1 and W2^T (h recompute, dd1, d1 / dh
+// stores), B holds W1^T (dxn, LayerNorm backward); dh [M,256] is written by A anyway (the W1 gradient contracts it).
+#include "kernels.h"
+#include "train.h"
+
+#define TX_WAVES 12
+
+// row-major W [R, K] (leading dimension ldw; transpose = 1: the image of W^T) -> x3 A-operand image
+// [R/16][K/32][hi | lo][64 lanes][8 halfs]: lane (c, g) slot e <-> W[16 rb + c][32 m + 16 (e >> 2) + 4 g + (e & 3)]
+struct PackX3Job { const float* w; int R, K, ldw, transpose; _Float16* out; };
+struct PackX3Jobs { PackX3Job j[4]; };
+__global__ void pack_x3_kernel(PackX3Jobs jobs) {
+    const PackX3Job& q = jobs.j[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (rb, m, lane)
+    const int M32 = q.K / 32;
+    if (i >= (q.R / 16) * M32 * 64) return;
+    const int lane = i & 63, blk = i >> 6, rb = blk / M32, m = blk - rb * M32;
+    const int row = 16 * rb + (lane & 15);
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int col = 32 * m + 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);
+        const float v = q.transpose ? q.w[(long)col * q.ldw + row] : q.w[(long)row * q.ldw + col];
+        const _Float16 h = (_Float16)v;
+        hi[e] = h;
+        lo[e] = (_Float16)(v - (float)h);
+    }
+    _Float16* o = q.out + (long)blk * 1024 + lane * 8;
+    *reinterpret_cast<f16x8*>(o) = hi;
+    *reinterpret_cast<f16x8*>(o + 512) = lo;
+}
+void launch_pack_x3(LaunchCtx ctx, const char* label, const PackX3Jobs& jobs, int njobs) {
+    int most = 0;
+    for (int k = 0; k < njobs; ++k) {
+        const int n = (jobs.j[k].R / 16) * (jobs.j[k].K / 32) * 64;
+        most = n > most ? n : most;
+    }
+    LAUNCH(ctx, label, (pack_x3_kernel<<<dim3((most + 255) / 256, njobs), 256, 0, ctx.stream>>>(jobs)));
+}
+
+__device__ __forceinline__ unsigned tx_mask_word(const unsigned char* __restrict__ m, long idx) {   // idx % 4 == 0
+    return *reinterpret_cast<const unsigned*>(m + idx);
+}
+__device__ __forceinline__ f32x4 tx_mask4(unsigned v, float ms) {
+    f32x4 r;
+    r[0] = (v & 0x000000ffu) ? ms : 0.f;
+    r[1] = (v & 0x0000ff00u) ? ms : 0.f;
+    r[2] = (v & 0x00ff0000u) ? ms : 0.f;
+    r[3] = (v & 0xff000000u) ? ms : 0.f;
+    return r;
+}
+
+// ---- exact power-of-two operand scaling ------------------------------------------------------------------------------
+// The fp16 split represents magnitudes between ~2^-24 and 65504.  Activations of this network live there; GRADIENTS
+// do not (dL/dy of a mean loss is ~1 / numel): their lo halves would flush to zero and a product would keep 11 bits.
+// Every gradient operand is therefore multiplied by an exact power of two that brings the largest magnitude of its
+// tile (per-token kernels) or of the running contraction (weight gradient) to [1, 2), and the result is multiplied by
+// the inverse - both exact, so the arithmetic is the split product of the unscaled values with unlimited range.
+__device__ __forceinline__ float tx_max_c(float v) {            // max over the 16 lanes of a DPP row
+    v = fmaxf(v, dpp_perm<0xB1>(v));
+    v = fmaxf(v, dpp_perm<0x4E>(v));
+    v = fmaxf(v, dpp_perm<0x141>(v));
+    v = fmaxf(v, dpp_perm<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float tx_wave_max(float v) { return red_g_max(tx_max_c(v)); }
+// s = 2^-e with e the binary exponent of m (m s in [1, 2)); inv = 2^e.  m = 0 (or denormal): both 1.
+__device__ __forceinline__ void tx_pow2(float m, float& s, float& inv) {
+    const unsigned e = (__float_as_uint(m) >> 23) & 0xffu;
+    const bool ok = e > 0u && e < 254u;
+    s = ok ? __uint_as_float((254u - e) << 23) : 1.0f;
+    inv = ok ? __uint_as_float(e << 23) : 1.0f;
+}
+__device__ __forceinline__ float tx_absmax4(const f32x4& v, float m) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+
+// LayerNorm of a 16-token block's rows: xh = (x - mean) rstd (returned for the backward), xn = xh gamma + beta as
+// split B operands of a K = 64 product (two k32 blocks)
+__device__ __forceinline__ void tx_load_norm(const float* __restrict__ x, long row, int g, const float* par_l,
+                                             f32x4 (&xh)[4], float& rstd, f32x4 (&xn)[4]) {
+    f32x4 xv[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) xv[kb] = ldg4(x + row * 64 + 16 * kb + 4 * g);
+    float mean;
+    ln_stats(xv, mean, rstd);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        xh[kb] = (xv[kb] - splat4(mean)) * splat4(rstd);
+        xn[kb] = xh[kb] * *reinterpret_cast<const f32x4*>(&par_l[16 * kb + 4 * g]) +
+                 *reinterpret_cast<const f32x4*>(&par_l[64 + 16 * kb + 4 * g]);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// forward.  LDS: W1 image [16][2] + W2 image [4][8] = 128 KB, gamma | beta | b1 | b2.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(TX_WAVES * 64) void ffn_train_fwd_x3_kernel(const float* __restrict__ x, long M,
+                                                                         const _Float16* __restrict__ w1i,
+                                                                         const _Float16* __restrict__ w2i,
+                                                                         FfnTrainParams p,
+                                                                         const unsigned char* __restrict__ m1,
+                                                                         const unsigned char* __restrict__ m2, float ms,
+                                                                         const float* __restrict__ res, float* __restrict__ y,
+                                                                         int ntiles) {
+    __shared__ __attribute__((aligned(16))) _Float16 wlds[65536];          // 128 KB
+    __shared__ __attribute__((aligned(16))) float par_l[448];              // gamma[64] | beta[64] | b1[256] | b2[64]
+    _Float16* w1 = wlds;
+    _Float16* w2 = wlds + 32768;
+    stage_lds16<4096, TX_WAVES * 64>(w1i, w1);
+    stage_lds16<4096, TX_WAVES * 64>(w2i, w2);
+    for (int i = threadIdx.x; i < 448; i += blockDim.x)
+        par_l[i] = i < 64 ? p.gamma[i] : (i < 128 ? p.beta[i - 64] : (i < 384 ? p.b1[i - 128] : p.b2[i - 384]));
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+
+#pragma unroll 1
+    for (int tile = blockIdx.x * TX_WAVES + wv; tile < ntiles; tile += gridDim.x * TX_WAVES) {
+        long row[2];
+        bool ok[2];
+        f16x8 xbh[2][2], xbl[2][2];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const long t = ((long)tile * 2 + tb) * 16 + c;
+            ok[tb] = t < M;
+            row[tb] = ok[tb] ? t : M - 1;
+            f32x4 xh[4], xn[4];
+            float rstd;
+            tx_load_norm(x, row[tb], g, par_l, xh, rstd, xn);
+            split8(xn[0], xn[1], xbh[tb][0], xbl[tb][0]);
+            split8(xn[2], xn[3], xbh[tb][1], xbl[tb][1]);
+        }
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) acc[tb][ob] = *reinterpret_cast<const f32x4*>(&par_l[384 + 16 * ob + 4 * g]);
+
+#pragma unroll 1
+        for (int m = 0; m < 8; ++m) {                                  // hidden units 32 m .. 32 m + 31
+            unsigned mw[2][2];
+            if (m1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int tb = 0; tb < 2; ++tb) mw[j][tb] = tx_mask_word(m1, row[tb] * 256 + 16 * (2 * m + j) + 4 * g);
+            }
+            f32x4 h[2][2];                                             // [j][tb]
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int hb = 2 * m + j;
+                const f32x4 b1v = *reinterpret_cast<const f32x4*>(&par_l[128 + 16 * hb + 4 * g]);
+                h[j][0] = b1v; h[j][1] = b1v;
+                lin_acc_x3<2, 2>(w1 + hb * 2048 + lane * 8, xbh, xbl, h[j]);
+            }
+            f16x8 sh[2], sl[2];
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 mk = m1 ? tx_mask4(mw[j][tb], ms) : splat4(1.f);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[j][tb][r] = swishf(h[j][tb][r]) * mk[r];
+                }
+                split8(h[0][tb], h[1][tb], sh[tb], sl[tb]);
+            }
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+                const _Float16* wp = w2 + (ob * 8 + m) * 1024 + lane * 8;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(wp);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(wp + 512);
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) acc[tb][ob] = mfma32h(ah, sh[tb], acc[tb][ob]);
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) acc[tb][ob] = mfma32l(ah, sl[tb], acc[tb][ob]);
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) acc[tb][ob] = mfma32l(al, sh[tb], acc[tb][ob]);
+            }
+        }
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            if (ok[tb]) {
+#pragma unroll
+                for (int ob = 0; ob < 4; ++ob) {
+                    f32x4 v = acc[tb][ob] * splat4(0.5f);
+                    if (m2) v = v * tx_mask4(tx_mask_word(m2, row[tb] * 64 + 16 * ob + 4 * g), ms);
+                    if (res) v = v + ldg4(res + row[tb] * 64 + 16 * ob + 4 * g);
+                    stg4(y + row[tb] * 64 + 16 * ob + 4 * g, v);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// backward, part A.  LDS: W1 image [16][2] (h recompute) + W2^T image [16][2] (dd1 = W2^T dz) = 128 KB.
+// Writes dz [M,64], xn [M,64], d1 = m1 Swish(h) [M,256], dh = m1 dd1 Swish'(h) [M,256].
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(TX_WAVES * 64) void ffn_train_bwd_a_x3_kernel(const float* __restrict__ x,
+                                                                           const float* __restrict__ dy, long M,
+                                                                           const _Float16* __restrict__ w1i,
+                                                                           const _Float16* __restrict__ w2ti,
+                                                                           FfnTrainParams p,
+                                                                           const unsigned char* __restrict__ m1,
+                                                                           const unsigned char* __restrict__ m2, float ms,
+                                                                           float* __restrict__ o_dz, float* __restrict__ o_xn,
+                                                                           float* __restrict__ o_d1, float* __restrict__ o_dh,
+                                                                           float* __restrict__ o_dhmax, int ntiles) {
+    __shared__ __attribute__((aligned(16))) _Float16 wlds[65536];
+    __shared__ __attribute__((aligned(16))) float par_l[448];
+    _Float16* w1 = wlds;
+    _Float16* w2t = wlds + 32768;
+    stage_lds16<4096, TX_WAVES * 64>(w1i, w1);
+    stage_lds16<4096, TX_WAVES * 64>(w2ti, w2t);
+    for (int i = threadIdx.x; i < 448; i += blockDim.x)
+        par_l[i] = i < 64 ? p.gamma[i] : (i < 128 ? p.beta[i - 64] : (i < 384 ? p.b1[i - 128] : p.b2[i - 384]));
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+
+#pragma unroll 1
+    for (int tile = blockIdx.x * TX_WAVES + wv; tile < ntiles; tile += gridDim.x * TX_WAVES) {
+        long row[2];
+        bool ok[2];
+        f16x8 xbh[2][2], xbl[2][2], zbh[2][2], zbl[2][2];
+        float zinv[2], dhmax = 0.f;                          // inverse of the tile's dz scale; largest |dh| of the tile
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const long t = ((long)tile * 2 + tb) * 16 + c;
+            ok[tb] = t < M;
+            row[tb] = ok[tb] ? t : M - 1;
+            f32x4 xh[4], xn[4], dz[4];
+            float rstd, zmax = 0.f;
+            tx_load_norm(x, row[tb], g, par_l, xh, rstd, xn);
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+                f32x4 v = ldg4(dy + row[tb] * 64 + 16 * ob + 4 * g) * splat4(0.5f);
+                if (m2) v = v * tx_mask4(tx_mask_word(m2, row[tb] * 64 + 16 * ob + 4 * g), ms);
+                if (!ok[tb]) v = splat4(0.f);               // padding tokens of the last block contribute nothing
+                dz[ob] = v;
+                zmax = tx_absmax4(v, zmax);
+                if (ok[tb]) {
+                    stg4(o_dz + row[tb] * 64 + 16 * ob + 4 * g, v);
+                    stg4(o_xn + row[tb] * 64 + 16 * ob + 4 * g, xn[ob]);
+                }
+            }
+            float zs;
+            tx_pow2(tx_wave_max(zmax), zs, zinv[tb]);       // exact power-of-two scale of this 16-token block's dz
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) dz[ob] = dz[ob] * splat4(zs);
+            split8(xn[0], xn[1], xbh[tb][0], xbl[tb][0]);
+            split8(xn[2], xn[3], xbh[tb][1], xbl[tb][1]);
+            split8(dz[0], dz[1], zbh[tb][0], zbl[tb][0]);
+            split8(dz[2], dz[3], zbh[tb][1], zbl[tb][1]);
+        }
+#pragma unroll 1
+        for (int hb = 0; hb < 16; ++hb) {
+            unsigned mw[2];
+            if (m1) {
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) mw[tb] = tx_mask_word(m1, row[tb] * 256 + 16 * hb + 4 * g);
+            }
+            const f32x4 b1v = *reinterpret_cast<const f32x4*>(&par_l[128 + 16 * hb + 4 * g]);
+            f32x4 h[2] = {b1v, b1v}, dd[2] = {splat4(0.f), splat4(0.f)};
+            lin_acc_x3<2, 2>(w1 + hb * 2048 + lane * 8, xbh, xbl, h);
+            lin_acc_x3<2, 2>(w2t + hb * 2048 + lane * 8, zbh, zbl, dd);
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const f32x4 mk = m1 ? tx_mask4(mw[tb], ms) : splat4(1.f);
+                f32x4 d1v, dhv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float hv = h[tb][r], sg = sigmoidf_fast(hv);
+                    d1v[r] = hv * sg * mk[r];
+                    dhv[r] = (dd[tb][r] * zinv[tb]) * mk[r] * (sg * (1.f + hv * (1.f - sg)));
+                }
+                dhmax = tx_absmax4(dhv, dhmax);
+                if (ok[tb]) {
+                    stg4(o_d1 + row[tb] * 256 + 16 * hb + 4 * g, d1v);
+                    stg4(o_dh + row[tb] * 256 + 16 * hb + 4 * g, dhv);
+                }
+            }
+        }
+        dhmax = tx_wave_max(dhmax);                          // part B scales this tile's dh by it
+        if (lane == 0) o_dhmax[tile] = dhmax;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// backward, part B.  LDS: W1^T image [4][8] = 64 KB.  dxn = W1^T dh, then the LayerNorm backward:
+//   dx = rstd (g dxn - mean(g dxn) - xh mean(g dxn xh)) + dres;   g1 = dxn xh, dxn -> the column sums of dgamma, dbeta
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void ffn_train_bwd_b_x3_kernel(const float* __restrict__ x, const float* __restrict__ dh,
+                                                                 const float* __restrict__ dhmax, long M,
+                                                                 const _Float16* __restrict__ w1ti,
+                                                                 FfnTrainParams p, const float* __restrict__ dres,
+                                                                 float* __restrict__ dx, float* __restrict__ o_g1,
+                                                                 float* __restrict__ o_dxn, int ntiles) {
+    __shared__ __attribute__((aligned(16))) _Float16 wlds[32768];          // 64 KB
+    __shared__ __attribute__((aligned(16))) float par_l[128];              // gamma | beta
+    stage_lds16<4096, 512>(w1ti, wlds);
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) par_l[i] = i < 64 ? p.gamma[i] : p.beta[i - 64];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+
+#pragma unroll 1
+    for (int tile = blockIdx.x * 8 + wv; tile < ntiles; tile += gridDim.x * 8) {
+        long row[2];
+        bool ok[2];
+        f32x4 dxn[2][4];
+        float hs, hinv;
+        tx_pow2(dhmax[tile], hs, hinv);                      // the tile's exact power-of-two dh scale (from part A)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const long t = ((long)tile * 2 + tb) * 16 + c;
+            ok[tb] = t < M;
+            row[tb] = ok[tb] ? t : M - 1;
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) dxn[tb][ob] = splat4(0.f);
+        }
+#pragma unroll 2
+        for (int m = 0; m < 8; ++m) {
+            f16x8 bh[2], bl[2];
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                f32x4 a = ldg4(dh + row[tb] * 256 + 32 * m + 4 * g), b = ldg4(dh + row[tb] * 256 + 32 * m + 16 + 4 * g);
+                if (!ok[tb]) { a = splat4(0.f); b = splat4(0.f); }
+                split8(a * splat4(hs), b * splat4(hs), bh[tb], bl[tb]);
+            }
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+                const _Float16* wp = wlds + (ob * 8 + m) * 1024 + lane * 8;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(wp);
+                const f16x8 al = *reinterpret_cast<const f16x8*>(wp + 512);
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) dxn[tb][ob] = mfma32h(ah, bh[tb], dxn[tb][ob]);
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) dxn[tb][ob] = mfma32l(ah, bl[tb], dxn[tb][ob]);
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) dxn[tb][ob] = mfma32l(al, bh[tb], dxn[tb][ob]);
+            }
+        }
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            f32x4 xh[4], xn[4], dxh[4];
+            float rstd;
+            tx_load_norm(x, row[tb], g, par_l, xh, rstd, xn);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) dxn[tb][kb] = dxn[tb][kb] * splat4(hinv);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                dxh[kb] = dxn[tb][kb] * *reinterpret_cast<const f32x4*>(&par_l[16 * kb + 4 * g]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s1 += dxh[kb][r];
+                    s2 = fmaf(dxh[kb][r], xh[kb][r], s2);
+                }
+            }
+            const float mu1 = red_g_sum(s1) * (1.0f / 64.0f), mu2 = red_g_sum(s2) * (1.0f / 64.0f);
+            if (ok[tb]) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    f32x4 dv = (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd);
+                    if (dres) dv = dv + ldg4(dres + row[tb] * 64 + 16 * kb + 4 * g);
+                    stg4(dx + row[tb] * 64 + 16 * kb + 4 * g, dv);
+                    stg4(o_g1 + row[tb] * 64 + 16 * kb + 4 * g, dxn[tb][kb] * xh[kb]);
+                    stg4(o_dxn + row[tb] * 64 + 16 * kb + 4 * g, dxn[tb][kb]);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// out_partial[s][i][j] = sum over the s-th token range of P[m][i] Q[m][j]  (P [M,R], Q [M,C] row-major fp32): the
+// token-contraction weight gradient of wgrad_partial64_kernel (train.hip) with split products.  A wave-step is 32
+// tokens: lane (c, g) feeds slot e of the contraction with token 8 g + e, i.e. eight dwords of one column of P
+// (resp. Q) per 16-wide block, split to fp16 hi / lo in registers; 16 output tiles x 3 products = 48 MFMAs per step
+// instead of 128 fp32 ones.  Same 64 x 64 tile per block, same fixed-order LDS combine, same slab layout.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wgrad_partial64_x3_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                                 long M, int R, int C, float* __restrict__ partial) {
+    __shared__ float red[2][64 * 64];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ic = blockIdx.x, jc = blockIdx.y, s = blockIdx.z;
+    const int nsplit = gridDim.z;
+    const long full = M / 32, per = (full + nsplit - 1) / nsplit;            // full 32-row steps, dealt to the splits
+    const long st0 = (long)s * per, st1 = st0 + per < full ? st0 + per : full;
+    f32x4 acc[4][4];                                  // [ib][jb]
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = splat4(0.f);
+    const unsigned oa = (unsigned)(8 * g * R + 64 * ic + c), ob = (unsigned)(8 * g * C + 64 * jc + c);
+    struct Raw { f32x4 a[4][2], b[4][2]; };           // [block][e >> 2][e & 3]: token 8 g + e of the step (64 dwords)
+    struct Ops { f16x8 ah[4], al[4], bh[4], bl[4]; }; // the same step as split operands (64 registers)
+    auto load = [&](long st, Raw& t) {
+        const float* __restrict__ pa = P + st * 32 * R + oa;             // uniform base + lane offset
+        const float* __restrict__ qa = Q + st * 32 * C + ob;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) t.a[ib][e >> 2][e & 3] = pa[e * R + 16 * ib];
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) t.b[jb][e >> 2][e & 3] = qa[e * C + 16 * jb];
+        }
+    };
+    auto split = [&](const Raw& t, Ops& o) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            split8(t.a[k][0], t.a[k][1], o.ah[k], o.al[k]);
+            split8(t.b[k][0], t.b[k][1], o.bh[k], o.bl[k]);
+        }
+    };
+    auto mma = [&](const Ops& o) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma32h(o.ah[ib], o.bh[jb], acc[ib][jb]);
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma32l(o.ah[ib], o.bl[jb], acc[ib][jb]);
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma32l(o.al[ib], o.bh[jb], acc[ib][jb]);
+        }
+    };
+    // P is a gradient (unbounded below: ~1 / numel), Q an activation (bounded): P is multiplied by an exact power of two
+    // sP kept - like the stale softmax reference of the attention kernels - in a band around the running magnitude of
+    // this wave's steps: a step whose largest |P| leaves [2^-2, 2^13] / sP re-references (sP from that step, the
+    // accumulators rescaled by the exact ratio; wave-uniform and rare); the final sums are multiplied by 1 / sP.
+    float sP = 1.f, iP = 1.f;
+    bool fresh = true;
+    auto rescale = [&](Raw& t) {
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m = tx_absmax4(t.a[k][1], tx_absmax4(t.a[k][0], m));
+        m = tx_wave_max(m);
+        const float ms_ = m * sP;
+        if (m > 0.f && (fresh || ms_ > 8192.f || ms_ < 0.25f)) {           // wave-uniform
+            float s2, i2;
+            tx_pow2(m, s2, i2);
+            const float ratio = s2 * iP;                                   // exact: both are powers of two
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = acc[ib][jb] * splat4(ratio);
+            sP = s2; iP = i2; fresh = false;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            t.a[k][0] = t.a[k][0] * splat4(sP);
+            t.a[k][1] = t.a[k][1] * splat4(sP);
+        }
+    };
+    // the 64 operand dwords of the next step are in flight while the 48 MFMAs of the current one run
+    Raw raw;
+    Ops ops;
+    long st = st0 + wv;
+    if (st < st1) {
+        load(st, raw);
+        rescale(raw);
+        split(raw, ops);
+    }
+    while (st < st1) {
+        const long sn = st + 4;
+        if (sn < st1) load(sn, raw);
+        mma(ops);
+        if (sn < st1) {
+            rescale(raw);
+            split(raw, ops);
+        }
+        st = sn;
+    }
+    if ((M & 31) && s == nsplit - 1 && wv == 0) {   // the one ragged step of the tensor: rows past M contribute zeros
+        const float* __restrict__ pa = P + full * 32 * R + oa;
+        const float* __restrict__ qa = Q + full * 32 * C + ob;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool okr = full * 32 + 8 * g + e < M;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) raw.a[ib][e >> 2][e & 3] = okr ? pa[e * R + 16 * ib] : 0.f;
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) raw.b[jb][e >> 2][e & 3] = okr ? qa[e * C + 16 * jb] : 0.f;
+        }
+        rescale(raw);
+        split(raw, ops);
+        mma(ops);
+    }
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = acc[ib][jb] * splat4(iP);
+    // (wave 2 + wave 0), (wave 3 + wave 1), then (wave 1 + wave 0): element (row 16 ib + 4 g + r, col 16 jb + c)
+    auto put = [&](float* dst) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(16 * ib + 4 * g + r) * 64 + 16 * jb + c] = acc[ib][jb][r];
+    };
+    auto add = [&](const float* src) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ib][jb][r] += src[(16 * ib + 4 * g + r) * 64 + 16 * jb + c];
+    };
+    if (wv >= 2) put(red[wv - 2]);
+    __syncthreads();
+    if (wv < 2) add(red[wv]);
+    __syncthreads();
+    if (wv == 1) put(red[0]);
+    __syncthreads();
+    if (wv == 0) {
+        add(red[0]);
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    partial[((long)s * R + 64 * ic + 16 * ib + 4 * g + r) * C + 64 * jc + 16 * jb + c] = acc[ib][jb][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// host side (called from train.hip's launch_ffn_train_* when TRAIN_X3 is on)
+// ---------------------------------------------------------------------------------
+static int tx_grid(int ntiles, int waves) {
+    const int want = (ntiles + waves - 1) / waves;
+    return want < 256 ? (want > 0 ? want : 1) : 256;
+}
+
+// images live where the fp32 fragment images did: four 64 KB slots at the head of the module's workspace
+void ffn_x3_pack(LaunchCtx ctx, const FfnTrainParams& p, float* img) {
+    _Float16* h = reinterpret_cast<_Float16*>(img);
+    launch_pack_x3(ctx, "ffn_train_pack", PackX3Jobs{{{p.w1, 256, 64, 64, 0, h},                 // rows = hidden
+                                                      {p.w2, 64, 256, 256, 0, h + 32768},        // rows = out
+                                                      {p.w2, 256, 64, 256, 1, h + 2 * 32768},    // W2^T: rows = hidden
+                                                      {p.w1, 64, 256, 64, 1, h + 3 * 32768}}},   // W1^T: rows = in
+                   4);
+}
+void ffn_x3_forward(LaunchCtx ctx, const float* x, long M, const FfnTrainParams& p, const float* img,
+                    const unsigned char* m1, const unsigned char* m2, float ms, const float* res, float* y) {
+    const _Float16* h = reinterpret_cast<const _Float16*>(img);
+    const int ntiles = (int)((M + 31) / 32);
+    LAUNCH(ctx, "ffn_train_fwd", (ffn_train_fwd_x3_kernel<<<tx_grid(ntiles, TX_WAVES), TX_WAVES * 64, 0, ctx.stream>>>(
+                                     x, M, h, h + 32768, p, m1, m2, ms, res, y, ntiles)));
+}
+// dhmax: scratch of ceil(M / 32) floats (one per tile), written by part A and read by part B
+void ffn_x3_backward(LaunchCtx ctx, const float* x, const float* dy, long M, const FfnTrainParams& p, const float* img,
+                     const unsigned char* m1, const unsigned char* m2, float ms, const float* dres, float* dx,
+                     float* o_dz, float* o_d1, float* o_dh, float* o_xn, float* o_g1, float* o_dxn, float* dhmax) {
+    const _Float16* h = reinterpret_cast<const _Float16*>(img);
+    const int ntiles = (int)((M + 31) / 32);
+    LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_a_x3_kernel<<<tx_grid(ntiles, TX_WAVES), TX_WAVES * 64, 0, ctx.stream>>>(
+                                     x, dy, M, h, h + 2 * 32768, p, m1, m2, ms, o_dz, o_xn, o_d1, o_dh, dhmax, ntiles)));
+    const int gridb = (ntiles + 7) / 8 < 512 ? ((ntiles + 7) / 8 > 0 ? (ntiles + 7) / 8 : 1) : 512;
+    LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_b_x3_kernel<<<gridb, 512, 0, ctx.stream>>>(
+                                     x, o_dh, dhmax, M, h + 3 * 32768, p, dres, dx, o_g1, o_dxn, ntiles)));
+}
+void launch_wgrad_partial64_x3(LaunchCtx ctx, const char* label, const float* P, const float* Q, long M, int R, int C,
+                               float* partial, int nsplit) {
+    LAUNCH(ctx, label, (wgrad_partial64_x3_kernel<<<dim3(R / 64, C / 64, nsplit), 256, 0, ctx.stream>>>(P, Q, M, R, C, partial)));
+}

@@ -72,6 +72,30 @@ def test_feed_forward_train_ragged_token_count_and_determinism(ff):
     assert torch.equal(dx, dx2) and all(torch.equal(first[k], grads2[k]) for k in KEYS)
 
 
+def test_feed_forward_backward_is_exactly_scale_equivariant(ff):
+    """Gradients arrive with any magnitude (dL/dy of a mean loss is ~1 / numel), far below what an fp16 split can
+    represent.  The split-product kernels therefore scale every gradient operand by an exact power of two (per tile /
+    per running contraction, train_x3.hip), so the backward of 2^-40 dy must be BIT-IDENTICAL to 2^-40 times the
+    backward of dy - input gradient and all six parameter gradients - including across a re-reference of the weight
+    gradient's running scale (the second half of the tokens is 2^24 times larger than the first)."""
+    rng = np.random.Generator(np.random.PCG64(15))
+    x = torch.from_numpy(rng.standard_normal((1000, 64)).astype(np.float32)).to(DEV)
+    dy = torch.from_numpy(rng.standard_normal((1000, 64)).astype(np.float32)).to(DEV)
+    dy[500:] *= 2.0 ** 24
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    m1, m2 = ff.masks(1000, gen)
+    ff.forward(x, m1, m2)
+    dx, grads = ff.backward(x, dy, m1, m2)
+    ref = {k: v.clone() for k, v in grads.items()}
+    dx = dx.clone()
+    k2 = 2.0 ** -40
+    dx_s, grads_s = ff.backward(x, dy * k2, m1, m2)
+    assert torch.isfinite(dx_s).all() and float(dx_s.abs().max()) > 0
+    assert torch.equal(dx_s, dx * k2)
+    for k in KEYS:
+        assert torch.equal(grads_s[k], ref[k] * k2), k
+
+
 def test_eval_arithmetic_of_the_train_kernel_matches_the_inference_path(ff):
     """masks = None is the eval forward: 0.5 FF(LN(x)) must agree with the oracle's eval feed_forward."""
     csd = conformer_state_dict(seed=3)
@@ -174,7 +198,12 @@ def test_three_adamw_steps_of_the_feed_forward_branch_match_torch():
             torch.mean((yr - tgt) ** 2).backward()
         ref_opt.step()
     for k in KEYS:
-        assert _report(f"param {k} after 3 AdamW steps", rel_err(ffm.params[k], leaf["ff1." + k].detach())) < 1e-5, k
+        # Adam divides every gradient element by its own running magnitude, so an absolute gradient error of 1e-6 of the
+        # tensor's maximum (the split-f16 products: 2^-21 each) becomes a RELATIVE update error of 1e-3 on an element
+        # whose gradient is a thousand times below that maximum: 3 steps x lr 5e-4 x 1e-3 = 1.5e-6 absolute, i.e. 1e-5
+        # of the largest parameter (the fp32-MFMA build, -DTRAIN_X3=0, sits at 1e-6 here).  The second bar - the update
+        # itself is resolved to 2 % - is unchanged.
+        assert _report(f"param {k} after 3 AdamW steps", rel_err(ffm.params[k], leaf["ff1." + k].detach())) < 5e-5, k
         # the update itself (3 x lr = 1.5e-3 per element at most) is resolved, not just the unchanged bulk
         moved = (leaf["ff1." + k].detach() - csd["ff1." + k]).abs().max()
         assert float((ffm.params[k].cpu() - leaf["ff1." + k].detach()).abs().max()) < 2e-2 * float(moved), k
