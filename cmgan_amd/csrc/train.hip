@@ -2406,22 +2406,69 @@ size_t dense_train_ws_floats(int B, int T, int F) { return db_plan(B, T, F).tota
 static int db_img_index(int i, int s) { return 6 * (i * (i + 1) / 2 + s); }
 
 // all 6 (i+1) tap images of layer i, plain (blockIdx.z = 0) and transposed (1), in one launch
-__global__ void db_pack_layer_kernel(const float* __restrict__ w, int i, float* __restrict__ img, float* __restrict__ imgT) {
+__global__ void db_pack_layer_kernel(const float* __restrict__ w, int i, float* __restrict__ img, float* __restrict__ imgT,
+                                     int zbase = 0) {       // zbase = 1 with gridDim.z = 1: the transposed images only
     const int e = blockIdx.x * blockDim.x + threadIdx.x;          // element of one 64x64 image
     if (e >= 4096) return;
     const int st = blockIdx.y, s = st / 6, tap = st - 6 * s, Cin = 64 * (i + 1);
     const int cbase = 64 * (i - s);                                 // newest-first concat: slot s sits at channel block i - s
     const int r = e & 3, lane = (e >> 2) & 63, blk = e >> 8, rb = blk >> 2, kb = blk & 3;
     const int row = 16 * rb + (lane & 15), col = 16 * kb + 4 * (lane >> 4) + r;
-    const int co = blockIdx.z ? col : row, ci = blockIdx.z ? row : col;
+    const int tr = blockIdx.z + zbase;
+    const int co = tr ? col : row, ci = tr ? row : col;
     const float v = w[((long)co * Cin + cbase + ci) * 6 + tap];
-    (blockIdx.z ? imgT : img)[(long)st * 4096 + e] = v;
+    (tr ? imgT : img)[(long)st * 4096 + e] = v;
 }
 
-static void db_pack_images(LaunchCtx ctx, const DenseTrainParams& p, float* ws, const DbPlan& pl, bool pack = true) {
+#if TRAIN_X3
+// The forward convolution of the training step IS the inference kernel (conv3x_kernel<2, 64>, conv_x3.hip: 256-position
+// tiles staged through LDS, split-f16 products): the training plane layout, the causal time taps and the raw output
+// are the same; only the operand image has to be rebuilt from the raw weight after every optimiser step.
+// x3 conv image of layer i: [32-channel chunk in SLOT order][tap = kt * 3 + kf][4 cb][hi | lo][64][8 halfs], lane (c, g)
+// slot e <-> w[co = 16 cb + c][slot-order channel 32 chunk + 16 (e >> 2) + 4 g + (e & 3)][tap]   (api.hip: x3_conv_image)
+__global__ void db_pack_x3_layer_kernel(const float* __restrict__ w, int i, _Float16* __restrict__ img) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;          // (chunk, tap, cb, lane)
+    const int nch = 2 * (i + 1), Cin = 64 * (i + 1);
+    if (t >= nch * 6 * 4 * 64) return;
+    const int lane = t & 63, cb = (t >> 6) & 3, rest = t >> 8, tap = rest % 6, chunk = rest / 6;
+    const int co = 16 * cb + (lane & 15), s = chunk >> 1;
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int cs = 32 * (chunk & 1) + 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);       // channel inside slot s
+        const float v = w[((long)co * Cin + 64 * (i - s) + cs) * 6 + tap];                 // newest-first concat order
+        const _Float16 h = (_Float16)v;
+        hi[e] = h;
+        lo[e] = (_Float16)(v - (float)h);
+    }
+    _Float16* o = img + ((long)(chunk * 6 + tap) * 4 + cb) * 1024 + lane * 8;
+    *reinterpret_cast<f16x8*>(o) = hi;
+    *reinterpret_cast<f16x8*>(o + 512) = lo;
+}
+// halfs offset of layer i's x3 image inside the (re-used) fp32 image area: 2 (i + 1) * 6 * 4 * 1024 halfs per layer
+static long db_x3_img_off(int i) { return (long)(i * (i + 1)) * 24576; }
+#endif
+
+// the inference conv kernel steps its staging rows by 64 per load and assumes a plane row (F + 1 positions with the
+// virtual zero column) is at least that long: true for every model size (F = 201 / 101 / 601 / 301); tiny test planes
+// take the per-position fp32 kernel
+static bool db_x3_forward(int F) { return TRAIN_X3 && F + 1 >= 64; }
+
+static void db_pack_images(LaunchCtx ctx, const DenseTrainParams& p, float* ws, const DbPlan& pl, int F, bool pack = true) {
     if (!pack) return;
     for (int i = 0; i < 4; ++i) {
         const long off = (long)db_img_index(i, 0) * 4096;
+#if TRAIN_X3
+        if (db_x3_forward(F)) {
+            // forward images in split-f16 form (exactly the space of the fp32 ones); transposed fp32 images for dgrad
+            LAUNCH(ctx, "dense_train_pack", (db_pack_layer_kernel<<<dim3(16, 6 * (i + 1), 1), 256, 0, ctx.stream>>>(
+                                                p.conv_w[i], i, nullptr, ws + pl.imgT + off, 1)));
+            const int nthr = 2 * (i + 1) * 6 * 4 * 64;
+            LAUNCH(ctx, "dense_train_pack", (db_pack_x3_layer_kernel<<<(nthr + 255) / 256, 256, 0, ctx.stream>>>(
+                                                p.conv_w[i], i, reinterpret_cast<_Float16*>(ws + pl.img) + db_x3_img_off(i))));
+            continue;
+        }
+#endif
         LAUNCH(ctx, "dense_train_pack", (db_pack_layer_kernel<<<dim3(16, 6 * (i + 1), 2), 256, 0, ctx.stream>>>(
                                             p.conv_w[i], i, ws + pl.img + off, ws + pl.imgT + off)));
     }
@@ -2441,19 +2488,32 @@ void launch_dense_train_forward(LaunchCtx ctx, const float* x, int B, int T, int
     const DbPlan pl = db_plan(B, T, F);
     const long M = (long)B * T * F;
     const int P = T * F;
-    db_pack_images(ctx, p, ws, pl);
+    db_pack_images(ctx, p, ws, pl, F);
     DbSlots in{};
     in.p[0] = x;
     for (int i = 0; i < 4; ++i) {
         float* z = ws + pl.z + (size_t)i * M * 64;
         float* a = i == 3 ? y : ws + pl.a + (size_t)i * M * 64;
-        const float* wimg = ws + pl.img + (long)db_img_index(i, 0) * 4096;
         const int dil = 1 << i;
-        switch (i) {
-            case 0: db_launch_conv<1>(ctx, in, wimg, p.conv_b[i], B, T, F, dil, z); break;
-            case 1: db_launch_conv<2>(ctx, in, wimg, p.conv_b[i], B, T, F, dil, z); break;
-            case 2: db_launch_conv<3>(ctx, in, wimg, p.conv_b[i], B, T, F, dil, z); break;
-            default: db_launch_conv<4>(ctx, in, wimg, p.conv_b[i], B, T, F, dil, z); break;
+#if TRAIN_X3
+        if (db_x3_forward(F)) {
+            ConvArgs ca{};                                  // slots arrive normalised + activated (or raw: slot 0): identity on load
+            for (int sl = 0; sl <= i; ++sl) ca.in[sl] = in.p[sl];
+            ca.nslots = i + 1;
+            ca.bias = p.conv_b[i];
+            ca.out = z;
+            ca.T = T; ca.F = F; ca.dil = dil; ca.mode = 0; ca.ntiles = conv3x_ntiles(T, F, 64);
+            launch_conv3_x3(ctx, ca, reinterpret_cast<const _Float16*>(ws + pl.img) + db_x3_img_off(i), B, 2, 64);
+        } else
+#endif
+        {
+            const float* wimg = ws + pl.img + (long)db_img_index(i, 0) * 4096;
+            switch (i) {
+                case 0: db_launch_conv<1>(ctx, in, wimg, p.conv_b[i], B, T, F, dil, z); break;
+                case 1: db_launch_conv<2>(ctx, in, wimg, p.conv_b[i], B, T, F, dil, z); break;
+                case 2: db_launch_conv<3>(ctx, in, wimg, p.conv_b[i], B, T, F, dil, z); break;
+                default: db_launch_conv<4>(ctx, in, wimg, p.conv_b[i], B, T, F, dil, z); break;
+            }
         }
         float* mean = ws + pl.mean + (size_t)i * B * 64;
         float* rstd = ws + pl.rstd + (size_t)i * B * 64;
@@ -2474,7 +2534,7 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
     const DbPlan pl = db_plan(B, T, F);
     const long M = (long)B * T * F;
     const int P = T * F;
-    db_pack_images(ctx, p, ws, pl, false);
+    db_pack_images(ctx, p, ws, pl, F, false);
     auto ga = [&](int s) { return ws + pl.ga + (size_t)s * M * 64; };
     auto aslot = [&](int s) -> const float* { return s == 0 ? x : ws + pl.a + (size_t)(s - 1) * M * 64; };
     hipMemsetAsync(ws + pl.ga, 0, (size_t)4 * M * 64 * sizeof(float), st);                       // ga_0 .. ga_3
