@@ -71,7 +71,10 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
     const _Float16* const alane = sm + 2 * ACT + lane * 8;                       /* A-operand reads */    \
     unsigned off1[NACT];                                                                                 \
     unsigned inv1 = 0, inv0 = 0;                                                                         \
+    const bool revt_ = TRAINV && a.revt != 0;              /* training dgrad: the plane is walked backwards in time */ \
     const unsigned dFb = (unsigned)(a.dil * a.F) * 256u;                                                 \
+    const unsigned dFs = revt_ ? dFb : 0u - dFb;          /* byte step from frame t to the logical frame t - dil */ \
+    const float osc_ = (TRAINV && a.oscale != nullptr) ? *a.oscale : 1.0f;                               \
     /* (t, f) of row e by one division and 32-row steps (every F + 1 here is > 32) */                    \
     const int qfirst_ = q0 - 1 + (tid >> 3);                                                             \
     int tt_ = (qfirst_ < 0 ? 0 : qfirst_) / Fp, ff_ = qfirst_ - tt_ * Fp;    /* q = -1 -> (0, -1): padding */ \
@@ -80,7 +83,7 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
         off1[e] = qd * 16;                                                                               \
         if ((VALID) && ff_ >= 0 && ff_ < a.F && tt_ < a.T) {                                             \
             ok1 = true;                                                                                  \
-            off1[e] = (unsigned)(tt_ * a.F + ff_) * 256u + qd * 16;                                      \
+            off1[e] = (unsigned)((revt_ ? a.T - 1 - tt_ : tt_) * a.F + ff_) * 256u + qd * 16;            \
             if (NT == 2 && tt_ >= a.dil) ok0 = true;                                                     \
         }                                                                                                \
         if (!ok1) inv1 |= 1u << e;                                                                       \
@@ -107,7 +110,7 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
         const char* src_ = reinterpret_cast<const char*>(sel4(a.in, slot_)) + b * clip_bytes + half_ * 128; \
         _Pragma("unroll") for (int e = 0; e < NACT; ++e) {                                               \
             /* t - dil plane: same row dil*F positions earlier where it exists, else any in-bounds row */ \
-            const unsigned o_ = (NT == 2 && kt_ == 0) ? off1[e] - ((inv0 >> e) & 1u ? 0u : dFb) : off1[e]; \
+            const unsigned o_ = (NT == 2 && kt_ == 0) ? off1[e] + ((inv0 >> e) & 1u ? 0u : dFs) : off1[e]; \
             pre[e] = *reinterpret_cast<const f32x4*>(src_ + o_);     /* unconditional; masked at write */ \
         }                                                                                                \
         const float* nsc_ = sel4(a.nscale, slot_);                                                       \
@@ -172,7 +175,7 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
         _Pragma("unroll") for (int e = 0; e < NACT; ++e) {                                               \
             f32x4 v = pre[e];                                                                            \
             if (HAS_NEXT) {                                                                              \
-                const unsigned o_ = (NT == 2 && ktn_ == 0) ? off1[e] - ((inv0 >> e) & 1u ? 0u : dFb) : off1[e]; \
+                const unsigned o_ = (NT == 2 && ktn_ == 0) ? off1[e] + ((inv0 >> e) & 1u ? 0u : dFs) : off1[e]; \
                 pre[e] = *reinterpret_cast<const f32x4*>(srcn_ + o_);                                    \
             }                                                                                            \
             v = v * sc + sh;                                                                             \
@@ -261,7 +264,7 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
             } else if (a.mode == 2) {                                                                    \
                 obase[tb] = ((long)(b * a.T + t) * (2 * a.F) + 2 * f) * 64;                              \
             } else {                                                                                     \
-                obase[tb] = ((long)(b * a.T + t) * a.F + f) * 64;                                        \
+                obase[tb] = ((long)(b * a.T + (revt_ ? a.T - 1 - t : t)) * a.F + f) * 64;                \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int cb = 0; cb < CB; ++cb) {                                              \
@@ -271,7 +274,8 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
                 if (ok[tb]) {                                                                            \
                     long off = obase[tb] + 16 * (cb & 3) + 4 * g;                                        \
                     if (a.mode == 2) off += (cb >> 2) * 64;                                              \
-                    stg4(a.out + off, v);                                                                \
+                    if (TRAINV && a.accum) stg4(a.out + off, ldg4(a.out + off) + v * splat4(osc_));      \
+                    else stg4(a.out + off, v);                                                           \
                     s1 += v;                                                                             \
                     s2 += v * v;                                                                         \
                 }                                                                                        \
@@ -298,7 +302,9 @@ __device__ __forceinline__ int xcd_contiguous_block() {
     return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
 }
 
-template <int NT, int COUT, int NPB, int NWV = 4>
+// TRAINV = true: the training-step instantiation that honours ConvArgs::revt / accum / oscale (dense-block data
+// gradient, train.hip); the inference instantiations compile those paths out
+template <int NT, int COUT, int NPB, int NWV = 4, bool TRAINV = false>
 __global__ __launch_bounds__(64 * NWV) void conv3x_kernel(ConvArgs a, const _Float16* __restrict__ w16) {
     CX_DECLS
     __shared__ __attribute__((aligned(16))) _Float16 sm[SMEM];
@@ -356,6 +362,12 @@ __global__ __launch_bounds__(64 * NWV) void conv3x_kernel(ConvArgs a, const _Flo
 int conv3x_ntiles(int T, int F, int cout) {
     const int tile = (cout == 128 ? 16 * CX_NPB128 * CX_NWV128 : 16 * CX_NPB64 * CX_NWV64) - 2;
     return (T * (F + 1) + tile - 1) / tile;
+}
+
+void launch_conv3_x3_dgrad(LaunchCtx ctx, const ConvArgs& a, const void* w16, int B) {
+    dim3 grid(a.ntiles * B);
+    LAUNCH(ctx, "dense_train_bwd", (conv3x_kernel<2, 64, CX_NPB64, CX_NWV64, true><<<grid, 64 * CX_NWV64, 0, ctx.stream>>>(
+                                       a, reinterpret_cast<const _Float16*>(w16))));
 }
 
 void launch_conv3_x3(LaunchCtx ctx, const ConvArgs& a, const void* w16, int B, int time_taps, int cout) {

@@ -73,6 +73,12 @@ struct ConvArgs {
     int T, F, dil;
     int mode;                  // 0 plain, 1 keep even f only (stride-2 conv), 2 pixel shuffle (COUT = 128)
     int ntiles;
+    // training only (launch_conv3_x3_dgrad; ignored by the inference instantiations): the data gradient of a dense-block
+    // conv is the same conv on the TIME-REVERSED plane (the causal tap t - dil becomes the anti-causal t + dil) with
+    // transposed, frequency-mirrored weights, accumulated into the slot's gradient plane
+    int revt;                  // 1: logical frame t is physical frame T - 1 - t, for inputs and outputs alike
+    int accum;                 // 1: out += oscale * result
+    const float* oscale;       // device scalar (the inverse of the power-of-two input scale carried by nscale)
 };
 int  conv3_ntiles(int T, int F);
 void launch_conv3(LaunchCtx, const ConvArgs&, int B, int time_taps, int cout);
@@ -129,6 +135,7 @@ void launch_attn32_out_x3(LaunchCtx, const _Float16* qimg, const _Float16* kimg,
                           const float* bo, const unsigned char* mask);
 int  conv3x_ntiles(int T, int F, int cout);
 void launch_conv3_x3(LaunchCtx, const ConvArgs&, const void* w16, int B, int time_taps, int cout);
+void launch_conv3_x3_dgrad(LaunchCtx, const ConvArgs&, const void* w16, int B);      // 2 time taps, 64 -> 64, revt / accum honoured
 void launch_selftest_x3(hipStream_t, const void* a_img, const float* b_fm, float* d, int M32);
 
 // ------------------------------- selftest ---------------------------------------

@@ -1255,11 +1255,43 @@ __device__ __forceinline__ bool at_task(long ntask, int nb, AtTask& t) {
     t.blk = __builtin_amdgcn_readfirstlane((int)(task - (long)nh * nb));
     return true;
 }
-__device__ __forceinline__ f32x4 at_dot(const f32x4& a, const f32x4& b) {
-    f32x4 acc = splat4(0.f);
+#ifndef AT_X3
+#define AT_X3 0             // 1: the attention cores on split-f16 products.  Built and parity-green (38 training tests), but
+#endif                      // NOT faster: 57.9 -> 57.5 ms backward, 14.1 -> 12.9 ms forward per step at batch 32 - the
+                            // cores are bound by their skew / scalar-operand traffic, and the fp16 splits (12 VALU per
+                            // product) take back what the matrix pipe gives.  The exact fp32 products stay the default.
+// acc + sum over the 16 contraction indices (g, s) of a(lane (i, g))[s] * b(lane (j, g))[s]: four fp32 MFMA steps, or -
+// AT_X3 - two split-f16 MFMAs: each lane's float4 becomes [hi(4) | lo(4)] along the 32-wide contraction on the A
+// side and [hi | hi], then [lo | lo], on the B side, which yields all four split terms with no data movement (the
+// operand a lane needs is the float4 it already holds).  Gradient operands must be pre-scaled into fp16 range by an
+// exact power of two (at_scale below); activations, probabilities and the relative-position table are in range as is.
+__device__ __forceinline__ f32x4 at_mma4(const f32x4& a, const f32x4& b, f32x4 acc) {
+#if AT_X3
+    f16x4 ah, al, bh, bl;
+    split4(a, ah, al);
+    split4(b, bh, bl);
+    const f16x8 av = __builtin_shufflevector(ah, al, 0, 1, 2, 3, 4, 5, 6, 7);
+    acc = mfma32h(av, __builtin_shufflevector(bh, bh, 0, 1, 2, 3, 0, 1, 2, 3), acc);
+    acc = mfma32l(av, __builtin_shufflevector(bl, bl, 0, 1, 2, 3, 0, 1, 2, 3), acc);
+#else
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma16(a[s], b[s], acc);
+#endif
     return acc;
+}
+__device__ __forceinline__ f32x4 at_dot(const f32x4& a, const f32x4& b) { return at_mma4(a, b, splat4(0.f)); }
+// exact power-of-two scale of the backward cores' gradient operands (dO and D = rowsum(dO o)): s brings the largest
+// |dO| of the whole tensor (bit pattern in *amax, collected by at_out_bwd_kernel with atomicMax - order-independent) to
+// [1, 2); every output of a core is linear in dO, so it is multiplied by inv = 1 / s at the end.  fp32 build: 1, 1.
+__device__ __forceinline__ void at_scale(const float* __restrict__ amax, float& s, float& inv) {
+    s = 1.0f; inv = 1.0f;
+#if AT_X3
+    const unsigned e = (__float_as_uint(amax[0]) >> 23) & 0xffu;
+    if (e > 0u && e < 254u) {
+        s = __uint_as_float((254u - e) << 23);
+        inv = __uint_as_float(e << 23);
+    }
+#endif
 }
 // lane offsets (floats) of the fragments of the 16 rows that start at row R0 of a sequence of L rows, relative to row
 // R0: rows past the end read row L - 1 (finite; masked or never stored).  Full blocks use the affine forms
@@ -1367,8 +1399,7 @@ __global__ __launch_bounds__(256) void at_fwd_kernel(AtBufs b, const float* __re
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(sc[r] - m);
         l += (p[0] + p[1]) + (p[2] + p[3]);               // this lane's four keys; the four lane groups are summed at the end
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ot = mfma16(f.vb[r], p[r], ot);
+        ot = at_mma4(f.vb, p, ot);
     };
     if (nfull > 0) {
         // two blocks per trip: the other block's operands are in flight while one is being worked on
@@ -1417,13 +1448,15 @@ __global__ __launch_bounds__(256) void at_out_kernel(const float* __restrict__ o
 __global__ __launch_bounds__(256) void at_out_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ mask, float ms,
                                                          const float* __restrict__ o, long M,
                                                          const float* __restrict__ wotfm, float* __restrict__ dout,
-                                                         float* __restrict__ dO, float* __restrict__ D) {
+                                                         float* __restrict__ dO, float* __restrict__ D,
+                                                         unsigned* __restrict__ amax) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (t0 >= M) return;
     const long t = t0 + c;
     const bool ok = t < M;
     const long row = ok ? t : M - 1;
+    float mx = 0.f;
     f32x4 dyf[1][4];
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) {
@@ -1442,16 +1475,24 @@ __global__ __launch_bounds__(256) void at_out_bwd_kernel(const float* __restrict
         if (ok) {
             stg4(dO + row * 64 + 16 * hb + 4 * g, acc[0]);
             if (g == 0) D[row * 4 + hb] = part;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(acc[0][0]), fabsf(acc[0][1]))), fmaxf(fabsf(acc[0][2]), fabsf(acc[0][3])));
         }
     }
+    // the largest |dO| of the tensor, for the exact power-of-two scale of the split-f16 cores (at_scale)
+    mx = red_g_max(mx);
+    mx = fmaxf(mx, dpp_perm<0xB1>(mx));
+    mx = fmaxf(mx, dpp_perm<0x4E>(mx));
+    mx = fmaxf(mx, dpp_perm<0x141>(mx));
+    mx = fmaxf(mx, dpp_perm<0x140>(mx));
+    if (lane == 0 && mx > 0.f) atomicMax(amax, __float_as_uint(mx));
 }
 
 // p_ij and ds_ij of one (query i, key j) pair; scores are recomputed, never stored.  q is the RAW query row (the
 // 16^-0.5 scale is applied to the score), so that rows can come straight from wave-uniform scalar loads.
 // dq: task (n, h, query block); P^T / dS^T tiles (key 4g + r, query c).   dq_i = scale sum_j ds_ij (k_j + E[i - j])
 __global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ dO,
-                                                    const float* __restrict__ D, int L, int nb, long ntask,
-                                                    float* __restrict__ dqkv) {
+                                                    const float* __restrict__ D, const float* __restrict__ amax, int L, int nb,
+                                                    long ntask, float* __restrict__ dqkv) {
     __shared__ float sm[4][32 * AT_PA + 16 * AT_PS];
     AtTask t;
     if (!at_task(ntask, nb, t)) return;
@@ -1465,8 +1506,10 @@ __global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __res
     const float* __restrict__ e_blk = ewin + (long)(I0 - 15 + W) * 16;
     const int ri = I0 + c < L ? I0 + c : L - 1;
     const f32x4 qa = ldg4(qh + (long)ri * 192 + 4 * g) * splat4(AT_QSCALE);
-    const f32x4 ga = ldg4(dO + (base + ri) * 64 + 16 * h + 4 * g);
-    const float lse = b.lse[(long)t.nh * L + ri] * AT_LOG2E, Di = D[(base + ri) * 4 + h];
+    float gs, ginv;
+    at_scale(amax, gs, ginv);
+    const f32x4 ga = ldg4(dO + (base + ri) * 64 + 16 * h + 4 * g) * splat4(gs);
+    const float lse = b.lse[(long)t.nh * L + ri] * AT_LOG2E, Di = D[(base + ri) * 4 + h] * gs;
     const unsigned la = c * 192 + 4 * g, lb = 4 * g * 192 + c, le = c * 16 + 4 * g, lg = g * 16 + c;
     const unsigned la_t = at_off_a(16 * nfull, L, 192, c, g);
     unsigned lb_t[4];
@@ -1506,17 +1549,19 @@ __global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __res
             const float p = (!TAIL || vt[r]) ? __builtin_amdgcn_exp2f(st[r] + rt[r] - lse) : 0.f;
             ds[r] = p * (dpt[r] - Di);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dq = mfma16(ds[r], kb[r], dq);
+        dq = at_mma4(ds, kb, dq);
         // unskew: dSE[query c][distance 4s + g] = dS[c][15 + c - (4s + g)], zero outside the tile (the pads)
         wave_lds_fence();
         *reinterpret_cast<f32x4*>(buf2 + c * AT_PS + 16 + 4 * g) = ds;
         wave_lds_fence();
+        f32x4 a_lo, a_hi;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float a = buf2[c * (AT_PS + 1) + 3 - g + 4 * (7 - s)];
-            dq = mfma16(a, s < 4 ? eb_lo[s] : eb_prev[s - 4], dq);
+        for (int s = 0; s < 4; ++s) {
+            a_lo[s] = buf2[c * (AT_PS + 1) + 3 - g + 4 * (7 - s)];
+            a_hi[s] = buf2[c * (AT_PS + 1) + 3 - g + 4 * (3 - s)];
         }
+        dq = at_mma4(a_lo, eb_lo, dq);
+        dq = at_mma4(a_hi, eb_prev, dq);
         eb_prev = eb_lo;
     };
     if (nfull > 0) {
@@ -1534,7 +1579,7 @@ __global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __res
     if (nfull < nb) tile(std::true_type{}, load(std::true_type{}, nfull));
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (I0 + 4 * g + r < L) dqkv[(base + I0 + 4 * g + r) * 192 + 16 * h + c] = dq[r] * 0.25f;
+        if (I0 + 4 * g + r < L) dqkv[(base + I0 + 4 * g + r) * 192 + 16 * h + c] = dq[r] * (0.25f * ginv);
 }
 
 // one tile in the (query 4g + r, key c) orientation: P and dS.  lse (log2 units) / D are per query ROW here.
@@ -1553,8 +1598,8 @@ __device__ __forceinline__ void at_tile_pds(float* buf, const f32x4& qa, const f
 // dk, dv: task (n, h, key block).          dk_j = scale sum_i ds_ij q_i,  dv_j = sum_i p_ij dO_i
 // (key columns past the end of the sequence only feed their own, never stored, rows: no mask for them)
 __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ dO,
-                                                     const float* __restrict__ D, int L, int nb, long ntask,
-                                                     float* __restrict__ dqkv) {
+                                                     const float* __restrict__ D, const float* __restrict__ amax, int L, int nb,
+                                                     long ntask, float* __restrict__ dqkv) {
     __shared__ float sm[4][16 * AT_PB];
     AtTask t;
     if (!at_task(ntask, nb, t)) return;
@@ -1570,6 +1615,8 @@ __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __re
     const long rj = (long)J0 * 192 + at_off_a(J0, L, 192, c, g);
     const f32x4 ka = ldg4(qh + 64 + rj), va = ldg4(qh + 128 + rj);
     const unsigned le = c * 16 + 4 * g;
+    float gs, ginv;
+    at_scale(amax, gs, ginv);
     f32x4 dk = splat4(0.f), dv = splat4(0.f);        // [key 4g + r][d = c]
     f32x4 e0 = ldg4(e_blk + le);
     struct Frag { f32x4 qa, ga, e1, qb, gb, lse, Dr; int I0; };
@@ -1596,20 +1643,19 @@ __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __re
     auto tile = [&](auto tail, const Frag& f) {
         constexpr bool TAIL = decltype(tail)::value;
         const int I0 = f.I0;
-        const f32x4 &qb = f.qb, &gb = f.gb;
+        const f32x4& qb = f.qb;
+        const f32x4 gb = f.gb * splat4(gs);
         f32x4 p, ds;
-        at_tile_pds(buf, f.qa * splat4(AT_QSCALE), f.ga, ka, va, e0, f.e1, f.lse * splat4(AT_LOG2E), f.Dr, c, g, p, ds);
+        at_tile_pds(buf, f.qa * splat4(AT_QSCALE), f.ga * splat4(gs), ka, va, e0, f.e1, f.lse * splat4(AT_LOG2E),
+                    f.Dr * splat4(gs), c, g, p, ds);
         e0 = f.e1;
         if (TAIL) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (I0 + 4 * g + r >= L) { p[r] = 0.f; ds[r] = 0.f; }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            dk = mfma16(ds[r], qb[r], dk);
-            dv = mfma16(p[r], gb[r], dv);
-        }
+        dk = at_mma4(ds, qb, dk);
+        dv = at_mma4(p, gb, dv);
     };
     if (nfull > 0) {
         // two blocks per trip: the other block's operands are in flight while one is being worked on
@@ -1627,8 +1673,8 @@ __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __re
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (J0 + 4 * g + r < L) {
-            dqkv[(base + J0 + 4 * g + r) * 192 + 64 + 16 * h + c] = dk[r] * 0.25f;
-            dqkv[(base + J0 + 4 * g + r) * 192 + 128 + 16 * h + c] = dv[r];
+            dqkv[(base + J0 + 4 * g + r) * 192 + 64 + 16 * h + c] = dk[r] * (0.25f * ginv);
+            dqkv[(base + J0 + 4 * g + r) * 192 + 128 + 16 * h + c] = dv[r] * ginv;
         }
 }
 
@@ -1637,8 +1683,8 @@ __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __re
 //   dEband[dist][:] = scale sum_{i - j = dist} ds_ij q_i
 // stays in two accumulators and is written once per diagonal: slab [(n, h)][delta + nb - 1][32][16].
 __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ dO,
-                                                    const float* __restrict__ D, int L, int nb, long ntask,
-                                                    float* __restrict__ partial) {
+                                                    const float* __restrict__ D, const float* __restrict__ amax, int L, int nb,
+                                                    long ntask, float* __restrict__ partial) {
     __shared__ float sm[4][16 * AT_PB + 16 * AT_PS];
     AtTask t;
     if (!at_task(ntask, nb, t)) return;
@@ -1653,6 +1699,8 @@ __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __res
     const float* __restrict__ lh = b.lse + (long)t.nh * L;
     const float* __restrict__ Dh = D + base * 4 + h;
     const unsigned le = c * 16 + 4 * g;
+    float gs, ginv;
+    at_scale(amax, gs, ginv);
     for (int seg = 0; seg < 2; ++seg) {
         if (seg == 1 && t.blk == 0) break;
         const int delta = seg == 0 ? t.blk : t.blk - nb;
@@ -1689,7 +1737,8 @@ __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __res
             const int I0 = f.I0, J0 = f.J0;
             const f32x4& qb = f.qb;
             f32x4 p, ds;
-            at_tile_pds(buf, f.qa * splat4(AT_QSCALE), f.ga, f.ka, f.va, e0, e1, f.lse * splat4(AT_LOG2E), f.Dr, c, g, p, ds);
+            at_tile_pds(buf, f.qa * splat4(AT_QSCALE), f.ga * splat4(gs), f.ka, f.va, e0, e1, f.lse * splat4(AT_LOG2E),
+                        f.Dr * splat4(gs), c, g, p, ds);
             if (TAIL) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -1700,12 +1749,15 @@ __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __res
 #pragma unroll
             for (int r = 0; r < 4; ++r) buf2[(4 * g + r) * AT_PS + 16 + c] = ds[r];
             wave_lds_fence();
+            f32x4 r0, r1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float* row = buf2 + 4 * g * (AT_PS + 1) + 15 - c + r * (AT_PS + 1);
-                de0 = mfma16(row[16], qb[r], de0);
-                de1 = mfma16(row[0], qb[r], de1);
+                r0[r] = row[16];
+                r1[r] = row[0];
             }
+            de0 = at_mma4(r0, qb, de0);
+            de1 = at_mma4(r1, qb, de1);
         };
         // a diagonal's tiles are full except (when L is not a multiple of 16) its last one
         const int nfl = (ib0 + ntile > nfull || jb0 + ntile > nfull) ? ntile - 1 : ntile;
@@ -1725,8 +1777,8 @@ __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __res
         float* out = partial + ((long)t.nh * (2 * nb - 1) + (delta + nb - 1)) * 512;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            out[(4 * g + r) * 16 + c] = de0[r] * 0.25f;
-            out[(16 + 4 * g + r) * 16 + c] = de1[r] * 0.25f;
+            out[(4 * g + r) * 16 + c] = de0[r] * (0.25f * ginv);
+            out[(16 + 4 * g + r) * 16 + c] = de1[r] * (0.25f * ginv);
         }
     }
 }
@@ -1887,8 +1939,10 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     const AtBufs b{ws + pl.qkv, ws + pl.o, ws + pl.lse};
     const unsigned grid = (unsigned)((M + 63) / 64);
     float* cpart = ws + pl.cpart;
+    hipMemsetAsync(cpart, 0, sizeof(float), s);           // max |dO| (bit pattern): the column-sum slabs are idle until the end
     LAUNCH(ctx, "attn_train_bwd", (at_out_bwd_kernel<<<grid, 256, 0, s>>>(dy, mask, ms, b.o, M, ws + pl.wot, ws + pl.dout,
-                                                                          ws + pl.dO, ws + pl.D)));
+                                                                          ws + pl.dO, ws + pl.D,
+                                                                          reinterpret_cast<unsigned*>(cpart))));
     // to_out gradients: dWo [64,64] = dout^T O, dbo = colsum dout
     wgrad_partial64(ctx, "attn_train_wgrad", ws + pl.dout, b.o, M, 64, 64, ws + pl.wpart, wg_split(1));
     LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<64, 1024, 0, s>>>(ws + pl.wpart, wg_split(1), 4096,
@@ -1897,11 +1951,11 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     const int nb = at_blocks(L);
     const long ntask = (long)N * 4 * nb;
     const unsigned cgrid = at_core_grid(ntask);
-    LAUNCH(ctx, "attn_train_bwd", (at_dq_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.D, L, nb, ntask,
+    LAUNCH(ctx, "attn_train_bwd", (at_dq_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.D, cpart, L, nb, ntask,
                                                                       ws + pl.dqkv)));
-    LAUNCH(ctx, "attn_train_bwd", (at_dkv_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.D, L, nb, ntask,
+    LAUNCH(ctx, "attn_train_bwd", (at_dkv_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.D, cpart, L, nb, ntask,
                                                                        ws + pl.dqkv)));
-    LAUNCH(ctx, "attn_train_bwd", (at_de_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.D, L, nb, ntask,
+    LAUNCH(ctx, "attn_train_bwd", (at_de_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.D, cpart, L, nb, ntask,
                                                                       ws + pl.depart)));
     // rel_pos_emb gradient: sum the band slabs over (n, h) first (grouped, coalesced), then fold the band rows onto
     // the clamped table rows
@@ -2062,6 +2116,14 @@ void launch_swap_axes(LaunchCtx ctx, const float* in, const float* add, float* o
 #define MT_NCH 32                      // the single-channel mask head's planes are 64 x smaller
 
 struct DbSlots { const float* p[5]; };
+
+__device__ __forceinline__ float wave_max_all(float v) {        // maximum over the 64 lanes
+    v = fmaxf(v, dpp_perm<0xB1>(v));
+    v = fmaxf(v, dpp_perm<0x4E>(v));
+    v = fmaxf(v, dpp_perm<0x141>(v));
+    v = fmaxf(v, dpp_perm<0x140>(v));
+    return red_g_max(v);
+}
 
 // (b, t, f) of the 16 positions of a wave; `src` = flat row of the position shifted by (dt, df) or -1 outside the plane
 struct DbPos { long m; int b, t, f; bool ok; };
@@ -2228,15 +2290,24 @@ __global__ __launch_bounds__(256) void db_bwd_finalize_kernel(const float* __res
 }
 
 // dz = gamma rstd (dn - mean(dn) - zhat mean(dn zhat)), in place on dn
+// absmax (may be NULL): bit pattern of the largest |dz| of the plane, combined with atomicMax on the unsigned bits (the
+// order of a maximum does not matter, so the result is deterministic) - the split-f16 data gradient scales dz by it
 __global__ __launch_bounds__(256) void db_in_bwd_kernel(float* __restrict__ dn, const float* __restrict__ z, long total, int P,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ m1,
-                                                        const float* __restrict__ m2) {
+                                                        const float* __restrict__ m2, unsigned* __restrict__ absmax = nullptr) {
+    float mx = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i & 63);
         const long bc = (i >> 6) / P * 64 + c;
         const float zh = (z[i] - mean[bc]) * rstd[bc];
-        dn[i] = gamma[c] * rstd[bc] * (dn[i] - m1[bc] - zh * m2[bc]);
+        const float v = gamma[c] * rstd[bc] * (dn[i] - m1[bc] - zh * m2[bc]);
+        dn[i] = v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+    if (absmax) {
+        mx = wave_max_all(mx);
+        if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(absmax, __float_as_uint(mx));
     }
 }
 
@@ -2447,6 +2518,46 @@ __global__ void db_pack_x3_layer_kernel(const float* __restrict__ w, int i, _Flo
 }
 // halfs offset of layer i's x3 image inside the (re-used) fp32 image area: 2 (i + 1) * 6 * 4 * 1024 halfs per layer
 static long db_x3_img_off(int i) { return (long)(i * (i + 1)) * 24576; }
+
+// The DATA GRADIENT of the same convolution is that kernel again (launch_conv3_x3_dgrad): on the time-reversed plane the
+// anti-causal tap of the transposed conv (dz at t + dil) is the causal one, the frequency taps are mirrored in the
+// image, the contraction runs over layer i's 64 output channels and the 64 results accumulate into slot s's gradient.
+// Image of (layer i, slot s): [2 chunks of 32 dz channels][tap = kt * 3 + kfc][4 cb][hi | lo][64][8], lane (c, g) slot e
+// <-> w[co = 32 chunk + 16 (e >> 2) + 4 g + (e & 3)][64 (i - s) + 16 cb + c][kt][kf = 2 - kfc]
+__global__ void db_pack_x3_dgrad_kernel(const float* __restrict__ w, int i, _Float16* __restrict__ img) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;          // (slot, chunk, tap, cb, lane)
+    const int Cin = 64 * (i + 1);
+    if (t >= (i + 1) * 2 * 6 * 4 * 64) return;
+    const int lane = t & 63, cb = (t >> 6) & 3, rest = t >> 8, tap = rest % 6, chunk = (rest / 6) & 1, s = rest / 12;
+    const int ci = 64 * (i - s) + 16 * cb + (lane & 15), kt = tap / 3, kf = 2 - (tap - 3 * kt);
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int co = 32 * chunk + 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);
+        const float v = w[((long)co * Cin + ci) * 6 + kt * 3 + kf];
+        const _Float16 h = (_Float16)v;
+        hi[e] = h;
+        lo[e] = (_Float16)(v - (float)h);
+    }
+    _Float16* o = img + ((long)((s * 2 + chunk) * 6 + tap) * 4 + cb) * 1024 + lane * 8;
+    *reinterpret_cast<f16x8*>(o) = hi;
+    *reinterpret_cast<f16x8*>(o + 512) = lo;
+}
+// halfs offset of (layer i, slot s) in the (re-used) transposed-image area: 49152 halfs per (i, s), layers in order
+static long db_x3_dgrad_off(int i, int s) { return (long)(i * (i + 1) / 2 + s) * 49152; }
+
+// scratch of the dgrad launches, carved out of the per-(b, c) partial-sum area (idle between a layer's InstanceNorm
+// backward and the next layer's sums): [0] bits of max |dz|, [64] 1 / scale, [128..191] ones, [192..255] zeros,
+// [256 ..] scale per (b, c), then zeros per (b, c)
+__global__ void db_dgrad_setup_kernel(float* __restrict__ sc, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned e = (__float_as_uint(sc[0]) >> 23) & 0xffu;          // sc[0] holds the bit pattern of the maximum
+    const bool ok = e > 0u && e < 254u;
+    const float s = ok ? __uint_as_float((254u - e) << 23) : 1.0f, inv = ok ? __uint_as_float(e << 23) : 1.0f;
+    if (i == 0) sc[64] = inv;
+    if (i < 64) { sc[128 + i] = 1.0f; sc[192 + i] = 0.0f; }
+    if (i < B * 64) { sc[256 + i] = s; sc[256 + B * 64 + i] = 0.0f; }
+}
 #endif
 
 // the inference conv kernel steps its staging rows by 64 per load and assumes a plane row (F + 1 positions with the
@@ -2460,12 +2571,13 @@ static void db_pack_images(LaunchCtx ctx, const DenseTrainParams& p, float* ws, 
         const long off = (long)db_img_index(i, 0) * 4096;
 #if TRAIN_X3
         if (db_x3_forward(F)) {
-            // forward images in split-f16 form (exactly the space of the fp32 ones); transposed fp32 images for dgrad
-            LAUNCH(ctx, "dense_train_pack", (db_pack_layer_kernel<<<dim3(16, 6 * (i + 1), 1), 256, 0, ctx.stream>>>(
-                                                p.conv_w[i], i, nullptr, ws + pl.imgT + off, 1)));
+            // forward and data-gradient operand images in split-f16 form (exactly the space of the fp32 ones)
             const int nthr = 2 * (i + 1) * 6 * 4 * 64;
             LAUNCH(ctx, "dense_train_pack", (db_pack_x3_layer_kernel<<<(nthr + 255) / 256, 256, 0, ctx.stream>>>(
                                                 p.conv_w[i], i, reinterpret_cast<_Float16*>(ws + pl.img) + db_x3_img_off(i))));
+            LAUNCH(ctx, "dense_train_pack", (db_pack_x3_dgrad_kernel<<<(nthr + 255) / 256, 256, 0, ctx.stream>>>(
+                                                p.conv_w[i], i, reinterpret_cast<_Float16*>(ws + pl.imgT) + db_x3_dgrad_off(i, 0))));
+            (void)off;
             continue;
         }
 #endif
@@ -2551,14 +2663,34 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
         LAUNCH(ctx, "dense_train_bwd", (db_bwd_finalize_kernel<<<64, 256, 0, st>>>(ws + pl.part, B, (double)P, ws + pl.m1,
                                                                                 ws + pl.m2, grad.norm_w[i], grad.norm_b[i],
                                                                                 grad.prelu_w[i])));
+        const bool x3d = db_x3_forward(F);
+        float* sc = ws + pl.part;                          // dgrad scratch (see db_dgrad_setup_kernel)
+        if (x3d) hipMemsetAsync(sc, 0, sizeof(float), st);
         LAUNCH(ctx, "dense_train_bwd", (db_in_bwd_kernel<<<2048, 256, 0, st>>>(g, z, M * 64, P, mean, rstd, p.norm_w[i],
-                                                                               ws + pl.m1, ws + pl.m2)));
+                                                                               ws + pl.m1, ws + pl.m2,
+                                                                               x3d ? reinterpret_cast<unsigned*>(sc) : nullptr)));
         const int dil = 1 << i, Cin = 64 * (i + 1);
+#if TRAIN_X3
+        if (x3d) LAUNCH(ctx, "dense_train_bwd", (db_dgrad_setup_kernel<<<(B * 64 + 255) / 256, 256, 0, st>>>(sc, B)));
+#endif
         for (int s = 0; s <= i; ++s) {
             LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_kernel<<<dim3(6, DB_WG_SPLIT), 256, 0, st>>>(
                                                  g, aslot(s), B, T, F, dil, ws + pl.wpart)));
             LAUNCH(ctx, "dense_train_reduce", (db_wgrad_scatter_kernel<<<6 * 64, 256, 0, st>>>(ws + pl.wpart, Cin, 64 * (i - s),
                                                                                                grad.conv_w[i])));
+#if TRAIN_X3
+            if (x3d) {
+                ConvArgs ca{};                              // dz scaled by an exact power of two on load, ga(s) += result / scale
+                ca.in[0] = g; ca.nscale[0] = sc + 256; ca.nshift[0] = sc + 256 + (size_t)B * 64; ca.nalpha[0] = sc + 128;
+                ca.nslots = 1;
+                ca.bias = sc + 192;
+                ca.out = ga(s);
+                ca.T = T; ca.F = F; ca.dil = dil; ca.mode = 0; ca.ntiles = conv3x_ntiles(T, F, 64);
+                ca.revt = 1; ca.accum = 1; ca.oscale = sc + 64;
+                launch_conv3_x3_dgrad(ctx, ca, reinterpret_cast<const _Float16*>(ws + pl.imgT) + db_x3_dgrad_off(i, s), B);
+                continue;
+            }
+#endif
             LAUNCH(ctx, "dense_train_bwd", (db_conv_dgrad_kernel<<<(unsigned)((M + 63) / 64), 256, 0, st>>>(
                                                g, ws + pl.imgT + (long)db_img_index(i, s) * 4096, B, T, F, dil, ga(s))));
         }
