@@ -1478,13 +1478,18 @@ __global__ __launch_bounds__(256) void at_out_bwd_kernel(const float* __restrict
             mx = fmaxf(fmaxf(mx, fmaxf(fabsf(acc[0][0]), fabsf(acc[0][1]))), fmaxf(fabsf(acc[0][2]), fabsf(acc[0][3])));
         }
     }
-    // the largest |dO| of the tensor, for the exact power-of-two scale of the split-f16 cores (at_scale)
+#if AT_X3
+    // the largest |dO| of the tensor, for the exact power-of-two scale of the split-f16 cores (at_scale).  (One atomic per
+    // wave on a single word costs ~70 us per launch at batch 4: a per-block slot array would be the form to ship.)
     mx = red_g_max(mx);
     mx = fmaxf(mx, dpp_perm<0xB1>(mx));
     mx = fmaxf(mx, dpp_perm<0x4E>(mx));
     mx = fmaxf(mx, dpp_perm<0x141>(mx));
     mx = fmaxf(mx, dpp_perm<0x140>(mx));
     if (lane == 0 && mx > 0.f) atomicMax(amax, __float_as_uint(mx));
+#else
+    (void)mx; (void)amax;
+#endif
 }
 
 // p_ij and ds_ij of one (query i, key j) pair; scores are recomputed, never stored.  q is the RAW query row (the
@@ -1939,7 +1944,9 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     const AtBufs b{ws + pl.qkv, ws + pl.o, ws + pl.lse};
     const unsigned grid = (unsigned)((M + 63) / 64);
     float* cpart = ws + pl.cpart;
+#if AT_X3
     hipMemsetAsync(cpart, 0, sizeof(float), s);           // max |dO| (bit pattern): the column-sum slabs are idle until the end
+#endif
     LAUNCH(ctx, "attn_train_bwd", (at_out_bwd_kernel<<<grid, 256, 0, s>>>(dy, mask, ms, b.o, M, ws + pl.wot, ws + pl.dout,
                                                                           ws + pl.dO, ws + pl.D,
                                                                           reinterpret_cast<unsigned*>(cpart))));
@@ -2114,6 +2121,7 @@ void launch_swap_axes(LaunchCtx ctx, const float* in, const float* add, float* o
 #define DB_NCH 256                     // position chunks per clip of the per-(b, c) reductions: B x 256 blocks fill the chip
                                        // (32 chunks = 128 blocks at batch 4 ran these streaming sums at 0.2 TB/s)
 #define MT_NCH 32                      // the single-channel mask head's planes are 64 x smaller
+#define DB_MAXBLK 2048                 // blocks of db_in_bwd_kernel = per-block |dz| maxima it leaves for the dgrad scale
 
 struct DbSlots { const float* p[5]; };
 
@@ -2290,12 +2298,13 @@ __global__ __launch_bounds__(256) void db_bwd_finalize_kernel(const float* __res
 }
 
 // dz = gamma rstd (dn - mean(dn) - zhat mean(dn zhat)), in place on dn
-// absmax (may be NULL): bit pattern of the largest |dz| of the plane, combined with atomicMax on the unsigned bits (the
-// order of a maximum does not matter, so the result is deterministic) - the split-f16 data gradient scales dz by it
+// absmax (may be NULL): [gridDim.x] per-block maxima of |dz| (no atomics: 8192 of them on one word cost 70 us per
+// launch), reduced by db_dgrad_setup_kernel - the split-f16 data gradient scales dz by the plane's maximum
 __global__ __launch_bounds__(256) void db_in_bwd_kernel(float* __restrict__ dn, const float* __restrict__ z, long total, int P,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ m1,
-                                                        const float* __restrict__ m2, unsigned* __restrict__ absmax = nullptr) {
+                                                        const float* __restrict__ m2, float* __restrict__ absmax = nullptr) {
+    __shared__ float wmax[4];
     float mx = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i & 63);
@@ -2307,7 +2316,9 @@ __global__ __launch_bounds__(256) void db_in_bwd_kernel(float* __restrict__ dn, 
     }
     if (absmax) {
         mx = wave_max_all(mx);
-        if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(absmax, __float_as_uint(mx));
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        if (threadIdx.x == 0) absmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
     }
 }
 
@@ -2547,16 +2558,25 @@ __global__ void db_pack_x3_dgrad_kernel(const float* __restrict__ w, int i, _Flo
 static long db_x3_dgrad_off(int i, int s) { return (long)(i * (i + 1) / 2 + s) * 49152; }
 
 // scratch of the dgrad launches, carved out of the per-(b, c) partial-sum area (idle between a layer's InstanceNorm
-// backward and the next layer's sums): [0] bits of max |dz|, [64] 1 / scale, [128..191] ones, [192..255] zeros,
-// [256 ..] scale per (b, c), then zeros per (b, c)
-__global__ void db_dgrad_setup_kernel(float* __restrict__ sc, int B) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned e = (__float_as_uint(sc[0]) >> 23) & 0xffu;          // sc[0] holds the bit pattern of the maximum
+// backward and the next layer's sums): [64] 1 / scale, [128..191] ones, [192..255] zeros, [256 ..] scale per (b, c),
+// then zeros per (b, c), then the DB_MAXBLK per-block maxima of |dz| written by db_in_bwd_kernel.  One block.
+__global__ __launch_bounds__(256) void db_dgrad_setup_kernel(float* __restrict__ sc, int B) {
+    __shared__ float red[256];
+    const float* slots = sc + 256 + 2 * B * 64;
+    float m = 0.f;
+    for (int k = threadIdx.x; k < DB_MAXBLK; k += 256) m = fmaxf(m, slots[k]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + w]);
+        __syncthreads();
+    }
+    const unsigned e = (__float_as_uint(red[0]) >> 23) & 0xffu;
     const bool ok = e > 0u && e < 254u;
     const float s = ok ? __uint_as_float((254u - e) << 23) : 1.0f, inv = ok ? __uint_as_float(e << 23) : 1.0f;
-    if (i == 0) sc[64] = inv;
-    if (i < 64) { sc[128 + i] = 1.0f; sc[192 + i] = 0.0f; }
-    if (i < B * 64) { sc[256 + i] = s; sc[256 + B * 64 + i] = 0.0f; }
+    if (threadIdx.x == 0) sc[64] = inv;
+    if (threadIdx.x < 64) { sc[128 + threadIdx.x] = 1.0f; sc[192 + threadIdx.x] = 0.0f; }
+    for (int i = threadIdx.x; i < B * 64; i += 256) { sc[256 + i] = s; sc[256 + B * 64 + i] = 0.0f; }
 }
 #endif
 
@@ -2665,13 +2685,12 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
                                                                                 grad.prelu_w[i])));
         const bool x3d = db_x3_forward(F);
         float* sc = ws + pl.part;                          // dgrad scratch (see db_dgrad_setup_kernel)
-        if (x3d) hipMemsetAsync(sc, 0, sizeof(float), st);
-        LAUNCH(ctx, "dense_train_bwd", (db_in_bwd_kernel<<<2048, 256, 0, st>>>(g, z, M * 64, P, mean, rstd, p.norm_w[i],
-                                                                               ws + pl.m1, ws + pl.m2,
-                                                                               x3d ? reinterpret_cast<unsigned*>(sc) : nullptr)));
+        LAUNCH(ctx, "dense_train_bwd", (db_in_bwd_kernel<<<DB_MAXBLK, 256, 0, st>>>(g, z, M * 64, P, mean, rstd, p.norm_w[i],
+                                                                                    ws + pl.m1, ws + pl.m2,
+                                                                                    x3d ? sc + 256 + (size_t)2 * B * 64 : nullptr)));
         const int dil = 1 << i, Cin = 64 * (i + 1);
 #if TRAIN_X3
-        if (x3d) LAUNCH(ctx, "dense_train_bwd", (db_dgrad_setup_kernel<<<(B * 64 + 255) / 256, 256, 0, st>>>(sc, B)));
+        if (x3d) LAUNCH(ctx, "dense_train_bwd", (db_dgrad_setup_kernel<<<1, 256, 0, st>>>(sc, B)));
 #endif
         for (int s = 0; s <= i; ++s) {
             LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_kernel<<<dim3(6, DB_WG_SPLIT), 256, 0, st>>>(
