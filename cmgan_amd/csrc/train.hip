@@ -587,6 +587,8 @@ void ffn_x3_backward(LaunchCtx, const float* x, const float* dy, long M, const F
                      float* o_d1, float* o_dh, float* o_xn, float* o_g1, float* o_dxn, float* dhmax);
 void launch_wgrad_partial64_x3(LaunchCtx, const char* label, const float* P, const float* Q, long M, int R, int C,
                                float* partial, int nsplit);
+void launch_db_conv_wgrad_x3(LaunchCtx, const float* dz, const float* a, int B, int T, int F, int dil, int nsplit,
+                             float* partial);
 // the token-contraction weight gradient in either mode: grid (R / 64, C / 64, nsplit)
 static void wgrad_partial64(LaunchCtx ctx, const char* label, const float* P, const float* Q, long M, int R, int C,
                             float* partial, int nsplit) {
@@ -2693,8 +2695,12 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
         if (x3d) LAUNCH(ctx, "dense_train_bwd", (db_dgrad_setup_kernel<<<1, 256, 0, st>>>(sc, B)));
 #endif
         for (int s = 0; s <= i; ++s) {
+#if TRAIN_X3
+            launch_db_conv_wgrad_x3(ctx, g, aslot(s), B, T, F, dil, DB_WG_SPLIT, ws + pl.wpart);
+#else
             LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_kernel<<<dim3(6, DB_WG_SPLIT), 256, 0, st>>>(
                                                  g, aslot(s), B, T, F, dil, ws + pl.wpart)));
+#endif
             LAUNCH(ctx, "dense_train_reduce", (db_wgrad_scatter_kernel<<<6 * 64, 256, 0, st>>>(ws + pl.wpart, Cin, 64 * (i - s),
                                                                                                grad.conv_w[i])));
 #if TRAIN_X3

@@ -536,6 +536,130 @@ __global__ __launch_bounds__(256) void wgrad_partial64_x3_kernel(const float* __
     }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Dense-block weight gradient (db_conv_wgrad_kernel of train.hip with split products):
+//   partial[tap][s][co][ci] = sum over the s-th range of positions m of dz[m][co] * a[m shifted by tap][ci]
+// Steps of 32 positions; lane (c, g) feeds slot e with position m0 + 8 g + e: eight dwords of one dz column and of one
+// (shifted, zero outside the plane) activation column per 16-wide block.  dz is a gradient: scaled by the running
+// exact power of two of wgrad_partial64_x3_kernel.  Same block shape, LDS combine and slab layout as the fp32 kernel.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void db_conv_wgrad_x3_kernel(const float* __restrict__ dz, const float* __restrict__ a,
+                                                               int B, int T, int F, int dil, int nsplit,
+                                                               float* __restrict__ partial) {
+    __shared__ float red[2][64 * 64];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int tap = blockIdx.x, s = blockIdx.y;
+    const int kt = tap / 3, kf = tap - 3 * kt, dt = (kt - 1) * dil, df = kf - 1;
+    const unsigned M = (unsigned)B * T * F, tf = (unsigned)T * F;
+    const unsigned steps = (M + 31) / 32, per = (steps + nsplit - 1) / nsplit;
+    const unsigned st0 = s * per, st1 = st0 + per < steps ? st0 + per : steps;
+    f32x4 acc[4][4];                                  // [ib][jb]
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = splat4(0.f);
+    float sP = 1.f, iP = 1.f;
+    bool fresh = true;
+    for (unsigned st = st0 + wv; st < st1; st += 4) {
+        const unsigned m0 = st * 32 + 8 * g;
+        unsigned bb = m0 / tf;
+        const unsigned rem = m0 - bb * tf;
+        int t = (int)(rem / (unsigned)F), f = (int)(rem - (unsigned)t * F);
+        f32x4 av[4][2], bv[4][2];                     // [block][e >> 2][e & 3]
+        float mx = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned m = m0 + e;
+            const bool ok = m < M;
+            const int ts = t + dt, fs = f + df;
+            const bool inb = ok && ts >= 0 && ts < T && fs >= 0 && fs < F;
+            const long src = inb ? ((long)bb * T + ts) * F + fs : 0;
+            const long mm = ok ? m : M - 1;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                const float v = ok ? dz[mm * 64 + 16 * ib + c] : 0.f;
+                av[ib][e >> 2][e & 3] = v;
+                mx = fmaxf(mx, fabsf(v));
+            }
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const float v = a[src * 64 + 16 * jb + c];
+                bv[jb][e >> 2][e & 3] = inb ? v : 0.f;
+            }
+            if (++f == F) { f = 0; if (++t == T) { t = 0; ++bb; } }
+        }
+        mx = tx_wave_max(mx);
+        const float ms_ = mx * sP;
+        if (mx > 0.f && (fresh || ms_ > 8192.f || ms_ < 0.25f)) {          // wave-uniform, rare (see wgrad_partial64_x3_kernel)
+            float s2, i2;
+            tx_pow2(mx, s2, i2);
+            const float ratio = s2 * iP;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = acc[ib][jb] * splat4(ratio);
+            sP = s2; iP = i2; fresh = false;
+        }
+        f16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            split8(av[k][0] * splat4(sP), av[k][1] * splat4(sP), ah[k], al[k]);
+            split8(bv[k][0], bv[k][1], bh[k], bl[k]);
+        }
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma32h(ah[ib], bh[jb], acc[ib][jb]);
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma32l(ah[ib], bl[jb], acc[ib][jb]);
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma32l(al[ib], bh[jb], acc[ib][jb]);
+        }
+    }
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = acc[ib][jb] * splat4(iP);
+    auto put = [&](float* dst) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(16 * ib + 4 * g + r) * 64 + 16 * jb + c] = acc[ib][jb][r];
+    };
+    auto add = [&](const float* src) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ib][jb][r] += src[(16 * ib + 4 * g + r) * 64 + 16 * jb + c];
+    };
+    if (wv >= 2) put(red[wv - 2]);
+    __syncthreads();
+    if (wv < 2) add(red[wv]);
+    __syncthreads();
+    if (wv == 1) put(red[0]);
+    __syncthreads();
+    if (wv == 0) {
+        add(red[0]);
+        float* out = partial + ((long)tap * nsplit + s) * 4096;
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(16 * ib + 4 * g + r) * 64 + 16 * jb + c] = acc[ib][jb][r];
+    }
+}
+void launch_db_conv_wgrad_x3(LaunchCtx ctx, const float* dz, const float* a, int B, int T, int F, int dil, int nsplit,
+                             float* partial) {
+    LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_x3_kernel<<<dim3(6, nsplit), 256, 0, ctx.stream>>>(dz, a, B, T, F, dil,
+                                                                                                      nsplit, partial)));
+}
+
 // ---------------------------------------------------------------------------------
 // host side (called from train.hip's launch_ffn_train_* when TRAIN_X3 is on)
 // ---------------------------------------------------------------------------------
