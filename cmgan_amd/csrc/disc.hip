@@ -156,25 +156,79 @@ __global__ __launch_bounds__(256) void dc_conv_dgrad_kernel(const float* __restr
     }
 }
 
-// partial[s][tap][ci][co] = sum over the s-th chunk of output positions of dout[pos][co] * in[pos shifted by tap][ci]
+// partial[s][tap][ci][co] = sum over the s-th chunk of output positions of dout[pos][co] * in[pos shifted by tap][ci]:
+// the token contraction G = X_col^T dz (X_col = the im2col rows, m = tap * Ci + ci) as an LDS-tiled register-blocked
+// product.  A block owns MB rows x all Co columns of G (MB * Co = 8192 except for the first layer: 32 x 16) and one
+// chunk of DW_TP-position tiles; a thread owns RM x RN accumulators, the tile's im2col slice and dz rows are staged once
+// (consecutive m = consecutive (kf, ci) = consecutive floats of the input row) and read back as broadcast b128s.
+// (Round 2 had one thread per (ci, co) pair walking all positions: 43 ms per step at batch 32 for 7 GMAC.)
+#define DW_TP 32
+template <int RM, int RN>
 __global__ __launch_bounds__(256) void dc_conv_wgrad_kernel(const float* __restrict__ dout, const float* __restrict__ in,
-                                                            DcGeom gm, float* __restrict__ partial) {
-    const int tap = blockIdx.x, kt = tap >> 2, kf = tap & 3, s = blockIdx.z;
-    const int pair = blockIdx.y * 256 + threadIdx.x;
-    if (pair >= gm.Ci * gm.Co) return;
-    const int ci = pair / gm.Co, co = pair - ci * gm.Co;
+                                                            DcGeom gm, int MB, int lgCi, int tiles_total, int tiles_per_chunk,
+                                                            float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float xs[DW_TP * 256];       // [p][MB]
+    __shared__ __attribute__((aligned(16))) float dz[DW_TP * 128];       // [p][Co]
+    __shared__ int p_b[DW_TP], p_ti[DW_TP], p_fi[DW_TP];
+    const int tid = threadIdx.x, s = blockIdx.x, mg = blockIdx.y;
+    const int ncol = gm.Co / RN, tn = tid % ncol, tm = tid / ncol;
     const long P = (long)gm.B * gm.To * gm.Fo;
-    const long per = (P + DC_SPLIT - 1) / DC_SPLIT, p0 = (long)s * per, p1 = p0 + per < P ? p0 + per : P;
-    float acc = 0.f;
-    for (long pos = p0; pos < p1; ++pos) {
-        const int fo = (int)(pos % gm.Fo);
-        const long r = pos / gm.Fo;
-        const int to = (int)(r % gm.To), b = (int)(r / gm.To);
-        const int ti = 2 * to - 1 + kt, fi = 2 * fo - 1 + kf;
-        if (ti < 0 || ti >= gm.Ti || fi < 0 || fi >= gm.Fi) continue;
-        acc = fmaf(dout[pos * gm.Co + co], in[(((long)b * gm.Ti + ti) * gm.Fi + fi) * gm.Ci + ci], acc);
+    float acc[RM][RN];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = 0.f;
+    const int t_begin = s * tiles_per_chunk;
+    const int t_end = t_begin + tiles_per_chunk < tiles_total ? t_begin + tiles_per_chunk : tiles_total;
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const long p0 = (long)tile * DW_TP;
+        __syncthreads();                                              // the previous tile is consumed
+        if (tid < DW_TP) {
+            const long pos = p0 + tid;
+            int b = -1, ti = 0, fi = 0;
+            if (pos < P) {
+                const int fo = (int)(pos % gm.Fo);
+                const long r = pos / gm.Fo;
+                const int to = (int)(r % gm.To);
+                b = (int)(r / gm.To);
+                ti = 2 * to - 1;
+                fi = 2 * fo - 1;
+            }
+            p_b[tid] = b; p_ti[tid] = ti; p_fi[tid] = fi;
+        }
+        __syncthreads();
+        for (int e = tid; e < DW_TP * MB; e += 256) {
+            const int p = e / MB, ml = e - p * MB, m = mg * MB + ml;
+            const int tap = m >> lgCi, ci = m & (gm.Ci - 1);
+            const int b = p_b[p], ti = p_ti[p] + (tap >> 2), fi = p_fi[p] + (tap & 3);
+            float v = 0.f;
+            if (b >= 0 && ti >= 0 && ti < gm.Ti && fi >= 0 && fi < gm.Fi)
+                v = in[(((long)b * gm.Ti + ti) * gm.Fi + fi) * gm.Ci + ci];
+            xs[p * MB + ml] = v;
+        }
+        for (int e = tid; e < DW_TP * gm.Co; e += 256) {
+            const int p = e / gm.Co;
+            dz[e] = p_b[p] >= 0 ? dout[p0 * gm.Co + e] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < DW_TP; ++k) {
+            float xr[RM], dr[RN];
+#pragma unroll
+            for (int i = 0; i < RM; ++i) xr[i] = xs[k * MB + tm * RM + i];
+#pragma unroll
+            for (int j = 0; j < RN; ++j) dr[j] = dz[k * gm.Co + tn * RN + j];
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) acc[i][j] = fmaf(xr[i], dr[j], acc[i][j]);
+        }
     }
-    partial[(((long)s * 16 + tap) * gm.Ci + ci) * gm.Co + co] = acc;
+    float* out = partial + ((long)s * 16 * gm.Ci + (long)mg * MB + tm * RM) * gm.Co + tn * RN;
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) out[(long)i * gm.Co + j] = acc[i][j];
 }
 // G[e] = sum_s partial[s][e]
 __global__ void dc_reduce_kernel(const float* __restrict__ partial, int nsplit, long n, float* __restrict__ G) {
@@ -578,9 +632,26 @@ void launch_disc_backward(LaunchCtx ctx, const float* xy, const float* dscore, i
                                                                           ws + pl.rstd[i], p.norm_w[i], m1, m2)));
         const float* in = i == 0 ? xy : ws + pl.a[i - 1];
         const int nw = 16 * L.Ci * L.Co;
-        LAUNCH(ctx, "disc_conv_wgrad", (dc_conv_wgrad_kernel<<<dim3(16, (L.Ci * L.Co + 255) / 256, DC_SPLIT), 256, 0, st>>>(
-                                           g, in, gm, ws + pl.wpart)));
-        LAUNCH(ctx, "disc_conv_wgrad", (dc_reduce_kernel<<<(nw + 255) / 256, 256, 0, st>>>(ws + pl.wpart, DC_SPLIT, nw, ws + pl.G)));
+        {
+            // rows per block: MB * Co = 8192 (first layer: all 32 rows); chunks so that ~1024 blocks run and the partial
+            // slabs fit the DC_SPLIT * maxw floats of the workspace
+            const int Mtot = 16 * L.Ci, MB = Mtot < 8192 / L.Co ? Mtot : 8192 / L.Co, groups = Mtot / MB;
+            const int tiles_total = (int)(((long)B * P + DW_TP - 1) / DW_TP);
+            int ns = 1024 / groups;
+            const long cap = ((long)DC_SPLIT * 16 * 64 * 128) / nw;
+            if (ns > cap) ns = (int)cap;
+            if (ns > tiles_total) ns = tiles_total;
+            const int tpc = (tiles_total + ns - 1) / ns;
+            int lg = 0;
+            while ((1 << lg) < L.Ci) ++lg;
+            if (L.Ci * L.Co == 32)
+                LAUNCH(ctx, "disc_conv_wgrad", (dc_conv_wgrad_kernel<2, 1><<<dim3(ns, groups), 256, 0, st>>>(g, in, gm, MB, lg, tiles_total,
+                                                                                                          tpc, ws + pl.wpart)));
+            else
+                LAUNCH(ctx, "disc_conv_wgrad", (dc_conv_wgrad_kernel<8, 4><<<dim3(ns, groups), 256, 0, st>>>(g, in, gm, MB, lg, tiles_total,
+                                                                                                          tpc, ws + pl.wpart)));
+            LAUNCH(ctx, "disc_conv_wgrad", (dc_reduce_kernel<<<(nw + 255) / 256, 256, 0, st>>>(ws + pl.wpart, ns, nw, ws + pl.G)));
+        }
         LAUNCH(ctx, "disc_spectral_norm", (sn_conv_finish_kernel<<<1, 1024, 0, st>>>(ws + pl.G, ws + pl.wf[i], L.Co, L.Ci, ws + pl.uu[i],
                                                                                     ws + pl.vv[i], ws + pl.sigma + i, grad.conv_w[i])));
         float* din = i == 0 ? dxy : ws + pl.g[i - 1];
