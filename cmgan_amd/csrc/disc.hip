@@ -34,57 +34,51 @@ __device__ __forceinline__ float dc_block_sum(float v, float* red) {
     return r;
 }
 
-// one block of 256 threads; W [out, K] row-major (out <= 128, K <= 1024)
-__global__ __launch_bounds__(256) void sn_power_kernel(const float* __restrict__ W, int out, int K, float* __restrict__ u_state,
-                                                       float* __restrict__ v_state, int update, float* __restrict__ u_used,
-                                                       float* __restrict__ v_used, float* __restrict__ sigma) {
-    __shared__ float su[128], sv[1024], swv[128], red[256];
-    const int t = threadIdx.x;
-    for (int o = t; o < out; o += 256) su[o] = u_state[o];
-    for (int k = t; k < K; k += 256) sv[k] = v_state[k];
+// one block of 1024 threads; W [out, K] row-major (out <= 128, K <= 1024).  W^T u: one column per thread (coalesced
+// rows); W v: one row per wave at a time with a DPP wave reduction - no block barrier per row (the 256-thread form with
+// a block reduction per row took ~100 us per launch, 18 launches per step).
+__global__ __launch_bounds__(1024) void sn_power_kernel(const float* __restrict__ W, int out, int K, float* __restrict__ u_state,
+                                                        float* __restrict__ v_state, int update, float* __restrict__ u_used,
+                                                        float* __restrict__ v_used, float* __restrict__ sigma) {
+    __shared__ float su[128], sv[1024], swv[128], red[1024];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t < out) su[t] = u_state[t];
+    if (t < K) sv[t] = v_state[t];
     __syncthreads();
     if (update) {
-        float part = 0.f;
-        float mine[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = t + 256 * q;
-            float s = 0.f;
-            if (k < K)
-                for (int o = 0; o < out; ++o) s = fmaf(W[(long)o * K + k], su[o], s);
-            mine[q] = s;
-            part = fmaf(s, s, part);
+        float mine = 0.f;
+        if (t < K) {
+            float s0 = 0.f, s1 = 0.f;
+            int o = 0;
+            for (; o + 1 < out; o += 2) {
+                s0 = fmaf(W[(long)o * K + t], su[o], s0);
+                s1 = fmaf(W[(long)(o + 1) * K + t], su[o + 1], s1);
+            }
+            if (o < out) s0 = fmaf(W[(long)o * K + t], su[o], s0);
+            mine = s0 + s1;
         }
-        const float nrm = sqrtf(dc_block_sum(part, red));
+        const float nrm = sqrtf(dc_block_sum(mine * mine, red));
         const float inv = 1.0f / fmaxf(nrm, 1e-12f);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = t + 256 * q;
-            if (k < K) sv[k] = mine[q] * inv;
-        }
+        if (t < K) sv[t] = mine * inv;
         __syncthreads();
     }
-    for (int o = 0; o < out; ++o) {
+    for (int o = wv; o < out; o += 16) {
         float s = 0.f;
-        for (int k = t; k < K; k += 256) s = fmaf(W[(long)o * K + k], sv[k], s);
-        const float r = dc_block_sum(s, red);
-        if (t == 0) swv[o] = r;
+        for (int k = lane; k < K; k += 64) s = fmaf(W[(long)o * K + k], sv[k], s);
+        s = wave_sum(s);
+        if (lane == 0) swv[o] = s;
     }
     __syncthreads();
     if (update) {
-        float part = 0.f;
-        for (int o = t; o < out; o += 256) part = fmaf(swv[o], swv[o], part);
-        const float nrm = sqrtf(dc_block_sum(part, red));
+        const float nrm = sqrtf(dc_block_sum(t < out ? swv[t] * swv[t] : 0.f, red));
         const float inv = 1.0f / fmaxf(nrm, 1e-12f);
-        for (int o = t; o < out; o += 256) su[o] = swv[o] * inv;
+        if (t < out) su[t] = swv[t] * inv;
         __syncthreads();
     }
-    float part = 0.f;
-    for (int o = t; o < out; o += 256) part = fmaf(su[o], swv[o], part);
-    const float sg = dc_block_sum(part, red);
+    const float sg = dc_block_sum(t < out ? su[t] * swv[t] : 0.f, red);
     if (t == 0) sigma[0] = sg;
-    for (int o = t; o < out; o += 256) { u_used[o] = su[o]; if (update) u_state[o] = su[o]; }
-    for (int k = t; k < K; k += 256) { v_used[k] = sv[k]; if (update) v_state[k] = sv[k]; }
+    if (t < out) { u_used[t] = su[t]; if (update) u_state[t] = su[t]; }
+    if (t < K) { v_used[t] = sv[t]; if (update) v_state[t] = sv[t]; }
 }
 
 // effective conv weights W / sigma in the two thread-friendly layouts: wf [tap][ci][co], wb [tap][co][ci]
@@ -102,58 +96,120 @@ __global__ void dc_pack_kernel(const float* __restrict__ W, int Co, int Ci, cons
 // ---- 4x4 stride-2 pad-1 convolution ----------------------------------------------------------------------------------
 struct DcGeom { int B, Ti, Fi, Ci, To, Fo, Co; };
 
-__global__ __launch_bounds__(256) void dc_conv_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wf, DcGeom gm,
-                                                          float* __restrict__ out) {
-    const long total = (long)gm.B * gm.To * gm.Fo * gm.Co;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int co = (int)(idx % gm.Co);
-        long pos = idx / gm.Co;
-        const int fo = (int)(pos % gm.Fo); pos /= gm.Fo;
-        const int to = (int)(pos % gm.To);
-        const int b = (int)(pos / gm.To);
-        float acc = 0.f;
-        for (int kt = 0; kt < 4; ++kt) {
-            const int ti = 2 * to - 1 + kt;
-            if (ti < 0 || ti >= gm.Ti) continue;
-            for (int kf = 0; kf < 4; ++kf) {
-                const int fi = 2 * fo - 1 + kf;
-                if (fi < 0 || fi >= gm.Fi) continue;
-                const float* ip = in + (((long)b * gm.Ti + ti) * gm.Fi + fi) * gm.Ci;
-                const float* wp = wf + ((long)(kt * 4 + kf) * gm.Ci) * gm.Co + co;
-                for (int ci = 0; ci < gm.Ci; ++ci) acc = fmaf(ip[ci], wp[(long)ci * gm.Co], acc);
-            }
+// Forward convolution and data gradient as one LDS-tiled register-blocked GEMM over gathered rows:
+//   MODE 0 (forward):  out[pos][co] = sum_m xcol[pos][m] wf[m][co],  m = tap * Ci + ci  (K = 16 Ci, N = Co), pos = (b, to, fo)
+//   MODE 1 (dgrad):    din[pos][ci] = sum_m dcol[pos][m] wb[row(m)][ci], m = j * Co + co (K = 4 Co, N = Ci): an input
+//                      position (ti, fi) = (2a + rt, 2c + rf) receives the 2 x 2 taps kt = 1 - rt + 2 jt, kf = 1 - rf + 2 jf
+//                      from the outputs (a + rt - jt, c + rf - jf); blockIdx.y = the parity class (rt, rf), pos = (b, a, c)
+// A block owns TPF positions x all N columns (TPF * N = 4096), a thread RP positions x RN columns; K is walked in chunks of KC
+// rows staged once per chunk (consecutive m = consecutive floats of the source row).  (Round 2: one thread per output
+// element, 9 ms per step at batch 32 for 10 GMAC.)
+template <int MODE, int TPF, int RP, int RN, int KC>
+__global__ __launch_bounds__(256) void dc_conv_gemm_kernel(const float* __restrict__ src, const float* __restrict__ wmat, DcGeom gm,
+                                                           int lgC, float* __restrict__ dst) {
+    __shared__ __attribute__((aligned(16))) float xs[TPF * (KC + 1)];
+    __shared__ __attribute__((aligned(16))) float wsm[KC * 128];
+    __shared__ int p_b[TPF], p_x[TPF], p_y[TPF];
+    const int tid = threadIdx.x;
+    const int N = MODE == 0 ? gm.Co : gm.Ci, Kt = MODE == 0 ? 16 * gm.Ci : 4 * gm.Co, C = 1 << lgC;
+    const int rt = MODE == 1 ? (int)(blockIdx.y >> 1) : 0, rf = MODE == 1 ? (int)(blockIdx.y & 1) : 0;
+    const int X = MODE == 0 ? gm.To : (gm.Ti - rt + 1) / 2, Y = MODE == 0 ? gm.Fo : (gm.Fi - rf + 1) / 2;
+    const long P = (long)gm.B * X * Y, p0 = (long)blockIdx.x * TPF;
+    if (p0 >= P) return;
+    for (int p = tid; p < TPF; p += 256) {
+        const long pos = p0 + p;
+        int b = -1, x = 0, y = 0;
+        if (pos < P) {
+            y = (int)(pos % Y);
+            const long r = pos / Y;
+            x = (int)(r % X);
+            b = (int)(r / X);
         }
-        out[idx] = acc;
+        p_b[p] = b; p_x[p] = x; p_y[p] = y;
+    }
+    const int ncol = N / RN, tn = tid % ncol, tp = tid / ncol;
+    float acc[RP][RN];
+#pragma unroll
+    for (int i = 0; i < RP; ++i)
+#pragma unroll
+        for (int j = 0; j < RN; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < Kt; k0 += KC) {
+        __syncthreads();                                          // position table ready / previous chunk consumed
+        for (int e = tid; e < TPF * KC; e += 256) {
+            const int p = e / KC, kk = e - p * KC, m = k0 + kk;
+            const int hi = m >> lgC, ch = m & (C - 1);            // tap | 2x2 tap index, channel
+            const int b = p_b[p];
+            float v = 0.f;
+            if (MODE == 0) {
+                const int ti = 2 * p_x[p] - 1 + (hi >> 2), fi = 2 * p_y[p] - 1 + (hi & 3);
+                if (b >= 0 && ti >= 0 && ti < gm.Ti && fi >= 0 && fi < gm.Fi)
+                    v = src[(((long)b * gm.Ti + ti) * gm.Fi + fi) * gm.Ci + ch];
+            } else {
+                const int to = p_x[p] + rt - (hi >> 1), fo = p_y[p] + rf - (hi & 1);
+                if (b >= 0 && to >= 0 && to < gm.To && fo >= 0 && fo < gm.Fo)
+                    v = src[(((long)b * gm.To + to) * gm.Fo + fo) * gm.Co + ch];
+            }
+            xs[p * (KC + 1) + kk] = v;
+        }
+        for (int e = tid; e < KC * N; e += 256) {
+            const int kk = e / N, n = e - kk * N, m = k0 + kk;
+            long row = m;
+            if (MODE == 1) {
+                const int j = m >> lgC, co = m & (C - 1);
+                row = (long)((1 - rt + 2 * (j >> 1)) * 4 + (1 - rf + 2 * (j & 1))) * gm.Co + co;
+            }
+            wsm[kk * N + n] = wmat[row * N + n];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < KC; ++k) {
+            float xr[RP], wr[RN];
+#pragma unroll
+            for (int i = 0; i < RP; ++i) xr[i] = xs[(tp * RP + i) * (KC + 1) + k];
+#pragma unroll
+            for (int j = 0; j < RN; ++j) wr[j] = wsm[k * N + tn * RN + j];
+#pragma unroll
+            for (int i = 0; i < RP; ++i)
+#pragma unroll
+                for (int j = 0; j < RN; ++j) acc[i][j] = fmaf(xr[i], wr[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+        const int p = tp * RP + i, b = p_b[p];
+        if (b < 0) continue;
+        long o;
+        if (MODE == 0) o = (p0 + p) * gm.Co;
+        else o = (((long)b * gm.Ti + 2 * p_x[p] + rt) * gm.Fi + 2 * p_y[p] + rf) * gm.Ci;
+#pragma unroll
+        for (int j = 0; j < RN; ++j) dst[o + tn * RN + j] = acc[i][j];
     }
 }
 
-__global__ __launch_bounds__(256) void dc_conv_dgrad_kernel(const float* __restrict__ dout, const float* __restrict__ wb,
-                                                            DcGeom gm, float* __restrict__ din) {
-    const long total = (long)gm.B * gm.Ti * gm.Fi * gm.Ci;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int ci = (int)(idx % gm.Ci);
-        long pos = idx / gm.Ci;
-        const int fi = (int)(pos % gm.Fi); pos /= gm.Fi;
-        const int ti = (int)(pos % gm.Ti);
-        const int b = (int)(pos / gm.Ti);
-        float acc = 0.f;
-        for (int kt = 0; kt < 4; ++kt) {
-            const int tn = ti + 1 - kt;
-            if (tn < 0 || (tn & 1)) continue;
-            const int to = tn >> 1;
-            if (to >= gm.To) continue;
-            for (int kf = 0; kf < 4; ++kf) {
-                const int fn = fi + 1 - kf;
-                if (fn < 0 || (fn & 1)) continue;
-                const int fo = fn >> 1;
-                if (fo >= gm.Fo) continue;
-                const float* op = dout + (((long)b * gm.To + to) * gm.Fo + fo) * gm.Co;
-                const float* wp = wb + ((long)(kt * 4 + kf) * gm.Co) * gm.Ci + ci;
-                for (int co = 0; co < gm.Co; ++co) acc = fmaf(op[co], wp[(long)co * gm.Ci], acc);
-            }
-        }
-        din[idx] = acc;
-    }
+// tile shapes per layer (TPF * N = 4096; the two-channel data gradient of the first layer: 512 x 2)
+static void dc_launch_fwd(LaunchCtx ctx, const float* in, const float* wf, const DcGeom& gm, float* out) {
+    const long P = (long)gm.B * gm.To * gm.Fo;
+    int lg = 0;
+    while ((1 << lg) < gm.Ci) ++lg;
+    hipStream_t st = ctx.stream;
+#define DC_FWD(TPF) LAUNCH(ctx, "disc_conv_fwd", (dc_conv_gemm_kernel<0, TPF, 4, 4, 32><<<(unsigned)((P + TPF - 1) / TPF), 256, 0, st>>>(in, wf, gm, lg, out)))
+    if (gm.Co == 16) DC_FWD(256);
+    else if (gm.Co == 32) DC_FWD(128);
+    else if (gm.Co == 64) DC_FWD(64);
+    else DC_FWD(32);
+#undef DC_FWD
+}
+static void dc_launch_dgrad(LaunchCtx ctx, const float* dout, const float* wb, const DcGeom& gm, float* din) {
+    const long P = (long)gm.B * ((gm.Ti + 1) / 2) * ((gm.Fi + 1) / 2);   // the largest parity class
+    int lg = 0;
+    while ((1 << lg) < gm.Co) ++lg;
+    hipStream_t st = ctx.stream;
+#define DC_DG(TPF, RP, RN, KC) LAUNCH(ctx, "disc_conv_bwd", (dc_conv_gemm_kernel<1, TPF, RP, RN, KC><<<dim3((unsigned)((P + TPF - 1) / TPF), 4), 256, 0, st>>>(dout, wb, gm, lg, din)))
+    if (gm.Ci == 2) DC_DG(512, 2, 2, 16);
+    else if (gm.Ci == 16) DC_DG(256, 4, 4, 32);
+    else if (gm.Ci == 32) DC_DG(128, 4, 4, 32);
+    else DC_DG(64, 4, 4, 32);
+#undef DC_DG
 }
 
 // partial[s][tap][ci][co] = sum over the s-th chunk of output positions of dout[pos][co] * in[pos shifted by tap][ci]:
@@ -570,7 +626,7 @@ void launch_disc_forward(LaunchCtx ctx, const float* xy, int B, int T, int F, co
     for (int i = 0; i < 4; ++i) {
         const DcLayer& L = pl.L[i];
         const DcGeom gm{B, L.Ti, L.Fi, L.Ci, L.To, L.Fo, L.Co};
-        LAUNCH(ctx, "disc_spectral_norm", (sn_power_kernel<<<1, 256, 0, st>>>(p.conv_w[i], L.Co, L.Ci * 16, p.conv_u[i], p.conv_v[i],
+        LAUNCH(ctx, "disc_spectral_norm", (sn_power_kernel<<<1, 1024, 0, st>>>(p.conv_w[i], L.Co, L.Ci * 16, p.conv_u[i], p.conv_v[i],
                                                                              update_uv, ws + pl.uu[i], ws + pl.vv[i],
                                                                              ws + pl.sigma + i)));
         const int nw = 16 * L.Ci * L.Co;
@@ -579,7 +635,7 @@ void launch_disc_forward(LaunchCtx ctx, const float* xy, int B, int T, int F, co
         const long total = (long)B * L.To * L.Fo * L.Co;
         const int P = L.To * L.Fo;
         const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        LAUNCH(ctx, "disc_conv_fwd", (dc_conv_fwd_kernel<<<grid, 256, 0, st>>>(in, ws + pl.wf[i], gm, ws + pl.z[i])));
+        dc_launch_fwd(ctx, in, ws + pl.wf[i], gm, ws + pl.z[i]);
         LAUNCH(ctx, "disc_norm", (gin_sums_kernel<0><<<dim3(B, DC_NCH), 256, 0, st>>>(ws + pl.z[i], nullptr, P, L.Co, nullptr, nullptr,
                                                                                      nullptr, nullptr, nullptr, ws + pl.part)));
         LAUNCH(ctx, "disc_norm", (gin_stats_finalize_kernel<<<(B * L.Co + 255) / 256, 256, 0, st>>>(ws + pl.part, B, L.Co, (double)P,
@@ -591,9 +647,9 @@ void launch_disc_forward(LaunchCtx ctx, const float* xy, int B, int T, int F, co
     }
     const int P4 = pl.L[3].To * pl.L[3].Fo;
     LAUNCH(ctx, "disc_head", (dc_maxpool_kernel<<<B, 128, 0, st>>>(ws + pl.a[3], P4, ws + pl.pooled, (int*)(ws + pl.idx))));
-    LAUNCH(ctx, "disc_spectral_norm", (sn_power_kernel<<<1, 256, 0, st>>>(p.fc1_w, 64, 128, p.fc1_u, p.fc1_v, update_uv, ws + pl.uu[4],
+    LAUNCH(ctx, "disc_spectral_norm", (sn_power_kernel<<<1, 1024, 0, st>>>(p.fc1_w, 64, 128, p.fc1_u, p.fc1_v, update_uv, ws + pl.uu[4],
                                                                          ws + pl.vv[4], ws + pl.sigma + 4)));
-    LAUNCH(ctx, "disc_spectral_norm", (sn_power_kernel<<<1, 256, 0, st>>>(p.fc2_w, 1, 64, p.fc2_u, p.fc2_v, update_uv, ws + pl.uu[5],
+    LAUNCH(ctx, "disc_spectral_norm", (sn_power_kernel<<<1, 1024, 0, st>>>(p.fc2_w, 1, 64, p.fc2_u, p.fc2_v, update_uv, ws + pl.uu[5],
                                                                          ws + pl.vv[5], ws + pl.sigma + 5)));
     LAUNCH(ctx, "disc_head", (dc_head_fwd_kernel<<<B, 64, 0, st>>>(ws + pl.pooled, dc_head(p, ws, pl), mask, ws + pl.h1, ws + pl.x2,
                                                                   score)));
@@ -656,9 +712,7 @@ void launch_disc_backward(LaunchCtx ctx, const float* xy, const float* dscore, i
                                                                                     ws + pl.vv[i], ws + pl.sigma + i, grad.conv_w[i])));
         float* din = i == 0 ? dxy : ws + pl.g[i - 1];
         if (din) {
-            const long tin = (long)B * L.Ti * L.Fi * L.Ci;
-            const unsigned gin = (unsigned)((tin + 255) / 256 < 4096 ? (tin + 255) / 256 : 4096);
-            LAUNCH(ctx, "disc_conv_bwd", (dc_conv_dgrad_kernel<<<gin, 256, 0, st>>>(g, ws + pl.wb[i], gm, din)));
+            dc_launch_dgrad(ctx, g, ws + pl.wb[i], gm, din);
         }
     }
 }
