@@ -781,51 +781,99 @@ __global__ __launch_bounds__(256) void cm_pw1glu_kernel(const float* __restrict_
     }
 }
 
+// Staging of one 32-position tile of a [N, L, 128] tensor for the depthwise kernels: the 62 rows l0 - 15 .. l0 + 46
+// (zero outside [0, L)) as 16-byte loads - 8 per thread, coalesced 512-byte rows - held in registers one tile ahead and
+// dropped into LDS when the previous tile has been consumed.  (Round 2 had every thread fetch its 46 window values as
+// scalar loads, 2.9 x halo re-read, one tile in flight per block: 56 / 174 us per launch at batch 4 against a
+// bandwidth floor of ~27 us.)
+#define CMD_ROWS 62
+struct CmWin { f32x4 r[8]; };
+__device__ __forceinline__ void cm_win_load(const float* __restrict__ src, long n, int L, int l0, int tid, CmWin& w) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = tid + 256 * k;
+        const int rr = i < CMD_ROWS * 32 ? (i >> 5) : CMD_ROWS - 1;
+        const int l = l0 - 15 + rr, lc = l < 0 ? 0 : (l < L ? l : L - 1);
+        f32x4 v = ldg4(src + (n * L + lc) * 128 + (i & 31) * 4);
+        if (l < 0 || l >= L) v = splat4(0.f);
+        w.r[k] = v;
+    }
+}
+__device__ __forceinline__ void cm_win_store(float* win, int tid, const CmWin& w) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int i = tid + 256 * k;
+        if (i < CMD_ROWS * 32) *reinterpret_cast<f32x4*>(win + (i >> 5) * 128 + (i & 31) * 4) = w.r[k];
+    }
+}
+
 // out[(n,l)][ch] = bias[ch] + sum_t taps[ch][flip ? 30 - t : t] * in[(n, l + t - 15)][ch], zero outside [0, L).
 // flip = 0: the forward depthwise conv; flip = 1 (bias = NULL): its gradient w.r.t. the input.
+// A block walks `tpb` consecutive (sequence, 32-position) tiles; thread = (channel, 16-output half tile).
 // stats (forward only): per block and channel (sum, sum of squares) of the outputs -> partial [blk][128][2].
 __global__ __launch_bounds__(256) void cm_depthwise_kernel(const float* __restrict__ in, const float* __restrict__ taps,
-                                                           const float* __restrict__ bias, int flip, int L,
-                                                           float* __restrict__ out, float* __restrict__ stats) {
-    __shared__ float red[2][128][2];
-    const int ch = threadIdx.x & 127, sub = threadIdx.x >> 7;
-    const int n = blockIdx.x, l0 = blockIdx.y * 32 + sub * 16;
+                                                           const float* __restrict__ bias, int flip, int L, int ntile_l,
+                                                           long ntile, int tpb, float* __restrict__ out,
+                                                           float* __restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) float win[CMD_ROWS * 128];
+    __shared__ float tl[128 * 31];
+    const int tid = threadIdx.x, ch = tid & 127, sub = tid >> 7;
+    const long t_begin = (long)blockIdx.x * tpb, t_end = t_begin + tpb < ntile ? t_begin + tpb : ntile;
+    for (int i = tid; i < 128 * 31; i += 256) tl[i] = taps[i];
+    CmWin pre;
+    if (t_begin < t_end) {
+        const long n = t_begin / ntile_l;
+        cm_win_load(in, n, L, (int)(t_begin - n * ntile_l) * 32, tid, pre);
+    }
+    __syncthreads();
     float w[31];
 #pragma unroll
-    for (int t = 0; t < 31; ++t) w[t] = taps[ch * 31 + (flip ? 30 - t : t)];
+    for (int t = 0; t < 31; ++t) w[t] = tl[ch * 31 + (flip ? 30 - t : t)];
     const float b = bias ? bias[ch] : 0.f;
-    float acc[16];
-#pragma unroll
-    for (int oo = 0; oo < 16; ++oo) acc[oo] = b;
-    const float* base = in + (long)n * L * 128 + ch;
-#pragma unroll
-    for (int kk = 0; kk < 46; ++kk) {
-        const int l = l0 - 15 + kk;
-        const float v = (l >= 0 && l < L) ? base[(long)l * 128] : 0.f;
-#pragma unroll
-        for (int oo = 0; oo < 16; ++oo) {
-            const int t = kk - oo;
-            if (t >= 0 && t < 31) acc[oo] = fmaf(w[t], v, acc[oo]);
-        }
-    }
     float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int oo = 0; oo < 16; ++oo) {
-        const int l = l0 + oo;
-        if (l < L) {
-            out[((long)n * L + l) * 128 + ch] = acc[oo];
-            s1 += acc[oo];
-            s2 = fmaf(acc[oo], acc[oo], s2);
+    const float* ucol = win + sub * 16 * 128 + ch;
+    for (long tile = t_begin; tile < t_end; ++tile) {
+        const long n = tile / ntile_l;
+        const int l0 = (int)(tile - n * ntile_l) * 32 + sub * 16;
+        cm_win_store(win, tid, pre);
+        __syncthreads();
+        if (tile + 1 < t_end) {
+            const long n1 = (tile + 1) / ntile_l;
+            cm_win_load(in, n1, L, (int)(tile + 1 - n1 * ntile_l) * 32, tid, pre);
         }
+        if (l0 < L) {
+            float acc[16];
+#pragma unroll
+            for (int oo = 0; oo < 16; ++oo) acc[oo] = b;
+#pragma unroll
+            for (int kk = 0; kk < 46; ++kk) {
+                const float v = ucol[kk * 128];
+#pragma unroll
+                for (int oo = 0; oo < 16; ++oo) {
+                    const int t = kk - oo;
+                    if (t >= 0 && t < 31) acc[oo] = fmaf(w[t], v, acc[oo]);
+                }
+            }
+#pragma unroll
+            for (int oo = 0; oo < 16; ++oo) {
+                const int l = l0 + oo;
+                if (l < L) {
+                    out[(n * L + l) * 128 + ch] = acc[oo];
+                    s1 += acc[oo];
+                    s2 = fmaf(acc[oo], acc[oo], s2);
+                }
+            }
+        }
+        __syncthreads();                                          // the window is free for the next tile
     }
     if (stats) {
-        red[sub][ch][0] = s1;
-        red[sub][ch][1] = s2;
+        float* red = win;                                         // [2][128][2]
+        red[(sub * 128 + ch) * 2 + 0] = s1;
+        red[(sub * 128 + ch) * 2 + 1] = s2;
         __syncthreads();
         if (sub == 0) {
-            const long blk = (long)blockIdx.x * gridDim.y + blockIdx.y;
-            stats[(blk * 128 + ch) * 2 + 0] = red[0][ch][0] + red[1][ch][0];
-            stats[(blk * 128 + ch) * 2 + 1] = red[0][ch][1] + red[1][ch][1];
+            stats[((long)blockIdx.x * 128 + ch) * 2 + 0] = red[ch * 2] + red[(128 + ch) * 2];
+            stats[((long)blockIdx.x * 128 + ch) * 2 + 1] = red[ch * 2 + 1] + red[(128 + ch) * 2 + 1];
         }
     }
 }
@@ -947,36 +995,52 @@ __global__ __launch_bounds__(256) void cm_bn_bwd_kernel(float* __restrict__ ddn,
 }
 
 // depthwise weight gradient: dw[ch][t] = sum_{n,l} dd[(n,l)][ch] u[(n, l + t - 15)][ch] -> partial [blk][128*31].
-// At most CM_DW_SLABS blocks walk the (sequence, 32-token tile) list with a fixed stride and keep their 31 taps in
-// registers across tiles, so the second-stage reduction reads a few hundred slabs instead of one per tile.
-#define CM_DW_SLABS 512
+// At most CM_DW_SLABS blocks each walk `tpb` consecutive (sequence, 32-token) tiles and keep their 31 taps in registers
+// across tiles, so the second-stage reduction reads a few hundred slabs instead of one per tile; the u window and the
+// dd rows of a tile are staged through LDS one tile ahead (cm_win_load).
+#define CM_DW_SLABS 768
 __global__ __launch_bounds__(256) void cm_dw_wgrad_kernel(const float* __restrict__ dd, const float* __restrict__ u, int L,
-                                                          int ntile_l, long ntile, float* __restrict__ partial) {
-    __shared__ float red[128 * 31];
-    const int ch = threadIdx.x & 127, sub = threadIdx.x >> 7;
+                                                          int ntile_l, long ntile, int tpb, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float win[CMD_ROWS * 128];
+    __shared__ __attribute__((aligned(16))) float dt[32 * 128];
+    const int tid = threadIdx.x, ch = tid & 127, sub = tid >> 7;
+    const long t_begin = (long)blockIdx.x * tpb, t_end = t_begin + tpb < ntile ? t_begin + tpb : ntile;
     float acc[31];
 #pragma unroll
     for (int t = 0; t < 31; ++t) acc[t] = 0.f;
-    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    CmWin pre;
+    f32x4 pd[4];
+    auto load_dd = [&](long tile) {
         const long n = tile / ntile_l;
-        const int l0 = (int)(tile - n * ntile_l) * 32 + sub * 16;
-        const float* ub = u + n * L * 128 + ch;
-        const float* db = dd + n * L * 128 + ch;
-        // unconditional (clamped) loads + selects, and tap-major loops with compile-time indices only: the
-        // output-major form with `acc[kk - oo]` left the 46-step loop rolled and indexed registers dynamically
+        const int l0 = (int)(tile - n * ntile_l) * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + 256 * k, l = l0 + (i >> 5), lc = l < L ? l : L - 1;
+            f32x4 v = ldg4(dd + (n * L + lc) * 128 + (i & 31) * 4);
+            if (l >= L) v = splat4(0.f);
+            pd[k] = v;
+        }
+        cm_win_load(u, n, L, l0, tid, pre);
+    };
+    if (t_begin < t_end) load_dd(t_begin);
+    const float* ucol = win + sub * 16 * 128 + ch;
+    const float* dcol = dt + sub * 16 * 128 + ch;
+    for (long tile = t_begin; tile < t_end; ++tile) {
+        cm_win_store(win, tid, pre);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + 256 * k;
+            *reinterpret_cast<f32x4*>(dt + (i >> 5) * 128 + (i & 31) * 4) = pd[k];
+        }
+        __syncthreads();
+        if (tile + 1 < t_end) load_dd(tile + 1);
+        // tap-major loops with compile-time indices only: the output-major form with `acc[kk - oo]` left the 46-step
+        // loop rolled and indexed registers dynamically
         float g[16], uw[46];
 #pragma unroll
-        for (int oo = 0; oo < 16; ++oo) {
-            const int l = l0 + oo, lc = l < L ? l : L - 1;
-            const float v = db[(long)lc * 128];
-            g[oo] = l < L ? v : 0.f;
-        }
+        for (int oo = 0; oo < 16; ++oo) g[oo] = dcol[oo * 128];
 #pragma unroll
-        for (int kk = 0; kk < 46; ++kk) {
-            const int l = l0 - 15 + kk, lc = l < 0 ? 0 : (l < L ? l : L - 1);
-            const float v = ub[(long)lc * 128];
-            uw[kk] = (l >= 0 && l < L) ? v : 0.f;
-        }
+        for (int kk = 0; kk < 46; ++kk) uw[kk] = ucol[kk * 128];
 #pragma unroll
         for (int t = 0; t < 31; ++t) {
             float a = acc[t];
@@ -984,7 +1048,9 @@ __global__ __launch_bounds__(256) void cm_dw_wgrad_kernel(const float* __restric
             for (int oo = 0; oo < 16; ++oo) a = fmaf(g[oo], uw[oo + t], a);
             acc[t] = a;
         }
+        __syncthreads();
     }
+    float* red = win;                                             // [128 * 31] of the 62 x 128 window
     if (sub == 1) {
 #pragma unroll
         for (int t = 0; t < 31; ++t) red[ch * 31 + t] = acc[t];
@@ -1075,6 +1141,10 @@ __global__ __launch_bounds__(256) void cm_bwd2_kernel(const float* __restrict__ 
     }
 }
 
+// tiles per block of the depthwise kernels: at most `cap` blocks (three 48 KB blocks fit a CU: 768 per round)
+#define CM_DW_BLOCKS 1536
+static int cm_dw_tpb(long ntile, int cap) { return (int)((ntile + cap - 1) / cap); }
+
 // workspace layout (floats): images | u | d | stats (4 x 128) | bwd buffers | partials
 struct CmPlan {
     size_t img, u, d, st, ddn, s, g2, du, dag, xn, g1, dxn, wpart, dwpart, bnpart, bnred, cpart, sums, total;
@@ -1118,11 +1188,12 @@ void launch_convmod_train_forward(LaunchCtx ctx, const float* x, int N, int L, c
     const unsigned grid = (unsigned)((M + 63) / 64);
     const dim3 dgrid(N, (L + 31) / 32);
     LAUNCH(ctx, "convmod_train_fwd", (cm_pw1glu_kernel<<<grid, 256, 0, s>>>(x, M, im.w1, p, ws + pl.u)));
-    LAUNCH(ctx, "convmod_train_fwd", (cm_depthwise_kernel<<<dgrid, 256, 0, s>>>(ws + pl.u, p.dw_w, p.dw_b, 0, L, ws + pl.d,
-                                                                                ws + pl.bnpart)));
+    const long ntile = (long)dgrid.x * dgrid.y;
+    const int tpb = cm_dw_tpb(ntile, CM_DW_BLOCKS), dblocks = (int)((ntile + tpb - 1) / tpb);
+    LAUNCH(ctx, "convmod_train_fwd", (cm_depthwise_kernel<<<dblocks, 256, 0, s>>>(ws + pl.u, p.dw_w, p.dw_b, 0, L, (int)dgrid.y, ntile,
+                                                                                  tpb, ws + pl.d, ws + pl.bnpart)));
     double* bnred = (double*)(ws + pl.bnred);
-    LAUNCH(ctx, "convmod_train_fwd", (cm_bn_reduce_kernel<<<CM_BN_RED, 256, 0, s>>>(ws + pl.bnpart, (long)dgrid.x * dgrid.y,
-                                                                                    bnred)));
+    LAUNCH(ctx, "convmod_train_fwd", (cm_bn_reduce_kernel<<<CM_BN_RED, 256, 0, s>>>(ws + pl.bnpart, (long)dblocks, bnred)));
     LAUNCH(ctx, "convmod_train_fwd", (cm_bn_finalize_kernel<<<1, 128, 0, s>>>(bnred, (double)M, p.bn_w, p.bn_b, st,
                                                                               running_mean, running_var)));
     LAUNCH(ctx, "convmod_train_fwd", (cm_bn_swish_pw2_kernel<<<grid, 256, 0, s>>>(ws + pl.d, M, st, im.w2, p.pw2_b, res, y)));
@@ -1164,12 +1235,15 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     float* dd = ws + pl.ddn;
     // depthwise: bias / weight gradients, then the data gradient (same kernel, flipped taps)
     colsum(dd, 128, grad.dw_b);
-    const int nslab = (int)(nblk < CM_DW_SLABS ? nblk : CM_DW_SLABS);
-    LAUNCH(ctx, "convmod_train_wgrad", (cm_dw_wgrad_kernel<<<nslab, 256, 0, s>>>(dd, ws + pl.u, L, (int)dgrid.y, nblk,
+    const int wtpb = cm_dw_tpb(nblk, CM_DW_SLABS), nslab = (int)((nblk + wtpb - 1) / wtpb);
+    LAUNCH(ctx, "convmod_train_wgrad", (cm_dw_wgrad_kernel<<<nslab, 256, 0, s>>>(dd, ws + pl.u, L, (int)dgrid.y, nblk, wtpb,
                                                                                  ws + pl.dwpart)));
     LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<62, 1024, 0, s>>>(ws + pl.dwpart, nslab, 3968, grad.dw_w)));
-    LAUNCH(ctx, "convmod_train_bwd", (cm_depthwise_kernel<<<dgrid, 256, 0, s>>>(dd, p.dw_w, nullptr, 1, L, ws + pl.du,
-                                                                                nullptr)));
+    {
+        const int tpb = cm_dw_tpb(nblk, CM_DW_BLOCKS), dblocks = (int)((nblk + tpb - 1) / tpb);
+        LAUNCH(ctx, "convmod_train_bwd", (cm_depthwise_kernel<<<dblocks, 256, 0, s>>>(dd, p.dw_w, nullptr, 1, L, (int)dgrid.y, nblk, tpb,
+                                                                                      ws + pl.du, nullptr)));
+    }
     LAUNCH(ctx, "convmod_train_bwd", (cm_bwd2_kernel<<<grid, 256, 0, s>>>(x, ws + pl.du, M, im.w1, im.w1t, p, dres, dx,
                                                                           ws + pl.dag, ws + pl.xn, ws + pl.g1,
                                                                           ws + pl.dxn)));
