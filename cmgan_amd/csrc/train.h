@@ -112,6 +112,25 @@ void launch_tsc_epilogue_backward(LaunchCtx, const float* spec, const float* d_r
 void launch_loss_backward(LaunchCtx, const float* est_real, const float* est_imag, const float* clean_spec,
                           const float* est_audio, const float* clean_audio, int B, int T, int F, int nfft, int hop, float w_ri,
                           float w_mag, float w_time, float* d_real, float* d_imag);
+// Column sums of one 16-token tile's LayerNorm-gradient rows - a = dxn * xhat (dgamma), b = dxn (dbeta), 16 features of
+// each per lane in the chain layout - reduced over the tile's tokens with DPP row sums and written as row `tile` of two
+// [tiles][64] slabs: the column-sum pass then reads 1/16 of what the full [M,64] tensors were (which existed only to
+// be summed).  Callers mask rows past the end of the batch before the call.
+__device__ __forceinline__ void ln_tile_colsums(f32x4 (&a)[4], f32x4 (&b)[4], int c, int g, long tile, float* __restrict__ g1c,
+                                                float* __restrict__ dxc) {
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a[kb][r] = red_c_sum(a[kb][r]);
+            b[kb][r] = red_c_sum(b[kb][r]);
+        }
+        if (c == 0) {
+            stg4(g1c + tile * 64 + 16 * kb + 4 * g, a[kb]);
+            stg4(dxc + tile * 64 + 16 * kb + 4 * g, b[kb]);
+        }
+    }
+}
 // ------------------------------- disc.hip ----------------------------------------
 // the metric discriminator Discriminator(ndf=16) (src/models/discriminator.py:29-64) on RAW parameters
 struct DiscParams {

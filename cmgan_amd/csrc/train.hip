@@ -336,10 +336,15 @@ __global__ __launch_bounds__(256) void ffn_train_bwd_kernel(const float* __restr
             f32x4 dv = (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd);
             if (dres) dv = dv + ldg4(dres + row * 64 + 16 * kb + 4 * g);   // + the gradient of the residual path
             stg4(dx + row * 64 + 16 * kb + 4 * g, dv);
-            stg4(o.g1 + row * 64 + 16 * kb + 4 * g, dxn[kb] * xh[kb]);
-            stg4(o.dxn + row * 64 + 16 * kb + 4 * g, dxn[kb]);
         }
     }
+    f32x4 ca[4], cb[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        ca[kb] = ok ? dxn[kb] * xh[kb] : splat4(0.f);
+        cb[kb] = ok ? dxn[kb] : splat4(0.f);
+    }
+    ln_tile_colsums(ca, cb, c, g, t0 >> 4, o.g1, o.dxn);
 }
 
 // out_partial[s][i][j] = sum over the s-th token range of P[m][i] * Q[m][j]   (P [M,R], Q [M,C], row-major), a 64 x 64
@@ -516,12 +521,14 @@ struct ColsumJobs {
     const float* X[COLSUM_MAX_JOBS];
     float* out[COLSUM_MAX_JOBS];
     int C[COLSUM_MAX_JOBS];
+    long rows[COLSUM_MAX_JOBS];     // 0: the launch's M; else this job's own row count (per-tile partial-sum slabs)
 };
 __global__ __launch_bounds__(256) void colsum_multi_partial_kernel(ColsumJobs jobs, long M, float* __restrict__ cpart) {
     __shared__ float red[256];
     const int job = blockIdx.y;
     const float* __restrict__ X = jobs.X[job];
     const int C = jobs.C[job];
+    if (jobs.rows[job] > 0) M = jobs.rows[job];
     float* partial = cpart + (size_t)job * FFN_COLSUM_BLOCKS * 256;
     const int col = threadIdx.x % C, sub = threadIdx.x / C, nsub = 256 / C;
     const long per = (M + gridDim.x - 1) / gridDim.x;
@@ -651,7 +658,10 @@ void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, l
     LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part, wg_split(4), 16384, grad.w2)));
     LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part + (size_t)WG_SPLIT * 16384, wg_split(4), 16384,
                                                                                  grad.w1)));
-    const ColsumJobs jobs{{o.dh, o.dz, o.g1, o.dxn}, {grad.b1, grad.b2, grad.gamma, grad.beta}, {256, 64, 64, 64}};
+    // o.g1 / o.dxn hold per-tile partial sums (ln_tile_colsums): one row per 32-token tile (x3) / 16-token tile (fp32)
+    const long trows = TRAIN_X3 ? (M + 31) / 32 : (M + 15) / 16;
+    const ColsumJobs jobs{{o.dh, o.dz, o.g1, o.dxn}, {grad.b1, grad.b2, grad.gamma, grad.beta}, {256, 64, 64, 64},
+                          {0, 0, trows, trows}};
     colsum_batch(ctx, "ffn_train_reduce", jobs, 4, M, cpart);
 }
 
@@ -1135,10 +1145,15 @@ __global__ __launch_bounds__(256) void cm_bwd2_kernel(const float* __restrict__ 
             if (dres) dv = dv + ldg4(dres + row * 64 + 16 * kb + 4 * g);
             stg4(dx + row * 64 + 16 * kb + 4 * g, dv);
             stg4(xn_out + row * 64 + 16 * kb + 4 * g, xn[0][kb]);
-            stg4(g1 + row * 64 + 16 * kb + 4 * g, dxn[kb] * xh[kb]);
-            stg4(dxn_out + row * 64 + 16 * kb + 4 * g, dxn[kb]);
         }
     }
+    f32x4 ca[4], cb[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        ca[kb] = ok ? dxn[kb] * xh[kb] : splat4(0.f);
+        cb[kb] = ok ? dxn[kb] : splat4(0.f);
+    }
+    ln_tile_colsums(ca, cb, c, g, t0 >> 4, g1, dxn_out);            // [tiles][64] slabs: dgamma / dbeta partial sums
 }
 
 // tiles per block of the depthwise kernels: at most `cap` blocks (three 48 KB blocks fit a CU: 768 per round)
@@ -1251,7 +1266,8 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     wgrad_partial64(ctx, "convmod_train_wgrad", ws + pl.dag, ws + pl.xn, M, 256, 64, ws + pl.wpart, wg_split(4));
     LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(ws + pl.wpart, wg_split(4), 16384,
                                                                                    grad.pw1_w)));
-    const ColsumJobs jobs{{ws + pl.dag, ws + pl.g1, ws + pl.dxn}, {grad.pw1_b, grad.ln_w, grad.ln_b}, {256, 64, 64}};
+    const ColsumJobs jobs{{ws + pl.dag, ws + pl.g1, ws + pl.dxn}, {grad.pw1_b, grad.ln_w, grad.ln_b}, {256, 64, 64},
+                          {0, (M + 15) / 16, (M + 15) / 16}};                     // g1 / dxn: per-tile partial sums
     colsum_batch(ctx, "convmod_train_reduce", jobs, 3, M, cpart);
 }
 
@@ -1950,10 +1966,15 @@ __global__ __launch_bounds__(256) void at_qkv_bwd_kernel(const float* __restrict
             if (dres) dv = dv + ldg4(dres + row * 64 + 16 * kb + 4 * g);
             stg4(dx + row * 64 + 16 * kb + 4 * g, dv);
             stg4(xn_out + row * 64 + 16 * kb + 4 * g, xn[0][kb]);
-            stg4(g1 + row * 64 + 16 * kb + 4 * g, dxn[kb] * xh[kb]);
-            stg4(dxn_out + row * 64 + 16 * kb + 4 * g, dxn[kb]);
         }
     }
+    f32x4 ca[4], cb[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        ca[kb] = ok ? dxn[kb] * xh[kb] : splat4(0.f);
+        cb[kb] = ok ? dxn[kb] : splat4(0.f);
+    }
+    ln_tile_colsums(ca, cb, c, g, t0 >> 4, g1, dxn_out);            // [tiles][64] slabs: dgamma / dbeta partial sums
 }
 
 // dynamic LDS above the 64 KB default needs an explicit opt-in per kernel
@@ -2056,7 +2077,8 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
                                                                                 ws + pl.raw)));      // [192,64], then split
     hipMemcpyAsync(grad.wq, ws + pl.raw, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);
     hipMemcpyAsync(grad.wkv, ws + pl.raw + 4096, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);
-    const ColsumJobs jobs{{ws + pl.dout, ws + pl.g1, ws + pl.dxn}, {grad.bo, grad.ln_w, grad.ln_b}, {64, 64, 64}};
+    const ColsumJobs jobs{{ws + pl.dout, ws + pl.g1, ws + pl.dxn}, {grad.bo, grad.ln_w, grad.ln_b}, {64, 64, 64},
+                          {0, (M + 15) / 16, (M + 15) / 16}};                     // g1 / dxn: per-tile partial sums
     colsum_batch(ctx, "attn_train_reduce", jobs, 3, M, cpart);
 }
 
@@ -2133,11 +2155,16 @@ __global__ __launch_bounds__(256) void ln_train_bwd_kernel(const float* __restri
     const float mu1 = red_g_sum(s1) * (1.0f / 64.0f), mu2 = red_g_sum(s2) * (1.0f / 64.0f);
     if (ok) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
+        for (int kb = 0; kb < 4; ++kb)
             stg4(dx + row * 64 + 16 * kb + 4 * g, (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd));
-            stg4(g1 + row * 64 + 16 * kb + 4 * g, dyv[kb] * xh[kb]);           // dgamma = colsum(dy xhat)
-        }
     }
+    f32x4 ca[4], cb[4];                                             // dgamma = colsum(dy xhat), dbeta = colsum(dy)
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        ca[kb] = ok ? dyv[kb] * xh[kb] : splat4(0.f);
+        cb[kb] = ok ? dyv[kb] : splat4(0.f);
+    }
+    ln_tile_colsums(ca, cb, c, g, t0 >> 4, g1, g1 + ((M + 15) / 16) * 64);
 }
 
 size_t ln_train_ws_floats(long M) { return (size_t)M * 64 + (size_t)2 * FFN_COLSUM_BLOCKS * 256; }
@@ -2153,7 +2180,8 @@ void launch_ln_train_backward(LaunchCtx ctx, const float* x, const float* dy, lo
     float* g1 = ws;
     float* cpart = ws + (size_t)M * 64;
     LAUNCH(ctx, "ln_train", (ln_train_bwd_kernel<<<(unsigned)((M + 63) / 64), 256, 0, s>>>(x, dy, M, gamma, beta, dx, g1)));
-    const ColsumJobs jobs{{g1, dy}, {dgamma, dbeta}, {64, 64}};
+    const long trows = (M + 15) / 16;                              // per-tile partial sums of dy xhat | dy
+    const ColsumJobs jobs{{g1, g1 + trows * 64}, {dgamma, dbeta}, {64, 64}, {trows, trows}};
     colsum_batch(ctx, "ln_train", jobs, 2, M, cpart);
 }
 

@@ -351,6 +351,7 @@ __global__ __launch_bounds__(512) void ffn_train_bwd_b_x3_kernel(const float* __
                 for (int tb = 0; tb < 2; ++tb) dxn[tb][ob] = mfma32l(al, bh[tb], dxn[tb][ob]);
             }
         }
+        f32x4 ca[4] = {splat4(0.f), splat4(0.f), splat4(0.f), splat4(0.f)}, cb[4] = {splat4(0.f), splat4(0.f), splat4(0.f), splat4(0.f)};
 #pragma unroll
         for (int tb = 0; tb < 2; ++tb) {
             f32x4 xh[4], xn[4], dxh[4];
@@ -375,11 +376,12 @@ __global__ __launch_bounds__(512) void ffn_train_bwd_b_x3_kernel(const float* __
                     f32x4 dv = (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd);
                     if (dres) dv = dv + ldg4(dres + row[tb] * 64 + 16 * kb + 4 * g);
                     stg4(dx + row[tb] * 64 + 16 * kb + 4 * g, dv);
-                    stg4(o_g1 + row[tb] * 64 + 16 * kb + 4 * g, dxn[tb][kb] * xh[kb]);
-                    stg4(o_dxn + row[tb] * 64 + 16 * kb + 4 * g, dxn[tb][kb]);
+                    ca[kb] = ca[kb] + dxn[tb][kb] * xh[kb];
+                    cb[kb] = cb[kb] + dxn[tb][kb];
                 }
             }
         }
+        ln_tile_colsums(ca, cb, c, g, tile, o_g1, o_dxn);      // row `tile` of the [ntiles][64] dgamma / dbeta partial slabs
     }
 }
 
