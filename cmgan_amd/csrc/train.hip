@@ -591,7 +591,7 @@ void ffn_x3_forward(LaunchCtx, const float* x, long M, const FfnTrainParams& p, 
                     const unsigned char* m2, float ms, const float* res, float* y);
 void ffn_x3_backward(LaunchCtx, const float* x, const float* dy, long M, const FfnTrainParams& p, const float* img,
                      const unsigned char* m1, const unsigned char* m2, float ms, const float* dres, float* dx, float* o_dz,
-                     float* o_d1, float* o_dh, float* o_xn, float* o_g1, float* o_dxn, float* dhmax);
+                     float* o_d1, float* o_dh, float* o_xn, float* o_g1, float* o_dxn, float* dhmax, float* o_dzc, float* o_dhc);
 void launch_wgrad_partial64_x3(LaunchCtx, const char* label, const float* P, const float* Q, long M, int R, int C,
                                float* partial, int nsplit);
 void launch_db_conv_wgrad_x3(LaunchCtx, const float* dz, const float* a, int B, int T, int F, int dil, int nsplit,
@@ -646,8 +646,13 @@ void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, l
     float* cpart = part + (size_t)WG_SPLIT * 16384 * 2;
 #if TRAIN_X3
     (void)w;
+    // per-tile partial sums for the four column sums: [tiles][64] dgamma | dz (db2) in the g1 region, [tiles][64] dbeta |
+    // [tiles][256] dh (db1) in the dxn region (the full [M,64] g1 / dxn tensors of round 2 are no longer written)
+    const long xrows = (M + 31) / 32;
+    float *dzc = o.g1 + xrows * 64, *dhc = o.dxn + xrows * 64;   // dzc: [2 tiles][64]
     ffn_x3_backward(ctx, x, dy, M, p, ws, m1, m2, ms, dres, dx, o.dz, o.d1, o.dh, o.xn, o.g1, o.dxn,
-                    cpart);                                       // per-tile |dh| maxima: the column-sum slabs are free until colsum_batch
+                    cpart,                                        // per-tile |dh| maxima: the column-sum slabs are free until colsum_batch
+                    dzc, dhc);
 #else
     const unsigned grid = (unsigned)((M + 63) / 64);
     LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_kernel<<<grid, 256, 0, s>>>(x, dy, M, w, m1, m2, ms, dres, dx, o)));
@@ -660,8 +665,13 @@ void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, l
                                                                                  grad.w1)));
     // o.g1 / o.dxn hold per-tile partial sums (ln_tile_colsums): one row per 32-token tile (x3) / 16-token tile (fp32)
     const long trows = TRAIN_X3 ? (M + 31) / 32 : (M + 15) / 16;
+#if TRAIN_X3
+    const ColsumJobs jobs{{dhc, dzc, o.g1, o.dxn}, {grad.b1, grad.b2, grad.gamma, grad.beta}, {256, 64, 64, 64},
+                          {trows, 2 * trows, trows, trows}};      // dz sums are per 16-token block
+#else
     const ColsumJobs jobs{{o.dh, o.dz, o.g1, o.dxn}, {grad.b1, grad.b2, grad.gamma, grad.beta}, {256, 64, 64, 64},
                           {0, 0, trows, trows}};
+#endif
     colsum_batch(ctx, "ffn_train_reduce", jobs, 4, M, cpart);
 }
 
@@ -956,12 +966,14 @@ __global__ __launch_bounds__(256) void cm_bn_swish_pw2_kernel(const float* __res
     }
 }
 
-// backward, part 1 (per token): ds = pw2^T dy, through Swish; writes ddn = dL/d(bn output), s (for dW_pw2) and
-// g2 = ddn * dhat (for the BatchNorm reductions)
+// backward, part 1 (per token): ds = pw2^T dy, through Swish; writes ddn = dL/d(bn output), s (for dW_pw2) and the
+// per-tile column sums the three reductions of this stage are finished from (ln_tile_colsums' scheme): rows of
+// [tiles][128] for g2 = ddn * dhat (BatchNorm dgamma) and ddn (dbeta), [tiles][64] for dy (the pointwise bias)
 __global__ __launch_bounds__(256) void cm_bwd1_kernel(const float* __restrict__ dy, const float* __restrict__ d, long M,
                                                       CmStats st, const float* __restrict__ w2tfm,
                                                       float* __restrict__ ddn, float* __restrict__ s_out,
-                                                      float* __restrict__ g2) {
+                                                      float* __restrict__ g2c, float* __restrict__ ddnc,
+                                                      float* __restrict__ dyc) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (t0 >= M) return;
@@ -971,6 +983,14 @@ __global__ __launch_bounds__(256) void cm_bwd1_kernel(const float* __restrict__ 
     f32x4 dyf[1][4];
 #pragma unroll
     for (int ob = 0; ob < 4; ++ob) dyf[0][ob] = ldg4(dy + row * 64 + 16 * ob + 4 * g);
+    const long tile = t0 >> 4;
+#pragma unroll
+    for (int ob = 0; ob < 4; ++ob) {
+        f32x4 v = ok ? dyf[0][ob] : splat4(0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = red_c_sum(v[r]);
+        if (c == 0) stg4(dyc + tile * 64 + 16 * ob + 4 * g, v);
+    }
 #pragma unroll 2
     for (int hb = 0; hb < 8; ++hb) {
         f32x4 ds[1] = {splat4(0.f)};
@@ -988,7 +1008,16 @@ __global__ __launch_bounds__(256) void cm_bwd1_kernel(const float* __restrict__ 
         if (ok) {
             stg4(ddn + row * 128 + 16 * hb + 4 * g, o_ddn);
             stg4(s_out + row * 128 + 16 * hb + 4 * g, o_s);
-            stg4(g2 + row * 128 + 16 * hb + 4 * g, o_ddn * dhat);
+        }
+        f32x4 ca = ok ? o_ddn * dhat : splat4(0.f), cb = ok ? o_ddn : splat4(0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ca[r] = red_c_sum(ca[r]);
+            cb[r] = red_c_sum(cb[r]);
+        }
+        if (c == 0) {
+            stg4(g2c + tile * 128 + 16 * hb + 4 * g, ca);
+            stg4(ddnc + tile * 128 + 16 * hb + 4 * g, cb);
         }
     }
 }
@@ -1232,15 +1261,17 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
         LAUNCH(ctx, "convmod_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(X, M, C, cpart)));
         LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, C, out)));
     };
+    const long trows = (M + 15) / 16;                             // per-tile partial sums inside the g2 region [M,128]
+    float *g2c = ws + pl.g2, *ddnc = g2c + trows * 128, *dyc = ddnc + trows * 128;
     LAUNCH(ctx, "convmod_train_bwd", (cm_bwd1_kernel<<<grid, 256, 0, s>>>(dy, ws + pl.d, M, st, im.w2t, ws + pl.ddn,
-                                                                          ws + pl.s, ws + pl.g2)));
+                                                                          ws + pl.s, g2c, ddnc, dyc)));
     // pointwise-2 gradients: dW_pw2 [64,128] = dy^T s, db_pw2 = colsum dy
     wgrad_partial64(ctx, "convmod_train_wgrad", dy, ws + pl.s, M, 64, 128, ws + pl.wpart, wg_split(2));
     LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<128, 1024, 0, s>>>(ws + pl.wpart, wg_split(2), 8192,
                                                                                    grad.pw2_w)));
     // BatchNorm: dbeta = sum ddn, dgamma = sum ddn dhat; then dd in place   (+ db_pw2 = colsum dy in the same pair of launches)
     {
-        const ColsumJobs jobs{{dy, ws + pl.ddn, ws + pl.g2}, {grad.pw2_b, sum_ddn, sum_g2}, {64, 128, 128}};
+        const ColsumJobs jobs{{dyc, ddnc, g2c}, {grad.pw2_b, sum_ddn, sum_g2}, {64, 128, 128}, {trows, trows, trows}};
         colsum_batch(ctx, "convmod_train_reduce", jobs, 3, M, cpart);
     }
     hipMemcpyAsync(grad.bn_b, sum_ddn, 128 * sizeof(float), hipMemcpyDeviceToDevice, s);

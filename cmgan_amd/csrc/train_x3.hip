@@ -217,7 +217,8 @@ __global__ __launch_bounds__(TX_WAVES * 64) void ffn_train_bwd_a_x3_kernel(const
                                                                            const unsigned char* __restrict__ m2, float ms,
                                                                            float* __restrict__ o_dz, float* __restrict__ o_xn,
                                                                            float* __restrict__ o_d1, float* __restrict__ o_dh,
-                                                                           float* __restrict__ o_dhmax, int ntiles) {
+                                                                           float* __restrict__ o_dhmax, float* __restrict__ o_dzc,
+                                                                           int ntiles) {
     __shared__ __attribute__((aligned(16))) _Float16 wlds[65536];
     __shared__ __attribute__((aligned(16))) float par_l[448];
     _Float16* w1 = wlds;
@@ -254,6 +255,13 @@ __global__ __launch_bounds__(TX_WAVES * 64) void ffn_train_bwd_a_x3_kernel(const
                     stg4(o_dz + row[tb] * 64 + 16 * ob + 4 * g, v);
                     stg4(o_xn + row[tb] * 64 + 16 * ob + 4 * g, xn[ob]);
                 }
+            }
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {                 // db2 partial: this 16-token block's column sums, row 2 tile + tb
+                f32x4 zs4;                                   // of the [2 ntiles][64] slab the bias gradient is summed from
+#pragma unroll
+                for (int r = 0; r < 4; ++r) zs4[r] = red_c_sum(dz[ob][r]);
+                if (c == 0) stg4(o_dzc + ((long)tile * 2 + tb) * 64 + 16 * ob + 4 * g, zs4);
             }
             float zs;
             tx_pow2(tx_wave_max(zmax), zs, zinv[tb]);       // exact power-of-two scale of this 16-token block's dz
@@ -306,7 +314,8 @@ __global__ __launch_bounds__(512) void ffn_train_bwd_b_x3_kernel(const float* __
                                                                  const _Float16* __restrict__ w1ti,
                                                                  FfnTrainParams p, const float* __restrict__ dres,
                                                                  float* __restrict__ dx, float* __restrict__ o_g1,
-                                                                 float* __restrict__ o_dxn, int ntiles) {
+                                                                 float* __restrict__ o_dxn, float* __restrict__ o_dhc,
+                                                                 int ntiles) {
     __shared__ __attribute__((aligned(16))) _Float16 wlds[32768];          // 64 KB
     __shared__ __attribute__((aligned(16))) float par_l[128];              // gamma | beta
     stage_lds16<4096, 512>(w1ti, wlds);
@@ -332,11 +341,23 @@ __global__ __launch_bounds__(512) void ffn_train_bwd_b_x3_kernel(const float* __
 #pragma unroll 2
         for (int m = 0; m < 8; ++m) {
             f16x8 bh[2], bl[2];
+            f32x4 sa = splat4(0.f), sb = splat4(0.f);          // db1 partial: the tile's column sums of dh -> [ntiles][256]
 #pragma unroll
             for (int tb = 0; tb < 2; ++tb) {
                 f32x4 a = ldg4(dh + row[tb] * 256 + 32 * m + 4 * g), b = ldg4(dh + row[tb] * 256 + 32 * m + 16 + 4 * g);
                 if (!ok[tb]) { a = splat4(0.f); b = splat4(0.f); }
+                sa = sa + a;
+                sb = sb + b;
                 split8(a * splat4(hs), b * splat4(hs), bh[tb], bl[tb]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sa[r] = red_c_sum(sa[r]);
+                sb[r] = red_c_sum(sb[r]);
+            }
+            if (c == 0) {
+                stg4(o_dhc + (long)tile * 256 + 32 * m + 4 * g, sa);
+                stg4(o_dhc + (long)tile * 256 + 32 * m + 16 + 4 * g, sb);
             }
 #pragma unroll
             for (int ob = 0; ob < 4; ++ob) {
@@ -689,14 +710,15 @@ void ffn_x3_forward(LaunchCtx ctx, const float* x, long M, const FfnTrainParams&
 // dhmax: scratch of ceil(M / 32) floats (one per tile), written by part A and read by part B
 void ffn_x3_backward(LaunchCtx ctx, const float* x, const float* dy, long M, const FfnTrainParams& p, const float* img,
                      const unsigned char* m1, const unsigned char* m2, float ms, const float* dres, float* dx,
-                     float* o_dz, float* o_d1, float* o_dh, float* o_xn, float* o_g1, float* o_dxn, float* dhmax) {
+                     float* o_dz, float* o_d1, float* o_dh, float* o_xn, float* o_g1, float* o_dxn, float* dhmax, float* o_dzc,
+                     float* o_dhc) {
     const _Float16* h = reinterpret_cast<const _Float16*>(img);
     const int ntiles = (int)((M + 31) / 32);
     LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_a_x3_kernel<<<tx_grid(ntiles, TX_WAVES), TX_WAVES * 64, 0, ctx.stream>>>(
-                                     x, dy, M, h, h + 2 * 32768, p, m1, m2, ms, o_dz, o_xn, o_d1, o_dh, dhmax, ntiles)));
+                                     x, dy, M, h, h + 2 * 32768, p, m1, m2, ms, o_dz, o_xn, o_d1, o_dh, dhmax, o_dzc, ntiles)));
     const int gridb = (ntiles + 7) / 8 < 512 ? ((ntiles + 7) / 8 > 0 ? (ntiles + 7) / 8 : 1) : 512;
     LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_b_x3_kernel<<<gridb, 512, 0, ctx.stream>>>(
-                                     x, o_dh, dhmax, M, h + 3 * 32768, p, dres, dx, o_g1, o_dxn, ntiles)));
+                                     x, o_dh, dhmax, M, h + 3 * 32768, p, dres, dx, o_g1, o_dxn, o_dhc, ntiles)));
 }
 void launch_wgrad_partial64_x3(LaunchCtx ctx, const char* label, const float* P, const float* Q, long M, int R, int C,
                                float* partial, int nsplit) {
