@@ -572,7 +572,10 @@ __global__ __launch_bounds__(256) void db_conv_wgrad_x3_kernel(const float* __re
                                                                float* __restrict__ partial) {
     __shared__ float red[2][64 * 64];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
-    const int tap = blockIdx.x, s = blockIdx.y;
+    // 1-D grid of 6 nsplit blocks (nsplit a multiple of 8), dealt round-robin to the 8 XCDs: the six tap blocks of one
+    // position range read the same dz / activation rows, so they are given to the SAME XCD (one L2 fill, five hits)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int tap = q % 6, s = (q / 6) * 8 + xcd;
     const int kt = tap / 3, kf = tap - 3 * kt, dt = (kt - 1) * dil, df = kf - 1;
     const unsigned M = (unsigned)B * T * F, tf = (unsigned)T * F;
     const unsigned steps = (M + 31) / 32, per = (steps + nsplit - 1) / nsplit;
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(256) void db_conv_wgrad_x3_kernel(const float* __re
 }
 void launch_db_conv_wgrad_x3(LaunchCtx ctx, const float* dz, const float* a, int B, int T, int F, int dil, int nsplit,
                              float* partial) {
-    LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_x3_kernel<<<dim3(6, nsplit), 256, 0, ctx.stream>>>(dz, a, B, T, F, dil,
+    LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_x3_kernel<<<6 * nsplit, 256, 0, ctx.stream>>>(dz, a, B, T, F, dil,
                                                                                                       nsplit, partial)));
 }
 
