@@ -1313,16 +1313,56 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
 // =====================================================================================
 #define AT_MAX_L 4096                 // a workspace-size bound only: the cores have no length-dependent resource
 
+#ifndef AT_X3
+#define AT_X3 1             // 1: the attention cores on split-f16 products fed from PRE-SPLIT operand images (below);
+#endif                      // 0: exact fp32 products (v_mfma_f32_16x16x4_f32), operands straight from the fp32 tensors
+// AT_X3 operand images.  Every tensor the cores read (q | k | v, dO, the relative-position window) is stored split into
+// fp16 hi / lo halves by its PRODUCER, in two interleavings of the same 4 bytes per element, so that a core's operand
+// load is the MFMA operand with no VALU work in between (round 3's first split-f16 form split inside the cores: 12
+// VALU per product, which took back what the matrix pipe gave - VALU and MFMA issue add up on this machine):
+//   quad image: the 16 bytes of floats 4i .. 4i + 3 hold [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3]  - a lane's A-type float4
+//               (four consecutive features of one row) IS the [hi | lo] operand of at_mma
+//   pair image: the 4 bytes of float i hold (hi_i, lo_i)                                        - row-type fragments (four
+//               scalar loads down a column) are re-packed with four v_perm_b32
+// q is stored PRE-SCALED by dim_head^-0.5 log2(e) (the factor every score product applies; dk and dE, which contract
+// with q, are multiplied by ln 2 instead of 0.25 at the end); dO is stored pre-scaled by the exact power of two of
+// at_scale.  fp32 build: both "images" are the fp32 tensor itself.
 struct AtBufs {
-    float *qkv;      // [M,192]  q | k | v  (features 16 h + d inside each 64)
+    float *qkv;      // [M,192]  q | k | v  (features 16 h + d inside each 64): fp32, or the quad image
+    float *qkvp;     //          the pair image (fp32 build: = qkv)
     float *o;        // [M,64]   softmax(.) v, heads concatenated
     float *lse;      // [N,4,L]  row log-sum-exp of the scaled scores
 };
+#define AT_LOG2E 1.4426950408889634f  // scores are kept in log2 units: p = v_exp_f32(s - lse) without a multiply
+#define AT_QSCALE (0.25f * AT_LOG2E)  // dim_head^-0.5 * log2(e), folded into the q fragment of every score product
+// one float4 -> its quad-image and pair-image forms
+__device__ __forceinline__ void at_img4(const f32x4& v, f32x4& quad, f32x4& pair) {
+    f16x4 h, l;
+    split4(v, h, l);
+    quad = __builtin_bit_cast(f32x4, __builtin_shufflevector(h, l, 0, 1, 2, 3, 4, 5, 6, 7));
+    pair = __builtin_bit_cast(f32x4, __builtin_shufflevector(h, l, 0, 4, 1, 5, 2, 6, 3, 7));
+}
 
+// fp32 build: the projection as is.  AT_X3: both operand images, the q part (output blocks 0 .. 3) pre-scaled
+__device__ __forceinline__ void at_store_qkv(float* __restrict__ qkv, float* __restrict__ qkvp, long off, f32x4 v, bool is_q,
+                                             bool ok) {
+#if AT_X3
+    if (is_q) v = v * splat4(AT_QSCALE);
+    f32x4 quad, pair;
+    at_img4(v, quad, pair);
+    if (ok) {
+        stg4(qkv + off, quad);
+        stg4(qkvp + off, pair);
+    }
+#else
+    (void)qkvp; (void)is_q;
+    if (ok) stg4(qkv + off, v);
+#endif
+}
 // LN -> [to_q ; to_kv] (A image [12][4]) -> qkv
 __global__ __launch_bounds__(256) void at_qkv_kernel(const float* __restrict__ x, long M, const float* __restrict__ wfm,
                                                      const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                                     float* __restrict__ qkv) {
+                                                     float* __restrict__ qkv, float* __restrict__ qkvp) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (t0 >= M) return;
@@ -1334,10 +1374,10 @@ __global__ __launch_bounds__(256) void at_qkv_kernel(const float* __restrict__ x
     for (int ob = 0; ob < 12; ob += 2) {
         f1 = ffn_frag_rows(wfm, ob + 1, lane);
         const f32x4 q0 = ffn_frag_mma(f0, xn[0], splat4(0.f));
-        if (ok) stg4(qkv + row * 192 + 16 * ob + 4 * g, q0);
+        at_store_qkv(qkv, qkvp, row * 192 + 16 * ob + 4 * g, q0, ob < 4, ok);
         f0 = ffn_frag_rows(wfm, ob + 2 < 12 ? ob + 2 : 11, lane);
         const f32x4 q1 = ffn_frag_mma(f1, xn[0], splat4(0.f));
-        if (ok) stg4(qkv + row * 192 + 16 * (ob + 1) + 4 * g, q1);
+        at_store_qkv(qkv, qkvp, row * 192 + 16 * (ob + 1) + 4 * g, q1, ob + 1 < 4, ok);
     }
 }
 
@@ -1362,8 +1402,6 @@ __global__ __launch_bounds__(256) void at_qkv_kernel(const float* __restrict__ x
 #define AT_PA 20                      // LDS pitch of the [32][16] band patch (E q^T)
 #define AT_PB 36                      // LDS pitch of the [16][32] band patch (q E^T): conflict-free writes, <= 2-way reads
 #define AT_PS 48                      // dS patch row: [16 zeros | 16 keys | 16 zeros] - out-of-tile reads of the unskew are 0
-#define AT_LOG2E 1.4426950408889634f  // scores are kept in log2 units: p = v_exp_f32(s - lse) without a multiply
-#define AT_QSCALE (0.25f * AT_LOG2E)  // dim_head^-0.5 * log2(e), folded into the q fragment of every score product
 
 struct AtTask { int nh, blk; };       // wave-uniform (SGPRs)
 // blocks are dealt round-robin to the 8 XCDs: give each XCD a contiguous range of tasks so that the waves sharing one
@@ -1378,34 +1416,68 @@ __device__ __forceinline__ bool at_task(long ntask, int nb, AtTask& t) {
     t.blk = __builtin_amdgcn_readfirstlane((int)(task - (long)nh * nb));
     return true;
 }
-#ifndef AT_X3
-#define AT_X3 0             // 1: the attention cores on split-f16 products.  Built and parity-green (38 training tests), but
-#endif                      // NOT faster: 57.9 -> 57.5 ms backward, 14.1 -> 12.9 ms forward per step at batch 32 - the
-                            // cores are bound by their skew / scalar-operand traffic, and the fp16 splits (12 VALU per
-                            // product) take back what the matrix pipe gives.  The exact fp32 products stay the default.
-// acc + sum over the 16 contraction indices (g, s) of a(lane (i, g))[s] * b(lane (j, g))[s]: four fp32 MFMA steps, or -
-// AT_X3 - two split-f16 MFMAs: each lane's float4 becomes [hi(4) | lo(4)] along the 32-wide contraction on the A
-// side and [hi | hi], then [lo | lo], on the B side, which yields all four split terms with no data movement (the
-// operand a lane needs is the float4 it already holds).  Gradient operands must be pre-scaled into fp16 range by an
-// exact power of two (at_scale below); activations, probabilities and the relative-position table are in range as is.
-__device__ __forceinline__ f32x4 at_mma4(const f32x4& a, const f32x4& b, f32x4 acc) {
+// ---- operand types of the cores ------------------------------------------------------------------------------------
+// at_mma(a, b, acc) = acc + sum over the 16 contraction indices (g, s) of a(lane (i, g))[s] * b(lane (j, g))[s].
+// fp32 build: operands are the lanes' float4s, four v_mfma_f32_16x16x4_f32 steps.  AT_X3: the A side is the lane's
+// [hi(4) | lo(4)] along the 32-wide contraction of v_mfma_f32_16x16x32_f16, the B side [hi | hi], then [lo | lo]: two
+// MFMAs give all four split terms.  Loaded operands arrive in these forms from the images (at_lda / at_row_a, no VALU
+// but register shuffles); operands computed in the core (probabilities, dS, unskewed bands) are split by at_a / at_b.
 #if AT_X3
-    f16x4 ah, al, bh, bl;
-    split4(a, ah, al);
-    split4(b, bh, bl);
-    const f16x8 av = __builtin_shufflevector(ah, al, 0, 1, 2, 3, 4, 5, 6, 7);
-    acc = mfma32h(av, __builtin_shufflevector(bh, bh, 0, 1, 2, 3, 0, 1, 2, 3), acc);
-    acc = mfma32l(av, __builtin_shufflevector(bl, bl, 0, 1, 2, 3, 0, 1, 2, 3), acc);
+typedef f16x8 AtA;
+struct AtB { f16x8 hh, ll; };
+__device__ __forceinline__ AtA at_a(const f32x4& x) {
+    f16x4 h, l;
+    split4(x, h, l);
+    return __builtin_shufflevector(h, l, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ AtB at_b_of(const AtA& a) {
+    return AtB{__builtin_shufflevector(a, a, 0, 1, 2, 3, 0, 1, 2, 3), __builtin_shufflevector(a, a, 4, 5, 6, 7, 4, 5, 6, 7)};
+}
+__device__ __forceinline__ AtB at_b(const f32x4& x) { return at_b_of(at_a(x)); }
+__device__ __forceinline__ AtA at_lda(const float* __restrict__ p) { return __builtin_bit_cast(f16x8, ldg4(p)); }
+// four (hi, lo) dwords of the pair image (a row-type fragment) -> [hi(4) | lo(4)]
+__device__ __forceinline__ AtA at_row_a(const f32x4& raw) {
+    const unsigned d0 = __float_as_uint(raw[0]), d1 = __float_as_uint(raw[1]), d2 = __float_as_uint(raw[2]),
+                   d3 = __float_as_uint(raw[3]);
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ v = {__builtin_amdgcn_perm(d1, d0, 0x05040100u), __builtin_amdgcn_perm(d3, d2, 0x05040100u),
+                      __builtin_amdgcn_perm(d1, d0, 0x07060302u), __builtin_amdgcn_perm(d3, d2, 0x07060302u)};
+    return __builtin_bit_cast(f16x8, v);
+}
+__device__ __forceinline__ f32x4 at_mma(const AtA& a, const AtB& b, f32x4 acc) {
+    acc = mfma32h(a, b.hh, acc);
+    return mfma32l(a, b.ll, acc);
+}
+#define AT_QBACK 0.6931471805599453f      // dk, dE contract with the PRE-SCALED q: 0.25 = (0.25 log2 e) ln 2
 #else
+typedef f32x4 AtA;
+typedef f32x4 AtB;
+__device__ __forceinline__ AtA at_a(const f32x4& x) { return x; }
+__device__ __forceinline__ AtB at_b_of(const AtA& a) { return a; }
+__device__ __forceinline__ AtB at_b(const f32x4& x) { return x; }
+__device__ __forceinline__ AtA at_lda(const float* __restrict__ p) { return ldg4(p); }
+__device__ __forceinline__ AtA at_row_a(const f32x4& raw) { return raw; }
+__device__ __forceinline__ f32x4 at_mma(const AtA& a, const AtB& b, f32x4 acc) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) acc = mfma16(a[s], b[s], acc);
-#endif
     return acc;
 }
-__device__ __forceinline__ f32x4 at_dot(const f32x4& a, const f32x4& b) { return at_mma4(a, b, splat4(0.f)); }
+#define AT_QBACK 0.25f
+#endif
+__device__ __forceinline__ AtB at_row_b(const f32x4& raw) { return at_b_of(at_row_a(raw)); }
+__device__ __forceinline__ f32x4 at_dot(const AtA& a, const AtB& b) { return at_mma(a, b, splat4(0.f)); }
+// the q fragment of a score product (A-type rows of the q image / tensor): fp32 build applies the score scale here
+__device__ __forceinline__ AtA at_ldq(const float* __restrict__ p) {
+#if AT_X3
+    return at_lda(p);
+#else
+    return ldg4(p) * splat4(AT_QSCALE);
+#endif
+}
 // exact power-of-two scale of the backward cores' gradient operands (dO and D = rowsum(dO o)): s brings the largest
-// |dO| of the whole tensor (bit pattern in *amax, collected by at_out_bwd_kernel with atomicMax - order-independent) to
-// [1, 2); every output of a core is linear in dO, so it is multiplied by inv = 1 / s at the end.  fp32 build: 1, 1.
+// |dO| of the whole tensor (*amax: per-block maxima of at_out_bwd_kernel reduced by at_amax_kernel - order-independent)
+// to [1, 2); the dO images are stored scaled, D is scaled on load, and every output of a core - linear in dO - is
+// multiplied by inv = 1 / s at the end.  fp32 build: 1, 1.
 __device__ __forceinline__ void at_scale(const float* __restrict__ amax, float& s, float& inv) {
     s = 1.0f; inv = 1.0f;
 #if AT_X3
@@ -1429,12 +1501,22 @@ __device__ __forceinline__ unsigned at_off_b(int R0, int L, int stride, int c, i
 }
 // relative-position window: row w <-> distance w - W (W = 16 nb + 16 covers every band a tile can ask for), table row
 // clamp(distance, +-max_pos) + max_pos - the clamp of conformer.py:104 is applied once here, the cores index affinely
-__global__ void at_window_kernel(const float* __restrict__ rel, int W, int max_pos, float* __restrict__ ewin) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (2 * W + 1) * 16) return;
-    int dist = (idx >> 4) - W;
+__global__ void at_window_kernel(const float* __restrict__ rel, int W, int max_pos, float* __restrict__ ewin,
+                                 float* __restrict__ ewinp) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;             // one float4 (four features of one distance) per thread
+    if (q >= (2 * W + 1) * 4) return;
+    int dist = (q >> 2) - W;
     dist = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
-    ewin[idx] = rel[(long)(dist + max_pos) * 16 + (idx & 15)];
+    const f32x4 v = ldg4(rel + (long)(dist + max_pos) * 16 + (q & 3) * 4);
+#if AT_X3
+    f32x4 quad, pair;
+    at_img4(v, quad, pair);
+    stg4(ewin + 4 * q, quad);
+    stg4(ewinp + 4 * q, pair);
+#else
+    (void)ewinp;
+    stg4(ewin + 4 * q, v);
+#endif
 }
 // band^T [32 distances][16 queries] (two accumulators) -> R^T[key 4g + r][query c] = band[15 + c - (4g + r)][c]
 __device__ __forceinline__ f32x4 at_skew_t(float* buf, const f32x4& eq0, const f32x4& eq1, int c, int g) {
@@ -1480,8 +1562,9 @@ __global__ __launch_bounds__(256) void at_fwd_kernel(AtBufs b, const float* __re
     const int h = t.nh & 3, I0 = 16 * t.blk, W = 16 * nb + 16, nfull = L >> 4;
     const long base = (long)(t.nh >> 2) * L;
     const float* __restrict__ qh = b.qkv + base * 192 + 16 * h;                    // uniform: this head's q | k | v rows
+    const float* __restrict__ qhp = b.qkvp + base * 192 + 16 * h;                  // the same rows of the pair image
     const float* __restrict__ e_blk = ewin + (long)(I0 - 15 + W) * 16;             // band of key block 0; block jb: - 256 jb
-    const f32x4 qa = ldg4(qh + (long)I0 * 192 + at_off_a(I0, L, 192, c, g)) * splat4(AT_QSCALE);
+    const AtB qa = at_b_of(at_ldq(qh + (long)I0 * 192 + at_off_a(I0, L, 192, c, g)));
     const unsigned la = c * 192 + 4 * g, lb = 4 * g * 192 + c, le = c * 16 + 4 * g;
     const unsigned la_t = at_off_a(16 * nfull, L, 192, c, g);
     unsigned lb_t[4];
@@ -1490,16 +1573,17 @@ __global__ __launch_bounds__(256) void at_fwd_kernel(AtBufs b, const float* __re
     for (int r = 0; r < 4; ++r) { lb_t[r] = at_off_b(16 * nfull, L, 192, c, g, r); vt[r] = 16 * nfull + 4 * g + r < L; }
     f32x4 ot = splat4(0.f);               // o^T[d = 4g + r][query c]
     float m = -1e30f, l = 0.f;
-    f32x4 eq1 = at_dot(ldg4(e_blk + 256 + le), qa);
-    struct Frag { f32x4 ka, vb, ea; };
+    f32x4 eq1 = at_dot(at_lda(e_blk + 256 + le), qa);
+    struct Frag { AtA ka, ea; f32x4 vb; };
     auto load = [&](auto tail, int jb) {
         constexpr bool TAIL = decltype(tail)::value;
         const float* __restrict__ kp = qh + 64 + (long)jb * (16 * 192);
+        const float* __restrict__ vp = qhp + 128 + (long)jb * (16 * 192);
         Frag f;
-        f.ka = ldg4(kp + (TAIL ? la_t : la));
+        f.ka = at_lda(kp + (TAIL ? la_t : la));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) f.vb[r] = kp[64 + (TAIL ? lb_t[r] : lb + r * 192)];
-        f.ea = ldg4(e_blk - (long)jb * 256 + le);
+        for (int r = 0; r < 4; ++r) f.vb[r] = vp[TAIL ? lb_t[r] : lb + r * 192];
+        f.ea = at_lda(e_blk - (long)jb * 256 + le);
         return f;
     };
     auto tile = [&](auto tail, const Frag& f) {
@@ -1522,7 +1606,7 @@ __global__ __launch_bounds__(256) void at_fwd_kernel(AtBufs b, const float* __re
 #pragma unroll
         for (int r = 0; r < 4; ++r) p[r] = __builtin_amdgcn_exp2f(sc[r] - m);
         l += (p[0] + p[1]) + (p[2] + p[3]);               // this lane's four keys; the four lane groups are summed at the end
-        ot = at_mma4(f.vb, p, ot);
+        ot = at_mma(at_row_a(f.vb), at_b(p), ot);
     };
     if (nfull > 0) {
         // two blocks per trip: the other block's operands are in flight while one is being worked on
@@ -1572,7 +1656,7 @@ __global__ __launch_bounds__(256) void at_out_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ o, long M,
                                                          const float* __restrict__ wotfm, float* __restrict__ dout,
                                                          float* __restrict__ dO, float* __restrict__ D,
-                                                         unsigned* __restrict__ amax) {
+                                                         float* __restrict__ maxslot) {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
     const long t0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
     if (t0 >= M) return;
@@ -1602,25 +1686,58 @@ __global__ __launch_bounds__(256) void at_out_bwd_kernel(const float* __restrict
         }
     }
 #if AT_X3
-    // the largest |dO| of the tensor, for the exact power-of-two scale of the split-f16 cores (at_scale).  (One atomic per
-    // wave on a single word costs ~70 us per launch at batch 4: a per-block slot array would be the form to ship.)
+    // the wave's largest |dO|, one slot per 16-token tile (at_amax_kernel reduces them): the exact power-of-two scale of
+    // the split-f16 cores (at_scale).  (One atomicMax per wave on a single word cost ~70 us per launch.)
     mx = red_g_max(mx);
     mx = fmaxf(mx, dpp_perm<0xB1>(mx));
     mx = fmaxf(mx, dpp_perm<0x4E>(mx));
     mx = fmaxf(mx, dpp_perm<0x141>(mx));
     mx = fmaxf(mx, dpp_perm<0x140>(mx));
-    if (lane == 0 && mx > 0.f) atomicMax(amax, __float_as_uint(mx));
+    if (lane == 0) maxslot[t0 >> 4] = mx;
 #else
-    (void)mx; (void)amax;
+    (void)mx; (void)maxslot;
 #endif
 }
+#if AT_X3
+// out[0] = max of n non-negative floats (one block; max is order-independent)
+__global__ __launch_bounds__(1024) void at_amax_kernel(const float* __restrict__ slots, long n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float m = 0.f;
+    for (long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, slots[i]);
+    m = red_g_max(m);
+    m = fmaxf(m, dpp_perm<0xB1>(m));
+    m = fmaxf(m, dpp_perm<0x4E>(m));
+    m = fmaxf(m, dpp_perm<0x141>(m));
+    m = fmaxf(m, dpp_perm<0x140>(m));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) m = fmaxf(m, red[k]);
+        out[0] = m;
+    }
+}
+// dO (fp32, as at_out_bwd_kernel left it) -> the scaled quad image IN PLACE (each float4 becomes its own 16 bytes) and
+// the pair image
+__global__ __launch_bounds__(256) void at_dO_split_kernel(float* __restrict__ dO, float* __restrict__ dOp,
+                                                          const float* __restrict__ amax, long n4) {
+    float gs, ginv;
+    at_scale(amax, gs, ginv);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 quad, pair;
+        at_img4(ldg4(dO + 4 * i) * splat4(gs), quad, pair);
+        stg4(dO + 4 * i, quad);
+        stg4(dOp + 4 * i, pair);
+    }
+}
+#endif
 
 // p_ij and ds_ij of one (query i, key j) pair; scores are recomputed, never stored.  q is the RAW query row (the
 // 16^-0.5 scale is applied to the score), so that rows can come straight from wave-uniform scalar loads.
 // dq: task (n, h, query block); P^T / dS^T tiles (key 4g + r, query c).   dq_i = scale sum_j ds_ij (k_j + E[i - j])
-__global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ dO,
-                                                    const float* __restrict__ D, const float* __restrict__ amax, int L, int nb,
-                                                    long ntask, float* __restrict__ dqkv) {
+__global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ ewinp,
+                                                    const float* __restrict__ dO, const float* __restrict__ D,
+                                                    const float* __restrict__ amax, int L, int nb, long ntask,
+                                                    float* __restrict__ dqkv) {
     __shared__ float sm[4][32 * AT_PA + 16 * AT_PS];
     AtTask t;
     if (!at_task(ntask, nb, t)) return;
@@ -1631,12 +1748,14 @@ __global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __res
     const int h = t.nh & 3, I0 = 16 * t.blk, W = 16 * nb + 16, nfull = L >> 4;
     const long base = (long)(t.nh >> 2) * L;
     const float* __restrict__ qh = b.qkv + base * 192 + 16 * h;
+    const float* __restrict__ qhp = b.qkvp + base * 192 + 16 * h;
     const float* __restrict__ e_blk = ewin + (long)(I0 - 15 + W) * 16;
+    const float* __restrict__ e_blkp = ewinp + (long)(I0 - 15 + W) * 16;
     const int ri = I0 + c < L ? I0 + c : L - 1;
-    const f32x4 qa = ldg4(qh + (long)ri * 192 + 4 * g) * splat4(AT_QSCALE);
+    const AtB qa = at_b_of(at_ldq(qh + (long)ri * 192 + 4 * g));
     float gs, ginv;
     at_scale(amax, gs, ginv);
-    const f32x4 ga = ldg4(dO + (base + ri) * 64 + 16 * h + 4 * g) * splat4(gs);
+    const AtB ga = at_b_of(at_lda(dO + (base + ri) * 64 + 16 * h + 4 * g));        // the dO image is stored scaled by gs
     const float lse = b.lse[(long)t.nh * L + ri] * AT_LOG2E, Di = D[(base + ri) * 4 + h] * gs;
     const unsigned la = c * 192 + 4 * g, lb = 4 * g * 192 + c, le = c * 16 + 4 * g, lg = g * 16 + c;
     const unsigned la_t = at_off_a(16 * nfull, L, 192, c, g);
@@ -1645,28 +1764,34 @@ __global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __res
 #pragma unroll
     for (int r = 0; r < 4; ++r) { lb_t[r] = at_off_b(16 * nfull, L, 192, c, g, r); vt[r] = 16 * nfull + 4 * g + r < L; }
     f32x4 dq = splat4(0.f);               // dq[query 4g + r][d = c]
-    f32x4 eq1 = at_dot(ldg4(e_blk + 256 + le), qa);
-    f32x4 eb_prev;                        // E rows of the previous key block's lower 16 distances = this block's upper 16
+    f32x4 eq1 = at_dot(at_lda(e_blk + 256 + le), qa);
+    AtB eb_prev;                          // E rows of the previous key block's lower 16 distances = this block's upper 16
+    {
+        f32x4 raw;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) eb_prev[s] = e_blk[256 + lg + 64 * s];
-    struct Frag { f32x4 ka, va, kb, ea, eb; };
+        for (int s = 0; s < 4; ++s) raw[s] = e_blkp[256 + lg + 64 * s];
+        eb_prev = at_row_b(raw);
+    }
+    struct Frag { AtA ka, va, ea; f32x4 kb, eb; };
     auto load = [&](auto tail, int jb) {
         constexpr bool TAIL = decltype(tail)::value;
         const float* __restrict__ kp = qh + 64 + (long)jb * (16 * 192);
+        const float* __restrict__ kpp = qhp + 64 + (long)jb * (16 * 192);
         const float* __restrict__ ep = e_blk - (long)jb * 256;
+        const float* __restrict__ epp = e_blkp - (long)jb * 256;
         Frag f;
-        f.ka = ldg4(kp + (TAIL ? la_t : la));
-        f.va = ldg4(kp + 64 + (TAIL ? la_t : la));
+        f.ka = at_lda(kp + (TAIL ? la_t : la));
+        f.va = at_lda(kp + 64 + (TAIL ? la_t : la));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) f.kb[r] = kp[TAIL ? lb_t[r] : lb + r * 192];
-        f.ea = ldg4(ep + le);
+        for (int r = 0; r < 4; ++r) f.kb[r] = kpp[TAIL ? lb_t[r] : lb + r * 192];
+        f.ea = at_lda(ep + le);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) f.eb[s] = ep[lg + 64 * s];
+        for (int s = 0; s < 4; ++s) f.eb[s] = epp[lg + 64 * s];
         return f;
     };
     auto tile = [&](auto tail, const Frag& f) {
         constexpr bool TAIL = decltype(tail)::value;
-        const f32x4 &kb = f.kb, &eb_lo = f.eb;
+        const AtB kb = at_row_b(f.kb), eb_lo = at_row_b(f.eb);
         const f32x4 eq0 = at_dot(f.ea, qa);
         const f32x4 st = at_dot(f.ka, qa), dpt = at_dot(f.va, ga);
         const f32x4 rt = at_skew_t(buf, eq0, eq1, c, g);
@@ -1677,7 +1802,7 @@ __global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __res
             const float p = (!TAIL || vt[r]) ? __builtin_amdgcn_exp2f(st[r] + rt[r] - lse) : 0.f;
             ds[r] = p * (dpt[r] - Di);
         }
-        dq = at_mma4(ds, kb, dq);
+        dq = at_mma(at_a(ds), kb, dq);
         // unskew: dSE[query c][distance 4s + g] = dS[c][15 + c - (4s + g)], zero outside the tile (the pads)
         wave_lds_fence();
         *reinterpret_cast<f32x4*>(buf2 + c * AT_PS + 16 + 4 * g) = ds;
@@ -1688,8 +1813,8 @@ __global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __res
             a_lo[s] = buf2[c * (AT_PS + 1) + 3 - g + 4 * (7 - s)];
             a_hi[s] = buf2[c * (AT_PS + 1) + 3 - g + 4 * (3 - s)];
         }
-        dq = at_mma4(a_lo, eb_lo, dq);
-        dq = at_mma4(a_hi, eb_prev, dq);
+        dq = at_mma(at_a(a_lo), eb_lo, dq);
+        dq = at_mma(at_a(a_hi), eb_prev, dq);
         eb_prev = eb_lo;
     };
     if (nfull > 0) {
@@ -1711,8 +1836,8 @@ __global__ __launch_bounds__(256) void at_dq_kernel(AtBufs b, const float* __res
 }
 
 // one tile in the (query 4g + r, key c) orientation: P and dS.  lse (log2 units) / D are per query ROW here.
-__device__ __forceinline__ void at_tile_pds(float* buf, const f32x4& qa, const f32x4& ga, const f32x4& ka, const f32x4& va,
-                                            const f32x4& e0, const f32x4& e1, const f32x4& lse, const f32x4& Dr, int c, int g,
+__device__ __forceinline__ void at_tile_pds(float* buf, const AtA& qa, const AtA& ga, const AtB& ka, const AtB& va,
+                                            const AtB& e0, const AtB& e1, const f32x4& lse, const f32x4& Dr, int c, int g,
                                             f32x4& p, f32x4& ds) {
     const f32x4 sc = at_dot(qa, ka), dp = at_dot(ga, va);
     const f32x4 rr = at_skew(buf, at_dot(qa, e0), at_dot(qa, e1), c, g);
@@ -1726,8 +1851,9 @@ __device__ __forceinline__ void at_tile_pds(float* buf, const f32x4& qa, const f
 // dk, dv: task (n, h, key block).          dk_j = scale sum_i ds_ij q_i,  dv_j = sum_i p_ij dO_i
 // (key columns past the end of the sequence only feed their own, never stored, rows: no mask for them)
 __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ dO,
-                                                     const float* __restrict__ D, const float* __restrict__ amax, int L, int nb,
-                                                     long ntask, float* __restrict__ dqkv) {
+                                                     const float* __restrict__ dOp, const float* __restrict__ D,
+                                                     const float* __restrict__ amax, int L, int nb, long ntask,
+                                                     float* __restrict__ dqkv) {
     __shared__ float sm[4][16 * AT_PB];
     AtTask t;
     if (!at_task(ntask, nb, t)) return;
@@ -1736,33 +1862,37 @@ __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __re
     const int h = t.nh & 3, J0 = 16 * t.blk, W = 16 * nb + 16, nfull = L >> 4;
     const long base = (long)(t.nh >> 2) * L;
     const float* __restrict__ qh = b.qkv + base * 192 + 16 * h;
+    const float* __restrict__ qhp = b.qkvp + base * 192 + 16 * h;
     const float* __restrict__ gh = dO + base * 64 + 16 * h;
+    const float* __restrict__ ghp = dOp + base * 64 + 16 * h;
     const float* __restrict__ lh = b.lse + (long)t.nh * L;
     const float* __restrict__ Dh = D + base * 4 + h;
     const float* __restrict__ e_blk = ewin + (long)(W - J0 - 15) * 16;             // band of query block 0; block ib: + 256 ib
     const long rj = (long)J0 * 192 + at_off_a(J0, L, 192, c, g);
-    const f32x4 ka = ldg4(qh + 64 + rj), va = ldg4(qh + 128 + rj);
+    const AtB ka = at_b_of(at_lda(qh + 64 + rj)), va = at_b_of(at_lda(qh + 128 + rj));
     const unsigned le = c * 16 + 4 * g;
     float gs, ginv;
     at_scale(amax, gs, ginv);
     f32x4 dk = splat4(0.f), dv = splat4(0.f);        // [key 4g + r][d = c]
-    f32x4 e0 = ldg4(e_blk + le);
-    struct Frag { f32x4 qa, ga, e1, qb, gb, lse, Dr; int I0; };
+    AtB e0 = at_b_of(at_lda(e_blk + le));
+    struct Frag { AtA qa, ga, e1; f32x4 qb, gb, lse, Dr; int I0; };
     auto load = [&](auto tail, int ib) {
         constexpr bool TAIL = decltype(tail)::value;
         const int I0 = 16 * ib;
         const float* __restrict__ qp = qh + (long)ib * (16 * 192);
         const float* __restrict__ gp = gh + (long)ib * (16 * 64);
+        const float* __restrict__ qpp = qhp + (long)ib * (16 * 192);
+        const float* __restrict__ gpp = ghp + (long)ib * (16 * 64);
         Frag f;
         f.I0 = I0;
-        f.qa = ldg4(qp + (TAIL ? at_off_a(I0, L, 192, c, g) : c * 192 + 4 * g));
-        f.ga = ldg4(gp + (TAIL ? at_off_a(I0, L, 64, c, g) : c * 64 + 4 * g));
-        f.e1 = ldg4(e_blk + (long)ib * 256 + 256 + le);
+        f.qa = at_ldq(qp + (TAIL ? at_off_a(I0, L, 192, c, g) : c * 192 + 4 * g));
+        f.ga = at_lda(gp + (TAIL ? at_off_a(I0, L, 64, c, g) : c * 64 + 4 * g));
+        f.e1 = at_lda(e_blk + (long)ib * 256 + 256 + le);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rr = TAIL ? (I0 + 4 * g + r < L ? 4 * g + r : L - 1 - I0) : 4 * g + r;
-            f.qb[r] = qp[rr * 192 + c];
-            f.gb[r] = gp[rr * 64 + c];
+            f.qb[r] = qpp[rr * 192 + c];
+            f.gb[r] = gpp[rr * 64 + c];
             f.lse[r] = lh[I0 + rr];
             f.Dr[r] = Dh[(long)(I0 + rr) * 4];
         }
@@ -1771,19 +1901,17 @@ __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __re
     auto tile = [&](auto tail, const Frag& f) {
         constexpr bool TAIL = decltype(tail)::value;
         const int I0 = f.I0;
-        const f32x4& qb = f.qb;
-        const f32x4 gb = f.gb * splat4(gs);
+        const AtB qb = at_row_b(f.qb), gb = at_row_b(f.gb), e1 = at_b_of(f.e1);
         f32x4 p, ds;
-        at_tile_pds(buf, f.qa * splat4(AT_QSCALE), f.ga * splat4(gs), ka, va, e0, f.e1, f.lse * splat4(AT_LOG2E),
-                    f.Dr * splat4(gs), c, g, p, ds);
-        e0 = f.e1;
+        at_tile_pds(buf, f.qa, f.ga, ka, va, e0, e1, f.lse * splat4(AT_LOG2E), f.Dr * splat4(gs), c, g, p, ds);
+        e0 = e1;
         if (TAIL) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (I0 + 4 * g + r >= L) { p[r] = 0.f; ds[r] = 0.f; }
         }
-        dk = at_mma4(ds, qb, dk);
-        dv = at_mma4(p, gb, dv);
+        dk = at_mma(at_a(ds), qb, dk);
+        dv = at_mma(at_a(p), gb, dv);
     };
     if (nfull > 0) {
         // two blocks per trip: the other block's operands are in flight while one is being worked on
@@ -1801,7 +1929,7 @@ __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __re
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         if (J0 + 4 * g + r < L) {
-            dqkv[(base + J0 + 4 * g + r) * 192 + 64 + 16 * h + c] = dk[r] * (0.25f * ginv);
+            dqkv[(base + J0 + 4 * g + r) * 192 + 64 + 16 * h + c] = dk[r] * (AT_QBACK * ginv);
             dqkv[(base + J0 + 4 * g + r) * 192 + 128 + 16 * h + c] = dv[r] * ginv;
         }
 }
@@ -1812,7 +1940,7 @@ __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __re
 // stays in two accumulators and is written once per diagonal: slab [(n, h)][delta + nb - 1][32][16].
 __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ dO,
                                                     const float* __restrict__ D, const float* __restrict__ amax, int L, int nb,
-                                                    long ntask, float* __restrict__ partial) {
+                                                    long ntask, float* __restrict__ partial) {   // dO: the quad image
     __shared__ float sm[4][16 * AT_PB + 16 * AT_PS];
     AtTask t;
     if (!at_task(ntask, nb, t)) return;
@@ -1823,6 +1951,7 @@ __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __res
     const int h = t.nh & 3, W = 16 * nb + 16, nfull = L >> 4;
     const long base = (long)(t.nh >> 2) * L;
     const float* __restrict__ qh = b.qkv + base * 192 + 16 * h;
+    const float* __restrict__ qhp = b.qkvp + base * 192 + 16 * h;
     const float* __restrict__ gh = dO + base * 64 + 16 * h;
     const float* __restrict__ lh = b.lse + (long)t.nh * L;
     const float* __restrict__ Dh = D + base * 4 + h;
@@ -1835,26 +1964,27 @@ __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __res
         const int ntile = seg == 0 ? nb - t.blk : t.blk;
         const int ib0 = seg == 0 ? t.blk : 0, jb0 = seg == 0 ? 0 : nb - t.blk;
         const float* __restrict__ ep = ewin + (long)(16 * delta - 15 + W) * 16;
-        const f32x4 e0 = ldg4(ep + le), e1 = ldg4(ep + 256 + le);
+        const AtB e0 = at_b_of(at_lda(ep + le)), e1 = at_b_of(at_lda(ep + 256 + le));
         f32x4 de0 = splat4(0.f), de1 = splat4(0.f);  // [distance 16 blk + 4g + r][d = c]
-        struct Frag { f32x4 qa, ga, ka, va, qb, lse, Dr; int I0, J0; };
+        struct Frag { AtA qa, ga, ka, va; f32x4 qb, lse, Dr; int I0, J0; };
         auto load = [&](auto tail, int k) {
             constexpr bool TAIL = decltype(tail)::value;
             const int I0 = 16 * (ib0 + k), J0 = 16 * (jb0 + k);
             const float* __restrict__ qp = qh + (long)I0 * 192;
+            const float* __restrict__ qpp = qhp + (long)I0 * 192;
             const float* __restrict__ gp = gh + (long)I0 * 64;
             const float* __restrict__ kp = qh + 64 + (long)J0 * 192;
             Frag f;
             f.I0 = I0; f.J0 = J0;
-            f.qa = ldg4(qp + (TAIL ? at_off_a(I0, L, 192, c, g) : c * 192 + 4 * g));
-            f.ga = ldg4(gp + (TAIL ? at_off_a(I0, L, 64, c, g) : c * 64 + 4 * g));
+            f.qa = at_ldq(qp + (TAIL ? at_off_a(I0, L, 192, c, g) : c * 192 + 4 * g));
+            f.ga = at_lda(gp + (TAIL ? at_off_a(I0, L, 64, c, g) : c * 64 + 4 * g));
             const unsigned oj = TAIL ? at_off_a(J0, L, 192, c, g) : c * 192 + 4 * g;
-            f.ka = ldg4(kp + oj);
-            f.va = ldg4(kp + 64 + oj);
+            f.ka = at_lda(kp + oj);
+            f.va = at_lda(kp + 64 + oj);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rr = TAIL ? (I0 + 4 * g + r < L ? 4 * g + r : L - 1 - I0) : 4 * g + r;
-                f.qb[r] = qp[rr * 192 + c];
+                f.qb[r] = qpp[rr * 192 + c];
                 f.lse[r] = lh[I0 + rr];
                 f.Dr[r] = Dh[(long)(I0 + rr) * 4];
             }
@@ -1863,10 +1993,10 @@ __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __res
         auto tile = [&](auto tail, const Frag& f) {
             constexpr bool TAIL = decltype(tail)::value;
             const int I0 = f.I0, J0 = f.J0;
-            const f32x4& qb = f.qb;
+            const AtB qb = at_row_b(f.qb);
             f32x4 p, ds;
-            at_tile_pds(buf, f.qa * splat4(AT_QSCALE), f.ga * splat4(gs), f.ka, f.va, e0, e1, f.lse * splat4(AT_LOG2E),
-                        f.Dr * splat4(gs), c, g, p, ds);
+            at_tile_pds(buf, f.qa, f.ga, at_b_of(f.ka), at_b_of(f.va), e0, e1, f.lse * splat4(AT_LOG2E), f.Dr * splat4(gs),
+                        c, g, p, ds);
             if (TAIL) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -1884,8 +2014,8 @@ __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __res
                 r0[r] = row[16];
                 r1[r] = row[0];
             }
-            de0 = at_mma4(r0, qb, de0);
-            de1 = at_mma4(r1, qb, de1);
+            de0 = at_mma(at_a(r0), qb, de0);
+            de1 = at_mma(at_a(r1), qb, de1);
         };
         // a diagonal's tiles are full except (when L is not a multiple of 16) its last one
         const int nfl = (ib0 + ntile > nfull || jb0 + ntile > nfull) ? ntile - 1 : ntile;
@@ -1905,8 +2035,8 @@ __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __res
         float* out = partial + ((long)t.nh * (2 * nb - 1) + (delta + nb - 1)) * 512;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            out[(4 * g + r) * 16 + c] = de0[r] * (0.25f * ginv);
-            out[(16 + 4 * g + r) * 16 + c] = de1[r] * (0.25f * ginv);
+            out[(4 * g + r) * 16 + c] = de0[r] * (AT_QBACK * ginv);
+            out[(16 + 4 * g + r) * 16 + c] = de1[r] * (AT_QBACK * ginv);
         }
     }
 }
@@ -2013,7 +2143,7 @@ static int at_blocks(int L) { return (L + 15) / 16; }
 static int at_window(int L) { return 16 * at_blocks(L) + 16; }      // half-width W of the relative-position window
 // launch width of the core kernels: four one-wave tasks per block, blocks rounded up to a multiple of the 8 XCDs
 static unsigned at_core_grid(long ntask) { return (unsigned)(((ntask + 3) / 4 + 7) / 8 * 8); }
-struct AtPlan { size_t raw, wqkv, wqkvt, wo, wot, ewin, qkv, o, lse, dout, dO, D, dqkv, xn, g1, dxn, depart, dewin, wpart, cpart, total; };
+struct AtPlan { size_t raw, wqkv, wqkvt, wo, wot, ewin, ewinp, qkv, qkvp, o, lse, dout, dO, dOp, D, dqkv, xn, g1, dxn, depart, dewin, wpart, cpart, total; };
 static AtPlan at_plan(int N, int L) {
     AtPlan p;
     const size_t M = (size_t)N * L;
@@ -2023,6 +2153,11 @@ static AtPlan at_plan(int N, int L) {
     p.ewin = take((size_t)(2 * at_window(L) + 1) * 16);
     p.qkv = take(M * 192); p.o = take(M * 64); p.lse = take((size_t)N * 4 * L);
     p.dout = take(M * 64); p.dO = take(M * 64); p.D = take(M * 4); p.dqkv = take(M * 192);
+#if AT_X3
+    p.ewinp = take((size_t)(2 * at_window(L) + 1) * 16); p.qkvp = take(M * 192); p.dOp = take(M * 64);   // pair images
+#else
+    p.ewinp = p.ewin; p.qkvp = p.qkv; p.dOp = p.dO;
+#endif
     p.xn = take(M * 64); p.g1 = take(M * 64); p.dxn = take(M * 64);
     const size_t slabs = (size_t)(2 * at_blocks(L) - 1) * 512;       // dE band slabs [2 nb - 1][32][16]
     p.depart = take((size_t)N * 4 * slabs);
@@ -2051,13 +2186,14 @@ void launch_attn_train_forward(LaunchCtx ctx, const float* x, int N, int L, cons
     const AtPlan pl = at_plan(N, L);
     const long M = (long)N * L;
     at_pack_images(ctx, p, ws, pl);
-    const AtBufs b{ws + pl.qkv, ws + pl.o, ws + pl.lse};
+    const AtBufs b{ws + pl.qkv, ws + pl.qkvp, ws + pl.o, ws + pl.lse};
     const unsigned grid = (unsigned)((M + 63) / 64);
-    LAUNCH(ctx, "attn_train_fwd", (at_qkv_kernel<<<grid, 256, 0, s>>>(x, M, ws + pl.wqkv, p.ln_w, p.ln_b, b.qkv)));
+    LAUNCH(ctx, "attn_train_fwd", (at_qkv_kernel<<<grid, 256, 0, s>>>(x, M, ws + pl.wqkv, p.ln_w, p.ln_b, b.qkv, b.qkvp)));
     const int nb = at_blocks(L);
     const long ntask = (long)N * 4 * nb;
     const int W = at_window(L);
-    LAUNCH(ctx, "attn_train_pack", (at_window_kernel<<<((2 * W + 1) * 16 + 255) / 256, 256, 0, s>>>(p.rel, W, max_pos, ws + pl.ewin)));
+    LAUNCH(ctx, "attn_train_pack", (at_window_kernel<<<((2 * W + 1) * 4 + 255) / 256, 256, 0, s>>>(p.rel, W, max_pos, ws + pl.ewin,
+                                                                                                   ws + pl.ewinp)));
     LAUNCH(ctx, "attn_train_fwd", (at_fwd_kernel<<<at_core_grid(ntask), 256, 0, s>>>(b, ws + pl.ewin, L, nb, ntask)));
     LAUNCH(ctx, "attn_train_fwd", (at_out_kernel<<<grid, 256, 0, s>>>(b.o, M, ws + pl.wo, p.bo, mask, ms, res, y)));
 }
@@ -2069,15 +2205,16 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     const AtPlan pl = at_plan(N, L);
     const long M = (long)N * L;
     at_pack_images(ctx, p, ws, pl, false);
-    const AtBufs b{ws + pl.qkv, ws + pl.o, ws + pl.lse};
+    const AtBufs b{ws + pl.qkv, ws + pl.qkvp, ws + pl.o, ws + pl.lse};
     const unsigned grid = (unsigned)((M + 63) / 64);
-    float* cpart = ws + pl.cpart;
-#if AT_X3
-    hipMemsetAsync(cpart, 0, sizeof(float), s);           // max |dO| (bit pattern): the column-sum slabs are idle until the end
-#endif
+    float* cpart = ws + pl.cpart;                         // [0]: max |dO|; [64 ..): its per-tile maxima (the column-sum slabs
+                                                          // are idle until the end of this function)
     LAUNCH(ctx, "attn_train_bwd", (at_out_bwd_kernel<<<grid, 256, 0, s>>>(dy, mask, ms, b.o, M, ws + pl.wot, ws + pl.dout,
-                                                                          ws + pl.dO, ws + pl.D,
-                                                                          reinterpret_cast<unsigned*>(cpart))));
+                                                                          ws + pl.dO, ws + pl.D, cpart + 64)));
+#if AT_X3
+    LAUNCH(ctx, "attn_train_bwd", (at_amax_kernel<<<1, 1024, 0, s>>>(cpart + 64, (M + 15) / 16, cpart)));
+    LAUNCH(ctx, "attn_train_bwd", (at_dO_split_kernel<<<2048, 256, 0, s>>>(ws + pl.dO, ws + pl.dOp, cpart, M * 16)));
+#endif
     // to_out gradients: dWo [64,64] = dout^T O, dbo = colsum dout
     wgrad_partial64(ctx, "attn_train_wgrad", ws + pl.dout, b.o, M, 64, 64, ws + pl.wpart, wg_split(1));
     LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<64, 1024, 0, s>>>(ws + pl.wpart, wg_split(1), 4096,
@@ -2086,10 +2223,10 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     const int nb = at_blocks(L);
     const long ntask = (long)N * 4 * nb;
     const unsigned cgrid = at_core_grid(ntask);
-    LAUNCH(ctx, "attn_train_bwd", (at_dq_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.D, cpart, L, nb, ntask,
-                                                                      ws + pl.dqkv)));
-    LAUNCH(ctx, "attn_train_bwd", (at_dkv_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.D, cpart, L, nb, ntask,
-                                                                       ws + pl.dqkv)));
+    LAUNCH(ctx, "attn_train_bwd", (at_dq_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.ewinp, ws + pl.dO, ws + pl.D, cpart, L,
+                                                                      nb, ntask, ws + pl.dqkv)));
+    LAUNCH(ctx, "attn_train_bwd", (at_dkv_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.dOp, ws + pl.D, cpart, L,
+                                                                       nb, ntask, ws + pl.dqkv)));
     LAUNCH(ctx, "attn_train_bwd", (at_de_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.D, cpart, L, nb, ntask,
                                                                       ws + pl.depart)));
     // rel_pos_emb gradient: sum the band slabs over (n, h) first (grouped, coalesced), then fold the band rows onto
