@@ -2,6 +2,8 @@
 // generator forward path: the non-adversarial loss terms of Trainer.calculate_generator_loss (train.py:124-151)
 // as deterministic reductions (the scalars the data-parallel step all-reduces over RCCL).
 #include "train.h"
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 // ---------------------------------------------------------------------------------
@@ -1333,6 +1335,11 @@ struct AtBufs {
     float *o;        // [M,64]   softmax(.) v, heads concatenated
     float *lse;      // [N,4,L]  row log-sum-exp of the scaled scores
 };
+// The fused backward core (at_bwd_fused_kernel, below) is selected at run time: CMGAN_ATTN_BWD=fused in the
+// environment.  It is parity-green (the whole training suite passes on it) and does 44 product steps per tile instead
+// of 76, but measured SLOWER than the three cores - 63.0 vs 54.4 ms of attention backward per step at batch 32: its
+// LDS accumulators leave one 7-wave block per CU (1.75 waves per SIMD), and at that occupancy a wave's dependent VALU
+// chain (294 VALU per tile; PMC: 48 % of wave cycles in issue stalls, 23 % parked) is not covered by other waves.
 #define AT_LOG2E 1.4426950408889634f  // scores are kept in log2 units: p = v_exp_f32(s - lse) without a multiply
 #define AT_QSCALE (0.25f * AT_LOG2E)  // dim_head^-0.5 * log2(e), folded into the q fragment of every score product
 // one float4 -> its quad-image and pair-image forms
@@ -2041,6 +2048,207 @@ __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Fused backward core (sequences of at most ATF_MAX_NB blocks): ONE block per (sequence, head) computes dq, dk, dv and
+// the band gradient from a single recomputation of P and dS per 16 x 16 tile, instead of three kernels that each
+// recompute them.  The obstacle to fusing is ownership: dq is summed along tile rows, dk / dv along tile columns and
+// dE along tile diagonals.  Here a wave owns WRAPPED DIAGONALS t (tiles with i - j = t mod nbp, nbp = the odd number
+// of blocks nb or nb + 1): in round r it works on tile (i, j) = ((r + 2t) mod nbp, (r + t) mod nbp), so that within a
+// round all waves hold distinct query blocks AND distinct key blocks (t -> 2t and t -> t are injective mod an odd
+// nbp: a Latin square).  dq / dk / dv tiles are accumulated in LDS without conflicts or atomics - a block barrier
+// separates the rounds, every sum keeps a fixed order - and the band gradient of the wave's diagonal stays in two
+// accumulators (a wrapped diagonal is two real ones, delta = t and t - nbp; the accumulators are flushed to the
+// diagonal's slab when delta changes - pos -> neg -> pos or neg -> pos -> neg - and the second visit of a real
+// diagonal adds to what the first one stored: same wave, fixed order).
+// Per tile: 16 + 8 + 8 + 12 product steps instead of 28 + 24 + 24, one skew, one exp pass, one set of operand loads.
+// LDS: three [16][16 nbp + 4] fp32 accumulators (transposed: a lane's four rows are one b128) + the two wave-private
+// patches.  SLOTS = wrapped diagonals per wave (waves = ceil(nbp / SLOTS) <= 8).
+// ---------------------------------------------------------------------------------
+#define ATF_MAX_NB 22                 // L <= 352: accumulators 3 x 16 x 372 x 4 B = 71 KB
+#define ATF_PATCH (16 * AT_PB + 16 * AT_PS)
+struct AtfStep { int i, j, delta, t; bool valid; };
+template <int SLOTS>
+__device__ __forceinline__ AtfStep atf_step(int r, int k, int NW, int wv, int nb, int nbp) {
+    AtfStep s;
+    s.t = wv + k * NW;
+    int i = r + 2 * s.t, j = r + s.t;
+    i -= i >= nbp ? nbp : 0;
+    i -= i >= nbp ? nbp : 0;
+    j -= j >= nbp ? nbp : 0;
+    s.valid = s.t < nbp && i < nb && j < nb;
+    s.i = s.valid ? i : 0;
+    s.j = s.valid ? j : 0;
+    s.delta = s.i - s.j;
+    return s;
+}
+template <int SLOTS>
+__global__ __launch_bounds__(512) void at_bwd_fused_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ ewinp,
+                                                           const float* __restrict__ dO, const float* __restrict__ dOp,
+                                                           const float* __restrict__ D, const float* __restrict__ amax, int L,
+                                                           int nb, int nbp, float* __restrict__ dqkv,
+                                                           float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float atf_sm[];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), NW = blockDim.x >> 6;
+    const int ROWP = 16 * nbp + 4;
+    float* accq = atf_sm;
+    float* acck = accq + 16 * ROWP;
+    float* accv = acck + 16 * ROWP;
+    float* buf = accv + 16 * ROWP + wv * ATF_PATCH;       // band patch [16][AT_PB]
+    float* buf2 = buf + 16 * AT_PB;                       // dS patch [query][16 + key]
+    for (int e = threadIdx.x; e < 3 * 16 * ROWP; e += blockDim.x) atf_sm[e] = 0.f;
+    at_zero_pads(buf2, lane);
+    const int nh = blockIdx.x, h = nh & 3, W = 16 * nb + 16;
+    const bool ragged = (L & 15) != 0;
+    const long base = (long)(nh >> 2) * L;
+    const float* __restrict__ qh = b.qkv + base * 192 + 16 * h;
+    const float* __restrict__ qhp = b.qkvp + base * 192 + 16 * h;
+    const float* __restrict__ gh = dO + base * 64 + 16 * h;
+    const float* __restrict__ ghp = dOp + base * 64 + 16 * h;
+    const float* __restrict__ lh = b.lse + (long)nh * L;
+    const float* __restrict__ Dh = D + base * 4 + h;
+    const unsigned le = c * 16 + 4 * g, lg = g * 16 + c;
+    float gs, ginv;
+    at_scale(amax, gs, ginv);
+    __syncthreads();
+
+    struct Frag { AtA qa, ga, ka, va, e0, e1; f32x4 qb, gb, kb, eb_lo, eb_hi, lse, Dr; };
+    auto load = [&](const AtfStep& s) {
+        const int I0 = 16 * s.i, J0 = 16 * s.j;
+        const bool tq = ragged && s.i == nb - 1, tk = ragged && s.j == nb - 1;
+        const float* __restrict__ qp = qh + (long)I0 * 192;
+        const float* __restrict__ qpp = qhp + (long)I0 * 192;
+        const float* __restrict__ gp = gh + (long)I0 * 64;
+        const float* __restrict__ gpp = ghp + (long)I0 * 64;
+        const float* __restrict__ kp = qh + 64 + (long)J0 * 192;
+        const float* __restrict__ kpp = qhp + 64 + (long)J0 * 192;
+        const float* __restrict__ ep = ewin + (long)(16 * s.delta - 15 + W) * 16;
+        const float* __restrict__ epp = ewinp + (long)(16 * s.delta - 15 + W) * 16;
+        Frag f;
+        const int ci = tq ? (I0 + c < L ? c : L - 1 - I0) : c;      // rows past the end read row L - 1 (masked below)
+        const int cj = tk ? (J0 + c < L ? c : L - 1 - J0) : c;
+        f.qa = at_ldq(qp + ci * 192 + 4 * g);
+        f.ga = at_lda(gp + ci * 64 + 4 * g);
+        f.ka = at_lda(kp + cj * 192 + 4 * g);
+        f.va = at_lda(kp + 64 + cj * 192 + 4 * g);
+        f.e0 = at_lda(ep + le);
+        f.e1 = at_lda(ep + 256 + le);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ri = tq ? (I0 + 4 * g + r < L ? 4 * g + r : L - 1 - I0) : 4 * g + r;
+            const int rj = tk ? (J0 + 4 * g + r < L ? 4 * g + r : L - 1 - J0) : 4 * g + r;
+            f.qb[r] = qpp[ri * 192 + c];
+            f.gb[r] = gpp[ri * 64 + c];
+            f.kb[r] = kpp[rj * 192 + c];
+            f.lse[r] = lh[I0 + ri];
+            f.Dr[r] = Dh[(long)(I0 + ri) * 4];
+            f.eb_lo[r] = epp[lg + 64 * r];
+            f.eb_hi[r] = epp[256 + lg + 64 * r];
+        }
+        return f;
+    };
+    auto tile = [&](const Frag& f, const AtfStep& s, f32x4& de0, f32x4& de1) {
+        const int I0 = 16 * s.i, J0 = 16 * s.j;
+        f32x4 p, ds;
+        at_tile_pds(buf, f.qa, f.ga, at_b_of(f.ka), at_b_of(f.va), at_b_of(f.e0), at_b_of(f.e1), f.lse * splat4(AT_LOG2E),
+                    f.Dr * splat4(gs), c, g, p, ds);
+        if (ragged && (s.i == nb - 1 || s.j == nb - 1)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (I0 + 4 * g + r >= L || J0 + c >= L) { p[r] = 0.f; ds[r] = 0.f; }
+        }
+        // dk_j += dS^T q,  dv_j += P^T dO       [key 4g + r][d = c], accumulated in the transposed LDS arrays
+        const AtB qb = at_row_b(f.qb);
+        {
+            const f32x4 dk = at_dot(at_a(ds), qb), dv = at_dot(at_a(p), at_row_b(f.gb));
+            f32x4* pk = reinterpret_cast<f32x4*>(acck + c * ROWP + J0 + 4 * g);
+            f32x4* pv = reinterpret_cast<f32x4*>(accv + c * ROWP + J0 + 4 * g);
+            *pk = *pk + dk;
+            *pv = *pv + dv;
+        }
+        // the dS patch serves the band gradient (unskew^T), dq's band term (unskew) and dq's key term (transpose)
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf2[(4 * g + r) * AT_PS + 16 + c] = ds[r];
+        wave_lds_fence();
+        f32x4 r0, r1, a_lo, a_hi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float* row = buf2 + 4 * g * (AT_PS + 1) + 15 - c + r * (AT_PS + 1);
+            r0[r] = row[16];
+            r1[r] = row[0];
+            a_lo[r] = buf2[c * (AT_PS + 1) + 3 - g + 4 * (7 - r)];
+            a_hi[r] = buf2[c * (AT_PS + 1) + 3 - g + 4 * (3 - r)];
+        }
+        const f32x4 dst = *reinterpret_cast<const f32x4*>(buf2 + c * AT_PS + 16 + 4 * g);   // dS[query c][key 4g + r]
+        de0 = at_mma(at_a(r0), qb, de0);
+        de1 = at_mma(at_a(r1), qb, de1);
+        f32x4 dq = at_dot(at_a(dst), at_row_b(f.kb));
+        dq = at_mma(at_a(a_lo), at_row_b(f.eb_lo), dq);
+        dq = at_mma(at_a(a_hi), at_row_b(f.eb_hi), dq);
+        f32x4* pq = reinterpret_cast<f32x4*>(accq + c * ROWP + I0 + 4 * g);
+        *pq = *pq + dq;
+    };
+    // band-gradient slabs [(n, h)][delta + nb - 1][32][16]: first visit of a real diagonal stores, the second adds
+    auto flush = [&](int delta, const f32x4& de0, const f32x4& de1, bool add) {
+        float* out = partial + ((long)nh * (2 * nb - 1) + (delta + nb - 1)) * 512;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float* o0 = out + (4 * g + r) * 16 + c;
+            float* o1 = out + (16 + 4 * g + r) * 16 + c;
+            const float v0 = de0[r] * (AT_QBACK * ginv), v1 = de1[r] * (AT_QBACK * ginv);
+            *o0 = add ? *o0 + v0 : v0;
+            *o1 = add ? *o1 + v1 : v1;
+        }
+    };
+    f32x4 de0[SLOTS], de1[SLOTS];
+    int cur[SLOTS];
+    bool posdone[SLOTS], negdone[SLOTS];      // a wrapped diagonal visits one of its two real diagonals twice
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        de0[k] = splat4(0.f); de1[k] = splat4(0.f); cur[k] = -4096; posdone[k] = false; negdone[k] = false;
+    }
+
+    AtfStep s = atf_step<SLOTS>(0, 0, NW, wv, nb, nbp);
+    Frag f = load(s);
+    for (int r = 0; r < nbp; ++r) {
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const bool last = k == SLOTS - 1;
+            const int rn = last ? r + 1 : r, kn = last ? 0 : k + 1;
+            AtfStep sn = atf_step<SLOTS>(rn < nbp ? rn : 0, kn, NW, wv, nb, nbp);
+            const Frag fn = load(sn);                                 // in flight while this tile is worked on
+            if (s.valid) {
+                if (s.delta != cur[k]) {
+                    if (cur[k] != -4096) {
+                        flush(cur[k], de0[k], de1[k], cur[k] >= 0 ? posdone[k] : negdone[k]);
+                        if (cur[k] >= 0) posdone[k] = true;
+                        else negdone[k] = true;
+                    }
+                    cur[k] = s.delta;
+                    de0[k] = splat4(0.f);
+                    de1[k] = splat4(0.f);
+                }
+                tile(f, s, de0[k], de1[k]);
+            }
+            f = fn;
+            s = sn;
+        }
+        __syncthreads();                                              // the round's dq / dk / dv tiles are in LDS
+    }
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k)
+        if (cur[k] != -4096) flush(cur[k], de0[k], de1[k], cur[k] >= 0 ? posdone[k] : negdone[k]);
+    for (int e = threadIdx.x; e < L * 16; e += blockDim.x) {
+        const int row = e >> 4, d = e & 15;
+        float* o = dqkv + (base + row) * 192 + 16 * h + d;
+        o[0] = accq[d * ROWP + row] * (0.25f * ginv);
+        o[64] = acck[d * ROWP + row] * (AT_QBACK * ginv);
+        o[128] = accv[d * ROWP + row] * ginv;
+    }
+}
+static size_t atf_lds_bytes(int nbp, int nw) { return ((size_t)3 * 16 * (16 * nbp + 4) + (size_t)nw * ATF_PATCH) * sizeof(float); }
+
 // rel_pos_emb gradient [2 max_pos + 1][16] from the (n, h)-summed diagonal slabs [2 nb - 1][32][16]: row e sums, in
 // distance then diagonal order, every band row whose clamped distance is e - max_pos (a distance lies in the bands of
 // one or two neighbouring diagonals)
@@ -2223,12 +2431,35 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     const int nb = at_blocks(L);
     const long ntask = (long)N * 4 * nb;
     const unsigned cgrid = at_core_grid(ntask);
+    const char* bwd_env = getenv("CMGAN_ATTN_BWD");               // read per launch: tests switch it inside one process
+    const bool fused_env = bwd_env != nullptr && strcmp(bwd_env, "fused") == 0;
+    if (fused_env && nb <= ATF_MAX_NB) {
+        const int nbp = nb | 1, slots = (nbp + 7) / 8, nw = (nbp + slots - 1) / slots;
+        const size_t lds = atf_lds_bytes(nbp, nw);
+#define ATF_LAUNCH(SL)                                                                                                     \
+        do {                                                                                                               \
+            static bool optin = false;                                                                                     \
+            if (!optin) {                                                                                                  \
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&at_bwd_fused_kernel<SL>),                               \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                               \
+                optin = true;                                                                                              \
+            }                                                                                                              \
+            LAUNCH(ctx, "attn_train_bwd", (at_bwd_fused_kernel<SL><<<N * 4, 64 * nw, lds, s>>>(                             \
+                                              b, ws + pl.ewin, ws + pl.ewinp, ws + pl.dO, ws + pl.dOp, ws + pl.D, cpart, L, \
+                                              nb, nbp, ws + pl.dqkv, ws + pl.depart)));                                    \
+        } while (0)
+        if (slots == 1) ATF_LAUNCH(1);
+        else if (slots == 2) ATF_LAUNCH(2);
+        else ATF_LAUNCH(3);
+#undef ATF_LAUNCH
+    } else {
     LAUNCH(ctx, "attn_train_bwd", (at_dq_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.ewinp, ws + pl.dO, ws + pl.D, cpart, L,
                                                                       nb, ntask, ws + pl.dqkv)));
     LAUNCH(ctx, "attn_train_bwd", (at_dkv_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.dOp, ws + pl.D, cpart, L,
                                                                        nb, ntask, ws + pl.dqkv)));
     LAUNCH(ctx, "attn_train_bwd", (at_de_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.dO, ws + pl.D, cpart, L, nb, ntask,
                                                                       ws + pl.depart)));
+    }
     // rel_pos_emb gradient: sum the band slabs over (n, h) first (grouped, coalesced), then fold the band rows onto
     // the clamped table rows
     const int slab_elems = (2 * nb - 1) * 512;

@@ -317,13 +317,18 @@ def test_fused_residual_pointers_equal_a_separate_add(ff):
         ff.forward(x, m1, m2, residual=r[:, :5])
 
 
-@pytest.mark.parametrize("n,l", [(2, 321), (3, 101), (1, 512), (2, 7), (1, 65), (1, 600)])
-def test_attention_train_full_length_sequences_vs_oracle_autograd(n, l):
-    """the two sequence lengths of the 2 s training clip (time axis T = 321, frequency axis F' = 101), a multiple of the
+@pytest.mark.parametrize("bwd", ["cores", "fused"])
+@pytest.mark.parametrize("n,l", [(2, 321), (3, 101), (1, 512), (2, 7), (1, 65), (1, 600), (2, 32), (1, 352)])
+def test_attention_train_full_length_sequences_vs_oracle_autograd(n, l, bwd, monkeypatch):
+    """bwd = "fused": the one-kernel backward (at_bwd_fused_kernel: wrapped-diagonal ownership, LDS accumulators; taken
+    for L <= 352, CMGAN_ATTN_BWD=fused) against the same gradients as the three cores - 32 and 352 are an even number
+    of blocks (padded Latin square), 512 and 600 fall back to the cores.
+    The two sequence lengths of the 2 s training clip (time axis T = 321, frequency axis F' = 101), a multiple of the
     16-row tile (512: no ragged block anywhere), two short ones (7: a single ragged block; 65: one row in the last
     block) and one longer than max_pos_emb (600: distances beyond +-512 share the end rows of the embedding table,
     in the scores and in its gradient); no dropout."""
     from cmgan_amd.training import AttentionTrain
+    monkeypatch.setenv("CMGAN_ATTN_BWD", bwd)
     csd = conformer_state_dict(seed=3)
     at = AttentionTrain({k: csd["attn." + k] for k in AT_KEYS})
     rng = np.random.Generator(np.random.PCG64(17 + l))
