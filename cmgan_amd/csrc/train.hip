@@ -1481,6 +1481,14 @@ __device__ __forceinline__ AtA at_ldq(const float* __restrict__ p) {
     return ldg4(p) * splat4(AT_QSCALE);
 #endif
 }
+// a q fragment that did not come through at_ldq (fp32 build: the score scale is still to be applied)
+__device__ __forceinline__ AtA at_qfix(const AtA& q) {
+#if AT_X3
+    return q;
+#else
+    return q * splat4(AT_QSCALE);
+#endif
+}
 // exact power-of-two scale of the backward cores' gradient operands (dO and D = rowsum(dO o)): s brings the largest
 // |dO| of the whole tensor (*amax: per-block maxima of at_out_bwd_kernel reduced by at_amax_kernel - order-independent)
 // to [1, 2); the dO images are stored scaled, D is scaled on load, and every output of a core - linear in dO - is
@@ -2062,7 +2070,7 @@ __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __res
 // diagonal adds to what the first one stored: same wave, fixed order).
 // Per tile: 16 + 8 + 8 + 12 product steps instead of 28 + 24 + 24, one skew, one exp pass, one set of operand loads.
 // LDS: three [16][16 nbp + 4] fp32 accumulators (transposed: a lane's four rows are one b128) + the two wave-private
-// patches.  SLOTS = wrapped diagonals per wave (waves = ceil(nbp / SLOTS) <= 8).
+// patches.  SLOTS = wrapped diagonals per wave: 1 up to 8 blocks, else 2 (waves = ceil(nbp / SLOTS) <= 12).
 // ---------------------------------------------------------------------------------
 #define ATF_MAX_NB 22                 // L <= 352: accumulators 3 x 16 x 372 x 4 B = 71 KB
 #define ATF_PATCH (16 * AT_PB + 16 * AT_PS)
@@ -2082,7 +2090,7 @@ __device__ __forceinline__ AtfStep atf_step(int r, int k, int NW, int wv, int nb
     return s;
 }
 template <int SLOTS>
-__global__ __launch_bounds__(512) void at_bwd_fused_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ ewinp,
+__global__ __launch_bounds__(SLOTS == 1 ? 512 : 768) void at_bwd_fused_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ ewinp,
                                                            const float* __restrict__ dO, const float* __restrict__ dOp,
                                                            const float* __restrict__ D, const float* __restrict__ amax, int L,
                                                            int nb, int nbp, float* __restrict__ dqkv,
@@ -2112,43 +2120,95 @@ __global__ __launch_bounds__(512) void at_bwd_fused_kernel(AtBufs b, const float
     at_scale(amax, gs, ginv);
     __syncthreads();
 
-    struct Frag { AtA qa, ga, ka, va, e0, e1; f32x4 qb, gb, kb, eb_lo, eb_hi, lse, Dr; };
+    // Frag: what a tile needs at its START, fetched one step ahead.  Rows: the row-type fragments it needs from its
+    // middle on (dk / dv / dE / dq products), fetched at the start of the tile itself - their latency hides under the
+    // score phase and they do not occupy registers across steps.
+    struct Frag { AtA qa, ga, ka, va, e0, e1; f32x4 lse, Dr; };
+    struct Rows { f32x4 qb, gb, kb, eb_lo, eb_hi; };
+    // operand loads as uniform base (SGPRs, the row / distance block folded in with scalar adds) + a loop-invariant 32-bit
+    // per-lane BYTE offset: the global_load "saddr" form, no 64-bit VALU address arithmetic per load
+    const unsigned oa192 = (c * 192 + 4 * g) * 4, oa64 = (c * 64 + 4 * g) * 4, ob192 = (4 * g * 192 + c) * 4,
+                   ob64 = (4 * g * 64 + c) * 4, ole = le * 4, olg = lg * 4;
+    auto ld4 = [](const float* base, unsigned off) {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + off);
+    };
+    auto ld1 = [](const float* base, unsigned off) {
+        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + off);
+    };
     auto load = [&](const AtfStep& s) {
         const int I0 = 16 * s.i, J0 = 16 * s.j;
         const bool tq = ragged && s.i == nb - 1, tk = ragged && s.j == nb - 1;
-        const float* __restrict__ qp = qh + (long)I0 * 192;
-        const float* __restrict__ qpp = qhp + (long)I0 * 192;
-        const float* __restrict__ gp = gh + (long)I0 * 64;
-        const float* __restrict__ gpp = ghp + (long)I0 * 64;
-        const float* __restrict__ kp = qh + 64 + (long)J0 * 192;
-        const float* __restrict__ kpp = qhp + 64 + (long)J0 * 192;
+        // A-type fragments from the PAIR images too (one 16-byte load + the four v_perm of at_row_a): reading both
+        // interleavings made a (sequence, head)'s working set 164 KB - 5.2 MB per XCD with one block per CU, more than
+        // its 4 MB L2, and the tile sweeps of the rounds missed it 67 % of the time (TCC counters; 17 % at L = 101)
+        const float* __restrict__ qp = qhp + (long)I0 * 192;
+        const float* __restrict__ gp = ghp + (long)I0 * 64;
+        const float* __restrict__ kp = qhp + 64 + (long)J0 * 192;
         const float* __restrict__ ep = ewin + (long)(16 * s.delta - 15 + W) * 16;
-        const float* __restrict__ epp = ewinp + (long)(16 * s.delta - 15 + W) * 16;
         Frag f;
-        const int ci = tq ? (I0 + c < L ? c : L - 1 - I0) : c;      // rows past the end read row L - 1 (masked below)
-        const int cj = tk ? (J0 + c < L ? c : L - 1 - J0) : c;
-        f.qa = at_ldq(qp + ci * 192 + 4 * g);
-        f.ga = at_lda(gp + ci * 64 + 4 * g);
-        f.ka = at_lda(kp + cj * 192 + 4 * g);
-        f.va = at_lda(kp + 64 + cj * 192 + 4 * g);
-        f.e0 = at_lda(ep + le);
-        f.e1 = at_lda(ep + 256 + le);
+        if (!(tq || tk)) {
+            f.qa = at_qfix(at_row_a(ld4(qp, oa192)));
+            f.ga = at_row_a(ld4(gp, oa64));
+            f.ka = at_row_a(ld4(kp, oa192));
+            f.va = at_row_a(ld4(kp + 64, oa192));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                f.lse[r] = ld1(lh + I0 + r, 16 * g);
+                f.Dr[r] = ld1(Dh + (long)(I0 + r) * 4, 64 * g);
+            }
+        } else {                                                  // ragged last block: rows past the end read row L - 1
+            const int ci = tq ? (I0 + c < L ? c : L - 1 - I0) : c;
+            const int cj = tk ? (J0 + c < L ? c : L - 1 - J0) : c;
+            f.qa = at_qfix(at_row_a(ldg4(qp + ci * 192 + 4 * g)));
+            f.ga = at_row_a(ldg4(gp + ci * 64 + 4 * g));
+            f.ka = at_row_a(ldg4(kp + cj * 192 + 4 * g));
+            f.va = at_row_a(ldg4(kp + 64 + cj * 192 + 4 * g));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ri = tq ? (I0 + 4 * g + r < L ? 4 * g + r : L - 1 - I0) : 4 * g + r;
+                f.lse[r] = lh[I0 + ri];
+                f.Dr[r] = Dh[(long)(I0 + ri) * 4];
+            }
+        }
+        f.e0 = __builtin_bit_cast(AtA, ld4(ep, ole));
+        f.e1 = __builtin_bit_cast(AtA, ld4(ep + 256, ole));
+        return f;
+    };
+    auto load_rows = [&](const AtfStep& s) {
+        const int I0 = 16 * s.i, J0 = 16 * s.j;
+        const bool tq = ragged && s.i == nb - 1, tk = ragged && s.j == nb - 1;
+        const float* __restrict__ qpp = qhp + (long)I0 * 192;
+        const float* __restrict__ gpp = ghp + (long)I0 * 64;
+        const float* __restrict__ kpp = qhp + 64 + (long)J0 * 192;
+        const float* __restrict__ epp = ewinp + (long)(16 * s.delta - 15 + W) * 16;
+        Rows w;
+        if (!(tq || tk)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                w.qb[r] = ld1(qpp + r * 192, ob192);
+                w.gb[r] = ld1(gpp + r * 64, ob64);
+                w.kb[r] = ld1(kpp + r * 192, ob192);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ri = tq ? (I0 + 4 * g + r < L ? 4 * g + r : L - 1 - I0) : 4 * g + r;
+                const int rj = tk ? (J0 + 4 * g + r < L ? 4 * g + r : L - 1 - J0) : 4 * g + r;
+                w.qb[r] = qpp[ri * 192 + c];
+                w.gb[r] = gpp[ri * 64 + c];
+                w.kb[r] = kpp[rj * 192 + c];
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int ri = tq ? (I0 + 4 * g + r < L ? 4 * g + r : L - 1 - I0) : 4 * g + r;
-            const int rj = tk ? (J0 + 4 * g + r < L ? 4 * g + r : L - 1 - J0) : 4 * g + r;
-            f.qb[r] = qpp[ri * 192 + c];
-            f.gb[r] = gpp[ri * 64 + c];
-            f.kb[r] = kpp[rj * 192 + c];
-            f.lse[r] = lh[I0 + ri];
-            f.Dr[r] = Dh[(long)(I0 + ri) * 4];
-            f.eb_lo[r] = epp[lg + 64 * r];
-            f.eb_hi[r] = epp[256 + lg + 64 * r];
+            w.eb_lo[r] = ld1(epp + 64 * r, olg);
+            w.eb_hi[r] = ld1(epp + 256 + 64 * r, olg);
         }
-        return f;
+        return w;
     };
     auto tile = [&](const Frag& f, const AtfStep& s, f32x4& de0, f32x4& de1) {
         const int I0 = 16 * s.i, J0 = 16 * s.j;
+        const Rows w = load_rows(s);
         f32x4 p, ds;
         at_tile_pds(buf, f.qa, f.ga, at_b_of(f.ka), at_b_of(f.va), at_b_of(f.e0), at_b_of(f.e1), f.lse * splat4(AT_LOG2E),
                     f.Dr * splat4(gs), c, g, p, ds);
@@ -2158,9 +2218,9 @@ __global__ __launch_bounds__(512) void at_bwd_fused_kernel(AtBufs b, const float
                 if (I0 + 4 * g + r >= L || J0 + c >= L) { p[r] = 0.f; ds[r] = 0.f; }
         }
         // dk_j += dS^T q,  dv_j += P^T dO       [key 4g + r][d = c], accumulated in the transposed LDS arrays
-        const AtB qb = at_row_b(f.qb);
+        const AtB qb = at_row_b(w.qb);
         {
-            const f32x4 dk = at_dot(at_a(ds), qb), dv = at_dot(at_a(p), at_row_b(f.gb));
+            const f32x4 dk = at_dot(at_a(ds), qb), dv = at_dot(at_a(p), at_row_b(w.gb));
             f32x4* pk = reinterpret_cast<f32x4*>(acck + c * ROWP + J0 + 4 * g);
             f32x4* pv = reinterpret_cast<f32x4*>(accv + c * ROWP + J0 + 4 * g);
             *pk = *pk + dk;
@@ -2183,9 +2243,9 @@ __global__ __launch_bounds__(512) void at_bwd_fused_kernel(AtBufs b, const float
         const f32x4 dst = *reinterpret_cast<const f32x4*>(buf2 + c * AT_PS + 16 + 4 * g);   // dS[query c][key 4g + r]
         de0 = at_mma(at_a(r0), qb, de0);
         de1 = at_mma(at_a(r1), qb, de1);
-        f32x4 dq = at_dot(at_a(dst), at_row_b(f.kb));
-        dq = at_mma(at_a(a_lo), at_row_b(f.eb_lo), dq);
-        dq = at_mma(at_a(a_hi), at_row_b(f.eb_hi), dq);
+        f32x4 dq = at_dot(at_a(dst), at_row_b(w.kb));
+        dq = at_mma(at_a(a_lo), at_row_b(w.eb_lo), dq);
+        dq = at_mma(at_a(a_hi), at_row_b(w.eb_hi), dq);
         f32x4* pq = reinterpret_cast<f32x4*>(accq + c * ROWP + I0 + 4 * g);
         *pq = *pq + dq;
     };
@@ -2209,32 +2269,45 @@ __global__ __launch_bounds__(512) void at_bwd_fused_kernel(AtBufs b, const float
         de0[k] = splat4(0.f); de1[k] = splat4(0.f); cur[k] = -4096; posdone[k] = false; negdone[k] = false;
     }
 
-    AtfStep s = atf_step<SLOTS>(0, 0, NW, wv, nb, nbp);
-    Frag f = load(s);
-    for (int r = 0; r < nbp; ++r) {
-#pragma unroll
-        for (int k = 0; k < SLOTS; ++k) {
-            const bool last = k == SLOTS - 1;
-            const int rn = last ? r + 1 : r, kn = last ? 0 : k + 1;
-            AtfStep sn = atf_step<SLOTS>(rn < nbp ? rn : 0, kn, NW, wv, nb, nbp);
-            const Frag fn = load(sn);                                 // in flight while this tile is worked on
-            if (s.valid) {
-                if (s.delta != cur[k]) {
-                    if (cur[k] != -4096) {
-                        flush(cur[k], de0[k], de1[k], cur[k] >= 0 ? posdone[k] : negdone[k]);
-                        if (cur[k] >= 0) posdone[k] = true;
-                        else negdone[k] = true;
-                    }
-                    cur[k] = s.delta;
-                    de0[k] = splat4(0.f);
-                    de1[k] = splat4(0.f);
-                }
-                tile(f, s, de0[k], de1[k]);
+    // one step = one (round, slot) tile of this wave; the next step's operands are in flight while a tile is worked on.
+    // Two rounds per trip so that the two operand buffers alternate with compile-time parity (no register copies).
+    auto work = [&](const Frag& f, const AtfStep& s, int k) {
+        if (!s.valid) return;
+        if (s.delta != cur[k]) {
+            if (cur[k] != -4096) {
+                flush(cur[k], de0[k], de1[k], cur[k] >= 0 ? posdone[k] : negdone[k]);
+                if (cur[k] >= 0) posdone[k] = true;
+                else negdone[k] = true;
             }
-            f = fn;
-            s = sn;
+            cur[k] = s.delta;
+            de0[k] = splat4(0.f);
+            de1[k] = splat4(0.f);
         }
-        __syncthreads();                                              // the round's dq / dk / dv tiles are in LDS
+        tile(f, s, de0[k], de1[k]);
+    };
+    auto step_at = [&](int q) {                                       // q = round * SLOTS + slot; past the end: a dummy
+        const int r = q / SLOTS, k = q - r * SLOTS;
+        return atf_step<SLOTS>(r < nbp ? r : 0, k, NW, wv, nb, nbp);
+    };
+    AtfStep sa = step_at(0), sb;
+    Frag fa = load(sa), fb;
+    for (int r = 0; r < nbp; r += 2) {
+        const bool second = r + 1 < nbp;                              // nbp is odd: the last trip has one round
+#pragma unroll
+        for (int p = 0; p < 2 * SLOTS; p += 2) {
+            // steps p (buffer a) and p + 1 (buffer b) of this trip; step p + 2 goes back into buffer a
+            const int q = r * SLOTS + p;
+            sb = step_at(q + 1);
+            if (!second && p + 1 >= SLOTS) sb.valid = false;
+            fb = load(sb);
+            if (second || p < SLOTS) work(fa, sa, p % SLOTS);
+            if (p % SLOTS == SLOTS - 1) __syncthreads();              // end of a round: its dq / dk / dv tiles are in LDS
+            sa = step_at(q + 2);
+            if (!second && p + 2 >= SLOTS) sa.valid = false;
+            fa = load(sa);
+            if (second || p + 1 < SLOTS) work(fb, sb, (p + 1) % SLOTS);
+            if ((p + 1) % SLOTS == SLOTS - 1) __syncthreads();
+        }
     }
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k)
@@ -2434,7 +2507,7 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     const char* bwd_env = getenv("CMGAN_ATTN_BWD");               // read per launch: tests switch it inside one process
     const bool fused_env = bwd_env != nullptr && strcmp(bwd_env, "fused") == 0;
     if (fused_env && nb <= ATF_MAX_NB) {
-        const int nbp = nb | 1, slots = (nbp + 7) / 8, nw = (nbp + slots - 1) / slots;
+        const int nbp = nb | 1, slots = nbp <= 8 ? 1 : 2, nw = (nbp + slots - 1) / slots;   // <= 8 / <= 12 waves
         const size_t lds = atf_lds_bytes(nbp, nw);
 #define ATF_LAUNCH(SL)                                                                                                     \
         do {                                                                                                               \
@@ -2449,8 +2522,7 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
                                               nb, nbp, ws + pl.dqkv, ws + pl.depart)));                                    \
         } while (0)
         if (slots == 1) ATF_LAUNCH(1);
-        else if (slots == 2) ATF_LAUNCH(2);
-        else ATF_LAUNCH(3);
+        else ATF_LAUNCH(2);
 #undef ATF_LAUNCH
     } else {
     LAUNCH(ctx, "attn_train_bwd", (at_dq_kernel<<<cgrid, 256, 0, s>>>(b, ws + pl.ewin, ws + pl.ewinp, ws + pl.dO, ws + pl.D, cpart, L,

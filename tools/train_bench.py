@@ -13,9 +13,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batches", default="4,16")
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--cut-len", type=int, default=32000)
+ap.add_argument("--attn-bwd", default=None, help="cores | fused: sets CMGAN_ATTN_BWD for the run")
 ap.add_argument("--adversarial", action="store_true",
                 help="time training.adversarial_train_step (generator + metric discriminator, given PESQ labels)")
 args = ap.parse_args()
+if args.attn_bwd:
+    os.environ["CMGAN_ATTN_BWD"] = args.attn_bwd
 
 gen = GeneratorTrain(make_state_dict(0), device="cuda:0")
 opt = AdamW(gen.engine, gen.param_bucket, gen.grad_bucket, lr=5e-4)
