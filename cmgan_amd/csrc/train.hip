@@ -1335,11 +1335,12 @@ struct AtBufs {
     float *o;        // [M,64]   softmax(.) v, heads concatenated
     float *lse;      // [N,4,L]  row log-sum-exp of the scaled scores
 };
-// The fused backward core (at_bwd_fused_kernel, below) is selected at run time: CMGAN_ATTN_BWD=fused in the
-// environment.  It is parity-green (the whole training suite passes on it) and does 44 product steps per tile instead
-// of 76, but measured SLOWER than the three cores - 63.0 vs 54.4 ms of attention backward per step at batch 32: its
-// LDS accumulators leave one 7-wave block per CU (1.75 waves per SIMD), and at that occupancy a wave's dependent VALU
-// chain (294 VALU per tile; PMC: 48 % of wave cycles in issue stalls, 23 % parked) is not covered by other waves.
+// Sequences of up to ATF_MAX_NB blocks run the fused backward core (at_bwd_fused_kernel, below): 44 product steps per
+// tile instead of the 76 of the three cores.  CMGAN_ATTN_BWD=cores in the environment forces the three cores (which
+// longer sequences always use); both paths are held to the same gradients by the tests.  Per step at batch 32
+// (rocprofv3): time axis 32.7 -> 30.0 ms, frequency axis 14.3 -> 13.9 ms.  Its first form was SLOWER (63 vs 54 ms):
+// one 7-wave block per CU, and operands read from both image interleavings - 164 KB per (sequence, head), 5.2 MB per
+// XCD against a 4 MB L2, 67 % TCC misses (PMC) - see the load lambda.
 #define AT_LOG2E 1.4426950408889634f  // scores are kept in log2 units: p = v_exp_f32(s - lse) without a multiply
 #define AT_QSCALE (0.25f * AT_LOG2E)  // dim_head^-0.5 * log2(e), folded into the q fragment of every score product
 // one float4 -> its quad-image and pair-image forms
@@ -2505,7 +2506,7 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     const long ntask = (long)N * 4 * nb;
     const unsigned cgrid = at_core_grid(ntask);
     const char* bwd_env = getenv("CMGAN_ATTN_BWD");               // read per launch: tests switch it inside one process
-    const bool fused_env = bwd_env != nullptr && strcmp(bwd_env, "fused") == 0;
+    const bool fused_env = !(bwd_env != nullptr && strcmp(bwd_env, "cores") == 0);
     if (fused_env && nb <= ATF_MAX_NB) {
         const int nbp = nb | 1, slots = nbp <= 8 ? 1 : 2, nw = (nbp + slots - 1) / slots;   // <= 8 / <= 12 waves
         const size_t lds = atf_lds_bytes(nbp, nw);
