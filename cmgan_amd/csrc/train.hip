@@ -2093,8 +2093,8 @@ __device__ __forceinline__ AtfStep atf_step(int r, int k, int NW, int wv, int nb
 template <int SLOTS>
 __global__ __launch_bounds__(SLOTS == 1 ? 512 : 768) void at_bwd_fused_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ ewinp,
                                                            const float* __restrict__ dO, const float* __restrict__ dOp,
-                                                           const float* __restrict__ D, const float* __restrict__ amax, int L,
-                                                           int nb, int nbp, float* __restrict__ dqkv,
+                                                           const float* __restrict__ D, const float* __restrict__ amax, int N,
+                                                           int L, int nb, int nbp, float* __restrict__ dqkv,
                                                            float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float atf_sm[];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -2105,9 +2105,15 @@ __global__ __launch_bounds__(SLOTS == 1 ? 512 : 768) void at_bwd_fused_kernel(At
     float* accv = acck + 16 * ROWP;
     float* buf = accv + 16 * ROWP + wv * ATF_PATCH;       // band patch [16][AT_PB]
     float* buf2 = buf + 16 * AT_PB;                       // dS patch [query][16 + key]
+    // blocks are dealt round-robin to the 8 XCDs: the four heads of a sequence (whose 64-byte row segments interleave
+    // in 128-byte lines) go to the SAME XCD - blocks b, b + 8, b + 16, b + 24 - so a line fetched into that L2 serves two
+    // heads instead of being fetched by two L2s (the grid is ceil(N / 8) * 32 blocks)
+    const int nseq = (int)(blockIdx.x >> 5) * 8 + (int)(blockIdx.x & 7);
+    if (nseq >= N) return;
+    const int nh = nseq * 4 + (int)((blockIdx.x >> 3) & 3);
     for (int e = threadIdx.x; e < 3 * 16 * ROWP; e += blockDim.x) atf_sm[e] = 0.f;
     at_zero_pads(buf2, lane);
-    const int nh = blockIdx.x, h = nh & 3, W = 16 * nb + 16;
+    const int h = nh & 3, W = 16 * nb + 16;
     const bool ragged = (L & 15) != 0;
     const long base = (long)(nh >> 2) * L;
     const float* __restrict__ qh = b.qkv + base * 192 + 16 * h;
@@ -2518,9 +2524,9 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                               \
                 optin = true;                                                                                              \
             }                                                                                                              \
-            LAUNCH(ctx, "attn_train_bwd", (at_bwd_fused_kernel<SL><<<N * 4, 64 * nw, lds, s>>>(                             \
-                                              b, ws + pl.ewin, ws + pl.ewinp, ws + pl.dO, ws + pl.dOp, ws + pl.D, cpart, L, \
-                                              nb, nbp, ws + pl.dqkv, ws + pl.depart)));                                    \
+            LAUNCH(ctx, "attn_train_bwd", (at_bwd_fused_kernel<SL><<<(N + 7) / 8 * 32, 64 * nw, lds, s>>>(                  \
+                                              b, ws + pl.ewin, ws + pl.ewinp, ws + pl.dO, ws + pl.dOp, ws + pl.D, cpart, N, \
+                                              L, nb, nbp, ws + pl.dqkv, ws + pl.depart)));                                 \
         } while (0)
         if (slots == 1) ATF_LAUNCH(1);
         else ATF_LAUNCH(2);
