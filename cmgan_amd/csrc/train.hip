@@ -1319,19 +1319,18 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
 #define AT_X3 1             // 1: the attention cores on split-f16 products fed from PRE-SPLIT operand images (below);
 #endif                      // 0: exact fp32 products (v_mfma_f32_16x16x4_f32), operands straight from the fp32 tensors
 // AT_X3 operand images.  Every tensor the cores read (q | k | v, dO, the relative-position window) is stored split into
-// fp16 hi / lo halves by its PRODUCER, in two interleavings of the same 4 bytes per element, so that a core's operand
-// load is the MFMA operand with no VALU work in between (round 3's first split-f16 form split inside the cores: 12
-// VALU per product, which took back what the matrix pipe gave - VALU and MFMA issue add up on this machine):
-//   quad image: the 16 bytes of floats 4i .. 4i + 3 hold [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3]  - a lane's A-type float4
-//               (four consecutive features of one row) IS the [hi | lo] operand of at_mma
-//   pair image: the 4 bytes of float i hold (hi_i, lo_i)                                        - row-type fragments (four
-//               scalar loads down a column) are re-packed with four v_perm_b32
+// fp16 hi / lo halves by its PRODUCER: the 4 bytes of element i hold (hi_i, lo_i), so that a core's operand is its
+// load plus four v_perm_b32 (at_row_a) instead of a 6-VALU split per float4 and product (round 3's first split-f16
+// form split inside the cores, which took back what the matrix pipe gave - VALU and MFMA issue add up on this
+// machine).  ONE interleaving serves both fragment types (an A-type float4 = 16 bytes of one row, a row-type fragment
+// = four dwords down a column): a second, MFMA-ready [hi x 4 | lo x 4] image for the A-type loads saved the perms but
+// doubled the bytes a (sequence, head) keeps in L2, which cost far more (at_bwd_fused_kernel).
 // q is stored PRE-SCALED by dim_head^-0.5 log2(e) (the factor every score product applies; dk and dE, which contract
 // with q, are multiplied by ln 2 instead of 0.25 at the end); dO is stored pre-scaled by the exact power of two of
 // at_scale.  fp32 build: both "images" are the fp32 tensor itself.
 struct AtBufs {
-    float *qkv;      // [M,192]  q | k | v  (features 16 h + d inside each 64): fp32, or the quad image
-    float *qkvp;     //          the pair image (fp32 build: = qkv)
+    float *qkv;      // [M,192]  q | k | v  (features 16 h + d inside each 64): fp32, or the (hi, lo) image
+    float *qkvp;     //          = qkv (a second interleaving lived here)
     float *o;        // [M,64]   softmax(.) v, heads concatenated
     float *lse;      // [N,4,L]  row log-sum-exp of the scaled scores
 };
@@ -1343,25 +1342,20 @@ struct AtBufs {
 // XCD against a 4 MB L2, 67 % TCC misses (PMC) - see the load lambda.
 #define AT_LOG2E 1.4426950408889634f  // scores are kept in log2 units: p = v_exp_f32(s - lse) without a multiply
 #define AT_QSCALE (0.25f * AT_LOG2E)  // dim_head^-0.5 * log2(e), folded into the q fragment of every score product
-// one float4 -> its quad-image and pair-image forms
-__device__ __forceinline__ void at_img4(const f32x4& v, f32x4& quad, f32x4& pair) {
+// one float4 -> its image form (hi0, lo0, hi1, lo1, hi2, lo2, hi3, lo3)
+__device__ __forceinline__ f32x4 at_img4(const f32x4& v) {
     f16x4 h, l;
     split4(v, h, l);
-    quad = __builtin_bit_cast(f32x4, __builtin_shufflevector(h, l, 0, 1, 2, 3, 4, 5, 6, 7));
-    pair = __builtin_bit_cast(f32x4, __builtin_shufflevector(h, l, 0, 4, 1, 5, 2, 6, 3, 7));
+    return __builtin_bit_cast(f32x4, __builtin_shufflevector(h, l, 0, 4, 1, 5, 2, 6, 3, 7));
 }
 
 // fp32 build: the projection as is.  AT_X3: both operand images, the q part (output blocks 0 .. 3) pre-scaled
 __device__ __forceinline__ void at_store_qkv(float* __restrict__ qkv, float* __restrict__ qkvp, long off, f32x4 v, bool is_q,
                                              bool ok) {
 #if AT_X3
+    (void)qkvp;
     if (is_q) v = v * splat4(AT_QSCALE);
-    f32x4 quad, pair;
-    at_img4(v, quad, pair);
-    if (ok) {
-        stg4(qkv + off, quad);
-        stg4(qkvp + off, pair);
-    }
+    if (ok) stg4(qkv + off, at_img4(v));
 #else
     (void)qkvp; (void)is_q;
     if (ok) stg4(qkv + off, v);
@@ -1442,8 +1436,8 @@ __device__ __forceinline__ AtB at_b_of(const AtA& a) {
     return AtB{__builtin_shufflevector(a, a, 0, 1, 2, 3, 0, 1, 2, 3), __builtin_shufflevector(a, a, 4, 5, 6, 7, 4, 5, 6, 7)};
 }
 __device__ __forceinline__ AtB at_b(const f32x4& x) { return at_b_of(at_a(x)); }
-__device__ __forceinline__ AtA at_lda(const float* __restrict__ p) { return __builtin_bit_cast(f16x8, ldg4(p)); }
-// four (hi, lo) dwords of the pair image (a row-type fragment) -> [hi(4) | lo(4)]
+// four (hi, lo) dwords of the image - an A-type float4 (four consecutive features of a row) or a row-type fragment
+// (four scalar loads down a column) - -> [hi(4) | lo(4)]
 __device__ __forceinline__ AtA at_row_a(const f32x4& raw) {
     const unsigned d0 = __float_as_uint(raw[0]), d1 = __float_as_uint(raw[1]), d2 = __float_as_uint(raw[2]),
                    d3 = __float_as_uint(raw[3]);
@@ -1452,6 +1446,7 @@ __device__ __forceinline__ AtA at_row_a(const f32x4& raw) {
                       __builtin_amdgcn_perm(d1, d0, 0x07060302u), __builtin_amdgcn_perm(d3, d2, 0x07060302u)};
     return __builtin_bit_cast(f16x8, v);
 }
+__device__ __forceinline__ AtA at_lda(const float* __restrict__ p) { return at_row_a(ldg4(p)); }
 __device__ __forceinline__ f32x4 at_mma(const AtA& a, const AtB& b, f32x4 acc) {
     acc = mfma32h(a, b.hh, acc);
     return mfma32l(a, b.ll, acc);
@@ -1525,10 +1520,8 @@ __global__ void at_window_kernel(const float* __restrict__ rel, int W, int max_p
     dist = dist < -max_pos ? -max_pos : (dist > max_pos ? max_pos : dist);
     const f32x4 v = ldg4(rel + (long)(dist + max_pos) * 16 + (q & 3) * 4);
 #if AT_X3
-    f32x4 quad, pair;
-    at_img4(v, quad, pair);
-    stg4(ewin + 4 * q, quad);
-    stg4(ewinp + 4 * q, pair);
+    (void)ewinp;
+    stg4(ewin + 4 * q, at_img4(v));
 #else
     (void)ewinp;
     stg4(ewin + 4 * q, v);
@@ -1732,17 +1725,14 @@ __global__ __launch_bounds__(1024) void at_amax_kernel(const float* __restrict__
         out[0] = m;
     }
 }
-// dO (fp32, as at_out_bwd_kernel left it) -> the scaled quad image IN PLACE (each float4 becomes its own 16 bytes) and
-// the pair image
+// dO (fp32, as at_out_bwd_kernel left it) -> the scaled image IN PLACE (each float4 becomes its own 16 bytes)
 __global__ __launch_bounds__(256) void at_dO_split_kernel(float* __restrict__ dO, float* __restrict__ dOp,
                                                           const float* __restrict__ amax, long n4) {
     float gs, ginv;
     at_scale(amax, gs, ginv);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        f32x4 quad, pair;
-        at_img4(ldg4(dO + 4 * i) * splat4(gs), quad, pair);
-        stg4(dO + 4 * i, quad);
-        stg4(dOp + 4 * i, pair);
+        (void)dOp;
+        stg4(dO + 4 * i, at_img4(ldg4(dO + 4 * i) * splat4(gs)));
     }
 }
 #endif
@@ -1956,7 +1946,7 @@ __global__ __launch_bounds__(256) void at_dkv_kernel(AtBufs b, const float* __re
 // stays in two accumulators and is written once per diagonal: slab [(n, h)][delta + nb - 1][32][16].
 __global__ __launch_bounds__(256) void at_de_kernel(AtBufs b, const float* __restrict__ ewin, const float* __restrict__ dO,
                                                     const float* __restrict__ D, const float* __restrict__ amax, int L, int nb,
-                                                    long ntask, float* __restrict__ partial) {   // dO: the quad image
+                                                    long ntask, float* __restrict__ partial) {
     __shared__ float sm[4][16 * AT_PB + 16 * AT_PS];
     AtTask t;
     if (!at_task(ntask, nb, t)) return;
@@ -2177,8 +2167,8 @@ __global__ __launch_bounds__(SLOTS == 1 ? 512 : 768) void at_bwd_fused_kernel(At
                 f.Dr[r] = Dh[(long)(I0 + ri) * 4];
             }
         }
-        f.e0 = __builtin_bit_cast(AtA, ld4(ep, ole));
-        f.e1 = __builtin_bit_cast(AtA, ld4(ep + 256, ole));
+        f.e0 = at_row_a(ld4(ep, ole));
+        f.e1 = at_row_a(ld4(ep + 256, ole));
         return f;
     };
     auto load_rows = [&](const AtfStep& s) {
@@ -2441,11 +2431,7 @@ static AtPlan at_plan(int N, int L) {
     p.ewin = take((size_t)(2 * at_window(L) + 1) * 16);
     p.qkv = take(M * 192); p.o = take(M * 64); p.lse = take((size_t)N * 4 * L);
     p.dout = take(M * 64); p.dO = take(M * 64); p.D = take(M * 4); p.dqkv = take(M * 192);
-#if AT_X3
-    p.ewinp = take((size_t)(2 * at_window(L) + 1) * 16); p.qkvp = take(M * 192); p.dOp = take(M * 64);   // pair images
-#else
-    p.ewinp = p.ewin; p.qkvp = p.qkv; p.dOp = p.dO;
-#endif
+    p.ewinp = p.ewin; p.qkvp = p.qkv; p.dOp = p.dO;             // one image per tensor (or the fp32 tensor itself)
     p.xn = take(M * 64); p.g1 = take(M * 64); p.dxn = take(M * 64);
     const size_t slabs = (size_t)(2 * at_blocks(L) - 1) * 512;       // dE band slabs [2 nb - 1][32][16]
     p.depart = take((size_t)N * 4 * slabs);
