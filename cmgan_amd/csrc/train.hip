@@ -1485,6 +1485,13 @@ __device__ __forceinline__ AtA at_qfix(const AtA& q) {
     return q * splat4(AT_QSCALE);
 #endif
 }
+// loads as uniform base + 32-bit per-lane BYTE offset: the global_load "saddr" form (no 64-bit VALU address arithmetic)
+__device__ __forceinline__ f32x4 at_ld4b(const float* __restrict__ base, unsigned boff) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + boff);
+}
+__device__ __forceinline__ float at_ld1b(const float* __restrict__ base, unsigned boff) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff);
+}
 // exact power-of-two scale of the backward cores' gradient operands (dO and D = rowsum(dO o)): s brings the largest
 // |dO| of the whole tensor (*amax: per-block maxima of at_out_bwd_kernel reduced by at_amax_kernel - order-independent)
 // to [1, 2); the dO images are stored scaled, D is scaled on load, and every output of a core - linear in dO - is
@@ -1574,12 +1581,12 @@ __global__ __launch_bounds__(256) void at_fwd_kernel(AtBufs b, const float* __re
     const float* __restrict__ qhp = b.qkvp + base * 192 + 16 * h;                  // the same rows of the pair image
     const float* __restrict__ e_blk = ewin + (long)(I0 - 15 + W) * 16;             // band of key block 0; block jb: - 256 jb
     const AtB qa = at_b_of(at_ldq(qh + (long)I0 * 192 + at_off_a(I0, L, 192, c, g)));
-    const unsigned la = c * 192 + 4 * g, lb = 4 * g * 192 + c, le = c * 16 + 4 * g;
-    const unsigned la_t = at_off_a(16 * nfull, L, 192, c, g);
+    const unsigned la = (c * 192 + 4 * g) * 4, lb = (4 * g * 192 + c) * 4, le = c * 16 + 4 * g;      // la, lb: BYTE offsets
+    const unsigned la_t = at_off_a(16 * nfull, L, 192, c, g) * 4;
     unsigned lb_t[4];
     bool vt[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { lb_t[r] = at_off_b(16 * nfull, L, 192, c, g, r); vt[r] = 16 * nfull + 4 * g + r < L; }
+    for (int r = 0; r < 4; ++r) { lb_t[r] = at_off_b(16 * nfull, L, 192, c, g, r) * 4; vt[r] = 16 * nfull + 4 * g + r < L; }
     f32x4 ot = splat4(0.f);               // o^T[d = 4g + r][query c]
     float m = -1e30f, l = 0.f;
     f32x4 eq1 = at_dot(at_lda(e_blk + 256 + le), qa);
@@ -1589,10 +1596,10 @@ __global__ __launch_bounds__(256) void at_fwd_kernel(AtBufs b, const float* __re
         const float* __restrict__ kp = qh + 64 + (long)jb * (16 * 192);
         const float* __restrict__ vp = qhp + 128 + (long)jb * (16 * 192);
         Frag f;
-        f.ka = at_lda(kp + (TAIL ? la_t : la));
+        f.ka = at_row_a(at_ld4b(kp, TAIL ? la_t : la));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) f.vb[r] = vp[TAIL ? lb_t[r] : lb + r * 192];
-        f.ea = at_lda(e_blk - (long)jb * 256 + le);
+        for (int r = 0; r < 4; ++r) f.vb[r] = TAIL ? at_ld1b(vp, lb_t[r]) : at_ld1b(vp + r * 192, lb);
+        f.ea = at_row_a(at_ld4b(e_blk - (long)jb * 256, le * 4));
         return f;
     };
     auto tile = [&](auto tail, const Frag& f) {
