@@ -3268,12 +3268,13 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
         if (x3d) LAUNCH(ctx, "dense_train_bwd", (db_dgrad_setup_kernel<<<1, 256, 0, st>>>(sc, B)));
 #endif
         for (int s = 0; s <= i; ++s) {
-#if TRAIN_X3
-            launch_db_conv_wgrad_x3(ctx, g, aslot(s), B, T, F, dil, DB_WG_SPLIT, ws + pl.wpart);
-#else
-            LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_kernel<<<dim3(6, DB_WG_SPLIT), 256, 0, st>>>(
-                                                 g, aslot(s), B, T, F, dil, ws + pl.wpart)));
-#endif
+            // the split-f16 kernel addresses a plane with 32-bit byte offsets: planes of 4 GB and more (16.7 M positions,
+            // 250 clips of the encoder's shape) take the fp32 kernel
+            if (TRAIN_X3 && (long)M * 256 < (1L << 32))
+                launch_db_conv_wgrad_x3(ctx, g, aslot(s), B, T, F, dil, DB_WG_SPLIT, ws + pl.wpart);
+            else
+                LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_kernel<<<dim3(6, DB_WG_SPLIT), 256, 0, st>>>(
+                                                     g, aslot(s), B, T, F, dil, ws + pl.wpart)));
             LAUNCH(ctx, "dense_train_reduce", (db_wgrad_scatter_kernel<<<6 * 64, 256, 0, st>>>(ws + pl.wpart, Cin, 64 * (i - s),
                                                                                                grad.conv_w[i])));
 #if TRAIN_X3

@@ -594,23 +594,27 @@ __global__ __launch_bounds__(256) void db_conv_wgrad_x3_kernel(const float* __re
         int t = (int)(rem / (unsigned)F), f = (int)(rem - (unsigned)t * F);
         f32x4 av[4][2], bv[4][2];                     // [block][e >> 2][e & 3]
         float mx = 0.f;
+        // 32-bit BYTE offsets from the (uniform) plane bases: a plane is at most 2^32 bytes (checked by the launcher), so
+        // every load is "saddr + lane offset + immediate" with no 64-bit VALU arithmetic per element
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const unsigned m = m0 + e;
             const bool ok = m < M;
             const int ts = t + dt, fs = f + df;
             const bool inb = ok && ts >= 0 && ts < T && fs >= 0 && fs < F;
-            const long src = inb ? ((long)bb * T + ts) * F + fs : 0;
-            const long mm = ok ? m : M - 1;
+            const unsigned src = inb ? ((bb * (unsigned)T + (unsigned)ts) * (unsigned)F + (unsigned)fs) : 0u;
+            const unsigned mm = ok ? m : M - 1u;
+            const unsigned oz = (mm * 64u + (unsigned)c) * 4u, oa = (src * 64u + (unsigned)c) * 4u;
 #pragma unroll
             for (int ib = 0; ib < 4; ++ib) {
-                const float v = ok ? dz[mm * 64 + 16 * ib + c] : 0.f;
+                const float v0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dz + 16 * ib) + oz);
+                const float v = ok ? v0 : 0.f;
                 av[ib][e >> 2][e & 3] = v;
                 mx = fmaxf(mx, fabsf(v));
             }
 #pragma unroll
             for (int jb = 0; jb < 4; ++jb) {
-                const float v = a[src * 64 + 16 * jb + c];
+                const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a + 16 * jb) + oa);
                 bv[jb][e >> 2][e & 3] = inb ? v : 0.f;
             }
             if (++f == F) { f = 0; if (++t == T) { t = 0; ++bb; } }
