@@ -598,6 +598,10 @@ void launch_wgrad_partial64_x3(LaunchCtx, const char* label, const float* P, con
                                float* partial, int nsplit);
 void launch_db_conv_wgrad_x3(LaunchCtx, const float* dz, const float* a, int B, int T, int F, int dil, int nsplit,
                              float* partial);
+void cm_x3_pack(LaunchCtx, const ConvModTrainParams& p, float* img_w1, float* img_w1t);
+void cm_x3_pw1glu(LaunchCtx, const float* x, long M, const float* img_w1, const ConvModTrainParams& p, float* u);
+void cm_x3_bwd2(LaunchCtx, const float* x, const float* du, long M, const float* img_w1, const float* img_w1t,
+                const ConvModTrainParams& p, const float* dres, float* dx, float* dag, float* xn_out, float* g1c, float* dxc);
 // the token-contraction weight gradient in either mode: grid (R / 64, C / 64, nsplit)
 static void wgrad_partial64(LaunchCtx ctx, const char* label, const float* P, const float* Q, long M, int R, int C,
                             float* partial, int nsplit) {
@@ -1219,8 +1223,15 @@ static CmImg cm_pack_images(LaunchCtx ctx, const ConvModTrainParams& p, float* i
     hipStream_t s = ctx.stream;
     float *w1 = img, *w1t = img + 16384, *w2 = img + 32768, *w2t = img + 32768 + 8192;
     if (!pack) return CmImg{w1, w1t, w2, w2t};
+#if TRAIN_X3
+    // pw1 (LN -> pw1 -> GLU and its backward run on split products): split-f16 images in the w1 / w1t slots
+    cm_x3_pack(ctx, p, w1, w1t);
+    launch_pack4(ctx, "convmod_train_pack", PackJobs{{{p.pw2_w, 64, 128, 128, 0, w2}, {p.pw2_w, 128, 64, 128, 1, w2t},
+                                                      {p.pw2_w, 64, 128, 128, 0, w2}, {p.pw2_w, 128, 64, 128, 1, w2t}}});
+#else
     launch_pack4(ctx, "convmod_train_pack", PackJobs{{{p.pw1_w, 256, 64, 64, 0, w1}, {p.pw1_w, 64, 256, 64, 1, w1t},
                                                       {p.pw2_w, 64, 128, 128, 0, w2}, {p.pw2_w, 128, 64, 128, 1, w2t}}});
+#endif
     return CmImg{w1, w1t, w2, w2t};
 }
 
@@ -1233,7 +1244,11 @@ void launch_convmod_train_forward(LaunchCtx ctx, const float* x, int N, int L, c
     const CmStats st{ws + pl.st, ws + pl.st + 128, ws + pl.st + 256, ws + pl.st + 384};
     const unsigned grid = (unsigned)((M + 63) / 64);
     const dim3 dgrid(N, (L + 31) / 32);
+#if TRAIN_X3
+    cm_x3_pw1glu(ctx, x, M, im.w1, p, ws + pl.u);
+#else
     LAUNCH(ctx, "convmod_train_fwd", (cm_pw1glu_kernel<<<grid, 256, 0, s>>>(x, M, im.w1, p, ws + pl.u)));
+#endif
     const long ntile = (long)dgrid.x * dgrid.y;
     const int tpb = cm_dw_tpb(ntile, CM_DW_BLOCKS), dblocks = (int)((ntile + tpb - 1) / tpb);
     LAUNCH(ctx, "convmod_train_fwd", (cm_depthwise_kernel<<<dblocks, 256, 0, s>>>(ws + pl.u, p.dw_w, p.dw_b, 0, L, (int)dgrid.y, ntile,
@@ -1292,9 +1307,13 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
         LAUNCH(ctx, "convmod_train_bwd", (cm_depthwise_kernel<<<dblocks, 256, 0, s>>>(dd, p.dw_w, nullptr, 1, L, (int)dgrid.y, nblk, tpb,
                                                                                       ws + pl.du, nullptr)));
     }
+#if TRAIN_X3
+    cm_x3_bwd2(ctx, x, ws + pl.du, M, im.w1, im.w1t, p, dres, dx, ws + pl.dag, ws + pl.xn, ws + pl.g1, ws + pl.dxn);
+#else
     LAUNCH(ctx, "convmod_train_bwd", (cm_bwd2_kernel<<<grid, 256, 0, s>>>(x, ws + pl.du, M, im.w1, im.w1t, p, dres, dx,
                                                                           ws + pl.dag, ws + pl.xn, ws + pl.g1,
                                                                           ws + pl.dxn)));
+#endif
     // pointwise-1 and LayerNorm gradients
     wgrad_partial64(ctx, "convmod_train_wgrad", ws + pl.dag, ws + pl.xn, M, 256, 64, ws + pl.wpart, wg_split(4));
     LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(ws + pl.wpart, wg_split(4), 16384,

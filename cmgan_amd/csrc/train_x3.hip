@@ -731,3 +731,175 @@ void launch_wgrad_partial64_x3(LaunchCtx ctx, const char* label, const float* P,
                                float* partial, int nsplit) {
     LAUNCH(ctx, label, (wgrad_partial64_x3_kernel<<<dim3(R / 64, C / 64, nsplit), 256, 0, ctx.stream>>>(P, Q, M, R, C, partial)));
 }
+
+// ---------------------------------------------------------------------------------
+// Conv module, per-token stages on split products (the fp32 kernels cm_pw1glu_kernel / cm_bwd2_kernel of train.hip ran
+// 256 / 512 v_mfma_f32_16x16x4_f32 per 16-token tile with L2-streamed weight fragments: 35-40 % matrix-pipe busy, the
+// largest fp32 items left in the step).  Same structure as the FeedForward kernels above: persistent blocks, weight
+// images resident in LDS, the per-token chain in registers.
+//   forward    u = a * sigmoid(gt),  [a ; gt] = W1 LN(x) + b1               conformer.py:161-164 (LayerNorm, pw conv, GLU)
+//   backward   da = du sigmoid(gt),  dg = du a sigmoid'(gt)  (a, gt recomputed);  dxn = W1^T [da ; dg];  LayerNorm backward
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void cm_pw1glu_x3_kernel(const float* __restrict__ x, long M,
+                                                           const _Float16* __restrict__ w1i, ConvModTrainParams p,
+                                                           float* __restrict__ u, int ntiles) {
+    __shared__ __attribute__((aligned(16))) _Float16 w1[32768];            // 64 KB: [16 output blocks][2 k32]
+    __shared__ __attribute__((aligned(16))) float par_l[384];              // gamma | beta | b1[256]
+    stage_lds16<4096, 512>(w1i, w1);
+    for (int i = threadIdx.x; i < 384; i += blockDim.x)
+        par_l[i] = i < 64 ? p.ln_w[i] : (i < 128 ? p.ln_b[i - 64] : p.pw1_b[i - 128]);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int tile = blockIdx.x * 8 + wv; tile < ntiles; tile += gridDim.x * 8) {
+        long row[2];
+        bool ok[2];
+        f16x8 xbh[2][2], xbl[2][2];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const long t = ((long)tile * 2 + tb) * 16 + c;
+            ok[tb] = t < M;
+            row[tb] = ok[tb] ? t : M - 1;
+            f32x4 xh[4], xn[4];
+            float rstd;
+            tx_load_norm(x, row[tb], g, par_l, xh, rstd, xn);
+            split8(xn[0], xn[1], xbh[tb][0], xbl[tb][0]);
+            split8(xn[2], xn[3], xbh[tb][1], xbl[tb][1]);
+        }
+#pragma unroll 2
+        for (int ob = 0; ob < 8; ++ob) {
+            const f32x4 ba = *reinterpret_cast<const f32x4*>(&par_l[128 + 16 * ob + 4 * g]);
+            const f32x4 bg = *reinterpret_cast<const f32x4*>(&par_l[256 + 16 * ob + 4 * g]);
+            f32x4 a[2] = {ba, ba}, gt[2] = {bg, bg};
+            lin_acc_x3<2, 2>(w1 + ob * 2048 + lane * 8, xbh, xbl, a);
+            lin_acc_x3<2, 2>(w1 + (ob + 8) * 2048 + lane * 8, xbh, xbl, gt);
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                f32x4 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = a[tb][e] * sigmoidf_fast(gt[tb][e]);
+                if (ok[tb]) stg4(u + row[tb] * 128 + 16 * ob + 4 * g, r);
+            }
+        }
+    }
+}
+
+// LDS: W1 image [16][2] (a, gt recompute) + W1^T image [4][8] (dxn) = 128 KB.  One 16-token block per wave trip: the
+// 256 values of [da ; dg] stay in registers between the two products, scaled by the exact power of two of the
+// block's largest magnitude before the split (du is a gradient).  g1c / dxc: per-block partial sums (ln_tile_colsums).
+__global__ __launch_bounds__(TX_WAVES * 64) void cm_bwd2_x3_kernel(const float* __restrict__ x, const float* __restrict__ du,
+                                                                   long M, const _Float16* __restrict__ w1i,
+                                                                   const _Float16* __restrict__ w1ti, ConvModTrainParams p,
+                                                                   const float* __restrict__ dres, float* __restrict__ dx,
+                                                                   float* __restrict__ dag, float* __restrict__ xn_out,
+                                                                   float* __restrict__ g1c, float* __restrict__ dxc,
+                                                                   int ntiles) {
+    __shared__ __attribute__((aligned(16))) _Float16 wlds[65536];
+    __shared__ __attribute__((aligned(16))) float par_l[384];
+    _Float16* w1 = wlds;
+    _Float16* w1t = wlds + 32768;
+    stage_lds16<4096, TX_WAVES * 64>(w1i, w1);
+    stage_lds16<4096, TX_WAVES * 64>(w1ti, w1t);
+    for (int i = threadIdx.x; i < 384; i += blockDim.x)
+        par_l[i] = i < 64 ? p.ln_w[i] : (i < 128 ? p.ln_b[i - 64] : p.pw1_b[i - 128]);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int tile = blockIdx.x * TX_WAVES + wv; tile < ntiles; tile += gridDim.x * TX_WAVES) {
+        const long t = (long)tile * 16 + c;
+        const bool ok = t < M;
+        const long row = ok ? t : M - 1;
+        f32x4 xh[4], xn[4];
+        float rstd;
+        tx_load_norm(x, row, g, par_l, xh, rstd, xn);
+        f16x8 xbh[1][2], xbl[1][2];
+        split8(xn[0], xn[1], xbh[0][0], xbl[0][0]);
+        split8(xn[2], xn[3], xbh[0][1], xbl[0][1]);
+        if (ok) {
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) stg4(xn_out + row * 64 + 16 * kb + 4 * g, xn[kb]);
+        }
+        f32x4 z[16];                                                   // [da (8 blocks) ; dg (8 blocks)]
+        float zmax = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < 8; ++ob) {
+            const f32x4 ba = *reinterpret_cast<const f32x4*>(&par_l[128 + 16 * ob + 4 * g]);
+            const f32x4 bg = *reinterpret_cast<const f32x4*>(&par_l[256 + 16 * ob + 4 * g]);
+            f32x4 a[1] = {ba}, gt[1] = {bg};
+            lin_acc_x3<2, 1>(w1 + ob * 2048 + lane * 8, xbh, xbl, a);
+            lin_acc_x3<2, 1>(w1 + (ob + 8) * 2048 + lane * 8, xbh, xbl, gt);
+            f32x4 duv = ldg4(du + row * 128 + 16 * ob + 4 * g);
+            if (!ok) duv = splat4(0.f);
+            f32x4 da, dg;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sg = sigmoidf_fast(gt[0][e]);
+                da[e] = duv[e] * sg;
+                dg[e] = duv[e] * a[0][e] * sg * (1.f - sg);
+            }
+            if (ok) {
+                stg4(dag + row * 256 + 16 * ob + 4 * g, da);
+                stg4(dag + row * 256 + 128 + 16 * ob + 4 * g, dg);
+            }
+            z[ob] = da;
+            z[8 + ob] = dg;
+            zmax = tx_absmax4(dg, tx_absmax4(da, zmax));
+        }
+        float zs, zinv;
+        tx_pow2(tx_wave_max(zmax), zs, zinv);
+        f16x8 zh[1][8], zl[1][8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) split8(z[2 * m] * splat4(zs), z[2 * m + 1] * splat4(zs), zh[0][m], zl[0][m]);
+        f32x4 dxn[4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x4 acc[1] = {splat4(0.f)};
+            lin_acc_x3<8, 1>(w1t + ob * 8 * 1024 + lane * 8, zh, zl, acc);
+            dxn[ob] = acc[0] * splat4(zinv);
+        }
+        f32x4 dxh[4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            dxh[kb] = dxn[kb] * *reinterpret_cast<const f32x4*>(&par_l[16 * kb + 4 * g]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s1 += dxh[kb][r];
+                s2 = fmaf(dxh[kb][r], xh[kb][r], s2);
+            }
+        }
+        const float mu1 = red_g_sum(s1) * (1.0f / 64.0f), mu2 = red_g_sum(s2) * (1.0f / 64.0f);
+        f32x4 ca[4], cb[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (ok) {
+                f32x4 dv = (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd);
+                if (dres) dv = dv + ldg4(dres + row * 64 + 16 * kb + 4 * g);
+                stg4(dx + row * 64 + 16 * kb + 4 * g, dv);
+            }
+            ca[kb] = ok ? dxn[kb] * xh[kb] : splat4(0.f);
+            cb[kb] = ok ? dxn[kb] : splat4(0.f);
+        }
+        ln_tile_colsums(ca, cb, c, g, tile, g1c, dxc);                 // row `tile` of the [ceil(M / 16)][64] slabs
+    }
+}
+
+// the conv module's pw1 images in the two 64 KB slots where the fp32 fragment images of pw1 lived
+void cm_x3_pack(LaunchCtx ctx, const ConvModTrainParams& p, float* img_w1, float* img_w1t) {
+    launch_pack_x3(ctx, "convmod_train_pack", PackX3Jobs{{{p.pw1_w, 256, 64, 64, 0, reinterpret_cast<_Float16*>(img_w1)},
+                                                          {p.pw1_w, 64, 256, 64, 1, reinterpret_cast<_Float16*>(img_w1t)},
+                                                          {}, {}}}, 2);
+}
+void cm_x3_pw1glu(LaunchCtx ctx, const float* x, long M, const float* img_w1, const ConvModTrainParams& p, float* u) {
+    const int ntiles = (int)((M + 31) / 32);
+    const int grid = (ntiles + 7) / 8 < 512 ? ((ntiles + 7) / 8 > 0 ? (ntiles + 7) / 8 : 1) : 512;
+    LAUNCH(ctx, "convmod_train_fwd", (cm_pw1glu_x3_kernel<<<grid, 512, 0, ctx.stream>>>(
+                                         x, M, reinterpret_cast<const _Float16*>(img_w1), p, u, ntiles)));
+}
+void cm_x3_bwd2(LaunchCtx ctx, const float* x, const float* du, long M, const float* img_w1, const float* img_w1t,
+                const ConvModTrainParams& p, const float* dres, float* dx, float* dag, float* xn_out, float* g1c, float* dxc) {
+    const int ntiles = (int)((M + 15) / 16);
+    LAUNCH(ctx, "convmod_train_bwd", (cm_bwd2_x3_kernel<<<tx_grid(ntiles, TX_WAVES), TX_WAVES * 64, 0, ctx.stream>>>(
+                                         x, du, M, reinterpret_cast<const _Float16*>(img_w1),
+                                         reinterpret_cast<const _Float16*>(img_w1t), p, dres, dx, dag, xn_out, g1c, dxc, ntiles)));
+}
