@@ -602,6 +602,16 @@ void cm_x3_pack(LaunchCtx, const ConvModTrainParams& p, float* img_w1, float* im
 void cm_x3_pw1glu(LaunchCtx, const float* x, long M, const float* img_w1, const ConvModTrainParams& p, float* u);
 void cm_x3_bwd2(LaunchCtx, const float* x, const float* du, long M, const float* img_w1, const float* img_w1t,
                 const ConvModTrainParams& p, const float* dres, float* dx, float* dag, float* xn_out, float* g1c, float* dxc);
+void cm_x3_pack_pw2(LaunchCtx, const ConvModTrainParams& p, float* img_w2, float* img_w2t);
+void cm_x3_bn_swish_pw2(LaunchCtx, const float* d, long M, const float* scale, const float* shift, const float* img_w2,
+                        const float* b2, const float* res, float* y);
+void cm_x3_bwd1(LaunchCtx, const float* dy, const float* d, long M, const float* mean, const float* rstd, const float* scale,
+                const float* shift, const float* img_w2t, float* ddn, float* s_out, float* g2c, float* ddnc, float* dyc);
+void at_x3_pack(LaunchCtx, const float* wraw, float* img_w, float* img_wt);
+void at_x3_qkv(LaunchCtx, const float* x, long M, const float* img_w, const float* ln_w, const float* ln_b, float* qkv,
+               int as_image, float qscale);
+void at_x3_qkv_bwd(LaunchCtx, const float* x, const float* dqkv, long M, const float* img_wt, const float* ln_w,
+                   const float* ln_b, const float* dres, float* dx, float* xn_out, float* g1c, float* dxc);
 // the token-contraction weight gradient in either mode: grid (R / 64, C / 64, nsplit)
 static void wgrad_partial64(LaunchCtx ctx, const char* label, const float* P, const float* Q, long M, int R, int C,
                             float* partial, int nsplit) {
@@ -1224,10 +1234,9 @@ static CmImg cm_pack_images(LaunchCtx ctx, const ConvModTrainParams& p, float* i
     float *w1 = img, *w1t = img + 16384, *w2 = img + 32768, *w2t = img + 32768 + 8192;
     if (!pack) return CmImg{w1, w1t, w2, w2t};
 #if TRAIN_X3
-    // pw1 (LN -> pw1 -> GLU and its backward run on split products): split-f16 images in the w1 / w1t slots
+    // every per-token stage of the module runs on split products: split-f16 images in the four slots
     cm_x3_pack(ctx, p, w1, w1t);
-    launch_pack4(ctx, "convmod_train_pack", PackJobs{{{p.pw2_w, 64, 128, 128, 0, w2}, {p.pw2_w, 128, 64, 128, 1, w2t},
-                                                      {p.pw2_w, 64, 128, 128, 0, w2}, {p.pw2_w, 128, 64, 128, 1, w2t}}});
+    cm_x3_pack_pw2(ctx, p, w2, w2t);
 #else
     launch_pack4(ctx, "convmod_train_pack", PackJobs{{{p.pw1_w, 256, 64, 64, 0, w1}, {p.pw1_w, 64, 256, 64, 1, w1t},
                                                       {p.pw2_w, 64, 128, 128, 0, w2}, {p.pw2_w, 128, 64, 128, 1, w2t}}});
@@ -1257,7 +1266,11 @@ void launch_convmod_train_forward(LaunchCtx ctx, const float* x, int N, int L, c
     LAUNCH(ctx, "convmod_train_fwd", (cm_bn_reduce_kernel<<<CM_BN_RED, 256, 0, s>>>(ws + pl.bnpart, (long)dblocks, bnred)));
     LAUNCH(ctx, "convmod_train_fwd", (cm_bn_finalize_kernel<<<1, 128, 0, s>>>(bnred, (double)M, p.bn_w, p.bn_b, st,
                                                                               running_mean, running_var)));
+#if TRAIN_X3
+    cm_x3_bn_swish_pw2(ctx, ws + pl.d, M, st.scale, st.shift, im.w2, p.pw2_b, res, y);
+#else
     LAUNCH(ctx, "convmod_train_fwd", (cm_bn_swish_pw2_kernel<<<grid, 256, 0, s>>>(ws + pl.d, M, st, im.w2, p.pw2_b, res, y)));
+#endif
 }
 
 void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* dy, int N, int L,
@@ -1280,8 +1293,12 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     };
     const long trows = (M + 15) / 16;                             // per-tile partial sums inside the g2 region [M,128]
     float *g2c = ws + pl.g2, *ddnc = g2c + trows * 128, *dyc = ddnc + trows * 128;
+#if TRAIN_X3
+    cm_x3_bwd1(ctx, dy, ws + pl.d, M, st.mean, st.rstd, st.scale, st.shift, im.w2t, ws + pl.ddn, ws + pl.s, g2c, ddnc, dyc);
+#else
     LAUNCH(ctx, "convmod_train_bwd", (cm_bwd1_kernel<<<grid, 256, 0, s>>>(dy, ws + pl.d, M, st, im.w2t, ws + pl.ddn,
                                                                           ws + pl.s, g2c, ddnc, dyc)));
+#endif
     // pointwise-2 gradients: dW_pw2 [64,128] = dy^T s, db_pw2 = colsum dy
     wgrad_partial64(ctx, "convmod_train_wgrad", dy, ws + pl.s, M, 64, 128, ws + pl.wpart, wg_split(2));
     LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<128, 1024, 0, s>>>(ws + pl.wpart, wg_split(2), 8192,
@@ -2475,9 +2492,15 @@ static void at_pack_images(LaunchCtx ctx, const AttnTrainParams& p, float* ws, c
     hipStream_t s = ctx.stream;
     hipMemcpyAsync(ws + pl.raw, p.wq, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);            // rows 0..63
     hipMemcpyAsync(ws + pl.raw + 4096, p.wkv, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);    // rows 64..191
+#if TRAIN_X3
+    at_x3_pack(ctx, ws + pl.raw, ws + pl.wqkv, ws + pl.wqkvt);      // the projections run on split products
+    launch_pack4(ctx, "attn_train_pack", PackJobs{{{p.wo, 64, 64, 64, 0, ws + pl.wo}, {p.wo, 64, 64, 64, 1, ws + pl.wot},
+                                                   {p.wo, 64, 64, 64, 0, ws + pl.wo}, {p.wo, 64, 64, 64, 1, ws + pl.wot}}});
+#else
     launch_pack4(ctx, "attn_train_pack", PackJobs{{{ws + pl.raw, 192, 64, 64, 0, ws + pl.wqkv},
                                                    {ws + pl.raw, 64, 192, 64, 1, ws + pl.wqkvt},
                                                    {p.wo, 64, 64, 64, 0, ws + pl.wo}, {p.wo, 64, 64, 64, 1, ws + pl.wot}}});
+#endif
 }
 
 void launch_attn_train_forward(LaunchCtx ctx, const float* x, int N, int L, const AttnTrainParams& p, int max_pos,
@@ -2488,7 +2511,11 @@ void launch_attn_train_forward(LaunchCtx ctx, const float* x, int N, int L, cons
     at_pack_images(ctx, p, ws, pl);
     const AtBufs b{ws + pl.qkv, ws + pl.qkvp, ws + pl.o, ws + pl.lse};
     const unsigned grid = (unsigned)((M + 63) / 64);
+#if TRAIN_X3
+    at_x3_qkv(ctx, x, M, ws + pl.wqkv, p.ln_w, p.ln_b, b.qkv, AT_X3, AT_QSCALE);
+#else
     LAUNCH(ctx, "attn_train_fwd", (at_qkv_kernel<<<grid, 256, 0, s>>>(x, M, ws + pl.wqkv, p.ln_w, p.ln_b, b.qkv, b.qkvp)));
+#endif
     const int nb = at_blocks(L);
     const long ntask = (long)N * 4 * nb;
     const int W = at_window(L);
@@ -2560,8 +2587,12 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     LAUNCH(ctx, "attn_train_reduce", (at_de_scatter_kernel<<<(rel_elems + 255) / 256, 256, 0, s>>>(ws + pl.dewin, L, nb, max_pos,
                                                                                                   grad.rel)));
     // projections + LayerNorm
+#if TRAIN_X3
+    at_x3_qkv_bwd(ctx, x, ws + pl.dqkv, M, ws + pl.wqkvt, p.ln_w, p.ln_b, dres, dx, ws + pl.xn, ws + pl.g1, ws + pl.dxn);
+#else
     LAUNCH(ctx, "attn_train_bwd", (at_qkv_bwd_kernel<<<grid, 256, 0, s>>>(x, ws + pl.dqkv, M, ws + pl.wqkvt, p.ln_w, p.ln_b,
                                                                           dres, dx, ws + pl.xn, ws + pl.g1, ws + pl.dxn)));
+#endif
     wgrad_partial64(ctx, "attn_train_wgrad", ws + pl.dqkv, ws + pl.xn, M, 192, 64, ws + pl.wpart, wg_split(3));
     LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<192, 1024, 0, s>>>(ws + pl.wpart, wg_split(3), 12288,
                                                                                 ws + pl.raw)));      // [192,64], then split

@@ -903,3 +903,279 @@ void cm_x3_bwd2(LaunchCtx ctx, const float* x, const float* du, long M, const fl
                                          x, du, M, reinterpret_cast<const _Float16*>(img_w1),
                                          reinterpret_cast<const _Float16*>(img_w1t), p, dres, dx, dag, xn_out, g1c, dxc, ntiles)));
 }
+
+// BatchNorm apply -> Swish -> pointwise 128 -> 64 + bias (+ residual).  LDS: pw2 image [4][4] = 32 KB.
+__global__ __launch_bounds__(512) void cm_bn_swish_pw2_x3_kernel(const float* __restrict__ d, long M,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const _Float16* __restrict__ w2i, const float* __restrict__ b2,
+                                                                 const float* __restrict__ res, float* __restrict__ y, int ntiles) {
+    __shared__ __attribute__((aligned(16))) _Float16 w2[16384];
+    __shared__ __attribute__((aligned(16))) float par_l[320];              // scale[128] | shift[128] | b2[64]
+    stage_lds16<2048, 512>(w2i, w2);
+    for (int i = threadIdx.x; i < 320; i += blockDim.x) par_l[i] = i < 128 ? scale[i] : (i < 256 ? shift[i - 128] : b2[i - 256]);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int tile = blockIdx.x * 8 + wv; tile < ntiles; tile += gridDim.x * 8) {
+        long row[2];
+        bool ok[2];
+        f16x8 sh[2][4], sl[2][4];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const long t = ((long)tile * 2 + tb) * 16 + c;
+            ok[tb] = t < M;
+            row[tb] = ok[tb] ? t : M - 1;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 s[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int kb = 2 * m + j;
+                    const f32x4 dn = ldg4(d + row[tb] * 128 + 16 * kb + 4 * g) * *reinterpret_cast<const f32x4*>(&par_l[16 * kb + 4 * g]) +
+                                     *reinterpret_cast<const f32x4*>(&par_l[128 + 16 * kb + 4 * g]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s[j][e] = swishf(dn[e]);
+                }
+                split8(s[0], s[1], sh[tb][m], sl[tb][m]);
+            }
+        }
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(&par_l[256 + 16 * ob + 4 * g]);
+            f32x4 acc[2] = {bv, bv};
+            lin_acc_x3<4, 2>(w2 + ob * 4 * 1024 + lane * 8, sh, sl, acc);
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                if (res) acc[tb] = acc[tb] + ldg4(res + row[tb] * 64 + 16 * ob + 4 * g);
+                if (ok[tb]) stg4(y + row[tb] * 64 + 16 * ob + 4 * g, acc[tb]);
+            }
+        }
+    }
+}
+
+// backward, part 1: ds = pw2^T dy (dy scaled by the block's exact power of two), through Swish; ddn, s and the per-block
+// partial sums of g2 = ddn dhat, ddn and dy (see cm_bwd1_kernel).  LDS: pw2^T image [8][2] = 32 KB.
+__global__ __launch_bounds__(512) void cm_bwd1_x3_kernel(const float* __restrict__ dy, const float* __restrict__ d, long M,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const _Float16* __restrict__ w2ti, float* __restrict__ ddn,
+                                                         float* __restrict__ s_out, float* __restrict__ g2c,
+                                                         float* __restrict__ ddnc, float* __restrict__ dyc, int ntiles) {
+    __shared__ __attribute__((aligned(16))) _Float16 w2t[16384];
+    __shared__ __attribute__((aligned(16))) float par_l[512];              // mean | rstd | scale | shift
+    stage_lds16<2048, 512>(w2ti, w2t);
+    for (int i = threadIdx.x; i < 512; i += blockDim.x)
+        par_l[i] = i < 128 ? mean[i] : (i < 256 ? rstd[i - 128] : (i < 384 ? scale[i - 256] : shift[i - 384]));
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int tile = blockIdx.x * 8 + wv; tile < ntiles; tile += gridDim.x * 8) {        // one 16-token block per trip
+        const long t = (long)tile * 16 + c;
+        const bool ok = t < M;
+        const long row = ok ? t : M - 1;
+        f32x4 dyv[4];
+        float zmax = 0.f;
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x4 v = ldg4(dy + row * 64 + 16 * ob + 4 * g);
+            if (!ok) v = splat4(0.f);
+            dyv[ob] = v;
+            zmax = tx_absmax4(v, zmax);
+            f32x4 sum;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum[r] = red_c_sum(v[r]);
+            if (c == 0) stg4(dyc + (long)tile * 64 + 16 * ob + 4 * g, sum);
+        }
+        float zs, zinv;
+        tx_pow2(tx_wave_max(zmax), zs, zinv);
+        f16x8 zh[1][2], zl[1][2];
+        split8(dyv[0] * splat4(zs), dyv[1] * splat4(zs), zh[0][0], zl[0][0]);
+        split8(dyv[2] * splat4(zs), dyv[3] * splat4(zs), zh[0][1], zl[0][1]);
+#pragma unroll 2
+        for (int hb = 0; hb < 8; ++hb) {
+            f32x4 ds[1] = {splat4(0.f)};
+            lin_acc_x3<2, 1>(w2t + hb * 2048 + lane * 8, zh, zl, ds);
+            const f32x4 dv = ldg4(d + row * 128 + 16 * hb + 4 * g);
+            const f32x4 dhat = (dv - *reinterpret_cast<const f32x4*>(&par_l[16 * hb + 4 * g])) *
+                               *reinterpret_cast<const f32x4*>(&par_l[128 + 16 * hb + 4 * g]);
+            const f32x4 dn = dv * *reinterpret_cast<const f32x4*>(&par_l[256 + 16 * hb + 4 * g]) +
+                             *reinterpret_cast<const f32x4*>(&par_l[384 + 16 * hb + 4 * g]);
+            f32x4 o_ddn, o_s;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sg = sigmoidf_fast(dn[e]);
+                o_s[e] = dn[e] * sg;
+                o_ddn[e] = (ds[0][e] * zinv) * (sg * (1.f + dn[e] * (1.f - sg)));
+            }
+            if (ok) {
+                stg4(ddn + row * 128 + 16 * hb + 4 * g, o_ddn);
+                stg4(s_out + row * 128 + 16 * hb + 4 * g, o_s);
+            }
+            f32x4 ca = ok ? o_ddn * dhat : splat4(0.f), cb = ok ? o_ddn : splat4(0.f);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ca[r] = red_c_sum(ca[r]);
+                cb[r] = red_c_sum(cb[r]);
+            }
+            if (c == 0) {
+                stg4(g2c + (long)tile * 128 + 16 * hb + 4 * g, ca);
+                stg4(ddnc + (long)tile * 128 + 16 * hb + 4 * g, cb);
+            }
+        }
+    }
+}
+
+// LN -> [to_q ; to_kv] (image [12][2] = 48 KB) -> q | k | v.  as_image: the attention cores' (hi, lo) operand image with
+// the q part (output blocks 0 .. 3) pre-scaled by qscale (train.hip, AT_X3); else the fp32 projection.
+__global__ __launch_bounds__(512) void at_qkv_x3_kernel(const float* __restrict__ x, long M, const _Float16* __restrict__ wi,
+                                                        const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                        float* __restrict__ qkv, int as_image, float qscale, int ntiles) {
+    __shared__ __attribute__((aligned(16))) _Float16 w[24576];
+    __shared__ __attribute__((aligned(16))) float par_l[128];
+    stage_lds16<3072, 512>(wi, w);
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) par_l[i] = i < 64 ? ln_w[i] : ln_b[i - 64];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int tile = blockIdx.x * 8 + wv; tile < ntiles; tile += gridDim.x * 8) {
+        long row[2];
+        bool ok[2];
+        f16x8 xbh[2][2], xbl[2][2];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const long t = ((long)tile * 2 + tb) * 16 + c;
+            ok[tb] = t < M;
+            row[tb] = ok[tb] ? t : M - 1;
+            f32x4 xh[4], xn[4];
+            float rstd;
+            tx_load_norm(x, row[tb], g, par_l, xh, rstd, xn);
+            split8(xn[0], xn[1], xbh[tb][0], xbl[tb][0]);
+            split8(xn[2], xn[3], xbh[tb][1], xbl[tb][1]);
+        }
+#pragma unroll 2
+        for (int ob = 0; ob < 12; ++ob) {
+            f32x4 acc[2] = {splat4(0.f), splat4(0.f)};
+            lin_acc_x3<2, 2>(w + ob * 2048 + lane * 8, xbh, xbl, acc);
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                f32x4 v = acc[tb];
+                if (as_image) {
+                    if (ob < 4) v = v * splat4(qscale);
+                    f16x4 h, l;
+                    split4(v, h, l);
+                    v = __builtin_bit_cast(f32x4, __builtin_shufflevector(h, l, 0, 4, 1, 5, 2, 6, 3, 7));
+                }
+                if (ok[tb]) stg4(qkv + row[tb] * 192 + 16 * ob + 4 * g, v);
+            }
+        }
+    }
+}
+
+// dxn = [to_q ; to_kv]^T dqkv (image [4][6] = 48 KB; dqkv scaled by the block's exact power of two), LayerNorm backward,
+// xn for the weight gradient, per-block partial sums of dgamma / dbeta
+__global__ __launch_bounds__(512) void at_qkv_bwd_x3_kernel(const float* __restrict__ x, const float* __restrict__ dqkv, long M,
+                                                            const _Float16* __restrict__ wti, const float* __restrict__ ln_w,
+                                                            const float* __restrict__ ln_b, const float* __restrict__ dres,
+                                                            float* __restrict__ dx, float* __restrict__ xn_out,
+                                                            float* __restrict__ g1c, float* __restrict__ dxc, int ntiles) {
+    __shared__ __attribute__((aligned(16))) _Float16 wt[24576];
+    __shared__ __attribute__((aligned(16))) float par_l[128];
+    stage_lds16<3072, 512>(wti, wt);
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) par_l[i] = i < 64 ? ln_w[i] : ln_b[i - 64];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int tile = blockIdx.x * 8 + wv; tile < ntiles; tile += gridDim.x * 8) {        // one 16-token block per trip
+        const long t = (long)tile * 16 + c;
+        const bool ok = t < M;
+        const long row = ok ? t : M - 1;
+        f32x4 z[12];
+        float zmax = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 12; ++kb) {
+            z[kb] = ldg4(dqkv + row * 192 + 16 * kb + 4 * g);
+            if (!ok) z[kb] = splat4(0.f);
+            zmax = tx_absmax4(z[kb], zmax);
+        }
+        float zs, zinv;
+        tx_pow2(tx_wave_max(zmax), zs, zinv);
+        f16x8 zh[1][6], zl[1][6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) split8(z[2 * m] * splat4(zs), z[2 * m + 1] * splat4(zs), zh[0][m], zl[0][m]);
+        f32x4 xh[4], xn[4];
+        float rstd;
+        tx_load_norm(x, row, g, par_l, xh, rstd, xn);
+        f32x4 dxn[4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            f32x4 acc[1] = {splat4(0.f)};
+            lin_acc_x3<6, 1>(wt + ob * 6 * 1024 + lane * 8, zh, zl, acc);
+            dxn[ob] = acc[0] * splat4(zinv);
+        }
+        f32x4 dxh[4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            dxh[kb] = dxn[kb] * *reinterpret_cast<const f32x4*>(&par_l[16 * kb + 4 * g]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s1 += dxh[kb][r];
+                s2 = fmaf(dxh[kb][r], xh[kb][r], s2);
+            }
+        }
+        const float mu1 = red_g_sum(s1) * (1.0f / 64.0f), mu2 = red_g_sum(s2) * (1.0f / 64.0f);
+        f32x4 ca[4], cb[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (ok) {
+                f32x4 dv = (dxh[kb] - splat4(mu1) - xh[kb] * splat4(mu2)) * splat4(rstd);
+                if (dres) dv = dv + ldg4(dres + row * 64 + 16 * kb + 4 * g);
+                stg4(dx + row * 64 + 16 * kb + 4 * g, dv);
+                stg4(xn_out + row * 64 + 16 * kb + 4 * g, xn[kb]);
+            }
+            ca[kb] = ok ? dxn[kb] * xh[kb] : splat4(0.f);
+            cb[kb] = ok ? dxn[kb] : splat4(0.f);
+        }
+        ln_tile_colsums(ca, cb, c, g, tile, g1c, dxc);
+    }
+}
+
+static int x3_grid8(int ntiles) { const int w = (ntiles + 7) / 8; return w < 512 ? (w > 0 ? w : 1) : 512; }
+// pw2 (R 64, K 128) and pw2^T images: 32 KB each, in the slots of the fp32 fragment images (w2, w2t)
+void cm_x3_pack_pw2(LaunchCtx ctx, const ConvModTrainParams& p, float* img_w2, float* img_w2t) {
+    launch_pack_x3(ctx, "convmod_train_pack", PackX3Jobs{{{p.pw2_w, 64, 128, 128, 0, reinterpret_cast<_Float16*>(img_w2)},
+                                                          {p.pw2_w, 128, 64, 128, 1, reinterpret_cast<_Float16*>(img_w2t)},
+                                                          {}, {}}}, 2);
+}
+void cm_x3_bn_swish_pw2(LaunchCtx ctx, const float* d, long M, const float* scale, const float* shift, const float* img_w2,
+                        const float* b2, const float* res, float* y) {
+    const int ntiles = (int)((M + 31) / 32);
+    LAUNCH(ctx, "convmod_train_fwd", (cm_bn_swish_pw2_x3_kernel<<<x3_grid8(ntiles), 512, 0, ctx.stream>>>(
+                                         d, M, scale, shift, reinterpret_cast<const _Float16*>(img_w2), b2, res, y, ntiles)));
+}
+void cm_x3_bwd1(LaunchCtx ctx, const float* dy, const float* d, long M, const float* mean, const float* rstd, const float* scale,
+                const float* shift, const float* img_w2t, float* ddn, float* s_out, float* g2c, float* ddnc, float* dyc) {
+    const int ntiles = (int)((M + 15) / 16);
+    LAUNCH(ctx, "convmod_train_bwd", (cm_bwd1_x3_kernel<<<x3_grid8(ntiles), 512, 0, ctx.stream>>>(
+                                         dy, d, M, mean, rstd, scale, shift, reinterpret_cast<const _Float16*>(img_w2t), ddn, s_out,
+                                         g2c, ddnc, dyc, ntiles)));
+}
+// [to_q ; to_kv] (R 192, K 64) and its transpose: 48 KB each, in the slots of the fp32 fragment images
+void at_x3_pack(LaunchCtx ctx, const float* wraw, float* img_w, float* img_wt) {
+    launch_pack_x3(ctx, "attn_train_pack", PackX3Jobs{{{wraw, 192, 64, 64, 0, reinterpret_cast<_Float16*>(img_w)},
+                                                       {wraw, 64, 192, 64, 1, reinterpret_cast<_Float16*>(img_wt)},
+                                                       {}, {}}}, 2);
+}
+void at_x3_qkv(LaunchCtx ctx, const float* x, long M, const float* img_w, const float* ln_w, const float* ln_b, float* qkv,
+               int as_image, float qscale) {
+    const int ntiles = (int)((M + 31) / 32);
+    LAUNCH(ctx, "attn_train_fwd", (at_qkv_x3_kernel<<<x3_grid8(ntiles), 512, 0, ctx.stream>>>(
+                                      x, M, reinterpret_cast<const _Float16*>(img_w), ln_w, ln_b, qkv, as_image, qscale, ntiles)));
+}
+void at_x3_qkv_bwd(LaunchCtx ctx, const float* x, const float* dqkv, long M, const float* img_wt, const float* ln_w,
+                   const float* ln_b, const float* dres, float* dx, float* xn_out, float* g1c, float* dxc) {
+    const int ntiles = (int)((M + 15) / 16);
+    LAUNCH(ctx, "attn_train_bwd", (at_qkv_bwd_x3_kernel<<<x3_grid8(ntiles), 512, 0, ctx.stream>>>(
+                                      x, dqkv, M, reinterpret_cast<const _Float16*>(img_wt), ln_w, ln_b, dres, dx, xn_out, g1c, dxc,
+                                      ntiles)));
+}
