@@ -106,6 +106,7 @@ SIGNATURES = {
                                           c_float, c_void_p, c_void_p, POINTER(AttnParams), c_void_p, c_size_t, c_void_p]),
     "cmgan_swap_axes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "cmgan_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),
+    "cmgan_dropout_masks": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p, c_void_p]),
     "cmgan_layernorm_train_workspace_bytes": (c_size_t, [c_void_p, c_longlong]),
     "cmgan_layernorm_train_forward": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p,
                                               c_void_p]),

@@ -152,6 +152,15 @@ extern "C" int cmgan_swap_axes(cmgan_handle* h, const float* in, const float* ad
     return check_launch(h, "swap_axes");
 }
 
+extern "C" int cmgan_dropout_masks(cmgan_handle* h, unsigned char* masks, long long nbytes, float keep_prob,
+                                   unsigned long long* state, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!masks || !state || nbytes <= 0 || (nbytes & 15) || !(keep_prob >= 0.f && keep_prob <= 1.f))
+        return fail(h, CMGAN_E_BADARG, "cmgan_dropout_masks: bad argument (nbytes must be a positive multiple of 16)");
+    launch_dropout_masks(begin(h, stream), masks, (long)nbytes, keep_prob, state);
+    return check_launch(h, "dropout_masks");
+}
+
 extern "C" int cmgan_add(cmgan_handle* h, const float* a, const float* b, float* out, long long n, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!a || !b || !out || n <= 0 || (n & 3)) return fail(h, CMGAN_E_BADARG, "cmgan_add: bad argument (n must be a multiple of 4)");

@@ -57,6 +57,8 @@ void launch_attn_train_backward(LaunchCtx, const float* x, const float* dy, int 
                                 int max_pos, const unsigned char* mask, float mask_scale, const float* dres, float* dx,
                                 const AttnTrainParams& grad, float* ws);
 void launch_swap_axes(LaunchCtx, const float* in, const float* add, float* out, int B, int A, int C);
+// nbytes % 16 == 0; state = {seed, offset} (device); advances the offset by nbytes / 16
+void launch_dropout_masks(LaunchCtx, unsigned char* out, long nbytes, float keep, unsigned long long* state);
 void launch_add(LaunchCtx, const float* a, const float* b, float* out, long n);
 size_t ln_train_ws_floats(long M);
 void launch_ln_train_forward(LaunchCtx, const float* x, long M, const float* gamma, const float* beta, const float* res,

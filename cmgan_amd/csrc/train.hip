@@ -2724,6 +2724,56 @@ __global__ __launch_bounds__(256) void swap_axes_kernel(const float* __restrict_
         stg4(out + 4 * i, v);
     }
 }
+// ---------------------------------------------------------------------------------
+// Keep-masks of the step's Dropout layers as bytes (1 = keep, probability `keep`), drawn by Philox4x32-10 - the
+// counter-based generator torch's own dropout uses - from (seed, offset) in DEVICE memory: counter = offset + the
+// index of a 16-byte group, each group = two Philox blocks = sixteen 16-bit uniforms compared with
+// round(keep * 65536).  The offset is advanced by a one-thread kernel after the draw, so a captured graph replays with
+// fresh masks and nothing in the launches changes from step to step.  (torch's bernoulli_ on the 5.8 GB of masks of a
+// 32-clip step took 4.7 ms; this writes them at the HBM rate.)   state = {seed, offset} as two 64-bit words.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const unsigned n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+__global__ __launch_bounds__(256) void dropout_mask_kernel(unsigned char* __restrict__ out, long ngroups, unsigned thresh,
+                                                           const unsigned long long* __restrict__ state) {
+    const unsigned long long seed = state[0], offset = state[1];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ngroups; i += (long)gridDim.x * 256) {
+        const unsigned long long ctr = offset + (unsigned long long)i;
+        unsigned w[4];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            unsigned c[4] = {(unsigned)ctr, (unsigned)(ctr >> 32), (unsigned)half, 0u};
+            philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {                          // two 32-bit words -> four mask bytes
+                const unsigned a = c[2 * j], b = c[2 * j + 1];
+                w[2 * half + j] = ((a & 0xffffu) < thresh ? 1u : 0u) | ((a >> 16) < thresh ? 0x100u : 0u) |
+                                  ((b & 0xffffu) < thresh ? 0x10000u : 0u) | ((b >> 16) < thresh ? 0x1000000u : 0u);
+            }
+        }
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        reinterpret_cast<u32x4_*>(out)[i] = u32x4_{w[0], w[1], w[2], w[3]};
+    }
+}
+__global__ void dropout_tick_kernel(unsigned long long* __restrict__ state, unsigned long long ngroups) { state[1] += ngroups; }
+void launch_dropout_masks(LaunchCtx ctx, unsigned char* out, long nbytes, float keep, unsigned long long* state) {
+    const long ngroups = nbytes / 16;
+    double th = (double)keep * 65536.0 + 0.5;
+    const unsigned thresh = th < 0.0 ? 0u : (th > 65536.0 ? 65536u : (unsigned)th);
+    const unsigned grid = (unsigned)((ngroups + 255) / 256 < 8192 ? (ngroups + 255) / 256 : 8192);
+    LAUNCH(ctx, "dropout_masks", (dropout_mask_kernel<<<grid, 256, 0, ctx.stream>>>(out, ngroups, thresh, state)));
+    LAUNCH(ctx, "dropout_masks", (dropout_tick_kernel<<<1, 1, 0, ctx.stream>>>(state, (unsigned long long)ngroups)));
+}
+
 void launch_swap_axes(LaunchCtx ctx, const float* in, const float* add, float* out, int B, int A, int C) {
     const long total4 = (long)B * A * C * 16, want = (total4 + 255) / 256;
     LAUNCH(ctx, "swap_axes", (swap_axes_kernel<<<(unsigned)(want < 8192 ? (want > 0 ? want : 1) : 8192), 256, 0, ctx.stream>>>(

@@ -234,6 +234,14 @@ int cmgan_attn_train_backward(cmgan_handle* h, const float* x_dev, const float* 
 int cmgan_swap_axes(cmgan_handle* h, const float* in_dev, const float* add_dev, float* out_dev, int B, int A, int C,
                     void* stream);
 int cmgan_add(cmgan_handle* h, const float* a_dev, const float* b_dev, float* out_dev, long long n, void* stream);
+/* Keep-masks of nn.Dropout(p) layers (src/models/conformer.py:64,70,98,172) as bytes, 1 = keep with probability
+ * keep_prob = 1 - p (compared at 16-bit resolution), for the mask_dev arguments of the training functions above: the
+ * reference draws them inside F.dropout with torch's Philox stream, here one launch fills ALL masks of a step.
+ * state_dev: two 64-bit words in device memory {seed, offset}; Philox4x32-10 counters offset .. offset + nbytes / 16 are
+ * consumed and the offset is advanced on the device, so the call is replayable inside a captured graph.  nbytes must be
+ * a positive multiple of 16.                                                                                        */
+int cmgan_dropout_masks(cmgan_handle* h, unsigned char* masks_dev, long long nbytes, float keep_prob,
+                        unsigned long long* state_dev, void* stream);
 size_t cmgan_layernorm_train_workspace_bytes(const cmgan_handle* h, long long M);
 int cmgan_layernorm_train_forward(cmgan_handle* h, const float* x_dev, long long M, const float* weight_dev,
                                   const float* bias_dev, const float* residual_dev, float* y_dev, void* stream);

@@ -982,3 +982,68 @@ def test_trainer_runs_an_epoch_like_the_reference_trainer(tmp_path):
     got = enhance_one_track(model, wav.to(DEV))
     want = O.enhance(ck, wav)
     assert _report("trained checkpoint: inference vs oracle", rel_err(got, want)) < 1e-4
+
+
+def _philox4x32_10_np(ctr_lo, ctr_hi, half, seed):
+    """numpy Philox4x32-10 (Salmon et al. 2011; the generator of torch's CUDA dropout) for counters (ctr, half, 0)."""
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    c = [ctr_lo.astype(np.uint64), ctr_hi.astype(np.uint64), np.full_like(ctr_lo, half, dtype=np.uint64),
+         np.zeros_like(ctr_lo, dtype=np.uint64)]
+    k0, k1 = seed & 0xffffffff, (seed >> 32) & 0xffffffff
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & np.uint64(0xffffffff), p1 >> np.uint64(32), p1 & np.uint64(0xffffffff)
+        c = [hi1 ^ c[1] ^ np.uint64(k0), lo1, hi0 ^ c[3] ^ np.uint64(k1), lo0]
+        k0, k1 = (k0 + W0) & 0xffffffff, (k1 + W1) & 0xffffffff
+    return c
+
+
+def test_dropout_keep_masks_are_philox_draws_with_a_device_side_offset():
+    """cmgan_dropout_masks: bytes = (16-bit uniform < round(keep * 65536)) of Philox4x32-10 at counters offset + group, the
+    offset living in device memory - checked bit for bit against a numpy Philox, for the advance of the offset between
+    two calls (what makes the draw replayable inside a captured graph), and for the keep rate."""
+    from cmgan_amd.engine import Engine
+    from cmgan_amd._lib import check
+    eng = Engine(device=DEV)
+    seed, keep, n = 0x1234567890ABCDEF & ((1 << 63) - 1), 0.8, 16 * 4096
+    state = torch.tensor([seed, 7], dtype=torch.int64, device=DEV)
+    bufs = []
+    for _ in range(2):
+        buf = torch.empty(n, dtype=torch.uint8, device=DEV)
+        check(eng._h, eng.lib.cmgan_dropout_masks(eng._h, buf.data_ptr(), n, keep, state.data_ptr(), eng._stream()))
+        bufs.append(buf.cpu().numpy())
+    assert state.cpu().tolist() == [seed, 7 + 2 * n // 16]
+    thresh = int(keep * 65536 + 0.5)
+    for call, got in enumerate(bufs):
+        ctr = np.arange(n // 16, dtype=np.uint64) + np.uint64(7 + call * (n // 16))
+        want = np.zeros((n // 16, 16), dtype=np.uint8)
+        for half in range(2):
+            c = _philox4x32_10_np(ctr & np.uint64(0xffffffff), ctr >> np.uint64(32), half, seed)
+            for j in range(2):
+                for w, word in enumerate((c[2 * j], c[2 * j + 1])):
+                    base = 8 * half + 4 * j + 2 * w
+                    want[:, base] = (word & np.uint64(0xffff)) < thresh
+                    want[:, base + 1] = (word >> np.uint64(16)) < thresh
+        assert np.array_equal(got.reshape(-1, 16), want), call
+    rate = float(np.concatenate(bufs).mean())
+    assert abs(rate - keep) < 4 * np.sqrt(keep * (1 - keep) / (2 * n))
+    assert not np.array_equal(bufs[0], bufs[1])
+    with pytest.raises(RuntimeError):
+        check(eng._h, eng.lib.cmgan_dropout_masks(eng._h, buf.data_ptr(), 24, keep, state.data_ptr(), eng._stream()))
+
+
+def test_generator_masks_come_from_the_library_generator_and_restart_with_the_model():
+    """GeneratorTrain.masks: one draw for all forty masks; a fresh model with the same generator seed repeats the stream,
+    the same model continues it."""
+    from cmgan_amd.training import GeneratorTrain
+    from oracle.weights import make_state_dict
+    sd = make_state_dict(seed=0)
+    g1 = GeneratorTrain(sd, device=DEV)
+    a = g1.masks(1, 5, torch.Generator(device=DEV).manual_seed(5))
+    b = g1.masks(1, 5, torch.Generator(device=DEV).manual_seed(5))
+    g2 = GeneratorTrain(sd, engine=g1.engine)
+    c = g2.masks(1, 5, torch.Generator(device=DEV).manual_seed(5))
+    first = lambda m: m[0][0]["ff1_1"]
+    assert torch.equal(first(a), first(c)) and not torch.equal(first(a), first(b))
+    assert first(a).dtype == torch.uint8 and set(first(a).unique().tolist()) <= {0, 1}
+    assert 0.7 < float(first(a).float().mean()) < 0.9
