@@ -128,10 +128,10 @@ __global__ void pack_fm4_kernel(PackJobs jobs) {
     const int row = 16 * rb + (lane & 15), col = 16 * kb + 4 * (lane >> 4) + r;
     q.out[i] = q.transpose ? q.w[(long)col * q.ldw + row] : q.w[(long)row * q.ldw + col];
 }
-static void launch_pack4(LaunchCtx ctx, const char* label, const PackJobs& jobs) {
+static void launch_pack4(LaunchCtx ctx, const char* label, const PackJobs& jobs, int njobs = 4) {
     int most = 0;
-    for (int k = 0; k < 4; ++k) most = jobs.j[k].R * jobs.j[k].K > most ? jobs.j[k].R * jobs.j[k].K : most;
-    LAUNCH(ctx, label, (pack_fm4_kernel<<<dim3((most + 255) / 256, 4), 256, 0, ctx.stream>>>(jobs)));
+    for (int k = 0; k < njobs; ++k) most = jobs.j[k].R * jobs.j[k].K > most ? jobs.j[k].R * jobs.j[k].K : most;
+    LAUNCH(ctx, label, (pack_fm4_kernel<<<dim3((most + 255) / 256, njobs), 256, 0, ctx.stream>>>(jobs)));
 }
 
 // Dropout keep-masks are BYTES (non-zero = keep; the kept values are scaled by `ms` = 1 / (1 - p)): a quarter of the
@@ -2495,7 +2495,7 @@ static void at_pack_images(LaunchCtx ctx, const AttnTrainParams& p, float* ws, c
 #if TRAIN_X3
     at_x3_pack(ctx, ws + pl.raw, ws + pl.wqkv, ws + pl.wqkvt);      // the projections run on split products
     launch_pack4(ctx, "attn_train_pack", PackJobs{{{p.wo, 64, 64, 64, 0, ws + pl.wo}, {p.wo, 64, 64, 64, 1, ws + pl.wot},
-                                                   {p.wo, 64, 64, 64, 0, ws + pl.wo}, {p.wo, 64, 64, 64, 1, ws + pl.wot}}});
+                                                   {}, {}}}, 2);
 #else
     launch_pack4(ctx, "attn_train_pack", PackJobs{{{ws + pl.raw, 192, 64, 64, 0, ws + pl.wqkv},
                                                    {ws + pl.raw, 64, 192, 64, 1, ws + pl.wqkvt},
