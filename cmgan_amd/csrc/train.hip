@@ -2936,6 +2936,30 @@ __global__ __launch_bounds__(256) void db_stats_finalize_kernel(const float* __r
     }
 }
 
+// the same from the convolution kernel's own per-(clip, tile) partial sums [b][ntiles][64][2] (conv3x_kernel's epilogue,
+// the inference path's InstanceNorm statistics): no separate pass over z
+__global__ __launch_bounds__(256) void db_stats_finalize_tiles_kernel(const float* __restrict__ partial, int ntiles,
+                                                                      double count, float* __restrict__ mean,
+                                                                      float* __restrict__ rstd) {
+    __shared__ double red[256];
+    const int i = blockIdx.x, b = i >> 6, c = i & 63, k = threadIdx.x;
+    double a1 = 0.0, a2 = 0.0;
+    for (int t = k; t < ntiles; t += 256) {
+        const long o = (((long)b * ntiles + t) * 64 + c) * 2;
+        a1 += (double)partial[o];
+        a2 += (double)partial[o + 1];
+    }
+    const double s1 = db_tree_sum(a1, red);
+    const double s2 = db_tree_sum(a2, red);
+    if (k == 0) {
+        const double mu = s1 / count;
+        double var = s2 / count - mu * mu;
+        var = var > 0.0 ? var : 0.0;
+        mean[i] = (float)mu;
+        rstd[i] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
 // a = PReLU(InstanceNorm(z))
 __global__ __launch_bounds__(256) void db_norm_prelu_kernel(const float* __restrict__ z, long total, int P,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -3150,7 +3174,10 @@ static DbPlan db_plan(int B, int T, int F) {
     p.z = take(4 * M * 64);
     p.ga = take(5 * M * 64);           // gradients w.r.t. a_0 .. a_4
     p.mean = take((size_t)4 * B * 64); p.rstd = take((size_t)4 * B * 64);
-    p.part = take((size_t)B * DB_NCH * 64 * 3);
+    {
+        const size_t chunks = (size_t)B * DB_NCH * 64 * 3, tiles = (size_t)B * conv3x_ntiles(T, F, 64) * 128;
+        p.part = take(chunks > tiles ? chunks : tiles);     // chunk partials, or the convolution kernel's tile partials
+    }
     p.m1 = take((size_t)B * 64); p.m2 = take((size_t)B * 64);
     p.wpart = take((size_t)6 * DB_WG_SPLIT * 4096);
     p.cpart = take((size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256);
@@ -3302,6 +3329,7 @@ void launch_dense_train_forward(LaunchCtx ctx, const float* x, int B, int T, int
         float* z = ws + pl.z + (size_t)i * M * 64;
         float* a = i == 3 ? y : ws + pl.a + (size_t)i * M * 64;
         const int dil = 1 << i;
+        bool tile_stats = false;
 #if TRAIN_X3
         if (db_x3_forward(F)) {
             ConvArgs ca{};                                  // slots arrive normalised + activated (or raw: slot 0): identity on load
@@ -3309,8 +3337,10 @@ void launch_dense_train_forward(LaunchCtx ctx, const float* x, int B, int T, int
             ca.nslots = i + 1;
             ca.bias = p.conv_b[i];
             ca.out = z;
+            ca.partials = ws + pl.part;                     // per-(clip, tile) (sum, sum of squares): the InstanceNorm statistics
             ca.T = T; ca.F = F; ca.dil = dil; ca.mode = 0; ca.ntiles = conv3x_ntiles(T, F, 64);
             launch_conv3_x3(ctx, ca, reinterpret_cast<const _Float16*>(ws + pl.img) + db_x3_img_off(i), B, 2, 64);
+            tile_stats = true;
         } else
 #endif
         {
@@ -3324,11 +3354,16 @@ void launch_dense_train_forward(LaunchCtx ctx, const float* x, int B, int T, int
         }
         float* mean = ws + pl.mean + (size_t)i * B * 64;
         float* rstd = ws + pl.rstd + (size_t)i * B * 64;
-        LAUNCH(ctx, "dense_train_fwd", (db_sums_kernel<0><<<dim3(B, DB_NCH), 256, 0, st>>>(z, nullptr, P, nullptr, nullptr,
-                                                                                         nullptr, nullptr, nullptr,
-                                                                                         ws + pl.part)));
-        LAUNCH(ctx, "dense_train_fwd", (db_stats_finalize_kernel<<<B * 64, 256, 0, st>>>(ws + pl.part, B,
-                                                                                                       (double)P, mean, rstd)));
+        if (tile_stats) {
+            LAUNCH(ctx, "dense_train_fwd", (db_stats_finalize_tiles_kernel<<<B * 64, 256, 0, st>>>(
+                                               ws + pl.part, conv3x_ntiles(T, F, 64), (double)P, mean, rstd)));
+        } else {
+            LAUNCH(ctx, "dense_train_fwd", (db_sums_kernel<0><<<dim3(B, DB_NCH), 256, 0, st>>>(z, nullptr, P, nullptr, nullptr,
+                                                                                             nullptr, nullptr, nullptr,
+                                                                                             ws + pl.part)));
+            LAUNCH(ctx, "dense_train_fwd", (db_stats_finalize_kernel<<<B * 64, 256, 0, st>>>(ws + pl.part, B,
+                                                                                                           (double)P, mean, rstd)));
+        }
         LAUNCH(ctx, "dense_train_fwd", (db_norm_prelu_kernel<<<2048, 256, 0, st>>>(z, M * 64, P, mean, rstd, p.norm_w[i],
                                                                                    p.norm_b[i], p.prelu_w[i], a)));
         if (i < 3) in.p[i + 1] = a;
