@@ -30,6 +30,7 @@
 //          (= the key a lane's score register v = 8 (grp & 1) + e belongs to), so O^T[(hi | lo) d][query] accumulates
 //          V_hi P_hi + V_hi P_lo (rows 0..15) and V_lo P_hi + V_lo P_lo (rows 16..31) in two MFMAs per group.
 #include "kernels.h"
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -49,7 +50,9 @@ __device__ __forceinline__ f32x16 zero16() {
 // device array that tools/probes/attn_stamps.py reads through cmgan_dbg_a32_stamps (phase names there); entries
 // 16 / 17 = waves / chunks; entries 32.. are the same for sequences shorter than 200 positions.
 #ifdef A32_STAMP
-__device__ unsigned long long g_a32_stamp[64];
+#define A32_SLOTS 2048
+__device__ unsigned long long g_a32_stamp[A32_SLOTS][64];   // per-wave-hashed slots: 18 same-address atomics per wave from
+                                                             // 25 k waves serialise in the L2 and slow every fetch of the kernel being measured
 struct A32Stamp {
     unsigned long long t, acc[16];
     int chunks;
@@ -415,7 +418,7 @@ __device__ __forceinline__ void a32_chunk(const A32Ctx& c, int n, int i0n, int n
 // wave w evaluates output block w of x += Wo . concat_h(O_h) + bo for the tile's 32 tokens, exactly as
 // attn_out_x3_kernel does.
 #ifndef A32_TPB
-#define A32_TPB 6
+#define A32_TPB 4
 #endif
 template <bool MASK>
 __global__ __launch_bounds__(256, MASK ? 1 : A32_OCC) void attn32_out_x3_kernel(const _Float16* __restrict__ qimg,
@@ -560,10 +563,11 @@ __global__ __launch_bounds__(256, MASK ? 1 : A32_OCC) void attn32_out_x3_kernel(
 #ifdef A32_STAMP
     if (lane == 0) {
         const int b = L < 200 ? 32 : 0;
+        unsigned long long* slot = g_a32_stamp[(blockIdx.x * 4 + (threadIdx.x >> 6)) & (A32_SLOTS - 1)];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) atomicAdd(&g_a32_stamp[b + i], sp.acc[i]);
-        atomicAdd(&g_a32_stamp[b + 16], 1ull);
-        atomicAdd(&g_a32_stamp[b + 17], (unsigned long long)sp.chunks);
+        for (int i = 0; i < 16; ++i) atomicAdd(&slot[b + i], sp.acc[i]);
+        atomicAdd(&slot[b + 16], 1ull);
+        atomicAdd(&slot[b + 17], (unsigned long long)sp.chunks);
     }
 #endif
 }
@@ -571,14 +575,529 @@ __global__ __launch_bounds__(256, MASK ? 1 : A32_OCC) void attn32_out_x3_kernel(
 #ifdef A32_STAMP
 extern "C" int cmgan_dbg_a32_stamps(unsigned long long* out, int reset) {
     hipDeviceSynchronize();
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_a32_stamp), sizeof(unsigned long long) * 64);
+    static unsigned long long host[A32_SLOTS][64];
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_a32_stamp), sizeof host);
+    for (int i = 0; i < 64; ++i) {
+        out[i] = 0;
+        for (int sl = 0; sl < A32_SLOTS; ++sl) out[i] += host[sl][i];
+    }
     if (e == hipSuccess && reset) {
-        unsigned long long z[64] = {};
-        e = hipMemcpyToSymbol(HIP_SYMBOL(g_a32_stamp), z, sizeof z);
+        memset(host, 0, sizeof host);
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_a32_stamp), host, sizeof host);
     }
     return e == hipSuccess ? 0 : -1;
 }
 #endif
+
+// =====================================================================================
+// Software-pipelined attention core (the default x3 attention, unmasked): same images and the same arithmetic per
+// product as above, but the work of a wave is one continuous stream of UNITS (query tile, 64-key chunk) and the
+// loop body is asp_fused: the BACK half of unit u (exp2, denominator, fp16 split, P V) and the FRONT half of unit
+// u + 1 (E q, window write, skewed read, K q) in one basic block, laid out in six hand-placed slots separated by
+// scheduling barriers, so that in every slot one 8-pass MFMA chain of one unit runs under the VALU work of the other
+// and every operand (E, K, V, Q) is requested one unit before its use into the registers its predecessor has just
+// left.  Units follow each other across query tiles (the front half of a tile's first chunk runs under the back half
+// of the previous tile's last chunk); only the block's first front half and last back half run alone.
+//
+//   * distance window stored QUERY-major, R[q][w] with a pitch of ASP_P = 100 floats: the 4 consecutive distances a
+//     lane holds per accumulator quad are one aligned ds_write_b128 (12 per chunk instead of 48 ds_write_b32;
+//     start banks 4 q mod 32: the eight lanes of a store group tile the 32 banks exactly), and the skewed read
+//     R[q][32 + key - q] walks a pitch of 99 floats (3 q mod 32 is a bijection: conflict-free ds_read2_b32);
+//   * the reference level -m of the online softmax is the INITIAL VALUE of the E q accumulator (a persistent
+//     16-register splat that changes only when a query tile is re-referenced), so scores leave the K q MFMAs
+//     already relative to it: no per-score subtraction;
+//   * the rare re-reference (running maximum outside (-4, +12]) is not a branch inside the hot loop body: the loop's
+//     only branch is its back edge, which also exits when any lane of the wave drifted in the chunk whose maximum
+//     was just taken; the fix-up (asp_reference) runs outside and the loop is re-entered.  The scores of that
+//     chunk have not been exponentiated yet, so nothing has to be undone;
+//   * CLAMP = false (sequence length + 96 <= max_pos, i.e. every model shape): the distance-table rows need no
+//     clamping, so an E fetch is lane-constant offset + SCALAR offset - no address VALU in the loop.
+// Block = the four heads (one per wave) of up to A32_TPB consecutive query tiles of one sequence; per tile the
+// normalised O goes through the stash, one barrier, and wave w applies output block w of to_out + bias + residual
+// exactly as attn_out_x3_kernel does (to_out operands fetched per tile from L2; LDS: 4 x 12.5 KB windows + 16 KB
+// stash = 66 KB per block, two blocks per CU).
+// =====================================================================================
+#ifndef ASP_OCC
+#define ASP_OCC 2
+#endif
+#define ASP_P 100
+#define ASP_RFL (32 * ASP_P)
+#define ASP_SB() __builtin_amdgcn_sched_barrier(0)
+// stamp builds: -DA32_STAMP=1 marks every slot of asp_fused (distorts the body: each mark drains lgkmcnt);
+// -DA32_STAMP=2 marks only the per-tile phases (compute / epilogue before the barrier / barrier / to_out)
+#if defined(A32_STAMP) && (A32_STAMP + 0 == 2)
+#define ASP_FMARK(ph) do { } while (0)
+#define ASP_CMARK(ph) A32_MARK(ph)
+#else
+#define ASP_FMARK(ph) A32_MARK(ph)
+#define ASP_CMARK(ph) do { } while (0)
+#endif
+// ASP_ABL: timing-only ablation builds (never shipped; results are wrong): 1 = no operand fetches inside the loop body,
+// 2 = no E q / distance window, 3 = no exp2 / fp16 split, 4 = no P V, 5 = no K q, 6 = no E fetches, 7 = no K / V fetches
+#ifndef ASP_ABL
+#define ASP_ABL 0
+#endif
+// 10 = 1 + 2 + 4 + 5 together (the loop and everything outside the body remain); 11 = no epilogue (stash / barrier / to_out)
+
+__device__ __forceinline__ f32x16 splat16(float v) {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = v;
+    return z;
+}
+
+struct AspCtx {
+    __amdgpu_buffer_rsrc_t qr, kr, vr, er;
+    unsigned lane16, evoff, eplane2;         // lane * 16; this lane's distance-table byte offset (see asp_load_e)
+    float* Rw;                               // window write base of this lane: R + q * ASP_P + 4 hh
+    const float* Rr;                         // window read base:  R + q * (ASP_P - 1) + 32 + 4 hh
+    int Lt, L, max_pos, a, hh, lpad;
+};
+
+// E rows of window tile t of chunk n of the query tile at i0: row = max_pos - (i0 - 64 n + 32 - 32 t - a), clamped to
+// the table (conformer.py:109) when CLAMP.  Without CLAMP the row is in range for every distance that exists in the
+// sequence (phantom distances past its ends read rows that are either valid or cut off by the buffer bounds check:
+// their scores belong to keys / queries that do not exist), and the fetch is
+//   lane offset (max_pos - 32 + a - lpad) * 16 + plane   +   scalar offset (64 n + 32 t - i0 + lpad) * 16,
+// lpad = 32 Lt >= i0 keeping both parts non-negative.
+template <bool CLAMP>
+__device__ __forceinline__ void asp_load_e(const AspCtx& c, int i0, int n, int t, f16x8& eh, f16x8& el) {
+    if (CLAMP) {
+        int row = c.max_pos - (i0 - 64 * n + 32 - 32 * t) + c.a;
+        row = row < 0 ? 0 : (row > 2 * c.max_pos ? 2 * c.max_pos : row);
+        const unsigned off = (unsigned)row * 16u + c.evoff;
+        eh = buf_h8(c.er, off, 0);
+        el = buf_h8(c.er, off, c.eplane2);
+    } else {
+        i0 = i0 < c.lpad ? i0 : c.lpad;                   // (prefetch past the sequence's last tile: keep the scalar offset >= 0)
+        const unsigned so = (unsigned)(64 * n + 32 * t - i0 + c.lpad) * 16u;
+        eh = buf_h8(c.er, c.evoff, so);
+        el = buf_h8(c.er, c.evoff, so + c.eplane2);
+    }
+}
+__device__ __forceinline__ void asp_load_k(const AspCtx& c, int n, int jt, f16x8& kh, f16x8& kl) {
+    int kt = 2 * n + jt;
+    kt = kt < c.Lt ? kt : c.Lt - 1;
+    kh = buf_h8(c.kr, c.lane16, (unsigned)kt * 2048u);
+    kl = buf_h8(c.kr, c.lane16 + 1024u, (unsigned)kt * 2048u);
+}
+__device__ __forceinline__ f16x8 asp_load_v(const AspCtx& c, int n, int grp4) {
+    int gr = 4 * n + grp4;
+    gr = gr < 2 * c.Lt ? gr : 2 * c.Lt - 1;
+    return buf_h8(c.vr, c.lane16, (unsigned)gr * 1024u);
+}
+__device__ __forceinline__ void asp_load_q(const AspCtx& c, int it, f16x8& qh, f16x8& ql) {
+    it = it < c.Lt ? it : c.Lt - 1;
+    qh = buf_h8(c.qr, c.lane16, (unsigned)it * 2048u);
+    ql = buf_h8(c.qr, c.lane16 + 1024u, (unsigned)it * 2048u);
+}
+
+// ---- pieces of the two halves ----
+__device__ __forceinline__ f32x16 asp_eq(const f16x8& eh, const f16x8& el, const f16x8& qh, const f16x8& ql,
+                                         const f32x16& negm) {
+    f32x16 r = mfma3216(eh, qh, negm);
+    r = mfma3216l(eh, ql, r);
+    return mfma3216l(el, qh, r);
+}
+__device__ __forceinline__ void asp_wwrite(const AspCtx& c, int t, const f32x16& r) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f32x4 w = {r[4 * k], r[4 * k + 1], r[4 * k + 2], r[4 * k + 3]};
+        *reinterpret_cast<f32x4*>(c.Rw + 32 * t + 8 * k) = w;           // distances 32 t + 8 k + 4 hh + 0..3 of query a
+    }
+}
+template <int NKT>
+__device__ __forceinline__ void asp_wread(const AspCtx& c, f32x16 (&sn)[2]) {
+#pragma unroll
+    for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) sn[jt][v] = c.Rr[32 * jt + 8 * (v >> 2) + (v & 3)];
+}
+// p = exp2(s) for the 8 scores of 16-key group g of a chunk (exp2(-inf) = 0 for non-existent keys), split to fp16
+__device__ __forceinline__ void asp_exp8(const f32x16 (&s)[2], int g, float& psum, f16x8& ph, f16x8& pl) {
+    if (ASP_ABL == 3) {
+        f32x4 a = {s[g >> 1][8 * (g & 1)], s[g >> 1][8 * (g & 1) + 1], s[g >> 1][8 * (g & 1) + 2], s[g >> 1][8 * (g & 1) + 3]};
+        f32x4 b = {s[g >> 1][8 * (g & 1) + 4], s[g >> 1][8 * (g & 1) + 5], s[g >> 1][8 * (g & 1) + 6], s[g >> 1][8 * (g & 1) + 7]};
+        ph = __builtin_bit_cast(f16x8, a); pl = __builtin_bit_cast(f16x8, b);
+        psum += a[0];
+        return;
+    }
+    f32x4 pa, pb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pa[r] = __builtin_amdgcn_exp2f(s[g >> 1][8 * (g & 1) + r]);
+        pb[r] = __builtin_amdgcn_exp2f(s[g >> 1][8 * (g & 1) + 4 + r]);
+        psum += pa[r] + pb[r];
+    }
+    asm volatile("" : "+v"(psum));                       // keeps the eight adds in this slot (they would sink to the loop's end)
+    split8(pa, pb, ph, pl);
+}
+__device__ __forceinline__ void asp_pv(f32x16& o, const f16x8& va, const f16x8& ph, const f16x8& pl) {
+    if (ASP_ABL == 4 || ASP_ABL == 10) {
+        o[0] += (float)ph[0] + (float)pl[0] + (float)va[0];
+        return;
+    }
+    o = mfma3216(va, ph, o);
+    o = mfma3216l(va, pl, o);
+}
+
+// Front half alone (the block's first unit): R = E q - m for the NKT + 1 window tiles, window write, skewed read,
+// K q on top; then E, K are refilled with the operands of unit (i0n, nn) and, if lastq, Q with tile itn's.
+template <int NKT, bool CLAMP, bool LASTQ>
+__device__ __forceinline__ void asp_front(const AspCtx& c, int i0n, int nn, int itn, f16x8& qh, f16x8& ql,
+                                          f16x8 (&eh)[3], f16x8 (&el)[3], f16x8 (&kh)[2], f16x8 (&kl)[2],
+                                          const f32x16& negm, f32x16 (&sn)[2]) {
+#pragma unroll
+    for (int t = 0; t <= NKT; ++t) {
+        const f32x16 r = asp_eq(eh[t], el[t], qh, ql, negm);
+        asp_wwrite(c, t, r);
+        ASP_SB();
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) asp_load_e<CLAMP>(c, i0n, nn, t, eh[t], el[t]);
+    wave_lds_fence();
+    asp_wread<NKT>(c, sn);
+    wave_lds_fence();                                    // the next front half's window writes come after these reads
+#pragma unroll
+    for (int jt = 0; jt < NKT; ++jt) sn[jt] = asp_eq(kh[jt], kl[jt], qh, ql, sn[jt]);
+    if (LASTQ) asp_load_q(c, itn, qh, ql);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) asp_load_k(c, nn, jt, kh[jt], kl[jt]);
+    // (single-chunk sequences only) nothing is left pending here: a Q fetch that MAY be in flight at the hot loop's
+    // header makes the compiler's s_waitcnt pass wait for vmcnt(0) at the top of every chunk
+    if (LASTQ) __builtin_amdgcn_s_waitcnt(0x0f70);
+}
+
+// Back half alone (the block's last unit).
+template <int NKT>
+__device__ __forceinline__ void asp_back(f32x16 (&s)[2], A32State& st, f32x16& o, const f16x8 (&va)[4]) {
+    float psum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 2 * NKT; ++g) {
+        f16x8 ph, pl;
+        asp_exp8(s, g, psum, ph, pl);
+        asp_pv(o, va[g], ph, pl);
+    }
+    st.l += psum;
+}
+
+// running maximum of the scores of a chunk (already relative to the reference level): this lane's query
+template <int NKT, bool FULL>
+__device__ __forceinline__ float asp_max(const AspCtx& c, f32x16 (&s)[2], int j0) {
+    float mx[2] = {-INFINITY, -INFINITY};                 // one chain per key tile (the tiles' K q chains end at different times)
+#pragma unroll
+    for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            if (!FULL) {
+                const int key = j0 + 32 * jt + 8 * (v >> 2) + 4 * c.hh + (v & 3);
+                s[jt][v] = key < c.L ? s[jt][v] : -INFINITY;
+            }
+            mx[jt] = fmaxf(mx[jt], s[jt][v]);
+        }
+    return red_h_max(fmaxf(mx[0], mx[1]));
+}
+
+// Reference step for the chunk whose scores are pending in s (outside the hot loop): takes the running maximum and,
+// if any lane of the wave left the band, re-references every lane to its running maximum (scores, denominator,
+// the O accumulator and the -m splat).  See att_softmax in conformer_x3.hip for the scheme.
+template <int NKT, bool FULL>
+__device__ __forceinline__ void asp_reference(const AspCtx& c, f32x16 (&s)[2], int j0, A32State& st, f32x16& o,
+                                              f32x16& negm) {
+    const float run = fmaxf(st.run, asp_max<NKT, FULL>(c, s, j0));
+    const bool drift = run > A32_HI || run < A32_LO;
+    if (__builtin_expect(__any(drift), 0)) {
+        asm volatile("; re-reference");                  // a side effect: keeps this rare path a branch (if-converted it costs
+                                                         // 80 VALU in every chunk)
+        const float alpha = st.l > 0.f ? __builtin_amdgcn_exp2f(-run) : 1.0f;
+#pragma unroll
+        for (int jt = 0; jt < NKT; ++jt)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) s[jt][v] -= run;
+        st.l *= alpha;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[v] *= alpha;
+        st.m += run;
+        negm = splat16(-st.m);
+        st.run = 0.f;
+    } else {
+        st.run = run;
+    }
+}
+
+// The loop body: back half of unit u (scores s, NB key tiles, accumulating into st / o with V operands va) under the
+// front half of unit u + 1 (NF key tiles, reference splat negm_n, scores out in sn).  Afterwards E / K hold the
+// operands of unit (i0n, nn) (= u + 2), V those of chunk vn (= unit u + 1's), and, if LASTQ (unit u + 1 is the last
+// chunk of its tile), Q tile itn's - requested BEFORE K and V, so that the next body's first wait (for E and Q) leaves
+// the K / V fetches in flight.
+// HOTMX: also returns the maximum of sn over this lane's query (both units are full chunks of one tile then).
+template <int NF, int NB, bool HOTMX, bool CLAMP, bool LASTQ>
+__device__ __forceinline__ float asp_fused(const AspCtx& c, int i0n, int nn, int vn, int itn, f16x8& qh,
+                                           f16x8& ql, f16x8 (&eh)[3], f16x8 (&el)[3], f16x8 (&kh)[2], f16x8 (&kl)[2],
+                                           f16x8 (&va)[4], const f32x16& negm_n, f32x16 (&s)[2], f32x16 (&sn)[2],
+                                           A32State& st, f32x16& o A32_STAMP_ARG) {
+    float psum = 0.f;
+    f16x8 ph[2], pl[2];
+    f32x16 racc = zero16();                              // (ASP_ABL == 8 only)
+    // (opaque to the optimiser: otherwise the exp2 of these scores is hoisted into the two arms of the reference step
+    // before this body, out from under the MFMAs)
+    asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+    // slot 0: E q of window tile 0 | exp2 + split of key group 0
+    {
+        f32x16 r;
+        if (ASP_ABL != 2 && ASP_ABL != 10) r = asp_eq(eh[0], el[0], qh, ql, negm_n);
+        if (ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, i0n, nn, 0, eh[0], el[0]);
+        asp_exp8(s, 0, psum, ph[0], pl[0]);
+        if (ASP_ABL == 8) racc = r; else if (ASP_ABL != 2 && ASP_ABL != 10) asp_wwrite(c, 0, r);
+    }
+    ASP_FMARK(1);
+    ASP_SB();
+    // slot 1: window tile 1, P V of group 0 | group 1
+    {
+        f32x16 r;
+        if (ASP_ABL != 2 && ASP_ABL != 10) r = asp_eq(eh[1], el[1], qh, ql, negm_n);
+        if (ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, i0n, nn, 1, eh[1], el[1]);
+        asp_pv(o, va[0], ph[0], pl[0]);
+        if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[0] = asp_load_v(c, vn, 0);
+        asp_exp8(s, 1, psum, ph[1], pl[1]);
+        if (ASP_ABL == 8) { for (int v = 0; v < 16; ++v) racc[v] = fmaxf(racc[v], r[v]); } else if (ASP_ABL != 2 && ASP_ABL != 10) asp_wwrite(c, 1, r);
+    }
+    ASP_FMARK(2);
+    ASP_SB();
+    // slot 2: window tile 2 (two live key tiles only), P V of group 1 | group 2 (two back tiles only)
+    {
+        f32x16 r;
+        if (NF == 2 && ASP_ABL != 2 && ASP_ABL != 10) r = asp_eq(eh[2], el[2], qh, ql, negm_n);
+        if (ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, i0n, nn, 2, eh[2], el[2]);
+        asp_pv(o, va[1], ph[1], pl[1]);
+        if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[1] = asp_load_v(c, vn, 1);
+        if (NB == 2) asp_exp8(s, 2, psum, ph[0], pl[0]);
+        if (ASP_ABL == 8) sn[1] = r; else if (NF == 2 && ASP_ABL != 2 && ASP_ABL != 10) asp_wwrite(c, 2, r);
+    }
+    ASP_FMARK(3);
+    ASP_SB();
+    // slot 3: skewed read, P V of group 2 | group 3
+    wave_lds_fence();
+    if (ASP_ABL == 8) sn[0] = racc;
+    else if (ASP_ABL != 2 && ASP_ABL != 10) asp_wread<NF>(c, sn);
+    else { sn[0] = splat16(psum); sn[1] = splat16(psum); }
+    wave_lds_fence();
+    if (NB == 2) asp_pv(o, va[2], ph[0], pl[0]);
+    if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[2] = asp_load_v(c, vn, 2);
+    if (NB == 2) asp_exp8(s, 3, psum, ph[1], pl[1]);
+    ASP_FMARK(4);
+    ASP_SB();
+    // slot 4: K q on top of the skewed window; next unit's K (and Q)
+#pragma unroll
+    for (int jt = 0; jt < NF; ++jt)
+        if (ASP_ABL != 5 && ASP_ABL != 10) sn[jt] = asp_eq(kh[jt], kl[jt], qh, ql, sn[jt]);
+    if (LASTQ) asp_load_q(c, itn, qh, ql);
+    if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) asp_load_k(c, nn, jt, kh[jt], kl[jt]);
+    }
+    ASP_FMARK(5);
+    ASP_SB();
+    // slot 5: P V of group 3; V of the next unit | running maximum of the new scores
+    if (NB == 2) asp_pv(o, va[3], ph[1], pl[1]);
+    if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[3] = asp_load_v(c, vn, 3);
+    st.l += psum;
+    float mx = 0.f;
+    if (HOTMX && ASP_ABL != 9) mx = asp_max<2, true>(c, sn, 0);
+    ASP_FMARK(6);
+#ifdef A32_STAMP
+    ++sp.chunks;
+#endif
+    return mx;
+}
+
+// NKTL / FULLL: live key tiles of a query tile's LAST chunk / that chunk has all 64 keys (L % 64 == 0)
+template <bool CLAMP, int NKTL, bool FULLL>
+__global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Float16* __restrict__ qimg,
+                                                                const _Float16* __restrict__ kimg,
+                                                                const _Float16* __restrict__ vimg,
+                                                                const _Float16* __restrict__ eimg, int max_pos,
+                                                                float* __restrict__ x, TokMap m,
+                                                                const _Float16* __restrict__ woi,
+                                                                const float* __restrict__ bo, int Lt, int tpb, int bps,
+                                                                long nblocks) {
+    __shared__ __attribute__((aligned(16))) float rbuf[4][ASP_RFL];
+    __shared__ __attribute__((aligned(16))) f32x4 stash[2][4][2][64];      // [parity][head][16-token block][16x16 lane]
+#ifdef A32_STAMP
+    A32Stamp sp;
+    sp.t = __builtin_readcyclecounter();
+    sp.chunks = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sp.acc[i] = 0;
+#endif
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long lblk = XCD_ORDER ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+    if (lblk >= nblocks) return;                          // padding blocks of the rounded-up grid (block-uniform)
+    const int n = __builtin_amdgcn_readfirstlane((int)((unsigned)lblk / (unsigned)bps));
+    const int it0 = ((int)lblk - n * bps) * tpb, it1 = it0 + tpb < Lt ? it0 + tpb : Lt;
+    const long nh = (long)n * 4 + wv;                     // this wave's head
+    const int L = m.L;
+    AspCtx c;
+    c.a = lane & 31; c.hh = lane >> 5;
+    c.Rw = rbuf[wv] + c.a * ASP_P + 4 * c.hh;
+    c.Rr = rbuf[wv] + c.a * (ASP_P - 1) + 32 + 4 * c.hh;
+    c.Lt = Lt; c.L = L; c.max_pos = max_pos; c.lpad = 32 * Lt;
+    c.kr = a32_rsrc(kimg + nh * Lt * 1024, (unsigned)Lt * 2048u);
+    c.vr = a32_rsrc(vimg + nh * Lt * 1024, (unsigned)Lt * 2048u);
+    c.er = a32_rsrc(eimg, (unsigned)(2 * max_pos + 1) * 64u);
+    c.qr = a32_rsrc(qimg + nh * Lt * 1024, (unsigned)Lt * 2048u);
+    c.lane16 = (unsigned)lane * 16u;
+    c.eplane2 = (unsigned)(2 * max_pos + 1) * 32u;
+    c.evoff = (unsigned)c.hh * (unsigned)(2 * max_pos + 1) * 16u;
+    if (!CLAMP) c.evoff += (unsigned)(max_pos - 32 + c.a - c.lpad) * 16u;
+    const int c16 = lane & 15, g16 = lane >> 4;
+    const int nq = __builtin_amdgcn_readfirstlane(n / m.inner);
+    char* xbase = reinterpret_cast<char*>(x + ((long)nq * m.outer + (long)(n - nq * m.inner) * m.istride) * 64 + 16 * wv);
+    const unsigned xstride = (unsigned)m.lstride * 256u, xlane = (unsigned)g16 * 16u;
+    const _Float16* wp = woi + wv * 2048 + lane * 8;      // this wave's output block of the to_out image (global)
+
+    f16x8 qh, ql, eh[3], el[3], kh[2], kl[2], va[4];
+    asp_load_q(c, it0, qh, ql);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) asp_load_e<CLAMP>(c, 32 * it0, 0, t, eh[t], el[t]);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) asp_load_k(c, 0, jt, kh[jt], kl[jt]);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) va[g4] = asp_load_v(c, 0, g4);
+    const int nfull = L >> 6, tail = L & 63;
+    const int nch = nfull + (tail ? 1 : 0);               // chunks of a query tile; the last one is the tail chunk if tail
+
+    A32State st;
+    st.m = 0.f; st.run = -INFINITY; st.l = 0.f;
+    f32x16 o = zero16(), negm = zero16();
+    f32x16 s[2];
+    // the block's first unit: front half alone
+    {
+        const bool last = nch == 1;
+        const int i0 = 32 * it0;
+        if (last) asp_front<NKTL, CLAMP, true>(c, i0 + 32, 0, it0 + 1, qh, ql, eh, el, kh, kl, negm, s);
+        else asp_front<2, CLAMP, false>(c, i0, 1, 0, qh, ql, eh, el, kh, kl, negm, s);
+    }
+
+    ASP_CMARK(0);                                         // prologue + the block's first front half
+#pragma unroll 1
+    for (int it = it0; it < it1; ++it) {
+        const int i0 = 32 * it;
+        // reference step of the tile's chunk 0 (its front half ran under the previous tile's last back half)
+        if (nch > 1) asp_reference<2, true>(c, s, 0, st, o, negm);
+        else asp_reference<NKTL, FULLL>(c, s, 0, st, o, negm);
+        int ch = 0;                                       // s = the referenced scores of chunk ch of this tile
+        // hot loop: back half of chunk ch under the front half of chunk ch + 1 (never the tile's last chunk)
+        while (ch < nch - 2) {
+            // (two bodies per iteration with the roles of s / sn swapped: no register copies between chunks)
+            bool drifted, odd = false;
+            f32x16 sn[2];
+            do {
+                ASP_FMARK(0);                             // (stamp builds) everything outside the hot body
+                float mx = asp_fused<2, 2, true, CLAMP, false>(c, i0, ch + 2, ch + 1, 0, qh, ql, eh, el, kh, kl, va, negm, s, sn,
+                                                               st, o A32_STAMP_PASS);
+                st.run = fmaxf(st.run, mx);               // (harmless if the chunk is re-referenced below: max is idempotent)
+                drifted = __any(st.run > A32_HI || st.run < A32_LO);
+                ++ch;
+                if (!(ch < nch - 2) || drifted) { odd = true; break; }
+                ASP_FMARK(0);
+                mx = asp_fused<2, 2, true, CLAMP, false>(c, i0, ch + 2, ch + 1, 0, qh, ql, eh, el, kh, kl, va, negm, sn, s, st,
+                                                         o A32_STAMP_PASS);
+                st.run = fmaxf(st.run, mx);
+                drifted = __any(st.run > A32_HI || st.run < A32_LO);
+                ++ch;
+            } while (ch < nch - 2 && !drifted);
+            if (odd) { s[0] = sn[0]; s[1] = sn[1]; }
+            if (drifted) asp_reference<2, true>(c, s, 0, st, o, negm);
+        }
+        if (ch < nch - 1) {
+            // the tile's last chunk: its front half (new Q afterwards; E / K of the next tile's chunk 0) under the back
+            // half of chunk nch - 2, then its reference step
+            f32x16 sn[2];
+            asp_fused<NKTL, 2, false, CLAMP, true>(c, i0 + 32, 0, nch - 1, it + 1, qh, ql, eh, el, kh, kl, va, negm, s, sn,
+                                                   st, o A32_STAMP_PASS);
+            asp_reference<NKTL, FULLL>(c, sn, 64 * nfull, st, o, negm);
+            s[0] = sn[0]; s[1] = sn[1];
+        }
+        // s = the referenced scores of the tile's last chunk.  Its back half runs under the front half of the next
+        // tile's chunk 0 (reference level 0), or alone for the block's last tile.
+        f32x16 sn[2];
+        if (it + 1 < it1) {
+            const bool nlast = nch == 1;                  // the next tile's chunk 0 is also its last chunk
+            const f32x16 zero = zero16();
+            const int i0n = nlast ? i0 + 64 : i0 + 32, nn = nlast ? 0 : 1;
+            if (nlast) asp_fused<NKTL, NKTL, false, CLAMP, true>(c, i0n, nn, 0, it + 2, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
+            else asp_fused<2, NKTL, false, CLAMP, false>(c, i0n, nn, 0, 0, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
+        } else {
+            asp_back<NKTL>(s, st, o, va);
+        }
+        ASP_CMARK(1);                                     // the tile's units
+        // ---- epilogue of the tile: O / l -> stash -> barrier -> to_out + bias + residual ----
+        unsigned xo[2];
+        f32x4 xold[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int l = i0 + 16 * i + c16;
+            xo[i] = (unsigned)(l < L ? l : L - 1) * xstride + xlane;
+            xold[i] = *reinterpret_cast<const f32x4*>(xbase + xo[i]);
+        }
+        const f32x4 bias = ldg4(bo + 16 * wv + 4 * g16);
+        const f16x8 ah0 = *reinterpret_cast<const f16x8*>(wp), al0 = *reinterpret_cast<const f16x8*>(wp + 512);
+        const f16x8 ah1 = *reinterpret_cast<const f16x8*>(wp + 1024), al1 = *reinterpret_cast<const f16x8*>(wp + 1536);
+        const float inv = __builtin_amdgcn_rcpf(red_h_sum(st.l));
+        f32x4 oa, ob;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            oa[r] = (o[r] + o[8 + r]) * inv;
+            ob[r] = (o[4 + r] + o[12 + r]) * inv;
+        }
+        const int par = (it - it0) & 1;
+        stash[par][wv][c.a >> 4][c.hh * 16 + (c.a & 15)] = oa;
+        stash[par][wv][c.a >> 4][(2 + c.hh) * 16 + (c.a & 15)] = ob;
+        st.m = 0.f; st.run = -INFINITY; st.l = 0.f;       // the next tile starts from scratch
+        o = zero16(); negm = zero16();
+        s[0] = sn[0]; s[1] = sn[1];
+        if (ASP_ABL == 11) {
+            if (i0 + c16 < L) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(xo[0]), "v"(oa + ob + xold[0] + bias), "s"(xbase) : "memory");
+            continue;
+        }
+        ASP_CMARK(2);
+        __syncthreads();
+        ASP_CMARK(3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f16x8 bh0, bl0, bh1, bl1;
+            split8(stash[par][0][i][lane], stash[par][1][i][lane], bh0, bl0);
+            split8(stash[par][2][i][lane], stash[par][3][i][lane], bh1, bl1);
+            f32x4 acc = bias;                              // same product order as lin_acc_x3 / outproj_x3_kernel
+            acc = mfma32h(ah0, bh0, acc);
+            acc = mfma32l(ah0, bl0, acc);
+            acc = mfma32l(al0, bh0, acc);
+            acc = mfma32h(ah1, bh1, acc);
+            acc = mfma32l(ah1, bl1, acc);
+            acc = mfma32l(al1, bh1, acc);
+            // The store is inline asm on purpose: a store the compiler knows about is a second kind of pending vector-memory
+            // event at the loop header, and with mixed kinds its s_waitcnt pass stops trusting the return order and waits
+            // for vmcnt(0) at the top of every chunk - i.e. for the operand prefetches issued a few instructions earlier.
+            // (Stores only make a counted wait longer, never too short, and nothing here reads x back.)
+            const f32x4 xnew = xold[i] + acc;
+            if (i0 + 16 * i + c16 < L)
+                asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(xo[i]), "v"(xnew), "s"(xbase) : "memory");
+        }
+        ASP_CMARK(4);
+    }
+#ifdef A32_STAMP
+    ASP_FMARK(0);
+    if (lane == 0) {
+        const int b = L < 200 ? 32 : 0;
+        unsigned long long* slot = g_a32_stamp[(blockIdx.x * 4 + (threadIdx.x >> 6)) & (A32_SLOTS - 1)];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) atomicAdd(&slot[b + i], sp.acc[i]);
+        atomicAdd(&slot[b + 16], 1ull);
+        atomicAdd(&slot[b + 17], (unsigned long long)sp.chunks);
+    }
+#endif
+}
 
 // ---------------------------------------------------------------------------------
 // host side
@@ -606,4 +1125,29 @@ void launch_attn32_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* k
     else
         LAUNCH(ctx, "attn_out", (attn32_out_x3_kernel<false><<<grid, 256, 0, ctx.stream>>>(
                                     qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, bps, nb, nullptr)));
+}
+
+void launch_attn_sp_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* kimg, const _Float16* vimg,
+                           const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
+                           const float* bo) {
+    const int N = seq.nblocks / seq.Lb, Lt = (seq.L + 31) / 32;
+    const int bps = (Lt + A32_TPB - 1) / A32_TPB;
+    const int tpb = (Lt + bps - 1) / bps;
+    const long nb = (long)N * bps;
+    const unsigned grid = XCD_ORDER ? (unsigned)(((nb + 7) / 8) * 8) : (unsigned)nb;
+    const int tail = seq.L & 63;
+    const bool clamp = seq.L + 96 > max_pos;
+#define ASP_LAUNCH(CL, NK, FU)                                                                                    \
+    LAUNCH(ctx, "attn_out", (attn_sp_out_x3_kernel<CL, NK, FU><<<grid, 256, 0, ctx.stream>>>(                     \
+                                qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, bps, nb)))
+    if (!clamp) {
+        if (tail == 0) ASP_LAUNCH(false, 2, true);
+        else if (tail > 32) ASP_LAUNCH(false, 2, false);
+        else ASP_LAUNCH(false, 1, false);
+    } else {
+        if (tail == 0) ASP_LAUNCH(true, 2, true);
+        else if (tail > 32) ASP_LAUNCH(true, 2, false);
+        else ASP_LAUNCH(true, 1, false);
+    }
+#undef ASP_LAUNCH
 }

@@ -245,7 +245,8 @@ __global__ __launch_bounds__(512) void qkv_x3_kernel(const float* __restrict__ x
 #define ATTN_FUSE_OUT 1      // attention + to_out + residual in one kernel (0 = attn_x3_kernel, then outproj_x3_kernel)
 #endif
 #ifndef ATTN32
-#define ATTN32 0             // 1 = attention on 32x32x16 MFMAs (attn32_x3.hip, measured 3-6 % slower: DESIGN.md section 7c); 0 = the 16x16x32 kernels below
+#define ATTN32 2             // 2 = software-pipelined attention on 32x32x16 MFMAs (attn32_x3.hip: attn_sp_out_x3_kernel; masked
+                             // calls take attn32_out_x3_kernel<true>); 1 = the un-pipelined 32x32x16 kernel; 0 = the 16x16x32 kernels below
 #endif
 #ifndef DWPW2_SLIDE
 #define DWPW2_SLIDE 1        // sliding-window depthwise + pointwise kernel (0 = one block per 32-position tile)
@@ -1044,7 +1045,10 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
 
 #if ATTN32
     launch_qkv32_x3(ctx, b.xb, seq, w16.qkv_w, w.qkv_b, io.qimg, io.kimg, io.vimg);
-    launch_attn32_out_x3(ctx, io.qimg, io.kimg, io.vimg, w16.rel_planes, w.max_pos, b.xb, seq, w16.wo, w.bo, mask);
+    if (ATTN32 == 2 && !mask)
+        launch_attn_sp_out_x3(ctx, io.qimg, io.kimg, io.vimg, w16.rel_planes, w.max_pos, b.xb, seq, w16.wo, w.bo);
+    else
+        launch_attn32_out_x3(ctx, io.qimg, io.kimg, io.vimg, w16.rel_planes, w.max_pos, b.xb, seq, w16.wo, w.bo, mask);
 #else
     const int qtiles = N * Lb2;
     LAUNCH(ctx, "qkv", (qkv_x3_kernel<<<persistent_grid(qtiles, 2), 512, 0, s>>>(

@@ -133,6 +133,9 @@ void launch_qkv32_x3(LaunchCtx, const float* x, const TokMap& seq, const _Float1
 void launch_attn32_out_x3(LaunchCtx, const _Float16* qimg, const _Float16* kimg, const _Float16* vimg,
                           const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
                           const float* bo, const unsigned char* mask);
+void launch_attn_sp_out_x3(LaunchCtx, const _Float16* qimg, const _Float16* kimg, const _Float16* vimg,
+                           const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
+                           const float* bo);
 int  conv3x_ntiles(int T, int F, int cout);
 void launch_conv3_x3(LaunchCtx, const ConvArgs&, const void* w16, int B, int time_taps, int cout);
 void launch_conv3_x3_dgrad(LaunchCtx, const ConvArgs&, const void* w16, int B);      // 2 time taps, 64 -> 64, revt / accum honoured

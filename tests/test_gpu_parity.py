@@ -162,9 +162,16 @@ def test_conformer_attention_mask_matches_reference_golden(conf):
     g = load_golden("conformer_mask.npz")
     y = conf(g["x"].to(DEV), mask=g["mask"].bool().to(DEV))
     _check("conformer(x, mask) vs golden", y, g["out"], gate=STAGE)
-    # the unmasked call is untouched by the masked variant, and an all-True mask equals no mask bit for bit
+    # the unmasked call is untouched by the masked variant.  In F32 mode an all-True mask equals no mask bit for bit
+    # (one kernel, the mask compiled in or out); in F16X3 mode the unmasked call runs the software-pipelined kernel
+    # (reference level folded into the E q accumulator, other summation order of the denominator) and a masked call
+    # the un-pipelined one: equal to rounding
     y0 = conf(g["x"].to(DEV))
-    assert torch.equal(conf(g["x"].to(DEV), mask=torch.ones(4, 83, dtype=torch.bool, device=DEV)), y0)
+    y1 = conf(g["x"].to(DEV), mask=torch.ones(4, 83, dtype=torch.bool, device=DEV))
+    if conf.engine.mfma_mode == "f32":
+        assert torch.equal(y1, y0)
+    else:
+        assert _report("conformer(x, all-True mask) vs conformer(x)", rel_err(y1, y0)) < 1e-6
 
 
 @pytest.mark.parametrize("n,l,seed", [(3, 321, 1), (5, 101, 2), (2, 130, 3)])

@@ -1,0 +1,49 @@
+"""Per-slot cycle breakdown of attn_sp_out_x3_kernel's loop body (measurement build -DA32_STAMP, attn32_x3.hip).
+
+    python -c "from cmgan_amd.build import build; build(variant='spstamp', extra_flags=['-DA32_STAMP'])"
+    gpurun -- env CMGAN_HIP_LIB=$PWD/cmgan_amd/lib/variants/spstamp/libcmgan_hip.so python tools/probes/attn_sp_stamps.py
+
+Runs one ConformerBlock at the two sequence shapes of the B = 32 workload and prints the average cycles a wave spends in
+each of the six slots of asp_fused (all variants of the body) and outside it."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from cmgan_amd import ConformerBlock, _lib  # noqa: E402
+from cmgan_amd.synth import conformer_state_dict  # noqa: E402
+
+PH = [(1, "slot 0: E q t0 | exp/split g0"), (2, "slot 1: E q t1, PV g0 | g1"), (3, "slot 2: E q t2, PV g1 | g2"),
+      (4, "slot 3: E loads, window read, PV g2 | g3"), (5, "slot 4: K q, K loads"), (6, "slot 5: PV g3, V loads, max"),
+      (0, "outside the body")]
+
+
+def main():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    fn = lib.cmgan_dbg_a32_stamps
+    fn.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+    blk = ConformerBlock(dim=64, dim_head=16, heads=4, conv_kernel_size=31, mfma_mode="f16x3")
+    blk.load_state_dict(conformer_state_dict(seed=3))
+    buf = (ctypes.c_ulonglong * 64)()
+    for n, l in ((3232, 321), (10272, 101)):
+        x = torch.from_numpy(np.random.default_rng(l).standard_normal((n, l, 64)).astype(np.float32)).cuda()
+        blk(x)
+        torch.cuda.synchronize()
+        fn(buf, 1)
+        blk(x)
+        torch.cuda.synchronize()
+        fn(buf, 1)
+        a = np.array(list(buf), dtype=np.float64)
+        b = a[32:] if l < 200 else a[:32]
+        waves, bodies = b[16], b[17]
+        tot = b[:16].sum()
+        print(f"--- N={n} L={l}: {int(waves)} waves, {bodies / waves:.2f} bodies/wave, {tot / waves:.0f} cycles/wave")
+        for i, name in PH:
+            print(f"  {name:>44}: {b[i] / waves:9.0f} cyc/wave ({100 * b[i] / tot:5.1f} %)  {b[i] / bodies:8.0f} per body")
+
+
+if __name__ == "__main__":
+    main()
