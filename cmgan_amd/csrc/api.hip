@@ -438,6 +438,7 @@ static bool conf_weights(cmgan_handle* h, int index, ConfWeights& w) {
 struct WsPlan {
     size_t total = 0;
     size_t e[5];          // encoder dense slots [B,P,64]; e[1..4] double as decoder slots, e[0] as SP
+    size_t img[3];        // F16X3 dense blocks: (hi, lo) fp16 images of the block input and of slots 1, 2 (ConvArgs::img_out)
     size_t xa, xb, q, k, v, o, u, w;
     size_t dm, dc;        // tail projections [B, T*W, 4]
     size_t partials;
@@ -462,6 +463,7 @@ static WsPlan plan_ws(const cmgan_config& c, int B, int T) {
     size_t cur = 0;
     p.e[0] = take(cur, (size_t)B * T * std::max(F, W2) * 64);
     for (int i = 1; i < 5; ++i) p.e[i] = take(cur, (size_t)B * P * 64);
+    for (int i = 0; i < 3; ++i) p.img[i] = c.mfma_mode == CMGAN_MFMA_F16X3 ? take(cur, (size_t)B * P * 64) : 0;
     p.xa = take(cur, M * 64);
     p.xb = take(cur, M * 64);
     const size_t qf = std::max(conf_qkv_floats((int)(B * F2), T), conf_qkv_floats(B * T, (int)F2));
@@ -619,15 +621,26 @@ static bool dense_weights(cmgan_handle* h, int grp, DenseW& d) {
 
 // DilatedDenseNet (generator.py:39-47): slot 0 = x0 (with optional norm-on-load), layer i writes slot i+1.
 // ns(j) -> {scale, shift} storage for norm instance j; returns the instance index used by the last layer.
+// F16X3 mode (imgs != null): layer i is the FIRST consumer of its newest input (x0 for i = 0, else slot i - 1): it
+// normalises it on load as before and also stores its split-fp16 image (imgs[i], i < 3); layers i + 1 .. 3 read that
+// image instead of the raw slot - same values to the bit, without the per-re-read normalise / PReLU / split.
 static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float* x0, const float* x0_scale,
                             const float* x0_shift, const float* x0_alpha, float* const slots[4], float* partials,
-                            float* const nsc[4], float* const nsh[4], int B, int T, int F) {
+                            float* const nsc[4], float* const nsh[4], int B, int T, int F, float* const* imgs = nullptr) {
     const int nt = x3 ? conv3x_ntiles(T, F, 64) : conv3_ntiles(T, F);
     for (int i = 0; i < 4; ++i) {
         ConvArgs a{};
         a.in[0] = x0; a.nscale[0] = x0_scale; a.nshift[0] = x0_shift; a.nalpha[0] = x0_alpha;
         for (int s = 1; s <= i; ++s) {
             a.in[s] = slots[s - 1]; a.nscale[s] = nsc[s - 1]; a.nshift[s] = nsh[s - 1]; a.nalpha[s] = d.prelu[s - 1];
+        }
+#ifndef CX_IMG
+#define CX_IMG 1             // 0 = every layer re-normalises the raw slots (A/B builds)
+#endif
+        if (CX_IMG && x3 && imgs) {
+            for (int s = 0; s < i; ++s) a.in[s] = imgs[s];
+            a.img_mask = (1u << i) - 1u;
+            a.img_out = i < 3 ? imgs[i] : nullptr;
         }
         a.nslots = i + 1;
         a.w = d.w[i]; a.bias = d.bias[i];
@@ -696,7 +709,8 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
         float* slots[4] = {f + p.e[1], f + p.e[2], f + p.e[3], f + p.e[4]};
         float* sc[4] = {nsc(1), nsc(2), nsc(3), nsc(4)};
         float* sh[4] = {nsh(1), nsh(2), nsh(3), nsh(4)};
-        run_dense_block(ctx, x3, dbe, f + p.e[0], nsc(0), nsh(0), c1pr, slots, partials, sc, sh, B, T, F);
+        float* imgs[3] = {f + p.img[0], f + p.img[1], f + p.img[2]};
+        run_dense_block(ctx, x3, dbe, f + p.e[0], nsc(0), nsh(0), c1pr, slots, partials, sc, sh, B, T, F, x3 ? imgs : nullptr);
     }
     {   // conv_2: (1,3) stride (1,2) pad (0,1) == stride-1 conv keeping the even columns
         ConvArgs a{};
@@ -734,7 +748,8 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
         const int j0 = dec == 0 ? 6 : 10;
         float* sc[4] = {nsc(j0), nsc(j0 + 1), nsc(j0 + 2), nsc(j0 + 3)};
         float* sh[4] = {nsh(j0), nsh(j0 + 1), nsh(j0 + 2), nsh(j0 + 3)};
-        run_dense_block(ctx, x3, d, f + p.xa, nullptr, nullptr, nullptr, dslots, partials, sc, sh, B, T, F2);
+        float* imgs[3] = {f + p.img[0], f + p.img[1], f + p.img[2]};
+        run_dense_block(ctx, x3, d, f + p.xa, nullptr, nullptr, nullptr, dslots, partials, sc, sh, B, T, F2, x3 ? imgs : nullptr);
         ConvArgs a{};
         a.in[0] = dslots[3]; a.nscale[0] = sc[3]; a.nshift[0] = sh[3]; a.nalpha[0] = d.prelu[3];
         a.nslots = 1; a.w = dec == 0 ? mk_spw : cx_spw; a.bias = dec == 0 ? mk_spb : cx_spb;

@@ -113,7 +113,7 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
             const unsigned o_ = (NT == 2 && kt_ == 0) ? off1[e] + ((inv0 >> e) & 1u ? 0u : dFs) : off1[e]; \
             pre[e] = *reinterpret_cast<const f32x4*>(src_ + o_);     /* unconditional; masked at write */ \
         }                                                                                                \
-        const float* nsc_ = sel4(a.nscale, slot_);                                                       \
+        const float* nsc_ = ((a.img_mask >> slot_) & 1u) ? nullptr : sel4(a.nscale, slot_);              \
         if (nsc_ != nullptr) {                                                                           \
             sc = ldg4(nsc_ + b * 64 + half_ * 32 + qd * 4);                                              \
             sh = ldg4(sel4(a.nshift, slot_) + b * 64 + half_ * 32 + qd * 4);                             \
@@ -135,9 +135,22 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
         u32x4 wpre[NW];                                                                                  \
         _Pragma("unroll") for (int i = 0; i < NW; ++i) wpre[i] = wsrc_[tid + NTHR * i];                   \
         const unsigned inv_ = (NT == 2 && ktw_ == 0) ? inv0 : inv1;                                      \
-        const f32x4 am1 = al - splat4(1.f);                                                              \
-        _Pragma("unroll") for (int e = 0; e < NACT; ++e) {                                               \
-            {                                                                                            \
+        const int slotw_ = chunkw_ >> 1;                                                                 \
+        if ((a.img_mask >> slotw_) & 1u) {              /* pre-split image slot (block-uniform): two LDS stores */ \
+            _Pragma("unroll") for (int e = 0; e < NACT; ++e) {                                           \
+                u32x4 v = __builtin_bit_cast(u32x4, pre[e]);                                             \
+                if (inv_ & (1u << e)) v = u32x4{0u, 0u, 0u, 0u};                                         \
+                *reinterpret_cast<unsigned long long*>(wrow + RSTEP * e * CX_STRIDE) =                   \
+                    (unsigned long long)v[0] | ((unsigned long long)v[1] << 32);                         \
+                *reinterpret_cast<unsigned long long*>(wrow + RSTEP * e * CX_STRIDE + ACT) =             \
+                    (unsigned long long)v[2] | ((unsigned long long)v[3] << 32);                         \
+            }                                                                                            \
+        } else {                                                                                         \
+            const f32x4 am1 = al - splat4(1.f);                                                          \
+            /* the newest slot's t-plane stage also stores the image for the block's later layers */     \
+            char* const wb_ = (a.img_out != nullptr && slotw_ == a.nslots - 1 && ktw_ == NT - 1)         \
+                                  ? reinterpret_cast<char*>(a.img_out) + b * clip_bytes + (chunkw_ & 1) * 128 : nullptr; \
+            _Pragma("unroll") for (int e = 0; e < NACT; ++e) {                                           \
                 f32x4 v = pre[e];                                                                        \
                 v = v * sc + sh;                          /* branch-free: identity slots carry (1, 0, 0) */ \
                 f32x4 mn;                                                                                \
@@ -146,8 +159,15 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
                 if (inv_ & (1u << e)) v = splat4(0.f);   /* zero padding (select, no branch) */          \
                 f16x4 hi, lo;                                                                            \
                 split4(v, hi, lo);                                                                       \
-                *reinterpret_cast<f16x4*>(wrow + RSTEP * e * CX_STRIDE) = hi;                               \
-                *reinterpret_cast<f16x4*>(wrow + RSTEP * e * CX_STRIDE + ACT) = lo;                         \
+                *reinterpret_cast<f16x4*>(wrow + RSTEP * e * CX_STRIDE) = hi;                            \
+                *reinterpret_cast<f16x4*>(wrow + RSTEP * e * CX_STRIDE + ACT) = lo;                      \
+                if (wb_ != nullptr) {                     /* rows 1 .. CX_TILE are this tile's own positions */ \
+                    const int p_ = (tid >> 3) + RSTEP * e;                                               \
+                    if (p_ >= 1 && p_ <= CX_TILE && !(inv_ & (1u << e))) {                               \
+                        f16x8 hl = __builtin_shufflevector(hi, lo, 0, 1, 2, 3, 4, 5, 6, 7);              \
+                        *reinterpret_cast<f16x8*>(wb_ + off1[e]) = hl;                                   \
+                    }                                                                                    \
+                }                                                                                        \
             }                                                                                            \
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                   \

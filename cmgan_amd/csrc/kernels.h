@@ -76,6 +76,13 @@ struct ConvArgs {
     // training only (launch_conv3_x3_dgrad; ignored by the inference instantiations): the data gradient of a dense-block
     // conv is the same conv on the TIME-REVERSED plane (the causal tap t - dil becomes the anti-causal t + dil) with
     // transposed, frequency-mirrored weights, accumulated into the slot's gradient plane
+    // x3 dense blocks only (conv_x3.hip): slot s with bit s of img_mask set is not raw fp32 but the NORMALISED, PReLU'd
+    // activation already split into fp16 (hi, lo) - per 4 channels 8 bytes of hi then 8 bytes of lo, i.e. the same 16
+    // bytes per channel quad and the same addressing as the raw slot - written by the slot's FIRST consumer (img_out:
+    // the newest slot's image, stored from the t-plane stage by the tile that owns the position), so that the later
+    // layers of the block stage it with two LDS stores instead of normalise -> PReLU -> split for every re-read
+    unsigned img_mask;
+    void* img_out;
     int revt;                  // 1: logical frame t is physical frame T - 1 - t, for inputs and outputs alike
     int accum;                 // 1: out += oscale * result
     const float* oscale;       // device scalar (the inverse of the power-of-two input scale carried by nscale)
