@@ -342,6 +342,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="16k")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f16x1", action="store_true",
+                    help="skip the reduced-precision (single fp16 product) mode leg of the line")
     ap.add_argument("--no-f32", action="store_true", help="skip the bit-exact fp32-MFMA mode leg of the line")
     ap.add_argument("--no-train", action="store_true",
                     help="skip the training-step leg (BASELINE configs[2]: adversarial train steps at 32 clips per GPU "
@@ -534,6 +536,30 @@ def main():
                                                                      FP32_MFMA_PEAK_TF, 4),
                                 "roofline": roof32}
             del m32, e32
+        # ---- the opt-in REDUCED-precision mode (BASELINE configs[1] "bf16": one fp16 product per contraction in the
+        # TSCNet body), same workload, same line; never the headline: its error is reported next to its time ----
+        if world == 1 and x3 and not args.no_f16x1:
+            ref_out = run(wav).clone()
+            m1 = TSCNet(64, sh.F, n_fft=sh.n_fft, hop=sh.hop, device=dev, mfma_mode="f16x1").load_state_dict(sd).eval()
+            e1 = m1.engine
+            run1 = e1.enhance if args.no_graph else e1.enhance_graphed
+            out1 = run1(wav)
+            torch.cuda.synchronize()
+            k1 = max(2, min(args.steps, 10))
+            t0 = time.perf_counter()
+            for _ in range(k1):
+                run1(wav)
+            torch.cuda.synchronize()
+            dt1 = (time.perf_counter() - t0) / k1
+            err = float((out1 - ref_out).abs().max() / ref_out.abs().max())
+            line["f16x1_mode"] = {"ms_per_step": round(1e3 * dt1, 3), "value": round(sh.B * sh.T / dt1, 1),
+                                  "unit": "frames/s", "steps": k1, "dtype": "f16 (single fp16 product, fp32 accumulate)",
+                                  "rel_err_vs_f16x3": float(f"{err:.3e}"),
+                                  "note": "opt-in reduced precision (TSCNet body only): 6e-4..9e-4 vs the reference on synthetic "
+                                          "and real clips (tests/test_gpu_parity.py::test_f16x1_mode_error_bands), "
+                                          "200x the default mode's error"}
+            e1._graphs.clear()
+            del m1, e1, out1, ref_out
         # ---- BASELINE configs[4] and [3] in the same line (N = 1 only; each takes about a second) ----------------
         if world == 1 and x3 and args.workload == "16k" and not args.no_extra:
             for key, fn in (("stream_config5", lambda: stream_leg(model, dev)),

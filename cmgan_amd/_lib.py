@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMGAN_HIP_LIB") or os.path.join(HERE, "lib", "libcmgan_hip.so")
 
 OK = 0
-ABI_VERSION = 3
-MFMA_F32, MFMA_F16X3 = 0, 1
+ABI_VERSION = 4
+MFMA_F32, MFMA_F16X3, MFMA_F16X1 = 0, 1, 2
 
 
 class CmganError(RuntimeError):

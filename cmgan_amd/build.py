@@ -18,6 +18,9 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcmgan_hip.so")
 SOURCES = ["api.hip", "api_train.hip", "conformer.hip", "conformer_x3.hip", "attn32_x3.hip", "conv.hip", "conv_x3.hip",
            "stft.hip", "train.hip", "train_x3.hip", "disc.hip"]
+# the F16X1 (single fp16 product) twins of the x3 kernels: the same sources compiled a second time with X1_FLAGS
+X1_SOURCES = ["conformer_x3.hip", "attn32_x3.hip", "conv_x3.hip"]
+X1_FLAGS = ["-DX3_SINGLE", "-DX3_TERMS=1"]
 HEADERS = ["common.hip.h", "kernels.h", "weights.h", "api_internal.h", "train.h",
            os.path.join("..", "..", "include", "cmgan_hip.h")]
 # the generator FORWARD path: what bench.py measures and what the PMC evidence under profiles/ was collected on.  The
@@ -41,7 +44,7 @@ def _digest() -> str:
     for name in SOURCES + HEADERS:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + X1_FLAGS).encode())
     return h.hexdigest()
 
 
@@ -69,9 +72,10 @@ def build(force: bool = False, verbose: bool = True, variant: str | None = None,
         return lib
     objs = []
 
-    def compile_one(src):
-        obj = os.path.join(libdir, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
+    def compile_one(job):
+        src, extra, suffix = job
+        obj = os.path.join(libdir, src.replace(".hip", suffix + ".o"))
+        cmd = [HIPCC, *flags, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
@@ -82,8 +86,9 @@ def build(force: bool = False, verbose: bool = True, variant: str | None = None,
             raise subprocess.CalledProcessError(r.returncode, cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    jobs = [(src, [], "") for src in SOURCES] + [(src, X1_FLAGS, "_x1") for src in X1_SOURCES]
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        objs = list(ex.map(compile_one, jobs))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -105,8 +105,9 @@ extern "C" int cmgan_create(cmgan_handle** out, const cmgan_config* cfg) {
                     "need n_fft %% 16 == 0, hop %% 4 == 0, hop | n_fft, num_features == n_fft/2+1 (odd)");
     if (cfg->num_tscb < 1 || cfg->num_tscb > 4 || cfg->max_pos_emb < 1)
         return fail(nullptr, CMGAN_E_UNSUPPORTED, "num_tscb must be 1..4, max_pos_emb >= 1");
-    if (cfg->mfma_mode != CMGAN_MFMA_F32 && cfg->mfma_mode != CMGAN_MFMA_F16X3)
-        return fail(nullptr, CMGAN_E_UNSUPPORTED, "mfma_mode must be CMGAN_MFMA_F32 (0) or CMGAN_MFMA_F16X3 (1)");
+    if (cfg->mfma_mode != CMGAN_MFMA_F32 && cfg->mfma_mode != CMGAN_MFMA_F16X3 && cfg->mfma_mode != CMGAN_MFMA_F16X1)
+        return fail(nullptr, CMGAN_E_UNSUPPORTED,
+                    "mfma_mode must be CMGAN_MFMA_F32 (0), CMGAN_MFMA_F16X3 (1) or CMGAN_MFMA_F16X1 (2)");
     cmgan_handle* h = new cmgan_handle();
     h->cfg = *cfg;
     hipError_t e = hipGetDevice(&h->device);
@@ -155,7 +156,7 @@ extern "C" int cmgan_create(cmgan_handle** out, const cmgan_config* cfg) {
     h->st.n_fft = N; h->st.hop = cfg->hop; h->st.F = F; h->st.FB = FB;
     h->st.fwd_fm = h->d_tables; h->st.inv_fm = h->d_tables + n_fwd; h->st.window = h->d_tables + n_fwd + n_inv;
     h->st.fold_fwd16 = nullptr; h->st.fold_inv16 = nullptr;
-    if (cfg->mfma_mode == CMGAN_MFMA_F16X3 && N == 400 && cfg->hop == 100) {
+    if (cfg->mfma_mode != CMGAN_MFMA_F32 && N == 400 && cfg->hop == 100) {
         std::vector<_Float16> img, inv_img;
         build_fold_fwd(N, F, win, img);
         build_fold_inv(N, win, inv_img);
@@ -463,7 +464,7 @@ static WsPlan plan_ws(const cmgan_config& c, int B, int T) {
     size_t cur = 0;
     p.e[0] = take(cur, (size_t)B * T * std::max(F, W2) * 64);
     for (int i = 1; i < 5; ++i) p.e[i] = take(cur, (size_t)B * P * 64);
-    for (int i = 0; i < 3; ++i) p.img[i] = c.mfma_mode == CMGAN_MFMA_F16X3 ? take(cur, (size_t)B * P * 64) : 0;
+    for (int i = 0; i < 3; ++i) p.img[i] = c.mfma_mode != CMGAN_MFMA_F32 ? take(cur, (size_t)B * P * 64) : 0;
     p.xa = take(cur, M * 64);
     p.xb = take(cur, M * 64);
     const size_t qf = std::max(conf_qkv_floats((int)(B * F2), T), conf_qkv_floats(B * T, (int)F2));
@@ -594,10 +595,11 @@ static int conformer_forward_impl(cmgan_handle* h, int index, const float* x, in
     const size_t M = (size_t)N * L;
     HIPCHK(h, hipMemcpyAsync(b.xa, x, M * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
     const TokMap seq = make_seq_map(N, L, 1, L, 0, 1);
-    if (h->cfg.mfma_mode == CMGAN_MFMA_F16X3) {
+    if (h->cfg.mfma_mode != CMGAN_MFMA_F32) {
         ConfWeightsX3 w16;
         if (!conf_weights_x3(h, index, w16)) return CMGAN_E_WEIGHTS;
-        conformer_forward_x3(begin(h, stream), w, w16, b, seq, (long)M, taps, false, mask);
+        (h->cfg.mfma_mode == CMGAN_MFMA_F16X1 ? conformer_forward_x1 : conformer_forward_x3)(
+            begin(h, stream), w, w16, b, seq, (long)M, taps, false, mask);
     } else {
         conformer_forward(begin(h, stream), w, b, seq, (long)M, taps, false, mask);
     }
@@ -624,9 +626,11 @@ static bool dense_weights(cmgan_handle* h, int grp, DenseW& d) {
 // F16X3 mode (imgs != null): layer i is the FIRST consumer of its newest input (x0 for i = 0, else slot i - 1): it
 // normalises it on load as before and also stores its split-fp16 image (imgs[i], i < 3); layers i + 1 .. 3 read that
 // image instead of the raw slot - same values to the bit, without the per-re-read normalise / PReLU / split.
+typedef void (*Conv3xFn)(LaunchCtx, const ConvArgs&, const void*, int, int, int);
 static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float* x0, const float* x0_scale,
                             const float* x0_shift, const float* x0_alpha, float* const slots[4], float* partials,
-                            float* const nsc[4], float* const nsh[4], int B, int T, int F, float* const* imgs = nullptr) {
+                            float* const nsc[4], float* const nsh[4], int B, int T, int F, float* const* imgs = nullptr,
+                            Conv3xFn conv3x = launch_conv3_x3) {
     const int nt = x3 ? conv3x_ntiles(T, F, 64) : conv3_ntiles(T, F);
     for (int i = 0; i < 4; ++i) {
         ConvArgs a{};
@@ -646,7 +650,7 @@ static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float
         a.w = d.w[i]; a.bias = d.bias[i];
         a.out = slots[i]; a.partials = partials;
         a.T = T; a.F = F; a.dil = 1 << i; a.mode = 0; a.ntiles = nt;
-        if (x3) launch_conv3_x3(ctx, a, d.w16[i], B, 2, 64);
+        if (x3) conv3x(ctx, a, d.w16[i], B, 2, 64);
         else launch_conv3(ctx, a, B, 2, 64);
         launch_in_finalize(ctx, partials, B, nt, 64, 0, (double)T * F, d.gb[i], nsc[i], nsh[i]);
     }
@@ -686,7 +690,9 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
     const float* cx_pr = W(h, WID(G_CPLX, CX_PRELU), ok);
     const float* cx_tail = W(h, WID(G_CPLX, CX_TAIL_W), ok);
     const float* cx_bias = W(h, WID(G_CPLX, CX_BIAS), ok);
-    const bool x3 = h->cfg.mfma_mode == CMGAN_MFMA_F16X3;
+    const bool x3 = h->cfg.mfma_mode != CMGAN_MFMA_F32, single = h->cfg.mfma_mode == CMGAN_MFMA_F16X1;
+    const Conv3xFn conv3x = single ? launch_conv3_x1 : launch_conv3_x3;
+    const auto conformer_x = single ? conformer_forward_x1 : conformer_forward_x3;
     ConfWeights cw[8];
     ConfWeightsX3 cw16[8];
     for (int i = 0; i < 2 * h->cfg.num_tscb; ++i) {
@@ -710,14 +716,14 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
         float* sc[4] = {nsc(1), nsc(2), nsc(3), nsc(4)};
         float* sh[4] = {nsh(1), nsh(2), nsh(3), nsh(4)};
         float* imgs[3] = {f + p.img[0], f + p.img[1], f + p.img[2]};
-        run_dense_block(ctx, x3, dbe, f + p.e[0], nsc(0), nsh(0), c1pr, slots, partials, sc, sh, B, T, F, x3 ? imgs : nullptr);
+        run_dense_block(ctx, x3, dbe, f + p.e[0], nsc(0), nsh(0), c1pr, slots, partials, sc, sh, B, T, F, x3 ? imgs : nullptr, conv3x);
     }
     {   // conv_2: (1,3) stride (1,2) pad (0,1) == stride-1 conv keeping the even columns
         ConvArgs a{};
         a.in[0] = f + p.e[4]; a.nscale[0] = nsc(4); a.nshift[0] = nsh(4); a.nalpha[0] = dbe.prelu[3];
         a.nslots = 1; a.w = c2w; a.bias = c2b; a.out = f + p.xb; a.partials = partials;
         a.T = T; a.F = F; a.dil = 1; a.mode = 1; a.ntiles = x3 ? conv3x_ntiles(T, F, 64) : conv3_ntiles(T, F);
-        if (x3) launch_conv3_x3(ctx, a, c2w16, B, 1, 64);
+        if (x3) conv3x(ctx, a, c2w16, B, 1, 64);
         else launch_conv3(ctx, a, B, 1, 64);
         launch_in_finalize(ctx, partials, B, a.ntiles, 64, 0, (double)P2, c2gb, nsc(5), nsh(5));
         launch_in_apply(ctx, f + p.xb, nsc(5), nsh(5), c2pr, f + p.xa, B, P2);
@@ -730,8 +736,8 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
     const TokMap fmap = make_seq_map(B * T, F2, 1, F2, 0, 1);
     for (int k = 0; k < h->cfg.num_tscb; ++k) {
         if (x3) {
-            conformer_forward_x3(ctx, cw[2 * k], cw16[2 * k], cb, tmap, M, nullptr, true);
-            conformer_forward_x3(ctx, cw[2 * k + 1], cw16[2 * k + 1], cb, fmap, M, nullptr, true);
+            conformer_x(ctx, cw[2 * k], cw16[2 * k], cb, tmap, M, nullptr, true, nullptr);
+            conformer_x(ctx, cw[2 * k + 1], cw16[2 * k + 1], cb, fmap, M, nullptr, true, nullptr);
         } else {
             conformer_forward(ctx, cw[2 * k], cb, tmap, M, nullptr, true);
             conformer_forward(ctx, cw[2 * k + 1], cb, fmap, M, nullptr, true);
@@ -749,13 +755,13 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
         float* sc[4] = {nsc(j0), nsc(j0 + 1), nsc(j0 + 2), nsc(j0 + 3)};
         float* sh[4] = {nsh(j0), nsh(j0 + 1), nsh(j0 + 2), nsh(j0 + 3)};
         float* imgs[3] = {f + p.img[0], f + p.img[1], f + p.img[2]};
-        run_dense_block(ctx, x3, d, f + p.xa, nullptr, nullptr, nullptr, dslots, partials, sc, sh, B, T, F2, x3 ? imgs : nullptr);
+        run_dense_block(ctx, x3, d, f + p.xa, nullptr, nullptr, nullptr, dslots, partials, sc, sh, B, T, F2, x3 ? imgs : nullptr, conv3x);
         ConvArgs a{};
         a.in[0] = dslots[3]; a.nscale[0] = sc[3]; a.nshift[0] = sh[3]; a.nalpha[0] = d.prelu[3];
         a.nslots = 1; a.w = dec == 0 ? mk_spw : cx_spw; a.bias = dec == 0 ? mk_spb : cx_spb;
         a.out = sp; a.partials = dec == 0 ? nullptr : partials;
         a.T = T; a.F = F2; a.dil = 1; a.mode = 2; a.ntiles = nt2;
-        if (x3) launch_conv3_x3(ctx, a, dec == 0 ? mk_spw16 : cx_spw16, B, 1, 128);
+        if (x3) conv3x(ctx, a, dec == 0 ? mk_spw16 : cx_spw16, B, 1, 128);
         else launch_conv3(ctx, a, B, 1, 128);
         if (dec == 0) {
             launch_tail_proj(ctx, sp, nullptr, nullptr, nullptr, mk_tail, f + p.dm, B, (long)T * W2);

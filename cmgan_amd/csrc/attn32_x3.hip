@@ -29,8 +29,13 @@
 //          V[key][d = row], rows 16..31 = lo of V[key][d = row - 16]; slot e <-> key 16 grp + 8 (e >> 2) + 4 hh + (e & 3)
 //          (= the key a lane's score register v = 8 (grp & 1) + e belongs to), so O^T[(hi | lo) d][query] accumulates
 //          V_hi P_hi + V_hi P_lo (rows 0..15) and V_lo P_hi + V_lo P_lo (rows 16..31) in two MFMAs per group.
+#if defined(X3_SINGLE) && defined(A32_STAMP)
+#undef A32_STAMP                                         // stamp builds instrument the default (F16X3) compile only
+#endif
 #include "kernels.h"
 #include <string.h>
+
+namespace X3_NS {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1098,6 +1103,9 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
     }
 #endif
 }
+
+}  // namespace X3_NS
+using namespace X3_NS;
 
 // ---------------------------------------------------------------------------------
 // host side

@@ -9,6 +9,8 @@
 //     (transposed through 1 KB of wave-private LDS in the producer)
 #include "kernels.h"
 
+namespace X3_NS {
+
 #define XNTB 2
 #define XWAVES 8
 #ifndef FFN_WAVES
@@ -1015,6 +1017,9 @@ __global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restric
 // ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
+}  // namespace X3_NS
+using namespace X3_NS;
+
 static int persistent_grid(int ntiles, int blocks_per_cu) {
     const int want = (ntiles + XWAVES - 1) / XWAVES;
     const int cap = 256 * blocks_per_cu;
@@ -1107,6 +1112,7 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
                                 w16.ff2_w2, w.ff2_b2, M, flat_tiles)));
 }
 
+#ifndef X3_SINGLE
 // f16 MFMA convention self-test: D = A(16 x 32KB2) * B with x3 images built like the loader does.
 __global__ void selftest_x3_kernel(const _Float16* __restrict__ a_img, const float* __restrict__ b_fm,
                                    float* __restrict__ d, int M32) {
@@ -1128,3 +1134,5 @@ __global__ void selftest_x3_kernel(const _Float16* __restrict__ a_img, const flo
 void launch_selftest_x3(hipStream_t s, const void* a_img, const float* b_fm, float* d, int M32) {
     selftest_x3_kernel<<<1, 64, 0, s>>>(reinterpret_cast<const _Float16*>(a_img), b_fm, d, M32);
 }
+
+#endif

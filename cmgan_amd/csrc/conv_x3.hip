@@ -11,6 +11,8 @@
 //     issue-early / write-late), so HBM/L2 latency hides under the matrix work.
 #include "kernels.h"
 
+namespace X3_NS {
+
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef CX_EARLY
 #define CX_EARLY 0            // 1 = weave the next stage's activation loads into the staging phase (CX_WRITE_PREFETCH):
@@ -362,6 +364,9 @@ __global__ __launch_bounds__(64 * NWV) void conv3x_kernel(ConvArgs a, const _Flo
     }
 }
 
+}  // namespace X3_NS
+using namespace X3_NS;
+
 // the dense / 1x3 convs stage 256-row tiles (254 outputs); the 128-channel sub-pixel conv 128-row tiles (126 outputs)
 // 64-channel kernels: 8 waves x 2 position blocks = the same 256-row tile and the same 76 KB of LDS as 4 waves x 4,
 // but four waves per SIMD instead of two (120 VGPRs): 3.5 % faster although every A fragment is now read by
@@ -379,6 +384,7 @@ __global__ __launch_bounds__(64 * NWV) void conv3x_kernel(ConvArgs a, const _Flo
 #ifndef CX_NWV128
 #define CX_NWV128 4
 #endif
+#ifndef X3_SINGLE
 int conv3x_ntiles(int T, int F, int cout) {
     const int tile = (cout == 128 ? 16 * CX_NPB128 * CX_NWV128 : 16 * CX_NPB64 * CX_NWV64) - 2;
     return (T * (F + 1) + tile - 1) / tile;
@@ -389,6 +395,7 @@ void launch_conv3_x3_dgrad(LaunchCtx ctx, const ConvArgs& a, const void* w16, in
     LAUNCH(ctx, "dense_train_bwd", (conv3x_kernel<2, 64, CX_NPB64, CX_NWV64, true><<<grid, 64 * CX_NWV64, 0, ctx.stream>>>(
                                        a, reinterpret_cast<const _Float16*>(w16))));
 }
+#endif
 
 void launch_conv3_x3(LaunchCtx ctx, const ConvArgs& a, const void* w16, int B, int time_taps, int cout) {
     dim3 grid(a.ntiles * B);                              // 1-D: see the XCD re-map in the kernel

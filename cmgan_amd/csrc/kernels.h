@@ -150,3 +150,29 @@ void launch_selftest_x3(hipStream_t, const void* a_img, const float* b_fm, float
 
 // ------------------------------- selftest ---------------------------------------
 void launch_selftest_mfma(hipStream_t, const float* a_fm, const float* b_fm, float* d, int KB);
+
+// ----------------------------- single-product twins (F16X1 mode) ------------------------------
+// conformer_x3.hip, attn32_x3.hip and conv_x3.hip are compiled a second time with -DX3_SINGLE -DX3_TERMS=1
+// (cmgan_amd/build.py): every product term with a lo operand is compiled out and operands are rounded to nearest
+// (common.hip.h), kernels live in their own namespace, and the host entry points take the _x1 names below.
+void conformer_forward_x1(LaunchCtx, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&, const TokMap& seq,
+                          long M, float* taps, bool outer_residual, const unsigned char* mask = nullptr);
+void launch_qkv32_x1(LaunchCtx, const float* x, const TokMap& seq, const _Float16* wi, const float* b,
+                     _Float16* qimg, _Float16* kimg, _Float16* vimg);
+void launch_attn32_out_x1(LaunchCtx, const _Float16* qimg, const _Float16* kimg, const _Float16* vimg,
+                          const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
+                          const float* bo, const unsigned char* mask);
+void launch_attn_sp_out_x1(LaunchCtx, const _Float16* qimg, const _Float16* kimg, const _Float16* vimg,
+                           const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
+                           const float* bo);
+void launch_conv3_x1(LaunchCtx, const ConvArgs&, const void* w16, int B, int time_taps, int cout);
+#ifdef X3_SINGLE
+#define X3_NS x1k
+#define conformer_forward_x3 conformer_forward_x1
+#define launch_qkv32_x3 launch_qkv32_x1
+#define launch_attn32_out_x3 launch_attn32_out_x1
+#define launch_attn_sp_out_x3 launch_attn_sp_out_x1
+#define launch_conv3_x3 launch_conv3_x1
+#else
+#define X3_NS x3k
+#endif

@@ -48,8 +48,9 @@ class Engine:
     def __init__(self, n_fft: int = 400, hop: int = 100, num_features: Optional[int] = None,
                  num_tscb: int = 4, max_pos_emb: int = 512, device: Optional[torch.device] = None,
                  mfma_mode: Optional[str] = None):
-        """mfma_mode: "f16x3" (default; fp32-accurate split products on the f16 matrix pipe) or
-        "f32" (bit-exact fp32 MFMA) - see include/cmgan_hip.h."""
+        """mfma_mode: "f16x3" (default; fp32-accurate split products on the f16 matrix pipe), "f32" (bit-exact fp32
+        MFMA) or "f16x1" (REDUCED precision, opt-in: one fp16 product per contraction in the TSCNet body, 6e-4 .. 9e-4 of
+        the peak vs the reference - inside the 1e-3 gate without margin, 200x the default mode's error) - see include/cmgan_hip.h."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("cmgan_amd needs a ROCm GPU: torch.cuda.is_available() is False")
@@ -63,11 +64,11 @@ class Engine:
         cfg.num_features = num_features if num_features is not None else n_fft // 2 + 1
         cfg.num_tscb, cfg.max_pos_emb = num_tscb, max_pos_emb
         if mfma_mode is not None:
-            modes = {"f32": _lib.MFMA_F32, "f16x3": _lib.MFMA_F16X3}
+            modes = {"f32": _lib.MFMA_F32, "f16x3": _lib.MFMA_F16X3, "f16x1": _lib.MFMA_F16X1}
             if mfma_mode not in modes:
                 raise ValueError(f"mfma_mode must be one of {sorted(modes)}")
             cfg.mfma_mode = modes[mfma_mode]
-        self.mfma_mode = "f16x3" if cfg.mfma_mode == _lib.MFMA_F16X3 else "f32"
+        self.mfma_mode = {_lib.MFMA_F32: "f32", _lib.MFMA_F16X3: "f16x3", _lib.MFMA_F16X1: "f16x1"}[cfg.mfma_mode]
         self.cfg = cfg
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):

@@ -412,6 +412,33 @@ def test_real_recordings_match_reference_golden(model, tag):
     _check(f"real track '{tag}' vs reference golden", out, g[f"enhanced_{tag}"], atol_rel=floor)
 
 
+def test_f16x1_mode_error_bands(sd):
+    """mfma_mode="f16x1" (CMGAN_MFMA_F16X1: one fp16 product per contraction in the TSCNet body - BASELINE configs[1]'s
+    "bf16"-class throughput mode; STFT / ISTFT stay on the split products) is an OPT-IN reduced-precision mode, and
+    this test pins what it costs: 6e-4 .. 9e-4 of the peak on synthetic clips AND on the three real recordings (measured
+    on MI355X; the 4.7e-2 of round 2's all-single-product probe on the track with digital silence came from the FRONT end,
+    |X|^-0.7 on near-silent bins, which stays fp32-class here).  That is inside the 1e-3 gate but with no margin - the
+    default mode sits at 4e-6 on the same inputs, asserted next to it - so the bands below are two-sided: a build
+    that silently became more (or less) accurate than a single fp16 product changes them."""
+    from cmgan_amd import TSCNet
+    from cmgan_amd.evaluation import enhance_one_track
+    m1 = TSCNet(num_channel=64, num_features=201, mfma_mode="f16x1").cuda().load_state_dict(sd).eval()
+    m3 = TSCNet(num_channel=64, num_features=201, mfma_mode="f16x3").cuda().load_state_dict(sd).eval()
+    assert m1.engine.mfma_mode == "f16x1"
+    wav = synthetic_clips(2, 32000, seed=5)
+    want = O.enhance_batch(sd, wav)
+    e1 = _report("f16x1: 2 x 2 s synthetic clips vs oracle", rel_err(m1.engine.enhance(wav.to(DEV)), want))
+    e3 = _report("f16x3: the same clips vs oracle", rel_err(m3.engine.enhance(wav.to(DEV)), want))
+    assert e3 < 2e-5 and 20 * e3 < e1 < 3e-3
+    g = load_golden("tracks.npz")
+    for tag in ("a", "b", "silence"):
+        noisy = (g[f"pcm_{tag}"].float() / 32768.0)[None, :]
+        out = enhance_one_track(m1, noisy.to(DEV))
+        assert torch.isfinite(out).all()
+        e = _report(f"f16x1: real track '{tag}' vs reference golden", rel_err(out, g[f"enhanced_{tag}"]))
+        assert 1e-4 < e < 3e-3, (tag, e)
+
+
 def test_one_row_of_the_full_config2_batch_matches_the_oracle_directly(model, sd):
     """BASELINE configs[1] shape (B = 32 x 2 s): row 17 of the batch against the CPU oracle run on that clip
     alone - a direct check at the benchmark size, not only shard == full by transitivity."""

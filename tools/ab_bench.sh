@@ -9,7 +9,7 @@ for round in $(seq 1 ${AB_ROUNDS:-4}); do
   if [ $((round % 2)) = 1 ]; then order="default $*"; else order="$(echo default "$@" | tr ' ' '\n' | tac | tr '\n' ' ')"; fi
   for v in $order; do
     if [ "$v" = default ]; then unset CMGAN_HIP_LIB; else export CMGAN_HIP_LIB=$PWD/cmgan_amd/lib/variants/$v/libcmgan_hip.so; fi
-    timeout 300 python bench.py --no-cpu-baseline --no-f32 --no-train --no-extra --steps 10 --warmup 3 > $OUT/ab_${v}_$round.json 2>/dev/null
+    timeout 300 python bench.py --no-cpu-baseline --no-f32 --no-f16x1 --no-train --no-extra --steps 10 --warmup 3 > $OUT/ab_${v}_$round.json 2>/dev/null
     python - "$v" "$round" "$OUT/ab_${v}_$round.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[3]))

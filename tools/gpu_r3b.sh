@@ -7,5 +7,5 @@ echo "=== stamps TPB=6"; CMGAN_HIP_LIB=$V/a32stamp/libcmgan_hip.so timeout 200 p
 echo "=== stamps TPB=1"; CMGAN_HIP_LIB=$V/a32stamp1/libcmgan_hip.so timeout 200 python tools/probes/attn_stamps.py 2>&1 | tail -24
 AB_ROUNDS=2 bash tools/ab_bench.sh tpb1 attn16 2>&1 | tail -8
 REPO=$PWD; cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace -d $REPO/$OUT/pmc_r3b -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f32 --no-train > $REPO/$OUT/pmc_r3b.log 2>&1; echo "pmc exit $?"
+timeout 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace -d $REPO/$OUT/pmc_r3b -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f32 --no-f16x1 --no-train > $REPO/$OUT/pmc_r3b.log 2>&1; echo "pmc exit $?"
 cd $REPO; python tools/rocpd_summary.py pmc $OUT/pmc_r3b/pmc_results.db 2>&1 | head -12 | cut -c1-260 || ls -R $OUT/pmc_r3b | head

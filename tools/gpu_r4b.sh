@@ -10,7 +10,7 @@ for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE" \
          "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_r4b_$i -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f32 --no-train --no-extra > $OUT/pmc_r4b_$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_r4b_$i -o pmc -- python $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f32 --no-f16x1 --no-train --no-extra > $OUT/pmc_r4b_$i.log 2>&1
   echo "pmc $i exit $?"
   cd $REPO; python tools/rocpd_summary.py pmc $(ls $OUT/pmc_r4b_$i/*results.db $OUT/pmc_r4b_$i/*/*results.db 2>/dev/null | head -1) > $OUT/pmc_r4b_$i.txt; cd /tmp
   grep -E '^kernel|attn_sp|conv3x_kernelILi2|dwpw2s' $OUT/pmc_r4b_$i.txt | cut -c1-400

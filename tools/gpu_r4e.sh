@@ -6,7 +6,7 @@ AB_ROUNDS=2 bash tools/ab_bench.sh attn16
 cd /tmp && export TMPDIR=/tmp
 for V in default attn16; do
   if [ "$V" = default ]; then unset CMGAN_HIP_LIB; else export CMGAN_HIP_LIB=$REPO/cmgan_amd/lib/variants/$V/libcmgan_hip.so; fi
-  timeout 300 rocprofv3 --kernel-trace -d $OUT/tr_r4e_$V -o tr -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32 --no-train --no-extra > $OUT/tr_r4e_$V.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace -d $OUT/tr_r4e_$V -o tr -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-f32 --no-f16x1 --no-train --no-extra > $OUT/tr_r4e_$V.log 2>&1
   cd $REPO; python - $(ls $OUT/tr_r4e_$V/*results.db $OUT/tr_r4e_$V/*/*results.db 2>/dev/null | head -1) <<'PY'
 import sqlite3, sys, collections
 db = sqlite3.connect(sys.argv[1])
