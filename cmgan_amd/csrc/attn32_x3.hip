@@ -1,26 +1,31 @@
 // attn32_x3.hip - Shaw relative-position attention of the ConformerBlock (conformer.py:100-133) on
 // v_mfma_f32_32x32x16_f16 (8-pass MFMAs, three split-f16 products per contraction), fused with to_out + bias +
-// residual (conformer.py:131-132, 218).  x3 mode only; replaces the 16x16x32 kernels of conformer_x3.hip
-// (attn_out_x3_kernel / qkv_x3_kernel, kept there for A/B builds with -DATTN32=0).
+// residual (conformer.py:131-132, 218).  x3 mode only.  Two kernels share the images, the arithmetic per product and
+// the epilogue:
+//   attn_sp_out_x3_kernel  the default (unmasked) path: software-pipelined unit stream, see its own header below;
+//   attn32_out_x3_kernel   ConformerBlock.forward(x, mask): one chunk after the other, mask logic in the softmax.
 //
-// Why this shape.  The 16x16x32 kernel was bound by instruction ISSUE, not by the matrix pipe (25 % busy): per
-// 2048 scores it issued 48 four-pass MFMAs (which leave no issue slots for other instructions on their SIMD,
-// tools/micro), ~200 VALU and 72 LDS instructions, and started every 64-key chunk with a cold load of its K / V /
-// E operands.  Here:
-//   * the contraction of an 8-pass 32x32x16 MFMA is exactly the head dimension d = 16, so a product costs three
-//     MFMAs (hi.hi + hi.lo + lo.hi) instead of the four terms of the [hi | lo]-packed 16x16x32 form: 23 MFMAs
-//     per 32-query x 64-key chunk (9 E q, 6 K q, 8 P V), each leaving ~5 issue slots for the softmax VALU;
-//   * scores are computed transposed (S^T = K Q^T, rows = keys, columns = queries), so a lane owns ONE query
-//     (column = lane & 31) and 16 keys of every 32-key tile: the row maximum / sum are in-lane plus one
-//     v_permlane32_swap, and exp2(S) converted to fp16 hi / lo IS the B operand of O^T += [V_hi ; V_lo]^T P -
-//     no data movement between the two products;
-//   * the operands of chunk n + 1 are requested right after their last use in chunk n (E after the E q MFMAs,
-//     K after the K q MFMAs, V after the P V MFMAs) into the same registers: the L2 latency is covered by the
-//     rest of the chunk at no register cost.
-// The relative-position term is the same Toeplitz skew as before, through a wave-private LDS window: R[w][q] =
-// E[i0 - w] . q_q for the 96 distances w = j - q a chunk can see (three 32x32 MFMA tiles), written row-major
-// (32 floats per distance, bank = query: conflict-free) and read back with per-lane base (32 + 4 hh - q) rows +
-// compile-time row offsets straight into the score accumulators, on which K q then accumulates.
+// Why this shape.  The contraction of an 8-pass 32x32x16 MFMA is exactly the head dimension d = 16, so a product
+// costs three MFMAs (hi.hi + hi.lo + lo.hi): 23 MFMAs per 32-query x 64-key chunk (9 E q, 6 K q, 8 P V), each leaving
+// issue slots for other instructions (the 4-pass 16x16x32 shape leaves none, tools/micro).  Scores are computed
+// transposed (S^T = K Q^T, rows = keys, columns = queries), so a lane owns ONE query (column = lane & 31) and 16
+// keys of every 32-key tile: the row maximum / sum are in-lane plus one v_permlane32_swap, and exp2(S) converted to
+// fp16 hi / lo IS the B operand of O^T += [V_hi ; V_lo]^T P - no data movement between the two products.
+// The relative-position term is a Toeplitz skew through a wave-private LDS window: R[w][q] = E[i0 - w] . q_q for the
+// 96 distances w = j - q a chunk can see (three 32x32 MFMA tiles), read back skewed straight into the score
+// accumulators, on which K q then accumulates.
+//
+// Online softmax with a STALE reference: p = exp2(s - m_ref) (scores are in log2 units: log2(e) and the 0.25 scale are
+// folded into the q projection); m_ref is the reference level of the query (0 before the first chunk) and `run` the
+// true running maximum RELATIVE to it.  The reference is kept inside the band  A32_LO < run <= A32_HI  = (-4, +12]:
+// +12 bounds p <= 2^12 (inside fp16 range for the split-product P V MFMAs), -4 keeps the largest p >= 2^-4 so the fp16
+// lo half of P stays normal (a reference that is too HIGH would silently cost mantissa bits).  Leaving the band takes
+// the re-reference path (m_ref += run, scores shifted, o and l rescaled by exp2(-run)); the branch is wave-uniform
+// (__any) and exact for every lane.  Scaling an empty accumulator is skipped (0 * exp2(+big) would be NaN).
+// MASK (conformer.py:113-126): a pair keeps its score only if query AND key are unmasked; the reference fills every
+// other score with -finfo.max, so an unmasked query ignores masked keys (p = 0) and a masked query attends uniformly to
+// all L keys (all its scores equal: 0 here).  A query whose keys so far were all masked has run = -inf ("dead"): it
+// contributes p = 0 and keeps its reference level untouched.
 //
 // Register images (all lane-linear 1 KiB fragments, written by qkv32_x3_kernel):
 //   Q, K : per (sequence, head, 32-token tile)  [hi | lo][64 lanes][8 halfs], lane (token = lane & 31, hh = lane >> 5)
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(512) void qkv32_x3_kernel(const float* __restrict__
 #ifndef A32_RSEQ
 #define A32_RSEQ 1
 #endif
-#define A32_HI 12.0f         // the stale-reference band of the online softmax, see att_softmax in conformer_x3.hip
+#define A32_HI 12.0f         // the stale-reference band of the online softmax (file header)
 #define A32_LO -4.0f
 #define A32_RFL (96 * 32)    // floats of one wave's distance window
 
@@ -261,8 +266,8 @@ __device__ __forceinline__ f16x8 a32_load_v(const A32Ctx& c, int n, int grp4) {
     return buf_h8(c.vr, c.lane16, (unsigned)gr * 1024u);
 }
 
-// Online softmax of one chunk for the lane's query (see att_softmax in conformer_x3.hip for the stale-reference
-// scheme and the mask semantics; same arithmetic, one query per lane).  On return s holds p = exp2(s - m).
+// Online softmax of one chunk for the lane's query (file header: the stale-reference scheme and the mask
+// semantics).  On return s holds p = exp2(s - m).
 template <int NKT, bool FULL, bool MASK>
 __device__ __forceinline__ void a32_softmax(f32x16 (&s)[2], const A32Ctx& c, int j0, A32State& st, f32x16& o,
                                             bool qvalid A32_STAMP_PTR) {
@@ -421,7 +426,7 @@ __device__ __forceinline__ void a32_chunk(const A32Ctx& c, int n, int i0n, int n
 // Epilogue of a tile: each wave parks its normalised O tile in the stash (double-buffered, so ONE barrier per
 // tile) in the 16x16 C-fragment form the to_out product consumes (the B fragment of k-block h); after the barrier
 // wave w evaluates output block w of x += Wo . concat_h(O_h) + bo for the tile's 32 tokens, exactly as
-// attn_out_x3_kernel does.
+// the pipelined kernel does.
 #ifndef A32_TPB
 #define A32_TPB 4
 #endif
@@ -619,7 +624,7 @@ extern "C" int cmgan_dbg_a32_stamps(unsigned long long* out, int reset) {
 //     clamping, so an E fetch is lane-constant offset + SCALAR offset - no address VALU in the loop.
 // Block = the four heads (one per wave) of up to A32_TPB consecutive query tiles of one sequence; per tile the
 // normalised O goes through the stash, one barrier, and wave w applies output block w of to_out + bias + residual
-// exactly as attn_out_x3_kernel does (to_out operands fetched per tile from L2; LDS: 4 x 12.5 KB windows + 16 KB
+// (to_out operands fetched per tile from L2; LDS: 4 x 12.5 KB windows + 16 KB
 // stash = 66 KB per block, two blocks per CU).
 // =====================================================================================
 #ifndef ASP_OCC
@@ -805,7 +810,7 @@ __device__ __forceinline__ float asp_max(const AspCtx& c, f32x16 (&s)[2], int j0
 
 // Reference step for the chunk whose scores are pending in s (outside the hot loop): takes the running maximum and,
 // if any lane of the wave left the band, re-references every lane to its running maximum (scores, denominator,
-// the O accumulator and the -m splat).  See att_softmax in conformer_x3.hip for the scheme.
+// the O accumulator and the -m splat).  The scheme: file header.
 template <int NKT, bool FULL>
 __device__ __forceinline__ void asp_reference(const AspCtx& c, f32x16 (&s)[2], int j0, A32State& st, f32x16& o,
                                               f32x16& negm) {
@@ -1127,12 +1132,9 @@ void launch_attn32_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* k
     const int tpb = (Lt + bps - 1) / bps;
     const long nb = (long)N * bps;
     const unsigned grid = XCD_ORDER ? (unsigned)(((nb + 7) / 8) * 8) : (unsigned)nb;
-    if (mask)
-        LAUNCH(ctx, "attn_out", (attn32_out_x3_kernel<true><<<grid, 256, 0, ctx.stream>>>(
-                                    qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, bps, nb, mask)));
-    else
-        LAUNCH(ctx, "attn_out", (attn32_out_x3_kernel<false><<<grid, 256, 0, ctx.stream>>>(
-                                    qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, bps, nb, nullptr)));
+    // the unmasked call is attn_sp_out_x3_kernel's (launch_attn_sp_out_x3); this kernel carries the mask logic
+    LAUNCH(ctx, "attn_out", (attn32_out_x3_kernel<true><<<grid, 256, 0, ctx.stream>>>(
+                                qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, bps, nb, mask)));
 }
 
 void launch_attn_sp_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* kimg, const _Float16* vimg,

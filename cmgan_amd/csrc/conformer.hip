@@ -197,7 +197,7 @@ struct AttnState {
 };
 
 // Online softmax with a stale reference kept in the band (-4, +12] around the running maximum; see
-// att_softmax in conformer_x3.hip for the derivation.  The rel-pos accumulator starts at -m_ref and
+// the header of attn32_x3.hip for the derivation.  The rel-pos accumulator starts at -m_ref and
 // the skewed tile is read straight into the score accumulators, so the common path has no per-score
 // add or subtract: p = exp2(K q + E q - m_ref).
 #define ATTN_HI 12.0f
