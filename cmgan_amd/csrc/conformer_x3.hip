@@ -65,6 +65,7 @@ __global__ __launch_bounds__(TWAVES * 64) void ffn_x3_kernel(const float* xin, f
         long row[TNTB];
         bool ok[TNTB];
         f16x8 xbh[TNTB][2], xbl[TNTB][2];
+        f32x4 y[TNTB][4];
 #pragma unroll
         for (int tb = 0; tb < TNTB; ++tb) {
             const long t = ((long)tile * TNTB + tb) * 16 + c;
@@ -73,13 +74,14 @@ __global__ __launch_bounds__(TWAVES * 64) void ffn_x3_kernel(const float* xin, f
             f32x4 x[4];
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) x[kb] = ldg4(xin + row[tb] * 64 + 16 * kb + 4 * g);
-            ln_split(x, xbh[tb], xbl[tb]);      // the residual is re-read in the epilogue (L2 hit): 32 VGPRs saved
+            ln_split(x, xbh[tb], xbl[tb]);
+            // The residual and the second bias are the INITIAL VALUE of the output accumulators: the B-fragment a lane
+            // loaded for k-block kb is exactly its C-fragment of output block ob = kb, and y is live through both
+            // GEMMs anyway.  (Re-reading the row in the epilogue - "an L2 hit" - missed 77 % of the time: 25 MB of rows
+            // in flight per launch against 32 MB of L2 also holding the output; 471 MB fetched for a 266 MB input.)
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) y[tb][ob] = x[ob] + *reinterpret_cast<const f32x4*>(&bias_l[256 + 16 * ob + 4 * g]);
         }
-        f32x4 y[TNTB][4];
-#pragma unroll
-        for (int tb = 0; tb < TNTB; ++tb)
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob) y[tb][ob] = splat4(0.f);
 
         // software pipeline over the 8 hidden k32-blocks: GEMM1(m2+1) is issued before the
         // Swish/split of block m2, so its MFMAs overlap that VALU work inside one wave
@@ -120,10 +122,6 @@ __global__ __launch_bounds__(TWAVES * 64) void ffn_x3_kernel(const float* xin, f
         }
 #pragma unroll
         for (int tb = 0; tb < TNTB; ++tb) {
-#pragma unroll
-            for (int ob = 0; ob < 4; ++ob)
-                y[tb][ob] = y[tb][ob] + *reinterpret_cast<const f32x4*>(&bias_l[256 + 16 * ob + 4 * g]) +
-                            ldg4(xin + row[tb] * 64 + 16 * ob + 4 * g);
             if (FINAL) {
                 float mean, rstd;
                 ln_stats(y[tb], mean, rstd);
@@ -230,6 +228,9 @@ __global__ __launch_bounds__(512) void pw1glu_x3_kernel(const float* __restrict_
 #ifndef DS_OCC
 #define DS_OCC 2             // blocks (= waves per SIMD) the register allocation is sized for
 #endif
+#ifndef DS_WRES
+#define DS_WRES (DS_OCC < 3) // pointwise operands resident in registers for the whole segment (1) or fetched per tile (0)
+#endif
 __global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restrict__ x, const float* __restrict__ u,
                                                         const float* __restrict__ dw_w,
                                                         const float* __restrict__ dw_b,
@@ -248,9 +249,10 @@ __global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restric
     const int ntiles = (l_end - l_begin + DP_TL - 1) / DP_TL;
     const long nbase = (long)(n / m.inner) * m.outer + (long)(n % m.inner) * m.istride;
 
-    // pointwise operands of this wave: token block tb, output blocks ob0, ob0 + 1 (held for the whole segment)
+    // pointwise operands of this wave: token block tb, output blocks ob0, ob0 + 1
     const int tb = wv >> 1, ob0 = (wv & 1) * 2;
-    f16x8 ah[2][4], al[2][4];
+#if DS_WRES
+    f16x8 ah[2][4], al[2][4];                                    // held for the whole segment (64 VGPRs)
 #pragma unroll
     for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -259,9 +261,12 @@ __global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restric
             ah[o][mm] = *reinterpret_cast<const f16x8*>(wp);
             al[o][mm] = *reinterpret_cast<const f16x8*>(wp + 512);
         }
+#endif
+#if DS_WRES
     f32x4 bias2[2];
 #pragma unroll
     for (int o = 0; o < 2; ++o) bias2[o] = ldg4(b2 + 16 * (ob0 + o) + 4 * g);
+#endif
 
     // window row r of the tile at l0 <-> sequence position l0 - 15 + r; rows outside [0, L) are the conv's zero padding
     auto load_row4 = [&](int l0, int rr, int qd) -> f32x4 {
@@ -312,8 +317,10 @@ __global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restric
         const bool live = lrow < m.L;
         float* xr = x + (nbase + (long)(live ? lrow : m.L - 1) * m.lstride) * 64;
         f32x4 xold[2];
+#if DS_WRES
 #pragma unroll
         for (int o = 0; o < 2; ++o) xold[o] = ldg4(xr + 16 * (ob0 + o) + 4 * g);
+#endif
 
         // ---- depthwise: 16 outputs of channel chn from a 46-row sliding window ----
         // (a half tile that lies entirely beyond the sequence end is skipped: 16 of the 128 slots of a frequency-axis
@@ -330,6 +337,9 @@ __global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restric
                     const int tp = kk - oo;
                     if (tp >= 0 && tp < DP_K) acc[oo] = fmaf(wt[tp], uv, acc[oo]);
                 }
+                // (three waves per SIMD: keep the scheduler from hoisting all 46 window reads above the FMAs - 46 live
+                // values on top of 31 taps and 16 accumulators do not fit 168 registers)
+                if (!DS_WRES && (kk & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int oo = 0; oo < 16; oo += 2) {
@@ -341,6 +351,14 @@ __global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restric
                 vtl[(sub * 16 + oo + 1) * DP_VS + vcol] = lo[1];
             }
         }
+#if !DS_WRES
+        f32x4 bias2[2];                                           // (after the depthwise phase: 16 VGPRs)
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            xold[o] = ldg4(xr + 16 * (ob0 + o) + 4 * g);
+            bias2[o] = ldg4(b2 + 16 * (ob0 + o) + 4 * g);
+        }
+#endif
         // the 30 rows the next window shares with this one (read before the barrier, written after it)
         f32x4 keep[4];
         if (has_next) {
@@ -355,6 +373,35 @@ __global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restric
 
         // ---- pointwise 128 -> 64 on the matrix pipe + bias + residual ----
         f32x4 acc2[2] = {bias2[0], bias2[1]};
+#if !DS_WRES
+        // the 16 KB of pointwise operands are fetched here, per tile and per k-block (L1 / L2 hits, one k-block ahead),
+        // instead of living in 64 VGPRs through the depthwise phase: the kernel then fits three waves per SIMD
+        auto wfetch = [&](int mm, f16x8 (&fh)[2], f16x8 (&fl)[2]) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const _Float16* wp = w2i + ((ob0 + o) * 4 + mm) * 1024 + lane * 8;
+                fh[o] = *reinterpret_cast<const f16x8*>(wp);
+                fl[o] = *reinterpret_cast<const f16x8*>(wp + 512);
+            }
+        };
+        f16x8 ch[2], cl[2];
+        wfetch(0, ch, cl);
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            f16x8 nh[2] = {ch[0], ch[1]}, nl[2] = {cl[0], cl[1]};
+            if (mm < 3) wfetch(mm + 1, nh, nl);
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(&vth[(16 * tb + c) * DP_VS + 32 * mm + 8 * g]);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(&vtl[(16 * tb + c) * DP_VS + 32 * mm + 8 * g]);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) acc2[o] = mfma32h(ch[o], bh, acc2[o]);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) acc2[o] = mfma32l(ch[o], bl, acc2[o]);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) acc2[o] = mfma32l(cl[o], bh, acc2[o]);
+#pragma unroll
+            for (int o = 0; o < 2; ++o) { ch[o] = nh[o]; cl[o] = nl[o]; }
+        }
+#else
 #pragma unroll
         for (int mm = 0; mm < 4; ++mm) {
             const f16x8 bh = *reinterpret_cast<const f16x8*>(&vth[(16 * tb + c) * DP_VS + 32 * mm + 8 * g]);
@@ -366,6 +413,7 @@ __global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restric
 #pragma unroll
             for (int o = 0; o < 2; ++o) acc2[o] = mfma32l(al[o][mm], bh, acc2[o]);
         }
+#endif
         if (live) {
 #pragma unroll
             for (int o = 0; o < 2; ++o) stg4(xr + 16 * (ob0 + o) + 4 * g, xold[o] + acc2[o]);
