@@ -637,7 +637,7 @@ def test_generator_train_step_matches_the_reference_trainer():
                    rel_err(out_sd["TSCB_2.freq_conformer.conv.net.5.running_var"], g["bn_var"])) < 1e-3
 
 
-def _whole_step_vs_oracle(sd, clean, noisy, npm, tag, bar, n_fft=400, hop=100):
+def _whole_step_vs_oracle(sd, clean, noisy, npm, tag, bar, n_fft=400, hop=100, loss_weights=(0.1, 0.9, 0.2)):
     """One generator optimisation step on the HIP path against autograd through the oracle on the same state dict,
     clips and dropout masks: loss terms, network outputs, output gradients and ALL parameter gradients, each tensor
     held to `bar` relative to its own maximum (worst tensor reported)."""
@@ -645,10 +645,11 @@ def _whole_step_vs_oracle(sd, clean, noisy, npm, tag, bar, n_fft=400, hop=100):
     from cmgan_amd.training import AdamW, GeneratorTrain, generator_train_step
     tm = lambda dev=None: [tuple({k: (torch.from_numpy(v) if dev is None else torch.from_numpy(v).to(dev))
                                   for k, v in d.items()} for d in pair) for pair in npm]
-    want = O.generator_step_gradients(sd, clean, noisy, tm(), n_fft=n_fft, hop=hop)
+    want = O.generator_step_gradients(sd, clean, noisy, tm(), loss_weights=loss_weights, n_fft=n_fft, hop=hop)
     gen = GeneratorTrain(sd, device=DEV) if n_fft == 400 else GeneratorTrain(sd, engine=Engine(n_fft=n_fft, hop=hop, device=DEV))
     opt = AdamW(gen.engine, gen.param_bucket, gen.grad_bucket, lr=5e-4)
-    loss, terms = generator_train_step(gen, opt, clean.to(DEV), noisy.to(DEV), masks=tm(DEV), update=False)
+    loss, terms = generator_train_step(gen, opt, clean.to(DEV), noisy.to(DEV), loss_weights=loss_weights, masks=tm(DEV),
+                                       update=False)
     assert _report(f"{tag}: loss", abs(float(loss) - float(want["loss"])) / abs(float(want["loss"]))) < 1e-4
     assert _report(f"{tag}: loss terms", rel_err(terms[:3], want["terms"])) < 1e-4
     scale = max(float(v.abs().max()) for v in want["grads"].values())
@@ -705,13 +706,19 @@ def test_generator_step_at_full_length_T321_kink_free_twin_vs_oracle_autograd():
 def test_generator_step_at_batch_4_x_T321_kink_free_twin_vs_oracle_autograd():
     """Four 2 s clips (T = 321): the largest whole step a CPU autograd oracle finishes in minutes (the bench's 32 clips per
     GPU do not fit one) - multi-clip BatchNorm batch statistics over 4 x 321 x 101 positions, several clips per XCD in the
-    per-XCD block orders of the training kernels, clip strides in every byte offset - all 335 gradient tensors at 1e-4."""
+    per-XCD block orders of the training kernels, clip strides in every byte offset - all 335 gradient tensors at 1e-4.
+    The time-domain L1 term is switched off here (weight 0): with 4 x 32 000 samples some |est - clean| falls inside the
+    forward's rounding error (this draw: 5.8e-6 at sample 1032 of clip 1, measured with tests/probes/b4_probe.py), the
+    sign of that one sample flips and the output gradient of its four frames moves by 5e-3 - the one kink the twin
+    does not remove.  The L1 term's own backward is pinned at T = 321 by the one-clip test above (no such sample there)
+    and at T = 33 by test_full_loss_gradient_at_the_network_output_vs_oracle_autograd."""
     from cmgan_amd.synth import kink_free_twin, synthetic_clips, synthetic_dropout_masks
     from oracle.weights import make_state_dict
     clean = synthetic_clips(4, 32000, seed=43)
     noisy = clean + 0.3 * synthetic_clips(4, 32000, seed=44)
     _whole_step_vs_oracle(kink_free_twin(make_state_dict(seed=0)), clean, noisy,
-                          synthetic_dropout_masks(92, 4, 321, 101), "kink-free twin, B = 4 x T = 321", 1e-4)
+                          synthetic_dropout_masks(92, 4, 321, 101), "kink-free twin, B = 4 x T = 321, no L1 term", 1e-4,
+                          loss_weights=(0.1, 0.9, 0.0))
 
 
 def test_generator_step_at_48_khz_kink_free_twin_holds_every_gradient_tensor_to_the_gate():
