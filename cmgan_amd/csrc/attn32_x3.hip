@@ -430,6 +430,9 @@ __device__ __forceinline__ void a32_chunk(const A32Ctx& c, int n, int i0n, int n
 #ifndef A32_TPB
 #define A32_TPB 4
 #endif
+#ifndef A32_TPB_SHORT
+#define A32_TPB_SHORT 4        // tiles per block for sequences of at most 4 tiles (the frequency axis: L = 101)
+#endif
 template <bool MASK>
 __global__ __launch_bounds__(256, MASK ? 1 : A32_OCC) void attn32_out_x3_kernel(const _Float16* __restrict__ qimg,
                                                                      const _Float16* __restrict__ kimg,
@@ -1141,7 +1144,8 @@ void launch_attn_sp_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* 
                            const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
                            const float* bo) {
     const int N = seq.nblocks / seq.Lb, Lt = (seq.L + 31) / 32;
-    const int bps = (Lt + A32_TPB - 1) / A32_TPB;
+    const int tpb_max = Lt <= 4 ? A32_TPB_SHORT : A32_TPB;
+    const int bps = (Lt + tpb_max - 1) / tpb_max;
     const int tpb = (Lt + bps - 1) / bps;
     const long nb = (long)N * bps;
     const unsigned grid = XCD_ORDER ? (unsigned)(((nb + 7) / 8) * 8) : (unsigned)nb;

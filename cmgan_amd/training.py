@@ -907,7 +907,9 @@ class GeneratorTrain:
         state = self.mask_rng_state(generator)
         n16 = (nbytes + 15) // 16 * 16
         buf = torch.empty(n16, dtype=torch.uint8, device=eng.device)
-        check(eng._h, eng.lib.cmgan_dropout_masks(eng._h, buf.data_ptr(), n16, 1.0 - p, state.data_ptr(), eng._stream()))
+        with torch.cuda.device(eng.device):              # (like every other native call: the launch goes to eng's device)
+            check(eng._h, eng.lib.cmgan_dropout_masks(eng._h, buf.data_ptr(), n16, 1.0 - p, state.data_ptr(),
+                                                      eng._stream()))
         return buf[:nbytes]
 
     def mask_rng_state(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
@@ -921,7 +923,24 @@ class GeneratorTrain:
         return state
 
     def reset_mask_rng(self) -> None:
-        self._mask_rng.clear()
+        """Restart every keep-mask stream of this model at offset 0.  The device tensors are kept and zeroed IN PLACE: a
+        captured GraphedTrainStep holds their raw pointers, and dropping them would leave its replays reading (and
+        advancing) memory the allocator has handed to someone else."""
+        for state in self._mask_rng.values():
+            state[1] = 0
+
+    def mask_rng_offsets(self) -> Dict[int, int]:
+        """{seed: offset} of the keep-mask streams (host copy) - save next to the optimiser state, restore with
+        `set_mask_rng_offsets`, so that a resumed run continues the mask sequence instead of repeating it from 0."""
+        return {seed: int(state[1]) for seed, state in self._mask_rng.items()}
+
+    def set_mask_rng_offsets(self, offsets: Dict[int, int]) -> None:
+        for seed, off in offsets.items():
+            state = self._mask_rng.get(int(seed))
+            if state is None:
+                self._mask_rng[int(seed)] = torch.tensor([int(seed), int(off)], dtype=torch.int64, device=self.engine.device)
+            else:
+                state[1] = int(off)
 
     def masks(self, B: int, T: int, generator: Optional[torch.Generator] = None):
         """Keep-masks of every Dropout of the four TSCBs for a [B, 2, T, F] input: [(time, freq)] * 4."""

@@ -137,10 +137,11 @@ def test_no_kernel_uses_scratch_memory():
 
     kernels_seen = [0]
 
-    def check(src):
+    def check(job):
+        src, extra = job
         with tempfile.TemporaryDirectory() as d:
             out = os.path.join(d, "k.s")
-            cmd = [B.HIPCC, *[f for f in B.FLAGS if f != "-fPIC"], "-S", "--cuda-device-only",
+            cmd = [B.HIPCC, *[f for f in B.FLAGS if f != "-fPIC"], *extra, "-S", "--cuda-device-only",
                    os.path.join(B.CSRC, src), "-o", out]
             subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
             text = open(out).read()
@@ -150,8 +151,9 @@ def test_no_kernel_uses_scratch_memory():
         kernels_seen[0] += len(names)
         return [(src, n, s) for n, s in zip(names, sizes) if s != 0]
 
-    with ThreadPoolExecutor(max_workers=len(B.SOURCES)) as ex:
-        bad = [b for res in ex.map(check, B.SOURCES) for b in res]
+    jobs = [(src, []) for src in B.SOURCES] + [(src, B.X1_FLAGS) for src in B.X1_SOURCES]   # + the F16X1 twins
+    with ThreadPoolExecutor(max_workers=len(jobs)) as ex:
+        bad = [b for res in ex.map(check, jobs) for b in res]
     assert not bad, f"kernels with scratch: {bad}"
     assert kernels_seen[0] >= 30            # the check really saw the library's kernels
 
