@@ -17,6 +17,11 @@ namespace X3_NS {
 #define FFN_WAVES 12          // waves per FeedForward block (one block per CU: 128 KB of weight images); three waves
                               // per SIMD at 150 VGPRs measured 7 % faster than two, a fourth would spill
 #endif
+#ifdef X3_SINGLE
+#define FFN_POST_WAVES 8      // the single-product twin of the FINAL variant wants 194 VGPRs: two waves per SIMD, no scratch
+#else
+#define FFN_POST_WAVES FFN_WAVES
+#endif
 
 __device__ __forceinline__ float swish_x(float hp) { return swish_scaled(hp); }
 
@@ -442,8 +447,8 @@ static int persistent_grid(int ntiles, int blocks_per_cu) {
     return want < cap ? (want > 0 ? want : 1) : cap;
 }
 
-static int ffn_grid(int ntiles) {                         // one persistent FeedForward block per CU
-    const int want = (ntiles + FFN_WAVES - 1) / FFN_WAVES;
+static int ffn_grid(int ntiles, int waves = FFN_WAVES) {  // one persistent FeedForward block per CU
+    const int want = (ntiles + waves - 1) / waves;
     return want < 256 ? (want > 0 ? want : 1) : 256;
 }
 
@@ -484,7 +489,7 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
                                b.xb, taps + (size_t)3 * M * 64, nullptr, nullptr, w16.ff2_w1, w.ff2_b1, w16.ff2_w2,
                                w.ff2_b2, M, flat_tiles)));
     }
-    LAUNCH(ctx, "ffn_post", (ffn_x3_kernel<true, 2, FFN_WAVES><<<ffn_grid(flat_tiles), 64 * FFN_WAVES, 0, s>>>(
+    LAUNCH(ctx, "ffn_post", (ffn_x3_kernel<true, 2, FFN_POST_WAVES><<<ffn_grid(flat_tiles, FFN_POST_WAVES), 64 * FFN_POST_WAVES, 0, s>>>(
                                 b.xb, b.xa, outer_residual ? b.xa : nullptr, w.post_gb, w16.ff2_w1, w.ff2_b1,
                                 w16.ff2_w2, w.ff2_b2, M, flat_tiles)));
 }
