@@ -659,15 +659,29 @@ def _whole_step_vs_oracle(sd, clean, noisy, npm, tag, bar, n_fft=400, hop=100, l
     # on both sides, no relative error to speak of - or vanishing (a relative-position table of which a short sequence
     # touches few rows): recognised by a maximum below 1e-6 of the largest gradient and held to an ABSOLUTE error
     # below that same 1e-6 of the largest gradient.
+    # A third kind shows up at B = 4 x T = 321: NEARLY cancelling sums - the sub-pixel conv bias (two sub-pixel biases per
+    # channel, of which the InstanceNorm behind the pixel shuffle removes the mean) and the dense block's last norm bias in
+    # the mask decoder, maxima 6e-4 of the largest gradient - whose fp32 column sums over 4 x 321 x 202 positions differ
+    # between any two summation orders by 1e-4 of that small maximum (the oracle's own fp32 autograd is 6.5e-5 from its
+    # fp64 one on it at B = 2): a tensor whose error is below the bar only in ABSOLUTE terms (1e-6 of the largest
+    # gradient, the zero-gradient floor) passes if it is also within 1e-2 of its own maximum.
     FLOOR = 1e-6
-    rel, small = [], []
+    rel, small, cancel = [], [], []
     for k, w in want["grads"].items():
         d, mx = float((gen.grads[k].cpu() - w).abs().max()), float(w.abs().max())
-        (rel if mx >= FLOOR * scale else small).append((d / max(mx, FLOOR * scale), k))
+        if mx < FLOOR * scale:
+            small.append((d / (FLOOR * scale), k))
+        elif d / mx >= bar and d < FLOOR * scale and d / mx < 1e-2:
+            cancel.append((d / mx, k))
+        else:
+            rel.append((d / mx, k))
     rel.sort(reverse=True)
     small.sort(reverse=True)
     for e, k in rel[:3]:
         _report(f"{tag}: {k}", e)
+    for e, k in cancel:
+        _report(f"{tag}: {k} (cancelling sum, absolute error below 1e-6 of the largest gradient)", e)
+    assert len(cancel) <= 4, cancel
     _report(f"{tag}: worst of {len(rel)} gradient tensors, each relative to its own max", rel[0][0])
     if small:
         _report(f"{tag}: worst of {len(small)} zero-gradient tensors, absolute error in units of 1e-6 of the largest "
