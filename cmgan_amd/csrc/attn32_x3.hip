@@ -844,7 +844,7 @@ __device__ __forceinline__ void asp_reference(const AspCtx& c, f32x16 (&s)[2], i
 // chunk of its tile), Q tile itn's - requested BEFORE K and V, so that the next body's first wait (for E and Q) leaves
 // the K / V fetches in flight.
 // HOTMX: also returns the maximum of sn over this lane's query (both units are full chunks of one tile then).
-template <int NF, int NB, bool HOTMX, bool CLAMP, bool LASTQ>
+template <int NF, int NB, bool HOTMX, bool CLAMP, bool LASTQ, bool ESHARE = false>
 __device__ __forceinline__ float asp_fused(const AspCtx& c, int i0n, int nn, int vn, int itn, f16x8& qh,
                                            f16x8& ql, f16x8 (&eh)[3], f16x8 (&el)[3], f16x8 (&kh)[2], f16x8 (&kl)[2],
                                            f16x8 (&va)[4], const f32x16& negm_n, f32x16 (&s)[2], f32x16 (&sn)[2],
@@ -859,7 +859,7 @@ __device__ __forceinline__ float asp_fused(const AspCtx& c, int i0n, int nn, int
     {
         f32x16 r;
         if (ASP_ABL != 2 && ASP_ABL != 10) r = asp_eq(eh[0], el[0], qh, ql, negm_n);
-        if (ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, i0n, nn, 0, eh[0], el[0]);
+        if (!ESHARE && ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, i0n, nn, 0, eh[0], el[0]);
         asp_exp8(s, 0, psum, ph[0], pl[0]);
         if (ASP_ABL == 8) racc = r; else if (ASP_ABL != 2 && ASP_ABL != 10) asp_wwrite(c, 0, r);
     }
@@ -881,6 +881,7 @@ __device__ __forceinline__ float asp_fused(const AspCtx& c, int i0n, int nn, int
     {
         f32x16 r;
         if (NF == 2 && ASP_ABL != 2 && ASP_ABL != 10) r = asp_eq(eh[2], el[2], qh, ql, negm_n);
+        if (ESHARE) { eh[0] = eh[2]; el[0] = el[2]; }   // window tile 2 of this chunk IS tile 0 of the next chunk of the tile
         if (ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, i0n, nn, 2, eh[2], el[2]);
         asp_pv(o, va[1], ph[1], pl[1]);
         if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[1] = asp_load_v(c, vn, 1);
@@ -1007,14 +1008,14 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
             f32x16 sn[2];
             do {
                 ASP_FMARK(0);                             // (stamp builds) everything outside the hot body
-                float mx = asp_fused<2, 2, true, CLAMP, false>(c, i0, ch + 2, ch + 1, 0, qh, ql, eh, el, kh, kl, va, negm, s, sn,
+                float mx = asp_fused<2, 2, true, CLAMP, false, true>(c, i0, ch + 2, ch + 1, 0, qh, ql, eh, el, kh, kl, va, negm, s, sn,
                                                                st, o A32_STAMP_PASS);
                 st.run = fmaxf(st.run, mx);               // (harmless if the chunk is re-referenced below: max is idempotent)
                 drifted = __any(st.run > A32_HI || st.run < A32_LO);
                 ++ch;
                 if (!(ch < nch - 2) || drifted) { odd = true; break; }
                 ASP_FMARK(0);
-                mx = asp_fused<2, 2, true, CLAMP, false>(c, i0, ch + 2, ch + 1, 0, qh, ql, eh, el, kh, kl, va, negm, sn, s, st,
+                mx = asp_fused<2, 2, true, CLAMP, false, true>(c, i0, ch + 2, ch + 1, 0, qh, ql, eh, el, kh, kl, va, negm, sn, s, st,
                                                          o A32_STAMP_PASS);
                 st.run = fmaxf(st.run, mx);
                 drifted = __any(st.run > A32_HI || st.run < A32_LO);
@@ -1032,6 +1033,18 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
             asp_reference<NKTL, FULLL>(c, sn, 64 * nfull, st, o, negm);
             s[0] = sn[0]; s[1] = sn[1];
         }
+        // residual rows + bias of this wave's output block (epilogue operands): requested BEFORE the tile's last body, whose
+        // ~3 k cycles cover their latency (12 VGPRs; the to_out image, 16 more, is fetched after the body: it is L1-hot)
+        // (the clamped-table variants have no registers to spare for it: they fetch after the body)
+        unsigned xo[2];
+        f32x4 xold[2], bias;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int l = i0 + 16 * i + c16;
+            xo[i] = (unsigned)(l < L ? l : L - 1) * xstride + xlane;
+            if (!CLAMP) xold[i] = *reinterpret_cast<const f32x4*>(xbase + xo[i]);
+        }
+        if (!CLAMP) bias = ldg4(bo + 16 * wv + 4 * g16);
         // s = the referenced scores of the tile's last chunk.  Its back half runs under the front half of the next
         // tile's chunk 0 (reference level 0), or alone for the block's last tile.
         f32x16 sn[2];
@@ -1046,15 +1059,11 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
         }
         ASP_CMARK(1);                                     // the tile's units
         // ---- epilogue of the tile: O / l -> stash -> barrier -> to_out + bias + residual ----
-        unsigned xo[2];
-        f32x4 xold[2];
+        if (CLAMP) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int l = i0 + 16 * i + c16;
-            xo[i] = (unsigned)(l < L ? l : L - 1) * xstride + xlane;
-            xold[i] = *reinterpret_cast<const f32x4*>(xbase + xo[i]);
+            for (int i = 0; i < 2; ++i) xold[i] = *reinterpret_cast<const f32x4*>(xbase + xo[i]);
+            bias = ldg4(bo + 16 * wv + 4 * g16);
         }
-        const f32x4 bias = ldg4(bo + 16 * wv + 4 * g16);
         const f16x8 ah0 = *reinterpret_cast<const f16x8*>(wp), al0 = *reinterpret_cast<const f16x8*>(wp + 512);
         const f16x8 ah1 = *reinterpret_cast<const f16x8*>(wp + 1024), al1 = *reinterpret_cast<const f16x8*>(wp + 1536);
         const float inv = __builtin_amdgcn_rcpf(red_h_sum(st.l));

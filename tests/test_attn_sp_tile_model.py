@@ -72,12 +72,17 @@ class Wave:
             sn.append(x)
         return sn
 
-    def front(self, nkt, negm, i0n, nn, lastq, itn):
-        """E q - m, window, K q; then the E / K (/ Q) registers are refilled for unit (i0n, nn)."""
+    def front(self, nkt, negm, i0n, nn, lastq, itn, eshare=False):
+        """E q - m, window, K q; then the E / K (/ Q) registers are refilled for unit (i0n, nn).  eshare (hot loop): the
+        next unit is the next chunk of the same tile, whose window tile 0 is this unit's tile 2 - copied, not fetched."""
         self.R[:] = np.nan
         for t in range(nkt + 1):
             self.wwrite(t, self.eq(self.eh[t], self.el[t], np.repeat(negm[:, None], 16, 1)))
-        for t in range(3):
+        if eshare:
+            want = self.load_e(i0n, nn, 0)
+            assert np.array_equal(want[0], self.eh[2]) and np.array_equal(want[1], self.el[2])
+            self.eh[0], self.el[0] = self.eh[2], self.el[2]
+        for t in range(1 if eshare else 0, 3):
             self.eh[t], self.el[t] = self.load_e(i0n, nn, t)
         sn = self.wread(nkt)
         sn = [self.eq(self.kh[jt], self.kl[jt], sn[jt]) for jt in range(nkt)]
@@ -156,7 +161,7 @@ class Wave:
                 self.reference(nktl, fulll, s, 0)
             ch = 0
             while ch < nch - 2:                                   # hot loop (+ reference outside on drift)
-                sn = self.front(2, -self.m, i0, ch + 2, False, 0)
+                sn = self.front(2, -self.m, i0, ch + 2, False, 0, eshare=True)
                 self.back(2, s, ch + 1)
                 s = sn
                 ch += 1
