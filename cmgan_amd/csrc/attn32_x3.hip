@@ -766,8 +766,9 @@ __device__ __forceinline__ void asp_front(const AspCtx& c, int i0n, int nn, int 
         asp_wwrite(c, t, r);
         ASP_SB();
     }
+    if (!LASTQ) { eh[0] = eh[2]; el[0] = el[2]; }        // the next unit is chunk 1 of this tile: its tile 0 = this tile 2
 #pragma unroll
-    for (int t = 0; t < 3; ++t) asp_load_e<CLAMP>(c, i0n, nn, t, eh[t], el[t]);
+    for (int t = LASTQ ? 0 : 1; t < 3; ++t) asp_load_e<CLAMP>(c, i0n, nn, t, eh[t], el[t]);
     wave_lds_fence();
     asp_wread<NKT>(c, sn);
     wave_lds_fence();                                    // the next front half's window writes come after these reads
@@ -1053,7 +1054,7 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
             const f32x16 zero = zero16();
             const int i0n = nlast ? i0 + 64 : i0 + 32, nn = nlast ? 0 : 1;
             if (nlast) asp_fused<NKTL, NKTL, false, CLAMP, true>(c, i0n, nn, 0, it + 2, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
-            else asp_fused<2, NKTL, false, CLAMP, false>(c, i0n, nn, 0, 0, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
+            else asp_fused<2, NKTL, false, CLAMP, false, true>(c, i0n, nn, 0, 0, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
         } else {
             asp_back<NKTL>(s, st, o, va);
         }

@@ -151,7 +151,7 @@ class Wave:
         if nch == 1:
             s = self.front(nktl, -self.m, i0 + 32, 0, True, it0 + 1)
         else:
-            s = self.front(2, -self.m, i0, 1, False, 0)
+            s = self.front(2, -self.m, i0, 1, False, 0, eshare=True)
         out = {}
         for it in range(it0, it1):
             i0 = 32 * it
@@ -177,7 +177,7 @@ class Wave:
                 if nlast:
                     sn = self.front(nktl, zero, i0 + 64, 0, True, it + 2)
                 else:
-                    sn = self.front(2, zero, i0 + 32, 1, False, 0)
+                    sn = self.front(2, zero, i0 + 32, 1, False, 0, eshare=True)
                 self.back(nktl, s, 0)
             else:
                 sn = None
