@@ -431,7 +431,10 @@ __device__ __forceinline__ void a32_chunk(const A32Ctx& c, int n, int i0n, int n
 #define A32_TPB 4
 #endif
 #ifndef A32_TPB_SHORT
-#define A32_TPB_SHORT 4        // tiles per block for sequences of at most 4 tiles (the frequency axis: L = 101)
+#define A32_TPB_SHORT 16       // least tiles per block for sequences of at most 4 tiles (the frequency axis, L = 101)
+#endif
+#ifndef A32_SLOTS_PER_GPU
+#define A32_SLOTS_PER_GPU 512   // resident blocks: 256 CUs x 2 (66 KB of LDS, 256 VGPRs)
 #endif
 template <bool MASK>
 __global__ __launch_bounds__(256, MASK ? 1 : A32_OCC) void attn32_out_x3_kernel(const _Float16* __restrict__ qimg,
@@ -688,22 +691,28 @@ __device__ __forceinline__ void asp_load_e(const AspCtx& c, int i0, int n, int t
         el = buf_h8(c.er, c.evoff, so + c.eplane2);
     }
 }
-__device__ __forceinline__ void asp_load_k(const AspCtx& c, int n, int jt, f16x8& kh, f16x8& kl) {
+// so = byte offset of the unit's (sequence, head) images relative to the block's first sequence (AspTile)
+__device__ __forceinline__ void asp_load_k(const AspCtx& c, unsigned so, int n, int jt, f16x8& kh, f16x8& kl) {
     int kt = 2 * n + jt;
     kt = kt < c.Lt ? kt : c.Lt - 1;
-    kh = buf_h8(c.kr, c.lane16, (unsigned)kt * 2048u);
-    kl = buf_h8(c.kr, c.lane16 + 1024u, (unsigned)kt * 2048u);
+    kh = buf_h8(c.kr, c.lane16, so + (unsigned)kt * 2048u);
+    kl = buf_h8(c.kr, c.lane16 + 1024u, so + (unsigned)kt * 2048u);
 }
-__device__ __forceinline__ f16x8 asp_load_v(const AspCtx& c, int n, int grp4) {
+__device__ __forceinline__ f16x8 asp_load_v(const AspCtx& c, unsigned so, int n, int grp4) {
     int gr = 4 * n + grp4;
     gr = gr < 2 * c.Lt ? gr : 2 * c.Lt - 1;
-    return buf_h8(c.vr, c.lane16, (unsigned)gr * 1024u);
+    return buf_h8(c.vr, c.lane16, so + (unsigned)gr * 1024u);
 }
-__device__ __forceinline__ void asp_load_q(const AspCtx& c, int it, f16x8& qh, f16x8& ql) {
+__device__ __forceinline__ void asp_load_q(const AspCtx& c, unsigned so, int it, f16x8& qh, f16x8& ql) {
     it = it < c.Lt ? it : c.Lt - 1;
-    qh = buf_h8(c.qr, c.lane16, (unsigned)it * 2048u);
-    ql = buf_h8(c.qr, c.lane16 + 1024u, (unsigned)it * 2048u);
+    qh = buf_h8(c.qr, c.lane16, so + (unsigned)it * 2048u);
+    ql = buf_h8(c.qr, c.lane16 + 1024u, so + (unsigned)it * 2048u);
 }
+// a query tile of the block's stream: tile `it` of the sequence whose images start `so` bytes after the block's first
+struct AspTile {
+    unsigned so;
+    int it;
+};
 
 // ---- pieces of the two halves ----
 __device__ __forceinline__ f32x16 asp_eq(const f16x8& eh, const f16x8& el, const f16x8& qh, const f16x8& ql,
@@ -755,9 +764,9 @@ __device__ __forceinline__ void asp_pv(f32x16& o, const f16x8& va, const f16x8& 
 }
 
 // Front half alone (the block's first unit): R = E q - m for the NKT + 1 window tiles, window write, skewed read,
-// K q on top; then E, K are refilled with the operands of unit (i0n, nn) and, if lastq, Q with tile itn's.
+// K q on top; then E, K are refilled with the operands of chunk nn of tile tn and, if LASTQ, Q with tile tn's.
 template <int NKT, bool CLAMP, bool LASTQ>
-__device__ __forceinline__ void asp_front(const AspCtx& c, int i0n, int nn, int itn, f16x8& qh, f16x8& ql,
+__device__ __forceinline__ void asp_front(const AspCtx& c, AspTile tn, int nn, f16x8& qh, f16x8& ql,
                                           f16x8 (&eh)[3], f16x8 (&el)[3], f16x8 (&kh)[2], f16x8 (&kl)[2],
                                           const f32x16& negm, f32x16 (&sn)[2]) {
 #pragma unroll
@@ -768,15 +777,15 @@ __device__ __forceinline__ void asp_front(const AspCtx& c, int i0n, int nn, int 
     }
     if (!LASTQ) { eh[0] = eh[2]; el[0] = el[2]; }        // the next unit is chunk 1 of this tile: its tile 0 = this tile 2
 #pragma unroll
-    for (int t = LASTQ ? 0 : 1; t < 3; ++t) asp_load_e<CLAMP>(c, i0n, nn, t, eh[t], el[t]);
+    for (int t = LASTQ ? 0 : 1; t < 3; ++t) asp_load_e<CLAMP>(c, 32 * tn.it, nn, t, eh[t], el[t]);
     wave_lds_fence();
     asp_wread<NKT>(c, sn);
     wave_lds_fence();                                    // the next front half's window writes come after these reads
 #pragma unroll
     for (int jt = 0; jt < NKT; ++jt) sn[jt] = asp_eq(kh[jt], kl[jt], qh, ql, sn[jt]);
-    if (LASTQ) asp_load_q(c, itn, qh, ql);
+    if (LASTQ) asp_load_q(c, tn.so, tn.it, qh, ql);
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) asp_load_k(c, nn, jt, kh[jt], kl[jt]);
+    for (int jt = 0; jt < 2; ++jt) asp_load_k(c, tn.so, nn, jt, kh[jt], kl[jt]);
     // (single-chunk sequences only) nothing is left pending here: a Q fetch that MAY be in flight at the hot loop's
     // header makes the compiler's s_waitcnt pass wait for vmcnt(0) at the top of every chunk
     if (LASTQ) __builtin_amdgcn_s_waitcnt(0x0f70);
@@ -841,12 +850,12 @@ __device__ __forceinline__ void asp_reference(const AspCtx& c, f32x16 (&s)[2], i
 
 // The loop body: back half of unit u (scores s, NB key tiles, accumulating into st / o with V operands va) under the
 // front half of unit u + 1 (NF key tiles, reference splat negm_n, scores out in sn).  Afterwards E / K hold the
-// operands of unit (i0n, nn) (= u + 2), V those of chunk vn (= unit u + 1's), and, if LASTQ (unit u + 1 is the last
-// chunk of its tile), Q tile itn's - requested BEFORE K and V, so that the next body's first wait (for E and Q) leaves
-// the K / V fetches in flight.
+// operands of chunk nn of tile tn (= unit u + 2), V those of chunk vn of tile tv (= unit u + 1), and, if LASTQ (unit
+// u + 1 is the last chunk of its tile), Q tile tn's.  Tiles may belong to different sequences (AspTile::so).  Every
+// register is refilled in the slot of its last use - a whole body before its next one.
 // HOTMX: also returns the maximum of sn over this lane's query (both units are full chunks of one tile then).
 template <int NF, int NB, bool HOTMX, bool CLAMP, bool LASTQ, bool ESHARE = false>
-__device__ __forceinline__ float asp_fused(const AspCtx& c, int i0n, int nn, int vn, int itn, f16x8& qh,
+__device__ __forceinline__ float asp_fused(const AspCtx& c, AspTile tn, int nn, AspTile tv, int vn, f16x8& qh,
                                            f16x8& ql, f16x8 (&eh)[3], f16x8 (&el)[3], f16x8 (&kh)[2], f16x8 (&kl)[2],
                                            f16x8 (&va)[4], const f32x16& negm_n, f32x16 (&s)[2], f32x16 (&sn)[2],
                                            A32State& st, f32x16& o A32_STAMP_ARG) {
@@ -860,7 +869,7 @@ __device__ __forceinline__ float asp_fused(const AspCtx& c, int i0n, int nn, int
     {
         f32x16 r;
         if (ASP_ABL != 2 && ASP_ABL != 10) r = asp_eq(eh[0], el[0], qh, ql, negm_n);
-        if (!ESHARE && ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, i0n, nn, 0, eh[0], el[0]);
+        if (!ESHARE && ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, 32 * tn.it, nn, 0, eh[0], el[0]);
         asp_exp8(s, 0, psum, ph[0], pl[0]);
         if (ASP_ABL == 8) racc = r; else if (ASP_ABL != 2 && ASP_ABL != 10) asp_wwrite(c, 0, r);
     }
@@ -870,9 +879,9 @@ __device__ __forceinline__ float asp_fused(const AspCtx& c, int i0n, int nn, int
     {
         f32x16 r;
         if (ASP_ABL != 2 && ASP_ABL != 10) r = asp_eq(eh[1], el[1], qh, ql, negm_n);
-        if (ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, i0n, nn, 1, eh[1], el[1]);
+        if (ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, 32 * tn.it, nn, 1, eh[1], el[1]);
         asp_pv(o, va[0], ph[0], pl[0]);
-        if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[0] = asp_load_v(c, vn, 0);
+        if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[0] = asp_load_v(c, tv.so, vn, 0);
         asp_exp8(s, 1, psum, ph[1], pl[1]);
         if (ASP_ABL == 8) { for (int v = 0; v < 16; ++v) racc[v] = fmaxf(racc[v], r[v]); } else if (ASP_ABL != 2 && ASP_ABL != 10) asp_wwrite(c, 1, r);
     }
@@ -883,9 +892,9 @@ __device__ __forceinline__ float asp_fused(const AspCtx& c, int i0n, int nn, int
         f32x16 r;
         if (NF == 2 && ASP_ABL != 2 && ASP_ABL != 10) r = asp_eq(eh[2], el[2], qh, ql, negm_n);
         if (ESHARE) { eh[0] = eh[2]; el[0] = el[2]; }   // window tile 2 of this chunk IS tile 0 of the next chunk of the tile
-        if (ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, i0n, nn, 2, eh[2], el[2]);
+        if (ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, 32 * tn.it, nn, 2, eh[2], el[2]);
         asp_pv(o, va[1], ph[1], pl[1]);
-        if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[1] = asp_load_v(c, vn, 1);
+        if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[1] = asp_load_v(c, tv.so, vn, 1);
         if (NB == 2) asp_exp8(s, 2, psum, ph[0], pl[0]);
         if (ASP_ABL == 8) sn[1] = r; else if (NF == 2 && ASP_ABL != 2 && ASP_ABL != 10) asp_wwrite(c, 2, r);
     }
@@ -898,7 +907,7 @@ __device__ __forceinline__ float asp_fused(const AspCtx& c, int i0n, int nn, int
     else { sn[0] = splat16(psum); sn[1] = splat16(psum); }
     wave_lds_fence();
     if (NB == 2) asp_pv(o, va[2], ph[0], pl[0]);
-    if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[2] = asp_load_v(c, vn, 2);
+    if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[2] = asp_load_v(c, tv.so, vn, 2);
     if (NB == 2) asp_exp8(s, 3, psum, ph[1], pl[1]);
     ASP_FMARK(4);
     ASP_SB();
@@ -906,16 +915,16 @@ __device__ __forceinline__ float asp_fused(const AspCtx& c, int i0n, int nn, int
 #pragma unroll
     for (int jt = 0; jt < NF; ++jt)
         if (ASP_ABL != 5 && ASP_ABL != 10) sn[jt] = asp_eq(kh[jt], kl[jt], qh, ql, sn[jt]);
-    if (LASTQ) asp_load_q(c, itn, qh, ql);
+    if (LASTQ) asp_load_q(c, tn.so, tn.it, qh, ql);
     if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) {
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt) asp_load_k(c, nn, jt, kh[jt], kl[jt]);
+        for (int jt = 0; jt < 2; ++jt) asp_load_k(c, tn.so, nn, jt, kh[jt], kl[jt]);
     }
     ASP_FMARK(5);
     ASP_SB();
     // slot 5: P V of group 3; V of the next unit | running maximum of the new scores
     if (NB == 2) asp_pv(o, va[3], ph[1], pl[1]);
-    if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[3] = asp_load_v(c, vn, 3);
+    if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[3] = asp_load_v(c, tv.so, vn, 3);
     st.l += psum;
     float mx = 0.f;
     if (HOTMX && ASP_ABL != 9) mx = asp_max<2, true>(c, sn, 0);
@@ -934,7 +943,7 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
                                                                 const _Float16* __restrict__ eimg, int max_pos,
                                                                 float* __restrict__ x, TokMap m,
                                                                 const _Float16* __restrict__ woi,
-                                                                const float* __restrict__ bo, int Lt, int tpb, int bps,
+                                                                const float* __restrict__ bo, int Lt, int tpb, int nseq,
                                                                 long nblocks) {
     __shared__ __attribute__((aligned(16))) float rbuf[4][ASP_RFL];
     __shared__ __attribute__((aligned(16))) f32x4 stash[2][4][2][64];      // [parity][head][16-token block][16x16 lane]
@@ -948,37 +957,55 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long lblk = XCD_ORDER ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
     if (lblk >= nblocks) return;                          // padding blocks of the rounded-up grid (block-uniform)
-    const int n = __builtin_amdgcn_readfirstlane((int)((unsigned)lblk / (unsigned)bps));
-    const int it0 = ((int)lblk - n * bps) * tpb, it1 = it0 + tpb < Lt ? it0 + tpb : Lt;
-    const long nh = (long)n * 4 + wv;                     // this wave's head
+    // The block walks tpb consecutive tiles of the FLATTENED (sequence, tile) space: G = n * Lt + it.  Its image
+    // descriptors start at the first sequence it touches (this wave's head) and every fetch carries the sequence's
+    // byte offset, so the unit stream runs on across sequence boundaries (the frequency axis has 4 tiles per sequence:
+    // 16 tiles = 4 sequences per block instead of a block, a cold prologue and a drain per sequence).
+    const int G0 = (int)lblk * tpb, GN = nseq * Lt;        // (the launcher keeps nseq * Lt below 2^31)
+    const int G1 = G0 + tpb < GN ? G0 + tpb : GN;
+    const int n0 = __builtin_amdgcn_readfirstlane((int)((unsigned)G0 / (unsigned)Lt));
+    const long nh0 = (long)n0 * 4 + wv;                   // this wave's head of the block's first sequence
     const int L = m.L;
     AspCtx c;
     c.a = lane & 31; c.hh = lane >> 5;
     c.Rw = rbuf[wv] + c.a * ASP_P + 4 * c.hh;
     c.Rr = rbuf[wv] + c.a * (ASP_P - 1) + 32 + 4 * c.hh;
     c.Lt = Lt; c.L = L; c.max_pos = max_pos; c.lpad = 32 * Lt;
-    c.kr = a32_rsrc(kimg + nh * Lt * 1024, (unsigned)Lt * 2048u);
-    c.vr = a32_rsrc(vimg + nh * Lt * 1024, (unsigned)Lt * 2048u);
+    const unsigned long left = ((unsigned long)nseq * 4 - (unsigned long)nh0) * Lt * 2048ul;    // bytes to the image's end
+    const unsigned span = left < 0xffffffc0ul ? (unsigned)left : 0xffffffc0u;
+    c.kr = a32_rsrc(kimg + nh0 * Lt * 1024, span);
+    c.vr = a32_rsrc(vimg + nh0 * Lt * 1024, span);
+    c.qr = a32_rsrc(qimg + nh0 * Lt * 1024, span);
     c.er = a32_rsrc(eimg, (unsigned)(2 * max_pos + 1) * 64u);
-    c.qr = a32_rsrc(qimg + nh * Lt * 1024, (unsigned)Lt * 2048u);
     c.lane16 = (unsigned)lane * 16u;
     c.eplane2 = (unsigned)(2 * max_pos + 1) * 32u;
     c.evoff = (unsigned)c.hh * (unsigned)(2 * max_pos + 1) * 16u;
     if (!CLAMP) c.evoff += (unsigned)(max_pos - 32 + c.a - c.lpad) * 16u;
     const int c16 = lane & 15, g16 = lane >> 4;
-    const int nq = __builtin_amdgcn_readfirstlane(n / m.inner);
-    char* xbase = reinterpret_cast<char*>(x + ((long)nq * m.outer + (long)(n - nq * m.inner) * m.istride) * 64 + 16 * wv);
+    const unsigned seq_bytes = (unsigned)Lt * 8192u;      // image bytes from one sequence to the next (4 heads)
     const unsigned xstride = (unsigned)m.lstride * 256u, xlane = (unsigned)g16 * 16u;
     const _Float16* wp = woi + wv * 2048 + lane * 8;      // this wave's output block of the to_out image (global)
+    // tile G of the stream (clamped to the last tile of the last sequence for prefetches past the end)
+    auto tile_of = [&](int G) -> AspTile {
+        G = G < GN ? G : GN - 1;
+        const int n = __builtin_amdgcn_readfirstlane((int)((unsigned)G / (unsigned)Lt));
+        AspTile t;
+        t.it = G - n * Lt;
+        t.so = (unsigned)(n - n0) * seq_bytes;
+        return t;
+    };
 
     f16x8 qh, ql, eh[3], el[3], kh[2], kl[2], va[4];
-    asp_load_q(c, it0, qh, ql);
+    {
+        const AspTile t0 = tile_of(G0);
+        asp_load_q(c, t0.so, t0.it, qh, ql);
 #pragma unroll
-    for (int t = 0; t < 3; ++t) asp_load_e<CLAMP>(c, 32 * it0, 0, t, eh[t], el[t]);
+        for (int t = 0; t < 3; ++t) asp_load_e<CLAMP>(c, 32 * t0.it, 0, t, eh[t], el[t]);
 #pragma unroll
-    for (int jt = 0; jt < 2; ++jt) asp_load_k(c, 0, jt, kh[jt], kl[jt]);
+        for (int jt = 0; jt < 2; ++jt) asp_load_k(c, t0.so, 0, jt, kh[jt], kl[jt]);
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) va[g4] = asp_load_v(c, 0, g4);
+        for (int g4 = 0; g4 < 4; ++g4) va[g4] = asp_load_v(c, t0.so, 0, g4);
+    }
     const int nfull = L >> 6, tail = L & 63;
     const int nch = nfull + (tail ? 1 : 0);               // chunks of a query tile; the last one is the tail chunk if tail
 
@@ -987,17 +1014,17 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
     f32x16 o = zero16(), negm = zero16();
     f32x16 s[2];
     // the block's first unit: front half alone
-    {
-        const bool last = nch == 1;
-        const int i0 = 32 * it0;
-        if (last) asp_front<NKTL, CLAMP, true>(c, i0 + 32, 0, it0 + 1, qh, ql, eh, el, kh, kl, negm, s);
-        else asp_front<2, CLAMP, false>(c, i0, 1, 0, qh, ql, eh, el, kh, kl, negm, s);
-    }
+    if (nch == 1) asp_front<NKTL, CLAMP, true>(c, tile_of(G0 + 1), 0, qh, ql, eh, el, kh, kl, negm, s);
+    else asp_front<2, CLAMP, false>(c, tile_of(G0), 1, qh, ql, eh, el, kh, kl, negm, s);
 
     ASP_CMARK(0);                                         // prologue + the block's first front half
 #pragma unroll 1
-    for (int it = it0; it < it1; ++it) {
-        const int i0 = 32 * it;
+    for (int G = G0; G < G1; ++G) {
+        const AspTile tc = tile_of(G), t1 = tile_of(G + 1);      // this tile, the next one (maybe of the next sequence)
+        const int i0 = 32 * tc.it;
+        const int n = n0 + (int)(tc.so / seq_bytes);
+        const int nq = __builtin_amdgcn_readfirstlane(n / m.inner);
+        char* xbase = reinterpret_cast<char*>(x + ((long)nq * m.outer + (long)(n - nq * m.inner) * m.istride) * 64 + 16 * wv);
         // reference step of the tile's chunk 0 (its front half ran under the previous tile's last back half)
         if (nch > 1) asp_reference<2, true>(c, s, 0, st, o, negm);
         else asp_reference<NKTL, FULLL>(c, s, 0, st, o, negm);
@@ -1009,14 +1036,14 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
             f32x16 sn[2];
             do {
                 ASP_FMARK(0);                             // (stamp builds) everything outside the hot body
-                float mx = asp_fused<2, 2, true, CLAMP, false, true>(c, i0, ch + 2, ch + 1, 0, qh, ql, eh, el, kh, kl, va, negm, s, sn,
+                float mx = asp_fused<2, 2, true, CLAMP, false, true>(c, tc, ch + 2, tc, ch + 1, qh, ql, eh, el, kh, kl, va, negm, s, sn,
                                                                st, o A32_STAMP_PASS);
                 st.run = fmaxf(st.run, mx);               // (harmless if the chunk is re-referenced below: max is idempotent)
                 drifted = __any(st.run > A32_HI || st.run < A32_LO);
                 ++ch;
                 if (!(ch < nch - 2) || drifted) { odd = true; break; }
                 ASP_FMARK(0);
-                mx = asp_fused<2, 2, true, CLAMP, false, true>(c, i0, ch + 2, ch + 1, 0, qh, ql, eh, el, kh, kl, va, negm, sn, s, st,
+                mx = asp_fused<2, 2, true, CLAMP, false, true>(c, tc, ch + 2, tc, ch + 1, qh, ql, eh, el, kh, kl, va, negm, sn, s, st,
                                                          o A32_STAMP_PASS);
                 st.run = fmaxf(st.run, mx);
                 drifted = __any(st.run > A32_HI || st.run < A32_LO);
@@ -1029,7 +1056,7 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
             // the tile's last chunk: its front half (new Q afterwards; E / K of the next tile's chunk 0) under the back
             // half of chunk nch - 2, then its reference step
             f32x16 sn[2];
-            asp_fused<NKTL, 2, false, CLAMP, true>(c, i0 + 32, 0, nch - 1, it + 1, qh, ql, eh, el, kh, kl, va, negm, s, sn,
+            asp_fused<NKTL, 2, false, CLAMP, true>(c, t1, 0, tc, nch - 1, qh, ql, eh, el, kh, kl, va, negm, s, sn,
                                                    st, o A32_STAMP_PASS);
             asp_reference<NKTL, FULLL>(c, sn, 64 * nfull, st, o, negm);
             s[0] = sn[0]; s[1] = sn[1];
@@ -1049,12 +1076,11 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
         // s = the referenced scores of the tile's last chunk.  Its back half runs under the front half of the next
         // tile's chunk 0 (reference level 0), or alone for the block's last tile.
         f32x16 sn[2];
-        if (it + 1 < it1) {
-            const bool nlast = nch == 1;                  // the next tile's chunk 0 is also its last chunk
+        if (G + 1 < G1) {
             const f32x16 zero = zero16();
-            const int i0n = nlast ? i0 + 64 : i0 + 32, nn = nlast ? 0 : 1;
-            if (nlast) asp_fused<NKTL, NKTL, false, CLAMP, true>(c, i0n, nn, 0, it + 2, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
-            else asp_fused<2, NKTL, false, CLAMP, false, true>(c, i0n, nn, 0, 0, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
+            // (single-chunk sequences: the next tile's chunk 0 is also its last chunk, the unit after it is tile G + 2's)
+            if (nch == 1) asp_fused<NKTL, NKTL, false, CLAMP, true>(c, tile_of(G + 2), 0, t1, 0, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
+            else asp_fused<2, NKTL, false, CLAMP, false, true>(c, t1, 1, t1, 0, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
         } else {
             asp_back<NKTL>(s, st, o, va);
         }
@@ -1074,7 +1100,7 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
             oa[r] = (o[r] + o[8 + r]) * inv;
             ob[r] = (o[4 + r] + o[12 + r]) * inv;
         }
-        const int par = (it - it0) & 1;
+        const int par = (G - G0) & 1;
         stash[par][wv][c.a >> 4][c.hh * 16 + (c.a & 15)] = oa;
         stash[par][wv][c.a >> 4][(2 + c.hh) * 16 + (c.a & 15)] = ob;
         st.m = 0.f; st.run = -INFINITY; st.l = 0.f;       // the next tile starts from scratch
@@ -1154,16 +1180,22 @@ void launch_attn_sp_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* 
                            const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
                            const float* bo) {
     const int N = seq.nblocks / seq.Lb, Lt = (seq.L + 31) / 32;
-    const int tpb_max = Lt <= 4 ? A32_TPB_SHORT : A32_TPB;
-    const int bps = (Lt + tpb_max - 1) / tpb_max;
-    const int tpb = (Lt + bps - 1) / bps;
-    const long nb = (long)N * bps;
+    // tiles per block of the flattened (sequence, tile) stream.  Long sequences: A32_TPB (their K / V working set wants
+    // several blocks per sequence in flight).  Short ones (the frequency axis): ONE round of
+    // persistent blocks - 256 CUs x 2 blocks each take an equal share of the stream, so there is one cold prologue per
+    // block slot and no partly filled last round (2568 blocks of 16 tiles were 5.02 rounds).
+    int tpb = A32_TPB;
+    if (Lt <= 4) {
+        const long share = ((long)N * Lt + A32_SLOTS_PER_GPU - 1) / A32_SLOTS_PER_GPU;
+        tpb = share > A32_TPB_SHORT ? (int)share : A32_TPB_SHORT;
+    }
+    const long nb = ((long)N * Lt + tpb - 1) / tpb;
     const unsigned grid = XCD_ORDER ? (unsigned)(((nb + 7) / 8) * 8) : (unsigned)nb;
     const int tail = seq.L & 63;
     const bool clamp = seq.L + 96 > max_pos;
 #define ASP_LAUNCH(CL, NK, FU)                                                                                    \
     LAUNCH(ctx, "attn_out", (attn_sp_out_x3_kernel<CL, NK, FU><<<grid, 256, 0, ctx.stream>>>(                     \
-                                qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, bps, nb)))
+                                qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, N, nb)))
     if (!clamp) {
         if (tail == 0) ASP_LAUNCH(false, 2, true);
         else if (tail > 32) ASP_LAUNCH(false, 2, false);

@@ -16,8 +16,10 @@ HI, LO = 12.0, -4.0
 
 
 class Wave:
-    def __init__(self, qimg, kimg, vimg, rel, max_pos, L, clamp):
-        self.qimg, self.kimg, self.vimg = qimg, kimg, vimg
+    """One wave = one head.  `seqs` = [(qimg, kimg, vimg)] of the consecutive sequences the block's stream may touch."""
+
+    def __init__(self, seqs, rel, max_pos, L, clamp):
+        self.seqs = seqs
         self.rel_hi, self.rel_lo = f16split(rel)
         self.max_pos, self.L, self.Lt, self.clamp = max_pos, L, (L + 31) // 32, clamp
         self.lpad = 32 * self.Lt
@@ -42,16 +44,21 @@ class Wave:
         el = np.stack([self.rel_lo[r, 8 * HH + e] for e in range(8)], 1)
         return eh, el
 
-    def load_k(self, n, jt):
+    def load_k(self, sq, n, jt):
         kt = min(2 * n + jt, self.Lt - 1)
-        return self.kimg[kt, 0], self.kimg[kt, 1]
+        return self.seqs[sq][1][kt, 0], self.seqs[sq][1][kt, 1]
 
-    def load_v(self, n, g4):
-        return self.vimg[min(4 * n + g4, 2 * self.Lt - 1)]
+    def load_v(self, sq, n, g4):
+        return self.seqs[sq][2][min(4 * n + g4, 2 * self.Lt - 1)]
 
-    def load_q(self, it):
+    def load_q(self, sq, it):
         it = min(it, self.Lt - 1)
-        return self.qimg[it, 0], self.qimg[it, 1]
+        return self.seqs[sq][0][it, 0], self.seqs[sq][0][it, 1]
+
+    def tile_of(self, G):
+        """(sequence, tile) of flattened tile G, clamped to the last tile of the last sequence (AspTile)."""
+        G = min(G, len(self.seqs) * self.Lt - 1)
+        return G // self.Lt, G % self.Lt
 
     # ---- pieces ----
     def eq(self, ah, al, acc):
@@ -72,27 +79,28 @@ class Wave:
             sn.append(x)
         return sn
 
-    def front(self, nkt, negm, i0n, nn, lastq, itn, eshare=False):
-        """E q - m, window, K q; then the E / K (/ Q) registers are refilled for unit (i0n, nn).  eshare (hot loop): the
-        next unit is the next chunk of the same tile, whose window tile 0 is this unit's tile 2 - copied, not fetched."""
+    def front(self, nkt, negm, tn, nn, lastq, eshare=False):
+        """E q - m, window, K q; then the E / K (/ Q) registers are refilled for chunk nn of tile tn = (sequence, tile).
+        eshare: that unit is the next chunk of the same tile, whose window tile 0 is this unit's tile 2 - copied."""
+        sq, it = tn
         self.R[:] = np.nan
         for t in range(nkt + 1):
             self.wwrite(t, self.eq(self.eh[t], self.el[t], np.repeat(negm[:, None], 16, 1)))
         if eshare:
-            want = self.load_e(i0n, nn, 0)
+            want = self.load_e(32 * it, nn, 0)
             assert np.array_equal(want[0], self.eh[2]) and np.array_equal(want[1], self.el[2])
             self.eh[0], self.el[0] = self.eh[2], self.el[2]
         for t in range(1 if eshare else 0, 3):
-            self.eh[t], self.el[t] = self.load_e(i0n, nn, t)
+            self.eh[t], self.el[t] = self.load_e(32 * it, nn, t)
         sn = self.wread(nkt)
         sn = [self.eq(self.kh[jt], self.kl[jt], sn[jt]) for jt in range(nkt)]
         if lastq:
-            self.qh, self.ql = self.load_q(itn)
+            self.qh, self.ql = self.load_q(sq, it)
         for jt in range(2):
-            self.kh[jt], self.kl[jt] = self.load_k(nn, jt)
+            self.kh[jt], self.kl[jt] = self.load_k(sq, nn, jt)
         return sn
 
-    def back(self, nkt, s, vn):
+    def back(self, nkt, s, tv, vn):
         psum = np.zeros(64)
         for g in range(2 * nkt):
             p = np.exp2(s[g >> 1][:, 8 * (g & 1):8 * (g & 1) + 8])
@@ -103,7 +111,7 @@ class Wave:
         self.l += psum
         if vn is not None:
             for g4 in range(4):
-                self.va[g4] = self.load_v(vn, g4)
+                self.va[g4] = self.load_v(tv[0], vn, g4)
 
     def reference(self, nkt, full, s, j0):
         mx = np.full(64, -np.inf)
@@ -131,57 +139,56 @@ class Wave:
         self.m, self.run, self.l = np.zeros(64), np.full(64, -np.inf), np.zeros(64)
         self.o = np.zeros((64, 16))
 
-    def run_block(self, it0, it1):
-        """attn_sp_out_x3_kernel for one wave over query tiles it0 .. it1 - 1; returns {tile: stash dict}."""
+    def run_block(self, G0, G1):
+        """attn_sp_out_x3_kernel for one wave over the flattened tiles G0 .. G1 - 1; returns {G: stash dict}."""
         L = self.L
         nfull, tail = L >> 6, L & 63
         nch = nfull + (1 if tail else 0)
         nktl = 1 if (tail and tail <= 32) else 2
         fulll = tail == 0
-        self.qh, self.ql = self.load_q(it0)
+        t0 = self.tile_of(G0)
+        self.qh, self.ql = self.load_q(*t0)
         self.eh, self.el, self.kh, self.kl, self.va = [None] * 3, [None] * 3, [None] * 2, [None] * 2, [None] * 4
         for t in range(3):
-            self.eh[t], self.el[t] = self.load_e(32 * it0, 0, t)
+            self.eh[t], self.el[t] = self.load_e(32 * t0[1], 0, t)
         for jt in range(2):
-            self.kh[jt], self.kl[jt] = self.load_k(0, jt)
+            self.kh[jt], self.kl[jt] = self.load_k(t0[0], 0, jt)
         for g4 in range(4):
-            self.va[g4] = self.load_v(0, g4)
+            self.va[g4] = self.load_v(t0[0], 0, g4)
         self.new_tile()
-        i0 = 32 * it0
         if nch == 1:
-            s = self.front(nktl, -self.m, i0 + 32, 0, True, it0 + 1)
+            s = self.front(nktl, -self.m, self.tile_of(G0 + 1), 0, True)
         else:
-            s = self.front(2, -self.m, i0, 1, False, 0, eshare=True)
+            s = self.front(2, -self.m, t0, 1, False, eshare=True)
         out = {}
-        for it in range(it0, it1):
-            i0 = 32 * it
+        for G in range(G0, G1):
+            tc, t1 = self.tile_of(G), self.tile_of(G + 1)
             if nch > 1:
                 self.reference(2, True, s, 0)
             else:
                 self.reference(nktl, fulll, s, 0)
             ch = 0
             while ch < nch - 2:                                   # hot loop (+ reference outside on drift)
-                sn = self.front(2, -self.m, i0, ch + 2, False, 0, eshare=True)
-                self.back(2, s, ch + 1)
+                sn = self.front(2, -self.m, tc, ch + 2, False, eshare=True)
+                self.back(2, s, tc, ch + 1)
                 s = sn
                 ch += 1
                 self.reference(2, True, s, 0)
             if ch < nch - 1:
-                sn = self.front(nktl, -self.m, i0 + 32, 0, True, it + 1)
-                self.back(2, s, nch - 1)
+                sn = self.front(nktl, -self.m, t1, 0, True)
+                self.back(2, s, tc, nch - 1)
                 self.reference(nktl, fulll, sn, 64 * nfull)
                 s = sn
-            if it + 1 < it1:
-                nlast = nch == 1
+            if G + 1 < G1:
                 zero = np.zeros(64)
-                if nlast:
-                    sn = self.front(nktl, zero, i0 + 64, 0, True, it + 2)
+                if nch == 1:
+                    sn = self.front(nktl, zero, self.tile_of(G + 2), 0, True)
                 else:
-                    sn = self.front(2, zero, i0 + 32, 1, False, 0, eshare=True)
-                self.back(nktl, s, 0)
+                    sn = self.front(2, zero, t1, 1, False, eshare=True)
+                self.back(nktl, s, t1, 0)
             else:
                 sn = None
-                self.back(nktl, s, None)
+                self.back(nktl, s, None, None)
             inv = 1.0 / (self.l + self.l[lane ^ 32])
             oa = np.stack([(self.o[:, r] + self.o[:, 8 + r]) * inv for r in range(4)], 1)
             ob = np.stack([(self.o[:, 4 + r] + self.o[:, 12 + r]) * inv for r in range(4)], 1)
@@ -190,7 +197,7 @@ class Wave:
                 i, cq = A[l] >> 4, A[l] & 15
                 stash[(i, HH[l] * 16 + cq)] = oa[l]
                 stash[(i, (2 + HH[l]) * 16 + cq)] = ob[l]
-            out[it] = stash
+            out[G] = stash
             self.new_tile()
             s = sn
         return out
@@ -208,43 +215,45 @@ def test_window_banks():
     assert ((A * P + 4 * HH) % 4 == 0).all()
 
 
-@pytest.mark.parametrize("L,max_pos,scale,tpb", [(101, 512, 1.0, 6), (321, 512, 1.0, 6), (65, 512, 1.0, 2),
-                                                 (33, 512, 1.0, 6), (64, 512, 1.0, 1), (128, 512, 1.0, 3),
-                                                 (200, 512, 1.0, 4), (70, 20, 1.0, 6), (96, 40, 6.0, 2),
-                                                 (321, 512, 5.0, 6), (600, 512, 1.0, 6)])
-def test_attn_sp_unit_stream(L, max_pos, scale, tpb):
-    """101 / 321: the model's lengths (no hot iteration / four of them; tail chunk of two key tiles / of one key);
-    64 / 128: no tail chunk; 33 / 64: single-chunk tiles (front halves under the previous tile's only back half);
-    70 / 96 / 600: distances beyond the table (clamped fetches); scale 5 / 6: re-reference inside and outside the hot
-    loop."""
+@pytest.mark.parametrize("L,max_pos,scale,tpb,nseq", [(101, 512, 1.0, 16, 5), (321, 512, 1.0, 4, 2), (65, 512, 1.0, 2, 3),
+                                                      (33, 512, 1.0, 6, 2), (64, 512, 1.0, 3, 4), (128, 512, 1.0, 3, 2),
+                                                      (200, 512, 1.0, 4, 2), (70, 20, 1.0, 6, 2), (96, 40, 6.0, 2, 2),
+                                                      (321, 512, 5.0, 4, 1), (600, 512, 1.0, 4, 1)])
+def test_attn_sp_unit_stream(L, max_pos, scale, tpb, nseq):
+    """Blocks of tpb consecutive tiles of the flattened (sequence, tile) space of nseq sequences (the stream crosses
+    sequence boundaries: other Q / K / V images, same distance table).  101 / 321: the model's lengths (no hot iteration
+    / four of them; tail chunk of two key tiles / of one key; 16 tiles = 4 sequences per block on the frequency axis);
+    64 / 128: no tail chunk; 33 / 64: single-chunk tiles (front halves under the previous tile's only back half, the
+    unit after it two tiles ahead); 70 / 96 / 600: distances beyond the table (clamped fetches); scale 5 / 6:
+    re-reference inside and outside the hot loop."""
     rng = np.random.default_rng(L + tpb)
-    q = rng.standard_normal((L, 16)) * scale
-    k = rng.standard_normal((L, 16))
-    v = rng.standard_normal((L, 16))
-    rel = rng.standard_normal((2 * max_pos + 1, 16)) * 0.5
     Lt = (L + 31) // 32
     i, j = np.arange(L)[:, None], np.arange(L)[None, :]
+    rel = rng.standard_normal((2 * max_pos + 1, 16)) * 0.5
     E = rel[np.clip(i - j, -max_pos, max_pos) + max_pos]
-    S = q @ k.T + np.einsum("id,ijd->ij", q, E)
-    Pm = np.exp2(S - S.max(1, keepdims=True))
-    o_ref = (Pm / Pm.sum(1, keepdims=True)) @ v
-
-    qimg, kimg, vimg = build_images(q, k, v, Lt)
+    seqs, refs = [], []
+    for _ in range(nseq):
+        q = rng.standard_normal((L, 16)) * scale
+        k = rng.standard_normal((L, 16))
+        v = rng.standard_normal((L, 16))
+        S = q @ k.T + np.einsum("id,ijd->ij", q, E)
+        Pm = np.exp2(S - S.max(1, keepdims=True))
+        refs.append((Pm / Pm.sum(1, keepdims=True)) @ v)
+        seqs.append(build_images(q, k, v, Lt))
     clamp = L + 96 > max_pos
-    bps = (Lt + tpb - 1) // tpb
-    tp = (Lt + bps - 1) // bps
+    GN = nseq * Lt
     logs = []
-    for b in range(bps):
-        w = Wave(qimg, kimg, vimg, rel, max_pos, L, clamp)
-        it0, it1 = b * tp, min(b * tp + tp, Lt)
-        out = w.run_block(it0, it1)
+    for G0 in range(0, GN, tpb):
+        w = Wave(seqs, rel, max_pos, L, clamp)
+        out = w.run_block(G0, min(G0 + tpb, GN))
         logs += w.log
-        for it, stash in out.items():
+        for G, stash in out.items():
+            sq, it = G // Lt, G % Lt
             for blk in range(2):
                 for l16 in range(64):
                     c, g = l16 & 15, l16 >> 4
                     tok = 32 * it + 16 * blk + c
                     if tok < L:
-                        np.testing.assert_allclose(stash[(blk, l16)], o_ref[tok, 4 * g:4 * g + 4], rtol=2e-5, atol=2e-5)
+                        np.testing.assert_allclose(stash[(blk, l16)], refs[sq][tok, 4 * g:4 * g + 4], rtol=2e-5, atol=2e-5)
     if scale > 1:
         assert "reref" in logs
