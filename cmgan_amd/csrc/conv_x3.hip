@@ -126,6 +126,23 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
         }                                                                                                \
     } while (0)
 
+// the stage's 24 KB weight image (L2-resident) goes global -> registers -> LDS.  CX_WEARLY = 1: the fetch is issued
+// BEFORE the barrier that ends the previous stage's MFMA phase (the MFMA operand registers are dead by then), so its
+// latency overlaps the barrier wait and the staging VALU instead of being waited for at the end of the staging phase.
+#ifndef CX_WEARLY
+#define CX_WEARLY 1
+#endif
+#define CX_WFETCH(S)                                                                                     \
+    do {                                                                                                 \
+        const int chunkf_ = (S) / NT, ktf_ = (S) - chunkf_ * NT;                                         \
+        const u32x4* wsrc_ = reinterpret_cast<const u32x4*>(w16) + ((long)chunkf_ * TAPS + ktf_ * 3) * (CB * 128); \
+        _Pragma("unroll") for (int i = 0; i < NW; ++i) wpre[i] = wsrc_[tid + NTHR * i];                   \
+    } while (0)
+#if CX_WEARLY
+#define CX_WFETCH_IN_WRITE(S)
+#else
+#define CX_WFETCH_IN_WRITE(S) CX_WFETCH(S);
+#endif
 // normalise + PReLU + fp16 hi/lo split of the prefetched stage S, written to this tile's LDS buffers.
 // PReLU(y) = y + (alpha - 1) min(y, 0): one v_min + half a packed FMA per value.
 // (the stage's 24 KB weight image is L2-resident: its loads are issued at the top and land while
@@ -133,9 +150,7 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
 #define CX_WRITE(S)                                                                                      \
     do {                                                                                                 \
         const int chunkw_ = (S) / NT, ktw_ = (S) - chunkw_ * NT;                                         \
-        const u32x4* wsrc_ = reinterpret_cast<const u32x4*>(w16) + ((long)chunkw_ * TAPS + ktw_ * 3) * (CB * 128); \
-        u32x4 wpre[NW];                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < NW; ++i) wpre[i] = wsrc_[tid + NTHR * i];                   \
+        CX_WFETCH_IN_WRITE(S)                                                                            \
         const unsigned inv_ = (NT == 2 && ktw_ == 0) ? inv0 : inv1;                                      \
         const int slotw_ = chunkw_ >> 1;                                                                 \
         if ((a.img_mask >> slotw_) & 1u) {              /* pre-split image slot (block-uniform): two LDS stores */ \
@@ -337,8 +352,12 @@ __global__ __launch_bounds__(64 * NWV) void conv3x_kernel(ConvArgs a, const _Flo
     CX_SETUP(true)
 
     CX_PREFETCH(0);
+    u32x4 wpre[NW];
 #pragma unroll 1
     for (int s = 0; s < nst; ++s) {
+#if CX_WEARLY
+        CX_WFETCH(s);                                     // in flight across the barrier and the staging VALU
+#endif
         __syncthreads();                                  // stage s-1 fully consumed
 #if CX_EARLY
         if (s + 1 < nst) CX_WRITE_PREFETCH(s, true);      // stage s+1's loads issued row group by row group
