@@ -436,6 +436,9 @@ __device__ __forceinline__ void a32_chunk(const A32Ctx& c, int n, int i0n, int n
 #ifndef A32_SLOTS_PER_GPU
 #define A32_SLOTS_PER_GPU 512   // resident blocks: 256 CUs x 2 (66 KB of LDS, 256 VGPRs)
 #endif
+#ifndef A32_GROUP
+#define A32_GROUP 64            // blocks resident together on one XCD (32 CUs x 2): their tiles interleave (see the kernel)
+#endif
 template <bool MASK>
 __global__ __launch_bounds__(256, MASK ? 1 : A32_OCC) void attn32_out_x3_kernel(const _Float16* __restrict__ qimg,
                                                                      const _Float16* __restrict__ kimg,
@@ -944,7 +947,7 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
                                                                 float* __restrict__ x, TokMap m,
                                                                 const _Float16* __restrict__ woi,
                                                                 const float* __restrict__ bo, int Lt, int tpb, int nseq,
-                                                                long nblocks) {
+                                                                int group) {
     __shared__ __attribute__((aligned(16))) float rbuf[4][ASP_RFL];
     __shared__ __attribute__((aligned(16))) f32x4 stash[2][4][2][64];      // [parity][head][16-token block][16x16 lane]
 #ifdef A32_STAMP
@@ -955,14 +958,24 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
     for (int i = 0; i < 16; ++i) sp.acc[i] = 0;
 #endif
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long lblk = XCD_ORDER ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
-    if (lblk >= nblocks) return;                          // padding blocks of the rounded-up grid (block-uniform)
-    // The block walks tpb consecutive tiles of the FLATTENED (sequence, tile) space: G = n * Lt + it.  Its image
-    // descriptors start at the first sequence it touches (this wave's head) and every fetch carries the sequence's
-    // byte offset, so the unit stream runs on across sequence boundaries (the frequency axis has 4 tiles per sequence:
-    // 16 tiles = 4 sequences per block instead of a block, a cold prologue and a drain per sequence).
-    const int G0 = (int)lblk * tpb, GN = nseq * Lt;        // (the launcher keeps nseq * Lt below 2^31)
-    const int G1 = G0 + tpb < GN ? G0 + tpb : GN;
+    // The block walks tpb tiles of the FLATTENED (sequence, tile) space: G = n * Lt + it.  Its image descriptors start
+    // at the first sequence it touches (this wave's head) and every fetch carries the sequence's byte offset, so the
+    // unit stream runs on across sequence boundaries.
+    // WHICH tiles: every XCD owns a contiguous range of the stream (its blocks' K / V meet in its own L2), and inside
+    // that range the blocks that are resident together - a group of `group` consecutive blocks, 32 CUs x ASP_OCC - take
+    // tiles that INTERLEAVE: block j of a group walks j, j + gs, j + 2 gs, ...  At any moment the group works on ~gs
+    // neighbouring tiles, i.e. on gs / Lt sequences (6 on the 321-frame axis, 16 on the 101-bin one: 1 - 1.5 MB of K / V
+    // in a 4 MB L2) instead of on gs * tpb / Lt of them (23 / 64 sequences = 4.1 - 4.2 MB, which missed half the time:
+    // DESIGN.md section 7e).  group = 1 is the plain consecutive order.
+    const int xcd = XCD_ORDER ? (int)(blockIdx.x & 7) : 0, li = XCD_ORDER ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int nbx = XCD_ORDER ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int grp = li / group, gleft = nbx - grp * group;
+    const int gs = gleft < group ? gleft : group;         // blocks of this group = its tile stride
+    const int GN = nseq * Lt;                             // (the launcher keeps nseq * Lt below 2^31)
+    const int G0 = (xcd * nbx + grp * group) * tpb + (li - grp * group);
+    if (G0 >= GN) return;                                 // the stream ended before this block (block-uniform)
+    const int nleft = (GN - 1 - G0) / gs + 1;
+    const int ntl = nleft < tpb ? nleft : tpb;            // this block's tiles: G0 + t * gs, t < ntl
     const int n0 = __builtin_amdgcn_readfirstlane((int)((unsigned)G0 / (unsigned)Lt));
     const long nh0 = (long)n0 * 4 + wv;                   // this wave's head of the block's first sequence
     const int L = m.L;
@@ -1014,13 +1027,14 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
     f32x16 o = zero16(), negm = zero16();
     f32x16 s[2];
     // the block's first unit: front half alone
-    if (nch == 1) asp_front<NKTL, CLAMP, true>(c, tile_of(G0 + 1), 0, qh, ql, eh, el, kh, kl, negm, s);
+    if (nch == 1) asp_front<NKTL, CLAMP, true>(c, tile_of(G0 + gs), 0, qh, ql, eh, el, kh, kl, negm, s);
     else asp_front<2, CLAMP, false>(c, tile_of(G0), 1, qh, ql, eh, el, kh, kl, negm, s);
 
     ASP_CMARK(0);                                         // prologue + the block's first front half
 #pragma unroll 1
-    for (int G = G0; G < G1; ++G) {
-        const AspTile tc = tile_of(G), t1 = tile_of(G + 1);      // this tile, the next one (maybe of the next sequence)
+    for (int tl = 0; tl < ntl; ++tl) {
+        const int G = G0 + tl * gs;
+        const AspTile tc = tile_of(G), t1 = tile_of(G + gs);     // this tile, the block's next one (maybe of another sequence)
         const int i0 = 32 * tc.it;
         const int n = n0 + (int)(tc.so / seq_bytes);
         const int nq = __builtin_amdgcn_readfirstlane(n / m.inner);
@@ -1076,10 +1090,10 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
         // s = the referenced scores of the tile's last chunk.  Its back half runs under the front half of the next
         // tile's chunk 0 (reference level 0), or alone for the block's last tile.
         f32x16 sn[2];
-        if (G + 1 < G1) {
+        if (tl + 1 < ntl) {
             const f32x16 zero = zero16();
             // (single-chunk sequences: the next tile's chunk 0 is also its last chunk, the unit after it is tile G + 2's)
-            if (nch == 1) asp_fused<NKTL, NKTL, false, CLAMP, true>(c, tile_of(G + 2), 0, t1, 0, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
+            if (nch == 1) asp_fused<NKTL, NKTL, false, CLAMP, true>(c, tile_of(G + 2 * gs), 0, t1, 0, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
             else asp_fused<2, NKTL, false, CLAMP, false, true>(c, t1, 1, t1, 0, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
         } else {
             asp_back<NKTL>(s, st, o, va);
@@ -1100,7 +1114,7 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
             oa[r] = (o[r] + o[8 + r]) * inv;
             ob[r] = (o[4 + r] + o[12 + r]) * inv;
         }
-        const int par = (G - G0) & 1;
+        const int par = tl & 1;
         stash[par][wv][c.a >> 4][c.hh * 16 + (c.a & 15)] = oa;
         stash[par][wv][c.a >> 4][(2 + c.hh) * 16 + (c.a & 15)] = ob;
         st.m = 0.f; st.run = -INFINITY; st.l = 0.f;       // the next tile starts from scratch
@@ -1195,7 +1209,7 @@ void launch_attn_sp_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* 
     const bool clamp = seq.L + 96 > max_pos;
 #define ASP_LAUNCH(CL, NK, FU)                                                                                    \
     LAUNCH(ctx, "attn_out", (attn_sp_out_x3_kernel<CL, NK, FU><<<grid, 256, 0, ctx.stream>>>(                     \
-                                qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, N, nb)))
+                                qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, N, A32_GROUP)))
     if (!clamp) {
         if (tail == 0) ASP_LAUNCH(false, 2, true);
         else if (tail > 32) ASP_LAUNCH(false, 2, false);

@@ -139,8 +139,8 @@ class Wave:
         self.m, self.run, self.l = np.zeros(64), np.full(64, -np.inf), np.zeros(64)
         self.o = np.zeros((64, 16))
 
-    def run_block(self, G0, G1):
-        """attn_sp_out_x3_kernel for one wave over the flattened tiles G0 .. G1 - 1; returns {G: stash dict}."""
+    def run_block(self, G0, ntl, gs=1):
+        """attn_sp_out_x3_kernel for one wave over the flattened tiles G0 + t * gs, t < ntl; returns {G: stash dict}."""
         L = self.L
         nfull, tail = L >> 6, L & 63
         nch = nfull + (1 if tail else 0)
@@ -157,12 +157,13 @@ class Wave:
             self.va[g4] = self.load_v(t0[0], 0, g4)
         self.new_tile()
         if nch == 1:
-            s = self.front(nktl, -self.m, self.tile_of(G0 + 1), 0, True)
+            s = self.front(nktl, -self.m, self.tile_of(G0 + gs), 0, True)
         else:
             s = self.front(2, -self.m, t0, 1, False, eshare=True)
         out = {}
-        for G in range(G0, G1):
-            tc, t1 = self.tile_of(G), self.tile_of(G + 1)
+        for tl in range(ntl):
+            G = G0 + tl * gs
+            tc, t1 = self.tile_of(G), self.tile_of(G + gs)
             if nch > 1:
                 self.reference(2, True, s, 0)
             else:
@@ -179,10 +180,10 @@ class Wave:
                 self.back(2, s, tc, nch - 1)
                 self.reference(nktl, fulll, sn, 64 * nfull)
                 s = sn
-            if G + 1 < G1:
+            if tl + 1 < ntl:
                 zero = np.zeros(64)
                 if nch == 1:
-                    sn = self.front(nktl, zero, self.tile_of(G + 2), 0, True)
+                    sn = self.front(nktl, zero, self.tile_of(G + 2 * gs), 0, True)
                 else:
                     sn = self.front(2, zero, t1, 1, False, eshare=True)
                 self.back(nktl, s, t1, 0)
@@ -215,13 +216,49 @@ def test_window_banks():
     assert ((A * P + 4 * HH) % 4 == 0).all()
 
 
-@pytest.mark.parametrize("L,max_pos,scale,tpb,nseq", [(101, 512, 1.0, 16, 5), (321, 512, 1.0, 4, 2), (65, 512, 1.0, 2, 3),
-                                                      (33, 512, 1.0, 6, 2), (64, 512, 1.0, 3, 4), (128, 512, 1.0, 3, 2),
-                                                      (200, 512, 1.0, 4, 2), (70, 20, 1.0, 6, 2), (96, 40, 6.0, 2, 2),
-                                                      (321, 512, 5.0, 4, 1), (600, 512, 1.0, 4, 1)])
-def test_attn_sp_unit_stream(L, max_pos, scale, tpb, nseq):
-    """Blocks of tpb consecutive tiles of the flattened (sequence, tile) space of nseq sequences (the stream crosses
-    sequence boundaries: other Q / K / V images, same distance table).  101 / 321: the model's lengths (no hot iteration
+def block_tiles(blk, grid, tpb, group, GN):
+    """attn_sp_out_x3_kernel's block -> tile map: XCD blk % 8 owns a contiguous range of the stream; inside it a group
+    of `group` consecutive blocks takes interleaved tiles (block j: j, j + gs, ...).  Returns (G0, ntl, gs) or None."""
+    xcd, li, nbx = blk & 7, blk >> 3, grid >> 3
+    grp = li // group
+    gs = min(group, nbx - grp * group)
+    G0 = (xcd * nbx + grp * group) * tpb + (li - grp * group)
+    if G0 >= GN:
+        return None
+    return G0, min(tpb, (GN - 1 - G0) // gs + 1), gs
+
+
+@pytest.mark.parametrize("GN,tpb,group", [(35552, 4, 64), (41088, 81, 64), (44, 4, 64), (20, 16, 64), (1000, 3, 5),
+                                          (17, 4, 1), (1, 4, 64), (123, 7, 2)])
+def test_block_tile_map_is_a_partition(GN, tpb, group):
+    """Every tile of the stream belongs to exactly one block, for the bench shapes (35552 tiles x 4, 41088 x 81) and
+    ragged ones; group = 1 is the consecutive order."""
+    nb = (GN + tpb - 1) // tpb
+    grid = (nb + 7) // 8 * 8
+    seen = np.zeros(GN, np.int32)
+    for blk in range(grid):
+        bt = block_tiles(blk, grid, tpb, group, GN)
+        if bt is None:
+            continue
+        G0, ntl, gs = bt
+        assert ntl >= 1 and G0 + (ntl - 1) * gs < GN
+        seen[G0 + gs * np.arange(ntl)] += 1
+        if group == 1:
+            assert gs == 1
+    assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("L,max_pos,scale,tpb,nseq,group",
+                         [(101, 512, 1.0, 16, 5, 1), (321, 512, 1.0, 4, 2, 1), (65, 512, 1.0, 2, 3, 1),
+                          (33, 512, 1.0, 6, 2, 1), (64, 512, 1.0, 3, 4, 1), (128, 512, 1.0, 3, 2, 1),
+                          (200, 512, 1.0, 4, 2, 1), (70, 20, 1.0, 6, 2, 1), (96, 40, 6.0, 2, 2, 1),
+                          (321, 512, 5.0, 4, 1, 1), (600, 512, 1.0, 4, 1, 1),
+                          (101, 512, 1.0, 3, 5, 2), (321, 512, 1.0, 4, 3, 64), (33, 512, 1.0, 3, 9, 2),
+                          (64, 512, 1.0, 2, 7, 3), (70, 20, 1.0, 3, 4, 2)])
+def test_attn_sp_unit_stream(L, max_pos, scale, tpb, nseq, group):
+    """Blocks of tpb tiles of the flattened (sequence, tile) space of nseq sequences, mapped as the kernel maps them
+    (group = 1: consecutive tiles; group > 1: the tiles of co-resident blocks interleave, so a block's next tile is
+    usually of another sequence: other Q / K / V images, same distance table).  101 / 321: the model's lengths (no hot iteration
     / four of them; tail chunk of two key tiles / of one key; 16 tiles = 4 sequences per block on the frequency axis);
     64 / 128: no tail chunk; 33 / 64: single-chunk tiles (front halves under the previous tile's only back half, the
     unit after it two tiles ahead); 70 / 96 / 600: distances beyond the table (clamped fetches); scale 5 / 6:
@@ -243,9 +280,15 @@ def test_attn_sp_unit_stream(L, max_pos, scale, tpb, nseq):
     clamp = L + 96 > max_pos
     GN = nseq * Lt
     logs = []
-    for G0 in range(0, GN, tpb):
+    grid = ((GN + tpb - 1) // tpb + 7) // 8 * 8
+    done = 0
+    for blk in range(grid):
+        bt = block_tiles(blk, grid, tpb, group, GN)
+        if bt is None:
+            continue
         w = Wave(seqs, rel, max_pos, L, clamp)
-        out = w.run_block(G0, min(G0 + tpb, GN))
+        out = w.run_block(*bt)
+        done += len(out)
         logs += w.log
         for G, stash in out.items():
             sq, it = G // Lt, G % Lt
@@ -255,5 +298,6 @@ def test_attn_sp_unit_stream(L, max_pos, scale, tpb, nseq):
                     tok = 32 * it + 16 * blk + c
                     if tok < L:
                         np.testing.assert_allclose(stash[(blk, l16)], refs[sq][tok, 4 * g:4 * g + 4], rtol=2e-5, atol=2e-5)
+    assert done == GN
     if scale > 1:
         assert "reref" in logs
