@@ -436,6 +436,9 @@ __device__ __forceinline__ void a32_chunk(const A32Ctx& c, int n, int i0n, int n
 #ifndef A32_SLOTS_PER_GPU
 #define A32_SLOTS_PER_GPU 512   // resident blocks: 256 CUs x 2 (66 KB of LDS, 256 VGPRs)
 #endif
+#ifndef A32_PERSIST_LONG
+#define A32_PERSIST_LONG 0      // 1: long sequences (the time axis) also run as one round of persistent blocks (measured: +1.5 %)
+#endif
 #ifndef A32_GROUP
 #define A32_GROUP 64            // blocks resident together on one XCD (32 CUs x 2): their tiles interleave (see the kernel)
 #endif
@@ -1194,14 +1197,15 @@ void launch_attn_sp_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* 
                            const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
                            const float* bo) {
     const int N = seq.nblocks / seq.Lb, Lt = (seq.L + 31) / 32;
-    // tiles per block of the flattened (sequence, tile) stream.  Long sequences: A32_TPB (their K / V working set wants
-    // several blocks per sequence in flight).  Short ones (the frequency axis): ONE round of
+    // tiles per block of the flattened (sequence, tile) stream.  Short sequences (the frequency axis): ONE round of
     // persistent blocks - 256 CUs x 2 blocks each take an equal share of the stream, so there is one cold prologue per
-    // block slot and no partly filled last round (2568 blocks of 16 tiles were 5.02 rounds).
-    int tpb = A32_TPB;
-    if (Lt <= 4) {
+    // block slot and no partly filled last round (2568 blocks of 16 tiles were 5.02 rounds).  Long ones (the time axis):
+    // A32_TPB tiles per block, 17.4 rounds - with the interleaved tile order a persistent round no longer costs L2 hits,
+    // but it measured 1.5 % SLOWER (5.70 vs 5.62 ms): short blocks balance the CUs dynamically.
+    int tpb = Lt <= 4 ? A32_TPB_SHORT : A32_TPB;
+    if (Lt <= 4 || A32_PERSIST_LONG) {
         const long share = ((long)N * Lt + A32_SLOTS_PER_GPU - 1) / A32_SLOTS_PER_GPU;
-        tpb = share > A32_TPB_SHORT ? (int)share : A32_TPB_SHORT;
+        if (share > tpb) tpb = (int)share;
     }
     const long nb = ((long)N * Lt + tpb - 1) / tpb;
     const unsigned grid = XCD_ORDER ? (unsigned)(((nb + 7) / 8) * 8) : (unsigned)nb;

@@ -1,0 +1,88 @@
+// Probe: operand layout and issue rate of v_mfma_f32_4x4x4_16B_f16 on gfx950 (16 independent 4x4x4 products per wave).
+// hipcc --offload-arch=gfx950 -O3 tools/probes/mfma4x4_probe.hip -o /tmp/mfma4x4_probe && /tmp/mfma4x4_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void layout_kernel(const float* A, const float* B, float* D) {
+    // hypothesis: A lane = 4 b + i holds A_b[i][k], k = 0..3; B lane = 4 b + j holds B_b[k][j]; D lane = 4 b + j, reg i
+    const int lane = threadIdx.x, b = lane >> 2, r = lane & 3;
+    f16x4 a, bb;
+    for (int k = 0; k < 4; ++k) {
+        a[k] = (_Float16)A[(b * 4 + r) * 4 + k];       // A[b][i = r][k]
+        bb[k] = (_Float16)B[(b * 4 + k) * 4 + r];      // B[b][k][j = r]
+    }
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+    d = __builtin_amdgcn_mfma_f32_4x4x4f16(a, bb, d, 0, 0, 0);
+    for (int i = 0; i < 4; ++i) D[(b * 4 + i) * 4 + r] = d[i];   // D[b][i][j = r]
+}
+
+template <int MODE>
+__global__ void rate_kernel(float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    f16x4 a = {(_Float16)(lane * 0.01f), (_Float16)1.f, (_Float16)0.5f, (_Float16)0.25f}, b = a;
+    f32x4 d[8];
+    for (int i = 0; i < 8; ++i) d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float v[8];
+    for (int i = 0; i < 8; ++i) v[i] = lane + i;
+    const float w = out[0];
+    long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] = __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, d[i], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = fmaf(v[i], w, 1.0f);
+        }
+    }
+    long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += d[i][0] + d[i][1] + d[i][2] + d[i][3] + v[i];
+    if (lane == 0) { out[1 + blockIdx.x * 4 + (threadIdx.x >> 6)] = (float)(t1 - t0) / (8.f * iters); }
+    if (s == 12345.678f) out[0] = s;
+}
+
+int main() {
+    std::vector<float> A(256), B(256), D(256), R(256);
+    for (int i = 0; i < 256; ++i) { A[i] = (float)((i * 7) % 11 - 5); B[i] = (float)((i * 5) % 13 - 6); }
+    for (int b = 0; b < 16; ++b)
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                float s = 0;
+                for (int k = 0; k < 4; ++k) s += A[(b * 4 + i) * 4 + k] * B[(b * 4 + k) * 4 + j];
+                R[(b * 4 + i) * 4 + j] = s;
+            }
+    float *dA, *dB, *dD, *dO;
+    hipMalloc(&dA, 1024); hipMalloc(&dB, 1024); hipMalloc(&dD, 1024); hipMalloc(&dO, 4096);
+    hipMemcpy(dA, A.data(), 1024, hipMemcpyHostToDevice);
+    hipMemcpy(dB, B.data(), 1024, hipMemcpyHostToDevice);
+    layout_kernel<<<1, 64>>>(dA, dB, dD);
+    hipMemcpy(D.data(), dD, 1024, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int i = 0; i < 256; ++i) bad += D[i] != R[i];
+    printf("layout hypothesis (A lane=4b+i, B lane=4b+j, D lane=4b+j reg i): %s (%d mismatches)\n", bad ? "WRONG" : "OK", bad);
+    if (bad) for (int i = 0; i < 32; ++i) printf("  D[%d]=%g ref %g\n", i, D[i], R[i]);
+    std::vector<float> O(1024, 0.f);
+    O[0] = 1.0001f;
+    for (int waves = 1; waves <= 4; waves *= 2) {
+        hipMemcpy(dO, O.data(), 4096, hipMemcpyHostToDevice);
+        rate_kernel<0><<<1, 64 * waves>>>(dO, 20000);
+        hipMemcpy(O.data(), dO, 4096, hipMemcpyDeviceToHost);
+        const float m = O[1];
+        O[0] = 1.0001f;
+        hipMemcpy(dO, O.data(), 4096, hipMemcpyHostToDevice);
+        rate_kernel<1><<<1, 64 * waves>>>(dO, 20000);
+        hipMemcpy(O.data(), dO, 4096, hipMemcpyDeviceToHost);
+        printf("%d wave(s)/block (one per SIMD up to 4): cycles per instr: mfma_4x4x4_16B %.2f   v_fma_f32 %.2f\n", waves, m, O[1]);
+        O[0] = 1.0001f;
+    }
+    // two waves on ONE SIMD would need 8 waves; check 8 waves/block too (2 per SIMD)
+    hipMemcpy(dO, O.data(), 4096, hipMemcpyHostToDevice);
+    rate_kernel<0><<<1, 512>>>(dO, 20000);
+    hipMemcpy(O.data(), dO, 4096, hipMemcpyDeviceToHost);
+    printf("8 waves/block: cycles per instr per wave: mfma %.2f\n", O[1]);
+    return 0;
+}
