@@ -276,6 +276,26 @@ static void x3_conv_image(const float* fm, int nchunk16, int taps, int CB, std::
                     }
 }
 
+// depthwise taps [31][128] (BatchNorm folded) -> A operands of dwpw2t_x3_kernel: [channel group 8][q 9][lane 64][hi 4 | lo 4],
+// lane = 4 b + i (b = channel of the group, i = output row of the 4 x 4 block), element k: w_c[4 q + k - i - 2] or 0
+static void dw_toeplitz_image(const float* w, std::vector<_Float16>& out) {
+    const size_t base = out.size();
+    out.resize(base + (size_t)8 * 9 * 64 * 8);
+    for (int cg = 0; cg < 8; ++cg)
+        for (int q = 0; q < 9; ++q)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int ch = 16 * cg + (lane >> 2), i = lane & 3;
+                const size_t o = base + (((size_t)cg * 9 + q) * 64 + lane) * 8;
+                for (int k = 0; k < 4; ++k) {
+                    const int tau = 4 * q + k - i - 2;
+                    _Float16 hi, lo;
+                    split_h(tau >= 0 && tau < 31 ? w[tau * 128 + ch] : 0.f, hi, lo);
+                    out[o + k] = hi;
+                    out[o + 4 + k] = lo;
+                }
+            }
+}
+
 // host-side only: the caller uploads the image and swaps it in together with the fp32 payload
 static int build_x3_images(const float* payload, const std::map<uint32_t, WEntry>& dir,
                            std::vector<_Float16>& host_img, std::map<uint32_t, size_t>& d16_out) {
@@ -296,6 +316,7 @@ static int build_x3_images(const float* payload, const std::map<uint32_t, WEntry
                 default: break;
             }
             if (RB) { pad(); d16[id] = img.size(); x3_image(src, RB, KB, img); }
+            if (item == CF_DW_W) { pad(); d16[id] = img.size(); dw_toeplitz_image(src, img); }
             if (item == CF_REL) {                               // rows of [hi 16 | lo 16] halfs
                 const size_t rows = kv.second.count / 16;
                 pad(); d16[id] = img.size();
@@ -411,6 +432,7 @@ static bool conf_weights_x3(cmgan_handle* h, int index, ConfWeightsX3& w) {
     w.pw1_w = W16(h, WID(g, CF_PW1_W), ok);   w.pw2_w = W16(h, WID(g, CF_PW2_W), ok);
     w.ff2_w1 = W16(h, WID(g, CF_FF2_W1), ok); w.ff2_w2 = W16(h, WID(g, CF_FF2_W2), ok);
     w.rel_img = W16(h, WID(g, CF_REL), ok);
+    w.dw_img = W16(h, WID(g, CF_DW_W), ok);
     w.rel_planes = W16(h, WID(g, CF_REL) | 0x4000, ok);
     return ok;
 }

@@ -230,6 +230,9 @@ __global__ __launch_bounds__(512) void pw1glu_x3_kernel(const float* __restrict_
 #ifndef DS_SEG
 #define DS_SEG 4
 #endif
+#ifndef DS_TOEPLITZ
+#define DS_TOEPLITZ 1        // 1: dwpw2t_x3_kernel (depthwise taps as banded-Toeplitz operands of the 4x4x4 MFMA); 0: this kernel
+#endif
 #ifndef DS_OCC
 #define DS_OCC 2             // blocks (= waves per SIMD) the register allocation is sized for
 #endif
@@ -436,6 +439,225 @@ __global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restric
 }
 
 // ---------------------------------------------------------------------------------
+// dwpw2t_x3_kernel: dwpw2s_x3_kernel with the 31-tap depthwise on the MATRIX pipe (the default).
+//
+// A depthwise convolution has no contraction over channels, so the GEMM-shaped MFMAs do not apply - but
+// v_mfma_f32_4x4x4_16B_f16 is sixteen INDEPENDENT 4 x 4 x 4 products per wave, and a 1-D convolution is a banded
+// Toeplitz product.  Block b of the instruction is one channel; with the window of that channel cut into chunks of
+// four consecutive positions,
+//     D_b[i][j] += sum_k A_q[i][k] * B_q[k][j],   A_q[i][k] = w_c[4q + k - i - 2],   B_q[k][j] = win_c[4 (j + q) + k]
+// accumulates, over q = 0..8, out_c[4j + i] = sum_tau w_c[tau] win_c[4j + i + tau + 2]: 16 outputs x 16 channels per
+// 9 instructions (27 with the three split products) instead of 124 v_fma_f32, and the instruction's lane layout
+// (A: lane 4b + i holds k = 0..3; B: lane 4b + j; D: lane 4b + j holds i = 0..3; tools/probes/mfma4x4_probe.hip) makes
+// every operand one aligned 8-byte unit:
+//   * A_q is a constant of the weights: api.hip builds the image [channel group 8][q 9][lane 64][hi 4 | lo 4] once;
+//     a wave keeps the 18 units of its two channel groups in registers;
+//   * the window lives in LDS channel-major and already split: planes uh / ul of [128 channels][64 positions] halfs,
+//     position p <-> sequence row l0 - 17 + p (the "- 2" above: it puts the 32 NEW rows of a tile at positions
+//     32..63, chunk-aligned, and the chunks a lane reads at 4 (j + s), s = 0..12).  Row pitch 80 halfs: the
+//     ds_read_b64 of 8 channels x 4 chunks of a lane group fall on 64 different banks;
+//   * a thread stages 4 positions x 4 channels (four 16-byte fetches, a register transpose, split, eight
+//     ds_write_b64); after a tile positions 32..63 move to 0..31 (one 64-byte row per thread);
+//   * the second 16 outputs of a tile use chunks j + q + 4: one pass over s = j-relative chunk 0..12 feeds both
+//     halves (26 chunk reads per channel group instead of 36).
+// Everything after the depthwise (Swish, split, v tile, pointwise 128 -> 64, residual) is dwpw2s_x3_kernel's.
+// ---------------------------------------------------------------------------------
+#define DT_PITCH 80
+#ifndef DT_NB
+#define DT_NB 3                  // chunk buffers of the depthwise loop: reads run DT_NB - 1 steps ahead of their MFMAs
+#endif
+__device__ __forceinline__ f32x4 mfma4h(f16x4 a, f16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma4l(f16x4 a, f16x4 b, f32x4 c) {       // a term with a lo operand
+    return X3_TERMS == 3 ? __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0) : c;
+}
+// The depthwise of one tile for this wave (one channel group): chunk step s feeds q = s of the first 16 outputs (s <= 8)
+// and q = s - 4 of the second 16 (s >= 4; H1 = false: that half lies beyond the sequence end and is skipped - its v rows
+// keep stale values that feed only outputs which are never stored).  Chunk reads run two steps ahead of their MFMAs.
+// (Dependent 4x4x4 MFMAs issue every 13 cycles, independent ones every 8.5 - tools/probes/mfma4x4_probe.hip; the two halves
+// alternate in the middle steps; a second accumulator per half would cost 8 of the 128 registers four waves per SIMD leave.)
+template <bool H1>
+__device__ __forceinline__ void dt_taps(const _Float16* bhp, const _Float16* blp, const f16x4 (&wah)[9],
+                                        const f16x4 (&wal)[9], float dbias, int vcol, int dj, _Float16* vth,
+                                        _Float16* vtl) {
+    constexpr int NS = H1 ? 13 : 9, NH = H1 ? 2 : 1;
+    f32x4 d[2];                                                 // [half]
+    d[0] = d[1] = splat4(dbias);
+    f16x4 bh[DT_NB], bl[DT_NB];
+    auto rd = [&](int s) {
+        bh[s % DT_NB] = *reinterpret_cast<const f16x4*>(bhp + 4 * s);
+        bl[s % DT_NB] = *reinterpret_cast<const f16x4*>(blp + 4 * s);
+    };
+#pragma unroll
+    for (int s = 0; s < DT_NB - 1; ++s) rd(s);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + DT_NB - 1 < NS) rd(s + DT_NB - 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int hh = 0; hh < NH; ++hh) {
+                const int q = s - 4 * hh;
+                if (q < 0 || q > 8) continue;
+                if (term == 0) d[hh] = mfma4h(wah[q], bh[s % DT_NB], d[hh]);
+                if (term == 1) d[hh] = mfma4l(wah[q], bl[s % DT_NB], d[hh]);
+                if (term == 2) d[hh] = mfma4l(wal[q], bh[s % DT_NB], d[hh]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            f16x2 hi, lo;
+            split2(swishf(d[hh][i]), swishf(d[hh][i + 1]), hi, lo);
+            const int row = 16 * hh + 4 * dj + i;
+            vth[row * DP_VS + vcol] = hi[0];
+            vth[(row + 1) * DP_VS + vcol] = hi[1];
+            vtl[row * DP_VS + vcol] = lo[0];
+            vtl[(row + 1) * DP_VS + vcol] = lo[1];
+        }
+    }
+}
+
+// 512 threads: wave w = channel group w of the depthwise (16 channels, 36 operand registers) and one (token block, output
+// block) pair of the pointwise product (32 operand registers): everything a wave re-uses across the tiles of its segment
+// stays in registers at four waves per SIMD.
+__global__ __launch_bounds__(512, 4) void dwpw2t_x3_kernel(float* __restrict__ x, const float* __restrict__ u,
+                                                           const _Float16* __restrict__ dwi,
+                                                           const float* __restrict__ dw_b,
+                                                           const _Float16* __restrict__ w2i,
+                                                           const float* __restrict__ b2, TokMap m, int nseq, int nsegs) {
+    __shared__ __attribute__((aligned(16))) _Float16 uh[128 * DT_PITCH];
+    __shared__ __attribute__((aligned(16))) _Float16 ul[128 * DT_PITCH];
+    __shared__ __attribute__((aligned(16))) _Float16 vth[DP_TL * DP_VS];
+    __shared__ __attribute__((aligned(16))) _Float16 vtl[DP_TL * DP_VS];
+    __shared__ __attribute__((aligned(16))) _Float16 w2l[16 * 64 * 8];      // lo halves of the pointwise operand image
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long item = XCD_ORDER ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+    const int n = (int)(item / nsegs), seg = (int)(item - (long)n * nsegs);
+    if (n >= nseq) return;                                       // padding blocks of the rounded-up grid
+    const int l_begin = seg * DS_SEG * DP_TL;
+    const int l_end = l_begin + DS_SEG * DP_TL < m.L ? l_begin + DS_SEG * DP_TL : m.L;
+    const int ntiles = (l_end - l_begin + DP_TL - 1) / DP_TL;
+    const long nbase = (long)(n / m.inner) * m.outer + (long)(n % m.inner) * m.istride;
+
+    // pointwise operands of this wave: token block tb, output block ob.  The hi halves stay in registers for the whole
+    // segment; the lo halves (16 KB for the block) live in LDS - 128 registers do not hold both next to the depthwise taps
+    const int tb = wv >> 2, ob = wv & 3;
+    f16x8 ah[4];
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) ah[mm] = *reinterpret_cast<const f16x8*>(w2i + (ob * 4 + mm) * 1024 + lane * 8);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int un = tid + 512 * k;                            // 16-byte unit: (ob, mm) = un >> 6, lane un & 63
+        *reinterpret_cast<u32x4*>(&w2l[un * 8]) =
+            *reinterpret_cast<const u32x4*>(w2i + (un >> 6) * 1024 + 512 + (un & 63) * 8);
+    }
+    const _Float16* const alp = w2l + (ob * 4 * 64 + lane) * 8;
+
+    // depthwise operands of this wave: channel group wv (MFMA block db = channel 16 wv + db)
+    const int db = lane >> 2, dj = lane & 3;
+    f16x4 wah[9], wal[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const f16x8 t = *reinterpret_cast<const f16x8*>(dwi + ((wv * 9 + q) * 64 + lane) * 8);
+        wah[q] = __builtin_shufflevector(t, t, 0, 1, 2, 3);
+        wal[q] = __builtin_shufflevector(t, t, 4, 5, 6, 7);
+    }
+    const int chn = 16 * wv + db;
+    const float dbias = dw_b[chn];
+    const _Float16* const bhp = uh + chn * DT_PITCH + 4 * dj;    // this lane's chunk 0 (chunk s is 4 s halfs further)
+    const _Float16* const blp = ul + chn * DT_PITCH + 4 * dj;
+    // B-operand order inside a v row: channel 32m + 16h + 4gq + r  ->  32m + 8gq + 4h + r
+    const int vcol = (chn & ~31) + ((chn >> 2) & 3) * 8 + ((chn >> 4) & 1) * 4 + (chn & 3);
+
+    // staging item of this thread: position PAIR s_pp (of the 16 of a half window) x channel quad s_cq.  A wave fetch is
+    // 8 rows x 128 B; a 32-lane store group is 8 pairs x 4 quads (the quad does not move the bank at this pitch: 4-way,
+    // 16 cycles per ds_write_b32 instead of 4 - eight of them per tile)
+    const int s_pp = (lane & 7) + 8 * (wv & 1), s_cq = (lane >> 3) + 8 * (wv >> 1);
+    // rows 2 pp, 2 pp + 1 of half `half` of the window of the tile at l0 (position p <-> row l0 - 17 + p).  The fetch
+    // is unconditional (clamped row); rows outside [0, L) - the convolution's zero padding - are zeroed when the values
+    // are USED (a select on the fetched register here would make every boundary tile wait for its own prefetch)
+    auto load_pair = [&](int l0, int half, f32x4 (&r)[2], unsigned& okm) {
+        okm = 0;
+#pragma unroll
+        for (int rho = 0; rho < 2; ++rho) {
+            const int l = l0 - 17 + 32 * half + 2 * s_pp + rho;
+            const int lc = l < 0 ? 0 : (l < m.L ? l : m.L - 1);
+            r[rho] = ldg4(u + (nbase + (long)lc * m.lstride) * 128 + s_cq * 4);
+            if (l >= 0 && l < m.L) okm |= 1u << rho;
+        }
+    };
+    auto store_pair = [&](int half, const f32x4 (&r)[2], unsigned okm) {
+        const f32x4 r0 = (okm & 1u) ? r[0] : splat4(0.f), r1 = (okm & 2u) ? r[1] : splat4(0.f);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f16x2 hi, lo;
+            split2(r0[e], r1[e], hi, lo);                        // 2 consecutive positions of channel 4 s_cq + e
+            *reinterpret_cast<f16x2*>(&uh[(4 * s_cq + e) * DT_PITCH + 32 * half + 2 * s_pp]) = hi;
+            *reinterpret_cast<f16x2*>(&ul[(4 * s_cq + e) * DT_PITCH + 32 * half + 2 * s_pp]) = lo;
+        }
+    };
+    {
+        f32x4 r0[2], r1[2];
+        unsigned k0, k1;
+        load_pair(l_begin, 0, r0, k0);
+        load_pair(l_begin, 1, r1, k1);
+        store_pair(0, r0, k0);
+        store_pair(1, r1, k1);
+    }
+    // the window half-row this thread moves after a tile: plane tid >> 8, channel (tid >> 1) & 127, 16 positions of 32..63
+    _Float16* const krow = ((tid >> 8) ? ul : uh) + ((tid >> 1) & 127) * DT_PITCH + 16 * (tid & 1);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int t = 0; t < ntiles; ++t) {
+        const int l0 = l_begin + t * DP_TL;
+        const bool has_next = t + 1 < ntiles;
+        // ---- prefetch: the 32 new rows of the next tile, and this tile's residual rows for the epilogue ----
+        f32x4 nxt[2];
+        unsigned nxt_ok = 0;
+        if (has_next) load_pair(l0 + DP_TL, 1, nxt, nxt_ok);
+        const int lrow = l0 + 16 * tb + c;
+        const bool live = lrow < m.L;
+        float* xr = x + (nbase + (long)(live ? lrow : m.L - 1) * m.lstride) * 64 + 16 * ob + 4 * g;
+
+        // ---- depthwise: outputs 4 dj + i (+ 16 for the second half) of channel chn ----
+        if (l0 + 16 < m.L) dt_taps<true>(bhp, blp, wah, wal, dbias, vcol, dj, vth, vtl);
+        else dt_taps<false>(bhp, blp, wah, wal, dbias, vcol, dj, vth, vtl);
+        // epilogue operands (requested before the barrier), and the half of the window the next tile shares with this one
+        // (read before the barrier, written after it)
+        const f32x4 xold = ldg4(xr);
+        f32x4 acc2 = ldg4(b2 + 16 * ob + 4 * g);
+        u32x4 keep[2];
+        if (has_next) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) keep[k] = *reinterpret_cast<const u32x4*>(krow + 32 + 8 * k);
+        }
+        __syncthreads();                                          // all window reads and v-tile writes are done
+
+        // ---- pointwise 128 -> 64 on the matrix pipe + bias + residual ----
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            const f16x8 bh = *reinterpret_cast<const f16x8*>(&vth[(16 * tb + c) * DP_VS + 32 * mm + 8 * g]);
+            const f16x8 bl = *reinterpret_cast<const f16x8*>(&vtl[(16 * tb + c) * DP_VS + 32 * mm + 8 * g]);
+            acc2 = mfma32h(ah[mm], bh, acc2);
+            acc2 = mfma32l(ah[mm], bl, acc2);
+            acc2 = mfma32l(*reinterpret_cast<const f16x8*>(alp + mm * 512), bh, acc2);
+        }
+        if (live) stg4(xr, xold + acc2);
+        if (has_next) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) *reinterpret_cast<u32x4*>(krow + 8 * k) = keep[k];
+            store_pair(1, nxt, nxt_ok);
+        }
+        __syncthreads();                                          // window and v tiles are free for the next tile
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------
 }  // namespace X3_NS
@@ -480,8 +702,13 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
         const int nsegs = (ntl + DS_SEG - 1) / DS_SEG;
         const long items = (long)N * nsegs;
         const unsigned grid = XCD_ORDER ? (unsigned)(((items + 7) / 8) * 8) : (unsigned)items;
+#if DS_TOEPLITZ
+        LAUNCH(ctx, "dwpw2", (dwpw2t_x3_kernel<<<grid, 512, 0, s>>>(b.xb, b.u, w16.dw_img, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
+                                                                   nsegs)));
+#else
         LAUNCH(ctx, "dwpw2", (dwpw2s_x3_kernel<<<grid, 256, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
                                                                    nsegs)));
+#endif
     }
     if (taps) {
         hipMemcpyAsync(taps + (size_t)2 * M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);

@@ -129,6 +129,7 @@ void conformer_forward(LaunchCtx, const ConfWeights&, const ConfBuffers&, const 
 struct ConfWeightsX3 {
     const _Float16 *ff1_w1, *ff1_w2, *qkv_w, *wo, *pw1_w, *pw2_w, *ff2_w1, *ff2_w2;
     const _Float16* rel_img;    // [2*max_pos+1][hi 16 | lo 16] halfs
+    const _Float16* dw_img;     // [8 channel groups][9][64 lanes][hi 4 | lo 4]: Toeplitz operands of the depthwise taps (dwpw2t_x3_kernel)
     const _Float16* rel_planes; // 4 x [2*max_pos+1 rows, reversed][8 halfs]: hi d0-7 | hi d8-15 | lo d0-7 | lo d8-15 (attn32_x3.hip)
 };
 void conformer_forward_x3(LaunchCtx, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&, const TokMap& seq,

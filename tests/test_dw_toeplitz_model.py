@@ -1,0 +1,107 @@
+"""CPU model of dwpw2t_x3_kernel's depthwise convolution on v_mfma_f32_4x4x4_16B_f16 (csrc/conformer_x3.hip): the Toeplitz
+operand image api.hip builds from the 31 taps (dw_toeplitz_image), the channel-major window with position
+p <-> row l0 - 17 + p, the chunk a lane reads at step s, the instruction's lane layout as measured on the GPU
+(tools/probes/mfma4x4_probe.hip: A lane 4b + i, B lane 4b + j, D lane 4b + j / register i) and the sliding of the window
+between the tiles of a segment - against the plain 31-tap depthwise convolution with zero padding
+(reference: src/models/conformer.py:165-167, Conv1d(groups = channels, padding = 15))."""
+import numpy as np
+import pytest
+
+
+def toeplitz_image(w):
+    """w [31][128] -> [8 groups][9][64 lanes][4] (the fp32 value of hi + lo; the split itself is tested elsewhere)."""
+    img = np.zeros((8, 9, 64, 4))
+    for cg in range(8):
+        for q in range(9):
+            for lane in range(64):
+                ch, i = 16 * cg + (lane >> 2), lane & 3
+                for k in range(4):
+                    tau = 4 * q + k - i - 2
+                    if 0 <= tau < 31:
+                        img[cg, q, lane, k] = w[tau, ch]
+    return img
+
+
+def mfma_4x4x4_16b(a, b, d):
+    """a, b [64 lanes][4], d [64 lanes][4 regs]: D_blk[i][j] += sum_k A_blk[i][k] B_blk[k][j], 16 blocks."""
+    out = d.copy()
+    for blk in range(16):
+        A = a[4 * blk:4 * blk + 4]            # [i][k]
+        B = b[4 * blk:4 * blk + 4].T          # lane j holds k = 0..3  ->  [k][j]
+        out[4 * blk:4 * blk + 4] += (A @ B).T  # lane j, register i
+    return out
+
+
+def run_segment(u, w, bias, l_begin, ntiles, L):
+    """One block: tiles of 32 positions from l_begin; returns {l: out[128]} for the live positions."""
+    img = toeplitz_image(w)
+    win = np.full((128, 64), np.nan)
+
+    def rows(l0, chunk):                      # load_chunk: 4 rows x 128 channels, zero outside [0, L)
+        r = np.zeros((4, 128))
+        for rho in range(4):
+            l = l0 - 17 + 4 * chunk + rho
+            if 0 <= l < L:
+                r[rho] = u[l]
+        return r
+
+    for chunk in range(16):
+        win[:, 4 * chunk:4 * chunk + 4] = rows(l_begin, chunk).T
+    out = {}
+    for t in range(ntiles):
+        l0 = l_begin + 32 * t
+        h1 = l0 + 16 < L
+        for cg in range(8):
+            d = [np.tile(bias[16 * cg + (np.arange(64) >> 2)][:, None], (1, 4)) for _ in range(2)]
+            for s in range(13):
+                if s > 8 and not h1:
+                    break
+                b = np.stack([win[16 * cg + (lane >> 2), 4 * ((lane & 3) + s):4 * ((lane & 3) + s) + 4] for lane in range(64)])
+                if s <= 8:
+                    d[0] = mfma_4x4x4_16b(img[cg, s], b, d[0])
+                if s >= 4 and h1:
+                    d[1] = mfma_4x4x4_16b(img[cg, s - 4], b, d[1])
+            for hh in range(2 if h1 else 1):
+                for lane in range(64):
+                    for i in range(4):
+                        l = l0 + 16 * hh + 4 * (lane & 3) + i
+                        if l < L:
+                            out.setdefault(l, np.zeros(128))[16 * cg + (lane >> 2)] = d[hh][lane, i]
+        if t + 1 < ntiles:
+            win[:, 0:32] = win[:, 32:64]
+            for chunk in range(8, 16):
+                win[:, 4 * chunk:4 * chunk + 4] = rows(l0 + 32, chunk).T
+    return out
+
+
+@pytest.mark.parametrize("L", [321, 101, 33, 128, 17])
+def test_toeplitz_depthwise_matches_conv(L):
+    rng = np.random.default_rng(L)
+    u = rng.standard_normal((L, 128))
+    w = rng.standard_normal((31, 128))
+    bias = rng.standard_normal(128)
+    ref = np.zeros((L, 128))
+    for l in range(L):
+        for tau in range(31):
+            if 0 <= l - 15 + tau < L:
+                ref[l] += w[tau] * u[l - 15 + tau]
+    ref += bias
+    ntl = (L + 31) // 32
+    seen = 0
+    for seg in range((ntl + 3) // 4):                     # DS_SEG = 4 tiles per block
+        l_begin = seg * 128
+        nt = (min(l_begin + 128, L) - l_begin + 31) // 32
+        out = run_segment(u, w, bias, l_begin, nt, L)
+        for l, v in out.items():
+            np.testing.assert_allclose(v, ref[l], rtol=1e-12, atol=1e-12)
+            seen += 1
+    assert seen == L
+
+
+def test_image_zero_outside_the_taps():
+    """Positions 0, 1 of the window (rows l0 - 17, l0 - 16) and 62, 63 never reach an output: the operand image is zero
+    wherever 4q + k - i - 2 is not a tap (the kernel still needs them FINITE: it zero-fills or copies real rows there)."""
+    img = toeplitz_image(np.ones((31, 128)))
+    # per output row i, the taps it sees over q, k must be exactly 31
+    for i in range(4):
+        assert img[0, :, i, :].sum() == 31

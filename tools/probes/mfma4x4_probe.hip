@@ -45,6 +45,32 @@ __global__ void rate_kernel(float* out, int iters) {
     if (s == 12345.678f) out[0] = s;
 }
 
+// NCH independent accumulator chains, 32 MFMAs per loop iteration (round-robin over the chains): cycles per instruction
+template <int NCH>
+__global__ void chain_kernel(float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    f16x4 a = {(_Float16)(lane * 0.01f), (_Float16)1.f, (_Float16)0.5f, (_Float16)0.25f}, b = a;
+    f32x4 d[NCH];
+    for (int i = 0; i < NCH; ++i) d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 32; ++r) d[r % NCH] = __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, d[r % NCH], 0, 0, 0);
+    }
+    long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int i = 0; i < NCH; ++i) s += d[i][0] + d[i][1] + d[i][2] + d[i][3];
+    if (lane == 0) out[1 + (threadIdx.x >> 6)] = (float)(t1 - t0) / (32.f * iters);
+    if (s == 12345.678f) out[0] = s;
+}
+template <int NCH>
+static void run_chain(float* dO, int waves) {
+    float o[16];
+    chain_kernel<NCH><<<1, 64 * waves>>>(dO, 4000);
+    hipMemcpy(o, dO, sizeof o, hipMemcpyDeviceToHost);
+    printf("  %d chain(s), %d wave(s): %.2f cycles per mfma_4x4x4 per wave\n", NCH, waves, o[1]);
+}
+
 int main() {
     std::vector<float> A(256), B(256), D(256), R(256);
     for (int i = 0; i < 256; ++i) { A[i] = (float)((i * 7) % 11 - 5); B[i] = (float)((i * 5) % 13 - 6); }
@@ -84,5 +110,9 @@ int main() {
     rate_kernel<0><<<1, 512>>>(dO, 20000);
     hipMemcpy(O.data(), dO, 4096, hipMemcpyDeviceToHost);
     printf("8 waves/block: cycles per instr per wave: mfma %.2f\n", O[1]);
+    printf("dependent-accumulator chains (32 MFMAs per iteration):\n");
+    for (int waves = 4; waves <= 8; waves *= 2) {
+        run_chain<1>(dO, waves); run_chain<2>(dO, waves); run_chain<4>(dO, waves); run_chain<8>(dO, waves); run_chain<16>(dO, waves);
+    }
     return 0;
 }
