@@ -462,6 +462,29 @@ __global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restric
 //     halves (26 chunk reads per channel group instead of 36).
 // Everything after the depthwise (Swish, split, v tile, pointwise 128 -> 64, residual) is dwpw2s_x3_kernel's.
 // ---------------------------------------------------------------------------------
+// Cycle stamps of dwpw2t_x3_kernel (measurement builds only, -DDT_STAMP; tools/probes/dwpw2t_stamps.py): per-phase
+// s_memtime deltas of every wave summed into per-wave-hashed slots (same-address atomics would distort the kernel).
+#if defined(X3_SINGLE) && defined(DT_STAMP)
+#undef DT_STAMP
+#endif
+#ifdef DT_STAMP
+__device__ unsigned long long g_dt_stamp[2048][16];
+struct DtStamp { unsigned long long t, acc[12]; };
+#define DT_MARK(ph)                                             \
+    do {                                                        \
+        __builtin_amdgcn_sched_barrier(0);                      \
+        const unsigned long long _t = __builtin_readcyclecounter(); \
+        sp.acc[ph] += _t - sp.t;                                \
+        sp.t = _t;                                              \
+        __builtin_amdgcn_sched_barrier(0);                      \
+    } while (0)
+#define DT_STAMP_ARG , DtStamp& sp
+#define DT_STAMP_PASS , sp
+#else
+#define DT_MARK(ph)
+#define DT_STAMP_ARG
+#define DT_STAMP_PASS
+#endif
 #define DT_PITCH 80
 #ifndef DT_NB
 #define DT_NB 3                  // chunk buffers of the depthwise loop: reads run DT_NB - 1 steps ahead of their MFMAs
@@ -478,7 +501,7 @@ __device__ __forceinline__ f32x4 mfma4l(f16x4 a, f16x4 b, f32x4 c) {       // a 
 template <bool H1>
 __device__ __forceinline__ void dt_taps(const _Float16* bhp, const _Float16* blp, const f16x4 (&wah)[9],
                                         const f16x4 (&wal)[9], float dbias, int vcol, int dj, _Float16* vth,
-                                        _Float16* vtl) {
+                                        _Float16* vtl DT_STAMP_ARG) {
     constexpr int NS = H1 ? 13 : 9, NH = H1 ? 2 : 1;
     f32x4 d[2];                                                 // [half]
     d[0] = d[1] = splat4(dbias);
@@ -505,6 +528,7 @@ __device__ __forceinline__ void dt_taps(const _Float16* bhp, const _Float16* blp
             }
         __builtin_amdgcn_sched_barrier(0);
     }
+    DT_MARK(2);                                                 // chunk reads + 4x4x4 MFMAs
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh) {
 #pragma unroll
@@ -518,11 +542,25 @@ __device__ __forceinline__ void dt_taps(const _Float16* bhp, const _Float16* blp
             vtl[(row + 1) * DP_VS + vcol] = lo[1];
         }
     }
+    DT_MARK(3);                                                 // Swish, split, v-tile stores
 }
 
 // 512 threads: wave w = channel group w of the depthwise (16 channels, 36 operand registers) and one (token block, output
-// block) pair of the pointwise product (32 operand registers): everything a wave re-uses across the tiles of its segment
-// stays in registers at four waves per SIMD.
+// block) pair of the pointwise product (16 operand registers + the lo halves in LDS): everything a wave re-uses stays in
+// registers at four waves per SIMD.
+// The blocks are PERSISTENT: block b owns a contiguous range of the (sequence, segment) items (XCD-contiguous, so the 30
+// halo rows between two segments of a sequence are an L2 hit) and walks their tiles as one stream.  The operands are
+// fetched once per block, and the first window of the next item is fetched under the last tile of the current one (into
+// the registers the kept-half copy does not need there) - measured with cycle stamps, the per-item prologue (19 fetches,
+// their latency, one barrier) was 28 - 31 % of the one-block-per-item kernel.
+struct DtItem {
+    __amdgpu_buffer_rsrc_t ur, xr;      // rows of the item's sequence in u / in x (descriptor + 32-bit lane offset: a
+                                        // uniform pointer + lane offset is hoisted into 64-bit per-lane pointers, 8 VGPRs)
+    int l_begin, ntiles;
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dt_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
 __global__ __launch_bounds__(512, 4) void dwpw2t_x3_kernel(float* __restrict__ x, const float* __restrict__ u,
                                                            const _Float16* __restrict__ dwi,
                                                            const float* __restrict__ dw_b,
@@ -535,59 +573,55 @@ __global__ __launch_bounds__(512, 4) void dwpw2t_x3_kernel(float* __restrict__ x
     __shared__ __attribute__((aligned(16))) _Float16 w2l[16 * 64 * 8];      // lo halves of the pointwise operand image
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long item = XCD_ORDER ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
-    const int n = (int)(item / nsegs), seg = (int)(item - (long)n * nsegs);
-    if (n >= nseq) return;                                       // padding blocks of the rounded-up grid
-    const int l_begin = seg * DS_SEG * DP_TL;
-    const int l_end = l_begin + DS_SEG * DP_TL < m.L ? l_begin + DS_SEG * DP_TL : m.L;
-    const int ntiles = (l_end - l_begin + DP_TL - 1) / DP_TL;
-    const long nbase = (long)(n / m.inner) * m.outer + (long)(n % m.inner) * m.istride;
+#ifdef DT_STAMP
+    DtStamp sp;
+    sp.t = __builtin_readcyclecounter();
+#pragma unroll
+    for (int i = 0; i < 12; ++i) sp.acc[i] = 0;
+    int stamp_tiles = 0;
+#endif
+    const long lblk = XCD_ORDER ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+    const long nitems = (long)nseq * nsegs;
+    const int it0 = (int)(lblk * nitems / gridDim.x), it1 = (int)((lblk + 1) * nitems / gridDim.x);
+    if (it0 >= it1) return;                                      // more blocks than items (block-uniform)
 
-    // pointwise operands of this wave: token block tb, output block ob.  The hi halves stay in registers for the whole
-    // segment; the lo halves (16 KB for the block) live in LDS - 128 registers do not hold both next to the depthwise taps
-    const int tb = wv >> 2, ob = wv & 3;
-    f16x8 ah[4];
-#pragma unroll
-    for (int mm = 0; mm < 4; ++mm) ah[mm] = *reinterpret_cast<const f16x8*>(w2i + (ob * 4 + mm) * 1024 + lane * 8);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int un = tid + 512 * k;                            // 16-byte unit: (ob, mm) = un >> 6, lane un & 63
-        *reinterpret_cast<u32x4*>(&w2l[un * 8]) =
-            *reinterpret_cast<const u32x4*>(w2i + (un >> 6) * 1024 + 512 + (un & 63) * 8);
-    }
-    const _Float16* const alp = w2l + (ob * 4 * 64 + lane) * 8;
-
-    // depthwise operands of this wave: channel group wv (MFMA block db = channel 16 wv + db)
-    const int db = lane >> 2, dj = lane & 3;
-    f16x4 wah[9], wal[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) {
-        const f16x8 t = *reinterpret_cast<const f16x8*>(dwi + ((wv * 9 + q) * 64 + lane) * 8);
-        wah[q] = __builtin_shufflevector(t, t, 0, 1, 2, 3);
-        wal[q] = __builtin_shufflevector(t, t, 4, 5, 6, 7);
-    }
+    const int tb = wv >> 2, ob = wv & 3;                         // pointwise work of this wave: token block, output block
+    const int db = lane >> 2, dj = lane & 3;                     // depthwise: MFMA block (channel of group wv), column
     const int chn = 16 * wv + db;
-    const float dbias = dw_b[chn];
-    const _Float16* const bhp = uh + chn * DT_PITCH + 4 * dj;    // this lane's chunk 0 (chunk s is 4 s halfs further)
-    const _Float16* const blp = ul + chn * DT_PITCH + 4 * dj;
-    // B-operand order inside a v row: channel 32m + 16h + 4gq + r  ->  32m + 8gq + 4h + r
-    const int vcol = (chn & ~31) + ((chn >> 2) & 3) * 8 + ((chn >> 4) & 1) * 4 + (chn & 3);
+    const unsigned rowb = (unsigned)m.lstride * 512u, xrowb = (unsigned)m.lstride * 256u;    // bytes per row of u / of x
+    auto item_of = [&](int it) -> DtItem {
+        const int n = it / nsegs, seg = it - n * nsegs;
+        const int nq = n / m.inner;
+        const long nbase = (long)nq * m.outer + (long)(n - nq * m.inner) * m.istride;
+        DtItem d;
+        d.ur = dt_rsrc(u + nbase * 128, (unsigned)(m.L - 1) * rowb + 512u);
+        d.xr = dt_rsrc(x + nbase * 64, (unsigned)(m.L - 1) * xrowb + 256u);
+        d.l_begin = seg * DS_SEG * DP_TL;
+        const int l_end = d.l_begin + DS_SEG * DP_TL < m.L ? d.l_begin + DS_SEG * DP_TL : m.L;
+        d.ntiles = (l_end - d.l_begin + DP_TL - 1) / DP_TL;
+        return d;
+    };
 
     // staging item of this thread: position PAIR s_pp (of the 16 of a half window) x channel quad s_cq.  A wave fetch is
     // 8 rows x 128 B; a 32-lane store group is 8 pairs x 4 quads (the quad does not move the bank at this pitch: 4-way,
     // 16 cycles per ds_write_b32 instead of 4 - eight of them per tile)
     const int s_pp = (lane & 7) + 8 * (wv & 1), s_cq = (lane >> 3) + 8 * (wv >> 1);
-    // rows 2 pp, 2 pp + 1 of half `half` of the window of the tile at l0 (position p <-> row l0 - 17 + p).  The fetch
-    // is unconditional (clamped row); rows outside [0, L) - the convolution's zero padding - are zeroed when the values
-    // are USED (a select on the fetched register here would make every boundary tile wait for its own prefetch)
-    auto load_pair = [&](int l0, int half, f32x4 (&r)[2], unsigned& okm) {
+    // Rows 2 pp, 2 pp + 1 of a half of the window (position p <-> row l0 - 17 + p), addressed as uniform base + 32-bit
+    // lane offset (a sequence spans < 2^32 bytes of u: checked by the launcher).  The fetch is unconditional (clamped
+    // row); rows outside [0, L) - the convolution's zero padding - are zeroed when the values are USED (a select on the
+    // fetched register here would make every boundary tile wait for its own prefetch)
+    const unsigned cqb = (unsigned)s_cq * 16u;
+    auto load_pair = [&](__amdgpu_buffer_rsrc_t ur, int lfirst, f32x4 (&r)[2], unsigned& okm) {   // lfirst = row of position pair 0
         okm = 0;
+        int pp2 = 2 * s_pp;
+        asm volatile("" : "+v"(pp2));                            // (opaque: the next item's offsets are otherwise computed at the
+                                                                 // item's START and live through all its tiles - registers)
 #pragma unroll
         for (int rho = 0; rho < 2; ++rho) {
-            const int l = l0 - 17 + 32 * half + 2 * s_pp + rho;
-            const int lc = l < 0 ? 0 : (l < m.L ? l : m.L - 1);
-            r[rho] = ldg4(u + (nbase + (long)lc * m.lstride) * 128 + s_cq * 4);
-            if (l >= 0 && l < m.L) okm |= 1u << rho;
+            const int l = lfirst + pp2 + rho;
+            const int lc = min(max(l, 0), m.L - 1);             // (arithmetic clamp: a select between two ADDRESSES becomes a branch)
+            r[rho] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, (unsigned)lc * rowb + cqb, 0, 0));
+            okm |= (unsigned)(l == lc) << rho;
         }
     };
     auto store_pair = [&](int half, const f32x4 (&r)[2], unsigned okm) {
@@ -600,62 +634,160 @@ __global__ __launch_bounds__(512, 4) void dwpw2t_x3_kernel(float* __restrict__ x
             *reinterpret_cast<f16x2*>(&ul[(4 * s_cq + e) * DT_PITCH + 32 * half + 2 * s_pp]) = lo;
         }
     };
-    {
-        f32x4 r0[2], r1[2];
-        unsigned k0, k1;
-        load_pair(l_begin, 0, r0, k0);
-        load_pair(l_begin, 1, r1, k1);
-        store_pair(0, r0, k0);
-        store_pair(1, r1, k1);
+    DtItem cur = item_of(it0);
+    // the first window's rows are requested FIRST: everything below is in flight behind them and is waited for at its use
+    f32x4 low[2], nxt[2];                                        // (low doubles as the kept-half copy inside an item)
+    unsigned low_ok, nxt_ok;
+    load_pair(cur.ur, cur.l_begin - 17, low, low_ok);
+    load_pair(cur.ur, cur.l_begin + 15, nxt, nxt_ok);
+
+    // pointwise operands: the hi halves stay in registers; the lo halves (16 KB for the block) live in LDS - 128 registers
+    // do not hold both next to the depthwise taps
+    u32x4 w2t[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int un = tid + 512 * k;                            // 16-byte unit: (ob, mm) = un >> 6, lane un & 63
+        w2t[k] = *reinterpret_cast<const u32x4*>(w2i + (un >> 6) * 1024 + 512 + (un & 63) * 8);
     }
+    f16x8 ah[4];
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) ah[mm] = *reinterpret_cast<const f16x8*>(w2i + (ob * 4 + mm) * 1024 + lane * 8);
+    const _Float16* const alp = w2l + (ob * 4 * 64 + lane) * 8;
+    store_pair(0, low, low_ok);                                   // (before the 36 registers of depthwise operands are requested)
+    store_pair(1, nxt, nxt_ok);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) *reinterpret_cast<u32x4*>(&w2l[(tid + 512 * k) * 8]) = w2t[k];
+    // depthwise operands: channel group wv
+    f16x8 wimg[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) wimg[q] = *reinterpret_cast<const f16x8*>(dwi + ((wv * 9 + q) * 64 + lane) * 8);
+    float dbias = dw_b[chn];
+    const _Float16* const bhp = uh + chn * DT_PITCH + 4 * dj;    // this lane's chunk 0 (chunk s is 4 s halfs further)
+    const _Float16* const blp = ul + chn * DT_PITCH + 4 * dj;
+    // B-operand order inside a v row: channel 32m + 16h + 4gq + r  ->  32m + 8gq + 4h + r.  The 8-half units of row r are
+    // stored XOR-swizzled by (r >> 2) & 3: a depthwise lane group writes rows 4 j + i of four j's at once, which would
+    // meet in one bank (row pitch 72 dwords); the swizzle costs nothing on either side (per-lane constants) and keeps the
+    // pointwise product's ds_read_b128 conflict-free (brute-forced over the lane-group map)
+    const int vcol = ((chn & ~31) + ((chn >> 2) & 3) * 8 + ((chn >> 4) & 1) * 4 + (chn & 3)) ^ (8 * dj);
+    const int gx = g ^ ((c >> 2) & 3);
+    const _Float16* const vrh = vth + (16 * tb + c) * DP_VS + 8 * gx;     // this lane's B fragments of the pointwise product
+    const _Float16* const vrl = vtl + (16 * tb + c) * DP_VS + 8 * gx;
+    const unsigned xcolb = (unsigned)(16 * ob + 4 * g) * 4u;
     // the window half-row this thread moves after a tile: plane tid >> 8, channel (tid >> 1) & 127, 16 positions of 32..63
     _Float16* const krow = ((tid >> 8) ? ul : uh) + ((tid >> 1) & 127) * DT_PITCH + 16 * (tid & 1);
+    // Nothing may be pending at the loop header: with the operand fetches above possibly in flight there, the compiler's
+    // counted waits inside the depthwise loop become vmcnt(0) - i.e. a wait for the tile's own row prefetch.  (The empty
+    // asm statements make the operands live HERE: without them the fetches are sunk below the barrier, next to their
+    // first use inside the loop.)
+    f16x4 wah[9], wal[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        asm volatile("" : "+v"(wimg[q]));
+        wah[q] = __builtin_shufflevector(wimg[q], wimg[q], 0, 1, 2, 3);
+        wal[q] = __builtin_shufflevector(wimg[q], wimg[q], 4, 5, 6, 7);
+    }
+#pragma unroll
+    for (int mm = 0; mm < 4; ++mm) asm volatile("" : "+v"(ah[mm]));
+    asm volatile("" : "+v"(dbias));
     __syncthreads();
+    DT_MARK(0);                                                   // prologue: operands, first window
 
 #pragma unroll 1
-    for (int t = 0; t < ntiles; ++t) {
-        const int l0 = l_begin + t * DP_TL;
-        const bool has_next = t + 1 < ntiles;
-        // ---- prefetch: the 32 new rows of the next tile, and this tile's residual rows for the epilogue ----
-        f32x4 nxt[2];
-        unsigned nxt_ok = 0;
-        if (has_next) load_pair(l0 + DP_TL, 1, nxt, nxt_ok);
-        const int lrow = l0 + 16 * tb + c;
-        const bool live = lrow < m.L;
-        float* xr = x + (nbase + (long)(live ? lrow : m.L - 1) * m.lstride) * 64 + 16 * ob + 4 * g;
+    for (int it = it0; it < it1; ++it) {
+        const bool more = it + 1 < it1;
+        const DtItem nx = item_of(more ? it + 1 : it);
+#pragma unroll 1
+        for (int t = 0; t < cur.ntiles; ++t) {
+            const int l0 = cur.l_begin + t * DP_TL;
+            const bool has_next = t + 1 < cur.ntiles;             // another tile of this item: its 32 new rows
+            const bool new_item = !has_next && more;              // else the whole first window of the next item
+            // ---- prefetch ----
+            if (has_next) load_pair(cur.ur, l0 + DP_TL + 15, nxt, nxt_ok);
+            if (new_item) {
+                load_pair(nx.ur, nx.l_begin - 17, low, low_ok);
+                load_pair(nx.ur, nx.l_begin + 15, nxt, nxt_ok);
+            }
+            const int lrow = l0 + 16 * tb + c;
+            const bool live = lrow < m.L;
+            const unsigned xo = (unsigned)min(lrow, m.L - 1) * xrowb + xcolb;
+            DT_MARK(1);                                           // prefetch issue
 
-        // ---- depthwise: outputs 4 dj + i (+ 16 for the second half) of channel chn ----
-        if (l0 + 16 < m.L) dt_taps<true>(bhp, blp, wah, wal, dbias, vcol, dj, vth, vtl);
-        else dt_taps<false>(bhp, blp, wah, wal, dbias, vcol, dj, vth, vtl);
-        // epilogue operands (requested before the barrier), and the half of the window the next tile shares with this one
-        // (read before the barrier, written after it)
-        const f32x4 xold = ldg4(xr);
-        f32x4 acc2 = ldg4(b2 + 16 * ob + 4 * g);
-        u32x4 keep[2];
-        if (has_next) {
+            // ---- depthwise: outputs 4 dj + i (+ 16 for the second half) of channel chn ----
+            if (l0 + 16 < m.L) dt_taps<true>(bhp, blp, wah, wal, dbias, vcol, dj, vth, vtl DT_STAMP_PASS);
+            else dt_taps<false>(bhp, blp, wah, wal, dbias, vcol, dj, vth, vtl DT_STAMP_PASS);
+            // epilogue operands (requested before the barrier), and the half of the window the next tile shares with
+            // this one (read before the barrier, written after it)
+            const f32x4 xold = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cur.xr, xo, 0, 0));
+            f32x4 acc2 = ldg4(b2 + 16 * ob + 4 * g);
+            if (has_next) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) keep[k] = *reinterpret_cast<const u32x4*>(krow + 32 + 8 * k);
-        }
-        __syncthreads();                                          // all window reads and v-tile writes are done
+                for (int k = 0; k < 2; ++k) low[k] = *reinterpret_cast<const f32x4*>(krow + 32 + 8 * k);
+            }
+            DT_MARK(4);                                           // epilogue fetch issue, kept-half reads
+            __syncthreads();                                      // all window reads and v-tile writes are done
+            DT_MARK(5);                                           // barrier A
 
-        // ---- pointwise 128 -> 64 on the matrix pipe + bias + residual ----
+            // ---- pointwise 128 -> 64 on the matrix pipe + bias + residual (one accumulator per split term:
+            // consecutive MFMAs never chain) ----
+            f32x4 acc2b = splat4(0.f), acc2c = splat4(0.f);
 #pragma unroll
-        for (int mm = 0; mm < 4; ++mm) {
-            const f16x8 bh = *reinterpret_cast<const f16x8*>(&vth[(16 * tb + c) * DP_VS + 32 * mm + 8 * g]);
-            const f16x8 bl = *reinterpret_cast<const f16x8*>(&vtl[(16 * tb + c) * DP_VS + 32 * mm + 8 * g]);
-            acc2 = mfma32h(ah[mm], bh, acc2);
-            acc2 = mfma32l(ah[mm], bl, acc2);
-            acc2 = mfma32l(*reinterpret_cast<const f16x8*>(alp + mm * 512), bh, acc2);
-        }
-        if (live) stg4(xr, xold + acc2);
-        if (has_next) {
+            for (int mm = 0; mm < 4; ++mm) {
+                const f16x8 bh = *reinterpret_cast<const f16x8*>(vrh + 32 * mm);
+                const f16x8 bl = *reinterpret_cast<const f16x8*>(vrl + 32 * mm);
+                const f16x8 aw = *reinterpret_cast<const f16x8*>(alp + mm * 512);
+                acc2 = mfma32h(ah[mm], bh, acc2);
+                acc2b = mfma32l(ah[mm], bl, acc2b);
+                acc2c = mfma32l(aw, bh, acc2c);
+            }
+            acc2 = acc2 + (acc2b + acc2c);
+            DT_MARK(6);                                           // pointwise product
+            if (live) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xold + acc2), cur.xr, xo, 0, 0);
+            if (has_next) {
 #pragma unroll
-            for (int k = 0; k < 2; ++k) *reinterpret_cast<u32x4*>(krow + 8 * k) = keep[k];
-            store_pair(1, nxt, nxt_ok);
+                for (int k = 0; k < 2; ++k) *reinterpret_cast<f32x4*>(krow + 8 * k) = low[k];
+                store_pair(1, nxt, nxt_ok);
+            }
+            if (new_item) {
+                store_pair(0, low, low_ok);
+                store_pair(1, nxt, nxt_ok);
+            }
+            DT_MARK(7);                                           // store, kept half, split + store of the new rows
+            __syncthreads();                                      // window and v tiles are free for the next tile
+            DT_MARK(8);                                           // barrier B
+#ifdef DT_STAMP
+            ++stamp_tiles;
+#endif
         }
-        __syncthreads();                                          // window and v tiles are free for the next tile
+        cur = nx;
     }
+#ifdef DT_STAMP
+    if (lane == 0) {
+        unsigned long long* slot = g_dt_stamp[(blockIdx.x * 8 + wv) & 2047];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) atomicAdd(&slot[i], sp.acc[i]);
+        atomicAdd(&slot[14], 1ull);
+        atomicAdd(&slot[15], (unsigned long long)stamp_tiles);
+    }
+#endif
 }
+#ifdef DT_STAMP
+}  // namespace X3_NS
+extern "C" int cmgan_dbg_dt_stamps(unsigned long long* out, int reset) {
+    hipDeviceSynchronize();
+    static unsigned long long host[2048][16];
+    hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(X3_NS::g_dt_stamp), sizeof host);
+    for (int i = 0; i < 16; ++i) {
+        out[i] = 0;
+        for (int sl = 0; sl < 2048; ++sl) out[i] += host[sl][i];
+    }
+    if (e == hipSuccess && reset) {
+        for (auto& row : host) for (auto& v : row) v = 0;
+        e = hipMemcpyToSymbol(HIP_SYMBOL(X3_NS::g_dt_stamp), host, sizeof host);
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+namespace X3_NS {
+#endif
 
 // ---------------------------------------------------------------------------------
 // host side
@@ -702,13 +834,17 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
         const int nsegs = (ntl + DS_SEG - 1) / DS_SEG;
         const long items = (long)N * nsegs;
         const unsigned grid = XCD_ORDER ? (unsigned)(((items + 7) / 8) * 8) : (unsigned)items;
-#if DS_TOEPLITZ
-        LAUNCH(ctx, "dwpw2", (dwpw2t_x3_kernel<<<grid, 512, 0, s>>>(b.xb, b.u, w16.dw_img, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
-                                                                   nsegs)));
-#else
-        LAUNCH(ctx, "dwpw2", (dwpw2s_x3_kernel<<<grid, 256, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
-                                                                   nsegs)));
-#endif
+        // dwpw2t: persistent blocks (two per CU) over contiguous ranges of the items.  It addresses the rows of a sequence
+        // with 32-bit byte offsets; a sequence whose rows span 4 GB of u (no shape of this model: 321 x 101 x 512 B =
+        // 17 MB) takes the VALU kernel
+        if (DS_TOEPLITZ && (long)seq.L * seq.lstride * 512 < (1l << 32) && items < (1l << 31)) {
+            const unsigned pgrid = items < 512 ? (unsigned)(((items + 7) / 8) * 8) : 512u;
+            LAUNCH(ctx, "dwpw2", (dwpw2t_x3_kernel<<<pgrid, 512, 0, s>>>(b.xb, b.u, w16.dw_img, w.dw_b, w16.pw2_w, w.pw2_b, seq,
+                                                                        N, nsegs)));
+        } else {
+            LAUNCH(ctx, "dwpw2", (dwpw2s_x3_kernel<<<grid, 256, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
+                                                                       nsegs)));
+        }
     }
     if (taps) {
         hipMemcpyAsync(taps + (size_t)2 * M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
