@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
         o = zero16(); negm = zero16();
         s[0] = sn[0]; s[1] = sn[1];
         if (ASP_ABL == 11) {
-            if (i0 + c16 < L) asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(xo[0]), "v"(oa + ob + xold[0] + bias), "s"(xbase) : "memory");
+            if (i0 + c16 < L) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(xo[0]), "v"(oa + ob + xold[0] + bias), "s"(xbase) : "memory");
             continue;
         }
         ASP_CMARK(2);
@@ -1145,10 +1145,12 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
             // The store is inline asm on purpose: a store the compiler knows about is a second kind of pending vector-memory
             // event at the loop header, and with mixed kinds its s_waitcnt pass stops trusting the return order and waits
             // for vmcnt(0) at the top of every chunk - i.e. for the operand prefetches issued a few instructions earlier.
-            // (Stores only make a counted wait longer, never too short, and nothing here reads x back.)
+            // (Stores only make a counted wait longer, never too short, and nothing here reads x back.  The s_nop is the
+            // one the compiler puts after a 16-byte store it knows about: a VALU write of the data registers within two
+            // wait states corrupts the stored row - seen in dwpw2t_x3_kernel, conformer_x3.hip.)
             const f32x4 xnew = xold[i] + acc;
             if (i0 + 16 * i + c16 < L)
-                asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(xo[i]), "v"(xnew), "s"(xbase) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(xo[i]), "v"(xnew), "s"(xbase) : "memory");
         }
         ASP_CMARK(4);
     }

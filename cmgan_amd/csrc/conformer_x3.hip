@@ -486,6 +486,9 @@ struct DtStamp { unsigned long long t, acc[12]; };
 #define DT_STAMP_PASS
 #endif
 #define DT_PITCH 80
+#ifndef DT_MAPB
+#define DT_MAPB 1                // staging lane map: 1 = 16 position pairs x 2 channel quads per 32-lane store group
+#endif
 #ifndef DT_NB
 #define DT_NB 3                  // chunk buffers of the depthwise loop: reads run DT_NB - 1 steps ahead of their MFMAs
 #endif
@@ -494,15 +497,16 @@ __device__ __forceinline__ f32x4 mfma4l(f16x4 a, f16x4 b, f32x4 c) {       // a 
     return X3_TERMS == 3 ? __builtin_amdgcn_mfma_f32_4x4x4f16(a, b, c, 0, 0, 0) : c;
 }
 // The depthwise of one tile for this wave (one channel group): chunk step s feeds q = s of the first 16 outputs (s <= 8)
-// and q = s - 4 of the second 16 (s >= 4; H1 = false: that half lies beyond the sequence end and is skipped - its v rows
-// keep stale values that feed only outputs which are never stored).  Chunk reads run two steps ahead of their MFMAs.
-// (Dependent 4x4x4 MFMAs issue every 13 cycles, independent ones every 8.5 - tools/probes/mfma4x4_probe.hip; the two halves
-// alternate in the middle steps; a second accumulator per half would cost 8 of the 128 registers four waves per SIMD leave.)
-template <bool H1>
+// and q = s - 4 of the second 16 (s >= 4).  Both halves always: a second half beyond the sequence end - one tile in 11 / in
+// 4 - costs 27 MFMAs (its v rows feed only outputs which are never stored), but a second code path costs EVERY tile a
+// vmcnt(0) at its first MFMA: the structurised CFG has an edge from the end of one path, where the residual-row fetch is
+// pending, to the top of the other.  Chunk reads run DT_NB - 1 steps ahead of their MFMAs.  (Dependent 4x4x4 MFMAs issue
+// every 13 cycles, independent ones every 8.5 - tools/probes/mfma4x4_probe.hip; the two halves alternate in the middle
+// steps; a second accumulator per half would cost 8 of the 128 registers four waves per SIMD leave.)
 __device__ __forceinline__ void dt_taps(const _Float16* bhp, const _Float16* blp, const f16x4 (&wah)[9],
                                         const f16x4 (&wal)[9], float dbias, int vcol, int dj, _Float16* vth,
-                                        _Float16* vtl DT_STAMP_ARG) {
-    constexpr int NS = H1 ? 13 : 9, NH = H1 ? 2 : 1;
+                                        _Float16* vtl, __amdgpu_buffer_rsrc_t xrs, unsigned xo, f32x4& xold DT_STAMP_ARG) {
+    constexpr int NS = 13, NH = 2;
     f32x4 d[2];                                                 // [half]
     d[0] = d[1] = splat4(dbias);
     f16x4 bh[DT_NB], bl[DT_NB];
@@ -528,6 +532,9 @@ __device__ __forceinline__ void dt_taps(const _Float16* bhp, const _Float16* blp
             }
         __builtin_amdgcn_sched_barrier(0);
     }
+    // the residual row of this lane's pointwise output: requested here - the chunk registers are free, and Swish, the
+    // v-tile stores and a barrier lie between the request and its use
+    xold = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, 0, 0));
     DT_MARK(2);                                                 // chunk reads + 4x4x4 MFMAs
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh) {
@@ -571,6 +578,7 @@ __global__ __launch_bounds__(512, 4) void dwpw2t_x3_kernel(float* __restrict__ x
     __shared__ __attribute__((aligned(16))) _Float16 vth[DP_TL * DP_VS];
     __shared__ __attribute__((aligned(16))) _Float16 vtl[DP_TL * DP_VS];
     __shared__ __attribute__((aligned(16))) _Float16 w2l[16 * 64 * 8];      // lo halves of the pointwise operand image
+    __shared__ __attribute__((aligned(16))) float b2l[64];                  // pointwise bias
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef DT_STAMP
@@ -602,10 +610,15 @@ __global__ __launch_bounds__(512, 4) void dwpw2t_x3_kernel(float* __restrict__ x
         return d;
     };
 
-    // staging item of this thread: position PAIR s_pp (of the 16 of a half window) x channel quad s_cq.  A wave fetch is
-    // 8 rows x 128 B; a 32-lane store group is 8 pairs x 4 quads (the quad does not move the bank at this pitch: 4-way,
-    // 16 cycles per ds_write_b32 instead of 4 - eight of them per tile)
+    // staging item of this thread: position PAIR s_pp (of the 16 of a half window) x channel quad s_cq.  The channel quad
+    // does not move the LDS bank at this pitch (160 cq = 0 mod 32), so a 32-lane ds_write_b32 group should span as many
+    // pairs as possible: 16 pairs x 2 quads is 2-way (free); 8 pairs x 4 quads, whose wave fetch is 8 rows x 128 B instead
+    // of 16 rows x 64 B, is 4-way (16 cycles per store instead of 4) and measured 3 - 4 % slower (2.21 vs 2.13 ms)
+#if DT_MAPB
+    const int s_pp = lane & 15, s_cq = (lane >> 4) + 4 * wv;
+#else
     const int s_pp = (lane & 7) + 8 * (wv & 1), s_cq = (lane >> 3) + 8 * (wv >> 1);
+#endif
     // Rows 2 pp, 2 pp + 1 of a half of the window (position p <-> row l0 - 17 + p), addressed as uniform base + 32-bit
     // lane offset (a sequence spans < 2^32 bytes of u: checked by the launcher).  The fetch is unconditional (clamped
     // row); rows outside [0, L) - the convolution's zero padding - are zeroed when the values are USED (a select on the
@@ -657,6 +670,7 @@ __global__ __launch_bounds__(512, 4) void dwpw2t_x3_kernel(float* __restrict__ x
     store_pair(1, nxt, nxt_ok);
 #pragma unroll
     for (int k = 0; k < 2; ++k) *reinterpret_cast<u32x4*>(&w2l[(tid + 512 * k) * 8]) = w2t[k];
+    if (tid < 64) b2l[tid] = b2[tid];
     // depthwise operands: channel group wv
     f16x8 wimg[9];
 #pragma unroll
@@ -713,23 +727,20 @@ __global__ __launch_bounds__(512, 4) void dwpw2t_x3_kernel(float* __restrict__ x
             DT_MARK(1);                                           // prefetch issue
 
             // ---- depthwise: outputs 4 dj + i (+ 16 for the second half) of channel chn ----
-            if (l0 + 16 < m.L) dt_taps<true>(bhp, blp, wah, wal, dbias, vcol, dj, vth, vtl DT_STAMP_PASS);
-            else dt_taps<false>(bhp, blp, wah, wal, dbias, vcol, dj, vth, vtl DT_STAMP_PASS);
-            // epilogue operands (requested before the barrier), and the half of the window the next tile shares with
-            // this one (read before the barrier, written after it)
-            const f32x4 xold = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cur.xr, xo, 0, 0));
-            f32x4 acc2 = ldg4(b2 + 16 * ob + 4 * g);
+            f32x4 xold;
+            dt_taps(bhp, blp, wah, wal, dbias, vcol, dj, vth, vtl, cur.xr, xo, xold DT_STAMP_PASS);
+            // the half of the window the next tile shares with this one (read before the barrier, written after it)
             if (has_next) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) low[k] = *reinterpret_cast<const f32x4*>(krow + 32 + 8 * k);
             }
-            DT_MARK(4);                                           // epilogue fetch issue, kept-half reads
+            DT_MARK(4);                                           // kept-half reads
             __syncthreads();                                      // all window reads and v-tile writes are done
             DT_MARK(5);                                           // barrier A
 
             // ---- pointwise 128 -> 64 on the matrix pipe + bias + residual (one accumulator per split term:
             // consecutive MFMAs never chain) ----
-            f32x4 acc2b = splat4(0.f), acc2c = splat4(0.f);
+            f32x4 acc2 = *reinterpret_cast<const f32x4*>(&b2l[16 * ob + 4 * g]), acc2b = splat4(0.f), acc2c = splat4(0.f);
 #pragma unroll
             for (int mm = 0; mm < 4; ++mm) {
                 const f16x8 bh = *reinterpret_cast<const f16x8*>(vrh + 32 * mm);
@@ -741,7 +752,13 @@ __global__ __launch_bounds__(512, 4) void dwpw2t_x3_kernel(float* __restrict__ x
             }
             acc2 = acc2 + (acc2b + acc2c);
             DT_MARK(6);                                           // pointwise product
-            if (live) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xold + acc2), cur.xr, xo, 0, 0);
+            // (the sum is formed and pinned outside the branch: sunk into it, the wait for the residual row is repeated
+            // after the branch as vmcnt(0), which by then includes the store.  An inline-asm store, as attn_sp_out_x3_kernel
+            // uses, gains nothing here - and without the s_nop the compiler puts after a 16-byte store it knows about, the
+            // next VALU write of the data registers corrupts the stored row: measured, 0.3 relative error)
+            f32x4 xnew = xold + acc2;
+            asm volatile("" : "+v"(xnew));
+            if (live) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, xnew), cur.xr, xo, 0, 0);
             if (has_next) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) *reinterpret_cast<f32x4*>(krow + 8 * k) = low[k];

@@ -50,7 +50,7 @@ def run_segment(u, w, bias, l_begin, ntiles, L):
     out = {}
     for t in range(ntiles):
         l0 = l_begin + 32 * t
-        h1 = l0 + 16 < L
+        h1 = True                             # both halves always (outputs beyond L are computed and never stored)
         for cg in range(8):
             d = [np.tile(bias[16 * cg + (np.arange(64) >> 2)][:, None], (1, 4)) for _ in range(2)]
             for s in range(13):
