@@ -663,10 +663,14 @@ static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float
 #ifndef CX_IMG
 #define CX_IMG 1             // 0 = every layer re-normalises the raw slots (A/B builds)
 #endif
+#ifndef CX_NIMG
+#define CX_NIMG 3            // images written per block: of the block input and of slots 1 .. CX_NIMG - 1 (A/B builds: 1, 2)
+#endif
         if (CX_IMG && x3 && imgs) {
-            for (int s = 0; s < i; ++s) a.in[s] = imgs[s];
-            a.img_mask = (1u << i) - 1u;
-            a.img_out = i < 3 ? imgs[i] : nullptr;
+            const int ni = i < CX_NIMG ? i : CX_NIMG;            // slots 0 .. ni - 1 are read as images
+            for (int s = 0; s < ni; ++s) a.in[s] = imgs[s];
+            a.img_mask = (1u << ni) - 1u;
+            a.img_out = i < CX_NIMG ? imgs[i] : nullptr;
         }
         a.nslots = i + 1;
         a.w = d.w[i]; a.bias = d.bias[i];

@@ -132,6 +132,9 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
 #ifndef CX_WEARLY
 #define CX_WEARLY 1
 #endif
+#ifndef CX_NOWB
+#define CX_NOWB 0            // 1 = TIMING-ONLY ablation: the slot images are not written (later layers read garbage)
+#endif
 #define CX_WFETCH(S)                                                                                     \
     do {                                                                                                 \
         const int chunkf_ = (S) / NT, ktf_ = (S) - chunkf_ * NT;                                         \
@@ -165,7 +168,7 @@ __device__ __forceinline__ const float* sel4(const float* const (&p)[4], int i) 
         } else {                                                                                         \
             const f32x4 am1 = al - splat4(1.f);                                                          \
             /* the newest slot's t-plane stage also stores the image for the block's later layers */     \
-            char* const wb_ = (a.img_out != nullptr && slotw_ == a.nslots - 1 && ktw_ == NT - 1)         \
+            char* const wb_ = (!CX_NOWB && a.img_out != nullptr && slotw_ == a.nslots - 1 && ktw_ == NT - 1) \
                                   ? reinterpret_cast<char*>(a.img_out) + b * clip_bytes + (chunkw_ & 1) * 128 : nullptr; \
             _Pragma("unroll") for (int e = 0; e < NACT; ++e) {                                           \
                 f32x4 v = pre[e];                                                                        \
