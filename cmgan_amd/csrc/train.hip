@@ -4,7 +4,10 @@
 #include "train.h"
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 // ---------------------------------------------------------------------------------
 // loss_ri  = mse(est_real, clean_real) + mse(est_imag, clean_imag)        train.py:135-137
@@ -2360,6 +2363,21 @@ __global__ __launch_bounds__(SLOTS == 1 ? 512 : 768) void at_bwd_fused_kernel(At
         o[128] = accv[d * ROWP + row] * ginv;
     }
 }
+// > 64 KB of dynamic LDS is an opt-in per kernel AND per device; the answer is remembered per (device, kernel), a refusal
+// included (the caller then takes the three-kernel path)
+static bool atf_optin(const void* fn) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, bool> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = done.find({dev, fn});
+    if (it != done.end()) return it->second;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) (void)hipGetLastError();               // clear the sticky error: the fallback path is valid
+    done[{dev, fn}] = (e == hipSuccess);
+    return e == hipSuccess;
+}
 static size_t atf_lds_bytes(int nbp, int nw) { return ((size_t)3 * 16 * (16 * nbp + 4) + (size_t)nw * ATF_PATCH) * sizeof(float); }
 
 // rel_pos_emb gradient [2 max_pos + 1][16] from the (n, h)-summed diagonal slabs [2 nb - 1][32][16]: row e sums, in
@@ -2552,21 +2570,18 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     const unsigned cgrid = at_core_grid(ntask);
     const char* bwd_env = getenv("CMGAN_ATTN_BWD");               // read per launch: tests switch it inside one process
     const bool fused_env = !(bwd_env != nullptr && strcmp(bwd_env, "cores") == 0);
-    if (fused_env && nb <= ATF_MAX_NB) {
-        const int nbp = nb | 1, slots = nbp <= 8 ? 1 : 2, nw = (nbp + slots - 1) / slots;   // <= 8 / <= 12 waves
+    const int nbp = nb | 1, slots = nbp <= 8 ? 1 : 2, nw = (nbp + slots - 1) / slots;       // <= 8 / <= 12 waves
+    // the fused kernel needs more than 64 KB of dynamic LDS: opted into once per (device, instantiation); if the runtime
+    // refuses, the three cores run instead (same results)
+    const bool fused_ok = fused_env && nb <= ATF_MAX_NB &&
+                          atf_optin(slots == 1 ? reinterpret_cast<const void*>(&at_bwd_fused_kernel<1>)
+                                               : reinterpret_cast<const void*>(&at_bwd_fused_kernel<2>));
+    if (fused_ok) {
         const size_t lds = atf_lds_bytes(nbp, nw);
 #define ATF_LAUNCH(SL)                                                                                                     \
-        do {                                                                                                               \
-            static bool optin = false;                                                                                     \
-            if (!optin) {                                                                                                  \
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&at_bwd_fused_kernel<SL>),                               \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                               \
-                optin = true;                                                                                              \
-            }                                                                                                              \
-            LAUNCH(ctx, "attn_train_bwd", (at_bwd_fused_kernel<SL><<<(N + 7) / 8 * 32, 64 * nw, lds, s>>>(                  \
-                                              b, ws + pl.ewin, ws + pl.ewinp, ws + pl.dO, ws + pl.dOp, ws + pl.D, cpart, N, \
-                                              L, nb, nbp, ws + pl.dqkv, ws + pl.depart)));                                 \
-        } while (0)
+        LAUNCH(ctx, "attn_train_bwd", (at_bwd_fused_kernel<SL><<<(N + 7) / 8 * 32, 64 * nw, lds, s>>>(                      \
+                                          b, ws + pl.ewin, ws + pl.ewinp, ws + pl.dO, ws + pl.dOp, ws + pl.D, cpart, N, L,  \
+                                          nb, nbp, ws + pl.dqkv, ws + pl.depart)))
         if (slots == 1) ATF_LAUNCH(1);
         else ATF_LAUNCH(2);
 #undef ATF_LAUNCH

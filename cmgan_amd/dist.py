@@ -113,8 +113,22 @@ def broadcast_from_rank0(tensors) -> None:
         return
     if isinstance(tensors, torch.Tensor):
         tensors = [tensors]
+    # one collective per (device, dtype) group, not one per tensor: the per-step buffer broadcast is ~38 tensors of a few
+    # hundred bytes (BatchNorm statistics, spectral-norm vectors) - latency, not bytes
+    groups = {}
     for t in tensors:
-        dist.broadcast(t, src=0)
+        groups.setdefault((t.device, t.dtype), []).append(t)
+    for group in groups.values():
+        if len(group) == 1:
+            dist.broadcast(group[0], src=0)
+            continue
+        flat = torch.cat([t.detach().reshape(-1) for t in group])
+        dist.broadcast(flat, src=0)
+        off = 0
+        for t in group:
+            n = t.numel()
+            t.detach().copy_(flat[off:off + n].view_as(t))
+            off += n
 
 
 def all_agree(flag: bool, device="cpu") -> bool:
