@@ -607,6 +607,10 @@ static int conformer_forward_impl(cmgan_handle* h, int index, const float* x, in
                                   float* y, float* taps, void* ws, size_t ws_bytes, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !y || N <= 0 || L <= 0 || index < 0 || index >= 8) return fail(h, CMGAN_E_BADARG, "cmgan_conformer_forward: bad argument");
+    // the split-f16 conv-module kernel addresses the rows of a sequence with 32-bit byte offsets (512 B per row of the GLU
+    // output) and counts the 32-position tiles of a call in an int
+    if ((long)L * 512 >= (1l << 32) || (long)N * ((L + 31) / 32) >= (1l << 31))
+        return fail(h, CMGAN_E_BADARG, "cmgan_conformer_forward: N x L too large (L < 2^23, N * ceil(L / 32) < 2^31)");
     const ConfPlan p = plan_conf(N, L);
     if (int rc = check_ws(h, ws, ws_bytes, p.total * sizeof(float))) return rc;
     ConfWeights w;
@@ -685,6 +689,10 @@ static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float
 static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* out_re, float* out_im,
                        const cmgan_taps* taps, void* ws, size_t ws_bytes, void* stream, bool reset_prof) {
     if (!spec || !out_re || !out_im || B <= 0 || T <= 0) return fail(h, CMGAN_E_BADARG, "tscnet_forward: bad argument");
+    // a time-axis sequence is T rows F2 rows apart: the conv-module kernel addresses them with 32-bit byte offsets
+    // (512 B per row of the GLU output) - 83 k frames per clip at F = 201
+    if ((long)T * ((h->cfg.num_features + 1) / 2) * 512 >= (1l << 32))
+        return fail(h, CMGAN_E_BADARG, "tscnet_forward: T too large (T * ceil(F / 2) * 512 must stay below 2^32)");
     const WsPlan p = plan_ws(h->cfg, B, T);
     if (int rc = check_ws(h, ws, ws_bytes, p.total * sizeof(float))) return rc;
     const int F = h->cfg.num_features, F2 = (F + 1) / 2, W2 = 2 * F2;

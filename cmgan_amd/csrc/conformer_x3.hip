@@ -233,6 +233,7 @@ __global__ __launch_bounds__(512) void pw1glu_x3_kernel(const float* __restrict_
 #ifndef DS_TOEPLITZ
 #define DS_TOEPLITZ 1        // 1: dwpw2t_x3_kernel (depthwise taps as banded-Toeplitz operands of the 4x4x4 MFMA); 0: this kernel
 #endif
+#if !DS_TOEPLITZ              // the VALU kernel is an A/B build only (-DDS_TOEPLITZ=0): it is not in the product library
 #ifndef DS_OCC
 #define DS_OCC 2             // blocks (= waves per SIMD) the register allocation is sized for
 #endif
@@ -437,6 +438,7 @@ __global__ __launch_bounds__(256, DS_OCC) void dwpw2s_x3_kernel(float* __restric
         __syncthreads();                                          // window and v tiles are free for the next tile
     }
 }
+#endif  // !DS_TOEPLITZ
 
 // ---------------------------------------------------------------------------------
 // dwpw2t_x3_kernel: dwpw2s_x3_kernel with the 31-tap depthwise on the MATRIX pipe (the default).
@@ -850,18 +852,17 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
     {
         const int nsegs = (ntl + DS_SEG - 1) / DS_SEG;
         const long items = (long)N * nsegs;
+#if DS_TOEPLITZ
+        // persistent blocks (two per CU) over contiguous ranges of the items.  The kernel addresses the rows of a sequence
+        // with 32-bit byte offsets: api.hip rejects shapes whose sequences span 4 GB of u (83 k frames per clip)
+        const unsigned pgrid = items < 512 ? (unsigned)(((items + 7) / 8) * 8) : 512u;
+        LAUNCH(ctx, "dwpw2", (dwpw2t_x3_kernel<<<pgrid, 512, 0, s>>>(b.xb, b.u, w16.dw_img, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
+                                                                    nsegs)));
+#else
         const unsigned grid = XCD_ORDER ? (unsigned)(((items + 7) / 8) * 8) : (unsigned)items;
-        // dwpw2t: persistent blocks (two per CU) over contiguous ranges of the items.  It addresses the rows of a sequence
-        // with 32-bit byte offsets; a sequence whose rows span 4 GB of u (no shape of this model: 321 x 101 x 512 B =
-        // 17 MB) takes the VALU kernel
-        if (DS_TOEPLITZ && (long)seq.L * seq.lstride * 512 < (1l << 32) && items < (1l << 31)) {
-            const unsigned pgrid = items < 512 ? (unsigned)(((items + 7) / 8) * 8) : 512u;
-            LAUNCH(ctx, "dwpw2", (dwpw2t_x3_kernel<<<pgrid, 512, 0, s>>>(b.xb, b.u, w16.dw_img, w.dw_b, w16.pw2_w, w.pw2_b, seq,
-                                                                        N, nsegs)));
-        } else {
-            LAUNCH(ctx, "dwpw2", (dwpw2s_x3_kernel<<<grid, 256, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
-                                                                       nsegs)));
-        }
+        LAUNCH(ctx, "dwpw2", (dwpw2s_x3_kernel<<<grid, 256, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
+                                                                   nsegs)));
+#endif
     }
     if (taps) {
         hipMemcpyAsync(taps + (size_t)2 * M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
