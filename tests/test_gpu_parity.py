@@ -199,6 +199,16 @@ def test_conformer_rel_pos_clamp_beyond_512(conf):
     assert _report("conformer[n=600].out", rel_err(y, want)) < STAGE
 
 
+def test_oversized_sequences_are_rejected_before_any_launch(conf):
+    """The conv-module kernel addresses the rows of a sequence with 32-bit byte offsets: a call whose sequences would
+    overflow them fails loudly at the C ABI (CMGAN_E_BADARG + a message), before the workspace is even looked at."""
+    eng = conf.engine
+    x = torch.zeros(64, device=DEV)
+    rc = eng.lib.cmgan_conformer_forward(eng._h, 0, x.data_ptr(), 1, 1 << 23, x.data_ptr(), None, None, 0, None)
+    assert rc == -1
+    assert b"too large" in eng.lib.cmgan_last_error(eng._h)
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("gain", [40.0, 0.02])
 def test_attention_softmax_rereference_branch(mode, gain):
