@@ -114,12 +114,17 @@ def _ddp_semantics_worker(rank, world, port, ret):
     gen_p = cdist.FlatBucket({"w": (1000, 64)})             # stand-ins of different sizes, like 7.3 MB vs 0.7 MB
     disc_p = cdist.FlatBucket({"w": (300,)})
     gen_g, disc_g = cdist.FlatBucket({"w": (1000, 64)}), cdist.FlatBucket({"w": (300,)})
-    buffers = [torch.full((128,), float(rank + 5)), torch.full((16,), float(rank - 3))]
+    # mixed shapes AND dtypes, as a model's buffers are (running statistics, spectral-norm vectors, the int64
+    # num_batches_tracked): broadcast_from_rank0 sends one collective per (device, dtype) group and scatters it back
+    buffers = [torch.full((128,), float(rank + 5)), torch.full((16,), float(rank - 3)), torch.full((2, 3), float(rank)),
+               torch.tensor(100 + rank, dtype=torch.int64), torch.full((4,), 7 * rank, dtype=torch.int64)]
     gen_p.flat.fill_(float(rank + 1))                       # every rank was handed a DIFFERENT state dict
     disc_p.flat.fill_(float(10 * rank + 2))
     cdist.broadcast_from_rank0([gen_p.flat, disc_p.flat])   # Trainer.__init__
     cdist.broadcast_from_rank0(buffers)
     ok = float(gen_p.flat[0]) == 1.0 and float(disc_p.flat[7]) == 2.0 and float(buffers[0][3]) == 5.0
+    ok = ok and float(buffers[1][0]) == -3.0 and buffers[2].shape == (2, 3) and float(buffers[2].sum()) == 0.0
+    ok = ok and int(buffers[3]) == 100 and buffers[3].dtype == torch.int64 and buffers[4].tolist() == [0, 0, 0, 0]
     disc_steps = 0
     for step in range(3):
         buffers[0] += rank                                  # running statistics drift apart between steps ...
