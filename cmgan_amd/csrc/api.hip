@@ -607,10 +607,12 @@ static int conformer_forward_impl(cmgan_handle* h, int index, const float* x, in
                                   float* y, float* taps, void* ws, size_t ws_bytes, void* stream) {
     if (!h) return CMGAN_E_BADARG;
     if (!x || !y || N <= 0 || L <= 0 || index < 0 || index >= 8) return fail(h, CMGAN_E_BADARG, "cmgan_conformer_forward: bad argument");
-    // the split-f16 conv-module kernel addresses the rows of a sequence with 32-bit byte offsets (512 B per row of the GLU
-    // output) and counts the 32-position tiles of a call in an int
-    if ((long)L * 512 >= (1l << 32) || (long)N * ((L + 31) / 32) >= (1l << 31))
-        return fail(h, CMGAN_E_BADARG, "cmgan_conformer_forward: N x L too large (L < 2^23, N * ceil(L / 32) < 2^31)");
+    if ((long)N * L >= (1l << 31)) return fail(h, CMGAN_E_BADARG, "cmgan_conformer_forward: N x L too large");
+    const TokMap seq = make_seq_map(N, L, 1, L, 0, 1);
+    // the split-f16 kernels' own addressing limit (conformer_x3.hip, next to the kernel that has it); none in F32 mode
+    if (h->cfg.mfma_mode != CMGAN_MFMA_F32 && !conformer_x3_addressable(seq))
+        return fail(h, CMGAN_E_BADARG, "cmgan_conformer_forward: N x L too large for the split-f16 kernels "
+                                       "(L < 2^23, N * ceil(L / 32) < 2^31)");
     const ConfPlan p = plan_conf(N, L);
     if (int rc = check_ws(h, ws, ws_bytes, p.total * sizeof(float))) return rc;
     ConfWeights w;
@@ -620,7 +622,6 @@ static int conformer_forward_impl(cmgan_handle* h, int index, const float* x, in
     hipStream_t s = (hipStream_t)stream;
     const size_t M = (size_t)N * L;
     HIPCHK(h, hipMemcpyAsync(b.xa, x, M * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    const TokMap seq = make_seq_map(N, L, 1, L, 0, 1);
     if (h->cfg.mfma_mode != CMGAN_MFMA_F32) {
         ConfWeightsX3 w16;
         if (!conf_weights_x3(h, index, w16)) return CMGAN_E_WEIGHTS;
@@ -652,6 +653,12 @@ static bool dense_weights(cmgan_handle* h, int grp, DenseW& d) {
 // F16X3 mode (imgs != null): layer i is the FIRST consumer of its newest input (x0 for i = 0, else slot i - 1): it
 // normalises it on load as before and also stores its split-fp16 image (imgs[i], i < 3); layers i + 1 .. 3 read that
 // image instead of the raw slot - same values to the bit, without the per-re-read normalise / PReLU / split.
+#ifndef CX_IMG
+#define CX_IMG 1             // 0 = every layer re-normalises the raw slots (A/B builds)
+#endif
+#ifndef CX_NIMG
+#define CX_NIMG 3            // images written per block: of the block input and of slots 1 .. CX_NIMG - 1 (A/B builds: 1, 2)
+#endif
 typedef void (*Conv3xFn)(LaunchCtx, const ConvArgs&, const void*, int, int, int);
 static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float* x0, const float* x0_scale,
                             const float* x0_shift, const float* x0_alpha, float* const slots[4], float* partials,
@@ -664,12 +671,6 @@ static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float
         for (int s = 1; s <= i; ++s) {
             a.in[s] = slots[s - 1]; a.nscale[s] = nsc[s - 1]; a.nshift[s] = nsh[s - 1]; a.nalpha[s] = d.prelu[s - 1];
         }
-#ifndef CX_IMG
-#define CX_IMG 1             // 0 = every layer re-normalises the raw slots (A/B builds)
-#endif
-#ifndef CX_NIMG
-#define CX_NIMG 3            // images written per block: of the block input and of slots 1 .. CX_NIMG - 1 (A/B builds: 1, 2)
-#endif
         if (CX_IMG && x3 && imgs) {
             const int ni = i < CX_NIMG ? i : CX_NIMG;            // slots 0 .. ni - 1 are read as images
             for (int s = 0; s < ni; ++s) a.in[s] = imgs[s];
@@ -689,9 +690,9 @@ static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float
 static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* out_re, float* out_im,
                        const cmgan_taps* taps, void* ws, size_t ws_bytes, void* stream, bool reset_prof) {
     if (!spec || !out_re || !out_im || B <= 0 || T <= 0) return fail(h, CMGAN_E_BADARG, "tscnet_forward: bad argument");
-    // a time-axis sequence is T rows F2 rows apart: the conv-module kernel addresses them with 32-bit byte offsets
-    // (512 B per row of the GLU output) - 83 k frames per clip at F = 201
-    if ((long)T * ((h->cfg.num_features + 1) / 2) * 512 >= (1l << 32))
+    // a time-axis sequence is T rows F2 rows apart: the split-f16 conv-module kernel addresses them with 32-bit byte
+    // offsets (conformer_x3_addressable, conformer_x3.hip: 83 k frames per clip at F = 201); the fp32 kernels have no limit
+    if (h->cfg.mfma_mode != CMGAN_MFMA_F32 && (long)(T - 1) * ((h->cfg.num_features + 1) / 2) * 512 + 512 >= (1l << 32))
         return fail(h, CMGAN_E_BADARG, "tscnet_forward: T too large (T * ceil(F / 2) * 512 must stay below 2^32)");
     const WsPlan p = plan_ws(h->cfg, B, T);
     if (int rc = check_ws(h, ws, ws_bytes, p.total * sizeof(float))) return rc;

@@ -196,11 +196,12 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 mfma32h(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
-// X3_TERMS = 3 (the product): hi*hi + hi*lo + lo*hi.  X3_TERMS = 1 is a MEASUREMENT-ONLY build (cmgan_amd.build
-// variant "x1", never the shipped library): every product term that involves a lo half is compiled out, i.e. plain
-// fp16 operands with fp32 accumulation - the "single-product half precision" mode BASELINE.json's configs[1] names
-// ("TSCNet bf16"; fp16 has 3 more mantissa bits than bf16).  Its speed and its error against the oracle are quoted
-// once in DESIGN.md section 7; it does not meet the fp32-class bar, which is why it is not a library mode.
+// X3_TERMS = 3 (the product): hi*hi + hi*lo + lo*hi.  X3_TERMS = 1 (with -DX3_SINGLE; cmgan_amd/build.py compiles the
+// three x3 kernel files a second time this way into the `_x1` entry points) is the shipped, OPT-IN, reduced-precision
+// mode CMGAN_MFMA_F16X1: every product term that involves a lo half is compiled out, i.e. plain fp16 operands with
+// fp32 accumulation - the "single-product half precision" mode BASELINE.json's configs[1] names ("TSCNet bf16"; fp16
+// has 3 more mantissa bits than bf16).  6e-4 .. 9e-4 from the reference: inside the 1e-3 gate without margin, not
+// fp32-class, never the default (include/cmgan_hip.h; tests/test_gpu_parity.py::test_f16x1_mode_error_bands).
 #ifndef X3_TERMS
 #define X3_TERMS 3
 #endif

@@ -825,8 +825,15 @@ static int ffn_grid(int ntiles, int waves = FFN_WAVES) {  // one persistent Feed
     return want < 256 ? (want > 0 ? want : 1) : 256;
 }
 
-void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeightsX3& w16, const ConfBuffers& b,
+bool conformer_x3_addressable(const TokMap& seq) {
+    const long N = seq.nblocks / seq.Lb;
+    const long span = (long)(seq.L - 1) * seq.lstride + 1;       // rows between a sequence's first and last token
+    return span * 512 < (1l << 32) && N * ((seq.L + 31) / 32) < (1l << 31);
+}
+
+bool conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeightsX3& w16, const ConfBuffers& b,
                           const TokMap& seq, long M, float* taps, bool outer_residual, const unsigned char* mask) {
+    if (!conformer_x3_addressable(seq)) return false;
     hipStream_t s = ctx.stream;
     const int N = seq.nblocks / seq.Lb;
     const int flat_blocks = (int)((M + 15) / 16);
@@ -854,7 +861,7 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
         const long items = (long)N * nsegs;
 #if DS_TOEPLITZ
         // persistent blocks (two per CU) over contiguous ranges of the items.  The kernel addresses the rows of a sequence
-        // with 32-bit byte offsets: api.hip rejects shapes whose sequences span 4 GB of u (83 k frames per clip)
+        // with 32-bit byte offsets: conformer_x3_addressable (top of this function) rejects shapes whose sequences span 4 GB of u
         const unsigned pgrid = items < 512 ? (unsigned)(((items + 7) / 8) * 8) : 512u;
         LAUNCH(ctx, "dwpw2", (dwpw2t_x3_kernel<<<pgrid, 512, 0, s>>>(b.xb, b.u, w16.dw_img, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
                                                                     nsegs)));
@@ -873,6 +880,7 @@ void conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
     LAUNCH(ctx, "ffn_post", (ffn_x3_kernel<true, 2, FFN_POST_WAVES><<<ffn_grid(flat_tiles, FFN_POST_WAVES), 64 * FFN_POST_WAVES, 0, s>>>(
                                 b.xb, b.xa, outer_residual ? b.xa : nullptr, w.post_gb, w16.ff2_w1, w.ff2_b1,
                                 w16.ff2_w2, w.ff2_b2, M, flat_tiles)));
+    return true;
 }
 
 #ifndef X3_SINGLE

@@ -132,7 +132,11 @@ struct ConfWeightsX3 {
     const _Float16* dw_img;     // [8 channel groups][9][64 lanes][hi 4 | lo 4]: Toeplitz operands of the depthwise taps (dwpw2t_x3_kernel)
     const _Float16* rel_planes; // 4 x [2*max_pos+1 rows, reversed][8 halfs]: hi d0-7 | hi d8-15 | lo d0-7 | lo d8-15 (attn32_x3.hip)
 };
-void conformer_forward_x3(LaunchCtx, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&, const TokMap& seq,
+// Returns false WITHOUT launching anything when the shape is outside what the split-f16 conv-module kernel can address
+// (dwpw2t_x3_kernel: buffer descriptor + 32-bit lane byte offsets over a sequence's rows of the GLU output, 512 B each;
+// the 32-position tiles of a call counted in an int) - the limit lives with the kernel, every caller gets it.
+bool conformer_x3_addressable(const TokMap& seq);
+bool conformer_forward_x3(LaunchCtx, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&, const TokMap& seq,
                           long M, float* taps, bool outer_residual, const unsigned char* mask = nullptr);
 void launch_dwconv(LaunchCtx, const float* u, float* out, const float* dw_w, const float* dw_b, const TokMap& seq);
 // attn32_x3.hip: the x3 attention on 32x32x16 MFMAs (32-token Q / K / V tile images) + to_out + residual
@@ -156,7 +160,7 @@ void launch_selftest_mfma(hipStream_t, const float* a_fm, const float* b_fm, flo
 // conformer_x3.hip, attn32_x3.hip and conv_x3.hip are compiled a second time with -DX3_SINGLE -DX3_TERMS=1
 // (cmgan_amd/build.py): every product term with a lo operand is compiled out and operands are rounded to nearest
 // (common.hip.h), kernels live in their own namespace, and the host entry points take the _x1 names below.
-void conformer_forward_x1(LaunchCtx, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&, const TokMap& seq,
+bool conformer_forward_x1(LaunchCtx, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&, const TokMap& seq,
                           long M, float* taps, bool outer_residual, const unsigned char* mask = nullptr);
 void launch_qkv32_x1(LaunchCtx, const float* x, const TokMap& seq, const _Float16* wi, const float* b,
                      _Float16* qimg, _Float16* kimg, _Float16* vimg);
@@ -170,6 +174,7 @@ void launch_conv3_x1(LaunchCtx, const ConvArgs&, const void* w16, int B, int tim
 #ifdef X3_SINGLE
 #define X3_NS x1k
 #define conformer_forward_x3 conformer_forward_x1
+#define conformer_x3_addressable conformer_x1_addressable
 #define launch_qkv32_x3 launch_qkv32_x1
 #define launch_attn32_out_x3 launch_attn32_out_x1
 #define launch_attn_sp_out_x3 launch_attn_sp_out_x1

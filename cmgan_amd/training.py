@@ -1487,6 +1487,33 @@ class Trainer:
         self.log(f"GPU: {self.engine.device}, Generator loss: {gen_total / steps}, Discriminator loss: {disc_total / steps}")
         return gen_total / steps
 
+    def resume_state(self) -> Dict[str, object]:
+        """Everything a restarted run needs to CONTINUE this one bit for bit (the reference only saves the generator
+        state_dict, train.py:268-274, and so restarts its optimisers and dropout streams): both parameter buckets, both
+        AdamW states, the non-parameter buffers, the epoch counter and the keep-mask stream offsets of the generator
+        (`GeneratorTrain.mask_rng_offsets`) - without the last a resumed run would repeat the mask sequence from 0."""
+        opt = lambda o: {"exp_avg": o.exp_avg.cpu().clone(), "exp_avg_sq": o.exp_avg_sq.cpu().clone(),
+                         "state": o.state.cpu().clone()}
+        return {"gen_params": self.gen.param_bucket.flat.cpu().clone(),
+                "disc_params": self.disc.param_bucket.flat.cpu().clone(),
+                "opt_gen": opt(self.optimizer), "opt_disc": opt(self.optimizer_disc),
+                "buffers": [b.cpu().clone() for b in self.buffers()],
+                "epoch": int(self.epoch), "mask_rng_offsets": self.gen.mask_rng_offsets()}
+
+    def load_resume_state(self, state: Dict[str, object]) -> None:
+        """In place (captured graphs keep their pointers): the inverse of `resume_state`."""
+        self.gen.param_bucket.flat.copy_(state["gen_params"])
+        self.disc.param_bucket.flat.copy_(state["disc_params"])
+        for o, st in ((self.optimizer, state["opt_gen"]), (self.optimizer_disc, state["opt_disc"])):
+            o.exp_avg.copy_(st["exp_avg"])
+            o.exp_avg_sq.copy_(st["exp_avg_sq"])
+            o.state.copy_(st["state"])
+            o.lr = float(st["state"][0])
+        for b, v in zip(self.buffers(), state["buffers"]):
+            b.copy_(v)
+        self.epoch = int(state["epoch"])
+        self.gen.set_mask_rng_offsets(state["mask_rng_offsets"])
+
     def train(self, epochs: int, save_model_dir: Optional[str] = None, rank: Optional[int] = None) -> list:
         """train.py:247-275.  Returns the per-epoch validation losses; rank 0 (of the initialised process group unless
         `rank` is given, like the reference's `gpu_id == 0`) writes the generator checkpoints."""

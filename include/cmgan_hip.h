@@ -61,8 +61,9 @@ typedef struct cmgan_config {
     int32_t mfma_mode;     /* CMGAN_MFMA_F32, CMGAN_MFMA_F16X3 (default) or _F16X1  */
 } cmgan_config;
 
-/* How the dense contractions (convs, linears, attention) are evaluated - both keep fp32
- * storage and fp32 accumulation, and both meet the 1e-3 parity gate by >2 decades:
+/* How the dense contractions (convs, linears, attention) are evaluated.  Three modes; all keep fp32 storage and
+ * fp32 accumulation.  The first two are fp32-class and meet the 1e-3 parity gate by >2 decades; the third (F16X1,
+ * below) is an opt-in reduced-precision mode that sits inside the gate without margin:
  *   F32   : v_mfma_f32_16x16x4_f32, bit-exact fp32 products (157 TF peak)
  *   F16X3 : every operand split x = hi + lo in fp16 and the product evaluated as
  *           hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 (~2^-21 relative product error,

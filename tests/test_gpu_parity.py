@@ -205,6 +205,10 @@ def test_oversized_sequences_are_rejected_before_any_launch(conf):
     eng = conf.engine
     x = torch.zeros(64, device=DEV)
     rc = eng.lib.cmgan_conformer_forward(eng._h, 0, x.data_ptr(), 1, 1 << 23, x.data_ptr(), None, None, 0, None)
+    assert rc < 0
+    if eng.mfma_mode == "f32":          # the fp32 kernels have no such limit: the call gets as far as the (missing) workspace
+        assert b"too large" not in eng.lib.cmgan_last_error(eng._h)
+        rc = eng.lib.cmgan_conformer_forward(eng._h, 0, x.data_ptr(), 1 << 12, 1 << 19, x.data_ptr(), None, None, 0, None)
     assert rc == -1
     assert b"too large" in eng.lib.cmgan_last_error(eng._h)
 
@@ -226,6 +230,57 @@ def test_attention_softmax_rereference_branch(mode, gain):
     y, taps = blk.forward_with_taps(x.to(DEV))
     assert _report(f"attn re-reference gain={gain} [{mode}]", rel_err(taps[1], st["attn"])) < STAGE
     assert _report(f"conformer out gain={gain} [{mode}]", rel_err(y, want)) < STAGE
+
+
+X1_GATE = 3e-3     # the opt-in single-product mode's own band (test_f16x1_mode_error_bands); never the parity gate
+
+
+def test_f16x1_kernels_on_edge_shapes_mask_clamp_and_rereference():
+    """The F16X1 mode is a SECOND, separately compiled copy of every conformer / attention kernel (other register
+    allocation, FFN_POST_WAVES = 8): the ragged shapes (L = 1, 16, 17, 64, 65), the masked attention path, the > 512
+    relative-position clamp and the forced softmax re-reference branch run on those copies too, each against the
+    oracle at the mode's own gate - an indexing error shows as O(1), the mode's rounding as < 1e-3."""
+    from cmgan_amd import ConformerBlock
+    csd = conformer_state_dict(seed=3)
+    mk = lambda sd_: ConformerBlock(dim=64, dim_head=16, heads=4, conv_kernel_size=31, mfma_mode="f16x1").load_state_dict(sd_).eval()
+    blk = mk(csd)
+    assert blk.engine.mfma_mode == "f16x1"
+    for n, l in [(5, 101), (3, 321), (2, 16), (2, 17), (1, 1), (7, 64), (4, 65)]:
+        x = torch.from_numpy(np.random.Generator(np.random.PCG64(100 + l)).standard_normal((n, l, 64)).astype(np.float32))
+        st = {}
+        want = O.conformer_block(csd, "", x, st)
+        y, taps = blk.forward_with_taps(x.to(DEV))
+        for i, name in enumerate(("ff1", "attn", "conv", "ff2")):
+            assert _report(f"x1 conformer[{n}x{l}].{name}", rel_err(taps[i], st[name])) < X1_GATE, (n, l, name)
+        assert _report(f"x1 conformer[{n}x{l}].out", rel_err(y, want)) < X1_GATE
+    g = load_golden("conformer_mask.npz")
+    assert _report("x1 conformer(x, mask) vs golden", rel_err(blk(g["x"].to(DEV), mask=g["mask"].bool().to(DEV)), g["out"])) < X1_GATE
+    for n, l, seed in [(3, 321, 1), (5, 101, 2), (2, 130, 3)]:
+        rng = np.random.Generator(np.random.PCG64(500 + seed))
+        x = torch.from_numpy(rng.standard_normal((n, l, 64)).astype(np.float32))
+        mask = torch.from_numpy(rng.random((n, l)) > 0.3)
+        mask[0, :min(l, 70)] = False
+        mask[0, -1] = True
+        want = O.conformer_block(csd, "", x, mask=mask)
+        assert _report(f"x1 conformer[{n}x{l}](x, mask)", rel_err(blk(x.to(DEV), mask=mask.to(DEV)), want)) < X1_GATE
+    g = load_golden("attention_long.npz")
+    st = {}
+    want = O.conformer_block(csd, "", g["x"], st)
+    y, taps = blk.forward_with_taps(g["x"].to(DEV))
+    assert _report("x1 conformer[n=600].attn (clamp)", rel_err(taps[1], st["attn"])) < X1_GATE
+    assert _report("x1 conformer[n=600].out", rel_err(y, want)) < X1_GATE
+    for gain in (40.0, 0.02):
+        c2 = dict(csd)
+        c2["attn.fn.to_q.weight"] = c2["attn.fn.to_q.weight"] * gain
+        b2 = mk(c2)
+        x = torch.from_numpy(np.random.Generator(np.random.PCG64(77)).standard_normal((3, 200, 64)).astype(np.float32))
+        st = {}
+        want = O.conformer_block(c2, "", x, st)
+        y, taps = b2.forward_with_taps(x.to(DEV))
+        # a x40 score gain makes the softmax peaky: fp16 rounding of q / k moves scores by ~|s| 2^-11, so the band widens
+        gate = X1_GATE if gain < 1 else 3e-2
+        assert _report(f"x1 attn re-reference gain={gain}", rel_err(taps[1], st["attn"])) < gate
+        assert _report(f"x1 conformer out gain={gain}", rel_err(y, want)) < gate
 
 
 # ------------------------------------------------------------------ generator
@@ -456,6 +511,26 @@ def test_one_row_of_the_full_config2_batch_matches_the_oracle_directly(model, sd
     out = model.engine.enhance(wav.to(DEV))
     want = O.enhance_batch(sd, wav[17:18])
     _check("config-2 batch, row 17 vs oracle", out[17:18], want)
+
+
+def test_full_size_clips_match_the_references_own_modules(model, sd):
+    """T = 321 (2 s): the HIP path against oracle/_ref - the reference repo's OWN TSCNet / power_compress /
+    power_uncompress (bytecode built from /root/reference by oracle/make_ref.py; travels to the GPU box) behind the
+    src/evaluation.py:21-53 glue - not against the port.  Rows 0 and 31 of the benchmark batch plus a ragged track
+    through enhance_one_track."""
+    from oracle import ref_runner as R
+    from cmgan_amd.evaluation import enhance_one_track
+    if not R.available():
+        pytest.skip("oracle/_ref not built")
+    ref = R.tscnet(sd)
+    wav = synthetic_clips(32, 32000, seed=7)
+    out = model.engine.enhance(wav.to(DEV))
+    for row in (0, 31):
+        _check(f"config-2 batch, row {row} vs the reference modules", out[row:row + 1],
+               R.enhance_batch(ref, wav[row:row + 1]))
+    noisy = synthetic_clips(1, 32000 + 1234, seed=9)
+    _check("ragged 2.08 s track vs the reference's enhance_one_track glue",
+           enhance_one_track(model, noisy.to(DEV)).flatten(), R.enhance(ref, noisy))
 
 
 @pytest.mark.parametrize("mode", MODES)

@@ -637,7 +637,8 @@ def test_generator_train_step_matches_the_reference_trainer():
                    rel_err(out_sd["TSCB_2.freq_conformer.conv.net.5.running_var"], g["bn_var"])) < 1e-3
 
 
-def _whole_step_vs_oracle(sd, clean, noisy, npm, tag, bar, n_fft=400, hop=100, loss_weights=(0.1, 0.9, 0.2)):
+def _whole_step_vs_oracle(sd, clean, noisy, npm, tag, bar, n_fft=400, hop=100, loss_weights=(0.1, 0.9, 0.2),
+                          allow_cancelling=()):
     """One generator optimisation step on the HIP path against autograd through the oracle on the same state dict,
     clips and dropout masks: loss terms, network outputs, output gradients and ALL parameter gradients, each tensor
     held to `bar` relative to its own maximum (worst tensor reported)."""
@@ -664,14 +665,15 @@ def _whole_step_vs_oracle(sd, clean, noisy, npm, tag, bar, n_fft=400, hop=100, l
     # the mask decoder, maxima 6e-4 of the largest gradient - whose fp32 column sums over 4 x 321 x 202 positions differ
     # between any two summation orders by 1e-4 of that small maximum (the oracle's own fp32 autograd is 6.5e-5 from its
     # fp64 one on it at B = 2): a tensor whose error is below the bar only in ABSOLUTE terms (1e-6 of the largest
-    # gradient, the zero-gradient floor) passes if it is also within 1e-2 of its own maximum.
+    # gradient, the zero-gradient floor) passes if it is also within 1e-2 of its own maximum.  OPT-IN: only the tensors the
+    # caller names in `allow_cancelling` (the B = 4 test names exactly those two); every other caller keeps the strict rule.
     FLOOR = 1e-6
     rel, small, cancel = [], [], []
     for k, w in want["grads"].items():
         d, mx = float((gen.grads[k].cpu() - w).abs().max()), float(w.abs().max())
         if mx < FLOOR * scale:
             small.append((d / (FLOOR * scale), k))
-        elif d / mx >= bar and d < FLOOR * scale and d / mx < 1e-2:
+        elif k in allow_cancelling and d / mx >= bar and d < FLOOR * scale and d / mx < 1e-2:
             cancel.append((d / mx, k))
         else:
             rel.append((d / mx, k))
@@ -681,7 +683,6 @@ def _whole_step_vs_oracle(sd, clean, noisy, npm, tag, bar, n_fft=400, hop=100, l
         _report(f"{tag}: {k}", e)
     for e, k in cancel:
         _report(f"{tag}: {k} (cancelling sum, absolute error below 1e-6 of the largest gradient)", e)
-    assert len(cancel) <= 4, cancel
     _report(f"{tag}: worst of {len(rel)} gradient tensors, each relative to its own max", rel[0][0])
     if small:
         _report(f"{tag}: worst of {len(small)} zero-gradient tensors, absolute error in units of 1e-6 of the largest "
@@ -804,7 +805,8 @@ def test_generator_step_at_batch_4_x_T321_kink_free_twin_vs_oracle_autograd():
     noisy = clean + 0.3 * synthetic_clips(4, 32000, seed=44)
     _whole_step_vs_oracle(kink_free_twin(make_state_dict(seed=0)), clean, noisy,
                           synthetic_dropout_masks(92, 4, 321, 101), "kink-free twin, B = 4 x T = 321, no L1 term", 1e-4,
-                          loss_weights=(0.1, 0.9, 0.0))
+                          loss_weights=(0.1, 0.9, 0.0),
+                          allow_cancelling=("mask_decoder.sub_pixel.conv.bias", "mask_decoder.dense_block.norm4.bias"))
 
 
 def test_generator_step_at_48_khz_kink_free_twin_holds_every_gradient_tensor_to_the_gate():
@@ -1174,6 +1176,19 @@ def test_trainer_runs_an_epoch_like_the_reference_trainer(tmp_path):
     got = enhance_one_track(model, wav.to(DEV))
     want = O.enhance(ck, wav)
     assert _report("trained checkpoint: inference vs oracle", rel_err(got, want)) < 1e-4
+    # resume path: save -> one more step -> restore -> the same step again lands on bit-identical parameters, which
+    # needs the AdamW moments / step counts, the buffers AND the dropout-mask stream offsets to be carried
+    st = tr.resume_state()
+    assert st["epoch"] == 1 and all(v > 0 for v in st["mask_rng_offsets"].values())
+    clean = (synthetic_clips(2, 3200, seed=70) * 0.3).to(DEV)
+    noisy = clean + 0.1 * synthetic_clips(2, 3200, seed=71).to(DEV)
+    tr.train_step(clean, noisy)
+    p1, d1 = tr.gen.param_bucket.flat.clone(), tr.disc.param_bucket.flat.clone()
+    tr.epoch = 7
+    tr.load_resume_state(st)
+    assert tr.epoch == 1 and tr.optimizer.t == 2 and tr.gen.mask_rng_offsets() == st["mask_rng_offsets"]
+    tr.train_step(clean, noisy)
+    assert torch.equal(tr.gen.param_bucket.flat, p1) and torch.equal(tr.disc.param_bucket.flat, d1)
 
 
 def _philox4x32_10_np(ctr_lo, ctr_hi, half, seed):
@@ -1239,3 +1254,31 @@ def test_generator_masks_come_from_the_library_generator_and_restart_with_the_mo
     assert torch.equal(first(a), first(c)) and not torch.equal(first(a), first(b))
     assert first(a).dtype == torch.uint8 and set(first(a).unique().tolist()) <= {0, 1}
     assert 0.7 < float(first(a).float().mean()) < 0.9
+
+
+def test_mask_stream_offsets_survive_a_resume_and_reset_keeps_the_device_state_in_place():
+    """`mask_rng_offsets` / `set_mask_rng_offsets` are what `Trainer.resume_state` carries: a model restored to the saved
+    offsets draws the masks the original would have drawn next (not the first ones again); `reset_mask_rng` restarts the
+    stream at offset 0 WITHOUT replacing the device {seed, offset} tensor a captured graph points at."""
+    from cmgan_amd.training import GeneratorTrain
+    from oracle.weights import make_state_dict
+    sd = make_state_dict(seed=0)
+    g1 = GeneratorTrain(sd, device=DEV)
+    gen = lambda: torch.Generator(device=DEV).manual_seed(5)
+    first = lambda m: m[0][0]["ff1_1"].clone()
+    a = first(g1.masks(1, 5, gen()))
+    saved = g1.mask_rng_offsets()
+    assert len(saved) == 1 and next(iter(saved.values())) > 0
+    b = first(g1.masks(1, 5, gen()))                          # what the run draws next
+    g2 = GeneratorTrain(sd, engine=g1.engine)                 # the restarted process
+    g2.set_mask_rng_offsets(saved)
+    assert torch.equal(first(g2.masks(1, 5, gen())), b)
+    assert g2.mask_rng_offsets() == g1.mask_rng_offsets()
+    state = g1.mask_rng_state(gen())
+    ptr = state.data_ptr()
+    g1.reset_mask_rng()
+    assert g1.mask_rng_state(gen()).data_ptr() == ptr and g1.mask_rng_offsets() == {k: 0 for k in saved}
+    assert torch.equal(first(g1.masks(1, 5, gen())), a)       # the stream starts over
+    g1.set_mask_rng_offsets(saved)                            # existing stream: restored in place too
+    assert g1.mask_rng_state(gen()).data_ptr() == ptr
+    assert torch.equal(first(g1.masks(1, 5, gen())), b)

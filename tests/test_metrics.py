@@ -73,3 +73,43 @@ def test_length_mismatch_in_single_measures_raises():
     clean, enh = pair(*CASES[2])
     with pytest.raises(ValueError):
         M.wss(clean, enh[:-1], 8000)
+
+
+# ------------------------------------------------------------------ the reference's OWN logged answers
+KA = np.load(os.path.join(os.path.dirname(__file__), "golden", "metrics_known_answers.npz"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in KA["names"]])
+def test_logged_scores_of_the_reference_tool_on_its_shipped_tracks(name, tmp_path):
+    """src/tools/Noisy_metrics_results/python_noisy_metrics.log lines of three `AudioSamples` noisy / clean pairs
+    (fixture: tests/golden/make_metrics_known_answers.py): CSIG, CBAK, COVL, SSNR and STOI to the log's 6 decimals,
+    with the logged PESQ as the (third-party) input.  The log was made on int16-scale samples (path = 1)."""
+    pesq_mos, *want = [float(v) for v in KA[f"log_{name}"]]
+    clean, noisy = KA[f"clean_{name}"], KA[f"noisy_{name}"]
+    got = M.compute_metrics(clean, noisy, 16000, 0, pesq_mos=pesq_mos)
+    assert max(abs(a - b) for a, b in zip(got[1:], want)) < 1e-6, (got, want)
+    # and through the wav-file form the log was made with
+    from scipy.io import wavfile
+    a, b = str(tmp_path / "c.wav"), str(tmp_path / "n.wav")
+    wavfile.write(a, 16000, clean)
+    wavfile.write(b, 16000, noisy)
+    got1 = M.compute_metrics(a, b, 0, 1, pesq_mos=pesq_mos)
+    assert max(abs(a_ - b_) for a_, b_ in zip(got1[1:], want)) < 1e-6
+
+
+def test_all_shipped_tracks_against_the_log_when_the_reference_tree_is_here():
+    ref = "/root/reference/AudioSamples"
+    if not os.path.isdir(ref):
+        pytest.skip("no /root/reference here")
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_metrics_known_answers import logged
+    from scipy.io import wavfile
+    log, worst = logged(), 0.0
+    names = sorted(os.path.splitext(f)[0] for f in os.listdir(os.path.join(ref, "noisy")))
+    assert len(names) == 25
+    for n in names:
+        got = M.compute_metrics(os.path.join(ref, "clean", n + ".wav"), os.path.join(ref, "noisy", n + ".wav"), 0, 1,
+                                pesq_mos=log[n][0])
+        worst = max(worst, max(abs(a - b) for a, b in zip(got[1:], log[n][1:])))
+    assert worst < 1e-6, worst

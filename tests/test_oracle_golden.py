@@ -9,7 +9,7 @@ import torch
 
 from conftest import GOLDEN, assert_close, load_golden, rel_err
 from oracle import cmgan_oracle as O
-from oracle.weights import conformer_state_dict, make_state_dict
+from oracle.weights import conformer_state_dict, make_state_dict, synthetic_clips
 
 TOL = 2e-5   # fp32 re-association noise between two CPU formulations of the same sums
 
@@ -434,3 +434,37 @@ def test_chunk_rows_rule():
     assert O.chunk_rows(256100, 256000) == 2
     assert O.chunk_rows(3 * 256000, 256000) == 4      # 3 does not divide 100
     assert O.chunk_rows(6 * 256000 + 100, 256000) == 10
+
+
+# ------------------------------------------------------------------ oracle/_ref: the reference's own modules
+def _ref_runner():
+    from oracle import make_ref, ref_runner
+    make_ref.make_ref(verbose=False)                  # (re)build when /root/reference is here; no-op on the GPU box
+    if not ref_runner.available():
+        pytest.skip("oracle/_ref not built (no /root/reference in this environment)")
+    return ref_runner
+
+
+def test_ref_modules_reproduce_the_committed_goldens_bit_for_bit(sd):
+    """oracle/_ref is the bytecode of /root/reference/src/models/{generator,conformer}.py + utils.py: run on the
+    golden inputs it must return the golden outputs EXACTLY (the fixtures were made by the same modules), and the
+    oracle port must agree with it at fp32 rounding level on a fresh input."""
+    R = _ref_runner()
+    g = load_golden("tscnet.npz")
+    model = R.tscnet(sd)
+    real, imag = model(g["x"])
+    assert torch.equal(real, g["real"]) and torch.equal(imag, g["imag"])
+    wav = synthetic_clips(1, 3200, seed=21)
+    got = O.enhance_batch(sd, wav)
+    want = R.enhance_batch(model, wav)
+    assert rel_err(got, want) < 2e-5
+
+
+def test_ref_enhance_glue_matches_the_pipeline_golden(sd):
+    """ref_runner.enhance = src/evaluation.py:21-53 around the reference modules: the ragged clip and the > cut_len
+    chunked form of the committed golden, bit for bit."""
+    R = _ref_runner()
+    g = load_golden("pipeline.npz")
+    model = R.tscnet(sd)
+    assert torch.equal(R.enhance(model, g["noisy"]), g["enhanced"])
+    assert torch.equal(R.enhance(model, g["noisy"], cut_len=int(g["cut_len_chunked"])), g["enhanced_chunked"])
