@@ -39,6 +39,7 @@
 #endif
 #include "kernels.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace X3_NS {
 
@@ -1195,6 +1196,17 @@ void launch_attn32_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* k
                                 qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, bps, nb, mask)));
 }
 
+#ifndef A32_GROUP_SHORT
+#define A32_GROUP_SHORT A32_GROUP    // tile interleave of short sequences (the frequency axis)
+#endif
+#ifndef A32_ALIGN_SHORT
+#define A32_ALIGN_SHORT 0
+#endif
+static int env_knob(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
 void launch_attn_sp_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* kimg, const _Float16* vimg,
                            const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
                            const float* bo) {
@@ -1204,18 +1216,25 @@ void launch_attn_sp_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* 
     // block slot and no partly filled last round (2568 blocks of 16 tiles were 5.02 rounds).  Long ones (the time axis):
     // A32_TPB tiles per block, 17.4 rounds - with the interleaved tile order a persistent round no longer costs L2 hits,
     // but it measured 1.5 % SLOWER (5.70 vs 5.62 ms): short blocks balance the CUs dynamically.
-    int tpb = Lt <= 4 ? A32_TPB_SHORT : A32_TPB;
+    // (CMGAN_ASP_* environment overrides: launch-shape sweeps inside ONE GPU session, read once per process)
+    static const int k_tpb_long = env_knob("CMGAN_ASP_TPB_LONG", A32_TPB), k_group_long = env_knob("CMGAN_ASP_GROUP_LONG", A32_GROUP);
+    static const int k_group_short = env_knob("CMGAN_ASP_GROUP_SHORT", A32_GROUP_SHORT);
+    static const int k_align_short = env_knob("CMGAN_ASP_ALIGN_SHORT", A32_ALIGN_SHORT);
+    static const int k_slots = env_knob("CMGAN_ASP_SLOTS", A32_SLOTS_PER_GPU);
+    int tpb = Lt <= 4 ? A32_TPB_SHORT : k_tpb_long;
     if (Lt <= 4 || A32_PERSIST_LONG) {
-        const long share = ((long)N * Lt + A32_SLOTS_PER_GPU - 1) / A32_SLOTS_PER_GPU;
+        const long share = ((long)N * Lt + k_slots - 1) / k_slots;
         if (share > tpb) tpb = (int)share;
+        if (Lt <= 4 && k_align_short) tpb = (tpb + Lt - 1) / Lt * Lt;      // blocks own whole sequences
     }
+    const int group = Lt <= 4 ? k_group_short : k_group_long;
     const long nb = ((long)N * Lt + tpb - 1) / tpb;
     const unsigned grid = XCD_ORDER ? (unsigned)(((nb + 7) / 8) * 8) : (unsigned)nb;
     const int tail = seq.L & 63;
     const bool clamp = seq.L + 96 > max_pos;
 #define ASP_LAUNCH(CL, NK, FU)                                                                                    \
     LAUNCH(ctx, "attn_out", (attn_sp_out_x3_kernel<CL, NK, FU><<<grid, 256, 0, ctx.stream>>>(                     \
-                                qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, N, A32_GROUP)))
+                                qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, N, group)))
     if (!clamp) {
         if (tail == 0) ASP_LAUNCH(false, 2, true);
         else if (tail > 32) ASP_LAUNCH(false, 2, false);

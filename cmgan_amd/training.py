@@ -1498,7 +1498,9 @@ class Trainer:
                 "disc_params": self.disc.param_bucket.flat.cpu().clone(),
                 "opt_gen": opt(self.optimizer), "opt_disc": opt(self.optimizer_disc),
                 "buffers": [b.cpu().clone() for b in self.buffers()],
-                "epoch": int(self.epoch), "mask_rng_offsets": self.gen.mask_rng_offsets()}
+                "epoch": int(self.epoch), "mask_rng_offsets": self.gen.mask_rng_offsets(),
+                # the discriminator head's small Dropout mask still comes from torch's CUDA generator
+                "torch_cuda_rng": torch.cuda.get_rng_state(self.engine.device)}
 
     def load_resume_state(self, state: Dict[str, object]) -> None:
         """In place (captured graphs keep their pointers): the inverse of `resume_state`."""
@@ -1513,6 +1515,7 @@ class Trainer:
             b.copy_(v)
         self.epoch = int(state["epoch"])
         self.gen.set_mask_rng_offsets(state["mask_rng_offsets"])
+        torch.cuda.set_rng_state(state["torch_cuda_rng"], self.engine.device)
 
     def train(self, epochs: int, save_model_dir: Optional[str] = None, rank: Optional[int] = None) -> list:
         """train.py:247-275.  Returns the per-epoch validation losses; rank 0 (of the initialised process group unless
