@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMGAN_HIP_LIB") or os.path.join(HERE, "lib", "libcmgan_hip.so")
 
 OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 MFMA_F32, MFMA_F16X3, MFMA_F16X1 = 0, 1, 2
 
 
@@ -162,6 +162,13 @@ SIGNATURES = {
     "cmgan_conformer_forward_masked": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                                c_void_p, c_size_t, c_void_p]),
     "cmgan_tscnet_forward_taps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, POINTER(Taps), c_void_p, c_size_t, c_void_p]),
+    "cmgan_stats_floats": (c_size_t, [c_void_p, c_int]),
+    "cmgan_tscnet_forward_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_size_t, c_void_p]),
+    "cmgan_stream_encoder": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cmgan_stream_tscb": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "cmgan_stream_decoder": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
     "cmgan_selftest_mfma": (c_int, [c_void_p, POINTER(c_float)]),
     "cmgan_selftest_mfma_x3": (c_int, [c_void_p, POINTER(c_float)]),
     "cmgan_set_profiling": (c_int, [c_void_p, c_int]),

@@ -663,7 +663,7 @@ typedef void (*Conv3xFn)(LaunchCtx, const ConvArgs&, const void*, int, int, int)
 static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float* x0, const float* x0_scale,
                             const float* x0_shift, const float* x0_alpha, float* const slots[4], float* partials,
                             float* const nsc[4], float* const nsh[4], int B, int T, int F, float* const* imgs = nullptr,
-                            Conv3xFn conv3x = launch_conv3_x3) {
+                            Conv3xFn conv3x = launch_conv3_x3, bool frozen = false) {
     const int nt = x3 ? conv3x_ntiles(T, F, 64) : conv3_ntiles(T, F);
     for (int i = 0; i < 4; ++i) {
         ConvArgs a{};
@@ -683,13 +683,35 @@ static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float
         a.T = T; a.F = F; a.dil = 1 << i; a.mode = 0; a.ntiles = nt;
         if (x3) conv3x(ctx, a, d.w16[i], B, 2, 64);
         else launch_conv3(ctx, a, B, 2, 64);
-        launch_in_finalize(ctx, partials, B, nt, 64, 0, (double)T * F, d.gb[i], nsc[i], nsh[i]);
+        if (!frozen) launch_in_finalize(ctx, partials, B, nt, 64, 0, (double)T * F, d.gb[i], nsc[i], nsh[i]);
     }
 }
 
+// Options of the sliced / frozen-statistics forms of the forward (streaming with carried state, cmgan_stream_*):
+//   frozen    every InstanceNorm uses the scale / shift pairs of this statistics blob (cmgan_stats_floats) instead of
+//             the statistics of the tensor in hand: the in_finalize / mask_stats launches are skipped.  With frozen
+//             statistics the encoder and the decoders are exactly time-causal (receptive field 15 frames back,
+//             generator.py:16-20, 39-47): frame t of their output depends on frames t - 15 .. t of their input only.
+//   stats_out the blob of THIS call's own statistics is copied here after the run (calibration)
+//   phases    which third(s) of TSCNet.forward run: encoder (spec -> x_io), TSCBs (x_io in place), decoders
+//             (x_io + spec -> out_re / out_im); x_io = channels-last [B, T, F', 64], the layout the three share
+enum { PH_ENC = 1, PH_TSCB = 2, PH_DEC = 4, PH_ALL = 7 };
+struct TscnetOpts {
+    const float* frozen = nullptr;
+    float* stats_out = nullptr;
+    int phases = PH_ALL;
+    float* x_io = nullptr;
+};
+static size_t stats_floats(int B) { return (size_t)16 * 2 * B * 64 + (size_t)B * 2; }
+
 static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* out_re, float* out_im,
-                       const cmgan_taps* taps, void* ws, size_t ws_bytes, void* stream, bool reset_prof) {
-    if (!spec || !out_re || !out_im || B <= 0 || T <= 0) return fail(h, CMGAN_E_BADARG, "tscnet_forward: bad argument");
+                       const cmgan_taps* taps, void* ws, size_t ws_bytes, void* stream, bool reset_prof,
+                       const TscnetOpts& opt = TscnetOpts()) {
+    const bool ph_enc = opt.phases & PH_ENC, ph_tscb = opt.phases & PH_TSCB, ph_dec = opt.phases & PH_DEC;
+    if (B <= 0 || T <= 0 || ((ph_enc || ph_dec) && !spec) || (ph_dec && (!out_re || !out_im)) ||
+        (opt.phases != PH_ALL && !opt.x_io))
+        return fail(h, CMGAN_E_BADARG, "tscnet_forward: bad argument");
+    const bool frozen = opt.frozen != nullptr;
     // a time-axis sequence is T rows F2 rows apart: the split-f16 conv-module kernel addresses them with 32-bit byte
     // offsets (conformer_x3_addressable, conformer_x3.hip: 83 k frames per clip at F = 201); the fp32 kernels have no limit
     if (h->cfg.mfma_mode != CMGAN_MFMA_F32 && (long)(T - 1) * ((h->cfg.num_features + 1) / 2) * 512 + 512 >= (1l << 32))
@@ -742,16 +764,27 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
     auto nsc = [&](int j) { return f + p.ns + (size_t)j * 2 * B * 64; };
     auto nsh = [&](int j) { return f + p.ns + (size_t)j * 2 * B * 64 + (size_t)B * 64; };
     float* partials = f + p.partials;
+    hipStream_t hs = (hipStream_t)stream;
+    const size_t ns_floats = (size_t)16 * 2 * B * 64;
+    if (frozen) {                                         // the blob = [16 x {scale[B][64], shift[B][64]} | mask stats [B][2]]
+        HIPCHK(h, hipMemcpyAsync(f + p.ns, opt.frozen, ns_floats * sizeof(float), hipMemcpyDeviceToDevice, hs));
+        HIPCHK(h, hipMemcpyAsync(f + p.mstat, opt.frozen + ns_floats, (size_t)B * 2 * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    }
+    // (frozen statistics: the convs still write their partial sums, nobody reduces them)
+    auto finalize = [&](int ntiles, int cstride, int fold2, double count, const float* gb, float* sc_, float* sh_) {
+        if (!frozen) launch_in_finalize(ctx, partials, B, ntiles, cstride, fold2, count, gb, sc_, sh_);
+    };
 
     // ---- dense encoder (generator.py:65-69) --------------------------------------------
+    if (ph_enc) {
     launch_conv_in(ctx, spec, c1w, f + p.e[0], partials, B, (int)P);
-    launch_in_finalize(ctx, partials, B, conv_in_ntiles((int)P), 64, 0, (double)P, c1gb, nsc(0), nsh(0));
+    finalize(conv_in_ntiles((int)P), 64, 0, (double)P, c1gb, nsc(0), nsh(0));
     {
         float* slots[4] = {f + p.e[1], f + p.e[2], f + p.e[3], f + p.e[4]};
         float* sc[4] = {nsc(1), nsc(2), nsc(3), nsc(4)};
         float* sh[4] = {nsh(1), nsh(2), nsh(3), nsh(4)};
         float* imgs[3] = {f + p.img[0], f + p.img[1], f + p.img[2]};
-        run_dense_block(ctx, x3, dbe, f + p.e[0], nsc(0), nsh(0), c1pr, slots, partials, sc, sh, B, T, F, x3 ? imgs : nullptr, conv3x);
+        run_dense_block(ctx, x3, dbe, f + p.e[0], nsc(0), nsh(0), c1pr, slots, partials, sc, sh, B, T, F, x3 ? imgs : nullptr, conv3x, frozen);
     }
     {   // conv_2: (1,3) stride (1,2) pad (0,1) == stride-1 conv keeping the even columns
         ConvArgs a{};
@@ -760,16 +793,19 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
         a.T = T; a.F = F; a.dil = 1; a.mode = 1; a.ntiles = x3 ? conv3x_ntiles(T, F, 64) : conv3_ntiles(T, F);
         if (x3) conv3x(ctx, a, c2w16, B, 1, 64);
         else launch_conv3(ctx, a, B, 1, 64);
-        launch_in_finalize(ctx, partials, B, a.ntiles, 64, 0, (double)P2, c2gb, nsc(5), nsh(5));
+        finalize(a.ntiles, 64, 0, (double)P2, c2gb, nsc(5), nsh(5));
         launch_in_apply(ctx, f + p.xb, nsc(5), nsh(5), c2pr, f + p.xa, B, P2);
     }
     if (taps && taps->encoder_dev) launch_cl_to_nchw(ctx, f + p.xa, taps->encoder_dev, B, P2);
+    }   // ph_enc
+    const size_t x_bytes = (size_t)M * 64 * sizeof(float);
+    if (opt.x_io && !ph_enc) HIPCHK(h, hipMemcpyAsync(f + p.xa, opt.x_io, x_bytes, hipMemcpyDeviceToDevice, hs));
 
     // ---- TSCBs (generator.py:92-99) -----------------------------------------------------
     ConfBuffers cb{f + p.xa, f + p.xb, f + p.q, f + p.k, f + p.v, f + p.o, f + p.u, f + p.w};
     const TokMap tmap = make_seq_map(B * F2, T, F2, (long)T * F2, 1, F2);
     const TokMap fmap = make_seq_map(B * T, F2, 1, F2, 0, 1);
-    for (int k = 0; k < h->cfg.num_tscb; ++k) {
+    for (int k = 0; ph_tscb && k < h->cfg.num_tscb; ++k) {
         if (x3) {
             conformer_x(ctx, cw[2 * k], cw16[2 * k], cb, tmap, M, nullptr, true, nullptr);
             conformer_x(ctx, cw[2 * k + 1], cw16[2 * k + 1], cb, fmap, M, nullptr, true, nullptr);
@@ -779,6 +815,9 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
         }
         if (taps && taps->tscb_dev[k]) launch_cl_to_nchw(ctx, f + p.xa, taps->tscb_dev[k], B, P2);
     }
+
+    if (opt.x_io && !ph_dec) HIPCHK(h, hipMemcpyAsync(opt.x_io, f + p.xa, x_bytes, hipMemcpyDeviceToDevice, hs));
+    if (!ph_dec) return check_launch(h, "tscnet_forward");
 
     // ---- decoders (generator.py:133-139, 151-156) ------------------------------------
     float* dslots[4] = {f + p.e[1], f + p.e[2], f + p.e[3], f + p.e[4]};
@@ -790,7 +829,7 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
         float* sc[4] = {nsc(j0), nsc(j0 + 1), nsc(j0 + 2), nsc(j0 + 3)};
         float* sh[4] = {nsh(j0), nsh(j0 + 1), nsh(j0 + 2), nsh(j0 + 3)};
         float* imgs[3] = {f + p.img[0], f + p.img[1], f + p.img[2]};
-        run_dense_block(ctx, x3, d, f + p.xa, nullptr, nullptr, nullptr, dslots, partials, sc, sh, B, T, F2, x3 ? imgs : nullptr, conv3x);
+        run_dense_block(ctx, x3, d, f + p.xa, nullptr, nullptr, nullptr, dslots, partials, sc, sh, B, T, F2, x3 ? imgs : nullptr, conv3x, frozen);
         ConvArgs a{};
         a.in[0] = dslots[3]; a.nscale[0] = sc[3]; a.nshift[0] = sh[3]; a.nalpha[0] = d.prelu[3];
         a.nslots = 1; a.w = dec == 0 ? mk_spw : cx_spw; a.bias = dec == 0 ? mk_spb : cx_spb;
@@ -801,13 +840,17 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
         if (dec == 0) {
             launch_tail_proj(ctx, sp, nullptr, nullptr, nullptr, mk_tail, f + p.dm, B, (long)T * W2);
         } else {
-            launch_in_finalize(ctx, partials, B, nt2, 128, 1, (double)T * W2, cx_gb, nsc(14), nsh(14));
+            finalize(nt2, 128, 1, (double)T * W2, cx_gb, nsc(14), nsh(14));
             launch_tail_proj(ctx, sp, nsc(14), nsh(14), cx_pr, cx_tail, f + p.dc, B, (long)T * W2);
         }
     }
-    launch_mask_stats(ctx, f + p.dm, mk_sca, B, T, F, f + p.mstat);
+    if (!frozen) launch_mask_stats(ctx, f + p.dm, mk_sca, B, T, F, f + p.mstat);
     launch_final_combine(ctx, spec, f + p.dm, f + p.dc, f + p.mstat, mk_sca, mk_pout, cx_bias, B, T, F, out_re,
                          out_im, taps ? taps->mask_dev : nullptr, taps ? taps->complex_dev : nullptr);
+    if (opt.stats_out) {
+        HIPCHK(h, hipMemcpyAsync(opt.stats_out, f + p.ns, ns_floats * sizeof(float), hipMemcpyDeviceToDevice, hs));
+        HIPCHK(h, hipMemcpyAsync(opt.stats_out + ns_floats, f + p.mstat, (size_t)B * 2 * sizeof(float), hipMemcpyDeviceToDevice, hs));
+    }
     return check_launch(h, "tscnet_forward");
 }
 
@@ -822,6 +865,45 @@ extern "C" int cmgan_tscnet_forward_taps(cmgan_handle* h, const float* spec, int
                                          void* stream) {
     if (!h) return CMGAN_E_BADARG;
     return tscnet_impl(h, spec, B, T, out_re, out_im, taps, ws, ws_bytes, stream, true);
+}
+
+// ---- frozen-statistics / sliced forms: streaming with carried state (include/cmgan_hip.h, "streaming") ----
+extern "C" size_t cmgan_stats_floats(const cmgan_handle* h, int B) { return h && B > 0 ? stats_floats(B) : 0; }
+
+extern "C" int cmgan_tscnet_forward_stats(cmgan_handle* h, const float* spec, int B, int T, float* out_re, float* out_im,
+                                          const float* frozen_stats, float* stats_out, void* ws, size_t ws_bytes,
+                                          void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    TscnetOpts o;
+    o.frozen = frozen_stats; o.stats_out = stats_out;
+    return tscnet_impl(h, spec, B, T, out_re, out_im, nullptr, ws, ws_bytes, stream, true, o);
+}
+
+extern "C" int cmgan_stream_encoder(cmgan_handle* h, const float* spec, int B, int T, const float* frozen_stats,
+                                    float* x_out, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!frozen_stats || !x_out) return fail(h, CMGAN_E_BADARG, "cmgan_stream_encoder: bad argument");
+    TscnetOpts o;
+    o.frozen = frozen_stats; o.phases = PH_ENC; o.x_io = x_out;
+    return tscnet_impl(h, spec, B, T, nullptr, nullptr, nullptr, ws, ws_bytes, stream, false, o);
+}
+
+extern "C" int cmgan_stream_tscb(cmgan_handle* h, float* x, int B, int T, void* ws, size_t ws_bytes, void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!x) return fail(h, CMGAN_E_BADARG, "cmgan_stream_tscb: bad argument");
+    TscnetOpts o;
+    o.phases = PH_TSCB; o.x_io = x;
+    return tscnet_impl(h, nullptr, B, T, nullptr, nullptr, nullptr, ws, ws_bytes, stream, false, o);
+}
+
+extern "C" int cmgan_stream_decoder(cmgan_handle* h, const float* x, const float* spec, int B, int T,
+                                    const float* frozen_stats, float* out_re, float* out_im, void* ws, size_t ws_bytes,
+                                    void* stream) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!frozen_stats || !x) return fail(h, CMGAN_E_BADARG, "cmgan_stream_decoder: bad argument");
+    TscnetOpts o;
+    o.frozen = frozen_stats; o.phases = PH_DEC; o.x_io = const_cast<float*>(x);
+    return tscnet_impl(h, spec, B, T, out_re, out_im, nullptr, ws, ws_bytes, stream, false, o);
 }
 
 extern "C" int cmgan_enhance(cmgan_handle* h, const float* wav, int B, int L, float* wav_out, void* ws,

@@ -356,9 +356,12 @@ __global__ __launch_bounds__(64 * NWV) void conv3x_kernel(ConvArgs a, const _Flo
 
     CX_PREFETCH(0);
     u32x4 wpre[NW];
+#if CX_WEARLY == 2
+    CX_WFETCH(0);
+#endif
 #pragma unroll 1
     for (int s = 0; s < nst; ++s) {
-#if CX_WEARLY
+#if CX_WEARLY == 1
         CX_WFETCH(s);                                     // in flight across the barrier and the staging VALU
 #endif
         __syncthreads();                                  // stage s-1 fully consumed
@@ -370,6 +373,11 @@ __global__ __launch_bounds__(64 * NWV) void conv3x_kernel(ConvArgs a, const _Flo
         CX_WRITE(s);
         __syncthreads();
         if (s + 1 < nst) CX_PREFETCH(s + 1);              // in flight during the MFMAs below
+#if CX_WEARLY == 2
+        // the NEXT stage's weight image too: a whole MFMA phase ahead of its LDS store (NW more registers live across
+        // the MFMAs: needs the 3-waves-per-SIMD register budget of the 128-row tile, -DCX_NPB64=2 -DCX_NWV64=4)
+        if (s + 1 < nst) CX_WFETCH(s + 1);
+#endif
 #endif
         CX_MFMA();
     }

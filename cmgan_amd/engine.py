@@ -227,6 +227,83 @@ class Engine:
                                                           ws.numel(), self._stream()))
         return real, imag, st
 
+    # ---- frozen-statistics / sliced forms (streaming with carried state; include/cmgan_hip.h, "Streaming") ----
+    def stats_floats(self, B: int) -> int:
+        return int(self.lib.cmgan_stats_floats(self._h, B))
+
+    @_on_device
+    def tscnet_forward_stats(self, x: torch.Tensor, frozen: Optional[torch.Tensor] = None, export: bool = True):
+        """TSCNet.forward with every InstanceNorm on the `frozen` statistics blob (None = the tensor's own, i.e. the
+        reference's arithmetic).  Returns (real, imag, blob of the statistics this call used or None)."""
+        self._need_weights()
+        x = self._in(x, "x")
+        B, two, T, F = x.shape
+        if two != 2 or F != self.F:
+            raise ValueError(f"expected [B,2,T,{self.F}], got {tuple(x.shape)}")
+        ws = self._workspace(B, T)
+        real = torch.empty(B, 1, T, F, dtype=torch.float32, device=x.device)
+        imag = torch.empty_like(real)
+        fz = self._stats_arg(frozen, B)
+        out = torch.empty(self.stats_floats(B), dtype=torch.float32, device=x.device) if export else None
+        check(self._h, self.lib.cmgan_tscnet_forward_stats(self._h, x.data_ptr(), B, T, real.data_ptr(), imag.data_ptr(),
+                                                           fz, out.data_ptr() if export else None, ws.data_ptr(),
+                                                           ws.numel(), self._stream()))
+        return real, imag, out
+
+    def _stats_arg(self, stats: Optional[torch.Tensor], B: int):
+        if stats is None:
+            return None
+        stats = self._in(stats, "stats")
+        if stats.numel() != self.stats_floats(B):
+            raise ValueError(f"statistics blob has {stats.numel()} floats, a batch of {B} rows needs {self.stats_floats(B)}")
+        return stats.data_ptr()
+
+    @_on_device
+    def stream_encoder(self, spec: torch.Tensor, stats: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dense_encoder under frozen statistics: spec [B,2,T,F] -> x [B,T,F',64] (channels-last)."""
+        self._need_weights()
+        spec = self._in(spec, "spec")
+        B, two, T, F = spec.shape
+        if two != 2 or F != self.F:
+            raise ValueError(f"expected [B,2,T,{self.F}], got {tuple(spec.shape)}")
+        ws = self._workspace(B, T)
+        if out is None:
+            out = torch.empty(B, T, (F + 1) // 2, 64, dtype=torch.float32, device=spec.device)
+        check(self._h, self.lib.cmgan_stream_encoder(self._h, spec.data_ptr(), B, T, self._stats_arg(stats, B),
+                                                     self._in(out, "out").data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
+        return out
+
+    @_on_device
+    def stream_tscb(self, x: torch.Tensor) -> torch.Tensor:
+        """TSCB_1..4 on x [B,T,F',64], IN PLACE (returns x)."""
+        self._need_weights()
+        if not x.is_contiguous():
+            raise ValueError("stream_tscb works in place: x must be contiguous")
+        x = self._in(x, "x")
+        B, T, F2, C = x.shape
+        if C != 64 or F2 != (self.F + 1) // 2:
+            raise ValueError(f"expected [B,T,{(self.F + 1) // 2},64], got {tuple(x.shape)}")
+        ws = self._workspace(B, T)
+        check(self._h, self.lib.cmgan_stream_tscb(self._h, x.data_ptr(), B, T, ws.data_ptr(), ws.numel(), self._stream()))
+        return x
+
+    @_on_device
+    def stream_decoder(self, x: torch.Tensor, spec: torch.Tensor, stats: torch.Tensor):
+        """mask + complex decoder + recombination under frozen statistics: x [B,T,F',64], spec [B,2,T,F] ->
+        (est_real, est_imag) [B,1,T,F]."""
+        self._need_weights()
+        x, spec = self._in(x, "x"), self._in(spec, "spec")
+        B, T, F2, C = x.shape
+        if tuple(spec.shape) != (B, 2, T, self.F) or C != 64 or F2 != (self.F + 1) // 2:
+            raise ValueError(f"expected x [B,T,{(self.F + 1) // 2},64] and spec [B,2,T,{self.F}]")
+        ws = self._workspace(B, T)
+        real = torch.empty(B, 1, T, self.F, dtype=torch.float32, device=x.device)
+        imag = torch.empty_like(real)
+        check(self._h, self.lib.cmgan_stream_decoder(self._h, x.data_ptr(), spec.data_ptr(), B, T, self._stats_arg(stats, B),
+                                                     real.data_ptr(), imag.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                     self._stream()))
+        return real, imag
+
     @_on_device
     def conformer_forward(self, index: int, x: torch.Tensor, taps: bool = False, mask: Optional[torch.Tensor] = None):
         """mask: [N, L] bool (or any integer / float tensor, non-zero = keep) - ConformerBlock.forward(x, mask)."""

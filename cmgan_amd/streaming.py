@@ -24,7 +24,7 @@ import torch
 
 from .generator import TSCNet
 
-__all__ = ["enhance_windows"]
+__all__ = ["enhance_windows", "enhance_stream", "StreamState", "HIST_FRAMES"]
 
 
 @torch.no_grad()
@@ -90,3 +90,150 @@ def _enhance_rows(model: TSCNet, rows: torch.Tensor, graph: bool) -> torch.Tenso
     g_in.copy_(rows)
     g.replay()
     return g_out
+
+
+# ======================================================================================================================
+# Streaming with CARRIED state (BASELINE.json configs[4]: "chunked 400-frame windows with KV/state carry, hipGraph-captured")
+# ======================================================================================================================
+# Contract (include/cmgan_hip.h, "Streaming"; CPU restatement: oracle/stream_oracle.py).  What couples the frames of
+# the dense encoder and of the two decoders in the reference is only InstanceNorm2d's statistics over all of T; the
+# convolutions themselves are causal in time with a receptive field of 1 + 2 + 4 + 8 = 15 frames back
+# (generator.py:16-20, 39-47).  With the statistics FROZEN (a calibration pass, then held) their state carries
+# EXACTLY: window k feeds them 15 frames of input history in front of its new frames and drops the first 15 outputs -
+# every encoder / decoder frame is computed once, bit-identical to the whole-clip pass under the same statistics.
+# The four TSCBs attend over the whole window in both directions (no exact cache exists for them): window k runs them
+# on [context | window | look-ahead] frames of encoder outputs that are CACHED (context) or fresh, and keeps the window.
+#
+#   step k:  encoder   spec frames [e0 - 15, e1)        -> keep [e0, e1),  e1 = min((k + 1) W + La, T): each frame once
+#            TSCBs     encoder outputs [k W - Ca, e1)    -> keep [k W, (k + 1) W)
+#            decoders  [15 kept TSCB frames of step k - 1 | the kept frames] + their spec frames -> keep the W new ones
+#
+# STFT / ISTFT are frame-local (a frame sees 400 samples, a sample 4 frames) and run over the clip's frames before /
+# after the steps; the steps are what is captured into hipGraphs (one per step shape: first, steady, last).
+HIST_FRAMES = 15
+
+
+class StreamState:
+    """Carried state of one stream (or B streams in lock-step): the statistics blob, the encoder-output cache, the
+    decoder's input history and the spectrogram frames they belong to.  `step(spec_frames)` is frame-level."""
+
+    def __init__(self, model: TSCNet, stats: torch.Tensor, B: int, window: int, context: int, lookahead: int,
+                 graph: bool = True):
+        if window <= 0 or context < 0 or lookahead < 0:
+            raise ValueError("window must be positive, context / lookahead non-negative (frames)")
+        self.model, self.eng, self.stats, self.B = model, model.engine, stats, B
+        self.W, self.Ca, self.La, self.graph = window, context, lookahead, graph
+        self.F, self.F2 = self.eng.F, (self.eng.F + 1) // 2
+        dev = self.eng.device
+        self.k = 0                       # steps done
+        self.e1 = 0                      # encoder outputs exist for frames [enc_lo, e1)
+        self.enc_lo = 0
+        self.enc = torch.empty(B, 0, self.F2, 64, device=dev)          # cached encoder outputs
+        self.spec_tail = torch.empty(B, 2, 0, self.F, device=dev)       # spec frames [spec_lo, ...) still needed
+        self.spec_lo = 0
+        self.dec_hist = None             # kept TSCB outputs of the last HIST_FRAMES frames before k W
+
+    # ---- one step on explicit tensors (the part a hipGraph replays) ----
+    def _run(self, spec_enc, enc_ctx, dec_hist, spec_dec, n_new_enc, keep_lo, n_keep):
+        eng = self.eng
+        x_new = eng.stream_encoder(spec_enc, self.stats)[:, spec_enc.size(2) - n_new_enc:]      # drop the history outputs
+        x = torch.cat([enc_ctx, x_new], dim=1).contiguous()
+        eng.stream_tscb(x)
+        kept = x[:, keep_lo:keep_lo + n_keep]
+        xin = kept if dec_hist is None else torch.cat([dec_hist, kept], dim=1)
+        real, imag = eng.stream_decoder(xin.contiguous(), spec_dec, self.stats)
+        return x_new, kept, real[:, :, xin.size(1) - n_keep:], imag[:, :, xin.size(1) - n_keep:]
+
+    def _run_graphed(self, args, ints):
+        """Replay (capture on first use) the hipGraph of this step shape; tensors are copied into static inputs."""
+        key = ("stream", ints) + tuple(None if a is None else tuple(a.shape) for a in args)
+        cache = self.eng._row_graphs
+        ent = cache.get(key)
+        if ent is None or ent[3] != self.eng._ws_token() or ent[4] is not self.stats:
+            static = [None if a is None else a.clone() for a in args]
+            side = torch.cuda.Stream(device=self.eng.device)
+            side.wait_stream(torch.cuda.current_stream(self.eng.device))
+            with torch.cuda.stream(side):                       # warm-up outside capture (workspace, allocator)
+                self._run(*static, *ints)
+            torch.cuda.current_stream(self.eng.device).wait_stream(side)
+            torch.cuda.synchronize(self.eng.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                outs = self._run(*static, *ints)
+            ent = (g, static, outs, self.eng._ws_token(), self.stats)
+            cache[key] = ent
+        g, static, outs, _, _ = ent
+        for dst, src in zip(static, args):
+            if dst is not None:
+                dst.copy_(src)
+        g.replay()
+        return tuple(o.clone() for o in outs)
+
+    @torch.no_grad()
+    def step(self, spec_new: torch.Tensor, last: bool = False):
+        """spec_new: [B,2,n,F] = the spectrogram frames that arrived since the previous step (frames [e1, e1 + n)).
+        Step k needs frames up to (k + 1) W + La (fewer only when `last`: the clip ended).  Returns (est_real, est_imag)
+        [B,1,w,F] for frames [k W, k W + w), w = W (or what is left of the clip when `last`)."""
+        W, Ca, H = self.W, self.Ca, HIST_FRAMES
+        k, e0 = self.k, self.e1
+        n_new = spec_new.size(2)
+        e1 = e0 + n_new
+        want = (k + 1) * W + self.La
+        if (e1 < want and not last) or e1 > want:
+            raise ValueError(f"step {k} takes the frames up to {want} (fewer only at the end of the clip), got up to {e1}")
+        self.spec_tail = torch.cat([self.spec_tail, spec_new], dim=2)
+        lo = k * W                                             # first frame this step emits
+        n_keep = min(W, e1 - lo)
+        if n_keep <= 0:
+            raise ValueError("no frame left to emit")
+        h_enc = min(H, e0)                                     # history the encoder can see (0 at the start of the clip)
+        spec_enc = self.spec_tail[:, :, e0 - h_enc - self.spec_lo:e1 - self.spec_lo].contiguous()
+        a0 = max(lo - Ca, 0)                                   # TSCB frames [a0, e1): cached context + fresh
+        enc_ctx = self.enc[:, a0 - self.enc_lo:e0 - self.enc_lo].contiguous()
+        h_dec = 0 if self.dec_hist is None else self.dec_hist.size(1)
+        spec_dec = self.spec_tail[:, :, lo - h_dec - self.spec_lo:lo + n_keep - self.spec_lo].contiguous()
+        args = (spec_enc, enc_ctx, self.dec_hist, spec_dec)
+        ints = (n_new, lo - a0, n_keep)
+        x_new, kept, real, imag = (self._run_graphed(args, ints) if self.graph else self._run(*args, *ints))
+        # carry: encoder outputs from the next step's context start on, the last H kept TSCB frames, the spec frames both need
+        nxt_lo = lo + W
+        self.enc = torch.cat([self.enc, x_new], dim=1)
+        drop = max(nxt_lo - Ca, 0) - self.enc_lo
+        if drop > 0:
+            self.enc, self.enc_lo = self.enc[:, drop:].contiguous(), self.enc_lo + drop
+        hist = kept if self.dec_hist is None else torch.cat([self.dec_hist, kept], dim=1)
+        self.dec_hist = hist[:, -min(H, hist.size(1)):].contiguous()      # the frames just before nxt_lo
+        sdrop = max(nxt_lo - H, 0) - self.spec_lo                          # both histories start at nxt_lo - H or later
+        if sdrop > 0:
+            self.spec_tail, self.spec_lo = self.spec_tail[:, :, sdrop:].contiguous(), self.spec_lo + sdrop
+        self.k, self.e1 = k + 1, e1
+        return real, imag
+
+
+@torch.no_grad()
+def enhance_stream(model: TSCNet, noisy: torch.Tensor, window: int = 400, context: int = 40, lookahead: int = 40,
+                   stats: torch.Tensor | None = None, calib_frames: int | None = None, graph: bool = True) -> torch.Tensor:
+    """noisy: float32 [1, L] on the GPU -> enhanced [L'] (L' = hop * (T - 1), T = L // hop + 1, like one reference row).
+    window / context / lookahead are in FRAMES.  `stats`: a frozen statistics blob (Engine.tscnet_forward_stats); by
+    default the clip's first `calib_frames` (default window + lookahead) frames calibrate it."""
+    if noisy.dim() != 2 or noisy.size(0) != 1:
+        raise ValueError("expected a mono track shaped [1, L]")
+    eng = model.engine
+    noisy = noisy.to(dtype=torch.float32).contiguous()
+    c = eng.rms_scale(noisy)                                   # file-level scale, as evaluation.py:21
+    spec = eng.stft_compress(noisy, c)                         # [1,2,T,F]: frame-local, see the contract above
+    T = spec.size(2)
+    if stats is None:
+        n = min(T, calib_frames if calib_frames is not None else window + lookahead)
+        stats = eng.tscnet_forward_stats(spec[:, :, :n].contiguous())[2]
+    st = StreamState(model, stats, 1, window, context, lookahead, graph)
+    real = torch.empty(1, 1, T, eng.F, device=noisy.device)
+    imag = torch.empty_like(real)
+    k, fed = 0, 0
+    while k * window < T:
+        upto = min((k + 1) * window + lookahead, T)
+        r, i = st.step(spec[:, :, fed:upto].contiguous(), last=upto == T)
+        w = r.size(2)
+        real[:, :, k * window:k * window + w], imag[:, :, k * window:k * window + w] = r, i
+        fed, k = upto, k + 1
+    return (eng.uncompress_istft(real, imag) / c[:, None]).reshape(-1)

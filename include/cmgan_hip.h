@@ -39,7 +39,7 @@ extern "C" {
 #define CMGAN_E_WORKSPACE   -5   /* workspace too small or misaligned              */
 #define CMGAN_E_HIP         -6   /* a HIP runtime call failed (see last_error)     */
 
-#define CMGAN_ABI_VERSION 4
+#define CMGAN_ABI_VERSION 5
 
 typedef struct cmgan_handle cmgan_handle;
 
@@ -439,6 +439,43 @@ typedef struct cmgan_taps {
 int cmgan_tscnet_forward_taps(cmgan_handle* h, const float* spec_dev, int B, int T,
                               float* out_real_dev, float* out_imag_dev, const cmgan_taps* taps,
                               void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* ---- Streaming with carried state (BASELINE.json configs[4]) --------------------------
+ * The reference has no streaming mode; the hooks it leaves are its already-causal dilated convs (generator.py:16-20,
+ * 39-47) and the unused `causal` flag of the conv module (conformer.py:153,158,168).  What makes the encoder and the
+ * decoders non-causal in the reference is ONLY InstanceNorm2d's statistics over all of T (generator.py:35,55,61,
+ * 128,148).  With the statistics FROZEN (taken from a calibration pass and then held, like BatchNorm in eval mode) the
+ * dense encoder and both decoders are exactly time-causal with a receptive field of 1 + 2 + 4 + 8 = 15 frames back:
+ * frame t of their output is a function of frames t - 15 .. t of their input.  So their state CAN be carried across
+ * windows exactly: 15 frames of input history in front of the new frames, first 15 output frames dropped.  The four
+ * TSCBs attend over the whole window (bidirectional, no exact cache exists): they run on [context | window |
+ * look-ahead] frames of cached / fresh encoder outputs, as before.
+ *
+ *   cmgan_stats_floats(h, B)        floats of one statistics blob: the (scale, shift) pairs of the 15 InstanceNorms
+ *                                   per row + the mask head's one-channel norm.  Opaque; valid for that B.
+ *   cmgan_tscnet_forward_stats      cmgan_tscnet_forward with `frozen_stats` (may be NULL = the tensor's own
+ *                                   statistics, i.e. the reference's arithmetic) and `stats_out` (may be NULL): the blob
+ *                                   of the statistics this call used.  A call with frozen_stats = its own stats_out
+ *                                   reproduces the unfrozen call bit for bit.
+ *   cmgan_stream_encoder            spec[B,2,T,F] -> x[B,T,F',64] (channels-last, the layout the TSCBs and decoders
+ *                                   share) = dense_encoder (generator.py:65-69) under frozen statistics
+ *   cmgan_stream_tscb               x[B,T,F',64] in place = TSCB_1..4 (generator.py:92-99, 182-185)
+ *   cmgan_stream_decoder            x[B,T,F',64] + spec[B,2,T,F] -> est_real / est_imag [B,1,T,F] = mask + complex decoder
+ *                                   + recombination (generator.py:187-194) under frozen statistics
+ * Exactness (tests/test_gpu_parity.py::test_stream_*): frames t >= 15 of cmgan_stream_encoder on ANY slice of a clip's
+ * spectrogram equal the same frames of the whole-clip call bit for bit; likewise the decoder.  Workspace:
+ * cmgan_workspace_bytes(h, B, T) of the call's own T.                                                           */
+size_t cmgan_stats_floats(const cmgan_handle* h, int B);
+int cmgan_tscnet_forward_stats(cmgan_handle* h, const float* spec_dev, int B, int T, float* out_real_dev,
+                               float* out_imag_dev, const float* frozen_stats_dev, float* stats_out_dev,
+                               void* workspace_dev, size_t workspace_bytes, void* stream);
+int cmgan_stream_encoder(cmgan_handle* h, const float* spec_dev, int B, int T, const float* frozen_stats_dev,
+                         float* x_out_dev, void* workspace_dev, size_t workspace_bytes, void* stream);
+int cmgan_stream_tscb(cmgan_handle* h, float* x_dev, int B, int T, void* workspace_dev, size_t workspace_bytes,
+                      void* stream);
+int cmgan_stream_decoder(cmgan_handle* h, const float* x_dev, const float* spec_dev, int B, int T,
+                         const float* frozen_stats_dev, float* out_real_dev, float* out_imag_dev,
+                         void* workspace_dev, size_t workspace_bytes, void* stream);
 
 /* Self-test of the MFMA fragment conventions every kernel relies on: computes
  * D = A(16xK) * B(Kx16) with the f32 16x16x4 MFMA and the library's fragment

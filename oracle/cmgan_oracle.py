@@ -229,8 +229,39 @@ def tscb_train(sd, p, x, masks_time: dict | None = None, masks_freq: dict | None
     return x_f.view(b, t, f, c).permute(0, 3, 1, 2)
 
 
+class norm_stats:
+    """Context manager for FROZEN InstanceNorm statistics (the carried-state streaming contract of
+    include/cmgan_hip.h, "Streaming"; oracle/stream_oracle.py).  `norm_stats("record", d)`: every InstanceNorm2d of the
+    generator (generator.py:35,55,61,128,148) stores the per-(b, c) mean and biased variance it used in d[<its
+    state-dict prefix>]; `norm_stats("replay", d)`: it normalises with the stored pair instead of its input's own -
+    BatchNorm-in-eval-mode arithmetic, under which the dense encoder and both decoders are exactly time-causal."""
+    active = None
+
+    def __init__(self, mode: str, store: dict):
+        assert mode in ("record", "replay")
+        self.mode, self.store = mode, store
+
+    def __enter__(self):
+        self.prev, norm_stats.active = norm_stats.active, self
+        return self.store
+
+    def __exit__(self, *exc):
+        norm_stats.active = self.prev
+
+
+def _instance_norm(x, w, b, key):
+    ctx = norm_stats.active
+    if ctx is None:
+        return F.instance_norm(x, weight=w, bias=b, eps=EPS)
+    if ctx.mode == "record":
+        ctx.store[key] = (x.mean(dim=(2, 3), keepdim=True), x.var(dim=(2, 3), unbiased=False, keepdim=True))
+        return F.instance_norm(x, weight=w, bias=b, eps=EPS)
+    mean, var = ctx.store[key]
+    return (x - mean) / torch.sqrt(var + EPS) * w.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+
+
 def _in_prelu(sd, norm, prelu, x):
-    x = F.instance_norm(x, weight=sd[norm + ".weight"], bias=sd[norm + ".bias"], eps=EPS)
+    x = _instance_norm(x, sd[norm + ".weight"], sd[norm + ".bias"], norm)
     return F.prelu(x, sd[prelu + ".weight"])
 
 

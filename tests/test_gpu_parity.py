@@ -681,3 +681,83 @@ def test_unloaded_model_refuses_to_run():
         m(torch.zeros(1, 2, 4, 201, device=DEV))
     with pytest.raises(KeyError):
         m.load_state_dict({"dense_encoder.conv_1.0.weight": torch.zeros(64, 3, 1, 1)})
+
+
+# ------------------------------------------------------------------ streaming with carried state
+def _stream_setup(model, L=6000, seed=31):
+    wav = synthetic_clips(1, L, seed=seed)
+    spec = O.stft_compress(wav * O.rms_scale(wav)[:, None])
+    return wav, spec
+
+
+def test_stream_frozen_statistics_of_the_clip_itself_reproduce_the_forward_bit_for_bit(model):
+    """cmgan_tscnet_forward_stats: stats_out of an unfrozen call, fed back as frozen_stats, skips every in_finalize /
+    mask_stats launch and must give the SAME bits; the unfrozen call is cmgan_tscnet_forward."""
+    eng = model.engine
+    _, spec = _stream_setup(model)
+    x = spec.to(DEV)
+    r0, i0 = eng.tscnet_forward(x)
+    r1, i1, blob = eng.tscnet_forward_stats(x)
+    assert torch.equal(r0, r1) and torch.equal(i0, i1) and blob.numel() == eng.stats_floats(1)
+    r2, i2, blob2 = eng.tscnet_forward_stats(x, frozen=blob)
+    assert torch.equal(r2, r0) and torch.equal(i2, i0) and torch.equal(blob2, blob)
+    # other statistics -> another result (the blob really is what normalises)
+    r3, _, _ = eng.tscnet_forward_stats(x, frozen=blob * 1.01)
+    assert not torch.equal(r3, r0)
+
+
+def test_stream_encoder_and_decoder_state_carry_is_exact(model):
+    """The N3 exactness claim: under frozen statistics frame t of the dense encoder / of the decoders depends on input
+    frames t - 15 .. t only, so ANY slice with 15 frames of history in front reproduces the whole-clip frames BIT FOR
+    BIT (same kernels, same per-output summation order, other tile positions) - and the whole-clip frozen pass is the
+    plain forward (previous test).  14 frames of history are not enough."""
+    eng = model.engine
+    _, spec = _stream_setup(model)
+    x = spec.to(DEV)
+    real, imag, st = eng.tscnet_forward(x, taps=True)
+    _, _, blob = eng.tscnet_forward_stats(x)
+    whole = eng.stream_encoder(x, blob)                                        # [1,T,F',64]
+    assert torch.equal(whole.permute(0, 3, 1, 2), st["encoder"])               # = the forward's own encoder output
+    H = 15
+    for lo, hi in ((20, 45), (15, 61), (33, 34), (40, 61)):
+        part = eng.stream_encoder(x[:, :, lo - H:hi].contiguous(), blob)
+        assert torch.equal(part[:, H:], whole[:, lo:hi]), (lo, hi)
+    short = eng.stream_encoder(x[:, :, 20 - 14:45].contiguous(), blob)
+    assert not torch.equal(short[:, 14:15], whole[:, 20:21])
+    # decoders: whole-clip TSCB output in, the forward's own outputs out; slices with history equal them
+    h = st["tscb4"].permute(0, 2, 3, 1).contiguous()                           # [1,T,F',64]
+    wr, wi = eng.stream_decoder(h, x, blob)
+    assert torch.equal(wr, real) and torch.equal(wi, imag)
+    for lo, hi in ((25, 50), (15, 61), (30, 31)):
+        pr, pi = eng.stream_decoder(h[:, lo - H:hi].contiguous(), x[:, :, lo - H:hi].contiguous(), blob)
+        assert torch.equal(pr[:, :, H:], real[:, :, lo:hi]) and torch.equal(pi[:, :, H:], imag[:, :, lo:hi]), (lo, hi)
+    # the TSCB slice = the forward's TSCBs
+    xt = whole.clone()
+    eng.stream_tscb(xt)
+    assert torch.equal(xt.permute(0, 3, 1, 2), st["tscb4"])
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_enhance_stream_matches_the_stream_oracle_and_graph_replay_equals_eager(model, sd, graph):
+    """cmgan_amd.streaming.enhance_stream (carried encoder / decoder state, cached encoder outputs as attention
+    context, frozen statistics calibrated on the first window) against oracle/stream_oracle.py on a 1.6 s clip in
+    40-frame windows: five steps of three shapes (first, steady, last)."""
+    from cmgan_amd.streaming import enhance_stream
+    from oracle import stream_oracle as S
+    wav = synthetic_clips(1, 16000, seed=33)
+    want = S.enhance_stream(sd, wav, window=40, context=12, lookahead=8)
+    got = enhance_stream(model, wav.to(DEV), window=40, context=12, lookahead=8, graph=graph)
+    _check(f"enhance_stream (graph={graph}) vs stream oracle", got, want, gate=STAGE)
+    if graph:
+        again = enhance_stream(model, wav.to(DEV), window=40, context=12, lookahead=8, graph=True)      # cached graphs
+        eager = enhance_stream(model, wav.to(DEV), window=40, context=12, lookahead=8, graph=False)
+        assert torch.equal(again, got) and torch.equal(eager, got)
+
+
+def test_enhance_stream_with_one_window_is_the_plain_forward(model):
+    """window >= T, calibration on the whole clip: one step whose frozen statistics are the clip's own = enhance()."""
+    from cmgan_amd.streaming import enhance_stream
+    wav = synthetic_clips(1, 6000, seed=35).to(DEV)
+    got = enhance_stream(model, wav, window=64, context=8, lookahead=8, graph=False)
+    want = model.engine.enhance(wav)[0]
+    assert torch.equal(got, want)
