@@ -105,6 +105,7 @@ def _enhance_rows(model: TSCNet, rows: torch.Tensor, graph: bool) -> torch.Tenso
 # on [context | window | look-ahead] frames of encoder outputs that are CACHED (context) or fresh, and keeps the window.
 #
 #   step k:  encoder   spec frames [e0 - 15, e1)        -> keep [e0, e1),  e1 = min((k + 1) W + La, T): each frame once
+#            (the step with e1 = T is the last one and emits every frame from k W on)
 #            TSCBs     encoder outputs [k W - Ca, e1)    -> keep [k W, (k + 1) W)
 #            decoders  [15 kept TSCB frames of step k - 1 | the kept frames] + their spec frames -> keep the W new ones
 #
@@ -150,7 +151,7 @@ class StreamState:
         cache = self.eng._row_graphs
         ent = cache.get(key)
         if ent is None or ent[3] != self.eng._ws_token() or ent[4] is not self.stats:
-            static = [None if a is None else a.clone() for a in args]
+            static = [None if a is None else a.contiguous().clone() for a in args]
             side = torch.cuda.Stream(device=self.eng.device)
             side.wait_stream(torch.cuda.current_stream(self.eng.device))
             with torch.cuda.stream(side):                       # warm-up outside capture (workspace, allocator)
@@ -167,13 +168,14 @@ class StreamState:
             if dst is not None:
                 dst.copy_(src)
         g.replay()
-        return tuple(o.clone() for o in outs)
+        return outs              # static buffers of this shape's graph: step() copies what it keeps before the next replay
 
     @torch.no_grad()
     def step(self, spec_new: torch.Tensor, last: bool = False):
         """spec_new: [B,2,n,F] = the spectrogram frames that arrived since the previous step (frames [e1, e1 + n)).
         Step k needs frames up to (k + 1) W + La (fewer only when `last`: the clip ended).  Returns (est_real, est_imag)
-        [B,1,w,F] for frames [k W, k W + w), w = W (or what is left of the clip when `last`)."""
+        [B,1,w,F] for frames [k W, k W + w), w = W - or, when `last`, all that is left of the clip (at most W + La: the
+        step whose look-ahead reaches the clip's end is the last one)."""
         W, Ca, H = self.W, self.Ca, HIST_FRAMES
         k, e0 = self.k, self.e1
         n_new = spec_new.size(2)
@@ -183,15 +185,16 @@ class StreamState:
             raise ValueError(f"step {k} takes the frames up to {want} (fewer only at the end of the clip), got up to {e1}")
         self.spec_tail = torch.cat([self.spec_tail, spec_new], dim=2)
         lo = k * W                                             # first frame this step emits
-        n_keep = min(W, e1 - lo)
+        n_keep = e1 - lo if last else min(W, e1 - lo)          # the clip's last step also emits what is left past its window
         if n_keep <= 0:
             raise ValueError("no frame left to emit")
         h_enc = min(H, e0)                                     # history the encoder can see (0 at the start of the clip)
-        spec_enc = self.spec_tail[:, :, e0 - h_enc - self.spec_lo:e1 - self.spec_lo].contiguous()
+        cg = (lambda t: t) if self.graph else (lambda t: t.contiguous())   # (the graph path copies slices into static inputs)
+        spec_enc = cg(self.spec_tail[:, :, e0 - h_enc - self.spec_lo:e1 - self.spec_lo])
         a0 = max(lo - Ca, 0)                                   # TSCB frames [a0, e1): cached context + fresh
-        enc_ctx = self.enc[:, a0 - self.enc_lo:e0 - self.enc_lo].contiguous()
+        enc_ctx = cg(self.enc[:, a0 - self.enc_lo:e0 - self.enc_lo])
         h_dec = 0 if self.dec_hist is None else self.dec_hist.size(1)
-        spec_dec = self.spec_tail[:, :, lo - h_dec - self.spec_lo:lo + n_keep - self.spec_lo].contiguous()
+        spec_dec = cg(self.spec_tail[:, :, lo - h_dec - self.spec_lo:lo + n_keep - self.spec_lo])
         args = (spec_enc, enc_ctx, self.dec_hist, spec_dec)
         ints = (n_new, lo - a0, n_keep)
         x_new, kept, real, imag = (self._run_graphed(args, ints) if self.graph else self._run(*args, *ints))
@@ -202,12 +205,12 @@ class StreamState:
         if drop > 0:
             self.enc, self.enc_lo = self.enc[:, drop:].contiguous(), self.enc_lo + drop
         hist = kept if self.dec_hist is None else torch.cat([self.dec_hist, kept], dim=1)
-        self.dec_hist = hist[:, -min(H, hist.size(1)):].contiguous()      # the frames just before nxt_lo
+        self.dec_hist = hist[:, -min(H, hist.size(1)):].clone()           # the frames just before nxt_lo (a COPY: `kept` may be a graph's static output)
         sdrop = max(nxt_lo - H, 0) - self.spec_lo                          # both histories start at nxt_lo - H or later
         if sdrop > 0:
             self.spec_tail, self.spec_lo = self.spec_tail[:, :, sdrop:].contiguous(), self.spec_lo + sdrop
         self.k, self.e1 = k + 1, e1
-        return real, imag
+        return (real.clone(), imag.clone()) if self.graph else (real, imag)     # (not views of a graph's static outputs)
 
 
 @torch.no_grad()
@@ -230,7 +233,7 @@ def enhance_stream(model: TSCNet, noisy: torch.Tensor, window: int = 400, contex
     real = torch.empty(1, 1, T, eng.F, device=noisy.device)
     imag = torch.empty_like(real)
     k, fed = 0, 0
-    while k * window < T:
+    while fed < T:
         upto = min((k + 1) * window + lookahead, T)
         r, i = st.step(spec[:, :, fed:upto].contiguous(), last=upto == T)
         w = r.size(2)

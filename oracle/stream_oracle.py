@@ -66,7 +66,7 @@ def stream_forward(sd, spec, stats, window: int, context: int, lookahead: int):
     kept_all = None                              # kept TSCB outputs of frames [0, k W)
     e1, k = 0, 0
     with O.norm_stats("replay", stats):
-        while k * window < T:
+        while e1 < T:
             lo, e0 = k * window, e1
             e1 = min((k + 1) * window + lookahead, T)
             h0 = max(e0 - HIST, 0)
@@ -76,7 +76,7 @@ def stream_forward(sd, spec, stats, window: int, context: int, lookahead: int):
             x = enc[:, :, a0:e1]
             for b in range(1, 5):
                 x = O.tscb(sd, f"TSCB_{b}", x)
-            n_keep = min(window, e1 - lo)
+            n_keep = e1 - lo if e1 == T else min(window, e1 - lo)      # the last step emits what is left
             kept = x[:, :, lo - a0:lo - a0 + n_keep]
             kept_all = kept if kept_all is None else torch.cat([kept_all, kept], dim=2)
             d0 = max(lo - HIST, 0)
