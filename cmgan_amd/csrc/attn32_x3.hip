@@ -742,7 +742,12 @@ __device__ __forceinline__ void asp_wread(const AspCtx& c, f32x16 (&sn)[2]) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) sn[jt][v] = c.Rr[32 * jt + 8 * (v >> 2) + (v & 3)];
 }
+// Key offset inside its chunk of score register v of key tile jt, for the lane half hh = 0 (hh = 1: + 4)
+__host__ __device__ constexpr int asp_koff(int jt, int v) { return 32 * jt + 8 * (v >> 2) + (v & 3); }
+// TAILK > 0: the sequence's tail chunk has exactly TAILK keys (a compile-time constant of the instantiation): a score
+// whose key offset is >= TAILK even for hh = 0 is dead for EVERY lane and costs nothing (no exp2, no compare).
 // p = exp2(s) for the 8 scores of 16-key group g of a chunk (exp2(-inf) = 0 for non-existent keys), split to fp16
+template <int TAILK = 0>
 __device__ __forceinline__ void asp_exp8(const f32x16 (&s)[2], int g, float& psum, f16x8& ph, f16x8& pl) {
     if (ASP_ABL == 3) {
         f32x4 a = {s[g >> 1][8 * (g & 1)], s[g >> 1][8 * (g & 1) + 1], s[g >> 1][8 * (g & 1) + 2], s[g >> 1][8 * (g & 1) + 3]};
@@ -754,13 +759,18 @@ __device__ __forceinline__ void asp_exp8(const f32x16 (&s)[2], int g, float& psu
     f32x4 pa, pb;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        pa[r] = __builtin_amdgcn_exp2f(s[g >> 1][8 * (g & 1) + r]);
-        pb[r] = __builtin_amdgcn_exp2f(s[g >> 1][8 * (g & 1) + 4 + r]);
-        psum += pa[r] + pb[r];
+        const bool la = TAILK == 0 || asp_koff(g >> 1, 8 * (g & 1) + r) < TAILK;
+        const bool lb = TAILK == 0 || asp_koff(g >> 1, 8 * (g & 1) + 4 + r) < TAILK;
+        pa[r] = la ? __builtin_amdgcn_exp2f(s[g >> 1][8 * (g & 1) + r]) : 0.f;
+        pb[r] = lb ? __builtin_amdgcn_exp2f(s[g >> 1][8 * (g & 1) + 4 + r]) : 0.f;
+        if (la) psum += pa[r];
+        if (lb) psum += pb[r];
     }
     asm volatile("" : "+v"(psum));                       // keeps the eight adds in this slot (they would sink to the loop's end)
     split8(pa, pb, ph, pl);
 }
+// live 16-key groups of a tail chunk of TAILK keys (2 * NKT when the tail length is a run-time value)
+__host__ __device__ constexpr int asp_live_groups(int TAILK, int NKT) { return TAILK > 0 ? (TAILK + 15) / 16 : 2 * NKT; }
 __device__ __forceinline__ void asp_pv(f32x16& o, const f16x8& va, const f16x8& ph, const f16x8& pl) {
     if (ASP_ABL == 4 || ASP_ABL == 10) {
         o[0] += (float)ph[0] + (float)pl[0] + (float)va[0];
@@ -799,27 +809,34 @@ __device__ __forceinline__ void asp_front(const AspCtx& c, AspTile tn, int nn, f
 }
 
 // Back half alone (the block's last unit).
-template <int NKT>
+template <int NKT, int TAILK = 0>
 __device__ __forceinline__ void asp_back(f32x16 (&s)[2], A32State& st, f32x16& o, const f16x8 (&va)[4]) {
     float psum = 0.f;
 #pragma unroll
-    for (int g = 0; g < 2 * NKT; ++g) {
+    for (int g = 0; g < asp_live_groups(TAILK, NKT); ++g) {
         f16x8 ph, pl;
-        asp_exp8(s, g, psum, ph, pl);
+        asp_exp8<TAILK>(s, g, psum, ph, pl);
         asp_pv(o, va[g], ph, pl);
     }
     st.l += psum;
 }
 
 // running maximum of the scores of a chunk (already relative to the reference level): this lane's query
-template <int NKT, bool FULL>
+template <int NKT, bool FULL, int TAILK = 0>
 __device__ __forceinline__ float asp_max(const AspCtx& c, f32x16 (&s)[2], int j0) {
     float mx[2] = {-INFINITY, -INFINITY};                 // one chain per key tile (the tiles' K q chains end at different times)
 #pragma unroll
     for (int jt = 0; jt < NKT; ++jt)
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
-            if (!FULL) {
+            if (!FULL && TAILK > 0) {
+                // compile-time tail: dead for every lane / live for every lane / live for the hh = 0 half only.  (As a
+                // run-time test - below - the 32 compares are loop invariants the compiler keeps as 32 SGPR-pair masks:
+                // 119 SGPR spills through v_writelane / v_readlane per query tile on the L = 101 axis.)
+                const int koff = asp_koff(jt, v);
+                if (koff >= TAILK) { s[jt][v] = -INFINITY; continue; }
+                if (koff + 4 >= TAILK) s[jt][v] = c.hh ? -INFINITY : s[jt][v];
+            } else if (!FULL) {
                 const int key = j0 + 32 * jt + 8 * (v >> 2) + 4 * c.hh + (v & 3);
                 s[jt][v] = key < c.L ? s[jt][v] : -INFINITY;
             }
@@ -831,10 +848,10 @@ __device__ __forceinline__ float asp_max(const AspCtx& c, f32x16 (&s)[2], int j0
 // Reference step for the chunk whose scores are pending in s (outside the hot loop): takes the running maximum and,
 // if any lane of the wave left the band, re-references every lane to its running maximum (scores, denominator,
 // the O accumulator and the -m splat).  The scheme: file header.
-template <int NKT, bool FULL>
+template <int NKT, bool FULL, int TAILK = 0>
 __device__ __forceinline__ void asp_reference(const AspCtx& c, f32x16 (&s)[2], int j0, A32State& st, f32x16& o,
                                               f32x16& negm) {
-    const float run = fmaxf(st.run, asp_max<NKT, FULL>(c, s, j0));
+    const float run = fmaxf(st.run, asp_max<NKT, FULL, TAILK>(c, s, j0));
     const bool drift = run > A32_HI || run < A32_LO;
     if (__builtin_expect(__any(drift), 0)) {
         asm volatile("; re-reference");                  // a side effect: keeps this rare path a branch (if-converted it costs
@@ -861,11 +878,13 @@ __device__ __forceinline__ void asp_reference(const AspCtx& c, f32x16 (&s)[2], i
 // u + 1 is the last chunk of its tile), Q tile tn's.  Tiles may belong to different sequences (AspTile::so).  Every
 // register is refilled in the slot of its last use - a whole body before its next one.
 // HOTMX: also returns the maximum of sn over this lane's query (both units are full chunks of one tile then).
-template <int NF, int NB, bool HOTMX, bool CLAMP, bool LASTQ, bool ESHARE = false>
+// TB > 0: the BACK unit is the sequence's tail chunk and has exactly TB keys (compile-time): dead 16-key groups are skipped
+template <int NF, int NB, bool HOTMX, bool CLAMP, bool LASTQ, bool ESHARE = false, int TB = 0>
 __device__ __forceinline__ float asp_fused(const AspCtx& c, AspTile tn, int nn, AspTile tv, int vn, f16x8& qh,
                                            f16x8& ql, f16x8 (&eh)[3], f16x8 (&el)[3], f16x8 (&kh)[2], f16x8 (&kl)[2],
                                            f16x8 (&va)[4], const f32x16& negm_n, f32x16 (&s)[2], f32x16 (&sn)[2],
                                            A32State& st, f32x16& o A32_STAMP_ARG) {
+    constexpr int LG = asp_live_groups(TB, NB);           // live 16-key groups of the back unit
     float psum = 0.f;
     f16x8 ph[2], pl[2];
     f32x16 racc = zero16();                              // (ASP_ABL == 8 only)
@@ -877,7 +896,7 @@ __device__ __forceinline__ float asp_fused(const AspCtx& c, AspTile tn, int nn, 
         f32x16 r;
         if (ASP_ABL != 2 && ASP_ABL != 10) r = asp_eq(eh[0], el[0], qh, ql, negm_n);
         if (!ESHARE && ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, 32 * tn.it, nn, 0, eh[0], el[0]);
-        asp_exp8(s, 0, psum, ph[0], pl[0]);
+        asp_exp8<TB>(s, 0, psum, ph[0], pl[0]);
         if (ASP_ABL == 8) racc = r; else if (ASP_ABL != 2 && ASP_ABL != 10) asp_wwrite(c, 0, r);
     }
     ASP_FMARK(1);
@@ -889,7 +908,7 @@ __device__ __forceinline__ float asp_fused(const AspCtx& c, AspTile tn, int nn, 
         if (ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, 32 * tn.it, nn, 1, eh[1], el[1]);
         asp_pv(o, va[0], ph[0], pl[0]);
         if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[0] = asp_load_v(c, tv.so, vn, 0);
-        asp_exp8(s, 1, psum, ph[1], pl[1]);
+        if (LG > 1) asp_exp8<TB>(s, 1, psum, ph[1], pl[1]);
         if (ASP_ABL == 8) { for (int v = 0; v < 16; ++v) racc[v] = fmaxf(racc[v], r[v]); } else if (ASP_ABL != 2 && ASP_ABL != 10) asp_wwrite(c, 1, r);
     }
     ASP_FMARK(2);
@@ -900,9 +919,9 @@ __device__ __forceinline__ float asp_fused(const AspCtx& c, AspTile tn, int nn, 
         if (NF == 2 && ASP_ABL != 2 && ASP_ABL != 10) r = asp_eq(eh[2], el[2], qh, ql, negm_n);
         if (ESHARE) { eh[0] = eh[2]; el[0] = el[2]; }   // window tile 2 of this chunk IS tile 0 of the next chunk of the tile
         if (ASP_ABL != 1 && ASP_ABL != 6 && ASP_ABL != 10) asp_load_e<CLAMP>(c, 32 * tn.it, nn, 2, eh[2], el[2]);
-        asp_pv(o, va[1], ph[1], pl[1]);
+        if (LG > 1) asp_pv(o, va[1], ph[1], pl[1]);
         if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[1] = asp_load_v(c, tv.so, vn, 1);
-        if (NB == 2) asp_exp8(s, 2, psum, ph[0], pl[0]);
+        if (LG > 2) asp_exp8<TB>(s, 2, psum, ph[0], pl[0]);
         if (ASP_ABL == 8) sn[1] = r; else if (NF == 2 && ASP_ABL != 2 && ASP_ABL != 10) asp_wwrite(c, 2, r);
     }
     ASP_FMARK(3);
@@ -913,9 +932,9 @@ __device__ __forceinline__ float asp_fused(const AspCtx& c, AspTile tn, int nn, 
     else if (ASP_ABL != 2 && ASP_ABL != 10) asp_wread<NF>(c, sn);
     else { sn[0] = splat16(psum); sn[1] = splat16(psum); }
     wave_lds_fence();
-    if (NB == 2) asp_pv(o, va[2], ph[0], pl[0]);
+    if (LG > 2) asp_pv(o, va[2], ph[0], pl[0]);
     if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[2] = asp_load_v(c, tv.so, vn, 2);
-    if (NB == 2) asp_exp8(s, 3, psum, ph[1], pl[1]);
+    if (LG > 3) asp_exp8<TB>(s, 3, psum, ph[1], pl[1]);
     ASP_FMARK(4);
     ASP_SB();
     // slot 4: K q on top of the skewed window; next unit's K (and Q)
@@ -930,7 +949,7 @@ __device__ __forceinline__ float asp_fused(const AspCtx& c, AspTile tn, int nn, 
     ASP_FMARK(5);
     ASP_SB();
     // slot 5: P V of group 3; V of the next unit | running maximum of the new scores
-    if (NB == 2) asp_pv(o, va[3], ph[1], pl[1]);
+    if (LG > 3) asp_pv(o, va[3], ph[1], pl[1]);
     if (ASP_ABL != 1 && ASP_ABL != 7 && ASP_ABL != 10) va[3] = asp_load_v(c, tv.so, vn, 3);
     st.l += psum;
     float mx = 0.f;
@@ -943,7 +962,9 @@ __device__ __forceinline__ float asp_fused(const AspCtx& c, AspTile tn, int nn, 
 }
 
 // NKTL / FULLL: live key tiles of a query tile's LAST chunk / that chunk has all 64 keys (L % 64 == 0)
-template <bool CLAMP, int NKTL, bool FULLL>
+// TAILK > 0: L % 64 as a compile-time constant (the model's own shapes: 1 for the 321-frame axis, 37 for the 101-bin
+// axis, 45 for the 301-bin axis of the 48 kHz variant); 0 = any tail, tested at run time
+template <bool CLAMP, int NKTL, bool FULLL, int TAILK = 0>
 __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Float16* __restrict__ qimg,
                                                                 const _Float16* __restrict__ kimg,
                                                                 const _Float16* __restrict__ vimg,
@@ -951,7 +972,7 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
                                                                 float* __restrict__ x, TokMap m,
                                                                 const _Float16* __restrict__ woi,
                                                                 const float* __restrict__ bo, int Lt, int tpb, int nseq,
-                                                                int group) {
+                                                                int group, unsigned lt_magic) {
     __shared__ __attribute__((aligned(16))) float rbuf[4][ASP_RFL];
     __shared__ __attribute__((aligned(16))) f32x4 stash[2][4][2][64];      // [parity][head][16-token block][16x16 lane]
 #ifdef A32_STAMP
@@ -980,7 +1001,17 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
     if (G0 >= GN) return;                                 // the stream ended before this block (block-uniform)
     const int nleft = (GN - 1 - G0) / gs + 1;
     const int ntl = nleft < tpb ? nleft : tpb;            // this block's tiles: G0 + t * gs, t < ntl
-    const int n0 = __builtin_amdgcn_readfirstlane((int)((unsigned)G0 / (unsigned)Lt));
+    // G / Lt for the (uniform) tile numbers of the stream: a multiply-high by lt_magic = floor(2^32 / Lt) + 1 on the
+    // scalar unit (exact while G * Lt < 2^32: the launcher passes 0 otherwise).  An integer division runs on the VALU
+    // (~15 instructions + a readfirstlane), two or three times per query tile.
+    auto div_lt = [&](int G) -> int {
+        if (__builtin_expect(lt_magic == 0u, 0)) {
+            asm volatile("; division path");             // (a side effect: keeps this a branch - if-converted, the division would run every time)
+            return __builtin_amdgcn_readfirstlane((int)((unsigned)G / (unsigned)Lt));
+        }
+        return (int)__umulhi((unsigned)__builtin_amdgcn_readfirstlane(G), lt_magic);
+    };
+    const int n0 = div_lt(G0);
     const long nh0 = (long)n0 * 4 + wv;                   // this wave's head of the block's first sequence
     const int L = m.L;
     AspCtx c;
@@ -1005,7 +1036,7 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
     // tile G of the stream (clamped to the last tile of the last sequence for prefetches past the end)
     auto tile_of = [&](int G) -> AspTile {
         G = G < GN ? G : GN - 1;
-        const int n = __builtin_amdgcn_readfirstlane((int)((unsigned)G / (unsigned)Lt));
+        const int n = div_lt(G);
         AspTile t;
         t.it = G - n * Lt;
         t.so = (unsigned)(n - n0) * seq_bytes;
@@ -1045,7 +1076,7 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
         char* xbase = reinterpret_cast<char*>(x + ((long)nq * m.outer + (long)(n - nq * m.inner) * m.istride) * 64 + 16 * wv);
         // reference step of the tile's chunk 0 (its front half ran under the previous tile's last back half)
         if (nch > 1) asp_reference<2, true>(c, s, 0, st, o, negm);
-        else asp_reference<NKTL, FULLL>(c, s, 0, st, o, negm);
+        else asp_reference<NKTL, FULLL, TAILK>(c, s, 0, st, o, negm);
         int ch = 0;                                       // s = the referenced scores of chunk ch of this tile
         // hot loop: back half of chunk ch under the front half of chunk ch + 1 (never the tile's last chunk)
         while (ch < nch - 2) {
@@ -1076,7 +1107,7 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
             f32x16 sn[2];
             asp_fused<NKTL, 2, false, CLAMP, true>(c, t1, 0, tc, nch - 1, qh, ql, eh, el, kh, kl, va, negm, s, sn,
                                                    st, o A32_STAMP_PASS);
-            asp_reference<NKTL, FULLL>(c, sn, 64 * nfull, st, o, negm);
+            asp_reference<NKTL, FULLL, TAILK>(c, sn, 64 * nfull, st, o, negm);
             s[0] = sn[0]; s[1] = sn[1];
         }
         // residual rows + bias of this wave's output block (epilogue operands): requested BEFORE the tile's last body, whose
@@ -1097,10 +1128,10 @@ __global__ __launch_bounds__(256, ASP_OCC) void attn_sp_out_x3_kernel(const _Flo
         if (tl + 1 < ntl) {
             const f32x16 zero = zero16();
             // (single-chunk sequences: the next tile's chunk 0 is also its last chunk, the unit after it is tile G + 2's)
-            if (nch == 1) asp_fused<NKTL, NKTL, false, CLAMP, true>(c, tile_of(G + 2 * gs), 0, t1, 0, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
-            else asp_fused<2, NKTL, false, CLAMP, false, true>(c, t1, 1, t1, 0, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
+            if (nch == 1) asp_fused<NKTL, NKTL, false, CLAMP, true, false, TAILK>(c, tile_of(G + 2 * gs), 0, t1, 0, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
+            else asp_fused<2, NKTL, false, CLAMP, false, true, TAILK>(c, t1, 1, t1, 0, qh, ql, eh, el, kh, kl, va, zero, s, sn, st, o A32_STAMP_PASS);
         } else {
-            asp_back<NKTL>(s, st, o, va);
+            asp_back<NKTL, TAILK>(s, st, o, va);
         }
         ASP_CMARK(1);                                     // the tile's units
         // ---- epilogue of the tile: O / l -> stash -> barrier -> to_out + bias + residual ----
@@ -1228,15 +1259,22 @@ void launch_attn_sp_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* 
         if (Lt <= 4 && k_align_short) tpb = (tpb + Lt - 1) / Lt * Lt;      // blocks own whole sequences
     }
     const int group = Lt <= 4 ? k_group_short : k_group_long;
+    // (Lt = 1: the magic would be 2^32 + 1; such sequences take the division path)
+    const unsigned lt_magic = Lt > 1 && (long)N * Lt * Lt < (1l << 32) ? (unsigned)((1ul << 32) / (unsigned long)Lt) + 1u : 0u;
     const long nb = ((long)N * Lt + tpb - 1) / tpb;
     const unsigned grid = XCD_ORDER ? (unsigned)(((nb + 7) / 8) * 8) : (unsigned)nb;
     const int tail = seq.L & 63;
     const bool clamp = seq.L + 96 > max_pos;
-#define ASP_LAUNCH(CL, NK, FU)                                                                                    \
-    LAUNCH(ctx, "attn_out", (attn_sp_out_x3_kernel<CL, NK, FU><<<grid, 256, 0, ctx.stream>>>(                     \
-                                qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, N, group)))
+#define ASP_LAUNCH(CL, NK, FU, ...)                                                                               \
+    LAUNCH(ctx, "attn_out", (attn_sp_out_x3_kernel<CL, NK, FU, ##__VA_ARGS__><<<grid, 256, 0, ctx.stream>>>(      \
+                                qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, N, group, lt_magic)))
     if (!clamp) {
+        // the model's own tails as compile-time constants (attn_sp_out_x3_kernel: TAILK); any other length: run-time test
+        static const int k_tailk = env_knob("CMGAN_ASP_TAILK", 1);
         if (tail == 0) ASP_LAUNCH(false, 2, true);
+        else if (k_tailk && tail == 1) ASP_LAUNCH(false, 1, false, 1);
+        else if (k_tailk && tail == 37) ASP_LAUNCH(false, 2, false, 37);
+        else if (k_tailk && tail == 45) ASP_LAUNCH(false, 2, false, 45);
         else if (tail > 32) ASP_LAUNCH(false, 2, false);
         else ASP_LAUNCH(false, 1, false);
     } else {
