@@ -454,14 +454,14 @@ def main():
             torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if world > 1 or cdist._active():
             torch.distributed.barrier()
 
     # did the collective really span `world` ranks?
     ones = torch.ones(1, device=dev)
     cdist.allreduce_scalars(ones)
     ranks_seen = int(round(float(ones.item())))
-    backend = torch.distributed.get_backend() if world > 1 else "none (single process)"
+    backend = torch.distributed.get_backend() if cdist._active() else "none (single process)"
 
     for _ in range(args.warmup):
         step()
@@ -478,7 +478,7 @@ def main():
     elapsed = time.perf_counter() - t0
     et = torch.tensor([elapsed, own], device=dev, dtype=torch.float64)
     per_rank = [et.clone() for _ in range(world)]
-    if world > 1:
+    if world > 1 or cdist._active():
         torch.distributed.all_gather(per_rank, et)
     elapsed = max(float(t[0]) for t in per_rank)              # MAX over ranks
     unit_frames = sh.B * sh.T if not args.stub_cpu else 2 * 17
@@ -618,12 +618,19 @@ def main():
             line["train_step"] = {"stub": True, "grad_mean_ok": bool(abs(float(b["w"][0]) - want) < 1e-6),
                                   "bucket_floats": int(b.numel)}
 
-    if rank == 0:
-        print(json.dumps(line), flush=True)
-
-    if world > 1:
+    # The JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio, which sits in libc's
+    # buffer until exit and would otherwise land after the line - so the process group is shut down and libc's
+    # buffers are flushed first.
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                           # noqa: BLE001 - cosmetic
+        pass
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -9,6 +9,7 @@
 // mirror image (uncompress fused into the operand staging, synthesis window folded into
 // the inverse DFT matrix) followed by a small overlap-add / envelope / un-scale kernel.
 #include "kernels.h"
+#include <stdlib.h>
 
 // m2^p for the power-law (de)compression: 2^(p log2 m2) on the transcendental unit (v_log_f32 / v_exp_f32,
 // relative error ~1e-7 |log2 m2|) instead of libm powf (~60 instructions; 52 of them per lane used to be most
@@ -265,6 +266,9 @@ __global__ __launch_bounds__(256, 2) void stft_fold_x3_kernel(SpectralTables tb,
     }
 }
 
+#ifndef STFT_BSPLIT
+#define STFT_BSPLIT 3
+#endif
 void launch_stft_compress(LaunchCtx ctx, const SpectralTables& tb, const float* wav, const float* scale, int B,
                           int L, int T, float* spec) {
     if (tb.fold_fwd16 && tb.n_fft == 400 && tb.hop == 100) {
@@ -274,9 +278,19 @@ void launch_stft_compress(LaunchCtx ctx, const SpectralTables& tb, const float* 
             LAUNCH(ctx, "stft_compress",
                    (stft_fold_x3_kernel<400, 100, 1><<<grid64, 256, 0, ctx.stream>>>(tb, wav, scale, L, T, spec)));
         } else {
-            dim3 grid64(tiles, B, 3);
-            LAUNCH(ctx, "stft_compress",
-                   (stft_fold_x3_kernel<400, 100, 3><<<grid64, 256, 0, ctx.stream>>>(tb, wav, scale, L, T, spec)));
+            // bin blocks per thread block: the fewer, the shorter the dependent chain of one block (CMGAN_STFT_BSPLIT:
+            // same-session sweep knob; every bin is computed by the same instructions whatever the split)
+            static const int k_split = [] { const char* v = getenv("CMGAN_STFT_BSPLIT"); return v && *v ? atoi(v) : STFT_BSPLIT; }();
+#define STFT_LAUNCH(S)                                                                                             \
+    do {                                                                                                           \
+        dim3 grid64(tiles, B, S);                                                                                  \
+        LAUNCH(ctx, "stft_compress",                                                                               \
+               (stft_fold_x3_kernel<400, 100, S><<<grid64, 256, 0, ctx.stream>>>(tb, wav, scale, L, T, spec)));    \
+    } while (0)
+            if (k_split >= 13) STFT_LAUNCH(13);
+            else if (k_split >= 7) STFT_LAUNCH(7);
+            else STFT_LAUNCH(3);
+#undef STFT_LAUNCH
         }
         return;
     }

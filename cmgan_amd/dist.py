@@ -18,7 +18,10 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # CMGAN_DIST_FORCE_INIT=1: build the process group even for ONE rank, so that a single-GPU box can run the real
+    # "nccl" (= RCCL) code path end to end - communicator set-up, the loss-scalar / gradient-bucket all-reduces, the
+    # buffer broadcasts, the barrier - as a self-test (tests/test_gpu_dist_rccl.py); a 1-rank collective is the identity
+    if (world > 1 or _forced()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -27,6 +30,15 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def _forced() -> bool:
+    return os.environ.get("CMGAN_DIST_FORCE_INIT", "0") == "1"
+
+
+def _active() -> bool:
+    """Collectives run: a process group exists and spans several ranks (or the single-rank self-test is on)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _forced())
 
 
 def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
@@ -43,7 +55,7 @@ def shard_batch(batch: torch.Tensor, rank: int, world: int) -> torch.Tensor:
 
 def allreduce_scalars(values: torch.Tensor, op=dist.ReduceOp.SUM) -> torch.Tensor:
     """One small all-reduce (RCCL over xGMI on the GPU box); identity in a single process."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(values, op=op)
     return values
 
@@ -95,14 +107,14 @@ class FlatBucket:
 def allreduce_mean(flat: torch.Tensor) -> torch.Tensor:
     """Gradient averaging over ranks as ONE collective on a flat bucket (what DDP's bucketed all-reduce computes,
     src/train.py:192,200); identity in a single process."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         flat /= dist.get_world_size()
     return flat
 
 
 def _multi() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return _active()
 
 
 def broadcast_from_rank0(tensors) -> None:
