@@ -1,0 +1,38 @@
+#!/bin/bash
+# evidence session of a round (round 5: tag r05): full GPU suite, smoke, the default bench line, kernel trace + separate PMC passes of the
+# inference command (raw rocpd databases KEPT under gpurun_out/), stall / instruction-mix / exact fabric-byte counters,
+# batch sweep
+TAG=${1:-r05}
+OUT=$PWD/gpurun_out; REPO=$PWD; mkdir -p $OUT
+timeout 1800 python -m pytest tests -m gpu -q -s -p no:cacheprovider > $OUT/pytest_gpu_$TAG.log 2>&1
+echo "pytest exit $?"; grep -E "passed|failed" $OUT/pytest_gpu_$TAG.log | tail -2
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 900 python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "bench exit $?"
+BENCH="$REPO/bench.py --no-cpu-baseline --no-f32 --no-f16x1 --no-train --no-extra"
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o trace -- python $BENCH --steps 3 --warmup 1 > $OUT/prof_$TAG.log 2>&1; echo "trace $?"
+i=0
+for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
+         "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAVES SQ_WAVE_CYCLES" \
+         "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" \
+         "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
+         "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_${TAG}_$i -o pmc -- python $BENCH --steps 1 --warmup 1 > $OUT/pmc_${TAG}_$i.log 2>&1; echo "pmc $i $?"
+done
+cd $REPO
+db() { ls $1/*results.db $1/*/*results.db 2>/dev/null | head -1; }
+python tools/rocpd_summary.py trace $(db $OUT/prof_$TAG) > $OUT/${TAG}_x3_kernel_trace_stats.txt
+python tools/rocpd_summary.py pmc $(db $OUT/pmc_${TAG}_1) $(db $OUT/pmc_${TAG}_2) $(db $OUT/pmc_${TAG}_3) > $OUT/${TAG}_x3_pmc.txt
+python tools/rocpd_summary.py pmc $(db $OUT/pmc_${TAG}_4) $(db $OUT/pmc_${TAG}_5) > $OUT/${TAG}_x3_stall_counters.txt
+python tools/rocpd_summary.py pmc $(db $OUT/pmc_${TAG}_6) $(db $OUT/pmc_${TAG}_7) > $OUT/${TAG}_x3_fabric_requests.txt
+python tools/rocpd_summary.py traffic $(db $OUT/pmc_${TAG}_1) $(db $OUT/pmc_${TAG}_2) $OUT/bench_$TAG.json > $OUT/${TAG}_x3_hbm_traffic.json
+timeout 300 python tools/batch_sweep.py > $OUT/${TAG}_x3_batch_sweep.txt 2>/dev/null; echo "sweep $?"
+# keep the raw databases, drop everything else rocprofv3 wrote next to them
+mkdir -p $OUT/raw_$TAG
+for d in $OUT/prof_$TAG $OUT/pmc_${TAG}_*; do
+  f=$(db $d); [ -n "$f" ] && cp $f $OUT/raw_$TAG/$(basename $d).db
+  rm -rf $d
+done
+du -sh $OUT/raw_$TAG; ls $OUT/raw_$TAG | head -20
+tail -c 600 $OUT/bench_$TAG.json
