@@ -24,7 +24,7 @@ import torch
 
 from .generator import TSCNet
 
-__all__ = ["enhance_windows", "enhance_stream", "StreamState", "HIST_FRAMES"]
+__all__ = ["enhance_windows", "enhance_stream", "StreamState", "StreamingEnhancer", "HIST_FRAMES"]
 
 
 @torch.no_grad()
@@ -240,3 +240,125 @@ def enhance_stream(model: TSCNet, noisy: torch.Tensor, window: int = 400, contex
         real[:, :, k * window:k * window + w], imag[:, :, k * window:k * window + w] = r, i
         fed, k = upto, k + 1
     return (eng.uncompress_istft(real, imag) / c[:, None]).reshape(-1)
+
+
+class StreamingEnhancer:
+    """Sample-level front end of `StreamState` for live audio: `push(samples)` takes whatever arrived (any chunk size)
+    and returns the enhanced samples that are final by then; `flush()` ends the stream.
+
+    Everything outside the network is frame-local and therefore incremental WITHOUT approximation: STFT frame t reads
+    samples [100 t - 200, 100 t + 200) (reflect padding only at the true ends of the stream), output sample s sums the
+    four frames floor((s - 200) / 100) + 1 .. floor((s + 200) / 100); so frames are transformed as their samples arrive
+    (a block with two guard frames on each side), network steps run as soon as a window's look-ahead is covered, and
+    sample s is emitted once frame floor(s / 100) + 2 has been estimated.  Algorithmic latency = window + look-ahead
+    frames + 3 frames.  `scale` = the RMS normalisation factor c (evaluation.py:21-23): a live stream cannot know its
+    file-level RMS, so it is a parameter (e.g. from the calibration stretch); the output is divided by it again.
+    The result equals `enhance_stream` on the whole signal with the same statistics and scale to rounding (1.5e-6: the
+    split-f16 transforms scale each 64-frame tile by its own power of two, and the blocks tile the frames differently)."""
+
+    def __init__(self, model: TSCNet, stats: torch.Tensor, window: int = 400, context: int = 40, lookahead: int = 40,
+                 scale: float | torch.Tensor = 1.0, graph: bool = True):
+        self.eng = model.engine
+        self.hop, self.n_fft = self.eng.cfg.hop, self.eng.cfg.n_fft
+        if self.n_fft != 4 * self.hop:
+            raise ValueError("StreamingEnhancer assumes n_fft = 4 hop (400 / 100, 1200 / 300)")
+        dev = self.eng.device
+        self.c = torch.as_tensor(scale, dtype=torch.float32, device=dev).reshape(1)
+        self.state = StreamState(model, stats, 1, window, context, lookahead, graph)
+        self.W, self.La = window, lookahead
+        self.samples = torch.empty(0, device=dev)      # received samples from index `s_lo` on
+        self.s_lo = 0
+        self.n_in = 0                                  # samples received
+        self.t_spec = 0                                # spectrogram frames computed
+        self.spec_pend = torch.empty(1, 2, 0, self.eng.F, device=dev)   # computed, not yet fed to the network
+        self.est_r = torch.empty(1, 1, 0, self.eng.F, device=dev)       # estimated frames from `f_lo` on
+        self.est_i = torch.empty(1, 1, 0, self.eng.F, device=dev)
+        self.f_lo = 0
+        self.t_est = 0                                 # estimated frames
+        self.n_out = 0                                 # samples emitted
+        self.closed = False
+
+    # ---- STFT of the frames whose samples have arrived ----
+    def _advance_spec(self, final: bool):
+        hop = self.hop
+        t_b = (self.n_in // hop + 1) if final else (self.n_in - 2 * hop) // hop + 1      # frames [0, t_b) are computable
+        t_b = max(t_b, 0)
+        if t_b <= self.t_spec:
+            return
+        t_a = self.t_spec
+        g0 = max(t_a - 2, 0)                                            # two guard frames on the left (none at the start)
+        lo = g0 * hop
+        hi = self.n_in if final else (t_b + 1) * hop                    # ... and the samples of two on the right
+        if hi - lo <= self.n_fft // 2:                                  # (the very first samples: not enough for one block yet)
+            return
+        x = self.samples[lo - self.s_lo:hi - self.s_lo].reshape(1, -1).contiguous()
+        spec = self.eng.stft_compress(x, self.c)
+        self.spec_pend = torch.cat([self.spec_pend, spec[:, :, t_a - g0:t_b - g0]], dim=2)
+        self.t_spec = t_b
+        keep = max((t_b - 2) * hop - 2 * hop, 0)                        # samples the next block still needs
+        if keep > self.s_lo:
+            self.samples, self.s_lo = self.samples[keep - self.s_lo:].contiguous(), keep
+
+    # ---- network steps for every window whose look-ahead is covered ----
+    def _advance_net(self, final: bool):
+        st = self.state
+        while True:
+            want = (st.k + 1) * self.W + self.La
+            have = st.e1 + self.spec_pend.size(2)
+            # a step runs once at least one frame BEYOND its look-ahead exists (then it is not the stream's last step) or
+            # the stream has ended (then the step that takes the remaining frames is the last one and also emits what
+            # is left past its window): exactly enhance_stream's rule `last = (upto == T)`
+            if have > want:
+                n, last = want - st.e1, False
+            elif final and self.spec_pend.size(2) > 0:
+                n, last = self.spec_pend.size(2), True
+            else:
+                return
+            r, i = st.step(self.spec_pend[:, :, :n].contiguous(), last=last)
+            self.spec_pend = self.spec_pend[:, :, n:]
+            self.est_r, self.est_i = torch.cat([self.est_r, r], dim=2), torch.cat([self.est_i, i], dim=2)
+            self.t_est += r.size(2)
+            if last:
+                return
+
+    # ---- ISTFT of the samples whose four frames exist ----
+    def _advance_out(self, final: bool) -> torch.Tensor:
+        hop = self.hop
+        end = (self.t_est - 1) * hop if final else (self.t_est - 2) * hop      # samples [n_out, end) are final
+        if end <= self.n_out or self.t_est - self.f_lo < 2:
+            return torch.empty(0, device=self.eng.device)
+        f0 = max(self.n_out // hop - 2, 0)                                      # two guard frames on the left
+        r = self.est_r[:, :, f0 - self.f_lo:].contiguous()
+        i = self.est_i[:, :, f0 - self.f_lo:].contiguous()
+        wav = self.eng.uncompress_istft(r, i)[0]                                # samples [f0 hop, (t_est - 1) hop)
+        out = wav[self.n_out - f0 * hop:end - f0 * hop] / self.c
+        self.n_out = end
+        keep = max(end // hop - 2, 0)
+        if keep > self.f_lo:
+            self.est_r, self.est_i = self.est_r[:, :, keep - self.f_lo:], self.est_i[:, :, keep - self.f_lo:]
+            self.f_lo = keep
+        return out
+
+    @torch.no_grad()
+    def push(self, samples: torch.Tensor) -> torch.Tensor:
+        """samples: float32 GPU tensor, any shape (flattened) -> the enhanced samples that became final (maybe none)."""
+        if self.closed:
+            raise RuntimeError("stream already flushed")
+        x = samples.reshape(-1).to(device=self.eng.device, dtype=torch.float32)
+        self.samples = torch.cat([self.samples, x])
+        self.n_in += x.numel()
+        self._advance_spec(False)
+        self._advance_net(False)
+        return self._advance_out(False)
+
+    @torch.no_grad()
+    def flush(self) -> torch.Tensor:
+        """End of the stream (its length must be a multiple of hop, like one reference row): the remaining samples."""
+        if self.closed:
+            return torch.empty(0, device=self.eng.device)
+        if self.n_in % self.hop or self.n_in <= self.n_fft // 2:
+            raise ValueError("a stream must end on a multiple of hop and be longer than n_fft / 2")
+        self.closed = True
+        self._advance_spec(True)
+        self._advance_net(True)
+        return self._advance_out(True)

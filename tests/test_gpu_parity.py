@@ -761,3 +761,31 @@ def test_enhance_stream_with_one_window_is_the_plain_forward(model):
     got = enhance_stream(model, wav, window=64, context=8, lookahead=8, graph=False)
     want = model.engine.enhance(wav)[0]
     assert torch.equal(got, want)
+
+
+def test_streaming_enhancer_on_arbitrary_chunks_equals_enhance_stream(model):
+    """Sample-level live front end (StreamingEnhancer.push / flush): incremental STFT blocks with guard frames, network
+    steps as soon as a window's look-ahead is covered, samples emitted once their four frames exist - fed with ragged
+    chunk sizes it returns, piece by piece, the samples enhance_stream computes from the whole signal with the same
+    statistics and scale.  Equal to rounding, not to the bit: the split-f16 STFT / ISTFT scale every 64-frame TILE by the
+    power of two of its own maximum, and a block of frames cut at another place puts a frame into another tile (1.5e-6)."""
+    from cmgan_amd.streaming import StreamingEnhancer, enhance_stream
+    eng = model.engine
+    wav = synthetic_clips(1, 16000, seed=37).to(DEV)
+    c = eng.rms_scale(wav)
+    stats = eng.tscnet_forward_stats(eng.stft_compress(wav[:, :4800].contiguous(), c))[2]
+    want = enhance_stream(model, wav, window=40, context=12, lookahead=8, stats=stats, graph=False)
+    for sizes in ((1600,) * 10, (137, 3333, 50, 4000, 1, 2479, 6000), (16000,)):
+        live = StreamingEnhancer(model, stats, window=40, context=12, lookahead=8, scale=c, graph=False)
+        out, pos, got_before_end = [], 0, 0
+        for n in sizes:
+            out.append(live.push(wav[0, pos:pos + n]))
+            pos += n
+            got_before_end += out[-1].numel()
+        assert pos == 16000
+        out.append(live.flush())
+        got = torch.cat(out)
+        assert got.shape == want.shape
+        assert _report(f"StreamingEnhancer in {len(sizes)} chunks vs enhance_stream", rel_err(got, want)) < 1e-5, sizes
+        if len(sizes) > 1:
+            assert got_before_end > 0                     # samples really come out while the stream is still running
