@@ -143,9 +143,12 @@ def test_conformer_stages_match_reference_golden(conf):
     assert _report("conformer.out vs golden", rel_err(y, g["out"])) < STAGE
 
 
-@pytest.mark.parametrize("n,l", [(5, 101), (3, 321), (2, 16), (2, 17), (1, 1), (7, 64), (4, 65)])
+@pytest.mark.parametrize("n,l", [(5, 101), (3, 321), (2, 16), (2, 17), (1, 1), (7, 64), (4, 65), (3, 37), (2, 45), (1, 129),
+                                 (2, 301), (2, 109)])
 def test_conformer_matches_oracle_over_lengths(conf, n, l):
-    """ragged block edges: L below / at / above the 16-token and 64-key tile sizes."""
+    """ragged block edges: L below / at / above the 16-token and 64-key tile sizes; every compile-time-tail instantiation of
+    the attention (L % 64 = 1: 1, 65, 129, 321; 37: 37, 101; 45: 45, 109, 301) as a single chunk, as the last of two and of
+    several, next to run-time tails (16, 17)."""
     csd = conformer_state_dict(seed=3)
     x = torch.from_numpy(np.random.Generator(np.random.PCG64(100 + l)).standard_normal((n, l, 64)).astype(np.float32))
     st = {}
