@@ -519,8 +519,8 @@ def test_one_row_of_the_full_config2_batch_matches_the_oracle_directly(model, sd
 def test_full_size_clips_match_the_references_own_modules(model, sd):
     """T = 321 (2 s): the HIP path against oracle/_ref - the reference repo's OWN TSCNet / power_compress /
     power_uncompress (bytecode built from /root/reference by oracle/make_ref.py; travels to the GPU box) behind the
-    src/evaluation.py:21-53 glue - not against the port.  Rows 0 and 31 of the benchmark batch plus a ragged track
-    through enhance_one_track."""
+    src/evaluation.py:21-53 glue - not against the port.  Five rows spread over the benchmark batch plus a ragged
+    track through enhance_one_track."""
     from oracle import ref_runner as R
     from cmgan_amd.evaluation import enhance_one_track
     if not R.available():
@@ -528,7 +528,7 @@ def test_full_size_clips_match_the_references_own_modules(model, sd):
     ref = R.tscnet(sd)
     wav = synthetic_clips(32, 32000, seed=7)
     out = model.engine.enhance(wav.to(DEV))
-    for row in (0, 31):
+    for row in (0, 5, 11, 23, 31):                    # (row 17: the oracle test above)
         _check(f"config-2 batch, row {row} vs the reference modules", out[row:row + 1],
                R.enhance_batch(ref, wav[row:row + 1]))
     noisy = synthetic_clips(1, 32000 + 1234, seed=9)
