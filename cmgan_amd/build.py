@@ -16,17 +16,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcmgan_hip.so")
-SOURCES = ["api.hip", "api_train.hip", "conformer.hip", "conformer_x3.hip", "attn32_x3.hip", "conv.hip", "conv_x3.hip",
+SOURCES = ["api.hip", "api_train.hip", "conformer.hip", "conformer_x3.hip", "attn32_x3.hip", "ffn32_x3.hip", "conv.hip", "conv_x3.hip",
            "stft.hip", "train.hip", "train_x3.hip", "disc.hip"]
 # the F16X1 (single fp16 product) twins of the x3 kernels: the same sources compiled a second time with X1_FLAGS
-X1_SOURCES = ["conformer_x3.hip", "attn32_x3.hip", "conv_x3.hip"]
+X1_SOURCES = ["conformer_x3.hip", "attn32_x3.hip", "ffn32_x3.hip", "conv_x3.hip"]
 X1_FLAGS = ["-DX3_SINGLE", "-DX3_TERMS=1"]
 HEADERS = ["common.hip.h", "kernels.h", "weights.h", "api_internal.h", "train.h",
            os.path.join("..", "..", "include", "cmgan_hip.h")]
 # the generator FORWARD path: what bench.py measures and what the PMC evidence under profiles/ was collected on.  The
 # training-step slices (train.hip, api_train.hip, train.h) and the public header (which grows with them) are left
 # out, so committed counters stay valid while the training side is being built.
-INFERENCE_FILES = ["api.hip", "conformer.hip", "conformer_x3.hip", "attn32_x3.hip", "conv.hip", "conv_x3.hip", "stft.hip",
+INFERENCE_FILES = ["api.hip", "conformer.hip", "conformer_x3.hip", "attn32_x3.hip", "ffn32_x3.hip", "conv.hip", "conv_x3.hip", "stft.hip",
                    "common.hip.h", "kernels.h", "weights.h", "api_internal.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -packed-fp32-ops: v_pk_{fma,mul,add}_f32 issue slower than the scalar pair they replace when the SIMD is

@@ -257,6 +257,45 @@ static void x3_image(const float* fm, int RB, int KB, std::vector<_Float16>& out
                     out[o + 512] = lo;
                 }
 }
+// FeedForward operand images of ffn32_x3_kernel (32x32x16 MFMAs; layouts: ffn32_x3.hip, tests/test_ffn32_tile_model.py).
+// M[row][col] read back from the fragment-major fp32 array fm [RB][KB][64][4]:
+static float fm_at(const float* fm, int KB, int row, int col) {
+    return fm[(((size_t)(row >> 4) * KB + (col >> 4)) * 64 + (row & 15) + 16 * ((col & 15) >> 2)) * 4 + (col & 3)];
+}
+// W1 [256][64] -> [t 8][kk 4][hi|lo][64][8]: lane (row, hh) slot e = W1[32 t + row][16 kk + 8 (e >> 2) + 4 hh + (e & 3)]
+static void x3_image_ffn32_w1(const float* fm, std::vector<_Float16>& out) {
+    const size_t base = out.size();
+    out.resize(base + (size_t)8 * 4 * 1024);
+    for (int t = 0; t < 8; ++t)
+        for (int kk = 0; kk < 4; ++kk)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int row = 32 * t + (lane & 31), hh = lane >> 5;
+                    const int col = 8 * (2 * kk + (e >> 2)) + 4 * hh + (e & 3);
+                    _Float16 hi, lo;
+                    split_h(fm_at(fm, 4, row, col), hi, lo);
+                    const size_t o = base + ((size_t)t * 4 + kk) * 1024 + lane * 8 + e;
+                    out[o] = hi;
+                    out[o + 512] = lo;
+                }
+}
+// W2 [64][256] -> [u 2][ks 16][hi|lo][64][8]: lane (row, hh) slot e = W2[32 u + row][32 (ks >> 1) + 16 (ks & 1) + 8 (e >> 2) + 4 hh + (e & 3)]
+static void x3_image_ffn32_w2(const float* fm, std::vector<_Float16>& out) {
+    const size_t base = out.size();
+    out.resize(base + (size_t)2 * 16 * 1024);
+    for (int u = 0; u < 2; ++u)
+        for (int ks = 0; ks < 16; ++ks)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int row = 32 * u + (lane & 31), hh = lane >> 5;
+                    const int col = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (e >> 2) + 4 * hh + (e & 3);
+                    _Float16 hi, lo;
+                    split_h(fm_at(fm, 16, row, col), hi, lo);
+                    const size_t o = base + ((size_t)u * 16 + ks) * 1024 + lane * 8 + e;
+                    out[o] = hi;
+                    out[o + 512] = lo;
+                }
+}
 // conv fm [chunk16][taps][CB][64][4]  ->  [chunk32][taps][CB][hi|lo][64][8]
 static void x3_conv_image(const float* fm, int nchunk16, int taps, int CB, std::vector<_Float16>& out) {
     const size_t base = out.size();
@@ -316,6 +355,8 @@ static int build_x3_images(const float* payload, const std::map<uint32_t, WEntry
                 default: break;
             }
             if (RB) { pad(); d16[id] = img.size(); x3_image(src, RB, KB, img); }
+            if (item == CF_FF1_W1 || item == CF_FF2_W1) { pad(); d16[id | 0x2000] = img.size(); x3_image_ffn32_w1(src, img); }
+            if (item == CF_FF1_W2 || item == CF_FF2_W2) { pad(); d16[id | 0x2000] = img.size(); x3_image_ffn32_w2(src, img); }
             if (item == CF_DW_W) { pad(); d16[id] = img.size(); dw_toeplitz_image(src, img); }
             if (item == CF_REL) {                               // rows of [hi 16 | lo 16] halfs
                 const size_t rows = kv.second.count / 16;
@@ -434,6 +475,8 @@ static bool conf_weights_x3(cmgan_handle* h, int index, ConfWeightsX3& w) {
     w.rel_img = W16(h, WID(g, CF_REL), ok);
     w.dw_img = W16(h, WID(g, CF_DW_W), ok);
     w.rel_planes = W16(h, WID(g, CF_REL) | 0x4000, ok);
+    w.ff1_w1_32 = W16(h, WID(g, CF_FF1_W1) | 0x2000, ok); w.ff1_w2_32 = W16(h, WID(g, CF_FF1_W2) | 0x2000, ok);
+    w.ff2_w1_32 = W16(h, WID(g, CF_FF2_W1) | 0x2000, ok); w.ff2_w2_32 = W16(h, WID(g, CF_FF2_W2) | 0x2000, ok);
     return ok;
 }
 

@@ -8,6 +8,10 @@
 //   * Q / K are exchanged as row-major fp16 hi/lo rows, V as ready-made A-operand images
 //     (transposed through 1 KB of wave-private LDS in the producer)
 #include "kernels.h"
+#include <stdlib.h>
+#ifndef FFN32_DEFAULT
+#define FFN32_DEFAULT 1      // 1: the FeedForward branches run ffn32_x3_kernel (32x32x16 MFMAs); 0: ffn_x3_kernel
+#endif
 
 namespace X3_NS {
 
@@ -842,6 +846,10 @@ bool conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
     _Float16 *qimg = reinterpret_cast<_Float16*>(b.q), *kimg = reinterpret_cast<_Float16*>(b.k),
              *vimg = reinterpret_cast<_Float16*>(b.v);
 
+    // FeedForward on 32x32x16 MFMAs (ffn32_x3.hip) unless CMGAN_FFN32=0 (the 16x16x32 kernel above: same-session A/B)
+    static const bool k_ffn32 = [] { const char* v = getenv("CMGAN_FFN32"); return v && *v ? atoi(v) != 0 : FFN32_DEFAULT != 0; }();
+    if (k_ffn32) launch_ffn32_x3(ctx, false, b.xa, b.xb, nullptr, nullptr, w16.ff1_w1_32, w.ff1_b1, w16.ff1_w2_32, w.ff1_b2, M);
+    else
     LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, FFN_WAVES><<<ffn_grid(flat_tiles), 64 * FFN_WAVES, 0, s>>>(
                            b.xa, b.xb, nullptr, nullptr, w16.ff1_w1, w.ff1_b1, w16.ff1_w2, w.ff1_b2, M, flat_tiles)));
     if (taps) hipMemcpyAsync(taps, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
@@ -873,10 +881,16 @@ bool conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
     }
     if (taps) {
         hipMemcpyAsync(taps + (size_t)2 * M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
+        if (k_ffn32) launch_ffn32_x3(ctx, false, b.xb, taps + (size_t)3 * M * 64, nullptr, nullptr, w16.ff2_w1_32, w.ff2_b1,
+                                     w16.ff2_w2_32, w.ff2_b2, M);
+        else
         LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, FFN_WAVES><<<ffn_grid(flat_tiles), 64 * FFN_WAVES, 0, s>>>(
                                b.xb, taps + (size_t)3 * M * 64, nullptr, nullptr, w16.ff2_w1, w.ff2_b1, w16.ff2_w2,
                                w.ff2_b2, M, flat_tiles)));
     }
+    if (k_ffn32) launch_ffn32_x3(ctx, true, b.xb, b.xa, outer_residual ? b.xa : nullptr, w.post_gb, w16.ff2_w1_32, w.ff2_b1,
+                                 w16.ff2_w2_32, w.ff2_b2, M);
+    else
     LAUNCH(ctx, "ffn_post", (ffn_x3_kernel<true, 2, FFN_POST_WAVES><<<ffn_grid(flat_tiles, FFN_POST_WAVES), 64 * FFN_POST_WAVES, 0, s>>>(
                                 b.xb, b.xa, outer_residual ? b.xa : nullptr, w.post_gb, w16.ff2_w1, w.ff2_b1,
                                 w16.ff2_w2, w.ff2_b2, M, flat_tiles)));

@@ -131,7 +131,11 @@ struct ConfWeightsX3 {
     const _Float16* rel_img;    // [2*max_pos+1][hi 16 | lo 16] halfs
     const _Float16* dw_img;     // [8 channel groups][9][64 lanes][hi 4 | lo 4]: Toeplitz operands of the depthwise taps (dwpw2t_x3_kernel)
     const _Float16* rel_planes; // 4 x [2*max_pos+1 rows, reversed][8 halfs]: hi d0-7 | hi d8-15 | lo d0-7 | lo d8-15 (attn32_x3.hip)
+    const _Float16 *ff1_w1_32, *ff1_w2_32, *ff2_w1_32, *ff2_w2_32;   // FeedForward operand images of ffn32_x3_kernel (ffn32_x3.hip)
 };
+// ffn32_x3.hip: FeedForward (+ post LayerNorm + TSCB residual when final_) on 32x32x16 MFMAs; x0 / post_gb as ffn_x3_kernel
+void launch_ffn32_x3(LaunchCtx, bool final_, const float* xin, float* xout, const float* x0, const float* post_gb,
+                     const _Float16* w1i, const float* b1, const _Float16* w2i, const float* b2, long M);
 // Returns false WITHOUT launching anything when the shape is outside what the split-f16 conv-module kernel can address
 // (dwpw2t_x3_kernel: buffer descriptor + 32-bit lane byte offsets over a sequence's rows of the GLU output, 512 B each;
 // the 32-position tiles of a call counted in an int) - the limit lives with the kernel, every caller gets it.
@@ -171,6 +175,8 @@ void launch_attn_sp_out_x1(LaunchCtx, const _Float16* qimg, const _Float16* kimg
                            const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
                            const float* bo);
 void launch_conv3_x1(LaunchCtx, const ConvArgs&, const void* w16, int B, int time_taps, int cout);
+void launch_ffn32_x1(LaunchCtx, bool final_, const float* xin, float* xout, const float* x0, const float* post_gb,
+                     const _Float16* w1i, const float* b1, const _Float16* w2i, const float* b2, long M);
 #ifdef X3_SINGLE
 #define X3_NS x1k
 #define conformer_forward_x3 conformer_forward_x1
@@ -179,6 +185,7 @@ void launch_conv3_x1(LaunchCtx, const ConvArgs&, const void* w16, int B, int tim
 #define launch_attn32_out_x3 launch_attn32_out_x1
 #define launch_attn_sp_out_x3 launch_attn_sp_out_x1
 #define launch_conv3_x3 launch_conv3_x1
+#define launch_ffn32_x3 launch_ffn32_x1
 #else
 #define X3_NS x3k
 #endif
