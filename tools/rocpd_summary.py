@@ -78,6 +78,7 @@ LABELS = [("conv3x_kernelILi2ELi64", "conv_dense"), ("conv3x_kernelILi1ELi128", 
           ("conv3_kernelILi1ELi128", "conv_subpixel"), ("conv3_kernelILi1ELi64", "conv_1x3"),
           ("attn_sp_out_x3_kernel", "attn_out"), ("attn32_out_x3_kernel", "attn_out"), ("qkv32_x3_kernel", "qkv"),
           ("attn_out_x3_kernel", "attn_out"), ("attn_x3_kernel", "attn"), ("attn_kernel", "attn"), ("dwpw2s_x3_kernel", "dwpw2"), ("dwpw2t_x3_kernel", "dwpw2"), ("dwpw2_x3_kernel", "dwpw2"),
+          ("ffn32_x3_kernelILb1", "ffn_post"), ("ffn32_x3_kernelILb0", "ffn"),
           ("ffn_x3_kernelILb1", "ffn_post"), ("ffn_x3_kernelILb0", "ffn"), ("ffn_kernelILb1", "ffn_post"),
           ("ffn_kernelILb0", "ffn"), ("qkv_x3_kernel", "qkv"), ("qkv_kernel", "qkv"),
           ("pw1glu_x3_kernel", "pw1glu"), ("pw1glu_kernel", "pw1glu"), ("outproj_x3_kernel", "outproj"),
