@@ -792,3 +792,18 @@ def test_streaming_enhancer_on_arbitrary_chunks_equals_enhance_stream(model):
         assert _report(f"StreamingEnhancer in {len(sizes)} chunks vs enhance_stream", rel_err(got, want)) < 1e-5, sizes
         if len(sizes) > 1:
             assert got_before_end > 0                     # samples really come out while the stream is still running
+
+
+def test_the_16x16x32_feed_forward_kernel_behind_CMGAN_FFN32_0_still_matches_the_goldens():
+    """ffn32_x3_kernel (32x32x16 MFMAs) is the default FeedForward; ffn_x3_kernel stays in the library as the A/B partner
+    (CMGAN_FFN32=0, read once per process): run the conformer / TSCNet stage goldens on it in a fresh process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, CMGAN_FFN32="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-p",
+                        "no:cacheprovider", "-k", "conformer_stages_match_reference_golden or tscnet_stages_match_reference_golden"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert "4 passed" in r.stdout, r.stdout[-500:]
