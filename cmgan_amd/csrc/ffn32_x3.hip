@@ -40,8 +40,12 @@ __device__ __forceinline__ f32x16 fmfmal(f16x8 a, f16x8 b, f32x16 c) {        //
 #define FFN32_X0_EARLY 0      // 1: the TSCB residual rows of the FINAL variant are requested in slot 16 (32 more live registers:
                               // spills 5 dwords at the 168-register budget of 12 waves)
 #endif
+#ifndef FFN32_X0_HALF
+#define FFN32_X0_HALF 1       // FINAL: the u = 0 half of the TSCB residual rows is requested in slot 16 (16 registers; the whole
+                              // row set spills at the 168-register budget): ffn_post 1.93 -> 1.87 ms
+#endif
 #ifndef FFN32_AHEAD
-#define FFN32_AHEAD 2         // MFMA groups between an operand fragment's LDS read and its use
+#define FFN32_AHEAD 1         // MFMA groups between an operand fragment's LDS read and its use (1 / 2 / 3 measured equal)
 #endif
 #ifndef FFN32_WAVES
 #define FFN32_WAVES 12        // waves per block (one persistent block per CU: 128 KB of weight images)
@@ -145,6 +149,7 @@ __global__ __launch_bounds__(TWAVES * 64) void ffn32_x3_kernel(const float* xin,
         //   VALU : fp16 split of slot s - 1's activations, Swish of hidden registers 8 jp .. 8 jp + 7 of tile t
         //   MFMA : GEMM 1 of tile t + 1, k-steps 2 jp and 2 jp + 1 (two triples), GEMM 2 of slot s - 1 (two triples: u = 0, 1)
         // laid out as four groups { triple | VALU chunk } so that VALU issues while the matrix pipe is busy.
+        f32x4 xe[4];                                             // (FFN32_X0_HALF) early half of the residual rows
         float av[2][8];                                          // activations of the current / previous slot
         f16x8 ph, pl;
         // Operand fragments (hi, lo) of MFMA group i = 4 s + g are read from LDS FFN32_AHEAD groups ahead of their triple
@@ -182,6 +187,13 @@ __global__ __launch_bounds__(TWAVES * 64) void ffn32_x3_kernel(const float* xin,
             if (FINAL && s == 16 && x0) {                         // TSCB residual rows: under the last GEMM 2 triples
 #pragma unroll
                 for (int q = 0; q < 8; ++q) x[q] = ldg4(x0 + off_of(tile) + 8 * q);      // (recomputed: two registers less across the slots)
+            }
+#endif
+#if FFN32_X0_HALF
+            if (FINAL && s == 16 && x0) {                         // the u = 0 half of the TSCB residual rows: under the last GEMM 2 triples
+                const long oh = off_of(tile);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xe[j] = ldg4(x0 + oh + 8 * j);
             }
 #endif
             if (s == 14) {                                        // xh / xl are dead from here on: 32 registers for the rows needed next
@@ -290,6 +302,8 @@ __global__ __launch_bounds__(TWAVES * 64) void ffn32_x3_kernel(const float* xin,
                     r0 = (r0 - splat4(pm)) * splat4(pr) * gm + bt;
 #if FFN32_X0_EARLY
                     if (x0) r0 += x[4 * u + j];                  // TSCB residual rows: requested in slot 16
+#elif FFN32_X0_HALF
+                    if (x0) r0 += u == 0 ? xe[j] : ldg4(x0 + oe + 32 * u + 8 * j);
 #else
                     if (x0) r0 += ldg4(x0 + oe + 32 * u + 8 * j);
 #endif
