@@ -700,7 +700,9 @@ static bool dense_weights(cmgan_handle* h, int grp, DenseW& d) {
 #define CX_IMG 1             // 0 = every layer re-normalises the raw slots (A/B builds)
 #endif
 #ifndef CX_NIMG
-#define CX_NIMG 3            // images written per block: of the block input and of slots 1 .. CX_NIMG - 1 (A/B builds: 1, 2)
+#define CX_NIMG 1            // images written per block: of the block input and of slots 1 .. CX_NIMG - 1.  1, 2 and 3 run at the
+                             // same speed (5.96 / 5.92 / 5.91 ms, same-session A/B: what an image saves in staging VALU it costs as a
+                             // 266 - 528 MB store); 1 moves the fewest bytes: conv_dense's HBM traffic 1.29 x -> 1.07 x algorithmic
 #endif
 typedef void (*Conv3xFn)(LaunchCtx, const ConvArgs&, const void*, int, int, int);
 static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float* x0, const float* x0_scale,
