@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CMGAN_HIP_LIB") or os.path.join(HERE, "lib", "libcmgan_hip.so")
 
 OK = 0
-ABI_VERSION = 5
+ABI_VERSION = 6
 MFMA_F32, MFMA_F16X3, MFMA_F16X1 = 0, 1, 2
 
 
@@ -155,6 +155,8 @@ SIGNATURES = {
     "cmgan_tscnet_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cmgan_uncompress_istft": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cmgan_enhance": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "cmgan_enhance_branched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
+    "cmgan_workspace_bytes_branched": (c_size_t, [c_void_p, c_int, c_int]),
     "cmgan_power_compress": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cmgan_power_uncompress": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cmgan_conformer_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),

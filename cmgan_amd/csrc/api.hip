@@ -187,6 +187,9 @@ extern "C" void cmgan_destroy(cmgan_handle* h) {
     if (h->d_weights) hipFree(h->d_weights);
     if (h->d_w16) hipFree(h->d_w16);
     for (auto ev : h->prof.pool) hipEventDestroy(ev);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->side) hipStreamDestroy(h->side);
     delete h;
 }
 
@@ -971,6 +974,51 @@ extern "C" int cmgan_enhance(cmgan_handle* h, const float* wav, int B, int L, fl
         return rc;
     launch_uncompress_istft(ctx, h->st, f + p.est, f + p.est + (size_t)B * P, f + p.scale, B, T, f + p.frames, wav_out);
     return check_launch(h, "enhance");
+}
+
+// The same pipeline as two half-batch branches on two streams (fork / join by events, so a stream capture of `stream`
+// records both branches as parallel paths of one hipGraph): rows [0, ceil(B/2)) on `stream`, the rest on the handle's
+// side stream, which starts once the first branch has issued `offset_launches` kernels.  The rows are independent
+//  and each branch runs the unchanged per-row arithmetic, so the result equals cmgan_enhance bit for bit.
+static size_t branch_rows(int B, int which) { return which == 0 ? (size_t)(B + 1) / 2 : (size_t)B / 2; }
+
+extern "C" size_t cmgan_workspace_bytes_branched(const cmgan_handle* h, int B, int T) {
+    if (!h || B <= 0 || T <= 0) return 0;
+    if (B < 2) return plan_ws(h->cfg, B, T).total * sizeof(float);
+    return (plan_ws(h->cfg, (int)branch_rows(B, 0), T).total + plan_ws(h->cfg, (int)branch_rows(B, 1), T).total) * sizeof(float);
+}
+
+extern "C" int cmgan_enhance_branched(cmgan_handle* h, const float* wav, int B, int L, float* wav_out, void* ws,
+                                      size_t ws_bytes, void* stream, int offset_launches) {
+    if (!h) return CMGAN_E_BADARG;
+    if (!wav || !wav_out || B <= 0 || offset_launches < 0) return fail(h, CMGAN_E_BADARG, "cmgan_enhance_branched: bad argument");
+    if (B < 2) return cmgan_enhance(h, wav, B, L, wav_out, ws, ws_bytes, stream);
+    if (h->prof.enabled) return fail(h, CMGAN_E_BADARG, "cmgan_enhance_branched: per-launch profiling needs the one-stream form (cmgan_enhance)");
+    if (int rc = check_wave_len(h, L, true)) return rc;
+    const int T = L / h->cfg.hop + 1, B0 = (int)branch_rows(B, 0), B1 = (int)branch_rows(B, 1);
+    const size_t w0 = plan_ws(h->cfg, B0, T).total * sizeof(float), w1 = plan_ws(h->cfg, B1, T).total * sizeof(float);
+    if (int rc = check_ws(h, ws, ws_bytes, w0 + w1)) return rc;
+    if (!h->side) {                                       // first call (the warm-up a caller runs before capturing)
+        HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    hipStream_t s0 = (hipStream_t)stream;
+    Fork fork;
+    fork.at = offset_launches; fork.ev = h->ev_fork;
+    if (offset_launches == 0) { HIPCHK(h, hipEventRecord(h->ev_fork, s0)); fork.fired = true; }
+    h->fork = &fork;
+    int rc = cmgan_enhance(h, wav, B0, L, wav_out, ws, w0, stream);
+    h->fork = nullptr;
+    if (rc) return rc;
+    if (!fork.fired) HIPCHK(h, hipEventRecord(h->ev_fork, s0));          // fewer launches than the offset: plain sequence
+    HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    rc = cmgan_enhance(h, wav + (size_t)B0 * L, B1, L, wav_out + (size_t)B0 * L, (char*)ws + w0, w1, (void*)h->side);
+    // join even when the second branch failed: a capturing caller must not be left with an unjoined stream
+    hipEventRecord(h->ev_join, h->side);
+    hipStreamWaitEvent(s0, h->ev_join, 0);
+    if (rc) return rc;
+    return check_launch(h, "enhance_branched");
 }
 
 // ------------------------------------------------------------------------------------

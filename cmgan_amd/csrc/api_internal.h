@@ -38,6 +38,10 @@ struct cmgan_handle {
     std::map<uint32_t, size_t> dir16;     // id -> offset in halfs (rel-pos lo plane at id | 0x8000)
     Profiler prof;
     std::vector<std::string> prof_names;
+    // cmgan_enhance_branched: side stream + fork / join events (created by the first call, outside any capture)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    Fork* fork = nullptr;                 // non-null while the first branch of cmgan_enhance_branched is being issued
 };
 
 inline int fail(cmgan_handle* h, int code, const char* fmt, ...) {
@@ -71,6 +75,6 @@ inline int check_ws(cmgan_handle* h, void* ws, size_t bytes, size_t need) {
 }
 
 inline LaunchCtx begin(cmgan_handle* h, void* stream) {
-    return LaunchCtx{(hipStream_t)stream, &h->prof};
+    return LaunchCtx{(hipStream_t)stream, &h->prof, h->fork};
 }
 

@@ -19,9 +19,21 @@ struct Profiler {
     void reset() { recs.clear(); used = 0; }
 };
 
+// cmgan_enhance_branched: the second half-batch branch starts on another stream once the first branch has issued `at`
+// launches (an event recorded behind that launch), so that the two branches are in different kernels at any time.
+struct Fork {
+    int count = 0, at = 0;
+    bool fired = false;
+    hipEvent_t ev = nullptr;
+    void tick(hipStream_t s) {
+        if (!fired && ++count >= at) { hipEventRecord(ev, s); fired = true; }
+    }
+};
+
 struct LaunchCtx {
     hipStream_t stream;
     Profiler* prof;
+    Fork* fork = nullptr;
 };
 
 #define LAUNCH(ctx, name, ...)                                         \
@@ -35,6 +47,7 @@ struct LaunchCtx {
         } else {                                                       \
             __VA_ARGS__;                                               \
         }                                                              \
+        if ((ctx).fork) (ctx).fork->tick((ctx).stream);                \
     } while (0)
 
 // ------------------------------- stft.hip ---------------------------------------

@@ -78,6 +78,7 @@ class Engine:
             raise _lib.CmganError(rc, msg.decode() if msg else "?")
         self._ws: Optional[torch.Tensor] = None
         self._cws: Optional[torch.Tensor] = None
+        self._bws: Optional[torch.Tensor] = None          # workspace of the two-branch form (enhance_graphed(branches=2))
         self._graphs: dict = {}          # enhance_graphed: input shape -> (graph, in, out, token)
         self._row_graphs: dict = {}      # streaming.enhance_windows: row shape -> (graph, in, out, token)
         self.weights_loaded = False
@@ -123,7 +124,7 @@ class Engine:
             raise ValueError(f"bad batch/frames ({B}, {T})")
         if self._ws is None or self._ws.numel() < need:
             # graphs captured on the old allocation are stale AND keep it (multi-GB) alive: evict them all
-            self._graphs.clear()
+            self._graphs = {k: v for k, v in self._graphs.items() if k[1] != 1}
             self._row_graphs.clear()
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -343,19 +344,73 @@ class Engine:
         return out
 
     # ---- hipGraph replay of the whole pipeline -------------------------------------------
+    #: launches the first half-batch branch issues before the second starts (enhance_graphed(branches=2)); None = the
+    #: CMGAN_BRANCH_OFFSET environment variable, else this default
+    BRANCH_OFFSET = 24
+
+    def _enhance_call(self, wav, out, B, L, branches: int, offset: int):
+        if branches == 1:
+            ws = self._workspace(B, self.num_frames(L))
+            check(self._h, self.lib.cmgan_enhance(self._h, wav.data_ptr(), B, L, out.data_ptr(), ws.data_ptr(),
+                                                  ws.numel(), self._stream()))
+        else:
+            ws = self._branched_workspace(B, self.num_frames(L))
+            check(self._h, self.lib.cmgan_enhance_branched(self._h, wav.data_ptr(), B, L, out.data_ptr(), ws.data_ptr(),
+                                                           ws.numel(), self._stream(), offset))
+
+    def _branched_workspace(self, B: int, T: int) -> torch.Tensor:
+        need = self.lib.cmgan_workspace_bytes_branched(self._h, B, T)
+        if need == 0:
+            raise ValueError(f"bad batch/frames ({B}, {T})")
+        if self._bws is None or self._bws.numel() < need:
+            self._graphs = {k: v for k, v in self._graphs.items() if k[1] == 1}
+            self._bws = None
+            self._bws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._bws
+
     @_on_device
-    def enhance_graphed(self, wav: torch.Tensor) -> torch.Tensor:
+    def enhance_branched(self, wav: torch.Tensor, offset: Optional[int] = None) -> torch.Tensor:
+        """enhance() as two half-batch branches on two streams (cmgan_enhance_branched); same result bit for bit."""
+        self._need_weights()
+        wav = self._in(wav, "wav")
+        B, L = wav.shape
+        out = torch.empty_like(wav)
+        self._enhance_call(wav, out, B, L, 2, self._branch_offset(offset))
+        return out
+
+    def _branch_offset(self, offset: Optional[int]) -> int:
+        import os
+        if offset is None:
+            offset = int(os.environ.get("CMGAN_BRANCH_OFFSET", self.BRANCH_OFFSET))
+        if offset < 0:
+            raise ValueError("branch offset must be >= 0")
+        return offset
+
+    @_on_device
+    def enhance_graphed(self, wav: torch.Tensor, branches: Optional[int] = None, offset: Optional[int] = None) -> torch.Tensor:
         """Same result as enhance(), but the ~250 kernel launches of cmgan_enhance are captured once
         per input shape into a hipGraph (torch.cuda.CUDAGraph on the capture stream) and replayed:
         the C ABI never allocates or synchronises, so it is capturable as is.  The returned tensor is
-        a static buffer that the next call with the same shape overwrites."""
+        a static buffer that the next call with the same shape overwrites.
+        branches = 2: the graph holds two half-batch branches (cmgan_enhance_branched) the GPU may overlap;
+        None = the CMGAN_BRANCHES environment variable, else 1."""
+        import os
         self._need_weights()
         wav = self._in(wav, "wav")
-        key = tuple(wav.shape)
+        if branches is None:
+            branches = int(os.environ.get("CMGAN_BRANCHES", "1"))
+        if branches not in (1, 2):
+            raise ValueError("branches must be 1 or 2")
         B, L = wav.shape
-        ws = self._workspace(B, self.num_frames(L))             # may grow (and evict every graph) first
+        if B < 2:
+            branches = 1
+        offset = self._branch_offset(offset) if branches == 2 else 0
+        key = (tuple(wav.shape), branches, offset)
+        # the workspace may grow (and evict every graph that points into it) first
+        ws = self._workspace(B, self.num_frames(L)) if branches == 1 else self._branched_workspace(B, self.num_frames(L))
+        token = (ws.data_ptr(), ws.numel(), int(self.lib.cmgan_weights_generation(self._h)))
         ent = self._graphs.get(key)
-        if ent is not None and ent[3] != self._ws_token():      # workspace or weights changed since capture
+        if ent is not None and ent[3] != token:                 # workspace or weights changed since capture
             ent = None
         if ent is None:
             g_in, g_out = torch.empty_like(wav), torch.empty_like(wav)
@@ -363,15 +418,13 @@ class Engine:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):                       # warm-up outside capture
-                check(self._h, self.lib.cmgan_enhance(self._h, g_in.data_ptr(), B, L, g_out.data_ptr(),
-                                                      ws.data_ptr(), ws.numel(), self._stream()))
+                self._enhance_call(g_in, g_out, B, L, branches, offset)
             torch.cuda.current_stream(self.device).wait_stream(side)
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                check(self._h, self.lib.cmgan_enhance(self._h, g_in.data_ptr(), B, L, g_out.data_ptr(),
-                                                      ws.data_ptr(), ws.numel(), self._stream()))
-            ent = (graph, g_in, g_out, self._ws_token())
+                self._enhance_call(g_in, g_out, B, L, branches, offset)
+            ent = (graph, g_in, g_out, token)
             self._graphs[key] = ent
         graph, g_in, g_out, _ = ent
         g_in.copy_(wav)

@@ -39,7 +39,7 @@ extern "C" {
 #define CMGAN_E_WORKSPACE   -5   /* workspace too small or misaligned              */
 #define CMGAN_E_HIP         -6   /* a HIP runtime call failed (see last_error)     */
 
-#define CMGAN_ABI_VERSION 5
+#define CMGAN_ABI_VERSION 6
 
 typedef struct cmgan_handle cmgan_handle;
 
@@ -142,6 +142,20 @@ int cmgan_uncompress_istft(cmgan_handle* h, const float* real_dev, const float* 
  * wav[B,L] -> wav_out[B,L];  L % hop == 0.                                      */
 int cmgan_enhance(cmgan_handle* h, const float* wav_dev, int B, int L, float* wav_out_dev,
                   void* workspace_dev, size_t workspace_bytes, void* stream);
+
+/* cmgan_enhance as TWO half-batch branches (rows [0, ceil(B/2)) on `stream`, the rest on a
+ * stream the handle owns), forked and joined with events so that a stream capture of
+ * `stream` records them as parallel paths of one hipGraph.  The second branch starts once
+ * the first has issued `offset_launches` kernels (0 = together), so the two are in
+ * different kernels at any time.  Utterances are independent in eval mode
+ * (src/models/generator.py:35, src/models/conformer.py:168; src/evaluation.py:30-34 batches
+ * rows the same way) and each branch runs the unchanged per-row arithmetic: the result
+ * equals cmgan_enhance bit for bit.  Workspace: cmgan_workspace_bytes_branched(B, T).
+ * The first call creates the side stream and events - make it outside a capture.        */
+size_t cmgan_workspace_bytes_branched(const cmgan_handle* h, int B, int T);
+int cmgan_enhance_branched(cmgan_handle* h, const float* wav_dev, int B, int L, float* wav_out_dev,
+                           void* workspace_dev, size_t workspace_bytes, void* stream,
+                           int offset_launches);
 
 /* The non-adversarial terms of Trainer.calculate_generator_loss (src/train.py:124-151)
  * as deterministic device reductions, out4_dev = {loss_ri, loss_mag, time_loss, time_mse}:

@@ -347,6 +347,31 @@ def test_hipgraph_replay_is_bit_identical_to_eager(model):
     assert not torch.equal(g1, g2)
 
 
+def test_two_branch_form_is_bit_identical(model):
+    """cmgan_enhance_branched: two half-batch branches on two streams (fork / join by events), eager and as parallel
+    paths of one captured hipGraph, any start offset, odd batch: the rows are independent, so nothing may change."""
+    eng = model.engine
+    for B in (5, 2):
+        wav = synthetic_clips(B, 8000, seed=40 + B).to(DEV)
+        want = eng.enhance(wav).clone()
+        for offset in (0, 7, 10 ** 6):
+            assert torch.equal(eng.enhance_branched(wav, offset=offset), want), (B, offset)
+        for offset in (0, 30):
+            g = eng.enhance_graphed(wav, branches=2, offset=offset).clone()
+            assert torch.equal(g, want), (B, offset)
+            wav2 = synthetic_clips(B, 8000, seed=50 + B).to(DEV)
+            g2 = eng.enhance_graphed(wav2, branches=2, offset=offset).clone()      # replay with new data
+            assert torch.equal(g2, eng.enhance(wav2))
+    one = synthetic_clips(1, 8000, seed=60).to(DEV)
+    assert torch.equal(eng.enhance_graphed(one, branches=2), eng.enhance(one))     # B = 1: the one-stream form
+    eng.set_profiling(True)
+    try:
+        with pytest.raises(Exception):
+            eng.enhance_branched(wav)
+    finally:
+        eng.set_profiling(False)
+
+
 # ------------------------------------------------------------------ pipeline
 def test_enhance_one_track_matches_reference_golden_ragged_and_chunked(model):
     from cmgan_amd.evaluation import enhance_one_track
