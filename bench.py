@@ -338,7 +338,43 @@ def stream_leg(model, dev, reps=5):
         dt = (time.perf_counter() - t0) / reps
         out[name] = {"ms_per_10s_clip": round(1e3 * dt, 3), "frames_per_s": round(1601 / dt, 1),
                      "real_time_factor": round(10.0 / dt, 1)}
-    return {"workload": "configs[4]: 10 s 16 kHz clip, 400-frame windows, 40 frames of attention context + 40 of "
+    # What the carried-state contract costs in accuracy: frozen statistics + windowed attention is a NEW numerical contract
+    # (the reference has none: src/evaluation.py:30-34 enhances whole rows), so the streamed output is compared with the
+    # WHOLE-CLIP forward of the same library on the same clip (cmgan_enhance, which equals the reference's own modules
+    # within 3e-6: tests/test_gpu_parity.py; the GPU suite repeats the comparison against oracle/_ref directly).
+    # SSNR / STOI use the whole-clip output as the reference signal (cmgan_amd.metrics, the reference tool's arithmetic).
+    import numpy as np
+    from cmgan_amd import metrics as M
+
+    def cost(got, whole):
+        a, ref = got.double().cpu().numpy(), whole.double().cpu().numpy()
+        d = a - ref
+        ss = M.segmental_snr(ref, a, 16000)
+        ss = ss[1] if isinstance(ss, tuple) else ss
+        return {"rel_err_max": float(f"{np.abs(d).max() / np.abs(ref).max():.3e}"),
+                "rel_err_rms": float(f"{np.sqrt((d * d).mean() / (ref * ref).mean()):.3e}"),
+                "ssnr_db_vs_whole_clip": round(float(np.mean(ss)), 2), "stoi_vs_whole_clip": round(float(M.stoi(ref, a, 16000)), 5)}
+
+    try:
+        acc = {}
+        clips = [("synthetic_10s", noisy, 400)]
+        tr = os.path.join(ROOT, "tests", "golden", "tracks.npz")
+        if os.path.exists(tr):
+            g = np.load(tr)
+            for name in ("a", "b", "silence"):                     # the reference repo's AudioSamples recordings (2.1 s each:
+                pcm = torch.from_numpy(g["pcm_" + name].astype(np.float32) / 32768.0)[None]     # one 400-frame window would
+                clips.append(("track_" + name, pcm[:, :pcm.size(1) // 100 * 100].contiguous().to(dev), 100))   # be the whole clip)
+        for name, clip, w in clips:
+            whole = model.engine.enhance(clip)[0]
+            for ca, la in ((40, 40), (40, 0)):
+                got = enhance_stream(model, clip, w, ca, la, graph=True)
+                acc[f"{name}_window{w}_context{ca}_lookahead{la}"] = cost(got, whole)
+        approx = {"reference": "whole-clip cmgan_enhance of the same clip (= the reference's TSCNet on the whole clip, 3e-6)",
+                  "statistics": "calibrated on the clip's first window + look-ahead frames, then frozen", "cases": acc}
+    except Exception as e:                                      # noqa: BLE001 - the headline line must survive
+        approx = {"error": f"{type(e).__name__}: {e}"[:300]}
+    return {"approximation_cost_vs_whole_clip": approx,
+            "workload": "configs[4]: 10 s 16 kHz clip, 400-frame windows, 40 frames of attention context + 40 of "
                         "look-ahead; carried_state = encoder / decoder state carried under frozen InstanceNorm statistics "
                         "(exact), TSCB context from cached encoder outputs; windows = context recomputed by every stage",
             "results": out}

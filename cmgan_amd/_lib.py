@@ -155,8 +155,8 @@ SIGNATURES = {
     "cmgan_tscnet_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cmgan_uncompress_istft": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "cmgan_enhance": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "cmgan_enhance_branched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
-    "cmgan_workspace_bytes_branched": (c_size_t, [c_void_p, c_int, c_int]),
+    "cmgan_enhance_branched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_int]),
+    "cmgan_workspace_bytes_branched": (c_size_t, [c_void_p, c_int, c_int, c_int]),
     "cmgan_power_compress": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cmgan_power_uncompress": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "cmgan_conformer_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),

@@ -187,9 +187,9 @@ extern "C" void cmgan_destroy(cmgan_handle* h) {
     if (h->d_weights) hipFree(h->d_weights);
     if (h->d_w16) hipFree(h->d_w16);
     for (auto ev : h->prof.pool) hipEventDestroy(ev);
-    if (h->ev_fork) hipEventDestroy(h->ev_fork);
-    if (h->ev_join) hipEventDestroy(h->ev_join);
-    if (h->side) hipStreamDestroy(h->side);
+    for (auto ev : h->ev_fork) hipEventDestroy(ev);
+    for (auto ev : h->ev_join) hipEventDestroy(ev);
+    for (auto st : h->side) hipStreamDestroy(st);
     delete h;
 }
 
@@ -504,10 +504,20 @@ static bool conf_weights(cmgan_handle* h, int index, ConfWeights& w) {
 // ------------------------------------------------------------------------------------
 // workspace plan (all offsets in floats, 64-float aligned)
 // ------------------------------------------------------------------------------------
+#ifndef CX_IMG
+#define CX_IMG 1             // 0 = every layer re-normalises the raw slots (A/B builds)
+#endif
+#ifndef CX_NIMG
+#define CX_NIMG 1            // images written per block: of the block input and of slots 1 .. CX_NIMG - 1.  1, 2 and 3 run at the
+                             // same speed (5.96 / 5.92 / 5.91 ms, same-session A/B: what an image saves in staging VALU it costs as a
+                             // 266 - 528 MB store); 1 moves the fewest bytes: conv_dense's HBM traffic 1.29 x -> 1.14 x algorithmic
+                             // (PMC, profiles/r05_x3_hbm_traffic.json).  plan_ws reserves exactly CX_NIMG images
+#endif
 struct WsPlan {
     size_t total = 0;
     size_t e[5];          // encoder dense slots [B,P,64]; e[1..4] double as decoder slots, e[0] as SP
-    size_t img[3];        // F16X3 dense blocks: (hi, lo) fp16 images of the block input and of slots 1, 2 (ConvArgs::img_out)
+    size_t img[3];        // F16X3 dense blocks: (hi, lo) fp16 images of the block input and of slots 1, 2 (ConvArgs::img_out);
+                          // only the first CX_NIMG are reserved (the others are never touched: run_dense_block)
     size_t xa, xb, q, k, v, o, u, w;
     size_t dm, dc;        // tail projections [B, T*W, 4]
     size_t partials;
@@ -532,7 +542,8 @@ static WsPlan plan_ws(const cmgan_config& c, int B, int T) {
     size_t cur = 0;
     p.e[0] = take(cur, (size_t)B * T * std::max(F, W2) * 64);
     for (int i = 1; i < 5; ++i) p.e[i] = take(cur, (size_t)B * P * 64);
-    for (int i = 0; i < 3; ++i) p.img[i] = c.mfma_mode != CMGAN_MFMA_F32 ? take(cur, (size_t)B * P * 64) : 0;
+    for (int i = 0; i < 3; ++i)
+        p.img[i] = (CX_IMG && c.mfma_mode != CMGAN_MFMA_F32 && i < CX_NIMG) ? take(cur, (size_t)B * P * 64) : 0;
     p.xa = take(cur, M * 64);
     p.xb = take(cur, M * 64);
     const size_t qf = std::max(conf_qkv_floats((int)(B * F2), T), conf_qkv_floats(B * T, (int)F2));
@@ -671,8 +682,9 @@ static int conformer_forward_impl(cmgan_handle* h, int index, const float* x, in
     if (h->cfg.mfma_mode != CMGAN_MFMA_F32) {
         ConfWeightsX3 w16;
         if (!conf_weights_x3(h, index, w16)) return CMGAN_E_WEIGHTS;
-        (h->cfg.mfma_mode == CMGAN_MFMA_F16X1 ? conformer_forward_x1 : conformer_forward_x3)(
-            begin(h, stream), w, w16, b, seq, (long)M, taps, false, mask);
+        if (!(h->cfg.mfma_mode == CMGAN_MFMA_F16X1 ? conformer_forward_x1 : conformer_forward_x3)(
+                begin(h, stream), w, w16, b, seq, (long)M, taps, false, mask))
+            return fail(h, CMGAN_E_BADARG, "cmgan_conformer_forward: N x L too large for the split-f16 kernels");
     } else {
         conformer_forward(begin(h, stream), w, b, seq, (long)M, taps, false, mask);
     }
@@ -699,14 +711,6 @@ static bool dense_weights(cmgan_handle* h, int grp, DenseW& d) {
 // F16X3 mode (imgs != null): layer i is the FIRST consumer of its newest input (x0 for i = 0, else slot i - 1): it
 // normalises it on load as before and also stores its split-fp16 image (imgs[i], i < 3); layers i + 1 .. 3 read that
 // image instead of the raw slot - same values to the bit, without the per-re-read normalise / PReLU / split.
-#ifndef CX_IMG
-#define CX_IMG 1             // 0 = every layer re-normalises the raw slots (A/B builds)
-#endif
-#ifndef CX_NIMG
-#define CX_NIMG 1            // images written per block: of the block input and of slots 1 .. CX_NIMG - 1.  1, 2 and 3 run at the
-                             // same speed (5.96 / 5.92 / 5.91 ms, same-session A/B: what an image saves in staging VALU it costs as a
-                             // 266 - 528 MB store); 1 moves the fewest bytes: conv_dense's HBM traffic 1.29 x -> 1.07 x algorithmic
-#endif
 typedef void (*Conv3xFn)(LaunchCtx, const ConvArgs&, const void*, int, int, int);
 static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float* x0, const float* x0_scale,
                             const float* x0_shift, const float* x0_alpha, float* const slots[4], float* partials,
@@ -855,8 +859,10 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
     const TokMap fmap = make_seq_map(B * T, F2, 1, F2, 0, 1);
     for (int k = 0; ph_tscb && k < h->cfg.num_tscb; ++k) {
         if (x3) {
-            conformer_x(ctx, cw[2 * k], cw16[2 * k], cb, tmap, M, nullptr, true, nullptr);
-            conformer_x(ctx, cw[2 * k + 1], cw16[2 * k + 1], cb, fmap, M, nullptr, true, nullptr);
+            if (!conformer_x(ctx, cw[2 * k], cw16[2 * k], cb, tmap, M, nullptr, true, nullptr) ||
+                !conformer_x(ctx, cw[2 * k + 1], cw16[2 * k + 1], cb, fmap, M, nullptr, true, nullptr))
+                return fail(h, CMGAN_E_BADARG, "tscnet_forward: B x T x F too large for the split-f16 conformer kernels "
+                                               "(conformer_x3_addressable, conformer_x3.hip)");
         } else {
             conformer_forward(ctx, cw[2 * k], cb, tmap, M, nullptr, true);
             conformer_forward(ctx, cw[2 * k + 1], cb, fmap, M, nullptr, true);
@@ -976,47 +982,68 @@ extern "C" int cmgan_enhance(cmgan_handle* h, const float* wav, int B, int L, fl
     return check_launch(h, "enhance");
 }
 
-// The same pipeline as two half-batch branches on two streams (fork / join by events, so a stream capture of `stream`
-// records both branches as parallel paths of one hipGraph): rows [0, ceil(B/2)) on `stream`, the rest on the handle's
-// side stream, which starts once the first branch has issued `offset_launches` kernels.  The rows are independent
-//  and each branch runs the unchanged per-row arithmetic, so the result equals cmgan_enhance bit for bit.
-static size_t branch_rows(int B, int which) { return which == 0 ? (size_t)(B + 1) / 2 : (size_t)B / 2; }
+// The same pipeline as `branches` part-batch branches on as many streams (fork / join by events, so a stream capture of
+// `stream` records them as parallel paths of one hipGraph): branch 0 on `stream`, the others on streams the handle
+// owns; branch i + 1 starts once branch i has issued `offset_launches` kernels (0 = all together).  The rows are
+// independent and each branch runs the unchanged per-row arithmetic, so the result equals cmgan_enhance bit
+// for bit.  Why it pays: a kernel's ramp-up and drain (and the dependent launch behind it) leave CUs idle ~240 times
+// per forward; with a second branch in flight the other branch's workgroups fill them.
+#define CMGAN_MAX_BRANCHES 8
+static int branch_rows(int B, int n, int i) { return B / n + (i < B % n ? 1 : 0); }
 
-extern "C" size_t cmgan_workspace_bytes_branched(const cmgan_handle* h, int B, int T) {
-    if (!h || B <= 0 || T <= 0) return 0;
-    if (B < 2) return plan_ws(h->cfg, B, T).total * sizeof(float);
-    return (plan_ws(h->cfg, (int)branch_rows(B, 0), T).total + plan_ws(h->cfg, (int)branch_rows(B, 1), T).total) * sizeof(float);
+extern "C" size_t cmgan_workspace_bytes_branched(const cmgan_handle* h, int B, int T, int branches) {
+    if (!h || B <= 0 || T <= 0 || branches < 1 || branches > CMGAN_MAX_BRANCHES) return 0;
+    const int n = branches < B ? branches : B;
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += plan_ws(h->cfg, branch_rows(B, n, i), T).total * sizeof(float);
+    return total;
 }
 
 extern "C" int cmgan_enhance_branched(cmgan_handle* h, const float* wav, int B, int L, float* wav_out, void* ws,
-                                      size_t ws_bytes, void* stream, int offset_launches) {
+                                      size_t ws_bytes, void* stream, int branches, int offset_launches) {
     if (!h) return CMGAN_E_BADARG;
-    if (!wav || !wav_out || B <= 0 || offset_launches < 0) return fail(h, CMGAN_E_BADARG, "cmgan_enhance_branched: bad argument");
-    if (B < 2) return cmgan_enhance(h, wav, B, L, wav_out, ws, ws_bytes, stream);
+    if (!wav || !wav_out || B <= 0 || offset_launches < 0 || branches < 1 || branches > CMGAN_MAX_BRANCHES)
+        return fail(h, CMGAN_E_BADARG, "cmgan_enhance_branched: bad argument");
+    const int n = branches < B ? branches : B;
+    if (n == 1) return cmgan_enhance(h, wav, B, L, wav_out, ws, ws_bytes, stream);
     if (h->prof.enabled) return fail(h, CMGAN_E_BADARG, "cmgan_enhance_branched: per-launch profiling needs the one-stream form (cmgan_enhance)");
     if (int rc = check_wave_len(h, L, true)) return rc;
-    const int T = L / h->cfg.hop + 1, B0 = (int)branch_rows(B, 0), B1 = (int)branch_rows(B, 1);
-    const size_t w0 = plan_ws(h->cfg, B0, T).total * sizeof(float), w1 = plan_ws(h->cfg, B1, T).total * sizeof(float);
-    if (int rc = check_ws(h, ws, ws_bytes, w0 + w1)) return rc;
-    if (!h->side) {                                       // first call (the warm-up a caller runs before capturing)
-        HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-        HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-        HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    const int T = L / h->cfg.hop + 1;
+    if (int rc = check_ws(h, ws, ws_bytes, cmgan_workspace_bytes_branched(h, B, T, n))) return rc;
+    while ((int)h->side.size() < n - 1) {                 // first call (the warm-up a caller runs before capturing)
+        hipStream_t st;
+        hipEvent_t ef, ej;
+        HIPCHK(h, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&ef, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+        h->side.push_back(st); h->ev_fork.push_back(ef); h->ev_join.push_back(ej);
     }
-    hipStream_t s0 = (hipStream_t)stream;
-    Fork fork;
-    fork.at = offset_launches; fork.ev = h->ev_fork;
-    if (offset_launches == 0) { HIPCHK(h, hipEventRecord(h->ev_fork, s0)); fork.fired = true; }
-    h->fork = &fork;
-    int rc = cmgan_enhance(h, wav, B0, L, wav_out, ws, w0, stream);
-    h->fork = nullptr;
-    if (rc) return rc;
-    if (!fork.fired) HIPCHK(h, hipEventRecord(h->ev_fork, s0));          // fewer launches than the offset: plain sequence
-    HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
-    rc = cmgan_enhance(h, wav + (size_t)B0 * L, B1, L, wav_out + (size_t)B0 * L, (char*)ws + w0, w1, (void*)h->side);
-    // join even when the second branch failed: a capturing caller must not be left with an unjoined stream
-    hipEventRecord(h->ev_join, h->side);
-    hipStreamWaitEvent(s0, h->ev_join, 0);
+    int rc = CMGAN_OK, rows_done = 0;
+    char* wsp = (char*)ws;
+    for (int i = 0; i < n && rc == CMGAN_OK; ++i) {
+        hipStream_t si = i == 0 ? (hipStream_t)stream : h->side[i - 1];
+        const int Bi = branch_rows(B, n, i);
+        const size_t wi = plan_ws(h->cfg, Bi, T).total * sizeof(float);
+        Fork fork;                                        // releases branch i + 1 after `offset_launches` launches of this one
+        if (i + 1 < n) {
+            fork.at = offset_launches; fork.ev = h->ev_fork[i];
+            if (offset_launches == 0) { hipEventRecord(fork.ev, si); fork.fired = true; }
+            h->fork = &fork;
+        }
+        rc = cmgan_enhance(h, wav + (size_t)rows_done * L, Bi, L, wav_out + (size_t)rows_done * L, wsp, wi, (void*)si);
+        h->fork = nullptr;
+        if (i + 1 < n) {
+            if (!fork.fired) hipEventRecord(fork.ev, si);  // fewer launches than the offset: plain sequence
+            hipStreamWaitEvent(h->side[i], fork.ev, 0);   // (even after a failure: a capturing caller needs every stream joined)
+        }
+        rows_done += Bi;
+        wsp += wi;
+    }
+    // join every side stream that was forked (a failed branch included: no unjoined stream may be left in a capture)
+    for (int i = 1; i < n; ++i) {
+        hipEventRecord(h->ev_join[i - 1], h->side[i - 1]);
+        hipStreamWaitEvent((hipStream_t)stream, h->ev_join[i - 1], 0);
+    }
     if (rc) return rc;
     return check_launch(h, "enhance_branched");
 }

@@ -38,9 +38,9 @@ struct cmgan_handle {
     std::map<uint32_t, size_t> dir16;     // id -> offset in halfs (rel-pos lo plane at id | 0x8000)
     Profiler prof;
     std::vector<std::string> prof_names;
-    // cmgan_enhance_branched: side stream + fork / join events (created by the first call, outside any capture)
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // cmgan_enhance_branched: side streams + fork / join events (created by the first call, outside any capture)
+    std::vector<hipStream_t> side;
+    std::vector<hipEvent_t> ev_fork, ev_join;
     Fork* fork = nullptr;                 // non-null while the first branch of cmgan_enhance_branched is being issued
 };
 

@@ -1233,11 +1233,6 @@ void launch_attn32_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* k
 #ifndef A32_ALIGN_SHORT
 #define A32_ALIGN_SHORT 0
 #endif
-static int env_knob(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
 void launch_attn_sp_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* kimg, const _Float16* vimg,
                            const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
                            const float* bo) {
@@ -1248,10 +1243,10 @@ void launch_attn_sp_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* 
     // A32_TPB tiles per block, 17.4 rounds - with the interleaved tile order a persistent round no longer costs L2 hits,
     // but it measured 1.5 % SLOWER (5.70 vs 5.62 ms): short blocks balance the CUs dynamically.
     // (CMGAN_ASP_* environment overrides: launch-shape sweeps inside ONE GPU session, read once per process)
-    static const int k_tpb_long = env_knob("CMGAN_ASP_TPB_LONG", A32_TPB), k_group_long = env_knob("CMGAN_ASP_GROUP_LONG", A32_GROUP);
-    static const int k_group_short = env_knob("CMGAN_ASP_GROUP_SHORT", A32_GROUP_SHORT);
-    static const int k_align_short = env_knob("CMGAN_ASP_ALIGN_SHORT", A32_ALIGN_SHORT);
-    static const int k_slots = env_knob("CMGAN_ASP_SLOTS", A32_SLOTS_PER_GPU);
+    static const int k_tpb_long = env_knob("CMGAN_ASP_TPB_LONG", A32_TPB, 1, 64), k_group_long = env_knob("CMGAN_ASP_GROUP_LONG", A32_GROUP, 1, 4096);
+    static const int k_group_short = env_knob("CMGAN_ASP_GROUP_SHORT", A32_GROUP_SHORT, 1, 4096);
+    static const int k_align_short = env_knob("CMGAN_ASP_ALIGN_SHORT", A32_ALIGN_SHORT, 0, 1);
+    static const int k_slots = env_knob("CMGAN_ASP_SLOTS", A32_SLOTS_PER_GPU, 8, 65536);
     int tpb = Lt <= 4 ? A32_TPB_SHORT : k_tpb_long;
     if (Lt <= 4 || A32_PERSIST_LONG) {
         const long share = ((long)N * Lt + k_slots - 1) / k_slots;
@@ -1270,7 +1265,7 @@ void launch_attn_sp_out_x3(LaunchCtx ctx, const _Float16* qimg, const _Float16* 
                                 qimg, kimg, vimg, rel_img, max_pos, x, seq, woi, bo, Lt, tpb, N, group, lt_magic)))
     if (!clamp) {
         // the model's own tails as compile-time constants (attn_sp_out_x3_kernel: TAILK); any other length: run-time test
-        static const int k_tailk = env_knob("CMGAN_ASP_TAILK", 1);
+        static const int k_tailk = env_knob("CMGAN_ASP_TAILK", 1, 0, 1);
         if (tail == 0) ASP_LAUNCH(false, 2, true);
         else if (k_tailk && tail == 1) ASP_LAUNCH(false, 1, false, 1);
         else if (k_tailk && tail == 37) ASP_LAUNCH(false, 2, false, 37);

@@ -847,7 +847,7 @@ bool conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeights
              *vimg = reinterpret_cast<_Float16*>(b.v);
 
     // FeedForward on 32x32x16 MFMAs (ffn32_x3.hip) unless CMGAN_FFN32=0 (the 16x16x32 kernel above: same-session A/B)
-    static const bool k_ffn32 = [] { const char* v = getenv("CMGAN_FFN32"); return v && *v ? atoi(v) != 0 : FFN32_DEFAULT != 0; }();
+    static const bool k_ffn32 = env_knob("CMGAN_FFN32", FFN32_DEFAULT, 0, 1) != 0;
     if (k_ffn32) launch_ffn32_x3(ctx, false, b.xa, b.xb, nullptr, nullptr, w16.ff1_w1_32, w.ff1_b1, w16.ff1_w2_32, w.ff1_b2, M);
     else
     LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, FFN_WAVES><<<ffn_grid(flat_tiles), 64 * FFN_WAVES, 0, s>>>(

@@ -50,6 +50,19 @@ struct LaunchCtx {
         if ((ctx).fork) (ctx).fork->tick((ctx).stream);                \
     } while (0)
 
+// Launch-shape / kernel-choice overrides read from the environment ONCE per process (same-session A/B sweeps,
+// tools/knob_sweep.sh; listed in include/cmgan_hip.h, "Environment").  Every value is validated: anything outside
+// [lo, hi] (or not a number) falls back to the built-in default, so no setting can produce an invalid launch.  None of
+// them changes a result: they select between kernels / launch shapes that are each parity-tested.
+#include <stdlib.h>
+inline int env_knob(const char* name, int dflt, int lo, int hi) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    char* end = nullptr;
+    const long x = strtol(v, &end, 10);
+    return (end && *end == 0 && x >= lo && x <= hi) ? (int)x : dflt;
+}
+
 // ------------------------------- stft.hip ---------------------------------------
 struct SpectralTables {
     int n_fft, hop, F, FB;          // FB = ceil(F/16) bin blocks

@@ -280,7 +280,7 @@ void launch_stft_compress(LaunchCtx ctx, const SpectralTables& tb, const float* 
         } else {
             // bin blocks per thread block: the fewer, the shorter the dependent chain of one block (CMGAN_STFT_BSPLIT:
             // same-session sweep knob; every bin is computed by the same instructions whatever the split)
-            static const int k_split = [] { const char* v = getenv("CMGAN_STFT_BSPLIT"); return v && *v ? atoi(v) : STFT_BSPLIT; }();
+            static const int k_split = env_knob("CMGAN_STFT_BSPLIT", STFT_BSPLIT, 1, 13);
 #define STFT_LAUNCH(S)                                                                                             \
     do {                                                                                                           \
         dim3 grid64(tiles, B, S);                                                                                  \

@@ -81,6 +81,7 @@ class Engine:
         self._bws: Optional[torch.Tensor] = None          # workspace of the two-branch form (enhance_graphed(branches=2))
         self._graphs: dict = {}          # enhance_graphed: input shape -> (graph, in, out, token)
         self._row_graphs: dict = {}      # streaming.enhance_windows: row shape -> (graph, in, out, token)
+        self._stream_slots: dict = {}    # streaming.StreamState(graph=True): (B, W, Ca, La) -> state buffers + step graphs
         self.weights_loaded = False
 
     def __del__(self):
@@ -100,6 +101,7 @@ class Engine:
         # and the graphs are simply re-captured on next use)
         self._graphs.clear()
         self._row_graphs.clear()
+        self._stream_slots.clear()
         with torch.cuda.device(self.device):
             check(self._h, self.lib.cmgan_load_weights(self._h, blob.ctypes.data_as(ctypes.c_void_p), blob.nbytes))
         self.weights_loaded = True
@@ -126,6 +128,8 @@ class Engine:
             # graphs captured on the old allocation are stale AND keep it (multi-GB) alive: evict them all
             self._graphs = {k: v for k, v in self._graphs.items() if k[1] != 1}
             self._row_graphs.clear()
+            for slot in self._stream_slots.values():
+                slot.graphs.clear()
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
@@ -268,8 +272,12 @@ class Engine:
         if two != 2 or F != self.F:
             raise ValueError(f"expected [B,2,T,{self.F}], got {tuple(spec.shape)}")
         ws = self._workspace(B, T)
+        want = (B, T, (F + 1) // 2, 64)
         if out is None:
-            out = torch.empty(B, T, (F + 1) // 2, 64, dtype=torch.float32, device=spec.device)
+            out = torch.empty(want, dtype=torch.float32, device=spec.device)
+        elif not out.is_contiguous() or tuple(out.shape) != want:
+            raise ValueError(f"out must be a contiguous [B,T,F',64] = {want} tensor (the kernel writes it in place), "
+                             f"got {tuple(out.shape)}{'' if out.is_contiguous() else ' (non-contiguous)'}")
         check(self._h, self.lib.cmgan_stream_encoder(self._h, spec.data_ptr(), B, T, self._stats_arg(stats, B),
                                                      self._in(out, "out").data_ptr(), ws.data_ptr(), ws.numel(), self._stream()))
         return out
@@ -344,9 +352,14 @@ class Engine:
         return out
 
     # ---- hipGraph replay of the whole pipeline -------------------------------------------
-    #: launches the first half-batch branch issues before the second starts (enhance_graphed(branches=2)); None = the
-    #: CMGAN_BRANCH_OFFSET environment variable, else this default
-    BRANCH_OFFSET = 24
+    #: enhance_graphed's defaults (overridable per call and through CMGAN_BRANCHES / CMGAN_BRANCH_OFFSET): part-batch
+    #: branches the captured graph holds, and the launches branch i issues before branch i + 1 starts.  Measured in one
+    #: session at 32 x 2 s (profiles/r06_branch_sweep.txt): 1 branch 21.7 ms, 2 branches together 21.0 - 21.1 ms (-3 %),
+    #: offsets of 12 / 24 / 60 launches 21.45 / 21.7 / 22.3 ms: what a second branch buys is the other branch's
+    #: workgroups in every kernel's ramp-up and drain, not unlike kernels side by side.
+    BRANCHES = 2
+    BRANCH_OFFSET = 0
+    MAX_BRANCHES = 8
 
     def _enhance_call(self, wav, out, B, L, branches: int, offset: int):
         if branches == 1:
@@ -354,37 +367,43 @@ class Engine:
             check(self._h, self.lib.cmgan_enhance(self._h, wav.data_ptr(), B, L, out.data_ptr(), ws.data_ptr(),
                                                   ws.numel(), self._stream()))
         else:
-            ws = self._branched_workspace(B, self.num_frames(L))
+            ws = self._branched_workspace(B, self.num_frames(L), branches)
             check(self._h, self.lib.cmgan_enhance_branched(self._h, wav.data_ptr(), B, L, out.data_ptr(), ws.data_ptr(),
-                                                           ws.numel(), self._stream(), offset))
+                                                           ws.numel(), self._stream(), branches, offset))
 
-    def _branched_workspace(self, B: int, T: int) -> torch.Tensor:
-        need = self.lib.cmgan_workspace_bytes_branched(self._h, B, T)
+    def _branched_workspace(self, B: int, T: int, branches: int) -> torch.Tensor:
+        need = self.lib.cmgan_workspace_bytes_branched(self._h, B, T, branches)
         if need == 0:
-            raise ValueError(f"bad batch/frames ({B}, {T})")
+            raise ValueError(f"bad batch / frames / branches ({B}, {T}, {branches})")
         if self._bws is None or self._bws.numel() < need:
             self._graphs = {k: v for k, v in self._graphs.items() if k[1] == 1}
             self._bws = None
             self._bws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._bws
 
+    def _branch_args(self, B: int, branches: Optional[int], offset: Optional[int]):
+        import os
+        if branches is None:
+            branches = int(os.environ.get("CMGAN_BRANCHES", self.BRANCHES))
+        if offset is None:
+            offset = int(os.environ.get("CMGAN_BRANCH_OFFSET", self.BRANCH_OFFSET))
+        if not 1 <= branches <= self.MAX_BRANCHES:
+            raise ValueError(f"branches must be 1 .. {self.MAX_BRANCHES}")
+        if offset < 0:
+            raise ValueError("branch offset must be >= 0")
+        branches = min(branches, B)
+        return branches, (offset if branches > 1 else 0)
+
     @_on_device
-    def enhance_branched(self, wav: torch.Tensor, offset: Optional[int] = None) -> torch.Tensor:
-        """enhance() as two half-batch branches on two streams (cmgan_enhance_branched); same result bit for bit."""
+    def enhance_branched(self, wav: torch.Tensor, branches: int = 2, offset: int = 0) -> torch.Tensor:
+        """enhance() as `branches` part-batch branches on as many streams (cmgan_enhance_branched); same result bit for bit."""
         self._need_weights()
         wav = self._in(wav, "wav")
         B, L = wav.shape
         out = torch.empty_like(wav)
-        self._enhance_call(wav, out, B, L, 2, self._branch_offset(offset))
+        branches, offset = self._branch_args(B, branches, offset)
+        self._enhance_call(wav, out, B, L, branches, offset)
         return out
-
-    def _branch_offset(self, offset: Optional[int]) -> int:
-        import os
-        if offset is None:
-            offset = int(os.environ.get("CMGAN_BRANCH_OFFSET", self.BRANCH_OFFSET))
-        if offset < 0:
-            raise ValueError("branch offset must be >= 0")
-        return offset
 
     @_on_device
     def enhance_graphed(self, wav: torch.Tensor, branches: Optional[int] = None, offset: Optional[int] = None) -> torch.Tensor:
@@ -392,22 +411,16 @@ class Engine:
         per input shape into a hipGraph (torch.cuda.CUDAGraph on the capture stream) and replayed:
         the C ABI never allocates or synchronises, so it is capturable as is.  The returned tensor is
         a static buffer that the next call with the same shape overwrites.
-        branches = 2: the graph holds two half-batch branches (cmgan_enhance_branched) the GPU may overlap;
-        None = the CMGAN_BRANCHES environment variable, else 1."""
-        import os
+        branches > 1: the graph holds that many part-batch branches (cmgan_enhance_branched) as parallel paths the GPU
+        overlaps; the result is the same bit for bit (rows are independent).  Defaults: BRANCHES / BRANCH_OFFSET."""
         self._need_weights()
         wav = self._in(wav, "wav")
-        if branches is None:
-            branches = int(os.environ.get("CMGAN_BRANCHES", "1"))
-        if branches not in (1, 2):
-            raise ValueError("branches must be 1 or 2")
         B, L = wav.shape
-        if B < 2:
-            branches = 1
-        offset = self._branch_offset(offset) if branches == 2 else 0
+        branches, offset = self._branch_args(B, branches, offset)
         key = (tuple(wav.shape), branches, offset)
         # the workspace may grow (and evict every graph that points into it) first
-        ws = self._workspace(B, self.num_frames(L)) if branches == 1 else self._branched_workspace(B, self.num_frames(L))
+        T = self.num_frames(L)
+        ws = self._workspace(B, T) if branches == 1 else self._branched_workspace(B, T, branches)
         token = (ws.data_ptr(), ws.numel(), int(self.lib.cmgan_weights_generation(self._h)))
         ent = self._graphs.get(key)
         if ent is not None and ent[3] != token:                 # workspace or weights changed since capture

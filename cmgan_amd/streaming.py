@@ -85,6 +85,8 @@ def _enhance_rows(model: TSCNet, rows: torch.Tensor, graph: bool) -> torch.Tenso
             real, imag = model(spec)
             g_out = eng.uncompress_istft(real, imag)
         ent = (g, g_in, g_out, eng._ws_token())
+        while len(cache) >= 8:                                  # one entry per (batch, span): a few configurations, oldest out
+            cache.pop(next(iter(cache)))
         cache[key] = ent
     g, g_in, g_out, _ = ent
     g_in.copy_(rows)
@@ -114,9 +116,34 @@ def _enhance_rows(model: TSCNet, rows: torch.Tensor, graph: bool) -> torch.Tenso
 HIST_FRAMES = 15
 
 
+class _StreamSlot:
+    """Device-resident state of one stream configuration (B, window, context, look-ahead) plus the hipGraphs of its step
+    shapes.  The graphs read AND update the state buffers themselves (a replay is the whole step: no host-side cat /
+    clone / contiguous, no allocation), so the buffers must outlive any one clip: the slot lives on the Engine and the
+    next StreamState of the same configuration re-uses buffers and graphs.
+
+        S  [B,2,cs,F]    spectrogram frames [s_lo, e0) from position 0 on; a step appends its new frames
+        E  [B,ce,F',64]  cached encoder outputs of frames [a0, e0); a step appends the fresh ones
+        D  [B,cd,F',64]  decoder input: [the last <= 15 kept TSCB frames of the previous step | this step's kept frames]
+
+    Valid lengths are host integers (StreamState); every step shape bakes its own offsets into its graph."""
+    MAX_GRAPHS = 6                                           # first / steady / last shapes of a clip length, with spares
+
+    def __init__(self, eng, B: int, W: int, Ca: int, La: int):
+        dev, F, F2 = eng.device, eng.F, (eng.F + 1) // 2
+        n_max = W + La                                       # most frames a step takes (the first one)
+        self.S = torch.empty(B, 2, HIST_FRAMES + La + n_max, F, device=dev)
+        self.E = torch.empty(B, Ca + La + n_max, F2, 64, device=dev)
+        self.D = torch.empty(B, HIST_FRAMES + n_max, F2, 64, device=dev)
+        self.stats = torch.empty(eng.stats_floats(B), device=dev)
+        self.graphs: dict = {}                               # step signature -> (graph, spec_in, out_real, out_imag, token); LRU
+        self.owner = None                                    # weakref of the StreamState using the buffers
+
+
 class StreamState:
     """Carried state of one stream (or B streams in lock-step): the statistics blob, the encoder-output cache, the
-    decoder's input history and the spectrogram frames they belong to.  `step(spec_frames)` is frame-level."""
+    decoder's input history and the spectrogram frames they belong to.  `step(spec_frames)` is frame-level.
+    graph=True: the state lives in an Engine-owned _StreamSlot and every step is ONE hipGraph replay."""
 
     def __init__(self, model: TSCNet, stats: torch.Tensor, B: int, window: int, context: int, lookahead: int,
                  graph: bool = True):
@@ -129,12 +156,33 @@ class StreamState:
         self.k = 0                       # steps done
         self.e1 = 0                      # encoder outputs exist for frames [enc_lo, e1)
         self.enc_lo = 0
-        self.enc = torch.empty(B, 0, self.F2, 64, device=dev)          # cached encoder outputs
-        self.spec_tail = torch.empty(B, 2, 0, self.F, device=dev)       # spec frames [spec_lo, ...) still needed
         self.spec_lo = 0
-        self.dec_hist = None             # kept TSCB outputs of the last HIST_FRAMES frames before k W
+        self.h_dec = 0                   # kept TSCB frames of the previous step held as decoder history
+        if graph:
+            self.slot = self._claim_slot()
+            self.slot.stats.copy_(self.eng._in(stats, "stats"))
+            self.stats = self.slot.stats                               # (what the graphs' kernel arguments point at)
+        else:
+            self.enc = torch.empty(B, 0, self.F2, 64, device=dev)          # cached encoder outputs
+            self.spec_tail = torch.empty(B, 2, 0, self.F, device=dev)       # spec frames [spec_lo, ...) still needed
+            self.dec_hist = None             # kept TSCB outputs of the last HIST_FRAMES frames before k W
 
-    # ---- one step on explicit tensors (the part a hipGraph replays) ----
+    def _claim_slot(self) -> _StreamSlot:
+        import weakref
+        slots = self.eng._stream_slots
+        key = (self.B, self.W, self.Ca, self.La)
+        slot = slots.get(key)
+        if slot is not None and slot.owner is not None and slot.owner() is not None and slot.owner() is not self:
+            slot = _StreamSlot(self.eng, *key)                         # another live stream holds the cached one: a private slot
+        elif slot is None:
+            slot = _StreamSlot(self.eng, *key)
+            while len(slots) >= 4:                                     # a handful of configurations per engine, oldest out
+                slots.pop(next(iter(slots)))
+            slots[key] = slot
+        slot.owner = weakref.ref(self)
+        return slot
+
+    # ---- one step on explicit tensors (eager form) ----
     def _run(self, spec_enc, enc_ctx, dec_hist, spec_dec, n_new_enc, keep_lo, n_keep):
         eng = self.eng
         x_new = eng.stream_encoder(spec_enc, self.stats)[:, spec_enc.size(2) - n_new_enc:]      # drop the history outputs
@@ -145,37 +193,69 @@ class StreamState:
         real, imag = eng.stream_decoder(xin.contiguous(), spec_dec, self.stats)
         return x_new, kept, real[:, :, xin.size(1) - n_keep:], imag[:, :, xin.size(1) - n_keep:]
 
-    def _run_graphed(self, args, ints):
-        """Replay (capture on first use) the hipGraph of this step shape; tensors are copied into static inputs."""
-        key = ("stream", ints) + tuple(None if a is None else tuple(a.shape) for a in args)
-        cache = self.eng._row_graphs
-        ent = cache.get(key)
-        if ent is None or ent[3] != self.eng._ws_token() or ent[4] is not self.stats:
-            static = [None if a is None else a.contiguous().clone() for a in args]
-            side = torch.cuda.Stream(device=self.eng.device)
-            side.wait_stream(torch.cuda.current_stream(self.eng.device))
-            with torch.cuda.stream(side):                       # warm-up outside capture (workspace, allocator)
-                self._run(*static, *ints)
-            torch.cuda.current_stream(self.eng.device).wait_stream(side)
-            torch.cuda.synchronize(self.eng.device)
+    # ---- one step as ONE graph replay over the slot's state buffers ----
+    def _graph_body(self, sl: _StreamSlot, spec_in, sig):
+        """The captured work of a step shape.  sig = (n_tail, h_enc, n_new, n_ctx, keep_lo, n_keep, h_dec, dec_lo,
+        spec_drop, enc_drop, h_dec_next, last): all host integers, baked into the graph."""
+        n_tail, h_enc, n_new, n_ctx, keep_lo, n_keep, h_dec, dec_lo, spec_drop, enc_drop, h_dec_next, last = sig
+        eng, S, E, D = self.eng, sl.S, sl.E, sl.D
+        S[:, :, n_tail:n_tail + n_new].copy_(spec_in)
+        enc = eng.stream_encoder(S[:, :, n_tail - h_enc:n_tail + n_new].contiguous(), sl.stats)
+        E[:, n_ctx:n_ctx + n_new].copy_(enc[:, h_enc:])                # the history outputs are dropped
+        x = E[:, :n_ctx + n_new].clone()                               # the TSCBs work in place: the cache keeps the encoder's
+        eng.stream_tscb(x)
+        D[:, h_dec:h_dec + n_keep].copy_(x[:, keep_lo:keep_lo + n_keep])
+        real, imag = eng.stream_decoder(D[:, :h_dec + n_keep].contiguous(),
+                                        S[:, :, dec_lo:dec_lo + h_dec + n_keep].contiguous(), sl.stats)
+        if not last:                                                   # carry: what the next step's three stages look back at
+            for buf, dim, lo, hi in ((S, 2, spec_drop, n_tail + n_new), (E, 1, enc_drop, n_ctx + n_new),
+                                     (D, 1, h_dec + n_keep - h_dec_next, h_dec + n_keep)):
+                if lo > 0 and hi > lo:
+                    tmp = buf.narrow(dim, lo, hi - lo).clone()         # (source and destination may overlap)
+                    buf.narrow(dim, 0, hi - lo).copy_(tmp)
+        return real[:, :, h_dec:], imag[:, :, h_dec:]
+
+    def _step_graphed(self, spec_new, sig):
+        sl, eng = self.slot, self.eng
+        token = eng._ws_token()
+        ent = sl.graphs.pop(sig, None)
+        if ent is not None and ent[4] != token:
+            ent = None
+        if ent is None:
+            spec_in = spec_new.contiguous().clone()
+            # warm-up outside capture on COPIES of the state (a step updates it): allocator pools, workspace growth
+            saved = (sl.S.clone(), sl.E.clone(), sl.D.clone())
+            side = torch.cuda.Stream(device=eng.device)
+            side.wait_stream(torch.cuda.current_stream(eng.device))
+            with torch.cuda.stream(side):
+                self._graph_body(sl, spec_in, sig)
+            torch.cuda.current_stream(eng.device).wait_stream(side)
+            torch.cuda.synchronize(eng.device)
+            token = eng._ws_token()                                    # (the warm-up may have grown the workspace)
+            for dst, src in zip((sl.S, sl.E, sl.D), saved):
+                dst.copy_(src)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                outs = self._run(*static, *ints)
-            ent = (g, static, outs, self.eng._ws_token(), self.stats)
-            cache[key] = ent
-        g, static, outs, _, _ = ent
-        for dst, src in zip(static, args):
-            if dst is not None:
+                out_r, out_i = self._graph_body(sl, spec_in, sig)
+            for dst, src in zip((sl.S, sl.E, sl.D), saved):            # (capture does not execute, but keep the rule simple)
                 dst.copy_(src)
+            del saved
+            ent = (g, spec_in, out_r, out_i, token)
+        sl.graphs[sig] = ent                                           # most recently used last
+        while len(sl.graphs) > _StreamSlot.MAX_GRAPHS:
+            sl.graphs.pop(next(iter(sl.graphs)))
+        g, spec_in, out_r, out_i, _ = ent
+        spec_in.copy_(spec_new)
         g.replay()
-        return outs              # static buffers of this shape's graph: step() copies what it keeps before the next replay
+        return out_r, out_i              # static buffers of this shape's graph: valid until its next replay
 
     @torch.no_grad()
-    def step(self, spec_new: torch.Tensor, last: bool = False):
+    def step(self, spec_new: torch.Tensor, last: bool = False, out=None):
         """spec_new: [B,2,n,F] = the spectrogram frames that arrived since the previous step (frames [e1, e1 + n)).
         Step k needs frames up to (k + 1) W + La (fewer only when `last`: the clip ended).  Returns (est_real, est_imag)
         [B,1,w,F] for frames [k W, k W + w), w = W - or, when `last`, all that is left of the clip (at most W + La: the
-        step whose look-ahead reaches the clip's end is the last one)."""
+        step whose look-ahead reaches the clip's end is the last one).  out = (real, imag) [B,1,>=w,F] tensors: the
+        result is written into their first w frames instead (views of them are returned)."""
         W, Ca, H = self.W, self.Ca, HIST_FRAMES
         k, e0 = self.k, self.e1
         n_new = spec_new.size(2)
@@ -183,34 +263,56 @@ class StreamState:
         want = (k + 1) * W + self.La
         if (e1 < want and not last) or e1 > want:
             raise ValueError(f"step {k} takes the frames up to {want} (fewer only at the end of the clip), got up to {e1}")
-        self.spec_tail = torch.cat([self.spec_tail, spec_new], dim=2)
         lo = k * W                                             # first frame this step emits
         n_keep = e1 - lo if last else min(W, e1 - lo)          # the clip's last step also emits what is left past its window
         if n_keep <= 0:
             raise ValueError("no frame left to emit")
         h_enc = min(H, e0)                                     # history the encoder can see (0 at the start of the clip)
-        cg = (lambda t: t) if self.graph else (lambda t: t.contiguous())   # (the graph path copies slices into static inputs)
-        spec_enc = cg(self.spec_tail[:, :, e0 - h_enc - self.spec_lo:e1 - self.spec_lo])
         a0 = max(lo - Ca, 0)                                   # TSCB frames [a0, e1): cached context + fresh
-        enc_ctx = cg(self.enc[:, a0 - self.enc_lo:e0 - self.enc_lo])
-        h_dec = 0 if self.dec_hist is None else self.dec_hist.size(1)
-        spec_dec = cg(self.spec_tail[:, :, lo - h_dec - self.spec_lo:lo + n_keep - self.spec_lo])
-        args = (spec_enc, enc_ctx, self.dec_hist, spec_dec)
-        ints = (n_new, lo - a0, n_keep)
-        x_new, kept, real, imag = (self._run_graphed(args, ints) if self.graph else self._run(*args, *ints))
-        # carry: encoder outputs from the next step's context start on, the last H kept TSCB frames, the spec frames both need
         nxt_lo = lo + W
+        if self.graph:
+            if self.slot.owner is None or self.slot.owner() is not self:
+                raise RuntimeError("this stream's state buffers were claimed by a newer StreamState of the same configuration")
+            h_dec = self.h_dec
+            h_dec_next = min(H, h_dec + n_keep)
+            spec_drop = max(nxt_lo - H, 0) - self.spec_lo
+            enc_drop = max(nxt_lo - Ca, 0) - self.enc_lo
+            sig = (e0 - self.spec_lo, h_enc, n_new, e0 - a0, lo - a0, n_keep, h_dec, lo - h_dec - self.spec_lo,
+                   max(spec_drop, 0), max(enc_drop, 0), h_dec_next, bool(last))
+            assert self.enc_lo == a0 or e0 == 0, (self.enc_lo, a0)
+            real, imag = self._step_graphed(self.eng._in(spec_new, "spec_new"), sig)
+            if not last:
+                self.spec_lo += max(spec_drop, 0)
+                self.enc_lo += max(enc_drop, 0)
+                self.h_dec = h_dec_next
+            self.k, self.e1 = k + 1, e1
+            if out is not None:
+                out[0][:, :, :n_keep].copy_(real)
+                out[1][:, :, :n_keep].copy_(imag)
+                return out[0][:, :, :n_keep], out[1][:, :, :n_keep]
+            return real.clone(), imag.clone()                  # (not views of a graph's static outputs)
+        self.spec_tail = torch.cat([self.spec_tail, spec_new], dim=2)
+        spec_enc = self.spec_tail[:, :, e0 - h_enc - self.spec_lo:e1 - self.spec_lo].contiguous()
+        enc_ctx = self.enc[:, a0 - self.enc_lo:e0 - self.enc_lo].contiguous()
+        h_dec = 0 if self.dec_hist is None else self.dec_hist.size(1)
+        spec_dec = self.spec_tail[:, :, lo - h_dec - self.spec_lo:lo + n_keep - self.spec_lo].contiguous()
+        x_new, kept, real, imag = self._run(spec_enc, enc_ctx, self.dec_hist, spec_dec, n_new, lo - a0, n_keep)
+        # carry: encoder outputs from the next step's context start on, the last H kept TSCB frames, the spec frames both need
         self.enc = torch.cat([self.enc, x_new], dim=1)
         drop = max(nxt_lo - Ca, 0) - self.enc_lo
         if drop > 0:
             self.enc, self.enc_lo = self.enc[:, drop:].contiguous(), self.enc_lo + drop
         hist = kept if self.dec_hist is None else torch.cat([self.dec_hist, kept], dim=1)
-        self.dec_hist = hist[:, -min(H, hist.size(1)):].clone()           # the frames just before nxt_lo (a COPY: `kept` may be a graph's static output)
+        self.dec_hist = hist[:, -min(H, hist.size(1)):].clone()           # the frames just before nxt_lo
         sdrop = max(nxt_lo - H, 0) - self.spec_lo                          # both histories start at nxt_lo - H or later
         if sdrop > 0:
             self.spec_tail, self.spec_lo = self.spec_tail[:, :, sdrop:].contiguous(), self.spec_lo + sdrop
         self.k, self.e1 = k + 1, e1
-        return (real.clone(), imag.clone()) if self.graph else (real, imag)     # (not views of a graph's static outputs)
+        if out is not None:
+            out[0][:, :, :n_keep].copy_(real)
+            out[1][:, :, :n_keep].copy_(imag)
+            return out[0][:, :, :n_keep], out[1][:, :, :n_keep]
+        return real, imag
 
 
 @torch.no_grad()
@@ -235,9 +337,7 @@ def enhance_stream(model: TSCNet, noisy: torch.Tensor, window: int = 400, contex
     k, fed = 0, 0
     while fed < T:
         upto = min((k + 1) * window + lookahead, T)
-        r, i = st.step(spec[:, :, fed:upto].contiguous(), last=upto == T)
-        w = r.size(2)
-        real[:, :, k * window:k * window + w], imag[:, :, k * window:k * window + w] = r, i
+        st.step(spec[:, :, fed:upto], last=upto == T, out=(real[:, :, k * window:], imag[:, :, k * window:]))
         fed, k = upto, k + 1
     return (eng.uncompress_istft(real, imag) / c[:, None]).reshape(-1)
 

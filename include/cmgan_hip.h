@@ -143,19 +143,18 @@ int cmgan_uncompress_istft(cmgan_handle* h, const float* real_dev, const float* 
 int cmgan_enhance(cmgan_handle* h, const float* wav_dev, int B, int L, float* wav_out_dev,
                   void* workspace_dev, size_t workspace_bytes, void* stream);
 
-/* cmgan_enhance as TWO half-batch branches (rows [0, ceil(B/2)) on `stream`, the rest on a
- * stream the handle owns), forked and joined with events so that a stream capture of
- * `stream` records them as parallel paths of one hipGraph.  The second branch starts once
- * the first has issued `offset_launches` kernels (0 = together), so the two are in
- * different kernels at any time.  Utterances are independent in eval mode
- * (src/models/generator.py:35, src/models/conformer.py:168; src/evaluation.py:30-34 batches
- * rows the same way) and each branch runs the unchanged per-row arithmetic: the result
- * equals cmgan_enhance bit for bit.  Workspace: cmgan_workspace_bytes_branched(B, T).
- * The first call creates the side stream and events - make it outside a capture.        */
-size_t cmgan_workspace_bytes_branched(const cmgan_handle* h, int B, int T);
+/* cmgan_enhance as `branches` (1..8) part-batch branches: rows split evenly, branch 0 on `stream`,
+ * the others on streams the handle owns, forked and joined with events so that a stream capture
+ * of `stream` records them as parallel paths of one hipGraph.  Branch i + 1 starts once branch i
+ * has issued `offset_launches` kernels (0 = all together).  Utterances are independent in eval
+ * mode (src/models/generator.py:35, src/models/conformer.py:168; src/evaluation.py:30-34 batches
+ * rows the same way) and each branch runs the unchanged per-row arithmetic: the result equals
+ * cmgan_enhance bit for bit.  Workspace: cmgan_workspace_bytes_branched(B, T, branches).
+ * The first call creates the side streams and events - make it outside a capture.            */
+size_t cmgan_workspace_bytes_branched(const cmgan_handle* h, int B, int T, int branches);
 int cmgan_enhance_branched(cmgan_handle* h, const float* wav_dev, int B, int L, float* wav_out_dev,
                            void* workspace_dev, size_t workspace_bytes, void* stream,
-                           int offset_launches);
+                           int branches, int offset_launches);
 
 /* The non-adversarial terms of Trainer.calculate_generator_loss (src/train.py:124-151)
  * as deterministic device reductions, out4_dev = {loss_ri, loss_mag, time_loss, time_mse}:
@@ -506,6 +505,18 @@ int cmgan_selftest_mfma_x3(cmgan_handle* h, float* max_err_host);
 typedef struct cmgan_kernel_time { const char* name; float ms; } cmgan_kernel_time;
 int cmgan_set_profiling(cmgan_handle* h, int enabled);
 int cmgan_profile_read(cmgan_handle* h, cmgan_kernel_time* out, int cap);
+
+/* ---- Environment ---------------------------------------------------------------------------------------------------
+ * Launch-shape / kernel-choice overrides, read ONCE per process on first use (same-session A/B sweeps,
+ * tools/knob_sweep.sh).  None changes a result beyond the last bits: each selects between kernels / launch shapes that
+ * are parity-tested on their own.  Values outside the range shown (or not a number) are ignored - the built-in default
+ * applies, so no setting can produce an invalid launch (kernels.h, env_knob):
+ *   CMGAN_FFN32=0|1            FeedForward on 32x32x16 MFMAs (1, default) or the 16x16x32 kernel (0)
+ *   CMGAN_STFT_BSPLIT=1..13    bin blocks per thread block of the small-batch STFT
+ *   CMGAN_ASP_TPB_LONG=1..64, CMGAN_ASP_GROUP_LONG=1..4096, CMGAN_ASP_GROUP_SHORT=1..4096, CMGAN_ASP_ALIGN_SHORT=0|1,
+ *   CMGAN_ASP_SLOTS=8..65536, CMGAN_ASP_TAILK=0|1    tile order / block shape of the attention kernel
+ * (The Python host adds CMGAN_BRANCHES=1|2 and CMGAN_BRANCH_OFFSET=n for Engine.enhance_graphed; CMGAN_HIP_LIB selects
+ * the library file.)                                                                                                  */
 
 #ifdef __cplusplus
 }

@@ -14,9 +14,18 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / at round end)")
+    config.addinivalue_line("markers", "slow: the widest GPU sweeps - skipped by the default `-m gpu` selection so that it stays "
+                                       "under ten minutes; run them with `-m \"gpu and slow\"` (or CMGAN_SLOW=1)")
 
 
 def pytest_collection_modifyitems(config, items):
+    # the `slow` tier: selected only when the -m expression names it (or CMGAN_SLOW=1); nothing is deleted
+    want_slow = "slow" in (config.getoption("-m") or "") or os.environ.get("CMGAN_SLOW", "") not in ("", "0")
+    if not want_slow:
+        skip_slow = pytest.mark.skip(reason="slow tier: run with -m \"gpu and slow\" or CMGAN_SLOW=1")
+        for item in items:
+            if "slow" in item.keywords:
+                item.add_marker(skip_slow)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no GPU visible")

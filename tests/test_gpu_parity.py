@@ -36,6 +36,17 @@ def sd():
 
 MODES = ["f16x3", "f32"]     # both matrix modes of the library are held to the same tolerances
 
+_CPU_CACHE = {}
+
+
+def _once(key, fn):
+    """A CPU-side expected value (oracle / reference modules) computed ONCE per session: the tests that use the
+    mode-parametrised `model` fixture run for both matrix modes against the same expectation, and the 2 s / 6 s / 10 s
+    oracle passes are what the suite's wall time is made of."""
+    if key not in _CPU_CACHE:
+        _CPU_CACHE[key] = fn()
+    return _CPU_CACHE[key]
+
 
 @pytest.fixture(scope="module", params=MODES)
 def model(request, sd):
@@ -300,8 +311,11 @@ def test_tscnet_matches_oracle_on_a_2s_clip(model, sd):
     """full T = 321 frames (2 s @ 16 kHz), B = 2: every tile loop runs its real trip count."""
     wav = synthetic_clips(2, 32000, seed=6)
     x = O.stft_compress(wav * O.rms_scale(wav)[:, None])
-    st = {}
-    wr, wi = O.tscnet_forward(sd, x, st)
+    def oracle():
+        st = {}
+        wr, wi = O.tscnet_forward(sd, x, st)
+        return st, wr, wi
+    st, wr, wi = _once("tscnet 2x321", oracle)
     real, imag, got = model.forward_with_taps(x.to(DEV))
     for name in ("encoder", "tscb1", "tscb2", "tscb3", "tscb4", "mask", "complex"):
         assert _report(f"tscnet[2x321].{name}", rel_err(got[name], st[name])) < GATE, name
@@ -347,23 +361,26 @@ def test_hipgraph_replay_is_bit_identical_to_eager(model):
     assert not torch.equal(g1, g2)
 
 
-def test_two_branch_form_is_bit_identical(model):
-    """cmgan_enhance_branched: two half-batch branches on two streams (fork / join by events), eager and as parallel
-    paths of one captured hipGraph, any start offset, odd batch: the rows are independent, so nothing may change."""
+def test_branched_form_is_bit_identical(model):
+    """cmgan_enhance_branched: part-batch branches on as many streams (fork / join by events), eager and as parallel
+    paths of one captured hipGraph, any branch count / start offset, uneven splits: the rows are independent, so nothing
+    may change."""
     eng = model.engine
     for B in (5, 2):
         wav = synthetic_clips(B, 8000, seed=40 + B).to(DEV)
         want = eng.enhance(wav).clone()
-        for offset in (0, 7, 10 ** 6):
-            assert torch.equal(eng.enhance_branched(wav, offset=offset), want), (B, offset)
-        for offset in (0, 30):
-            g = eng.enhance_graphed(wav, branches=2, offset=offset).clone()
-            assert torch.equal(g, want), (B, offset)
+        for branches, offset in ((2, 0), (2, 7), (2, 10 ** 6), (3, 0), (4, 5), (8, 0)):
+            assert torch.equal(eng.enhance_branched(wav, branches, offset), want), (B, branches, offset)
+        for branches, offset in ((2, 0), (2, 30), (3, 0), (4, 2)):
+            g = eng.enhance_graphed(wav, branches=branches, offset=offset).clone()
+            assert torch.equal(g, want), (B, branches, offset)
             wav2 = synthetic_clips(B, 8000, seed=50 + B).to(DEV)
-            g2 = eng.enhance_graphed(wav2, branches=2, offset=offset).clone()      # replay with new data
+            g2 = eng.enhance_graphed(wav2, branches=branches, offset=offset).clone()      # replay with new data
             assert torch.equal(g2, eng.enhance(wav2))
     one = synthetic_clips(1, 8000, seed=60).to(DEV)
     assert torch.equal(eng.enhance_graphed(one, branches=2), eng.enhance(one))     # B = 1: the one-stream form
+    with pytest.raises(ValueError):
+        eng.enhance_graphed(one, branches=9)
     eng.set_profiling(True)
     try:
         with pytest.raises(Exception):
@@ -406,7 +423,7 @@ def test_long_track_runs_unchunked_like_the_reference(model, sd):
     from cmgan_amd.evaluation import enhance_one_track
     noisy = synthetic_clips(1, 96000, seed=9)
     got = enhance_one_track(model, noisy.to(DEV))
-    assert _report("enhance 6 s track vs oracle", rel_err(got, O.enhance(sd, noisy))) < GATE
+    assert _report("enhance 6 s track vs oracle", rel_err(got, _once("6 s track", lambda: O.enhance(sd, noisy)))) < GATE
 
 
 def test_config5_ten_second_clip_in_400_frame_windows(model, sd):
@@ -417,7 +434,7 @@ def test_config5_ten_second_clip_in_400_frame_windows(model, sd):
     from cmgan_amd.evaluation import enhance_one_track
     noisy = synthetic_clips(1, 160000, seed=21)
     got = enhance_one_track(model, noisy.to(DEV), cut_len=40000)
-    want = O.enhance(sd, noisy, cut_len=40000)
+    want = _once("10 s clip as 4 rows", lambda: O.enhance(sd, noisy, cut_len=40000))
     assert got.shape == (160000,)
     assert _report("10 s clip, 4 x 400-frame windows vs oracle", rel_err(got, want)) < GATE
 
@@ -537,7 +554,7 @@ def test_one_row_of_the_full_config2_batch_matches_the_oracle_directly(model, sd
     alone - a direct check at the benchmark size, not only shard == full by transitivity."""
     wav = synthetic_clips(32, 32000, seed=7)
     out = model.engine.enhance(wav.to(DEV))
-    want = O.enhance_batch(sd, wav[17:18])
+    want = _once("config-2 row 17", lambda: O.enhance_batch(sd, wav[17:18]))
     _check("config-2 batch, row 17 vs oracle", out[17:18], want)
 
 
@@ -555,10 +572,10 @@ def test_full_size_clips_match_the_references_own_modules(model, sd):
     out = model.engine.enhance(wav.to(DEV))
     for row in (0, 5, 11, 23, 31):                    # (row 17: the oracle test above)
         _check(f"config-2 batch, row {row} vs the reference modules", out[row:row + 1],
-               R.enhance_batch(ref, wav[row:row + 1]))
+               _once(f"_ref row {row}", lambda: R.enhance_batch(ref, wav[row:row + 1])))
     noisy = synthetic_clips(1, 32000 + 1234, seed=9)
     _check("ragged 2.08 s track vs the reference's enhance_one_track glue",
-           enhance_one_track(model, noisy.to(DEV)).flatten(), R.enhance(ref, noisy))
+           enhance_one_track(model, noisy.to(DEV)).flatten(), _once("_ref ragged track", lambda: R.enhance(ref, noisy)))
 
 
 @pytest.mark.parametrize("mode", MODES)

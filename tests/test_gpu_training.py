@@ -790,6 +790,7 @@ def test_generator_step_at_full_length_T321_kink_free_twin_vs_oracle_autograd():
                           synthetic_dropout_masks(91, 1, 321, 101), "kink-free twin, B = 1 x T = 321", 1e-4)
 
 
+@pytest.mark.slow            # 125 s of CPU autograd at B = 4 x T = 321; the B = 1 x T = 321 twin above stays in the default tier
 def test_generator_step_at_batch_4_x_T321_kink_free_twin_vs_oracle_autograd():
     """Four 2 s clips (T = 321): the largest whole step a CPU autograd oracle finishes in minutes (the bench's 32 clips per
     GPU do not fit one) - multi-clip BatchNorm batch statistics over 4 x 321 x 101 positions, several clips per XCD in the

@@ -69,3 +69,29 @@ def test_stream_steps_equal_the_whole_clip_pass_where_state_is_exact_and_stay_cl
     approx = S.stream_forward(sd, spec, stats, window=16, context=8, lookahead=4)
     assert 1e-4 < rel_err(approx[0], want[0]) < 0.5
     assert torch.isfinite(approx[0]).all() and approx[0].shape == want[0].shape
+
+
+def test_config5_goldens_are_consistent_with_the_published_costs():
+    """tests/golden/stream10s.npz (reference whole-clip output + stream-oracle outputs at the named configs[4] shape) and
+    tests/golden/stream_cost_oracle.json (the approximation-cost bands of tests/test_gpu_stream_config5.py) come from two
+    scripts: the costs recomputed from the arrays must be the published ones."""
+    import json
+    import os
+    import numpy as np
+    from conftest import GOLDEN, load_golden
+    from cmgan_amd import metrics as M
+    g = load_golden("stream10s.npz")
+    costs = json.load(open(os.path.join(GOLDEN, "stream_cost_oracle.json")))
+    ref = g["whole"].double().numpy()
+    assert ref.shape == (160000,) and int(g["seed"]) == 3
+    for ca, la in ((40, 40), (40, 0)):
+        a = g[f"stream_{ca}_{la}"].double().numpy()
+        d = a - ref
+        want = costs[f"synthetic10s_w400_c{ca}_l{la}"]
+        assert abs(np.abs(d).max() / np.abs(ref).max() - want["rel_max"]) < 1e-4          # (whole: _ref here, the port there: 1e-6 apart)
+        assert abs(np.sqrt((d * d).mean() / (ref * ref).mean()) - want["rel_rms"]) < 1e-4
+        assert abs(float(np.mean(M.segmental_snr(ref, a, 16000)[1])) - want["ssnr"]) < 0.02
+        assert abs(M.stoi(ref, a, 16000) - want["stoi"]) < 1e-5
+    # a one-window stream IS the whole clip: the three 2 s recordings at window 400 cost nothing
+    for name in ("a", "b", "silence"):
+        assert costs[f"track_{name}_w400_c40_l40"]["rel_max"] < 2e-6

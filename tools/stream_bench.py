@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cmgan_amd import TSCNet
 from cmgan_amd.evaluation import enhance_one_track
-from cmgan_amd.streaming import enhance_windows
+from cmgan_amd.streaming import enhance_stream, enhance_windows
 from cmgan_amd.synth import make_state_dict, synthetic_clips
 
 model = TSCNet(64, 201).load_state_dict(make_state_dict(0)).eval()
@@ -27,8 +27,13 @@ def timed(fn, n=10):
     return (time.perf_counter() - t0) / n
 
 
+eng = model.engine
+stats = eng.tscnet_forward_stats(eng.stft_compress(noisy[:, :44000], eng.rms_scale(noisy)))[2]     # as bench.py's stream leg
 res = {}
-for name, fn in (("windows_graph_batch1", lambda: enhance_windows(model, noisy, W, C, batch=1, graph=True)),
+for name, fn in (("carried_state_graph_40_40", lambda: enhance_stream(model, noisy, 400, 40, 40, stats=stats, graph=True)),
+                 ("carried_state_graph_40_0", lambda: enhance_stream(model, noisy, 400, 40, 0, stats=stats, graph=True)),
+                 ("carried_state_eager_40_40", lambda: enhance_stream(model, noisy, 400, 40, 40, stats=stats, graph=False)),
+                 ("windows_graph_batch1", lambda: enhance_windows(model, noisy, W, C, batch=1, graph=True)),
                  ("windows_graph_batch4", lambda: enhance_windows(model, noisy, W, C, batch=4, graph=True)),
                  ("windows_eager_batch4", lambda: enhance_windows(model, noisy, W, C, batch=4, graph=False)),
                  ("reference_rows_rule_cut40000", lambda: enhance_one_track(model, noisy, cut_len=40000)),
