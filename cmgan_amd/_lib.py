@@ -16,7 +16,10 @@ LIB_PATH = os.environ.get("CMGAN_HIP_LIB") or os.path.join(HERE, "lib", "libcmga
 
 OK = 0
 ABI_VERSION = 6
-MFMA_F32, MFMA_F16X3, MFMA_F16X1 = 0, 1, 2
+MFMA_F32, MFMA_F16X3, MFMA_F16X1, MFMA_F16MIX = 0, 1, 2, 3
+# CMGAN_MIX_* bits of Config.single_mask (include/cmgan_hip.h)
+MIX = {"conv": 1, "ff1": 2, "ff2": 4, "qkv": 8, "attn": 16, "pw1": 32, "dwpw2": 64}
+MIX_ALL = 127
 
 
 class CmganError(RuntimeError):
@@ -27,7 +30,7 @@ class CmganError(RuntimeError):
 
 class Config(Structure):
     _fields_ = [(n, c_int32) for n in ("n_fft", "hop", "num_features", "num_channel", "num_tscb",
-                                       "heads", "dim_head", "conv_kernel", "max_pos_emb", "mfma_mode")]
+                                       "heads", "dim_head", "conv_kernel", "max_pos_emb", "mfma_mode", "single_mask")]
 
 
 class Taps(Structure):

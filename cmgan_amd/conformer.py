@@ -12,11 +12,11 @@ from .engine import Engine
 class ConformerBlock:
     def __init__(self, *, dim=64, dim_head=16, heads=4, ff_mult=4, conv_expansion_factor=2,
                  conv_kernel_size=31, attn_dropout=0.0, ff_dropout=0.0, conv_dropout=0.0, device=None,
-                 mfma_mode=None):
+                 mfma_mode=None, mix_single=None):
         if (dim, dim_head, heads, ff_mult, conv_expansion_factor, conv_kernel_size) != (64, 16, 4, 4, 2, 31):
             raise ValueError("HIP kernels are specialised for dim=64, dim_head=16, heads=4, ff_mult=4, "
                              "conv_expansion_factor=2, conv_kernel_size=31")
-        self.engine = Engine(device=device, mfma_mode=mfma_mode)     # dropouts are identity in eval mode
+        self.engine = Engine(device=device, mfma_mode=mfma_mode, mix_single=mix_single)     # dropouts are identity in eval mode
 
     def eval(self):
         return self

@@ -18,6 +18,7 @@ extern "C" void cmgan_default_config(cmgan_config* c) {
     c->n_fft = 400; c->hop = 100; c->num_features = 201; c->num_channel = 64; c->num_tscb = 4;
     c->heads = 4; c->dim_head = 16; c->conv_kernel = 31; c->max_pos_emb = 512;
     c->mfma_mode = CMGAN_MFMA_F16X3;
+    c->single_mask = 0;
 }
 
 extern "C" int cmgan_abi_version(void) { return CMGAN_ABI_VERSION; }
@@ -105,11 +106,15 @@ extern "C" int cmgan_create(cmgan_handle** out, const cmgan_config* cfg) {
                     "need n_fft %% 16 == 0, hop %% 4 == 0, hop | n_fft, num_features == n_fft/2+1 (odd)");
     if (cfg->num_tscb < 1 || cfg->num_tscb > 4 || cfg->max_pos_emb < 1)
         return fail(nullptr, CMGAN_E_UNSUPPORTED, "num_tscb must be 1..4, max_pos_emb >= 1");
-    if (cfg->mfma_mode != CMGAN_MFMA_F32 && cfg->mfma_mode != CMGAN_MFMA_F16X3 && cfg->mfma_mode != CMGAN_MFMA_F16X1)
+    if (cfg->mfma_mode < CMGAN_MFMA_F32 || cfg->mfma_mode > CMGAN_MFMA_F16MIX)
         return fail(nullptr, CMGAN_E_UNSUPPORTED,
-                    "mfma_mode must be CMGAN_MFMA_F32 (0), CMGAN_MFMA_F16X3 (1) or CMGAN_MFMA_F16X1 (2)");
+                    "mfma_mode must be CMGAN_MFMA_F32 (0), CMGAN_MFMA_F16X3 (1), CMGAN_MFMA_F16X1 (2) or CMGAN_MFMA_F16MIX (3)");
+    if (cfg->mfma_mode == CMGAN_MFMA_F16MIX && (cfg->single_mask & ~CMGAN_MIX_ALL))
+        return fail(nullptr, CMGAN_E_UNSUPPORTED, "single_mask has bits outside CMGAN_MIX_ALL");
     cmgan_handle* h = new cmgan_handle();
     h->cfg = *cfg;
+    // one representation inside: F16X3 = no family single, F16X1 = all of them (the pure modes keep their own entry points)
+    if (cfg->mfma_mode != CMGAN_MFMA_F16MIX) h->cfg.single_mask = cfg->mfma_mode == CMGAN_MFMA_F16X1 ? CMGAN_MIX_ALL : 0;
     hipError_t e = hipGetDevice(&h->device);
     if (e != hipSuccess) {
         fail(nullptr, CMGAN_E_HIP, "hipGetDevice: %s", hipGetErrorString(e));
@@ -648,6 +653,21 @@ extern "C" size_t cmgan_conformer_workspace_bytes(const cmgan_handle* h, int N, 
 static int conformer_forward_impl(cmgan_handle* h, int index, const float* x, int N, int L, const unsigned char* mask,
                                   float* y, float* taps, void* ws, size_t ws_bytes, void* stream);
 
+// One ConformerBlock in the handle's split-f16 mode: F16X3 / F16X1 through their own entry points, F16MIX through the
+// stage tables of both builds (kernels.h, ConfStageTbl), family by family as cmgan_config.single_mask says.
+static bool conformer_mix(cmgan_handle* h, LaunchCtx ctx, const ConfWeights& w, const ConfWeightsX3& w16, const ConfBuffers& b,
+                          const TokMap& seq, long M, float* taps, bool outer_residual, const unsigned char* mask) {
+    const int sm = h->cfg.single_mask;
+    if (sm == 0) return conformer_forward_x3(ctx, w, w16, b, seq, M, taps, outer_residual, mask);
+    if (sm == CMGAN_MIX_ALL || (sm | CMGAN_MIX_CONV) == CMGAN_MIX_ALL)
+        return conformer_forward_x1(ctx, w, w16, b, seq, M, taps, outer_residual, mask);
+    if (!conformer_x3_addressable(seq)) return false;
+    const ConfStageTbl &t3 = conf_stages_x3(), &t1 = conf_stages_x1();
+    auto pick = [&](int bit) -> const ConfStageTbl& { return (sm & bit) ? t1 : t3; };
+    return conformer_forward_tbl(ctx, pick(CMGAN_MIX_FF1), pick(CMGAN_MIX_QKV), pick(CMGAN_MIX_ATTN), pick(CMGAN_MIX_PW1),
+                                 pick(CMGAN_MIX_DWPW2), pick(CMGAN_MIX_FF2), w, w16, b, seq, M, taps, outer_residual, mask);
+}
+
 extern "C" int cmgan_conformer_forward(cmgan_handle* h, int index, const float* x, int N, int L, float* y,
                                        float* taps, void* ws, size_t ws_bytes, void* stream) {
     return conformer_forward_impl(h, index, x, N, L, nullptr, y, taps, ws, ws_bytes, stream);
@@ -682,8 +702,7 @@ static int conformer_forward_impl(cmgan_handle* h, int index, const float* x, in
     if (h->cfg.mfma_mode != CMGAN_MFMA_F32) {
         ConfWeightsX3 w16;
         if (!conf_weights_x3(h, index, w16)) return CMGAN_E_WEIGHTS;
-        if (!(h->cfg.mfma_mode == CMGAN_MFMA_F16X1 ? conformer_forward_x1 : conformer_forward_x3)(
-                begin(h, stream), w, w16, b, seq, (long)M, taps, false, mask))
+        if (!conformer_mix(h, begin(h, stream), w, w16, b, seq, (long)M, taps, false, mask))
             return fail(h, CMGAN_E_BADARG, "cmgan_conformer_forward: N x L too large for the split-f16 kernels");
     } else {
         conformer_forward(begin(h, stream), w, b, seq, (long)M, taps, false, mask);
@@ -799,9 +818,12 @@ static int tscnet_impl(cmgan_handle* h, const float* spec, int B, int T, float* 
     const float* cx_pr = W(h, WID(G_CPLX, CX_PRELU), ok);
     const float* cx_tail = W(h, WID(G_CPLX, CX_TAIL_W), ok);
     const float* cx_bias = W(h, WID(G_CPLX, CX_BIAS), ok);
-    const bool x3 = h->cfg.mfma_mode != CMGAN_MFMA_F32, single = h->cfg.mfma_mode == CMGAN_MFMA_F16X1;
-    const Conv3xFn conv3x = single ? launch_conv3_x1 : launch_conv3_x3;
-    const auto conformer_x = single ? conformer_forward_x1 : conformer_forward_x3;
+    const bool x3 = h->cfg.mfma_mode != CMGAN_MFMA_F32;
+    const Conv3xFn conv3x = (h->cfg.single_mask & CMGAN_MIX_CONV) ? launch_conv3_x1 : launch_conv3_x3;
+    auto conformer_x = [&](LaunchCtx c, const ConfWeights& w_, const ConfWeightsX3& w16_, const ConfBuffers& b_, const TokMap& m_,
+                           long M_, float* taps_, bool outer_, const unsigned char* mask_) {
+        return conformer_mix(h, c, w_, w16_, b_, m_, M_, taps_, outer_, mask_);
+    };
     ConfWeights cw[8];
     ConfWeightsX3 cw16[8];
     for (int i = 0; i < 2 * h->cfg.num_tscb; ++i) {

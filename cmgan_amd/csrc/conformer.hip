@@ -666,3 +666,30 @@ __global__ void selftest_mfma_kernel(const float* __restrict__ a_fm, const float
 void launch_selftest_mfma(hipStream_t s, const float* a_fm, const float* b_fm, float* d, int KB) {
     selftest_mfma_kernel<<<1, 64, 0, s>>>(a_fm, b_fm, d, KB);
 }
+
+// ---------------------------------------------------------------------------------
+// ConformerBlock.forward (conformer.py:216-222) on a table of per-stage launchers (ConfStageTbl, kernels.h): the stage
+// order, tap copies and buffer roles of the split-f16 path; which build each stage comes from is the caller's choice.
+// residual stream: xa (block input, kept for the TSCB residual) -> ff1 -> xb, then attention / conv module in place on
+// xb, ff2 + post norm (+ xa) -> xa.
+// ---------------------------------------------------------------------------------
+bool conformer_forward_tbl(LaunchCtx ctx, const ConfStageTbl& ff1, const ConfStageTbl& qkv, const ConfStageTbl& attn,
+                           const ConfStageTbl& pw1, const ConfStageTbl& dwpw2, const ConfStageTbl& ff2,
+                           const ConfWeights& w, const ConfWeightsX3& w16, const ConfBuffers& b, const TokMap& seq, long M,
+                           float* taps, bool outer_residual, const unsigned char* mask) {
+    hipStream_t s = ctx.stream;
+    const size_t tap_bytes = (size_t)M * 64 * sizeof(float);
+    ff1.ffn(ctx, 1, false, b.xa, b.xb, nullptr, w, w16, M);
+    if (taps) hipMemcpyAsync(taps, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
+    qkv.qkv(ctx, b.xb, seq, w, w16, b);
+    attn.attn(ctx, b.xb, seq, w, w16, b, mask);
+    if (taps) hipMemcpyAsync(taps + (size_t)M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
+    pw1.pw1glu(ctx, b.xb, w, w16, b, M);
+    dwpw2.dwpw2(ctx, b.xb, seq, w, w16, b);
+    if (taps) {
+        hipMemcpyAsync(taps + (size_t)2 * M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
+        ff2.ffn(ctx, 2, true, b.xb, taps + (size_t)3 * M * 64, nullptr, w, w16, M);     // the ff2 tap: before post_norm
+    }
+    ff2.ffn(ctx, 2, false, b.xb, b.xa, outer_residual ? b.xa : nullptr, w, w16, M);
+    return true;
+}

@@ -835,66 +835,78 @@ bool conformer_x3_addressable(const TokMap& seq) {
     return span * 512 < (1l << 32) && N * ((seq.L + 31) / 32) < (1l << 31);
 }
 
+// ---- the stages of a ConformerBlock in THIS build (split-f16, or its single-product twin): ConfStageTbl, kernels.h ----
+static void stage_ffn(LaunchCtx ctx, int ff, bool plain, const float* xin, float* xout, const float* x0, const ConfWeights& w,
+                      const ConfWeightsX3& w16, long M) {
+    // FeedForward on 32x32x16 MFMAs (ffn32_x3.hip) unless CMGAN_FFN32=0 (the 16x16x32 kernel above: same-session A/B)
+    static const bool k_ffn32 = env_knob("CMGAN_FFN32", FFN32_DEFAULT, 0, 1) != 0;
+    const int flat_tiles = (int)(((M + 15) / 16 + XNTB - 1) / XNTB);
+    hipStream_t s = ctx.stream;
+    const bool final_ = ff == 2 && !plain;
+    const _Float16 *w1 = ff == 1 ? w16.ff1_w1 : w16.ff2_w1, *w2 = ff == 1 ? w16.ff1_w2 : w16.ff2_w2;
+    const _Float16 *w1_32 = ff == 1 ? w16.ff1_w1_32 : w16.ff2_w1_32, *w2_32 = ff == 1 ? w16.ff1_w2_32 : w16.ff2_w2_32;
+    const float *b1 = ff == 1 ? w.ff1_b1 : w.ff2_b1, *b2 = ff == 1 ? w.ff1_b2 : w.ff2_b2;
+    if (k_ffn32) { launch_ffn32_x3(ctx, final_, xin, xout, final_ ? x0 : nullptr, final_ ? w.post_gb : nullptr, w1_32, b1, w2_32, b2, M); return; }
+    if (final_)
+        LAUNCH(ctx, "ffn_post", (ffn_x3_kernel<true, 2, FFN_POST_WAVES><<<ffn_grid(flat_tiles, FFN_POST_WAVES), 64 * FFN_POST_WAVES, 0, s>>>(
+                                    xin, xout, x0, w.post_gb, w1, b1, w2, b2, M, flat_tiles)));
+    else
+        LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, FFN_WAVES><<<ffn_grid(flat_tiles), 64 * FFN_WAVES, 0, s>>>(
+                               xin, xout, nullptr, nullptr, w1, b1, w2, b2, M, flat_tiles)));
+}
+
+// attn32_x3.hip: LN -> q, k, v tile images, then attention + to_out + residual (masked calls take the un-pipelined
+// kernel, which carries the mask logic)
+static void stage_qkv(LaunchCtx ctx, const float* x, const TokMap& seq, const ConfWeights& w, const ConfWeightsX3& w16,
+                      const ConfBuffers& b) {
+    launch_qkv32_x3(ctx, x, seq, w16.qkv_w, w.qkv_b, reinterpret_cast<_Float16*>(b.q), reinterpret_cast<_Float16*>(b.k),
+                    reinterpret_cast<_Float16*>(b.v));
+}
+
+static void stage_attn(LaunchCtx ctx, float* x, const TokMap& seq, const ConfWeights& w, const ConfWeightsX3& w16,
+                       const ConfBuffers& b, const unsigned char* mask) {
+    const _Float16 *qimg = reinterpret_cast<const _Float16*>(b.q), *kimg = reinterpret_cast<const _Float16*>(b.k),
+                   *vimg = reinterpret_cast<const _Float16*>(b.v);
+    if (!mask) launch_attn_sp_out_x3(ctx, qimg, kimg, vimg, w16.rel_planes, w.max_pos, x, seq, w16.wo, w.bo);
+    else launch_attn32_out_x3(ctx, qimg, kimg, vimg, w16.rel_planes, w.max_pos, x, seq, w16.wo, w.bo, mask);
+}
+
+static void stage_pw1glu(LaunchCtx ctx, const float* x, const ConfWeights& w, const ConfWeightsX3& w16, const ConfBuffers& b,
+                         long M) {
+    const int flat_tiles = (int)(((M + 15) / 16 + XNTB - 1) / XNTB);
+    LAUNCH(ctx, "pw1glu", (pw1glu_x3_kernel<<<persistent_grid(flat_tiles, 2), 512, 0, ctx.stream>>>(
+                              x, b.u, w16.pw1_w, w.pw1_b, M, flat_tiles)));
+}
+
+static void stage_dwpw2(LaunchCtx ctx, float* x, const TokMap& seq, const ConfWeights& w, const ConfWeightsX3& w16,
+                        const ConfBuffers& b) {
+    const int N = seq.nblocks / seq.Lb;
+    const int ntl = (seq.L + DP_TL - 1) / DP_TL;
+    const int nsegs = (ntl + DS_SEG - 1) / DS_SEG;
+    const long items = (long)N * nsegs;
+#if DS_TOEPLITZ
+    // persistent blocks (two per CU) over contiguous ranges of the items.  The kernel addresses the rows of a sequence
+    // with 32-bit byte offsets: conformer_x3_addressable rejects shapes whose sequences span 4 GB of u
+    const unsigned pgrid = items < 512 ? (unsigned)(((items + 7) / 8) * 8) : 512u;
+    LAUNCH(ctx, "dwpw2", (dwpw2t_x3_kernel<<<pgrid, 512, 0, ctx.stream>>>(x, b.u, w16.dw_img, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
+                                                                         nsegs)));
+#else
+    const unsigned grid = XCD_ORDER ? (unsigned)(((items + 7) / 8) * 8) : (unsigned)items;
+    LAUNCH(ctx, "dwpw2", (dwpw2s_x3_kernel<<<grid, 256, 0, ctx.stream>>>(x, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
+                                                                        nsegs)));
+#endif
+}
+
+const ConfStageTbl& conf_stages_x3() {
+    static const ConfStageTbl t{stage_ffn, stage_qkv, stage_attn, stage_pw1glu, stage_dwpw2};
+    return t;
+}
+
 bool conformer_forward_x3(LaunchCtx ctx, const ConfWeights& w, const ConfWeightsX3& w16, const ConfBuffers& b,
                           const TokMap& seq, long M, float* taps, bool outer_residual, const unsigned char* mask) {
     if (!conformer_x3_addressable(seq)) return false;
-    hipStream_t s = ctx.stream;
-    const int N = seq.nblocks / seq.Lb;
-    const int flat_blocks = (int)((M + 15) / 16);
-    const int flat_tiles = (flat_blocks + XNTB - 1) / XNTB;
-    const size_t tap_bytes = (size_t)M * 64 * sizeof(float);
-    _Float16 *qimg = reinterpret_cast<_Float16*>(b.q), *kimg = reinterpret_cast<_Float16*>(b.k),
-             *vimg = reinterpret_cast<_Float16*>(b.v);
-
-    // FeedForward on 32x32x16 MFMAs (ffn32_x3.hip) unless CMGAN_FFN32=0 (the 16x16x32 kernel above: same-session A/B)
-    static const bool k_ffn32 = env_knob("CMGAN_FFN32", FFN32_DEFAULT, 0, 1) != 0;
-    if (k_ffn32) launch_ffn32_x3(ctx, false, b.xa, b.xb, nullptr, nullptr, w16.ff1_w1_32, w.ff1_b1, w16.ff1_w2_32, w.ff1_b2, M);
-    else
-    LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, FFN_WAVES><<<ffn_grid(flat_tiles), 64 * FFN_WAVES, 0, s>>>(
-                           b.xa, b.xb, nullptr, nullptr, w16.ff1_w1, w.ff1_b1, w16.ff1_w2, w.ff1_b2, M, flat_tiles)));
-    if (taps) hipMemcpyAsync(taps, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
-
-    // attn32_x3.hip: LN -> q, k, v tile images, then attention + to_out + residual (masked calls take the un-pipelined
-    // kernel, which carries the mask logic)
-    launch_qkv32_x3(ctx, b.xb, seq, w16.qkv_w, w.qkv_b, qimg, kimg, vimg);
-    if (!mask) launch_attn_sp_out_x3(ctx, qimg, kimg, vimg, w16.rel_planes, w.max_pos, b.xb, seq, w16.wo, w.bo);
-    else launch_attn32_out_x3(ctx, qimg, kimg, vimg, w16.rel_planes, w.max_pos, b.xb, seq, w16.wo, w.bo, mask);
-    if (taps) hipMemcpyAsync(taps + (size_t)M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
-
-    LAUNCH(ctx, "pw1glu", (pw1glu_x3_kernel<<<persistent_grid(flat_tiles, 2), 512, 0, s>>>(
-                              b.xb, b.u, w16.pw1_w, w.pw1_b, M, flat_tiles)));
-    const int ntl = (seq.L + DP_TL - 1) / DP_TL;
-    {
-        const int nsegs = (ntl + DS_SEG - 1) / DS_SEG;
-        const long items = (long)N * nsegs;
-#if DS_TOEPLITZ
-        // persistent blocks (two per CU) over contiguous ranges of the items.  The kernel addresses the rows of a sequence
-        // with 32-bit byte offsets: conformer_x3_addressable (top of this function) rejects shapes whose sequences span 4 GB of u
-        const unsigned pgrid = items < 512 ? (unsigned)(((items + 7) / 8) * 8) : 512u;
-        LAUNCH(ctx, "dwpw2", (dwpw2t_x3_kernel<<<pgrid, 512, 0, s>>>(b.xb, b.u, w16.dw_img, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
-                                                                    nsegs)));
-#else
-        const unsigned grid = XCD_ORDER ? (unsigned)(((items + 7) / 8) * 8) : (unsigned)items;
-        LAUNCH(ctx, "dwpw2", (dwpw2s_x3_kernel<<<grid, 256, 0, s>>>(b.xb, b.u, w.dw_w, w.dw_b, w16.pw2_w, w.pw2_b, seq, N,
-                                                                   nsegs)));
-#endif
-    }
-    if (taps) {
-        hipMemcpyAsync(taps + (size_t)2 * M * 64, b.xb, tap_bytes, hipMemcpyDeviceToDevice, s);
-        if (k_ffn32) launch_ffn32_x3(ctx, false, b.xb, taps + (size_t)3 * M * 64, nullptr, nullptr, w16.ff2_w1_32, w.ff2_b1,
-                                     w16.ff2_w2_32, w.ff2_b2, M);
-        else
-        LAUNCH(ctx, "ffn", (ffn_x3_kernel<false, 2, FFN_WAVES><<<ffn_grid(flat_tiles), 64 * FFN_WAVES, 0, s>>>(
-                               b.xb, taps + (size_t)3 * M * 64, nullptr, nullptr, w16.ff2_w1, w.ff2_b1, w16.ff2_w2,
-                               w.ff2_b2, M, flat_tiles)));
-    }
-    if (k_ffn32) launch_ffn32_x3(ctx, true, b.xb, b.xa, outer_residual ? b.xa : nullptr, w.post_gb, w16.ff2_w1_32, w.ff2_b1,
-                                 w16.ff2_w2_32, w.ff2_b2, M);
-    else
-    LAUNCH(ctx, "ffn_post", (ffn_x3_kernel<true, 2, FFN_POST_WAVES><<<ffn_grid(flat_tiles, FFN_POST_WAVES), 64 * FFN_POST_WAVES, 0, s>>>(
-                                b.xb, b.xa, outer_residual ? b.xa : nullptr, w.post_gb, w16.ff2_w1, w.ff2_b1,
-                                w16.ff2_w2, w.ff2_b2, M, flat_tiles)));
-    return true;
+    const ConfStageTbl& t = conf_stages_x3();
+    return conformer_forward_tbl(ctx, t, t, t, t, t, t, w, w16, b, seq, M, taps, outer_residual, mask);
 }
 
 #ifndef X3_SINGLE

@@ -162,6 +162,28 @@ struct ConfWeightsX3 {
 // ffn32_x3.hip: FeedForward (+ post LayerNorm + TSCB residual when final_) on 32x32x16 MFMAs; x0 / post_gb as ffn_x3_kernel
 void launch_ffn32_x3(LaunchCtx, bool final_, const float* xin, float* xout, const float* x0, const float* post_gb,
                      const _Float16* w1i, const float* b1, const _Float16* w2i, const float* b2, long M);
+// The six launches of one ConformerBlock as a table of per-stage entry points.  conformer_x3.hip is compiled twice (the
+// split-f16 build and its single-product twin, cmgan_amd/build.py): each build exports its own table, and
+// conformer_forward_tbl (conformer.hip) walks ANY table - the pure ones behind conformer_forward_x3 / _x1, or one mixed
+// per stage from the two (CMGAN_MFMA_F16MIX).  Stages exchange only fp32 rows and hi | lo fp16 images whose layout is
+// the same in both builds, so any mix is well-formed.
+struct ConfStageTbl {
+    // ff: 1 = ff1 (xin -> xout), 2 = ff2 + post LayerNorm (+ x0 = the TSCB residual); plain = ff2 WITHOUT post norm (tap)
+    void (*ffn)(LaunchCtx, int ff, bool plain, const float* xin, float* xout, const float* x0, const ConfWeights&,
+                const ConfWeightsX3&, long M);
+    void (*qkv)(LaunchCtx, const float* x, const TokMap& seq, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&);
+    void (*attn)(LaunchCtx, float* x, const TokMap& seq, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&,
+                 const unsigned char* mask);
+    void (*pw1glu)(LaunchCtx, const float* x, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&, long M);
+    void (*dwpw2)(LaunchCtx, float* x, const TokMap& seq, const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&);
+};
+const ConfStageTbl& conf_stages_x3();
+const ConfStageTbl& conf_stages_x1();
+// stage order, tap copies and buffer roles of conformer_forward_x3, on any table (ff1 / ff2 may come from different builds)
+bool conformer_forward_tbl(LaunchCtx, const ConfStageTbl& ff1, const ConfStageTbl& qkv, const ConfStageTbl& attn,
+                           const ConfStageTbl& pw1, const ConfStageTbl& dwpw2, const ConfStageTbl& ff2,
+                           const ConfWeights&, const ConfWeightsX3&, const ConfBuffers&, const TokMap& seq, long M,
+                           float* taps, bool outer_residual, const unsigned char* mask);
 // Returns false WITHOUT launching anything when the shape is outside what the split-f16 conv-module kernel can address
 // (dwpw2t_x3_kernel: buffer descriptor + 32-bit lane byte offsets over a sequence's rows of the GLU output, 512 B each;
 // the 32-position tiles of a call counted in an int) - the limit lives with the kernel, every caller gets it.
@@ -207,6 +229,7 @@ void launch_ffn32_x1(LaunchCtx, bool final_, const float* xin, float* xout, cons
 #define X3_NS x1k
 #define conformer_forward_x3 conformer_forward_x1
 #define conformer_x3_addressable conformer_x1_addressable
+#define conf_stages_x3 conf_stages_x1
 #define launch_qkv32_x3 launch_qkv32_x1
 #define launch_attn32_out_x3 launch_attn32_out_x1
 #define launch_attn_sp_out_x3 launch_attn_sp_out_x1

@@ -41,16 +41,23 @@ def _on_device(fn):
     return wrapper
 
 
+#: kernel families (names of _lib.MIX) that run ONE fp16 product in mfma_mode="f16mix": every family whose own
+#: contribution to the end-to-end error stays below 1e-4 of the peak (the ablation table: DESIGN.md, tools/mix_ablation.py)
+F16MIX_PRESET = ("ff1", "ff2", "pw1")
+
+
 class Engine:
     """One handle = one device = one set of weights.  Not re-entrant: the workspace is shared by all calls,
     so use an Engine from ONE stream at a time (the stream current on its device when a method is called)."""
 
     def __init__(self, n_fft: int = 400, hop: int = 100, num_features: Optional[int] = None,
                  num_tscb: int = 4, max_pos_emb: int = 512, device: Optional[torch.device] = None,
-                 mfma_mode: Optional[str] = None):
+                 mfma_mode: Optional[str] = None, mix_single=None):
         """mfma_mode: "f16x3" (default; fp32-accurate split products on the f16 matrix pipe), "f32" (bit-exact fp32
-        MFMA) or "f16x1" (REDUCED precision, opt-in: one fp16 product per contraction in the TSCNet body, 6e-4 .. 9e-4 of
-        the peak vs the reference - inside the 1e-3 gate without margin, 200x the default mode's error) - see include/cmgan_hip.h."""
+        MFMA), "f16x1" (REDUCED precision, opt-in: one fp16 product per contraction in the TSCNet body, 6e-4 .. 9e-4 of
+        the peak vs the reference - inside the 1e-3 gate without margin, 200x the default mode's error) or "f16mix"
+        (REDUCED precision, opt-in, WITH margin: only the kernel families in `mix_single` - names of _lib.MIX, default
+        F16MIX_PRESET - run one product, the rest three; <= 2e-4 end to end) - see include/cmgan_hip.h."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("cmgan_amd needs a ROCm GPU: torch.cuda.is_available() is False")
@@ -64,11 +71,21 @@ class Engine:
         cfg.num_features = num_features if num_features is not None else n_fft // 2 + 1
         cfg.num_tscb, cfg.max_pos_emb = num_tscb, max_pos_emb
         if mfma_mode is not None:
-            modes = {"f32": _lib.MFMA_F32, "f16x3": _lib.MFMA_F16X3, "f16x1": _lib.MFMA_F16X1}
+            modes = {"f32": _lib.MFMA_F32, "f16x3": _lib.MFMA_F16X3, "f16x1": _lib.MFMA_F16X1, "f16mix": _lib.MFMA_F16MIX}
             if mfma_mode not in modes:
                 raise ValueError(f"mfma_mode must be one of {sorted(modes)}")
             cfg.mfma_mode = modes[mfma_mode]
-        self.mfma_mode = {_lib.MFMA_F32: "f32", _lib.MFMA_F16X3: "f16x3", _lib.MFMA_F16X1: "f16x1"}[cfg.mfma_mode]
+        if mix_single is not None and cfg.mfma_mode != _lib.MFMA_F16MIX:
+            raise ValueError("mix_single only applies to mfma_mode='f16mix'")
+        if cfg.mfma_mode == _lib.MFMA_F16MIX:
+            fams = F16MIX_PRESET if mix_single is None else tuple(mix_single)
+            unknown = [f for f in fams if f not in _lib.MIX]
+            if unknown:
+                raise ValueError(f"unknown kernel families {unknown}: choose from {sorted(_lib.MIX)}")
+            cfg.single_mask = sum(_lib.MIX[f] for f in set(fams))
+            self.mix_single = tuple(sorted(set(fams)))
+        self.mfma_mode = {_lib.MFMA_F32: "f32", _lib.MFMA_F16X3: "f16x3", _lib.MFMA_F16X1: "f16x1",
+                          _lib.MFMA_F16MIX: "f16mix"}[cfg.mfma_mode]
         self.cfg = cfg
         self._h = ctypes.c_void_p()
         with torch.cuda.device(self.device):

@@ -16,13 +16,14 @@ from .synth import state_dict_shapes
 
 class TSCNet:
     def __init__(self, num_channel: int = 64, num_features: int = 201, *, n_fft: int | None = None,
-                 hop: int | None = None, device=None, mfma_mode: str | None = None):
+                 hop: int | None = None, device=None, mfma_mode: str | None = None, mix_single=None):
         if num_channel != 64:
             raise ValueError("the HIP kernels are specialised for num_channel=64 (generator.py:160)")
         n_fft = n_fft if n_fft is not None else 2 * (num_features - 1)
         hop = hop if hop is not None else n_fft // 4            # evaluation.py:78
         self.num_channel, self.num_features = num_channel, num_features
-        self.engine = Engine(n_fft=n_fft, hop=hop, num_features=num_features, device=device, mfma_mode=mfma_mode)
+        self.engine = Engine(n_fft=n_fft, hop=hop, num_features=num_features, device=device, mfma_mode=mfma_mode,
+                             mix_single=mix_single)
 
     # nn.Module look-alikes so evaluation-style code runs unchanged
     def _check_device(self, device):

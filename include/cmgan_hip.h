@@ -58,7 +58,8 @@ typedef struct cmgan_config {
     int32_t dim_head;      /* 16                                                    */
     int32_t conv_kernel;   /* 31                                                    */
     int32_t max_pos_emb;   /* 512                                                   */
-    int32_t mfma_mode;     /* CMGAN_MFMA_F32, CMGAN_MFMA_F16X3 (default) or _F16X1  */
+    int32_t mfma_mode;     /* CMGAN_MFMA_F32, CMGAN_MFMA_F16X3 (default), _F16X1 or _F16MIX */
+    int32_t single_mask;   /* CMGAN_MFMA_F16MIX only: CMGAN_MIX_* bits = the kernel families that run ONE fp16 product */
 } cmgan_config;
 
 /* How the dense contractions (convs, linears, attention) are evaluated.  Three modes; all keep fp32 storage and
@@ -80,6 +81,21 @@ typedef struct cmgan_config {
  * margin, 200x the error of the other two modes - not fp32-class.  STFT / ISTFT run as in F16X3 (|X|^-0.7 on
  * near-silent bins is what a single-product front end gets wrong by several 1e-2). */
 #define CMGAN_MFMA_F16X1 2
+/* F16MIX - REDUCED precision, opt-in: the F16X3 library with the kernel families named in cmgan_config.single_mask
+ * switched to their single-product (F16X1) build, every other family on three split products.  What each family
+ * costs in accuracy when it alone is single is tabulated in DESIGN.md (tools/mix_ablation.py); the shipped "f16mix"
+ * preset of the Python host (cmgan_amd.engine.F16MIX_PRESET) takes every family whose own contribution stays below
+ * 1e-4 of the peak, for an end-to-end error <= 2e-4 (5 x margin to the 1e-3 gate, asserted two-sidedly by
+ * tests/test_gpu_parity.py::test_f16mix_mode_error_band).  single_mask = 0 is F16X3, all bits = F16X1.            */
+#define CMGAN_MFMA_F16MIX 3
+#define CMGAN_MIX_CONV   1    /* dilated dense convs, conv_2, sub-pixel convs   src/models/generator.py:39-47,60,107-118 */
+#define CMGAN_MIX_FF1    2    /* ff1 (LN -> W1 -> Swish -> W2)                  src/models/conformer.py:136-148, 216     */
+#define CMGAN_MIX_FF2    4    /* ff2 + post norm                                src/models/conformer.py:220-221          */
+#define CMGAN_MIX_QKV    8    /* LN -> to_q / to_kv                             src/models/conformer.py:100-101          */
+#define CMGAN_MIX_ATTN  16    /* q k^T, q E^T, P V, to_out                      src/models/conformer.py:103-133          */
+#define CMGAN_MIX_PW1   32    /* conv module: LN -> pointwise 64 -> 256 -> GLU  src/models/conformer.py:161-164          */
+#define CMGAN_MIX_DWPW2 64    /* depthwise k = 31 -> Swish -> pointwise 128 -> 64   src/models/conformer.py:165-170      */
+#define CMGAN_MIX_ALL  127
 
 /* Fills *cfg with the reference's 16 kHz defaults (above). */
 void cmgan_default_config(cmgan_config* cfg);
