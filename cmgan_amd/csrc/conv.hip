@@ -240,19 +240,20 @@ void launch_conv_in(LaunchCtx ctx, const float* spec, const float* w, float* out
 // GPU guarantee).  Biased variance, eps 1e-5 (generator.py:35,55,61,148).
 // fold2: channel c also owns partial column c + 64 (pixel-shuffled sub-pixel conv).
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restrict__ partials, int ntiles,
-                                                          int cstride, int fold2, double count,
-                                                          const float* __restrict__ gb,
-                                                          float* __restrict__ nscale, float* __restrict__ nshift) {
-    __shared__ double acc[4][64][2];
+#define INF_NP 16              // partial sums per (clip, channel): 16 x 64 threads walk the tiles 16 apart, 8 loads in flight each
+__global__ __launch_bounds__(64 * INF_NP) void in_finalize_kernel(const float* __restrict__ partials, int ntiles,
+                                                                  int cstride, int fold2, double count,
+                                                                  const float* __restrict__ gb,
+                                                                  float* __restrict__ nscale, float* __restrict__ nshift) {
+    __shared__ double acc[INF_NP][64][2];
     const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int b = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    for (int t0 = part; t0 < ntiles; t0 += 4 * 8) {           // 8 independent loads in flight, fixed summation order
+    for (int t0 = part; t0 < ntiles; t0 += INF_NP * 8) {      // 8 independent loads in flight, fixed summation order
         float v1[8], v2[8], f1[8], f2[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int t = t0 + 4 * k < ntiles ? t0 + 4 * k : ntiles - 1;
+            const int t = t0 + INF_NP * k < ntiles ? t0 + INF_NP * k : ntiles - 1;
             const float* p = partials + (((long)b * ntiles + t) * cstride + c) * 2;
             v1[k] = p[0];
             v2[k] = p[1];
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restric
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if (t0 + 4 * k < ntiles) {
+            if (t0 + INF_NP * k < ntiles) {
                 s1 += (double)v1[k];
                 s2 += (double)v2[k];
                 s1 += (double)f1[k];
@@ -273,8 +274,12 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restric
     acc[part][c][1] = s2;
     __syncthreads();
     if (part == 0) {
-        s1 = (acc[0][c][0] + acc[1][c][0]) + (acc[2][c][0] + acc[3][c][0]);
-        s2 = (acc[0][c][1] + acc[1][c][1]) + (acc[2][c][1] + acc[3][c][1]);
+        s1 = 0.0; s2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < INF_NP; q += 4) {                 // fixed order: groups of four, then the groups
+            s1 += (acc[q][c][0] + acc[q + 1][c][0]) + (acc[q + 2][c][0] + acc[q + 3][c][0]);
+            s2 += (acc[q][c][1] + acc[q + 1][c][1]) + (acc[q + 2][c][1] + acc[q + 3][c][1]);
+        }
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256) void in_finalize_kernel(const float* __restric
 
 void launch_in_finalize(LaunchCtx ctx, const float* partials, int B, int ntiles, int cstride, int fold2,
                         double count, const float* gb, float* nscale, float* nshift) {
-    LAUNCH(ctx, "in_finalize", (in_finalize_kernel<<<B, 256, 0, ctx.stream>>>(partials, ntiles, cstride, fold2, count,
+    LAUNCH(ctx, "in_finalize", (in_finalize_kernel<<<B, 64 * INF_NP, 0, ctx.stream>>>(partials, ntiles, cstride, fold2, count,
                                                                               gb, nscale, nshift)));
 }
 

@@ -41,9 +41,11 @@ def _on_device(fn):
     return wrapper
 
 
-#: kernel families (names of _lib.MIX) that run ONE fp16 product in mfma_mode="f16mix": every family whose own
-#: contribution to the end-to-end error stays below 1e-4 of the peak (the ablation table: DESIGN.md, tools/mix_ablation.py)
-F16MIX_PRESET = ("ff1", "ff2", "pw1")
+#: kernel families (names of _lib.MIX) that run ONE fp16 product in mfma_mode="f16mix".  The ablation
+#: (tools/mix_ablation.py -> profiles/r06_mix_ablation.json, 32 x 2 s clips + three real recordings, error vs the F16X3
+#: output): alone, every conformer family costs 1e-5 .. 7e-5 and the dense / sub-pixel convs 6e-4 .. 1.4e-3 - F16X1's whole
+#: error is the convs.  All six conformer families together: 5.9e-5 (batch) / 1.14e-4 (recordings) for 18.1 vs 21.1 ms.
+F16MIX_PRESET = ("ff1", "ff2", "qkv", "attn", "pw1", "dwpw2")
 
 
 class Engine:
@@ -506,6 +508,14 @@ class Engine:
         err = ctypes.c_float()
         check(self._h, self.lib.cmgan_selftest_mfma_x3(self._h, ctypes.byref(err)))
         return float(err.value)
+
+    def release_workspaces(self):
+        """Drop the inference workspaces and every captured graph that points into them (they are re-created on demand):
+        ~6 GB each at 32 x 2 s.  bench.py calls this before its training leg."""
+        self._graphs.clear()
+        self._row_graphs.clear()
+        self._stream_slots.clear()
+        self._ws = self._bws = self._cws = None
 
     def set_profiling(self, on: bool):
         check(self._h, self.lib.cmgan_set_profiling(self._h, 1 if on else 0))
