@@ -558,8 +558,7 @@ static WsPlan plan_ws(const cmgan_config& c, int B, int T) {
     p.dm = take(cur, (size_t)B * T * W2 * 4 + 64);
     p.dc = take(cur, (size_t)B * T * W2 * 4 + 64);
     const size_t nt = std::max({(size_t)conv3_ntiles(T, (int)F), (size_t)conv_in_ntiles((int)P),
-                                (size_t)conv3x_ntiles(T, (int)F, 64) * conv3x_dense_partial_sets(),
-                                (size_t)conv3x_ntiles(T, (int)F, 128)});
+                                (size_t)conv3x_ntiles(T, (int)F, 64), (size_t)conv3x_ntiles(T, (int)F, 128)});
     p.partials = take(cur, (size_t)B * nt * 128 * 2);
     p.ns = take(cur, (size_t)16 * 2 * B * 64);
     p.mstat = take(cur, (size_t)B * 2);
@@ -737,10 +736,8 @@ static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float
                             float* const nsc[4], float* const nsh[4], int B, int T, int F, float* const* imgs = nullptr,
                             Conv3xFn conv3x = launch_conv3_x3, bool frozen = false) {
     const int nt = x3 ? conv3x_ntiles(T, F, 64) : conv3_ntiles(T, F);
-    const int psets = x3 ? conv3x_dense_partial_sets() : 1;      // partial-sum sets per tile (4: producer / consumer kernel)
     for (int i = 0; i < 4; ++i) {
         ConvArgs a{};
-        a.psets = psets;
         a.in[0] = x0; a.nscale[0] = x0_scale; a.nshift[0] = x0_shift; a.nalpha[0] = x0_alpha;
         for (int s = 1; s <= i; ++s) {
             a.in[s] = slots[s - 1]; a.nscale[s] = nsc[s - 1]; a.nshift[s] = nsh[s - 1]; a.nalpha[s] = d.prelu[s - 1];
@@ -757,7 +754,7 @@ static void run_dense_block(LaunchCtx ctx, bool x3, const DenseW& d, const float
         a.T = T; a.F = F; a.dil = 1 << i; a.mode = 0; a.ntiles = nt;
         if (x3) conv3x(ctx, a, d.w16[i], B, 2, 64);
         else launch_conv3(ctx, a, B, 2, 64);
-        if (!frozen) launch_in_finalize(ctx, partials, B, nt * psets, 64, 0, (double)T * F, d.gb[i], nsc[i], nsh[i]);
+        if (!frozen) launch_in_finalize(ctx, partials, B, nt, 64, 0, (double)T * F, d.gb[i], nsc[i], nsh[i]);
     }
 }
 

@@ -394,242 +394,6 @@ __global__ __launch_bounds__(64 * NWV) void conv3x_kernel(ConvArgs a, const _Flo
     }
 }
 
-// =====================================================================================
-// conv3x_pc_kernel - the dilated dense conv (generator.py:39-47; NT = 2 time taps, 64 output channels) with SPECIALISED
-// waves: one 512-thread block per CU, persistent over a contiguous range of tiles.
-//   waves 4..7 = PRODUCERS: everything conv3x_kernel's staging phase does - global loads of a stage (one time plane of
-//     a 32-channel chunk, 256 rows) two stages ahead of its use, normalise + PReLU + fp16 split (or the pre-split slot
-//     image), the 24 KB weight image - written into the OTHER of two LDS buffers (2 x 72 KB) while
-//   waves 0..3 = CONSUMERS issue nothing but LDS operand reads and the stage's MFMAs (4 position blocks x 4 output
-//     blocks x 3 taps x 3 split products = 144 per wave and stage; with 4 position blocks a wave re-uses every A
-//     fragment four times: 48 ds_read_b128 per 144 MFMAs instead of 36 per 72) and, after a tile's last stage, the
-//     epilogue (output rows + InstanceNorm partial sums, one set PER CONSUMER WAVE: in_finalize sums ntiles * 4 of them).
-// ONE barrier per stage: behind barrier p the consumers read buffer p & 1 while the producers fill buffer (p + 1) & 1,
-// which the consumers left before they arrived at barrier p.  The stream of (tile, stage) pairs runs on across tiles:
-// the producers are already staging the next tile while the consumers store the last one.
-// Why: in conv3x_kernel every wave alternates staging VALU and MFMAs between two barriers per stage, and the second
-// block on the CU only fills those gaps by chance (matrix pipe 0.52 busy); here each SIMD pairs ONE
-// matrix-only wave with ONE VALU / memory wave - the complementary pairing MI355X_MICROARCH.md ("Two waves per SIMD")
-// describes - and neither waits for the other except at the stage barrier.
-// Results: outputs bit-identical to conv3x_kernel (same products in the same order per accumulator); the InstanceNorm
-// partials are grouped per wave instead of per tile (the fp64 reduction of in_finalize makes the statistics agree to
-// the last bits, not bit for bit).
-// =====================================================================================
-#define PC_NPB 4
-#define PC_CW 4
-struct PcTile {                 // per-thread staging map of one tile (CX_SETUP): byte offsets of the t plane, padding bits
-    unsigned off1[8];
-    unsigned inv1, inv0;
-    int b;
-};
-struct PcRegs {                 // one stage in flight: 8 activation quads, 6 weight units, the slot's norm parameters
-    f32x4 pre[8];
-    u32x4 wpre[6];
-    f32x4 sc, sh, al;
-};
-
-template <int NT, int COUT>
-__global__ __launch_bounds__(512, 2) void conv3x_pc_kernel(ConvArgs a, const _Float16* __restrict__ w16, int tiles_total) {
-    constexpr int NPB = PC_NPB, NWV = PC_CW, NTHR = 64 * NWV;       // (NTHR: threads of EACH role)
-    constexpr int RSTEP = NTHR / 8, CX_ROWS = 16 * NPB * NWV, CX_TILE = CX_ROWS - 2, CB = COUT / 16, TAPS = NT * 3;
-    constexpr int NACT = CX_ROWS * 8 / NTHR, W16 = 3 * CB * 2 * 64, NW = W16 / NTHR, ACT = CX_ROWS * CX_STRIDE;
-    constexpr int SMEM = 2 * ACT + W16 * 8;
-    static_assert(NACT == 8 && NW == 6, "PcRegs is sized for 256 rows x 32 channels and a 24 KB weight image");
-    __shared__ __attribute__((aligned(16))) _Float16 sm2[2 * SMEM];           // 144 KB: two stage buffers
-    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // XCD-contiguous persistent ranges: block lb owns tiles [t0, t1) of the (clip, tile) order (see xcd_contiguous_block)
-    const int nb = gridDim.x, lb = (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3);
-    const int t0 = (int)((long)lb * tiles_total / nb), t1 = (int)((long)(lb + 1) * tiles_total / nb);
-    if (t0 >= t1) return;
-    const int nst = a.nslots * 2 * NT;
-    const int G = (t1 - t0) * nst;                                   // stages of this block's stream
-    const int Fp = a.F + 1;
-    const size_t clip_bytes = (size_t)a.T * a.F * 256;
-
-    if (wv >= NWV) {
-        // ------------------------------------------------------------------ producers
-        const int pt = tid - NTHR, qd = pt & 7;
-        const int lds_col = 8 * (qd & 3) + 4 * (qd >> 2);           // chain slot order: [4g..4g+3 | 16+4g..]
-        const int wrow_off = (pt >> 3) * CX_STRIDE + lds_col;
-        const unsigned dFs = 0u - (unsigned)(a.dil * a.F) * 256u;   // byte step from frame t to frame t - dil
-        auto tile_setup = [&](int logical, PcTile& t) {
-            const int b = logical / a.ntiles, tile = logical - b * a.ntiles;
-            t.b = b; t.inv1 = 0; t.inv0 = 0;
-            const int qfirst = tile * CX_TILE - 1 + (pt >> 3);
-            int tt = (qfirst < 0 ? 0 : qfirst) / Fp, ff = qfirst - tt * Fp;      // q = -1 -> (0, -1): padding
-#pragma unroll
-            for (int e = 0; e < NACT; ++e) {
-                bool ok1 = false, ok0 = false;
-                t.off1[e] = qd * 16;
-                if (ff >= 0 && ff < a.F && tt < a.T) {
-                    ok1 = true;
-                    t.off1[e] = (unsigned)(tt * a.F + ff) * 256u + qd * 16;
-                    if (NT == 2 && tt >= a.dil) ok0 = true;
-                }
-                if (!ok1) t.inv1 |= 1u << e;
-                if (!ok0) t.inv0 |= 1u << e;
-                ff += RSTEP;
-                if (ff >= Fp) { ff -= Fp; ++tt; }
-            }
-        };
-        auto fetch = [&](const PcTile& t, int s, PcRegs& r) {
-            const int chunk = s / NT, kt = s - chunk * NT, slot = chunk >> 1, half = chunk & 1;
-            const char* src = reinterpret_cast<const char*>(sel4(a.in, slot)) + t.b * clip_bytes + half * 128;
-#pragma unroll
-            for (int e = 0; e < NACT; ++e) {
-                const unsigned o = (NT == 2 && kt == 0) ? t.off1[e] + ((t.inv0 >> e) & 1u ? 0u : dFs) : t.off1[e];
-                r.pre[e] = *reinterpret_cast<const f32x4*>(src + o);          // unconditional; masked at write
-            }
-            const u32x4* wsrc = reinterpret_cast<const u32x4*>(w16) + ((long)chunk * TAPS + kt * 3) * (CB * 128);
-#pragma unroll
-            for (int i = 0; i < NW; ++i) r.wpre[i] = wsrc[pt + NTHR * i];
-            const float* nsc = ((a.img_mask >> slot) & 1u) ? nullptr : sel4(a.nscale, slot);
-            if (nsc != nullptr) {
-                r.sc = ldg4(nsc + t.b * 64 + half * 32 + qd * 4);
-                r.sh = ldg4(sel4(a.nshift, slot) + t.b * 64 + half * 32 + qd * 4);
-                r.al = ldg4(sel4(a.nalpha, slot) + half * 32 + qd * 4);
-            } else {
-                r.sc = splat4(1.f); r.sh = splat4(0.f); r.al = splat4(1.f);
-            }
-        };
-        auto write = [&](const PcTile& t, int s, const PcRegs& r, _Float16* buf) {
-            const int chunk = s / NT, kt = s - chunk * NT, slot = chunk >> 1;
-            const unsigned inv = (NT == 2 && kt == 0) ? t.inv0 : t.inv1;
-            _Float16* const wrow = buf + wrow_off;
-            if ((a.img_mask >> slot) & 1u) {                          // pre-split image slot (block-uniform): two LDS stores
-#pragma unroll
-                for (int e = 0; e < NACT; ++e) {
-                    u32x4 v = __builtin_bit_cast(u32x4, r.pre[e]);
-                    if (inv & (1u << e)) v = u32x4{0u, 0u, 0u, 0u};
-                    *reinterpret_cast<unsigned long long*>(wrow + RSTEP * e * CX_STRIDE) =
-                        (unsigned long long)v[0] | ((unsigned long long)v[1] << 32);
-                    *reinterpret_cast<unsigned long long*>(wrow + RSTEP * e * CX_STRIDE + ACT) =
-                        (unsigned long long)v[2] | ((unsigned long long)v[3] << 32);
-                    asm volatile("s_nop 1" ::"v"(v) : "memory");      // (wide LDS store: see below)
-                }
-            } else {
-                const f32x4 am1 = r.al - splat4(1.f);
-                // the newest slot's t-plane stage also stores the image for the block's later layers
-                char* const wb = (!CX_NOWB && a.img_out != nullptr && slot == a.nslots - 1 && kt == NT - 1)
-                                     ? reinterpret_cast<char*>(a.img_out) + t.b * clip_bytes + (chunk & 1) * 128 : nullptr;
-#pragma unroll
-                for (int e = 0; e < NACT; ++e) {
-                    f32x4 v = r.pre[e];
-                    v = v * r.sc + r.sh;
-                    f32x4 mn;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) mn[q] = fminf(v[q], 0.f);
-                    v = mn * am1 + v;
-                    if (inv & (1u << e)) v = splat4(0.f);
-                    f16x4 hi, lo;
-                    split4(v, hi, lo);
-                    *reinterpret_cast<f16x4*>(wrow + RSTEP * e * CX_STRIDE) = hi;
-                    *reinterpret_cast<f16x4*>(wrow + RSTEP * e * CX_STRIDE + ACT) = lo;
-                    // (the two stores merge into one ds_write2st64_b64; its later data dwords are read by the LDS path for
-                    // several cycles after issue and the compiler inserts no wait states before re-using them - tools/isa_lint.py.
-                    // The producers have issue slots to spare: keep the registers live across one s_nop.)
-                    asm volatile("s_nop 1" ::"v"(hi), "v"(lo) : "memory");
-                    if (wb != nullptr) {                              // rows 1 .. CX_TILE are this tile's own positions
-                        const int p_ = (pt >> 3) + RSTEP * e;
-                        if (p_ >= 1 && p_ <= CX_TILE && !(inv & (1u << e))) {
-                            f16x8 hl = __builtin_shufflevector(hi, lo, 0, 1, 2, 3, 4, 5, 6, 7);
-                            *reinterpret_cast<f16x8*>(wb + t.off1[e]) = hl;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NW; ++i) *reinterpret_cast<u32x4*>(buf + 2 * ACT + (pt + NTHR * i) * 8) = r.wpre[i];
-        };
-        // fetch cursor (tile tf, stage sf) runs two stages ahead of the write cursor (tile state tw, stage sw)
-        PcTile tf, tw;
-        int lf = t0, sf = 0, sw = 0, gf = 0;                         // gf = stages fetched so far
-        tile_setup(lf, tf);
-        tw = tf;
-        auto advance_f = [&]() {
-            ++gf;
-            if (++sf == nst) { sf = 0; ++lf; if (gf < G) tile_setup(lf, tf); }
-        };
-        PcRegs r0, r1;
-        fetch(tf, sf, r0); advance_f();
-        if (gf < G) { fetch(tf, sf, r1); advance_f(); }
-        // one write per barrier: stage p is written before barrier p; its register set then takes stage p + 2
-#define PC_PRODUCE(R, BUF)                                                                    \
-        do {                                                                                      \
-            write(tw, sw, R, BUF);                                                                \
-            if (++sw == nst) { sw = 0; tw = tf; }   /* (the fetch cursor is already in the next tile: nst >= 4) */ \
-            if (gf < G) { fetch(tf, sf, R); advance_f(); }                                        \
-            __syncthreads();                                                                      \
-        } while (0)
-#pragma unroll 1
-        for (int p = 0; p < G; p += 2) {
-            PC_PRODUCE(r0, sm2);
-            if (p + 1 < G) PC_PRODUCE(r1, sm2 + SMEM);
-        }
-#undef PC_PRODUCE
-        return;
-    }
-    // ---------------------------------------------------------------------- consumers
-    f32x4 acc[CB][NPB], bias_[CB];
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-        bias_[cb] = ldg4(a.bias + 16 * cb + 4 * g);
-#pragma unroll
-        for (int tb = 0; tb < NPB; ++tb) acc[cb][tb] = bias_[cb];
-    }
-    int logical = t0, s = 0;
-#pragma unroll 1
-    for (int p = 0; p < G; ++p) {
-        __syncthreads();                                             // stage p is in buffer p & 1
-        const _Float16* const buf = sm2 + (p & 1) * SMEM;
-        const _Float16* const brow = buf + (16 * NPB * wv + c) * CX_STRIDE + 8 * g;     // B-operand reads
-        const _Float16* const alane = buf + 2 * ACT + lane * 8;                        // A-operand reads
-        CX_MFMA();
-        if (++s == nst) {
-            // ---- epilogue of the tile: rows + per-wave InstanceNorm partials (the producers are staging the next tile) ----
-            const int b = logical / a.ntiles, tile = logical - b * a.ntiles;
-            const int qe = tile * CX_TILE + 16 * NPB * wv + c;
-            int t = qe / Fp, f = qe - t * Fp;
-            bool ok[NPB];
-            long obase[NPB];
-#pragma unroll
-            for (int tb = 0; tb < NPB; ++tb) {
-                if (tb > 0) { f += 16; if (f >= Fp) { f -= Fp; ++t; } }
-                ok[tb] = (t < a.T) && (f < a.F) && (16 * NPB * wv + 16 * tb + c < CX_TILE);
-                obase[tb] = ((long)(b * a.T + t) * a.F + f) * 64;
-            }
-            float* const part = a.partials ? a.partials + (((long)b * a.ntiles + tile) * NWV + wv) * (COUT * 2) : nullptr;
-#pragma unroll
-            for (int cb = 0; cb < CB; ++cb) {
-                f32x4 s1 = splat4(0.f), s2 = splat4(0.f);
-#pragma unroll
-                for (int tb = 0; tb < NPB; ++tb) {
-                    const f32x4 v = acc[cb][tb];
-                    if (ok[tb]) {
-                        stg4(a.out + obase[tb] + 16 * cb + 4 * g, v);
-                        s1 += v;
-                        s2 += v * v;
-                    }
-                    acc[cb][tb] = bias_[cb];
-                }
-                if (part) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float u1 = red_c_sum(s1[r]), u2 = red_c_sum(s2[r]);
-                        if (c == 0) {
-                            part[(16 * cb + 4 * g + r) * 2] = u1;
-                            part[(16 * cb + 4 * g + r) * 2 + 1] = u2;
-                        }
-                    }
-                }
-            }
-            s = 0;
-            ++logical;
-        }
-    }
-}
-
 }  // namespace X3_NS
 using namespace X3_NS;
 
@@ -663,25 +427,10 @@ void launch_conv3_x3_dgrad(LaunchCtx ctx, const ConvArgs& a, const void* w16, in
 }
 #endif
 
-#ifndef CX_PC
-#define CX_PC 1              // 1: the dense conv runs conv3x_pc_kernel (specialised producer / consumer waves); 0: conv3x_kernel
-#endif
-#ifndef X3_SINGLE
-// InstanceNorm partial-sum sets one dense-conv tile writes (ConvArgs::partials is [B][ntiles * this][64][2])
-int conv3x_dense_partial_sets() {
-    static const int k_pc = env_knob("CMGAN_CONV_PC", CX_PC, 0, 1);
-    return k_pc ? PC_CW : 1;
-}
-#endif
-
 void launch_conv3_x3(LaunchCtx ctx, const ConvArgs& a, const void* w16, int B, int time_taps, int cout) {
     dim3 grid(a.ntiles * B);                              // 1-D: see the XCD re-map in the kernel
     const _Float16* w = reinterpret_cast<const _Float16*>(w16);
-    if (time_taps == 2 && cout == 64 && a.mode == 0 && a.psets == PC_CW && conv3x_dense_partial_sets() == PC_CW) {
-        const int total = a.ntiles * B;
-        const int nb = total < 256 ? (total + 7) / 8 * 8 : 256;          // one persistent block per CU, a multiple of 8 (XCDs)
-        LAUNCH(ctx, "conv_dense", (conv3x_pc_kernel<2, 64><<<nb, 512, 0, ctx.stream>>>(a, w, total)));
-    } else if (time_taps == 2 && cout == 64)
+    if (time_taps == 2 && cout == 64)
         LAUNCH(ctx, "conv_dense", (conv3x_kernel<2, 64, CX_NPB64, CX_NWV64><<<grid, 64 * CX_NWV64, 0, ctx.stream>>>(a, w)));
     else if (time_taps == 1 && cout == 64)
         LAUNCH(ctx, "conv_1x3", (conv3x_kernel<1, 64, CX_NPB64, CX_NWV64><<<grid, 64 * CX_NWV64, 0, ctx.stream>>>(a, w)));

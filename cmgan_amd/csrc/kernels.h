@@ -112,10 +112,6 @@ struct ConvArgs {
     int revt;                  // 1: logical frame t is physical frame T - 1 - t, for inputs and outputs alike
     int accum;                 // 1: out += oscale * result
     const float* oscale;       // device scalar (the inverse of the power-of-two input scale carried by nscale)
-    // x3 dense conv only: partial-sum sets per tile the caller provisioned in `partials` ([B][ntiles * psets][COUT][2]).
-    // 0 / 1 = one per tile (conv3x_kernel); conv3x_dense_partial_sets() (= 4: one per consumer wave) lets launch_conv3_x3
-    // take conv3x_pc_kernel, the specialised producer / consumer form (conv_x3.hip).  Zero-initialised callers keep the old kernel.
-    int psets;
 };
 int  conv3_ntiles(int T, int F);
 void launch_conv3(LaunchCtx, const ConvArgs&, int B, int time_taps, int cout);
@@ -205,7 +201,6 @@ void launch_attn_sp_out_x3(LaunchCtx, const _Float16* qimg, const _Float16* kimg
                            const _Float16* rel_img, int max_pos, float* x, const TokMap& seq, const _Float16* woi,
                            const float* bo);
 int  conv3x_ntiles(int T, int F, int cout);
-int  conv3x_dense_partial_sets();     // what ConvArgs::psets must be for the producer / consumer dense conv (1 when it is switched off)
 void launch_conv3_x3(LaunchCtx, const ConvArgs&, const void* w16, int B, int time_taps, int cout);
 void launch_conv3_x3_dgrad(LaunchCtx, const ConvArgs&, const void* w16, int B);      // 2 time taps, 64 -> 64, revt / accum honoured
 void launch_selftest_x3(hipStream_t, const void* a_img, const float* b_fm, float* d, int M32);
