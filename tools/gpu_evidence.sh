@@ -1,5 +1,5 @@
 #!/bin/bash
-# evidence session of a round (round 5: tag r05): full GPU suite, smoke, the default bench line, kernel trace + separate PMC passes of the
+# evidence session of a round (tag r05 / r06): full GPU suite, smoke, the default bench line, kernel trace + separate PMC passes of the
 # inference command (raw rocpd databases KEPT under gpurun_out/), stall / instruction-mix / exact fabric-byte counters,
 # batch sweep
 TAG=${1:-r05}
@@ -10,6 +10,11 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 timeout 900 python bench.py > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err; echo "bench exit $?"
 BENCH="$REPO/bench.py --no-cpu-baseline --no-f32 --no-f16x1 --no-train --no-extra"
 cd /tmp && export TMPDIR=/tmp
+# the headline replays a hipGraph with TWO half-batch branches (round 6); its trace is kept separately, and every per-kernel
+# pass below runs the one-stream form (CMGAN_BRANCHES=1) so that a launch is the full 32-clip launch bench.py's live table
+# and SURVEY 8(d)'s per-launch figures describe
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof2_$TAG -o trace -- python $BENCH --steps 3 --warmup 1 > $OUT/prof2_$TAG.log 2>&1; echo "trace (2 branches) $?"
+export CMGAN_BRANCHES=1
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o trace -- python $BENCH --steps 3 --warmup 1 > $OUT/prof_$TAG.log 2>&1; echo "trace $?"
 i=0
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
@@ -20,9 +25,11 @@ for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE
   i=$((i+1))
   timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_${TAG}_$i -o pmc -- python $BENCH --steps 1 --warmup 1 > $OUT/pmc_${TAG}_$i.log 2>&1; echo "pmc $i $?"
 done
+unset CMGAN_BRANCHES
 cd $REPO
 db() { ls $1/*results.db $1/*/*results.db 2>/dev/null | head -1; }
 python tools/rocpd_summary.py trace $(db $OUT/prof_$TAG) > $OUT/${TAG}_x3_kernel_trace_stats.txt
+python tools/rocpd_summary.py trace $(db $OUT/prof2_$TAG) > $OUT/${TAG}_x3_kernel_trace_stats_2branches.txt
 python tools/rocpd_summary.py pmc $(db $OUT/pmc_${TAG}_1) $(db $OUT/pmc_${TAG}_2) $(db $OUT/pmc_${TAG}_3) > $OUT/${TAG}_x3_pmc.txt
 python tools/rocpd_summary.py pmc $(db $OUT/pmc_${TAG}_4) $(db $OUT/pmc_${TAG}_5) > $OUT/${TAG}_x3_stall_counters.txt
 python tools/rocpd_summary.py pmc $(db $OUT/pmc_${TAG}_6) $(db $OUT/pmc_${TAG}_7) > $OUT/${TAG}_x3_fabric_requests.txt
@@ -30,7 +37,7 @@ python tools/rocpd_summary.py traffic $(db $OUT/pmc_${TAG}_1) $(db $OUT/pmc_${TA
 timeout 300 python tools/batch_sweep.py > $OUT/${TAG}_x3_batch_sweep.txt 2>/dev/null; echo "sweep $?"
 # keep the raw databases, drop everything else rocprofv3 wrote next to them
 mkdir -p $OUT/raw_$TAG
-for d in $OUT/prof_$TAG $OUT/pmc_${TAG}_*; do
+for d in $OUT/prof_$TAG $OUT/prof2_$TAG $OUT/pmc_${TAG}_*; do
   f=$(db $d); [ -n "$f" ] && cp $f $OUT/raw_$TAG/$(basename $d).db
   rm -rf $d
 done
