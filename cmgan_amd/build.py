@@ -17,25 +17,29 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcmgan_hip.so")
 SOURCES = ["api.hip", "api_train.hip", "conformer.hip", "conformer_x3.hip", "attn32_x3.hip", "ffn32_x3.hip", "conv.hip", "conv_x3.hip",
-           "stft.hip", "train.hip", "train_x3.hip", "disc.hip"]
+           "stft.hip", "stft_fft.hip", "train.hip", "train_x3.hip", "disc.hip"]
+# pure-VALU kernels that WANT packed fp32 instructions (complex arithmetic of the FFT front / back end): built without
+# the "-packed-fp32-ops" feature removal below
+PACKED_FP32_SOURCES = {"stft_fft.hip"}
 # the F16X1 (single fp16 product) twins of the x3 kernels: the same sources compiled a second time with X1_FLAGS
 X1_SOURCES = ["conformer_x3.hip", "attn32_x3.hip", "ffn32_x3.hip", "conv_x3.hip"]
 X1_FLAGS = ["-DX3_SINGLE", "-DX3_TERMS=1"]
-HEADERS = ["common.hip.h", "kernels.h", "weights.h", "api_internal.h", "train.h",
+HEADERS = ["common.hip.h", "kernels.h", "weights.h", "api_internal.h", "train.h", "stft_fft_tables.h",
            os.path.join("..", "..", "include", "cmgan_hip.h")]
 # the generator FORWARD path: what bench.py measures and what the PMC evidence under profiles/ was collected on.  The
 # training-step slices (train.hip, api_train.hip, train.h) and the public header (which grows with them) are left
 # out, so committed counters stay valid while the training side is being built.
 INFERENCE_FILES = ["api.hip", "conformer.hip", "conformer_x3.hip", "attn32_x3.hip", "ffn32_x3.hip", "conv.hip", "conv_x3.hip", "stft.hip",
-                   "common.hip.h", "kernels.h", "weights.h", "api_internal.h"]
+                   "stft_fft.hip",
+                   "common.hip.h", "kernels.h", "weights.h", "api_internal.h", "stft_fft_tables.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -packed-fp32-ops: v_pk_{fma,mul,add}_f32 issue slower than the scalar pair they replace when the SIMD is
 # also feeding MFMAs (measured: the whole step is 0.6% faster without them, dwpw2 with hand-packed FMAs
 # was 18% slower), so the SLP vectoriser is told the target has none.  The flag is a device feature; the
 # host pass of hipcc prints one "not a recognized feature" line per file for it, filtered below.
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
-         "-Wno-unused-result", "-Wno-unused-value",
-         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+         "-Wno-unused-result", "-Wno-unused-value", *NO_PACKED_FP32]
 _NOISE = "is not a recognized feature for this target"
 
 
@@ -75,7 +79,8 @@ def build(force: bool = False, verbose: bool = True, variant: str | None = None,
     def compile_one(job):
         src, extra, suffix = job
         obj = os.path.join(libdir, src.replace(".hip", suffix + ".o"))
-        cmd = [HIPCC, *flags, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        fl = flags if src not in PACKED_FP32_SOURCES else [f for f in flags if f not in NO_PACKED_FP32]
+        cmd = [HIPCC, *fl, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)

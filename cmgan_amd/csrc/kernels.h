@@ -82,6 +82,10 @@ void launch_stft_compress(LaunchCtx, const SpectralTables&, const float* wav, co
                           int B, int L, int T, float* spec);
 void launch_uncompress_istft(LaunchCtx, const SpectralTables&, const float* re, const float* im,
                              const float* scale, int B, int T, float* frames_ws, float* wav_out);
+// stft_fft.hip: n_fft 400 / hop 100 as real FFTs (16 x 25 factorisation on the VALU); window = SpectralTables::window
+void launch_stft_fft400(LaunchCtx, const float* wav, const float* scale, const float* window, int B, int L, int T, float* spec);
+void launch_istft_fft400(LaunchCtx, const float* re, const float* im, const float* scale, const float* window, int B, int T,
+                         float* wav_out);
 void launch_power_compress(LaunchCtx, const float* x, int B, int F, int T, float* y);
 void launch_power_uncompress(LaunchCtx, const float* re, const float* im, int B, int F, int T, float* y);
 

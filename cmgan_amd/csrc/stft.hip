@@ -269,8 +269,16 @@ __global__ __launch_bounds__(256, 2) void stft_fold_x3_kernel(SpectralTables tb,
 #ifndef STFT_BSPLIT
 #define STFT_BSPLIT 3
 #endif
+#ifndef STFT_FFT
+#define STFT_FFT 1             // 1: n_fft 400 / hop 100 runs the real-FFT kernels (stft_fft400_kernel); 0: the folded split-f16 DFT products
+#endif
 void launch_stft_compress(LaunchCtx ctx, const SpectralTables& tb, const float* wav, const float* scale, int B,
                           int L, int T, float* spec) {
+    static const int k_fft = env_knob("CMGAN_STFT_FFT", STFT_FFT, 0, 1);
+    if (k_fft && tb.fold_fwd16 && tb.n_fft == 400 && tb.hop == 100 && tb.F == 201) {
+        launch_stft_fft400(ctx, wav, scale, tb.window, B, L, T, spec);
+        return;
+    }
     if (tb.fold_fwd16 && tb.n_fft == 400 && tb.hop == 100) {
         const int tiles = (T + 63) / 64;
         if ((long)tiles * B >= 512) {                         // two blocks per CU already cover the chip
@@ -537,6 +545,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
 void launch_uncompress_istft(LaunchCtx ctx, const SpectralTables& tb, const float* re, const float* im,
                              const float* scale, int B, int T, float* frames_ws, float* wav_out) {
+    static const int k_fft = env_knob("CMGAN_STFT_FFT", STFT_FFT, 0, 1);
+    if (k_fft && tb.fold_inv16 && tb.n_fft == 400 && tb.hop == 100 && tb.F == 201) {
+        launch_istft_fft400(ctx, re, im, scale, tb.window, B, T, wav_out);
+        return;
+    }
     if (tb.fold_inv16 && tb.n_fft == 400 && tb.hop == 100) {
         dim3 grid64((T + 63) / 64, B);
         LAUNCH(ctx, "uncompress_irfft",
