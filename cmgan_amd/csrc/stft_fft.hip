@@ -133,10 +133,11 @@ __global__ __launch_bounds__(256) void stft_fft400_kernel(const float* __restric
                 const int kp = c + 5 * d;
                 if (kp < 13) {
                     const f2 h = cmul(z[d], cld(&fft_tw400[r * 13 + kp]));
-                    // (two 4-byte volatile stores: one 8-byte store per channel would merge pairwise into ds_write2_b64, whose
-                    // later data dwords the LDS path still reads when the next VALU instruction overwrites them - tools/isa_lint.py)
-                    volatile float* hv = reinterpret_cast<volatile float*>(hw + kp * FFT_HP);
-                    hv[0] = h.x; hv[1] = h.y;
+                    // (the compiler barrier keeps the 8-byte stores apart: merged pairwise into ds_write2_b64, the later data
+                    // dwords are still being read by the LDS path when the next VALU instruction overwrites them - tools/isa_lint.py;
+                    // a volatile store would do too, but it goes out as a system-scope FLAT store)
+                    hw[kp * FFT_HP] = make_float2(h.x, h.y);
+                    asm volatile("" ::: "memory");
                 }
             }
         }
@@ -166,8 +167,9 @@ __global__ __launch_bounds__(256) void stft_fft400_kernel(const float* __restric
         // addresses are two per-lane bases plus compile-time offsets.  Channel 0's mirror bins (k1 >= 9) are bins it also
         // produces directly: dropped (dump slot).  Lanes 52..63 recompute lane 51 and store the same values again.
         constexpr int DUMP = 2 * 804;
-        float* const od = out_w + j * 201 + kp;               // direct bins: + 25 k1
-        float* const om = out_w + j * 201 - kp;               // mirror bins: + 400 - 25 k1
+        // (indices into ONE LDS array: a select between two LDS POINTERS loses the address space and becomes a flat store)
+        const int id_ = j * 201 + kp;                         // direct bins: + 25 k1
+        const int im_ = j * 201 - kp;                         // mirror bins: + 400 - 25 k1
         const float sgn8 = kp == 0 ? 1.f : -1.f;
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_) {
@@ -181,12 +183,12 @@ __global__ __launch_bounds__(256) void stft_fft400_kernel(const float* __restric
                 const int k1 = s_ + 4 * u;
                 const float m2 = z[u].x * z[u].x + z[u].y * z[u].y;
                 const f2 c_ = z[u] * fft_pow_pos(m2, -0.35f);  // power compression (utils.py:20-29)
-                if (k1 <= 7) { od[25 * k1] = c_.x; od[804 + 25 * k1] = c_.y; }
-                else if (k1 == 8) { om[200] = c_.x; om[804 + 200] = sgn8 * c_.y; }
+                if (k1 <= 7) { out_w[id_ + 25 * k1] = c_.x; out_w[id_ + 804 + 25 * k1] = c_.y; }
+                else if (k1 == 8) { out_w[im_ + 200] = c_.x; out_w[im_ + 804 + 200] = sgn8 * c_.y; }
                 else {
-                    float* const o_ = kp == 0 ? out_w + DUMP : om + (400 - 25 * k1);
-                    o_[0] = c_.x;
-                    (kp == 0 ? o_ : o_ + 804)[0] = -c_.y;
+                    const int o_ = kp == 0 ? DUMP : im_ + (400 - 25 * k1);
+                    out_w[o_] = c_.x;
+                    out_w[kp == 0 ? DUMP : o_ + 804] = -c_.y;
                 }
             }
         }
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(320) void istft_fft400_kernel(const float* __restri
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_) inner[q][s_] = z[s_];
             }
-            float* const hbase = reinterpret_cast<float*>(hx_w + (j * 16) * IFFT_HP + kp);
+            float2* const hbase = hx_w + (j * 16) * IFFT_HP + kp;
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_) {
                 f2 z[4];
@@ -293,8 +295,8 @@ __global__ __launch_bounds__(320) void istft_fft400_kernel(const float* __restri
                     const int r = s_ + 4 * u;
                     const f2 h = cmulc(z[u], cld(&fft_tw400[r * 13 + kp]));
                     if (act) {
-                        volatile float* hv = hbase + r * (2 * IFFT_HP);   // (volatile: no merged wide LDS store, tools/isa_lint.py)
-                        hv[0] = h.x; hv[1] = h.y;
+                        hbase[r * IFFT_HP] = make_float2(h.x, h.y);
+                        asm volatile("" ::: "memory");        // (keeps the 8-byte stores apart: see stft_fft400_kernel)
                     }
                 }
             }
