@@ -312,7 +312,8 @@ def train_leg(eng, sd, dev, rank, world, barrier, batch=32, cut_len=32000, steps
 
 def stream_leg(model, dev, reps=5):
     """BASELINE configs[4]: one 10 s 16 kHz clip in 400-frame windows, each step replayed from a captured hipGraph.
-    `carried_state_*` = cmgan_amd.streaming.enhance_stream: frozen InstanceNorm statistics make the dense
+    `carried_state_*` = cmgan_amd.streaming.enhance_stream (by default the decoders of step k run on a second
+    stream beside the encoder / TSCBs of step k + 1, `_not_pipelined` = one graph per step): frozen InstanceNorm statistics make the dense
     encoder and both decoders exactly causal, so their state is CARRIED (15 frames of input history, every frame
     computed once) and only the four TSCBs - bidirectional attention - run on [40 cached context | 400 | 40 look-ahead]
     frames.  `windows_*` = the stateless per-window contract (enhance_windows: 40 frames of context recomputed on each
@@ -323,6 +324,8 @@ def stream_leg(model, dev, reps=5):
     stats = model.engine.tscnet_forward_stats(model.engine.stft_compress(noisy[:, :44000], model.engine.rms_scale(noisy)))[2]
     out = {}
     legs = (("carried_state_1_window_per_replay", lambda: enhance_stream(model, noisy, 400, 40, 40, stats=stats, graph=True)),
+            ("carried_state_1_window_per_replay_not_pipelined",
+             lambda: enhance_stream(model, noisy, 400, 40, 40, stats=stats, graph=True, pipeline=False)),
             ("carried_state_no_lookahead", lambda: enhance_stream(model, noisy, 400, 40, 0, stats=stats, graph=True)),
             ("windows_per_replay_1", lambda: enhance_windows(model, noisy, 40000, 4000, graph=True, batch=1)),
             ("windows_per_replay_4", lambda: enhance_windows(model, noisy, 40000, 4000, graph=True, batch=4)),

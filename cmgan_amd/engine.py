@@ -149,9 +149,13 @@ class Engine:
             self._row_graphs.clear()
             for slot in self._stream_slots.values():
                 slot.graphs.clear()
+                slot.stage_graphs.clear()
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
+
+    def workspace_bytes(self, B: int, T: int) -> int:
+        return int(self.lib.cmgan_workspace_bytes(self._h, B, T))
 
     def _conf_workspace(self, N: int, L: int) -> torch.Tensor:
         need = self.lib.cmgan_conformer_workspace_bytes(self._h, N, L)
@@ -282,15 +286,24 @@ class Engine:
             raise ValueError(f"statistics blob has {stats.numel()} floats, a batch of {B} rows needs {self.stats_floats(B)}")
         return stats.data_ptr()
 
+    def _own_ws(self, ws: Optional[torch.Tensor], B: int, T: int) -> torch.Tensor:
+        if ws is None:
+            return self._workspace(B, T)
+        if not ws.is_cuda or ws.dtype != torch.uint8 or ws.numel() < self.workspace_bytes(B, T):
+            raise ValueError("ws must be a uint8 GPU tensor of at least workspace_bytes(B, T) bytes")
+        return ws
+
     @_on_device
-    def stream_encoder(self, spec: torch.Tensor, stats: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """dense_encoder under frozen statistics: spec [B,2,T,F] -> x [B,T,F',64] (channels-last)."""
+    def stream_encoder(self, spec: torch.Tensor, stats: torch.Tensor, out: Optional[torch.Tensor] = None,
+                       ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """dense_encoder under frozen statistics: spec [B,2,T,F] -> x [B,T,F',64] (channels-last).  ws: a workspace of the
+        caller's instead of the engine's (lets the call run on another stream beside a step's TSCBs)."""
         self._need_weights()
         spec = self._in(spec, "spec")
         B, two, T, F = spec.shape
         if two != 2 or F != self.F:
             raise ValueError(f"expected [B,2,T,{self.F}], got {tuple(spec.shape)}")
-        ws = self._workspace(B, T)
+        ws = self._own_ws(ws, B, T)
         want = (B, T, (F + 1) // 2, 64)
         if out is None:
             out = torch.empty(want, dtype=torch.float32, device=spec.device)
@@ -316,15 +329,16 @@ class Engine:
         return x
 
     @_on_device
-    def stream_decoder(self, x: torch.Tensor, spec: torch.Tensor, stats: torch.Tensor):
+    def stream_decoder(self, x: torch.Tensor, spec: torch.Tensor, stats: torch.Tensor, ws: Optional[torch.Tensor] = None):
         """mask + complex decoder + recombination under frozen statistics: x [B,T,F',64], spec [B,2,T,F] ->
-        (est_real, est_imag) [B,1,T,F]."""
+        (est_real, est_imag) [B,1,T,F].  ws: a workspace of the caller's (uint8, >= workspace_bytes(B, T)) instead of the
+        engine's - what lets a decoder call run on another stream BESIDE the next step's encoder / TSCBs."""
         self._need_weights()
         x, spec = self._in(x, "x"), self._in(spec, "spec")
         B, T, F2, C = x.shape
         if tuple(spec.shape) != (B, 2, T, self.F) or C != 64 or F2 != (self.F + 1) // 2:
             raise ValueError(f"expected x [B,T,{(self.F + 1) // 2},64] and spec [B,2,T,{self.F}]")
-        ws = self._workspace(B, T)
+        ws = self._own_ws(ws, B, T)
         real = torch.empty(B, 1, T, self.F, dtype=torch.float32, device=x.device)
         imag = torch.empty_like(real)
         check(self._h, self.lib.cmgan_stream_decoder(self._h, x.data_ptr(), spec.data_ptr(), B, T, self._stats_arg(stats, B),

@@ -138,6 +138,26 @@ class _StreamSlot:
         self.stats = torch.empty(eng.stats_floats(B), device=dev)
         self.graphs: dict = {}                               # step signature -> (graph, spec_in, out_real, out_imag, token); LRU
         self.owner = None                                    # weakref of the StreamState using the buffers
+        # pipelined form (StreamState.step_pipelined): three stages on three streams - encoder of step k + 2 | TSCBs of step
+        # k + 1 | decoders of step k - so what crosses a stage boundary is double-buffered by step parity and the outer
+        # stages get workspaces of their own
+        self.n_max, self.B = n_max, B
+        self.ENC = self.D2 = self.SD = self.ws_enc = self.ws_dec = self.enc_stream = self.dec_stream = None
+        self.stage_graphs: dict = {}                         # (stage, signature) -> (graph, outputs, token); LRU
+        self.spec_in: dict = {}                              # n_new -> static input of the encoder stage
+        self.ev = {"front": [None, None], "mid": [None, None], "dec": [None, None]}   # per stage and parity: last run done
+
+    def pipeline_buffers(self, eng):
+        if self.D2 is None:
+            dev, F, F2 = eng.device, eng.F, (eng.F + 1) // 2
+            nd = HIST_FRAMES + self.n_max
+            self.ENC = [torch.empty(self.B, self.n_max, F2, 64, device=dev) for _ in range(2)]     # fresh encoder outputs
+            self.D2 = [torch.empty(self.B, nd, F2, 64, device=dev) for _ in range(2)]              # decoder input
+            self.SD = [torch.empty(self.B, 2, nd, F, device=dev) for _ in range(2)]                # its spectrogram frames
+            self.ws_enc = torch.empty(eng.workspace_bytes(self.B, nd), dtype=torch.uint8, device=dev)
+            self.ws_dec = torch.empty(eng.workspace_bytes(self.B, nd), dtype=torch.uint8, device=dev)
+            self.enc_stream = torch.cuda.Stream(device=dev)
+            self.dec_stream = torch.cuda.Stream(device=dev)
 
 
 class StreamState:
@@ -158,6 +178,9 @@ class StreamState:
         self.enc_lo = 0
         self.spec_lo = 0
         self.h_dec = 0                   # kept TSCB frames of the previous step held as decoder history
+        self._prev_len = 0               # (pipelined form) valid frames in the previous step's decoder input
+        #: stages of step_pipelined that get their own stream: 2 = [encoder + TSCBs] | decoders, 3 = encoder | TSCBs | decoders
+        self.pipeline_stages = int(__import__("os").environ.get("CMGAN_STREAM_STAGES", "2"))
         if graph:
             self.slot = self._claim_slot()
             self.slot.stats.copy_(self.eng._in(stats, "stats"))
@@ -249,6 +272,163 @@ class StreamState:
         g.replay()
         return out_r, out_i              # static buffers of this shape's graph: valid until its next replay
 
+    # ---- pipelined form: encoder of step k + 2 | TSCBs of step k + 1 | decoders of step k, on three streams ----
+    def _front_body(self, sl: _StreamSlot, spec_in, sig):
+        """Stage 1 (needs spectrogram frames only): append the new frames, encoder -> ENC[parity], the decoder's frames ->
+        SD[parity], carry of the spectrogram tail."""
+        n_tail, h_enc, n_new, dec_lo, n_dec, spec_drop, last, par = sig
+        S = sl.S
+        S[:, :, n_tail:n_tail + n_new].copy_(spec_in)
+        enc = self.eng.stream_encoder(S[:, :, n_tail - h_enc:n_tail + n_new].contiguous(), sl.stats, ws=sl.ws_enc)
+        sl.ENC[par][:, :n_new].copy_(enc[:, h_enc:])                   # the history outputs are dropped
+        sl.SD[par][:, :, :n_dec].copy_(S[:, :, dec_lo:dec_lo + n_dec])
+        if not last and spec_drop > 0:
+            tmp = S[:, :, spec_drop:n_tail + n_new].clone()            # (source and destination may overlap)
+            S[:, :, :n_tail + n_new - spec_drop].copy_(tmp)
+
+    def _mid_body(self, sl: _StreamSlot, sig):
+        """Stage 2: cached context + fresh encoder outputs -> TSCBs -> the decoder input D2[parity], carry of the cache."""
+        n_ctx, n_new, keep_lo, n_keep, h_dec, enc_drop, last, par, prev_len = sig
+        E, D, Dp = sl.E, sl.D2[par], sl.D2[par ^ 1]
+        E[:, n_ctx:n_ctx + n_new].copy_(sl.ENC[par][:, :n_new])
+        x = E[:, :n_ctx + n_new].clone()                               # the TSCBs work in place: the cache keeps the encoder's
+        self.eng.stream_tscb(x)
+        if h_dec:
+            D[:, :h_dec].copy_(Dp[:, prev_len - h_dec:prev_len])       # the previous step's last kept frames (other parity: read only)
+        D[:, h_dec:h_dec + n_keep].copy_(x[:, keep_lo:keep_lo + n_keep])
+        if not last and enc_drop > 0:
+            tmp = E[:, enc_drop:n_ctx + n_new].clone()
+            E[:, :n_ctx + n_new - enc_drop].copy_(tmp)
+
+    def _dec_body(self, sl: _StreamSlot, par, h_dec, n_keep):
+        """Stage 3: both decoders on [history | kept frames]."""
+        real, imag = self.eng.stream_decoder(sl.D2[par][:, :h_dec + n_keep].contiguous(),
+                                             sl.SD[par][:, :, :h_dec + n_keep].contiguous(), sl.stats, ws=sl.ws_dec)
+        return real[:, :, h_dec:], imag[:, :, h_dec:]
+
+    def _captured(self, sl: _StreamSlot, key, body, stream, restore=()):
+        """LRU-cached hipGraph of one stage (warm-up outside capture; `restore`: state a run of the body modifies)."""
+        eng = self.eng
+        token = eng._ws_token()
+        ent = sl.stage_graphs.pop(key, None)
+        if ent is not None and ent[2] != token:
+            ent = None
+        if ent is None:
+            torch.cuda.synchronize(eng.device)                         # the other stages are idle while this one is captured
+            saved = [t.clone() for t in restore]
+            side = torch.cuda.Stream(device=eng.device)
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                body()
+            stream.wait_stream(side)
+            torch.cuda.synchronize(eng.device)
+            for dst, src in zip(restore, saved):
+                dst.copy_(src)
+            torch.cuda.synchronize(eng.device)
+            g = torch.cuda.CUDAGraph()
+            # (a graph cannot be captured ON the default stream - the caller's, for the middle stage; torch's own capture
+            # stream does it then; replaying on the default stream is fine)
+            cap = None if stream == torch.cuda.default_stream(eng.device) else stream
+            with torch.cuda.graph(g, stream=cap):
+                outs = body()
+            for dst, src in zip(restore, saved):                       # (capture does not execute, but keep the rule simple)
+                dst.copy_(src)
+            torch.cuda.synchronize(eng.device)
+            ent = (g, outs, eng._ws_token())
+        sl.stage_graphs[key] = ent                                     # most recently used last
+        while len(sl.stage_graphs) > 3 * _StreamSlot.MAX_GRAPHS:
+            sl.stage_graphs.pop(next(iter(sl.stage_graphs)))
+        return ent
+
+    @torch.no_grad()
+    def step_pipelined(self, spec_new: torch.Tensor, out, last: bool = False):
+        """step() for a driver that has the next windows' frames at hand (offline enhance_stream; a live front end that is
+        fed faster than real time).  A step is three captured stages on three streams - encoder | TSCBs | decoders - tied
+        by events, so that the encoder of step k + 2 and the decoders of step k run beside the TSCBs of step k + 1: at one
+        clip per step no stage fills the chip by itself.  What crosses a stage boundary is double-buffered by step parity;
+        the same kernels run on the same values as in step(): the result is bit-identical.  `out` = (real, imag)
+        [B,1,>=w,F] are written on the decoder stream - call finish_pipeline() before reading them elsewhere."""
+        if not self.graph:
+            raise RuntimeError("the pipelined form replays captured graphs: graph=True")
+        W, Ca, H = self.W, self.Ca, HIST_FRAMES
+        k, e0 = self.k, self.e1
+        spec_new = self.eng._in(spec_new, "spec_new")
+        n_new = spec_new.size(2)
+        e1 = e0 + n_new
+        want = (k + 1) * W + self.La
+        if (e1 < want and not last) or e1 > want:
+            raise ValueError(f"step {k} takes the frames up to {want} (fewer only at the end of the clip), got up to {e1}")
+        lo = k * W
+        n_keep = e1 - lo if last else min(W, e1 - lo)
+        if n_keep <= 0:
+            raise ValueError("no frame left to emit")
+        sl, eng = self.slot, self.eng
+        if sl.owner is None or sl.owner() is not self:
+            raise RuntimeError("this stream's state buffers were claimed by a newer StreamState of the same configuration")
+        sl.pipeline_buffers(eng)
+        h_enc, a0, nxt_lo = min(H, e0), max(lo - Ca, 0), lo + W
+        h_dec, par, last = self.h_dec, k & 1, bool(last)
+        h_dec_next = min(H, h_dec + n_keep)
+        spec_drop = max(max(nxt_lo - H, 0) - self.spec_lo, 0)
+        enc_drop = max(max(nxt_lo - Ca, 0) - self.enc_lo, 0)
+        cur, ds = torch.cuda.current_stream(eng.device), sl.dec_stream
+        es = sl.enc_stream if self.pipeline_stages == 3 else cur       # 2 stages: the encoder stays in front of the TSCBs on one stream
+        ev = sl.ev
+
+        def after(stream, *events):
+            for e in events:
+                if e is not None:
+                    stream.wait_event(e)
+
+        def mark(stream):
+            e = torch.cuda.Event()
+            e.record(stream)
+            return e
+
+        # ---- stage 1 on the encoder stream: ENC / SD of this parity are free once step k - 2's TSCBs / decoders are done ----
+        spec_in = sl.spec_in.get(n_new)
+        if spec_in is None:
+            spec_in = sl.spec_in[n_new] = torch.empty_like(spec_new)
+        if es is not cur:
+            es.wait_stream(cur)                                        # (spec_new was produced on the caller's stream)
+        after(es, ev["mid"][par], ev["dec"][par])
+        fsig = (e0 - self.spec_lo, h_enc, n_new, lo - h_dec - self.spec_lo, h_dec + n_keep, spec_drop, last, par)
+        ent = self._captured(sl, ("front",) + fsig, lambda: self._front_body(sl, spec_in, fsig), es, restore=(sl.S,))
+        with torch.cuda.stream(es):
+            spec_in.copy_(spec_new)
+            ent[0].replay()
+        ev["front"][par] = mark(es)
+        # ---- stage 2 on the caller's stream: D2 of this parity is free once step k - 2's decoders are done ----
+        after(cur, ev["front"][par], ev["dec"][par])
+        msig = (e0 - a0, n_new, lo - a0, n_keep, h_dec, enc_drop, last, par, self._prev_len)
+        ent = self._captured(sl, ("mid",) + msig, lambda: self._mid_body(sl, msig), cur, restore=(sl.E,))
+        ent[0].replay()
+        ev["mid"][par] = mark(cur)
+        # ---- stage 3 on the decoder stream ----
+        after(ds, ev["mid"][par], ev["front"][par])
+        ent = self._captured(sl, ("dec", par, h_dec, n_keep), lambda: self._dec_body(sl, par, h_dec, n_keep), ds)
+        with torch.cuda.stream(ds):
+            ent[0].replay()
+            r, i = ent[1]
+            out[0][:, :, :n_keep].copy_(r)
+            out[1][:, :, :n_keep].copy_(i)
+        ev["dec"][par] = mark(ds)
+        if not last:
+            self.spec_lo += spec_drop
+            self.enc_lo += enc_drop
+            self.h_dec = h_dec_next
+        self._prev_len = h_dec + n_keep
+        self.k, self.e1 = k + 1, e1
+        return n_keep
+
+    def finish_pipeline(self):
+        """Make the current stream wait for the stages still running on the other two."""
+        sl = self.slot
+        if sl.dec_stream is not None:
+            cur = torch.cuda.current_stream(self.eng.device)
+            cur.wait_stream(sl.dec_stream)
+            cur.wait_stream(sl.enc_stream)
+
     @torch.no_grad()
     def step(self, spec_new: torch.Tensor, last: bool = False, out=None):
         """spec_new: [B,2,n,F] = the spectrogram frames that arrived since the previous step (frames [e1, e1 + n)).
@@ -317,7 +497,8 @@ class StreamState:
 
 @torch.no_grad()
 def enhance_stream(model: TSCNet, noisy: torch.Tensor, window: int = 400, context: int = 40, lookahead: int = 40,
-                   stats: torch.Tensor | None = None, calib_frames: int | None = None, graph: bool = True) -> torch.Tensor:
+                   stats: torch.Tensor | None = None, calib_frames: int | None = None, graph: bool = True,
+                   pipeline: bool | None = None) -> torch.Tensor:
     """noisy: float32 [1, L] on the GPU -> enhanced [L'] (L' = hop * (T - 1), T = L // hop + 1, like one reference row).
     window / context / lookahead are in FRAMES.  `stats`: a frozen statistics blob (Engine.tscnet_forward_stats); by
     default the clip's first `calib_frames` (default window + lookahead) frames calibrate it."""
@@ -335,10 +516,17 @@ def enhance_stream(model: TSCNet, noisy: torch.Tensor, window: int = 400, contex
     real = torch.empty(1, 1, T, eng.F, device=noisy.device)
     imag = torch.empty_like(real)
     k, fed = 0, 0
+    pipeline = graph if pipeline is None else pipeline         # (the whole clip is at hand: decoders of step k beside step k + 1)
     while fed < T:
         upto = min((k + 1) * window + lookahead, T)
-        st.step(spec[:, :, fed:upto], last=upto == T, out=(real[:, :, k * window:], imag[:, :, k * window:]))
+        o = (real[:, :, k * window:], imag[:, :, k * window:])
+        if pipeline:
+            st.step_pipelined(spec[:, :, fed:upto], o, last=upto == T)
+        else:
+            st.step(spec[:, :, fed:upto], last=upto == T, out=o)
         fed, k = upto, k + 1
+    if pipeline:
+        st.finish_pipeline()
     return (eng.uncompress_istft(real, imag) / c[:, None]).reshape(-1)
 
 

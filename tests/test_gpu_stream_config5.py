@@ -80,6 +80,10 @@ def test_enhance_stream_at_the_named_config5_shape(model, clip, golden, ctx_la):
     assert torch.equal(eager, got)                         # one replay per step over the state buffers == eager launches
     again = enhance_stream(model, clip.to(DEV), window=400, context=ca, lookahead=la, graph=True)    # cached graphs, re-used buffers
     assert torch.equal(again, got)
+    # graph=True pipelines by default (decoders of step k on a second stream beside the encoder / TSCBs of step k + 1);
+    # the one-graph-per-step form must give the same samples
+    serial = enhance_stream(model, clip.to(DEV), window=400, context=ca, lookahead=la, graph=True, pipeline=False)
+    assert torch.equal(serial, got)
     c = _cost(got, whole)
     print(f"[cost] streamed vs the reference's whole-clip output, context {ca} look-ahead {la}: " +
           ", ".join(f"{k} = {v:.4g}" for k, v in c.items()))

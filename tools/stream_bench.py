@@ -30,8 +30,22 @@ def timed(fn, n=10):
 eng = model.engine
 stats = eng.tscnet_forward_stats(eng.stft_compress(noisy[:, :44000], eng.rms_scale(noisy)))[2]     # as bench.py's stream leg
 res = {}
+import os
+def staged(n, la):
+    def run():
+        old = os.environ.get("CMGAN_STREAM_STAGES")
+        os.environ["CMGAN_STREAM_STAGES"] = str(n)
+        try:
+            return enhance_stream(model, noisy, 400, 40, la, stats=stats, graph=True)
+        finally:
+            os.environ.pop("CMGAN_STREAM_STAGES") if old is None else os.environ.__setitem__("CMGAN_STREAM_STAGES", old)
+    return run
 for name, fn in (("carried_state_graph_40_40", lambda: enhance_stream(model, noisy, 400, 40, 40, stats=stats, graph=True)),
+                 ("carried_state_2_stages_40_40", staged(2, 40)), ("carried_state_3_stages_40_40", staged(3, 40)),
+                 ("carried_state_2_stages_40_0", staged(2, 0)), ("carried_state_3_stages_40_0", staged(3, 0)),
+                 ("carried_state_not_pipelined_40_0", lambda: enhance_stream(model, noisy, 400, 40, 0, stats=stats, graph=True, pipeline=False)),
                  ("carried_state_graph_40_0", lambda: enhance_stream(model, noisy, 400, 40, 0, stats=stats, graph=True)),
+                 ("carried_state_graph_40_40_not_pipelined", lambda: enhance_stream(model, noisy, 400, 40, 40, stats=stats, graph=True, pipeline=False)),
                  ("carried_state_eager_40_40", lambda: enhance_stream(model, noisy, 400, 40, 40, stats=stats, graph=False)),
                  ("windows_graph_batch1", lambda: enhance_windows(model, noisy, W, C, batch=1, graph=True)),
                  ("windows_graph_batch4", lambda: enhance_windows(model, noisy, W, C, batch=4, graph=True)),
