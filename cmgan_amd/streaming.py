@@ -19,6 +19,7 @@ All windows have the same shape [1, W + 2C], so the ~250 kernel launches are cap
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -180,7 +181,7 @@ class StreamState:
         self.h_dec = 0                   # kept TSCB frames of the previous step held as decoder history
         self._prev_len = 0               # (pipelined form) valid frames in the previous step's decoder input
         #: stages of step_pipelined that get their own stream: 2 = [encoder + TSCBs] | decoders, 3 = encoder | TSCBs | decoders
-        self.pipeline_stages = int(__import__("os").environ.get("CMGAN_STREAM_STAGES", "2"))
+        self.pipeline_stages = 3 if os.environ.get("CMGAN_STREAM_STAGES", "2") == "3" else 2
         if graph:
             self.slot = self._claim_slot()
             self.slot.stats.copy_(self.eng._in(stats, "stats"))
