@@ -117,6 +117,52 @@ def _enhance_rows(model: TSCNet, rows: torch.Tensor, graph: bool) -> torch.Tenso
 HIST_FRAMES = 15
 
 
+class StreamCursor:
+    """The host-side bookkeeping of a carried-state stream: which frames the device buffers hold, and for every step
+    the integer offsets its captured graph bakes in.  Pure Python (no torch): tests/test_stream_plan.py replays it on
+    arrays of frame NUMBERS and checks that every stage sees exactly the frames the contract names.
+
+    Buffers (see _StreamSlot): S holds spectrogram frames [spec_lo, e1), E encoder outputs [enc_lo, e1), the decoder
+    input is [h_dec history frames | n_keep kept frames] ending at frame lo + n_keep."""
+
+    def __init__(self, window: int, context: int, lookahead: int):
+        self.W, self.Ca, self.La = window, context, lookahead
+        self.k = self.e1 = self.spec_lo = self.enc_lo = self.h_dec = self.prev_len = 0
+
+    def plan(self, n_new: int, last: bool) -> dict:
+        """Offsets of step k given `n_new` new frames (frames [e1, e1 + n_new)); raises like StreamState.step."""
+        W, Ca, H = self.W, self.Ca, HIST_FRAMES
+        k, e0 = self.k, self.e1
+        e1 = e0 + n_new
+        want = (k + 1) * W + self.La
+        if (e1 < want and not last) or e1 > want:
+            raise ValueError(f"step {k} takes the frames up to {want} (fewer only at the end of the clip), got up to {e1}")
+        lo = k * W                                             # first frame this step emits
+        n_keep = e1 - lo if last else min(W, e1 - lo)          # the clip's last step also emits what is left past its window
+        if n_keep <= 0:
+            raise ValueError("no frame left to emit")
+        a0 = max(lo - Ca, 0)                                   # TSCB frames [a0, e1): cached context + fresh
+        nxt_lo = lo + W
+        h_dec = self.h_dec
+        return dict(k=k, e0=e0, e1=e1, lo=lo, a0=a0, n_new=n_new, n_keep=n_keep, last=bool(last), par=k & 1,
+                    h_enc=min(H, e0),                          # history the encoder can see (0 at the start of the clip)
+                    n_tail=e0 - self.spec_lo,                  # frames in S before the new ones
+                    n_ctx=e0 - a0,                             # frames in E before the fresh ones (= enc_lo == a0)
+                    keep_lo=lo - a0,                           # first kept frame inside the TSCB span
+                    h_dec=h_dec, dec_lo=lo - h_dec - self.spec_lo,             # decoder frames [lo - h_dec, lo + n_keep) in S
+                    spec_drop=max(max(nxt_lo - H, 0) - self.spec_lo, 0),       # frames S / E shed after the step
+                    enc_drop=max(max(nxt_lo - Ca, 0) - self.enc_lo, 0),
+                    h_dec_next=min(H, h_dec + n_keep), prev_len=self.prev_len)
+
+    def commit(self, p: dict):
+        if not p["last"]:
+            self.spec_lo += p["spec_drop"]
+            self.enc_lo += p["enc_drop"]
+            self.h_dec = p["h_dec_next"]
+        self.prev_len = p["h_dec"] + p["n_keep"]
+        self.k, self.e1 = p["k"] + 1, p["e1"]
+
+
 class _StreamSlot:
     """Device-resident state of one stream configuration (B, window, context, look-ahead) plus the hipGraphs of its step
     shapes.  The graphs read AND update the state buffers themselves (a replay is the whole step: no host-side cat /
@@ -174,12 +220,7 @@ class StreamState:
         self.W, self.Ca, self.La, self.graph = window, context, lookahead, graph
         self.F, self.F2 = self.eng.F, (self.eng.F + 1) // 2
         dev = self.eng.device
-        self.k = 0                       # steps done
-        self.e1 = 0                      # encoder outputs exist for frames [enc_lo, e1)
-        self.enc_lo = 0
-        self.spec_lo = 0
-        self.h_dec = 0                   # kept TSCB frames of the previous step held as decoder history
-        self._prev_len = 0               # (pipelined form) valid frames in the previous step's decoder input
+        self.cur = StreamCursor(window, context, lookahead)     # steps done, frames held, per-step offsets
         #: stages of step_pipelined that get their own stream: 2 = [encoder + TSCBs] | decoders, 3 = encoder | TSCBs | decoders
         self.pipeline_stages = 3 if os.environ.get("CMGAN_STREAM_STAGES", "2") == "3" else 2
         if graph:
@@ -190,6 +231,9 @@ class StreamState:
             self.enc = torch.empty(B, 0, self.F2, 64, device=dev)          # cached encoder outputs
             self.spec_tail = torch.empty(B, 2, 0, self.F, device=dev)       # spec frames [spec_lo, ...) still needed
             self.dec_hist = None             # kept TSCB outputs of the last HIST_FRAMES frames before k W
+
+    k = property(lambda self: self.cur.k)                       # steps done
+    e1 = property(lambda self: self.cur.e1)                     # frames fed so far
 
     def _claim_slot(self) -> _StreamSlot:
         import weakref
@@ -351,27 +395,13 @@ class StreamState:
         [B,1,>=w,F] are written on the decoder stream - call finish_pipeline() before reading them elsewhere."""
         if not self.graph:
             raise RuntimeError("the pipelined form replays captured graphs: graph=True")
-        W, Ca, H = self.W, self.Ca, HIST_FRAMES
-        k, e0 = self.k, self.e1
         spec_new = self.eng._in(spec_new, "spec_new")
-        n_new = spec_new.size(2)
-        e1 = e0 + n_new
-        want = (k + 1) * W + self.La
-        if (e1 < want and not last) or e1 > want:
-            raise ValueError(f"step {k} takes the frames up to {want} (fewer only at the end of the clip), got up to {e1}")
-        lo = k * W
-        n_keep = e1 - lo if last else min(W, e1 - lo)
-        if n_keep <= 0:
-            raise ValueError("no frame left to emit")
+        p = self.cur.plan(spec_new.size(2), last)
+        n_new, n_keep, h_dec, par, last = p["n_new"], p["n_keep"], p["h_dec"], p["par"], p["last"]
         sl, eng = self.slot, self.eng
         if sl.owner is None or sl.owner() is not self:
             raise RuntimeError("this stream's state buffers were claimed by a newer StreamState of the same configuration")
         sl.pipeline_buffers(eng)
-        h_enc, a0, nxt_lo = min(H, e0), max(lo - Ca, 0), lo + W
-        h_dec, par, last = self.h_dec, k & 1, bool(last)
-        h_dec_next = min(H, h_dec + n_keep)
-        spec_drop = max(max(nxt_lo - H, 0) - self.spec_lo, 0)
-        enc_drop = max(max(nxt_lo - Ca, 0) - self.enc_lo, 0)
         cur, ds = torch.cuda.current_stream(eng.device), sl.dec_stream
         es = sl.enc_stream if self.pipeline_stages == 3 else cur       # 2 stages: the encoder stays in front of the TSCBs on one stream
         ev = sl.ev
@@ -393,7 +423,7 @@ class StreamState:
         if es is not cur:
             es.wait_stream(cur)                                        # (spec_new was produced on the caller's stream)
         after(es, ev["mid"][par], ev["dec"][par])
-        fsig = (e0 - self.spec_lo, h_enc, n_new, lo - h_dec - self.spec_lo, h_dec + n_keep, spec_drop, last, par)
+        fsig = (p["n_tail"], p["h_enc"], n_new, p["dec_lo"], h_dec + n_keep, p["spec_drop"], last, par)
         ent = self._captured(sl, ("front",) + fsig, lambda: self._front_body(sl, spec_in, fsig), es, restore=(sl.S,))
         with torch.cuda.stream(es):
             spec_in.copy_(spec_new)
@@ -401,7 +431,7 @@ class StreamState:
         ev["front"][par] = mark(es)
         # ---- stage 2 on the caller's stream: D2 of this parity is free once step k - 2's decoders are done ----
         after(cur, ev["front"][par], ev["dec"][par])
-        msig = (e0 - a0, n_new, lo - a0, n_keep, h_dec, enc_drop, last, par, self._prev_len)
+        msig = (p["n_ctx"], n_new, p["keep_lo"], n_keep, h_dec, p["enc_drop"], last, par, p["prev_len"])
         ent = self._captured(sl, ("mid",) + msig, lambda: self._mid_body(sl, msig), cur, restore=(sl.E,))
         ent[0].replay()
         ev["mid"][par] = mark(cur)
@@ -414,12 +444,7 @@ class StreamState:
             out[0][:, :, :n_keep].copy_(r)
             out[1][:, :, :n_keep].copy_(i)
         ev["dec"][par] = mark(ds)
-        if not last:
-            self.spec_lo += spec_drop
-            self.enc_lo += enc_drop
-            self.h_dec = h_dec_next
-        self._prev_len = h_dec + n_keep
-        self.k, self.e1 = k + 1, e1
+        self.cur.commit(p)
         return n_keep
 
     def finish_pipeline(self):
@@ -437,58 +462,38 @@ class StreamState:
         [B,1,w,F] for frames [k W, k W + w), w = W - or, when `last`, all that is left of the clip (at most W + La: the
         step whose look-ahead reaches the clip's end is the last one).  out = (real, imag) [B,1,>=w,F] tensors: the
         result is written into their first w frames instead (views of them are returned)."""
-        W, Ca, H = self.W, self.Ca, HIST_FRAMES
-        k, e0 = self.k, self.e1
-        n_new = spec_new.size(2)
-        e1 = e0 + n_new
-        want = (k + 1) * W + self.La
-        if (e1 < want and not last) or e1 > want:
-            raise ValueError(f"step {k} takes the frames up to {want} (fewer only at the end of the clip), got up to {e1}")
-        lo = k * W                                             # first frame this step emits
-        n_keep = e1 - lo if last else min(W, e1 - lo)          # the clip's last step also emits what is left past its window
-        if n_keep <= 0:
-            raise ValueError("no frame left to emit")
-        h_enc = min(H, e0)                                     # history the encoder can see (0 at the start of the clip)
-        a0 = max(lo - Ca, 0)                                   # TSCB frames [a0, e1): cached context + fresh
-        nxt_lo = lo + W
+        p = self.cur.plan(spec_new.size(2), last)
+        n_new, n_keep, h_enc = p["n_new"], p["n_keep"], p["h_enc"]
         if self.graph:
             if self.slot.owner is None or self.slot.owner() is not self:
                 raise RuntimeError("this stream's state buffers were claimed by a newer StreamState of the same configuration")
-            h_dec = self.h_dec
-            h_dec_next = min(H, h_dec + n_keep)
-            spec_drop = max(nxt_lo - H, 0) - self.spec_lo
-            enc_drop = max(nxt_lo - Ca, 0) - self.enc_lo
-            sig = (e0 - self.spec_lo, h_enc, n_new, e0 - a0, lo - a0, n_keep, h_dec, lo - h_dec - self.spec_lo,
-                   max(spec_drop, 0), max(enc_drop, 0), h_dec_next, bool(last))
-            assert self.enc_lo == a0 or e0 == 0, (self.enc_lo, a0)
+            sig = (p["n_tail"], h_enc, n_new, p["n_ctx"], p["keep_lo"], n_keep, p["h_dec"], p["dec_lo"], p["spec_drop"],
+                   p["enc_drop"], p["h_dec_next"], p["last"])
             real, imag = self._step_graphed(self.eng._in(spec_new, "spec_new"), sig)
-            if not last:
-                self.spec_lo += max(spec_drop, 0)
-                self.enc_lo += max(enc_drop, 0)
-                self.h_dec = h_dec_next
-            self.k, self.e1 = k + 1, e1
+            self.cur.commit(p)
             if out is not None:
                 out[0][:, :, :n_keep].copy_(real)
                 out[1][:, :, :n_keep].copy_(imag)
                 return out[0][:, :, :n_keep], out[1][:, :, :n_keep]
             return real.clone(), imag.clone()                  # (not views of a graph's static outputs)
+        # eager form: the same bookkeeping on tensors that are cut and concatenated on the host
+        c = self.cur
         self.spec_tail = torch.cat([self.spec_tail, spec_new], dim=2)
-        spec_enc = self.spec_tail[:, :, e0 - h_enc - self.spec_lo:e1 - self.spec_lo].contiguous()
-        enc_ctx = self.enc[:, a0 - self.enc_lo:e0 - self.enc_lo].contiguous()
-        h_dec = 0 if self.dec_hist is None else self.dec_hist.size(1)
-        spec_dec = self.spec_tail[:, :, lo - h_dec - self.spec_lo:lo + n_keep - self.spec_lo].contiguous()
-        x_new, kept, real, imag = self._run(spec_enc, enc_ctx, self.dec_hist, spec_dec, n_new, lo - a0, n_keep)
+        spec_enc = self.spec_tail[:, :, p["n_tail"] - h_enc:p["n_tail"] + n_new].contiguous()
+        enc_ctx = self.enc[:, :p["n_ctx"]].contiguous()
+        h_dec = p["h_dec"]
+        spec_dec = self.spec_tail[:, :, p["dec_lo"]:p["dec_lo"] + h_dec + n_keep].contiguous()
+        x_new, kept, real, imag = self._run(spec_enc, enc_ctx, self.dec_hist, spec_dec, n_new, p["keep_lo"], n_keep)
         # carry: encoder outputs from the next step's context start on, the last H kept TSCB frames, the spec frames both need
         self.enc = torch.cat([self.enc, x_new], dim=1)
-        drop = max(nxt_lo - Ca, 0) - self.enc_lo
-        if drop > 0:
-            self.enc, self.enc_lo = self.enc[:, drop:].contiguous(), self.enc_lo + drop
+        if not p["last"]:
+            if p["enc_drop"] > 0:
+                self.enc = self.enc[:, p["enc_drop"]:].contiguous()
+            if p["spec_drop"] > 0:
+                self.spec_tail = self.spec_tail[:, :, p["spec_drop"]:].contiguous()
         hist = kept if self.dec_hist is None else torch.cat([self.dec_hist, kept], dim=1)
-        self.dec_hist = hist[:, -min(H, hist.size(1)):].clone()           # the frames just before nxt_lo
-        sdrop = max(nxt_lo - H, 0) - self.spec_lo                          # both histories start at nxt_lo - H or later
-        if sdrop > 0:
-            self.spec_tail, self.spec_lo = self.spec_tail[:, :, sdrop:].contiguous(), self.spec_lo + sdrop
-        self.k, self.e1 = k + 1, e1
+        self.dec_hist = hist[:, -p["h_dec_next"]:].clone()                 # the frames just before the next window
+        c.commit(p)
         if out is not None:
             out[0][:, :, :n_keep].copy_(real)
             out[1][:, :, :n_keep].copy_(imag)
