@@ -594,6 +594,10 @@ static void colsum_batch(LaunchCtx ctx, const char* label, const ColsumJobs& job
 void ffn_x3_pack(LaunchCtx, const FfnTrainParams& p, float* img);
 void ffn_x3_forward(LaunchCtx, const float* x, long M, const FfnTrainParams& p, const float* img, const unsigned char* m1,
                     const unsigned char* m2, float ms, const float* res, float* y);
+int ffn_x3_backward_fused(LaunchCtx, const float* x, const float* dy, long M, const FfnTrainParams& p, const float* img,
+                          const unsigned char* m1, const unsigned char* m2, float ms, const float* dres, float* dx,
+                          float* o_dh, float* o_g1, float* o_dxn, float* dhmax, float* o_dzc, float* o_dhc, float* part_w2,
+                          float* part_w1);
 void ffn_x3_backward(LaunchCtx, const float* x, const float* dy, long M, const FfnTrainParams& p, const float* img,
                      const unsigned char* m1, const unsigned char* m2, float ms, const float* dres, float* dx, float* o_dz,
                      float* o_d1, float* o_dh, float* o_xn, float* o_g1, float* o_dxn, float* dhmax, float* o_dzc, float* o_dhc);
@@ -668,25 +672,35 @@ void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, l
     // per-tile partial sums for the four column sums: [tiles][64] dgamma | dz (db2) in the g1 region, [tiles][64] dbeta |
     // [tiles][256] dh (db1) in the dxn region (the full [M,64] g1 / dxn tensors of round 2 are no longer written)
     const long xrows = (M + 31) / 32;
-    float *dzc = o.g1 + xrows * 64, *dhc = o.dxn + xrows * 64;   // dzc: [2 tiles][64]
-    ffn_x3_backward(ctx, x, dy, M, p, ws, m1, m2, ms, dres, dx, o.dz, o.d1, o.dh, o.xn, o.g1, o.dxn,
-                    cpart,                                        // per-tile |dh| maxima: the column-sum slabs are free until colsum_batch
-                    dzc, dhc);
+    float *dzc = o.g1 + xrows * 64, *dhc = o.dxn + xrows * 64;   // dzc: [2 tiles][64] (fused form: [tiles][64])
+    // default: part A with both weight gradients contracted on the chip (train_x3.hip); CMGAN_FFN_BWD_FUSED=0: A/B
+    static const bool k_fused = env_knob("CMGAN_FFN_BWD_FUSED", 1, 0, 1) != 0;
+    const int fused_slabs = !k_fused ? 0
+        : ffn_x3_backward_fused(ctx, x, dy, M, p, ws, m1, m2, ms, dres, dx, o.dh, o.g1, o.dxn, cpart, dzc, dhc, part,
+                                part + (size_t)WG_SPLIT * 16384);
+    if (!fused_slabs)
+        ffn_x3_backward(ctx, x, dy, M, p, ws, m1, m2, ms, dres, dx, o.dz, o.d1, o.dh, o.xn, o.g1, o.dxn,
+                        cpart,                                    // per-tile |dh| maxima: the column-sum slabs are free until colsum_batch
+                        dzc, dhc);
 #else
+    const int fused_slabs = 0;
     const unsigned grid = (unsigned)((M + 63) / 64);
     LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_kernel<<<grid, 256, 0, s>>>(x, dy, M, w, m1, m2, ms, dres, dx, o)));
 #endif
     // dW2 [64,256] = dz^T d1 ; dW1 [256,64] = dh^T xn
-    wgrad_partial64(ctx, "ffn_train_wgrad", o.dz, o.d1, M, 64, 256, part, wg_split(4));
-    wgrad_partial64(ctx, "ffn_train_wgrad", o.dh, o.xn, M, 256, 64, part + (size_t)WG_SPLIT * 16384, wg_split(4));
-    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part, wg_split(4), 16384, grad.w2)));
-    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part + (size_t)WG_SPLIT * 16384, wg_split(4), 16384,
+    if (!fused_slabs) {
+        wgrad_partial64(ctx, "ffn_train_wgrad", o.dz, o.d1, M, 64, 256, part, wg_split(4));
+        wgrad_partial64(ctx, "ffn_train_wgrad", o.dh, o.xn, M, 256, 64, part + (size_t)WG_SPLIT * 16384, wg_split(4));
+    }
+    const int nslab = fused_slabs ? fused_slabs : wg_split(4);
+    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part, nslab, 16384, grad.w2)));
+    LAUNCH(ctx, "ffn_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(part + (size_t)WG_SPLIT * 16384, nslab, 16384,
                                                                                  grad.w1)));
     // o.g1 / o.dxn hold per-tile partial sums (ln_tile_colsums): one row per 32-token tile (x3) / 16-token tile (fp32)
     const long trows = TRAIN_X3 ? (M + 31) / 32 : (M + 15) / 16;
 #if TRAIN_X3
     const ColsumJobs jobs{{dhc, dzc, o.g1, o.dxn}, {grad.b1, grad.b2, grad.gamma, grad.beta}, {256, 64, 64, 64},
-                          {trows, 2 * trows, trows, trows}};      // dz sums are per 16-token block
+                          {trows, fused_slabs ? trows : 2 * trows, trows, trows}};      // dz sums: per 16-token block (per tile: fused)
 #else
     const ColsumJobs jobs{{o.dh, o.dz, o.g1, o.dxn}, {grad.b1, grad.b2, grad.gamma, grad.beta}, {256, 64, 64, 64},
                           {0, 0, trows, trows}};

@@ -14,6 +14,9 @@
 // stores), B holds W1^T (dxn, LayerNorm backward); dh [M,256] is written by A anyway (the W1 gradient contracts it).
 #include "kernels.h"
 #include "train.h"
+#include <map>
+#include <type_traits>
+#include <mutex>
 
 #define TX_WAVES 12
 
@@ -407,6 +410,324 @@ __global__ __launch_bounds__(512) void ffn_train_bwd_b_x3_kernel(const float* __
 }
 
 // ---------------------------------------------------------------------------------
+// backward, part A WITH both weight gradients contracted on the chip (the default; CMGAN_FFN_BWD_FUSED=0 selects part A
+// above + two wgrad_partial64_x3_kernel launches).  Part A wrote dz, xn [M,64] and d1, dh [M,256] so that the token
+// contraction could read them back: 2.5 KB written and 4 KB re-read per token, and the three kernels ran at the HBM
+// roof (9 KB per token and FeedForward: 2.1 ms at 32 clips).  Here only dh leaves the chip (part B needs it: W1^T does
+// not fit next to anything).
+//   * A block is 8 waves; WAVE w OWNS HIDDEN UNITS 32 w .. 32 w + 31 (two 16-blocks) for the whole launch: its rows of W1
+//     and columns of W2 live in registers as split B operands (64 VGPRs, no weight image in LDS), and so do its
+//     [32 x 64] blocks of dW1 and dW2 (64 VGPRs), accumulated over all tiles of the block and written once as slab
+//     blockIdx.x of the usual [split][R][C] partial layout (reduce_partials_kernel, fixed order).
+//   * The products are evaluated token-major: h^T = xn W1^T and dd1^T = dz W2 with the tile's xn / dz rows as A operands,
+//     so a lane ends with hidden unit c x tokens 4 g + r of both token blocks - which IS the A operand (rows = hidden
+//     units, contraction slots = the tile's 32 tokens, split8 order) of dW2 += d1^T dz and dW1 += dh^T xn.  Nothing is
+//     transposed in registers or exchanged between waves.
+//   * A tile (32 tokens) is staged ONCE by the block - four tokens per wave, 16 lanes x 4 channels each: LayerNorm,
+//     dz = 0.5 m2 dy, split - into four row-major planes (A operands), four transposed planes (B operands of the weight
+//     gradients; token slots in split8 order) and the m1 keep-mask as 16 bits per (token, 16 hidden units),
+//     double-buffered: one barrier per tile, the next tile's rows are in flight under the 96 MFMAs of the current one.
+//   * dz is a gradient: the staged images carry it multiplied by an exact power of two s kept in a band around the
+//     running magnitude (the rule of wgrad_partial64_x3_kernel; the 8 per-wave maxima of a tile go through LDS, every
+//     wave takes the same decision).  dd1 and dh are then AT SCALE s in registers: well inside fp16 range for the dW1
+//     product; dh is stored multiplied by 1 / s, the accumulators are rescaled by the exact ratio when s moves.
+// ---------------------------------------------------------------------------------
+#define FA_PR 72                      // halfs per row of the [token][channel] planes (144 B: conflict-free b128 reads)
+#define FA_PT 36                      // halfs per row of the [channel][token slot] planes (72 B: b64 reads, 2-way stores)
+struct FaImg {
+    _Float16 xnh[32 * FA_PR], xnl[32 * FA_PR], dzh[32 * FA_PR], dzl[32 * FA_PR];
+    _Float16 xth[64 * FA_PT], xtl[64 * FA_PT], zth[64 * FA_PT], ztl[64 * FA_PT];
+    unsigned short mbits[32 * 16];    // [token][hidden 16-block]: bit u = keep hidden unit 16 blk + u
+};
+__device__ __forceinline__ unsigned fa_pack4(unsigned w) {        // 4 keep bytes (non-zero = keep) -> 4 bits
+    w |= w >> 4; w |= w >> 2; w |= w >> 1;
+    w &= 0x01010101u;
+    return (w * 0x10204080u) >> 28;                               // byte k -> bit k
+}
+__device__ __forceinline__ f16x8 fa_ld8(const _Float16* p) {      // 8 halfs at an 8-byte aligned LDS address
+    const f16x4 a = *reinterpret_cast<const f16x4*>(p), b = *reinterpret_cast<const f16x4*>(p + 4);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <bool DROP>                   // both dropout keep-masks present (training) or both absent
+__global__ __launch_bounds__(512) void ffn_train_bwd_aw_x3_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  long M, FfnTrainParams p,
+                                                                  const unsigned char* __restrict__ m1,
+                                                                  const unsigned char* __restrict__ m2, float ms,
+                                                                  float* __restrict__ o_dh, float* __restrict__ o_dhmax,
+                                                                  float* __restrict__ o_dzc, float* __restrict__ part_w2,
+                                                                  float* __restrict__ part_w1, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fa_sm[];
+    FaImg* const img = reinterpret_cast<FaImg*>(fa_sm);                                   // [2]
+    float* const zmax_l = reinterpret_cast<float*>(fa_sm + 2 * sizeof(FaImg));            // [2][8]
+    unsigned* const dhmax_l = reinterpret_cast<unsigned*>(zmax_l + 16);                   // [2]
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = gridDim.x;
+    const int nloc = (ntiles - (int)blockIdx.x + G - 1) / G;       // this block's tiles: blockIdx.x + i G
+    if (threadIdx.x < 2) dhmax_l[threadIdx.x] = 0u;
+
+    // resident B operands of hidden unit 32 wv + 16 hb + c: slot (g, e) of k-step ks <-> channel / feature 32 ks + 8 g + e
+    f16x8 w1h[2][2], w1l[2][2], w2h[2][2], w2l[2][2];
+    float b1c[2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+        const int hu = 32 * wv + 16 * hb + c;
+        b1c[hb] = p.b1[hu];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* wp = p.w1 + (long)hu * 64 + 32 * ks + 8 * g;
+            split8(ldg4(wp), ldg4(wp + 4), w1h[hb][ks], w1l[hb][ks]);
+            f32x4 a, b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = p.w2[(long)(32 * ks + 8 * g + e) * 256 + hu];
+                b[e] = p.w2[(long)(32 * ks + 8 * g + 4 + e) * 256 + hu];
+            }
+            split8(a, b, w2h[hb][ks], w2l[hb][ks]);
+        }
+    }
+    // staging role: token tk = 4 wv + g of the tile, channels 4 c .. 4 c + 3 (hidden units 16 c .. 16 c + 15 of the mask)
+    const int tk = 4 * wv + g;
+    const int pos = 8 * ((tk & 15) >> 2) + 4 * (tk >> 4) + (tk & 3);          // split8 slot order of token tk
+    const f32x4 gam = ldg4(p.gamma + 4 * c), bet = ldg4(p.beta + 4 * c);
+
+    struct Raw { f32x4 x, dy; unsigned mk; u32x4 m1w; bool ok; };
+    struct Proc { f32x4 xn, dz; unsigned mb; };
+    // global accesses as buffer descriptor (whole tensor, SGPRs) + 32-bit lane offset + scalar tile offset: a uniform pointer
+    // + lane offset is hoisted out of the loop as 64-bit per-lane pointers - six of them were scratch here.  (The launcher
+    // takes this kernel only when the largest tensor, dh, spans < 4 GB.)
+    auto rsrc = [](const void* base, long bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (unsigned)bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t x_rs = rsrc(x, M * 256), dy_rs = rsrc(dy, M * 256), dh_rs = rsrc(o_dh, M * 1024);
+    const __amdgpu_buffer_rsrc_t m2_rs = rsrc(DROP ? m2 : reinterpret_cast<const unsigned char*>(x), M * 64),
+                                 m1_rs = rsrc(DROP ? m1 : reinterpret_cast<const unsigned char*>(x), M * 256);
+    auto load = [&](int i) __attribute__((always_inline)) {
+        long tile = (long)blockIdx.x + (long)i * G;
+        const bool have = i < nloc;
+        tile = have ? tile : ntiles - 1;                          // past the end: a readable dummy, contributes nothing
+        const int rem = (int)(M - tile * 32 < 32 ? M - tile * 32 : 32);
+        Raw r;
+        r.ok = have && tk < rem;
+        const unsigned trow = (unsigned)(tk < rem ? tk : rem - 1);
+        const unsigned tb_ = (unsigned)tile * 8192u;              // byte offset of the tile in x / dy (scalar)
+        r.x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, trow * 256 + 16 * c, tb_, 0));
+        r.dy = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dy_rs, trow * 256 + 16 * c, tb_, 0));
+        r.mk = 0x01010101u;
+        r.m1w = u32x4{0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
+        if (DROP) {
+            r.mk = __builtin_amdgcn_raw_buffer_load_b32(m2_rs, trow * 64 + 4 * c, (unsigned)tile * 2048u, 0);
+            r.m1w = __builtin_amdgcn_raw_buffer_load_b128(m1_rs, trow * 256 + 16 * c, tb_, 0);
+        }
+        return r;
+    };
+    // LayerNorm + dz of the staged token; posts the wave's largest |dz| in zmax_l[buf][wv]
+    auto process = [&](const Raw& r, Proc& q, int buf) __attribute__((always_inline)) {
+        const float mean = red_c_sum((r.x[0] + r.x[1]) + (r.x[2] + r.x[3])) * (1.0f / 64.0f);
+        const f32x4 d = r.x - splat4(mean);
+        const float rstd = rsqrtf(red_c_sum(fmaf(d[0], d[0], d[1] * d[1]) + fmaf(d[2], d[2], d[3] * d[3])) * (1.0f / 64.0f) + CMGAN_EPS);
+        q.xn = d * splat4(rstd) * gam + bet;
+        f32x4 k = splat4(0.5f);
+        if (DROP) k = tx_mask4(r.mk, 0.5f * ms);
+        q.dz = r.ok ? r.dy * k : splat4(0.f);
+        q.mb = fa_pack4(r.m1w[0]) | (fa_pack4(r.m1w[1]) << 4) | (fa_pack4(r.m1w[2]) << 8) | (fa_pack4(r.m1w[3]) << 12);
+        const float mx = tx_wave_max(tx_absmax4(q.dz, 0.f));
+        if (lane == 0) zmax_l[buf * 8 + wv] = mx;
+    };
+    auto uni = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };   // -> SGPR
+    float s_run = 1.f, inv_run = 1.f;
+    bool fresh = true;
+    auto decide = [&](int buf) __attribute__((always_inline)) {    // identical in every wave: same 8 values, same rule
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m = fmaxf(m, zmax_l[buf * 8 + k]);
+        const float ms_ = m * s_run;
+        if (m > 0.f && (fresh || ms_ > 8192.f || ms_ < 0.25f)) {
+            tx_pow2(m, s_run, inv_run);
+            fresh = false;
+        }
+        s_run = uni(s_run);
+        inv_run = uni(inv_run);
+    };
+    auto write_images = [&](int buf, const Proc& q, float sc) __attribute__((always_inline)) {
+        FaImg& I = img[buf];
+        f16x4 h, l;
+        split4(q.xn, h, l);
+        *reinterpret_cast<f16x4*>(&I.xnh[tk * FA_PR + 4 * c]) = h;
+        *reinterpret_cast<f16x4*>(&I.xnl[tk * FA_PR + 4 * c]) = l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            I.xth[(4 * c + e) * FA_PT + pos] = h[e];
+            I.xtl[(4 * c + e) * FA_PT + pos] = l[e];
+        }
+        split4(q.dz * splat4(sc), h, l);
+        *reinterpret_cast<f16x4*>(&I.dzh[tk * FA_PR + 4 * c]) = h;
+        *reinterpret_cast<f16x4*>(&I.dzl[tk * FA_PR + 4 * c]) = l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            I.zth[(4 * c + e) * FA_PT + pos] = h[e];
+            I.ztl[(4 * c + e) * FA_PT + pos] = l[e];
+        }
+        if (DROP) I.mbits[tk * 16 + c] = (unsigned short)q.mb;
+    };
+
+    f32x4 acc2[2][4], acc1[2][4];                                 // dW2 [hidden 4 g + r][out 16 ob + c], dW1 [hidden][in 16 cb + c]
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc2[hb][k] = splat4(0.f); acc1[hb][k] = splat4(0.f); }
+    float sA = 1.f, invA = 1.f;                                   // scale the accumulators are at
+    auto consume = [&](int i, int buf, float sc, float inv) __attribute__((always_inline)) {
+        const FaImg& I = img[buf];
+        const long tile = (long)blockIdx.x + (long)i * G;
+        const int rem = (int)(M - tile * 32 < 32 ? M - tile * 32 : 32);      // valid tokens of the tile (>= 1)
+        const unsigned dh_tb = (unsigned)tile * 32768u;           // byte offset of the tile in dh (scalar)
+        f32x4 h[2][2], dd[2][2];                                  // [hb][tb]   (b1 is added below: a splat is 4 VGPRs)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) { h[hb][tb] = splat4(0.f); dd[hb][tb] = splat4(0.f); }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const int o = (16 * tb + c) * FA_PR + 32 * ks + 8 * g;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(&I.xnh[o]), al = *reinterpret_cast<const f16x8*>(&I.xnl[o]);
+                const f16x8 zh = *reinterpret_cast<const f16x8*>(&I.dzh[o]), zl = *reinterpret_cast<const f16x8*>(&I.dzl[o]);
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    h[hb][tb] = mfma32h(ah, w1h[hb][ks], h[hb][tb]);
+                    dd[hb][tb] = mfma32h(zh, w2h[hb][ks], dd[hb][tb]);
+                }
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    h[hb][tb] = mfma32l(ah, w1l[hb][ks], h[hb][tb]);
+                    dd[hb][tb] = mfma32l(zh, w2l[hb][ks], dd[hb][tb]);
+                }
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    h[hb][tb] = mfma32l(al, w1h[hb][ks], h[hb][tb]);
+                    dd[hb][tb] = mfma32l(zl, w2h[hb][ks], dd[hb][tb]);
+                }
+            }
+        f16x8 d1h[2], d1l[2], dhh[2], dhl[2];
+        float dhm = 0.f;
+        unsigned mw[2][4];                                        // keep bits of token 16 tb + 4 g + r for this wave's two
+#pragma unroll                                                    // hidden 16-blocks: one dword
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                mw[tb][r] = DROP ? *reinterpret_cast<const unsigned*>(&I.mbits[(16 * tb + 4 * g + r) * 16 + 2 * wv]) : 0xffffffffu;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {                          // one hidden block at a time: h / dd die as d1 / dh are split
+            f32x4 d1v[2], dhv[2];
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float hv = h[hb][tb][r] + b1c[hb], sg = sigmoidf_fast(hv);
+                    const float mkf = DROP ? (((mw[tb][r] >> (16 * hb + c)) & 1u) ? ms : 0.f) : 1.f;
+                    d1v[tb][r] = hv * sg * mkf;
+                    dhv[tb][r] = dd[hb][tb][r] * mkf * (sg * (1.f + hv * (1.f - sg)));              // dh at scale sc
+                    const float dht = dhv[tb][r] * inv;
+                    dhm = fmaxf(dhm, fabsf(dht));
+                    if (16 * tb + 4 * g + r < rem)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dht), dh_rs,
+                                                              (unsigned)(((16 * tb + 4 * g + r) * 256 + 32 * wv + 16 * hb + c) * 4),
+                                                              dh_tb, 0);
+                }
+            split8(d1v[0], d1v[1], d1h[hb], d1l[hb]);
+            split8(dhv[0], dhv[1], dhh[hb], dhl[hb]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dhm = tx_wave_max(dhm);
+        if (lane == 0) atomicMax(&dhmax_l[i & 1], __float_as_uint(dhm));     // non-negative floats order as integers
+        if (sc != sA) {                                           // the scale moved: exact power-of-two ratio (wave-uniform, rare)
+            const float ratio = sc * invA;
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    acc2[hb][k] = acc2[hb][k] * splat4(ratio);
+                    acc1[hb][k] = acc1[hb][k] * splat4(ratio);
+                }
+            sA = sc; invA = inv;
+        }
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            const int o = (16 * ob + c) * FA_PT + 8 * g;
+            const f16x8 zh = fa_ld8(&I.zth[o]), zl = fa_ld8(&I.ztl[o]);
+            const f16x8 xh = fa_ld8(&I.xth[o]), xl = fa_ld8(&I.xtl[o]);
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                acc2[hb][ob] = mfma32h(d1h[hb], zh, acc2[hb][ob]);
+                acc1[hb][ob] = mfma32h(dhh[hb], xh, acc1[hb][ob]);
+            }
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                acc2[hb][ob] = mfma32l(d1h[hb], zl, acc2[hb][ob]);
+                acc1[hb][ob] = mfma32l(dhh[hb], xl, acc1[hb][ob]);
+            }
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                acc2[hb][ob] = mfma32l(d1l[hb], zh, acc2[hb][ob]);
+                acc1[hb][ob] = mfma32l(dhl[hb], xh, acc1[hb][ob]);
+            }
+            if (wv == ob) {                                       // db2 partial of the tile: column sums of dz (hi + lo: 2^-22)
+                float sm = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm += (float)zh[e] + (float)zl[e];
+                sm = red_g_sum(sm) * inv;
+                if (g == 0) o_dzc[tile * 64 + 16 * ob + c] = sm;
+            }
+        }
+    };
+
+    Raw rw = load(0);
+    Proc pc;
+    process(rw, pc, 0);
+    __syncthreads();
+    decide(0);
+    float s_cur = s_run, inv_cur = inv_run;
+    write_images(0, pc, s_cur);
+    rw = load(1);
+    process(rw, pc, 1);
+    __syncthreads();
+#pragma unroll 1
+    for (int i = 0; i < nloc; ++i) {
+        const int buf = i & 1;
+        if (wv == 0 && lane == 0 && i > 0) {                      // the previous tile's |dh| maximum (part B's scale)
+            o_dhmax[(long)blockIdx.x + (long)(i - 1) * G] = __uint_as_float(dhmax_l[buf ^ 1]);
+            dhmax_l[buf ^ 1] = 0u;
+        }
+        const Raw r2 = load(i + 2);                               // in flight under the products
+        decide(buf ^ 1);                                          // tile i + 1 (past the end: all-zero maxima, nothing moves)
+        const float s_nxt = s_run, inv_nxt = inv_run;
+        write_images(buf ^ 1, pc, s_nxt);
+        consume(i, buf, s_cur, inv_cur);
+        process(r2, pc, buf);                                     // tile i + 2
+        __syncthreads();
+        s_cur = s_nxt; inv_cur = inv_nxt;
+    }
+    // (lane id recomputed: threadIdx.x kept for this one test was the kernel's only scratch dword)
+    if (wv == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
+        o_dhmax[(long)blockIdx.x + (long)(nloc - 1) * G] = __uint_as_float(dhmax_l[(nloc - 1) & 1]);
+    float* s2 = part_w2 + (long)blockIdx.x * 16384;
+    float* s1 = part_w1 + (long)blockIdx.x * 16384;
+    int ce = c, ge = g;
+    asm volatile("" : "+v"(ce), "+v"(ge));                        // (opaque: the slab offsets would otherwise be computed before
+                                                                  // the loop and live - spilled - through it)
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            stg4(s2 + (unsigned)((16 * k + ce) * 256 + 32 * wv + 16 * hb + 4 * ge), acc2[hb][k] * splat4(invA));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1[(unsigned)((32 * wv + 16 * hb + 4 * ge + r) * 64 + 16 * k + ce)] = acc1[hb][k][r] * invA;
+        }
+}
+
+// ---------------------------------------------------------------------------------
 // out_partial[s][i][j] = sum over the s-th token range of P[m][i] Q[m][j]  (P [M,R], Q [M,C] row-major fp32): the
 // token-contraction weight gradient of wgrad_partial64_kernel (train.hip) with split products.  A wave-step is 32
 // tokens: lane (c, g) feeds slot e of the contraction with token 8 g + e, i.e. eight dwords of one column of P
@@ -726,6 +1047,46 @@ void ffn_x3_backward(LaunchCtx ctx, const float* x, const float* dy, long M, con
     const int gridb = (ntiles + 7) / 8 < 512 ? ((ntiles + 7) / 8 > 0 ? (ntiles + 7) / 8 : 1) : 512;
     LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_b_x3_kernel<<<gridb, 512, 0, ctx.stream>>>(
                                      x, o_dh, dhmax, M, h + 3 * 32768, p, dres, dx, o_g1, o_dxn, o_dhc, ntiles)));
+}
+// the fused form: part A + both weight gradients (slabs [grid][16384] of dW2 then dW1 behind `part`), then part B.
+// Returns the number of slabs written per gradient, 0 if the device refuses the kernel's LDS (the caller falls back).
+int ffn_x3_backward_fused(LaunchCtx ctx, const float* x, const float* dy, long M, const FfnTrainParams& p, const float* img,
+                          const unsigned char* m1, const unsigned char* m2, float ms, const float* dres, float* dx,
+                          float* o_dh, float* o_g1, float* o_dxn, float* dhmax, float* o_dzc, float* o_dhc, float* part_w2,
+                          float* part_w1) {
+    if ((m1 == nullptr) != (m2 == nullptr)) return 0;             // one mask only: not a case the trainer produces
+    if (M * 1024 >= (1l << 32)) return 0;                         // the kernel addresses dh with 32-bit byte offsets
+    const bool drop = m1 != nullptr;
+    const void* fn = drop ? reinterpret_cast<const void*>(&ffn_train_bwd_aw_x3_kernel<true>)
+                          : reinterpret_cast<const void*>(&ffn_train_bwd_aw_x3_kernel<false>);
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, bool> optin;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    const size_t lds = 2 * sizeof(FaImg) + 18 * sizeof(float);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = optin.find({dev, fn});
+        if (it == optin.end()) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) (void)hipGetLastError();
+            it = optin.emplace(std::make_pair(dev, fn), e == hipSuccess).first;
+        }
+        if (!it->second) return 0;
+    }
+    const _Float16* h = reinterpret_cast<const _Float16*>(img);
+    const int ntiles = (int)((M + 31) / 32);
+    const int grid = ntiles < 256 ? ntiles : 256;
+    if (drop)
+        LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_aw_x3_kernel<true><<<grid, 512, lds, ctx.stream>>>(
+                                         x, dy, M, p, m1, m2, ms, o_dh, dhmax, o_dzc, part_w2, part_w1, ntiles)));
+    else
+        LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_aw_x3_kernel<false><<<grid, 512, lds, ctx.stream>>>(
+                                         x, dy, M, p, m1, m2, ms, o_dh, dhmax, o_dzc, part_w2, part_w1, ntiles)));
+    const int gridb = (ntiles + 7) / 8 < 512 ? ((ntiles + 7) / 8 > 0 ? (ntiles + 7) / 8 : 1) : 512;
+    LAUNCH(ctx, "ffn_train_bwd", (ffn_train_bwd_b_x3_kernel<<<gridb, 512, 0, ctx.stream>>>(
+                                     x, o_dh, dhmax, M, h + 3 * 32768, p, dres, dx, o_g1, o_dxn, o_dhc, ntiles)));
+    return grid;
 }
 void launch_wgrad_partial64_x3(LaunchCtx ctx, const char* label, const float* P, const float* Q, long M, int R, int C,
                                float* partial, int nsplit) {
