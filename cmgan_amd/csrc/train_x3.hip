@@ -580,7 +580,6 @@ __global__ __launch_bounds__(512) void ffn_train_bwd_aw_x3_kernel(const float* _
     auto consume = [&](int i, int buf, float sc, float inv) __attribute__((always_inline)) {
         const FaImg& I = img[buf];
         const long tile = (long)blockIdx.x + (long)i * G;
-        const int rem = (int)(M - tile * 32 < 32 ? M - tile * 32 : 32);      // valid tokens of the tile (>= 1)
         const unsigned dh_tb = (unsigned)tile * 32768u;           // byte offset of the tile in dh (scalar)
         f32x4 h[2][2], dd[2][2];                                  // [hb][tb]   (b1 is added below: a splat is 4 VGPRs)
 #pragma unroll
@@ -626,15 +625,15 @@ __global__ __launch_bounds__(512) void ffn_train_bwd_aw_x3_kernel(const float* _
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float hv = h[hb][tb][r] + b1c[hb], sg = sigmoidf_fast(hv);
-                    const float mkf = DROP ? (((mw[tb][r] >> (16 * hb + c)) & 1u) ? ms : 0.f) : 1.f;
-                    d1v[tb][r] = hv * sg * mkf;
-                    dhv[tb][r] = dd[hb][tb][r] * mkf * (sg * (1.f + hv * (1.f - sg)));              // dh at scale sc
+                    const float sgm = DROP ? (((mw[tb][r] >> (16 * hb + c)) & 1u) ? sg * ms : 0.f) : sg;   // keep-mask x sigmoid
+                    d1v[tb][r] = hv * sgm;
+                    dhv[tb][r] = dd[hb][tb][r] * (sgm * fmaf(hv, 1.f - sg, 1.f));                   // dh at scale sc
                     const float dht = dhv[tb][r] * inv;
                     dhm = fmaxf(dhm, fabsf(dht));
-                    if (16 * tb + 4 * g + r < rem)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dht), dh_rs,
-                                                              (unsigned)(((16 * tb + 4 * g + r) * 256 + 32 * wv + 16 * hb + c) * 4),
-                                                              dh_tb, 0);
+                    // (unconditional: rows past M lie beyond the descriptor's num_records - the hardware drops the store)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dht), dh_rs,
+                                                          (unsigned)(((16 * tb + 4 * g + r) * 256 + 32 * wv + 16 * hb + c) * 4),
+                                                          dh_tb, 0);
                 }
             split8(d1v[0], d1v[1], d1h[hb], d1l[hb]);
             split8(dhv[0], dhv[1], dhh[hb], dhl[hb]);
