@@ -3093,7 +3093,7 @@ __global__ __launch_bounds__(256) void db_conv_dgrad_kernel(const float* __restr
 // of once per 16 output channels), and the (clip, t, f) coordinates of a lane's four tokens come from ONE 32-bit
 // division per step plus carries - the first version spent as many VALU cycles on 64-bit divisions as the matrix pipe
 // spent on the products.
-#define DB_WG_SPLIT 128
+#define DB_WG_SPLIT 256
 __global__ __launch_bounds__(256) void db_conv_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ a, int B,
                                                             int T, int F, int dil, float* __restrict__ partial) {
     __shared__ float red[2][64 * 64];

@@ -581,6 +581,16 @@ __global__ __launch_bounds__(512) void ffn_train_bwd_aw_x3_kernel(const float* _
         const FaImg& I = img[buf];
         const long tile = (long)blockIdx.x + (long)i * G;
         const unsigned dh_tb = (unsigned)tile * 32768u;           // byte offset of the tile in dh (scalar)
+        const int rem = (int)(M - tile * 32 < 32 ? M - tile * 32 : 32);      // valid tokens of the tile (>= 1)
+        // store offsets of this lane's 8 tokens; a token past M gets an offset beyond the descriptor's num_records and the
+        // hardware drops the store (the range check sees the VGPR offset only - not the scalar tile offset: the launcher
+        // keeps dh under 2 GB)
+        unsigned dh_vo[2][4];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dh_vo[tb][r] = 16 * tb + 4 * g + r < rem ? (unsigned)(((16 * tb + 4 * g + r) * 256 + 32 * wv + c) * 4) : 0x80000000u;
         f32x4 h[2][2], dd[2][2];                                  // [hb][tb]   (b1 is added below: a splat is 4 VGPRs)
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
@@ -630,10 +640,7 @@ __global__ __launch_bounds__(512) void ffn_train_bwd_aw_x3_kernel(const float* _
                     dhv[tb][r] = dd[hb][tb][r] * (sgm * fmaf(hv, 1.f - sg, 1.f));                   // dh at scale sc
                     const float dht = dhv[tb][r] * inv;
                     dhm = fmaxf(dhm, fabsf(dht));
-                    // (unconditional: rows past M lie beyond the descriptor's num_records - the hardware drops the store)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dht), dh_rs,
-                                                          (unsigned)(((16 * tb + 4 * g + r) * 256 + 32 * wv + 16 * hb + c) * 4),
-                                                          dh_tb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dht), dh_rs, dh_vo[tb][r] + 64u * hb, dh_tb, 0);
                 }
             split8(d1v[0], d1v[1], d1h[hb], d1l[hb]);
             split8(dhv[0], dhv[1], dhh[hb], dhl[hb]);
@@ -1054,7 +1061,8 @@ int ffn_x3_backward_fused(LaunchCtx ctx, const float* x, const float* dy, long M
                           float* o_dh, float* o_g1, float* o_dxn, float* dhmax, float* o_dzc, float* o_dhc, float* part_w2,
                           float* part_w1) {
     if ((m1 == nullptr) != (m2 == nullptr)) return 0;             // one mask only: not a case the trainer produces
-    if (M * 1024 >= (1l << 32)) return 0;                         // the kernel addresses dh with 32-bit byte offsets
+    if (M * 1024 >= (1l << 31)) return 0;                         // the kernel addresses dh with 32-bit byte offsets (and marks
+                                                                  // tokens past M with offset 2^31)
     const bool drop = m1 != nullptr;
     const void* fn = drop ? reinterpret_cast<const void*>(&ffn_train_bwd_aw_x3_kernel<true>)
                           : reinterpret_cast<const void*>(&ffn_train_bwd_aw_x3_kernel<false>);

@@ -72,6 +72,28 @@ def test_feed_forward_train_ragged_token_count_and_determinism(ff):
     assert torch.equal(dx, dx2) and all(torch.equal(first[k], grads2[k]) for k in KEYS)
 
 
+def test_feed_forward_backward_of_a_ragged_tile_stays_inside_the_dh_tensor(ff):
+    """The fused backward (train_x3.hip ffn_train_bwd_aw_x3_kernel, the default) stores dh [M,256] with buffer stores whose
+    rows past M must be DROPPED by the descriptor's range check - which sees the per-lane offset only, not the scalar tile
+    offset.  dh occupies floats [65536 + 320 M, 65536 + 576 M) of the module's workspace (train.hip
+    launch_ffn_train_backward: FfnBwdBufs); the region behind it is not written by this path: a sentinel there survives."""
+    import os
+    if os.environ.get("CMGAN_FFN_BWD_FUSED", "1") == "0":
+        pytest.skip("the un-fused path writes xn behind dh")
+    M = 1000                                               # last tile: 8 valid tokens, 24 beyond M
+    rng = np.random.Generator(np.random.PCG64(11))
+    x = torch.from_numpy(rng.standard_normal((M, 64)).astype(np.float32)).to(DEV)
+    dy = torch.from_numpy(rng.standard_normal((M, 64)).astype(np.float32)).to(DEV)
+    m1, m2 = ff.masks(M, torch.Generator(device=DEV).manual_seed(4))
+    ff.forward(x, m1, m2)                                  # sizes the workspace
+    ws = ff._workspace(M).view(torch.float32)
+    behind = ws[65536 + 576 * M: 65536 + 576 * M + 32 * 256]
+    behind.fill_(-12345.0)
+    ff.backward(x, dy, m1, m2)
+    torch.cuda.synchronize()
+    assert bool((behind == -12345.0).all()), "rows past M of the last tile were stored"
+
+
 def test_feed_forward_backward_is_exactly_scale_equivariant(ff):
     """Gradients arrive with any magnitude (dL/dy of a mean loss is ~1 / numel), far below what an fp16 split can
     represent.  The split-product kernels therefore scale every gradient operand by an exact power of two (per tile /
