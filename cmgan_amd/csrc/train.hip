@@ -602,7 +602,7 @@ void ffn_x3_backward(LaunchCtx, const float* x, const float* dy, long M, const F
                      const unsigned char* m1, const unsigned char* m2, float ms, const float* dres, float* dx, float* o_dz,
                      float* o_d1, float* o_dh, float* o_xn, float* o_g1, float* o_dxn, float* dhmax, float* o_dzc, float* o_dhc);
 void launch_wgrad_partial64_x3(LaunchCtx, const char* label, const float* P, const float* Q, long M, int R, int C,
-                               float* partial, int nsplit);
+                               float* partial, int nsplit, float* colp);
 void launch_db_conv_wgrad_x3(LaunchCtx, const float* dz, const float* a, int B, int T, int F, int dil, int nsplit,
                              float* partial);
 void cm_x3_pack(LaunchCtx, const ConvModTrainParams& p, float* img_w1, float* img_w1t);
@@ -620,11 +620,15 @@ void at_x3_qkv(LaunchCtx, const float* x, long M, const float* img_w, const floa
 void at_x3_qkv_bwd(LaunchCtx, const float* x, const float* dqkv, long M, const float* img_wt, const float* ln_w,
                    const float* ln_b, const float* dres, float* dx, float* xn_out, float* g1c, float* dxc);
 // the token-contraction weight gradient in either mode: grid (R / 64, C / 64, nsplit)
+// colp / colsum_out (split-f16 build only): also the column sums of P -> colsum_out[R], through [nsplit][R] partials at colp
 static void wgrad_partial64(LaunchCtx ctx, const char* label, const float* P, const float* Q, long M, int R, int C,
-                            float* partial, int nsplit) {
+                            float* partial, int nsplit, float* colp = nullptr, float* colsum_out = nullptr,
+                            const char* reduce_label = nullptr) {
 #if TRAIN_X3
-    launch_wgrad_partial64_x3(ctx, label, P, Q, M, R, C, partial, nsplit);
+    launch_wgrad_partial64_x3(ctx, label, P, Q, M, R, C, partial, nsplit, colp);
+    if (colp) LAUNCH(ctx, reduce_label, (reduce_partials_kernel<<<4, 1024, 0, ctx.stream>>>(colp, nsplit, R, colsum_out)));
 #else
+    (void)colp; (void)colsum_out; (void)reduce_label;
     LAUNCH(ctx, label, (wgrad_partial64_kernel<<<dim3(R / 64, C / 64, nsplit), 256, 0, ctx.stream>>>(P, Q, M, R, C, partial)));
 #endif
 }
@@ -1349,12 +1353,25 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
                                                                           ws + pl.dxn)));
 #endif
     // pointwise-1 and LayerNorm gradients
+#if TRAIN_X3
+    // db_pw1 = colsum [da ; dg] comes out of the weight-gradient kernel, which holds every element of dag anyway (the column-sum
+    // pass re-read the [M,256] tensor); its [split][256] partials use the fourth job's region of cpart
+    wgrad_partial64(ctx, "convmod_train_wgrad", ws + pl.dag, ws + pl.xn, M, 256, 64, ws + pl.wpart, wg_split(4),
+                    cpart + (size_t)3 * FFN_COLSUM_BLOCKS * 256, grad.pw1_b, "convmod_train_reduce");
+#else
     wgrad_partial64(ctx, "convmod_train_wgrad", ws + pl.dag, ws + pl.xn, M, 256, 64, ws + pl.wpart, wg_split(4));
+#endif
     LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(ws + pl.wpart, wg_split(4), 16384,
                                                                                    grad.pw1_w)));
+#if TRAIN_X3
+    const ColsumJobs jobs{{ws + pl.g1, ws + pl.dxn}, {grad.ln_w, grad.ln_b}, {64, 64},
+                          {(M + 15) / 16, (M + 15) / 16}};                        // g1 / dxn: per-tile partial sums
+    colsum_batch(ctx, "convmod_train_reduce", jobs, 2, M, cpart);
+#else
     const ColsumJobs jobs{{ws + pl.dag, ws + pl.g1, ws + pl.dxn}, {grad.pw1_b, grad.ln_w, grad.ln_b}, {256, 64, 64},
                           {0, (M + 15) / 16, (M + 15) / 16}};                     // g1 / dxn: per-tile partial sums
     colsum_batch(ctx, "convmod_train_reduce", jobs, 3, M, cpart);
+#endif
 }
 
 // =====================================================================================
@@ -2575,7 +2592,14 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
     LAUNCH(ctx, "attn_train_bwd", (at_dO_split_kernel<<<2048, 256, 0, s>>>(ws + pl.dO, ws + pl.dOp, cpart, M * 16)));
 #endif
     // to_out gradients: dWo [64,64] = dout^T O, dbo = colsum dout
+#if TRAIN_X3
+    // (cpart holds the per-block |dO| maxima in its first rows until at_amax_kernel / at_dO_split_kernel above have run; the
+    // column-sum partials of dout go to the fourth job's region, which colsum_batch below - three jobs at most - never uses)
+    wgrad_partial64(ctx, "attn_train_wgrad", ws + pl.dout, b.o, M, 64, 64, ws + pl.wpart, wg_split(1),
+                    cpart + (size_t)3 * FFN_COLSUM_BLOCKS * 256, grad.bo, "attn_train_reduce");
+#else
     wgrad_partial64(ctx, "attn_train_wgrad", ws + pl.dout, b.o, M, 64, 64, ws + pl.wpart, wg_split(1));
+#endif
     LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<64, 1024, 0, s>>>(ws + pl.wpart, wg_split(1), 4096,
                                                                                 grad.wo)));
     // attention core: dq (query blocks), dk / dv (key blocks), dE (tile diagonals)
@@ -2627,9 +2651,15 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
                                                                                 ws + pl.raw)));      // [192,64], then split
     hipMemcpyAsync(grad.wq, ws + pl.raw, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);
     hipMemcpyAsync(grad.wkv, ws + pl.raw + 4096, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);
+#if TRAIN_X3
+    const ColsumJobs jobs{{ws + pl.g1, ws + pl.dxn}, {grad.ln_w, grad.ln_b}, {64, 64},
+                          {(M + 15) / 16, (M + 15) / 16}};                        // g1 / dxn: per-tile partial sums (dbo: above)
+    colsum_batch(ctx, "attn_train_reduce", jobs, 2, M, cpart);
+#else
     const ColsumJobs jobs{{ws + pl.dout, ws + pl.g1, ws + pl.dxn}, {grad.bo, grad.ln_w, grad.ln_b}, {64, 64, 64},
                           {0, (M + 15) / 16, (M + 15) / 16}};                     // g1 / dxn: per-tile partial sums
     colsum_batch(ctx, "attn_train_reduce", jobs, 3, M, cpart);
+#endif
 }
 
 // ---------------------------------------------------------------------------------

@@ -740,9 +740,14 @@ __global__ __launch_bounds__(512) void ffn_train_bwd_aw_x3_kernel(const float* _
 // (resp. Q) per 16-wide block, split to fp16 hi / lo in registers; 16 output tiles x 3 products = 48 MFMAs per step
 // instead of 128 fp32 ones.  Same 64 x 64 tile per block, same fixed-order LDS combine, same slab layout.
 // ---------------------------------------------------------------------------------
+// colp (optional): the column sums of P - a bias gradient - as [split][R] partials for free: the blocks with jc = 0 hold
+// every P element of their range in registers anyway (the separate column-sum pass re-read P: 1 GB for the conv module's
+// [M,256] gate gradient).
 __global__ __launch_bounds__(256) void wgrad_partial64_x3_kernel(const float* __restrict__ P, const float* __restrict__ Q,
-                                                                 long M, int R, int C, float* __restrict__ partial) {
+                                                                 long M, int R, int C, float* __restrict__ partial,
+                                                                 float* __restrict__ colp) {
     __shared__ float red[2][64 * 64];
+    __shared__ float cs_l[4][64];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ic = blockIdx.x, jc = blockIdx.y, s = blockIdx.z;
     const int nsplit = gridDim.z;
@@ -791,8 +796,17 @@ __global__ __launch_bounds__(256) void wgrad_partial64_x3_kernel(const float* __
     // accumulators rescaled by the exact ratio; wave-uniform and rare); the final sums are multiplied by 1 / sP.
     float sP = 1.f, iP = 1.f;
     bool fresh = true;
+    const bool want_cs = colp != nullptr && jc == 0;              // block-uniform
+    f32x4 csum = splat4(0.f);                                     // [ib]: this lane's tokens of column 64 ic + 16 ib + c
     auto rescale = [&](Raw& t) {
         float m = 0.f;
+        if (want_cs) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 v = t.a[k][0] + t.a[k][1];
+                csum[k] += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) m = tx_absmax4(t.a[k][1], tx_absmax4(t.a[k][0], m));
         m = tx_wave_max(m);
@@ -868,6 +882,13 @@ __global__ __launch_bounds__(256) void wgrad_partial64_x3_kernel(const float* __
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[ib][jb][r] += src[(16 * ib + 4 * g + r) * 64 + 16 * jb + c];
     };
+    if (want_cs) {                                                // lane groups, then waves 0..3 in order: a fixed order
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            const float v = red_g_sum(csum[ib]);
+            if (g == 0) cs_l[wv][16 * ib + c] = v;
+        }
+    }
     if (wv >= 2) put(red[wv - 2]);
     __syncthreads();
     if (wv < 2) add(red[wv]);
@@ -883,6 +904,7 @@ __global__ __launch_bounds__(256) void wgrad_partial64_x3_kernel(const float* __
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     partial[((long)s * R + 64 * ic + 16 * ib + 4 * g + r) * C + 64 * jc + 16 * jb + c] = acc[ib][jb][r];
+        if (want_cs) colp[(long)s * R + 64 * ic + lane] = (cs_l[0][lane] + cs_l[1][lane]) + (cs_l[2][lane] + cs_l[3][lane]);
     }
 }
 
@@ -1096,8 +1118,9 @@ int ffn_x3_backward_fused(LaunchCtx ctx, const float* x, const float* dy, long M
     return grid;
 }
 void launch_wgrad_partial64_x3(LaunchCtx ctx, const char* label, const float* P, const float* Q, long M, int R, int C,
-                               float* partial, int nsplit) {
-    LAUNCH(ctx, label, (wgrad_partial64_x3_kernel<<<dim3(R / 64, C / 64, nsplit), 256, 0, ctx.stream>>>(P, Q, M, R, C, partial)));
+                               float* partial, int nsplit, float* colp) {
+    LAUNCH(ctx, label, (wgrad_partial64_x3_kernel<<<dim3(R / 64, C / 64, nsplit), 256, 0, ctx.stream>>>(P, Q, M, R, C, partial,
+                                                                                                        colp)));
 }
 
 // ---------------------------------------------------------------------------------
