@@ -3033,19 +3033,32 @@ __global__ __launch_bounds__(256) void db_norm_prelu_kernel(const float* __restr
 }
 
 // backward means per (b, c) and the per-channel parameter gradients (summed over clips in clip order): one block per
-// channel, the chunk partials of each clip added by the fp64 tree
+// channel; the DB_NCH = 256 chunk partials of a clip are added in fp64 by a butterfly inside each wave and the four waves
+// in wave order - one barrier per clip (the shared fixed-shape tree of db_tree_sum took 27 barriers per clip: 99 us per
+// launch at 32 clips, fifteen launches per step)
 __global__ __launch_bounds__(256) void db_bwd_finalize_kernel(const float* __restrict__ partial, int B, double count,
                                                               float* __restrict__ m1, float* __restrict__ m2,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ dalpha) {
-    __shared__ double red[256];
-    const int c = blockIdx.x, k = threadIdx.x;
+    static_assert(DB_NCH == 256, "one chunk per thread");
+    __shared__ double red[2][3][4];
+    const int c = blockIdx.x, k = threadIdx.x, lane = k & 63, wv = k >> 6;
     double g = 0.0, bsum = 0.0, a = 0.0;
     for (int b = 0; b < B; ++b) {
         const long o = (((long)b * DB_NCH + k) * 64 + c) * 3;
-        const double s0 = db_tree_sum(k < DB_NCH ? (double)partial[o] : 0.0, red);
-        const double s1 = db_tree_sum(k < DB_NCH ? (double)partial[o + 1] : 0.0, red);
-        const double s2 = db_tree_sum(k < DB_NCH ? (double)partial[o + 2] : 0.0, red);
+        double v0 = (double)partial[o], v1 = (double)partial[o + 1], v2 = (double)partial[o + 2];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            v0 += __shfl_xor(v0, d);
+            v1 += __shfl_xor(v1, d);
+            v2 += __shfl_xor(v2, d);
+        }
+        double (*r)[4] = red[b & 1];                              // (alternating buffers: the next clip's writes need no barrier)
+        if (lane == 0) { r[0][wv] = v0; r[1][wv] = v1; r[2][wv] = v2; }
+        __syncthreads();
+        const double s0 = (r[0][0] + r[0][1]) + (r[0][2] + r[0][3]);
+        const double s1 = (r[1][0] + r[1][1]) + (r[1][2] + r[1][3]);
+        const double s2 = (r[2][0] + r[2][1]) + (r[2][2] + r[2][3]);
         if (k == 0) {
             m1[b * 64 + c] = (float)(s0 / count);
             m2[b * 64 + c] = (float)(s1 / count);
