@@ -531,6 +531,10 @@ int cmgan_profile_read(cmgan_handle* h, cmgan_kernel_time* out, int cap);
  *   CMGAN_STFT_BSPLIT=1..13    bin blocks per thread block of the small-batch STFT
  *   CMGAN_ASP_TPB_LONG=1..64, CMGAN_ASP_GROUP_LONG=1..4096, CMGAN_ASP_GROUP_SHORT=1..4096, CMGAN_ASP_ALIGN_SHORT=0|1,
  *   CMGAN_ASP_SLOTS=8..65536, CMGAN_ASP_TAILK=0|1    tile order / block shape of the attention kernel
+ *   CMGAN_STFT_FFT=0|1         front / back end as 16 x 25 real FFTs (1, default) or the folded DFT products (0)
+ *   CMGAN_FFN_BWD_FUSED=0|1    training: FeedForward backward with both weight gradients contracted on the chip (1, default)
+ *                              or part A + two token-contraction launches (0)
+ *   CMGAN_ATTN_BWD=cores       training: the three attention backward cores instead of the fused kernel (read per launch)
  * (The Python host adds CMGAN_BRANCHES=1|2 and CMGAN_BRANCH_OFFSET=n for Engine.enhance_graphed; CMGAN_HIP_LIB selects
  * the library file.)                                                                                                  */
 
