@@ -3733,8 +3733,57 @@ static void in_prelu_backward(LaunchCtx ctx, const float* z, float* g, int B, in
     LAUNCH(ctx, "in_prelu_train", (db_in_bwd_kernel<<<2048, 256, 0, st>>>(g, z, (long)B * P * 64, P, mean, rstd, gamma, m1, m2)));
 }
 
+#if TRAIN_X3
+// The forward 1 x 3 convolutions of the training step (the encoder's stride-2 conv, the decoders' sub-pixel conv) ARE the
+// inference kernels (conv3x_kernel<1, 64> mode 1 / <1, 128> mode 2, conv_x3.hip), as the dense blocks' convs are: same
+// planes, same zero padding, raw output; only the operand image is rebuilt from the raw weight [Co, 64, 1, 3] every step.
+// Image: [2 chunks of 32 input channels][tap 3][Co / 16 cb][hi | lo][64][8 halfs], lane (c, g) slot e <->
+// w[co = 16 cb + c][ci = 32 chunk + 16 (e >> 2) + 4 g + (e & 3)][tap]   (api.hip: x3_conv_image(src, 4, 3, Co / 16))
+__global__ void rc_pack_x3_kernel(const float* __restrict__ w, int Co, _Float16* __restrict__ img) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, CB = Co / 16;
+    if (t >= 2 * 3 * CB * 64) return;
+    const int lane = t & 63, cb = (t >> 6) % CB, rest = (t >> 6) / CB, tap = rest % 3, chunk = rest / 3;
+    const int co = 16 * cb + (lane & 15);
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int ci = 32 * chunk + 16 * (e >> 2) + 4 * (lane >> 4) + (e & 3);
+        const float v = w[((long)co * 64 + ci) * 3 + tap];
+        const _Float16 h = (_Float16)v;
+        hi[e] = h;
+        lo[e] = (_Float16)(v - (float)h);
+    }
+    _Float16* o = img + ((long)(chunk * 3 + tap) * CB + cb) * 1024 + lane * 8;
+    *reinterpret_cast<f16x8*>(o) = hi;
+    *reinterpret_cast<f16x8*>(o + 512) = lo;
+}
+// the plane must be long enough for the kernel's tiles (db_x3_forward) and the geometry one of the two the modes express
+static bool rc_x3_forward(const RcGeom& gm, int NG) {
+    static const bool k_on = env_knob("CMGAN_RC_FWD_X3", 1, 0, 1) != 0;
+    return k_on && gm.KW == 3 && gm.PL == 1 && gm.Fi + 1 >= 64 &&
+           ((NG == 2 && gm.SF == 1 && gm.Fo == gm.Fi) || (NG == 1 && gm.SF == 2 && gm.Fo == (gm.Fi - 1) / 2 + 1));
+}
+#endif
+// img: the fp32 fragment image of rc_pack_kernel; the split-f16 path rebuilds it in place (same size) from the raw weight
 template <int NG>
-static void rc_forward(LaunchCtx ctx, const float* in, const float* img, const float* bias, const RcGeom& gm, float* z) {
+static void rc_forward(LaunchCtx ctx, const float* in, float* img, const float* wraw, const float* bias, const RcGeom& gm,
+                       float* z) {
+#if TRAIN_X3
+    if (rc_x3_forward(gm, NG)) {
+        const int nthr = 2 * 3 * 4 * NG * 64;
+        LAUNCH(ctx, "rowconv_train", (rc_pack_x3_kernel<<<(nthr + 255) / 256, 256, 0, ctx.stream>>>(
+                                         wraw, 64 * NG, reinterpret_cast<_Float16*>(img))));
+        ConvArgs ca{};
+        ca.in[0] = in;
+        ca.nslots = 1;
+        ca.bias = bias;
+        ca.out = z;
+        ca.T = gm.T; ca.F = gm.Fi; ca.dil = 1; ca.mode = NG == 2 ? 2 : 1; ca.ntiles = conv3x_ntiles(gm.T, gm.Fi, 64 * NG);
+        launch_conv3_x3(ctx, ca, img, gm.B, 1, 64 * NG);
+        return;
+    }
+#endif
+    (void)wraw;
     const long Mo = (long)gm.B * gm.T * gm.Fo;
     LAUNCH(ctx, "rowconv_train", (rc_fwd_kernel<NG><<<(unsigned)((Mo + 63) / 64), 256, 0, ctx.stream>>>(in, img, bias, gm, z)));
 }
@@ -3785,7 +3834,7 @@ void launch_encoder_train_forward(LaunchCtx ctx, const float* xin, int B, int T,
     float* stt = ws + pl.st;
     in_prelu_forward(ctx, ws + pl.z1, B, T * F, p.n1_w, p.n1_b, p.p1_w, stt, stt + B * 64, ws + pl.part, ws + pl.a1);
     launch_dense_train_forward(ctx, ws + pl.a1, B, T, F, p.dense, ws + pl.d, ws + pl.dense);
-    rc_forward<1>(ctx, ws + pl.d, ws + pl.img2, p.c2_b, g2, ws + pl.z2);
+    rc_forward<1>(ctx, ws + pl.d, ws + pl.img2, p.c2_w, p.c2_b, g2, ws + pl.z2);
     in_prelu_forward(ctx, ws + pl.z2, B, T * F2, p.n2_w, p.n2_b, p.p2_w, stt + 2 * B * 64, stt + 3 * B * 64, ws + pl.part, y);
 }
 
@@ -4078,7 +4127,7 @@ void launch_decoder_train_forward(LaunchCtx ctx, int kind, const float* x, int B
     const RcGeom gs{B, T, Fe, Fe, 3, 1, 1};
     LAUNCH(ctx, "decoder_train", (rc_pack_kernel<<<dim3(32, 3), 256, 0, st>>>(p.sp_w, 128, 3, ws + pl.img, ws + pl.imgT)));
     launch_dense_train_forward(ctx, x, B, T, Fe, p.dense, ws + pl.d, ws + pl.dense);
-    rc_forward<2>(ctx, ws + pl.d, ws + pl.img, p.sp_b, gs, ws + pl.s);
+    rc_forward<2>(ctx, ws + pl.d, ws + pl.img, p.sp_w, p.sp_b, gs, ws + pl.s);
     float* stt = ws + pl.st;
     if (kind == 0) {
         tail_forward<1>(ctx, ws + pl.s, R, W, p.c_w, p.c_b, ws + pl.t1);
