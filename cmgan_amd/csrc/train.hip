@@ -3517,6 +3517,8 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
 // that is twice as wide (SPConvTranspose2d, generator.py:102-119) - the shuffle is an index map, never a copy.
 // =====================================================================================
 struct RcGeom { int B, T, Fi, Fo, KW, SF, PL; };      // Fo = output positions per row (before the pixel shuffle)
+#define RC_WG_SPLIT 256               // position ranges of the split-f16 weight gradient (sizes the slab buffers; >= FFN_WGRAD_SPLIT)
+void launch_rc_wgrad_x3(LaunchCtx, int ng, const float* dz, const float* in, const int* gm7, int nsplit, float* partial);
 
 template <int NG>
 __global__ __launch_bounds__(256) void rc_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wimg,
@@ -3792,11 +3794,24 @@ static void rc_backward(LaunchCtx ctx, const float* dz, const float* in, const f
                         float* dW, float* wpart) {
     hipStream_t st = ctx.stream;
     const long Mi = (long)gm.B * gm.T * gm.Fi;
-    LAUNCH(ctx, "rowconv_train", (rc_wgrad_kernel<NG><<<dim3(4 * NG, gm.KW, FFN_WGRAD_SPLIT), 256, 0, st>>>(
-                                     dz, in, gm, FFN_WGRAD_SPLIT, wpart)));
     const int nw = gm.KW * 64 * NG * 64;
-    LAUNCH(ctx, "rowconv_train", (rc_wgrad_scatter_kernel<<<(nw + 255) / 256, 256, 0, st>>>(wpart, FFN_WGRAD_SPLIT, 64 * NG,
-                                                                                            gm.KW, dW)));
+    const long rows = (long)gm.B * gm.T * (gm.Fi > NG * gm.Fo ? gm.Fi : NG * gm.Fo);
+#if TRAIN_X3
+    static const bool k_wx3 = env_knob("CMGAN_RC_WGRAD_X3", 1, 0, 1) != 0;
+    if (k_wx3 && rows * 256 < (1l << 32)) {           // split products (train_x3.hip), RC_WG_SPLIT position ranges
+        const int gm7[7] = {gm.B, gm.T, gm.Fi, gm.Fo, gm.KW, gm.SF, gm.PL};
+        launch_rc_wgrad_x3(ctx, NG, dz, in, gm7, RC_WG_SPLIT, wpart);
+        LAUNCH(ctx, "rowconv_train", (rc_wgrad_scatter_kernel<<<(nw + 255) / 256, 256, 0, st>>>(wpart, RC_WG_SPLIT, 64 * NG,
+                                                                                                gm.KW, dW)));
+    } else
+#endif
+    {
+        (void)rows;
+        LAUNCH(ctx, "rowconv_train", (rc_wgrad_kernel<NG><<<dim3(4 * NG, gm.KW, FFN_WGRAD_SPLIT), 256, 0, st>>>(
+                                         dz, in, gm, FFN_WGRAD_SPLIT, wpart)));
+        LAUNCH(ctx, "rowconv_train", (rc_wgrad_scatter_kernel<<<(nw + 255) / 256, 256, 0, st>>>(wpart, FFN_WGRAD_SPLIT, 64 * NG,
+                                                                                                gm.KW, dW)));
+    }
     if (din)
         LAUNCH(ctx, "rowconv_train", (rc_dgrad_kernel<NG><<<(unsigned)((Mi + 63) / 64), 256, 0, st>>>(dz, imgT, gm, din)));
 }
@@ -3814,7 +3829,7 @@ static EncPlan enc_plan(int B, int T, int F) {
     p.st = take((size_t)4 * B * 64);            // mean1, rstd1, mean2, rstd2
     p.part = take((size_t)B * DB_NCH * 64 * 3);
     p.m = take((size_t)2 * B * 64);
-    p.wpart = take((size_t)3 * FFN_WGRAD_SPLIT * 4096);
+    p.wpart = take((size_t)3 * RC_WG_SPLIT * 4096);
     p.cpart = take((size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256);
     p.dense = take(dense_train_ws_floats(B, T, F));
     p.total = cur;
@@ -4107,7 +4122,7 @@ static DecPlan dec_plan(int B, int T, int Fe) {
     p.st = take((size_t)2 * B * 64);
     p.part = take((size_t)B * DB_NCH * 64 * 3);
     p.m = take((size_t)2 * B * 64);
-    p.wpart = take((size_t)3 * FFN_WGRAD_SPLIT * 8192);
+    p.wpart = take((size_t)3 * RC_WG_SPLIT * 8192);
     p.cpart = take((size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256);
     p.dense = take(dense_train_ws_floats(B, T, Fe));
     p.total = cur;

@@ -1040,6 +1040,128 @@ void launch_db_conv_wgrad_x3(LaunchCtx ctx, const float* dz, const float* a, int
 }
 
 // ---------------------------------------------------------------------------------
+// Row-conv weight gradient (rc_wgrad_kernel of train.hip with split products; the encoder's stride-2 1 x 3 conv, the
+// decoders' sub-pixel conv):  partial[kw][s][co][ci] = sum over the s-th range of OUTPUT positions m = (b, t, fo) of
+// dz[m][co] * in[(b, t, fo SF - PL + kw)][ci].  Block = (64-channel group of co, tap kw, range s), one 64 x 64 tile as in
+// db_conv_wgrad_x3_kernel: steps of 32 positions, lane (c, g) feeds slot e with position m0 + 8 g + e, the (row, fo) of a
+// lane's eight positions from ONE 32-bit division plus carries (the fp32 kernel: a 64-bit division per position), dz at
+// the running exact power-of-two scale.  NG = 2: dz is the pixel-shuffled plane, channel group r of position m at row 2 m + r.
+// ---------------------------------------------------------------------------------
+struct RcGeomX3 { int B, T, Fi, Fo, KW, SF, PL; };    // = RcGeom (train.hip)
+template <int NG>
+__global__ __launch_bounds__(256) void rc_wgrad_x3_kernel(const float* __restrict__ dz, const float* __restrict__ in, RcGeomX3 gm,
+                                                          int nsplit, float* __restrict__ partial) {
+    __shared__ float red[2][64 * 64];
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const int rb = blockIdx.x, kw = blockIdx.y, s = blockIdx.z;
+    const unsigned Mo = (unsigned)gm.B * gm.T * gm.Fo;
+    const unsigned steps = (Mo + 31) / 32, per = (steps + nsplit - 1) / nsplit;
+    const unsigned st0 = s * per, st1 = st0 + per < steps ? st0 + per : steps;
+    f32x4 acc[4][4];                                  // [ib][jb]
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = splat4(0.f);
+    float sP = 1.f, iP = 1.f;
+    bool fresh = true;
+    for (unsigned st = st0 + wv; st < st1; st += 4) {
+        const unsigned m0 = st * 32 + 8 * g;
+        unsigned bt = m0 / (unsigned)gm.Fo;
+        int fo = (int)(m0 - bt * (unsigned)gm.Fo);
+        f32x4 av[4][2], bv[4][2];                     // [block][e >> 2][e & 3]
+        float mx = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned m = m0 + e;
+            const bool ok = m < Mo;
+            const int fi = fo * gm.SF - gm.PL + kw;
+            const bool inb = ok && fi >= 0 && fi < gm.Fi;
+            const unsigned src = inb ? bt * (unsigned)gm.Fi + (unsigned)fi : 0u;
+            const unsigned zrow = ok ? (NG == 1 ? m : 2u * m + (unsigned)rb) : 0u;
+            const unsigned oz = (zrow * 64u + (unsigned)c) * 4u, oa = (src * 64u + (unsigned)c) * 4u;     // 32-bit byte offsets
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib) {
+                const float v0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dz + 16 * ib) + oz);
+                const float v = ok ? v0 : 0.f;
+                av[ib][e >> 2][e & 3] = v;
+                mx = fmaxf(mx, fabsf(v));
+            }
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(in + 16 * jb) + oa);
+                bv[jb][e >> 2][e & 3] = inb ? v : 0.f;
+            }
+            if (++fo == gm.Fo) { fo = 0; ++bt; }
+        }
+        mx = tx_wave_max(mx);
+        const float ms_ = mx * sP;
+        if (mx > 0.f && (fresh || ms_ > 8192.f || ms_ < 0.25f)) {          // wave-uniform, rare (see wgrad_partial64_x3_kernel)
+            float s2, i2;
+            tx_pow2(mx, s2, i2);
+            const float ratio = s2 * iP;
+#pragma unroll
+            for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = acc[ib][jb] * splat4(ratio);
+            sP = s2; iP = i2; fresh = false;
+        }
+        f16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            split8(av[k][0] * splat4(sP), av[k][1] * splat4(sP), ah[k], al[k]);
+            split8(bv[k][0], bv[k][1], bh[k], bl[k]);
+        }
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma32h(ah[ib], bh[jb], acc[ib][jb]);
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma32l(ah[ib], bl[jb], acc[ib][jb]);
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = mfma32l(al[ib], bh[jb], acc[ib][jb]);
+        }
+    }
+#pragma unroll
+    for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+        for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = acc[ib][jb] * splat4(iP);
+    auto put = [&](float* dst) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[(16 * ib + 4 * g + r) * 64 + 16 * jb + c] = acc[ib][jb][r];
+    };
+    auto add = [&](const float* src) {
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ib][jb][r] += src[(16 * ib + 4 * g + r) * 64 + 16 * jb + c];
+    };
+    if (wv >= 2) put(red[wv - 2]);
+    __syncthreads();
+    if (wv < 2) add(red[wv]);
+    __syncthreads();
+    if (wv == 1) put(red[0]);
+    __syncthreads();
+    if (wv == 0) {
+        add(red[0]);
+        put(partial + (((long)kw * nsplit + s) * (64 * NG) + 64 * rb) * 64);      // rows co = 64 rb + ..., 64 columns ci
+    }
+}
+// gm7: the seven ints of RcGeom.  The plane offsets are 32-bit: the caller checks rows * 256 < 2^32
+void launch_rc_wgrad_x3(LaunchCtx ctx, int ng, const float* dz, const float* in, const int* gm7, int nsplit, float* partial) {
+    const RcGeomX3 gm{gm7[0], gm7[1], gm7[2], gm7[3], gm7[4], gm7[5], gm7[6]};
+    if (ng == 1)
+        LAUNCH(ctx, "rowconv_train", (rc_wgrad_x3_kernel<1><<<dim3(1, gm.KW, nsplit), 256, 0, ctx.stream>>>(dz, in, gm, nsplit, partial)));
+    else
+        LAUNCH(ctx, "rowconv_train", (rc_wgrad_x3_kernel<2><<<dim3(2, gm.KW, nsplit), 256, 0, ctx.stream>>>(dz, in, gm, nsplit, partial)));
+}
+
+// ---------------------------------------------------------------------------------
 // host side (called from train.hip's launch_ffn_train_* when TRAIN_X3 is on)
 // ---------------------------------------------------------------------------------
 static int tx_grid(int ntiles, int waves) {
