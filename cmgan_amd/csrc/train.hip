@@ -3519,6 +3519,18 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
 struct RcGeom { int B, T, Fi, Fo, KW, SF, PL; };      // Fo = output positions per row (before the pixel shuffle)
 #define RC_WG_SPLIT 256               // position ranges of the split-f16 weight gradient (sizes the slab buffers; >= FFN_WGRAD_SPLIT)
 void launch_rc_wgrad_x3(LaunchCtx, int ng, const float* dz, const float* in, const int* gm7, int nsplit, float* partial);
+bool launch_rc_dgrad_x3(LaunchCtx, int ng, const float* dz, const float* wraw, const int* gm7, float* din);
+// the data gradient on split products (train_x3.hip) when the build and the geometry allow; CMGAN_RC_DGRAD_X3=0: A/B
+static bool rc_dgrad_x3(LaunchCtx ctx, int ng, const float* dz, const float* wraw, const RcGeom& gm, float* din) {
+#if TRAIN_X3
+    static const bool k_on = env_knob("CMGAN_RC_DGRAD_X3", 1, 0, 1) != 0;
+    const int gm7[7] = {gm.B, gm.T, gm.Fi, gm.Fo, gm.KW, gm.SF, gm.PL};
+    return k_on && launch_rc_dgrad_x3(ctx, ng, dz, wraw, gm7, din);
+#else
+    (void)ctx; (void)ng; (void)dz; (void)wraw; (void)gm; (void)din;
+    return false;
+#endif
+}
 
 template <int NG>
 __global__ __launch_bounds__(256) void rc_fwd_kernel(const float* __restrict__ in, const float* __restrict__ wimg,
@@ -3872,8 +3884,9 @@ void launch_encoder_train_backward(LaunchCtx ctx, const float* xin, const float*
     LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64, grad.c2_b)));
     // the weight gradient reads conv_2's input d; only then is d overwritten by its own gradient dd
     rc_backward<1>(ctx, dz2, ws + pl.d, ws + pl.img2T, g2, nullptr, grad.c2_w, ws + pl.wpart);
-    LAUNCH(ctx, "rowconv_train", (rc_dgrad_kernel<1><<<(unsigned)((M + 63) / 64), 256, 0, st>>>(dz2, ws + pl.img2T, g2,
-                                                                                               ws + pl.d)));
+    if (!rc_dgrad_x3(ctx, 1, dz2, p.c2_w, g2, ws + pl.d))
+        LAUNCH(ctx, "rowconv_train", (rc_dgrad_kernel<1><<<(unsigned)((M + 63) / 64), 256, 0, st>>>(dz2, ws + pl.img2T, g2,
+                                                                                                   ws + pl.d)));
     // dilated dense block: x = a1, dy = dd (in pl.d) -> da1 (into pl.g; dz2 is dead)
     launch_dense_train_backward(ctx, ws + pl.a1, ws + pl.d, B, T, F, p.dense, ws + pl.g, grad.dense, ws + pl.dense);
     // conv_1 + IN + PReLU
@@ -4189,7 +4202,8 @@ void launch_decoder_train_backward(LaunchCtx ctx, int kind, const float* x, cons
     LAUNCH(ctx, "decoder_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(g, Me, 128, ws + pl.cpart)));
     LAUNCH(ctx, "decoder_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(ws + pl.cpart, FFN_COLSUM_BLOCKS, 128, grad.sp_b)));
     rc_backward<2>(ctx, g, ws + pl.d, ws + pl.imgT, gs, nullptr, grad.sp_w, ws + pl.wpart);
-    LAUNCH(ctx, "rowconv_train", (rc_dgrad_kernel<2><<<(unsigned)((Me + 63) / 64), 256, 0, st>>>(g, ws + pl.imgT, gs, ws + pl.d)));
+    if (!rc_dgrad_x3(ctx, 2, g, p.sp_w, gs, ws + pl.d))
+        LAUNCH(ctx, "rowconv_train", (rc_dgrad_kernel<2><<<(unsigned)((Me + 63) / 64), 256, 0, st>>>(g, ws + pl.imgT, gs, ws + pl.d)));
     launch_dense_train_backward(ctx, x, ws + pl.d, B, T, Fe, p.dense, dx, grad.dense, ws + pl.dense);
 }
 

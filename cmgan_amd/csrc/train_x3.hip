@@ -1152,6 +1152,117 @@ __global__ __launch_bounds__(256) void rc_wgrad_x3_kernel(const float* __restric
         put(partial + (((long)kw * nsplit + s) * (64 * NG) + 64 * rb) * 64);      // rows co = 64 rb + ..., 64 columns ci
     }
 }
+// ---------------------------------------------------------------------------------
+// Row-conv data gradient (rc_dgrad_kernel of train.hip with split products):
+//   din[(b, t, fi)][ci] = sum_kw W_kw^T dz[(b, t, fo)]   with fo SF - PL + kw = fi
+// Per-token linear maps like the conv module's: persistent 512-thread blocks, one 16-position block per wave trip, the
+// three transposed tap images (rows = ci, contraction = the 64 NG output channels) built ONCE per block in LDS from the raw
+// weight [Co, 64, 1, 3]; the up to three dz rows a position touches are fetched first, scaled by the exact power of two of
+// the block's largest magnitude (dz is a gradient), split, and contracted with 12 NG x 3 MFMAs per output block.
+// ---------------------------------------------------------------------------------
+template <int NG>
+__global__ __launch_bounds__(512) void rc_dgrad_x3_kernel(const float* __restrict__ dz, const float* __restrict__ wraw, RcGeomX3 gm,
+                                                          float* __restrict__ din, int ntiles) {
+    constexpr int M32 = 2 * NG;                                   // k32 blocks of the contraction (64 NG output channels)
+    extern __shared__ __attribute__((aligned(16))) _Float16 rd_w[];             // [kw 3][ob 4][M32][hi | lo][64][8]
+    for (int u = threadIdx.x; u < 3 * 4 * M32 * 64; u += blockDim.x) {
+        const int ln = u & 63, blk = u >> 6, m = blk % M32, ob = (blk / M32) & 3, kw = blk / (4 * M32);
+        const int ci = 16 * ob + (ln & 15);
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int co = 32 * m + 16 * (e >> 2) + 4 * (ln >> 4) + (e & 3);
+            const float v = wraw[((long)co * 64 + ci) * 3 + kw];
+            const _Float16 h = (_Float16)v;
+            hi[e] = h;
+            lo[e] = (_Float16)(v - (float)h);
+        }
+        *reinterpret_cast<f16x8*>(rd_w + (long)blk * 1024 + ln * 8) = hi;
+        *reinterpret_cast<f16x8*>(rd_w + (long)blk * 1024 + 512 + ln * 8) = lo;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
+    const unsigned Mi = (unsigned)gm.B * gm.T * gm.Fi;
+#pragma unroll 1
+    for (int tile = blockIdx.x * 8 + wv; tile < ntiles; tile += gridDim.x * 8) {
+        const unsigned m = (unsigned)tile * 16u + (unsigned)c;
+        const bool ok = m < Mi;
+        const unsigned mm = ok ? m : Mi - 1u;
+        const unsigned bt = mm / (unsigned)gm.Fi;
+        const int fi = (int)(mm - bt * (unsigned)gm.Fi);
+        f32x4 v[3][4 * NG];
+        float mx = 0.f;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int num = fi + gm.PL - kw;
+            const int fo = gm.SF == 1 ? num : num >> 1;                         // SF is 1 or 2 (the launcher checks)
+            const bool inb = ok && num >= 0 && fo * gm.SF == num && fo < gm.Fo;
+            const unsigned srow = inb ? bt * (unsigned)gm.Fo + (unsigned)fo : 0u;
+#pragma unroll
+            for (int kb = 0; kb < 4 * NG; ++kb) {
+                const unsigned zrow = NG == 1 ? srow : 2u * srow + (unsigned)(kb >> 2);
+                f32x4 t = ldg4(dz + (size_t)zrow * 64 + 16 * (kb & 3) + 4 * g);
+                if (!inb) t = splat4(0.f);
+                v[kw][kb] = t;
+                mx = tx_absmax4(t, mx);
+            }
+        }
+        float zs, zinv;
+        tx_pow2(tx_wave_max(mx), zs, zinv);
+        f32x4 acc[4];
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) acc[ob] = splat4(0.f);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            f16x8 bh[1][M32], bl[1][M32];
+#pragma unroll
+            for (int mb = 0; mb < M32; ++mb)
+                split8(v[kw][2 * mb] * splat4(zs), v[kw][2 * mb + 1] * splat4(zs), bh[0][mb], bl[0][mb]);
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) {
+                f32x4 a1[1] = {acc[ob]};
+                lin_acc_x3<M32, 1>(rd_w + (long)((kw * 4 + ob) * M32) * 1024 + lane * 8, bh, bl, a1);
+                acc[ob] = a1[0];
+            }
+        }
+        if (ok) {
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob) stg4(din + (size_t)mm * 64 + 16 * ob + 4 * g, acc[ob] * splat4(zinv));
+        }
+    }
+}
+// returns false when the geometry is not one this kernel covers (the caller takes the fp32 kernel)
+bool launch_rc_dgrad_x3(LaunchCtx ctx, int ng, const float* dz, const float* wraw, const int* gm7, float* din) {
+    const RcGeomX3 gm{gm7[0], gm7[1], gm7[2], gm7[3], gm7[4], gm7[5], gm7[6]};
+    if (gm.KW != 3 || (gm.SF != 1 && gm.SF != 2)) return false;
+    const long Mi = (long)gm.B * gm.T * gm.Fi;
+    if (Mi * 256 >= (1l << 32) || (long)gm.B * gm.T * gm.Fo * ng * 256 >= (1l << 32)) return false;
+    const int ntiles = (int)((Mi + 15) / 16);
+    const size_t lds = (size_t)3 * 4 * 2 * ng * 1024 * sizeof(_Float16);        // 48 KB x NG
+    const void* fn = ng == 1 ? reinterpret_cast<const void*>(&rc_dgrad_x3_kernel<1>) : reinterpret_cast<const void*>(&rc_dgrad_x3_kernel<2>);
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, bool> optin;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = optin.find({dev, fn});
+        if (it == optin.end()) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) (void)hipGetLastError();
+            it = optin.emplace(std::make_pair(dev, fn), e == hipSuccess).first;
+        }
+        if (!it->second) return false;
+    }
+    const int want = (ntiles + 7) / 8, cap = ng == 1 ? 768 : 256;              // 48 KB: three blocks per CU; 96 KB: one
+    const int grid = want < cap ? (want > 0 ? want : 1) : cap;
+    if (ng == 1)
+        LAUNCH(ctx, "rowconv_train", (rc_dgrad_x3_kernel<1><<<grid, 512, lds, ctx.stream>>>(dz, wraw, gm, din, ntiles)));
+    else
+        LAUNCH(ctx, "rowconv_train", (rc_dgrad_x3_kernel<2><<<grid, 512, lds, ctx.stream>>>(dz, wraw, gm, din, ntiles)));
+    return true;
+}
+
 // gm7: the seven ints of RcGeom.  The plane offsets are 32-bit: the caller checks rows * 256 < 2^32
 void launch_rc_wgrad_x3(LaunchCtx ctx, int ng, const float* dz, const float* in, const int* gm7, int nsplit, float* partial) {
     const RcGeomX3 gm{gm7[0], gm7[1], gm7[2], gm7[3], gm7[4], gm7[5], gm7[6]};
