@@ -3518,7 +3518,8 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
 // =====================================================================================
 struct RcGeom { int B, T, Fi, Fo, KW, SF, PL; };      // Fo = output positions per row (before the pixel shuffle)
 #define RC_WG_SPLIT 256               // position ranges of the split-f16 weight gradient (sizes the slab buffers; >= FFN_WGRAD_SPLIT)
-void launch_rc_wgrad_x3(LaunchCtx, int ng, const float* dz, const float* in, const int* gm7, int nsplit, float* partial);
+void launch_rc_wgrad_x3(LaunchCtx, int ng, const float* dz, const float* in, const int* gm7, int nsplit, float* partial,
+                        float* colp);
 bool launch_rc_dgrad_x3(LaunchCtx, int ng, const float* dz, const float* wraw, const int* gm7, float* din);
 // the data gradient on split products (train_x3.hip) when the build and the geometry allow; CMGAN_RC_DGRAD_X3=0: A/B
 static bool rc_dgrad_x3(LaunchCtx ctx, int ng, const float* dz, const float* wraw, const RcGeom& gm, float* din) {
@@ -3801,9 +3802,12 @@ static void rc_forward(LaunchCtx ctx, const float* in, float* img, const float* 
     const long Mo = (long)gm.B * gm.T * gm.Fo;
     LAUNCH(ctx, "rowconv_train", (rc_fwd_kernel<NG><<<(unsigned)((Mo + 63) / 64), 256, 0, ctx.stream>>>(in, img, bias, gm, z)));
 }
+// db / cpart (optional): the bias gradient from the weight-gradient kernel ([RC_WG_SPLIT][64 NG] partials at cpart); returns
+// false if the caller still has to compute it (fp32 build / planes of 4 GB)
 template <int NG>
-static void rc_backward(LaunchCtx ctx, const float* dz, const float* in, const float* imgT, const RcGeom& gm, float* din,
-                        float* dW, float* wpart) {
+static bool rc_backward(LaunchCtx ctx, const float* dz, const float* in, const float* imgT, const RcGeom& gm, float* din,
+                        float* dW, float* wpart, float* db = nullptr, float* cpart = nullptr) {
+    bool db_done = false;
     hipStream_t st = ctx.stream;
     const long Mi = (long)gm.B * gm.T * gm.Fi;
     const int nw = gm.KW * 64 * NG * 64;
@@ -3812,9 +3816,13 @@ static void rc_backward(LaunchCtx ctx, const float* dz, const float* in, const f
     static const bool k_wx3 = env_knob("CMGAN_RC_WGRAD_X3", 1, 0, 1) != 0;
     if (k_wx3 && rows * 256 < (1l << 32)) {           // split products (train_x3.hip), RC_WG_SPLIT position ranges
         const int gm7[7] = {gm.B, gm.T, gm.Fi, gm.Fo, gm.KW, gm.SF, gm.PL};
-        launch_rc_wgrad_x3(ctx, NG, dz, in, gm7, RC_WG_SPLIT, wpart);
+        launch_rc_wgrad_x3(ctx, NG, dz, in, gm7, RC_WG_SPLIT, wpart, db ? cpart : nullptr);
         LAUNCH(ctx, "rowconv_train", (rc_wgrad_scatter_kernel<<<(nw + 255) / 256, 256, 0, st>>>(wpart, RC_WG_SPLIT, 64 * NG,
                                                                                                 gm.KW, dW)));
+        if (db) {
+            LAUNCH(ctx, "rowconv_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(cpart, RC_WG_SPLIT, 64 * NG, db)));
+            db_done = true;
+        }
     } else
 #endif
     {
@@ -3826,6 +3834,7 @@ static void rc_backward(LaunchCtx ctx, const float* dz, const float* in, const f
     }
     if (din)
         LAUNCH(ctx, "rowconv_train", (rc_dgrad_kernel<NG><<<(unsigned)((Mi + 63) / 64), 256, 0, st>>>(dz, imgT, gm, din)));
+    return db_done;
 }
 
 // ---- DenseEncoder (generator.py:50-69) --------------------------------------------------------------------------
@@ -3880,10 +3889,12 @@ void launch_encoder_train_backward(LaunchCtx ctx, const float* xin, const float*
     hipMemcpyAsync(dz2, dy, (size_t)M2 * 64 * sizeof(float), hipMemcpyDeviceToDevice, st);
     in_prelu_backward(ctx, ws + pl.z2, dz2, B, T * F2, p.n2_w, p.n2_b, p.p2_w, stt + 2 * B * 64, stt + 3 * B * 64, ws + pl.part,
                       ws + pl.m, ws + pl.m + B * 64, grad.n2_w, grad.n2_b, grad.p2_w);
-    LAUNCH(ctx, "encoder_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz2, M2, 64, cpart)));
-    LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64, grad.c2_b)));
-    // the weight gradient reads conv_2's input d; only then is d overwritten by its own gradient dd
-    rc_backward<1>(ctx, dz2, ws + pl.d, ws + pl.img2T, g2, nullptr, grad.c2_w, ws + pl.wpart);
+    // the weight gradient reads conv_2's input d; only then is d overwritten by its own gradient dd.  (db_c2 = colsum dz2
+    // comes out of the split-f16 weight-gradient kernel; otherwise the column-sum pass)
+    if (!rc_backward<1>(ctx, dz2, ws + pl.d, ws + pl.img2T, g2, nullptr, grad.c2_w, ws + pl.wpart, grad.c2_b, cpart)) {
+        LAUNCH(ctx, "encoder_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz2, M2, 64, cpart)));
+        LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64, grad.c2_b)));
+    }
     if (!rc_dgrad_x3(ctx, 1, dz2, p.c2_w, g2, ws + pl.d))
         LAUNCH(ctx, "rowconv_train", (rc_dgrad_kernel<1><<<(unsigned)((M + 63) / 64), 256, 0, st>>>(dz2, ws + pl.img2T, g2,
                                                                                                    ws + pl.d)));
@@ -4199,9 +4210,10 @@ void launch_decoder_train_backward(LaunchCtx ctx, int kind, const float* x, cons
                           ws + pl.m + B * 64, grad.n_w, grad.n_b, grad.p_w);
     }
     // sub-pixel conv: g = dL/ds on the 2 Fe wide grid = [Me, 128] rows in conv-channel order (64 r + c)
-    LAUNCH(ctx, "decoder_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(g, Me, 128, ws + pl.cpart)));
-    LAUNCH(ctx, "decoder_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(ws + pl.cpart, FFN_COLSUM_BLOCKS, 128, grad.sp_b)));
-    rc_backward<2>(ctx, g, ws + pl.d, ws + pl.imgT, gs, nullptr, grad.sp_w, ws + pl.wpart);
+    if (!rc_backward<2>(ctx, g, ws + pl.d, ws + pl.imgT, gs, nullptr, grad.sp_w, ws + pl.wpart, grad.sp_b, ws + pl.cpart)) {
+        LAUNCH(ctx, "decoder_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(g, Me, 128, ws + pl.cpart)));
+        LAUNCH(ctx, "decoder_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(ws + pl.cpart, FFN_COLSUM_BLOCKS, 128, grad.sp_b)));
+    }
     if (!rc_dgrad_x3(ctx, 2, g, p.sp_w, gs, ws + pl.d))
         LAUNCH(ctx, "rowconv_train", (rc_dgrad_kernel<2><<<(unsigned)((Me + 63) / 64), 256, 0, st>>>(g, ws + pl.imgT, gs, ws + pl.d)));
     launch_dense_train_backward(ctx, x, ws + pl.d, B, T, Fe, p.dense, dx, grad.dense, ws + pl.dense);

@@ -1048,10 +1048,13 @@ void launch_db_conv_wgrad_x3(LaunchCtx ctx, const float* dz, const float* a, int
 // the running exact power-of-two scale.  NG = 2: dz is the pixel-shuffled plane, channel group r of position m at row 2 m + r.
 // ---------------------------------------------------------------------------------
 struct RcGeomX3 { int B, T, Fi, Fo, KW, SF, PL; };    // = RcGeom (train.hip)
+// colp (optional): the bias gradient - column sums of dz - as [split][64 NG] partials from the kw = 0 blocks, which hold every
+// dz element of their range in registers (the separate pass re-read the whole gradient plane).
 template <int NG>
 __global__ __launch_bounds__(256) void rc_wgrad_x3_kernel(const float* __restrict__ dz, const float* __restrict__ in, RcGeomX3 gm,
-                                                          int nsplit, float* __restrict__ partial) {
+                                                          int nsplit, float* __restrict__ partial, float* __restrict__ colp) {
     __shared__ float red[2][64 * 64];
+    __shared__ float cs_l[4][64];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     const int rb = blockIdx.x, kw = blockIdx.y, s = blockIdx.z;
     const unsigned Mo = (unsigned)gm.B * gm.T * gm.Fo;
@@ -1064,6 +1067,8 @@ __global__ __launch_bounds__(256) void rc_wgrad_x3_kernel(const float* __restric
         for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = splat4(0.f);
     float sP = 1.f, iP = 1.f;
     bool fresh = true;
+    const bool want_cs = colp != nullptr && kw == 0;              // block-uniform
+    f32x4 csum = splat4(0.f);                                     // [ib]: this lane's positions of channel 64 rb + 16 ib + c
     for (unsigned st = st0 + wv; st < st1; st += 4) {
         const unsigned m0 = st * 32 + 8 * g;
         unsigned bt = m0 / (unsigned)gm.Fo;
@@ -1092,6 +1097,13 @@ __global__ __launch_bounds__(256) void rc_wgrad_x3_kernel(const float* __restric
                 bv[jb][e >> 2][e & 3] = inb ? v : 0.f;
             }
             if (++fo == gm.Fo) { fo = 0; ++bt; }
+        }
+        if (want_cs) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 t = av[k][0] + av[k][1];
+                csum[k] += (t[0] + t[1]) + (t[2] + t[3]);
+            }
         }
         mx = tx_wave_max(mx);
         const float ms_ = mx * sP;
@@ -1141,6 +1153,13 @@ __global__ __launch_bounds__(256) void rc_wgrad_x3_kernel(const float* __restric
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[ib][jb][r] += src[(16 * ib + 4 * g + r) * 64 + 16 * jb + c];
     };
+    if (want_cs) {                                                // lane groups, then waves 0..3 in order: a fixed order
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            const float t = red_g_sum(csum[ib]);
+            if (g == 0) cs_l[wv][16 * ib + c] = t;
+        }
+    }
     if (wv >= 2) put(red[wv - 2]);
     __syncthreads();
     if (wv < 2) add(red[wv]);
@@ -1150,6 +1169,7 @@ __global__ __launch_bounds__(256) void rc_wgrad_x3_kernel(const float* __restric
     if (wv == 0) {
         add(red[0]);
         put(partial + (((long)kw * nsplit + s) * (64 * NG) + 64 * rb) * 64);      // rows co = 64 rb + ..., 64 columns ci
+        if (want_cs) colp[(long)s * (64 * NG) + 64 * rb + lane] = (cs_l[0][lane] + cs_l[1][lane]) + (cs_l[2][lane] + cs_l[3][lane]);
     }
 }
 // ---------------------------------------------------------------------------------
@@ -1264,12 +1284,15 @@ bool launch_rc_dgrad_x3(LaunchCtx ctx, int ng, const float* dz, const float* wra
 }
 
 // gm7: the seven ints of RcGeom.  The plane offsets are 32-bit: the caller checks rows * 256 < 2^32
-void launch_rc_wgrad_x3(LaunchCtx ctx, int ng, const float* dz, const float* in, const int* gm7, int nsplit, float* partial) {
+void launch_rc_wgrad_x3(LaunchCtx ctx, int ng, const float* dz, const float* in, const int* gm7, int nsplit, float* partial,
+                        float* colp) {
     const RcGeomX3 gm{gm7[0], gm7[1], gm7[2], gm7[3], gm7[4], gm7[5], gm7[6]};
     if (ng == 1)
-        LAUNCH(ctx, "rowconv_train", (rc_wgrad_x3_kernel<1><<<dim3(1, gm.KW, nsplit), 256, 0, ctx.stream>>>(dz, in, gm, nsplit, partial)));
+        LAUNCH(ctx, "rowconv_train", (rc_wgrad_x3_kernel<1><<<dim3(1, gm.KW, nsplit), 256, 0, ctx.stream>>>(dz, in, gm, nsplit, partial,
+                                                                                                            colp)));
     else
-        LAUNCH(ctx, "rowconv_train", (rc_wgrad_x3_kernel<2><<<dim3(2, gm.KW, nsplit), 256, 0, ctx.stream>>>(dz, in, gm, nsplit, partial)));
+        LAUNCH(ctx, "rowconv_train", (rc_wgrad_x3_kernel<2><<<dim3(2, gm.KW, nsplit), 256, 0, ctx.stream>>>(dz, in, gm, nsplit, partial,
+                                                                                                            colp)));
 }
 
 // ---------------------------------------------------------------------------------

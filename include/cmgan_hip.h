@@ -534,8 +534,10 @@ int cmgan_profile_read(cmgan_handle* h, cmgan_kernel_time* out, int cap);
  *   CMGAN_STFT_FFT=0|1         front / back end as 16 x 25 real FFTs (1, default) or the folded DFT products (0)
  *   CMGAN_FFN_BWD_FUSED=0|1    training: FeedForward backward with both weight gradients contracted on the chip (1, default)
  *                              or part A + two token-contraction launches (0)
- *   CMGAN_RC_FWD_X3=0|1        training: the encoder's stride-2 conv and the decoders' sub-pixel conv forward through the
- *                              inference kernels on split-f16 products (1, default) or the fp32-MFMA row-conv kernel (0)
+ *   CMGAN_RC_FWD_X3=0|1, CMGAN_RC_WGRAD_X3=0|1, CMGAN_RC_DGRAD_X3=0|1
+ *                              training: forward (through the inference kernels), weight gradient and data gradient of the
+ *                              encoder's stride-2 conv and the decoders' sub-pixel conv on split-f16 products (1, default)
+ *                              or the fp32-MFMA row-conv kernels (0)
  *   CMGAN_ATTN_BWD=cores       training: the three attention backward cores instead of the fused kernel (read per launch)
  * (The Python host adds CMGAN_BRANCHES=1|2 and CMGAN_BRANCH_OFFSET=n for Engine.enhance_graphed; CMGAN_HIP_LIB selects
  * the library file.)                                                                                                  */
