@@ -3714,7 +3714,19 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const float* __restrict__
     const int co = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const long per = (M + gridDim.x - 1) / gridDim.x, m0 = (long)blockIdx.x * per, m1 = m0 + per < M ? m0 + per : M;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (long m = m0 + sub; m < m1; m += 4) {
+    long m = m0 + sub;
+    for (; m + 12 < m1; m += 16) {                                // four positions' operands in flight (same sum order)
+        float d[4], x[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            d[u] = dz[(m + 4 * u) * 64 + co];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x[u][k] = xin[(m + 4 * u) * 3 + k];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s0 = fmaf(d[u], x[u][0], s0); s1 = fmaf(d[u], x[u][1], s1); s2 = fmaf(d[u], x[u][2], s2); }
+    }
+    for (; m < m1; m += 4) {
         const float d = dz[m * 64 + co];
         s0 = fmaf(d, xin[m * 3], s0); s1 = fmaf(d, xin[m * 3 + 1], s1); s2 = fmaf(d, xin[m * 3 + 2], s2);
     }
@@ -3910,6 +3922,10 @@ void launch_encoder_train_backward(LaunchCtx ctx, const float* xin, const float*
     LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(ws + pl.wpart, FFN_COLSUM_BLOCKS, 192, grad.c1_w)));
 }
 
+// row of position m in rows of `w` positions.  The [R, W, 64] fp32 plane of these kernels fits the GPU's memory, so positions are
+// far below 2^31 and a 32-bit division does (a 64-bit one is ~100 VALU instructions per lane: tail_wgrad / tail_dgrad spent
+// most of their time in it - 0.55 / 0.40 ms per launch against 0.11 ms of HBM time)
+__device__ __forceinline__ long tail_row(long m, int w) { return (long)((unsigned)m / (unsigned)w); }
 // ---- decoder tails: Conv2d(64 -> NO, (1,2)) with NO = 1 (mask head) or 2 (complex head) on a [R, W, 64] plane -------
 // out[(r, f)][o] = b[o] + sum_{kw, ci} w[o][ci][0][kw] in[(r, f + kw)][ci],  f < W - 1.       (generator.py:126,148)
 // 16 lanes share one output position: the 128-float window (two adjacent rows) is read once, coalesced.
@@ -3927,7 +3943,7 @@ __global__ __launch_bounds__(256) void tail_fwd_kernel(const float* __restrict__
             wv[o][e] = w[(o * 64 + ci) * 2 + kw];
         }
     for (long m = (long)blockIdx.x * 16 + (threadIdx.x >> 4); m < Mo; m += (long)gridDim.x * 16) {
-        const long r = m / (W - 1);
+        const long r = tail_row(m, W - 1);
         const long base = (m + r) * 64;                         // position (r, f) of the W wide plane = m + r
         const f32x4 v0 = ldg4(in + base + 8 * l), v1 = ldg4(in + base + 8 * l + 4);
         float s[NO];
@@ -3953,7 +3969,7 @@ __global__ __launch_bounds__(256) void tail_dgrad_kernel(const float* __restrict
     const long total = R * W * 64;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int ci = (int)(i & 63);
-        const long pos = i >> 6, r = pos / W;
+        const long pos = i >> 6, r = tail_row(pos, W);
         const int fi = (int)(pos - r * W);
         float s = 0.f;
 #pragma unroll
@@ -3977,8 +3993,29 @@ __global__ __launch_bounds__(256) void tail_wgrad_kernel(const float* __restrict
     float s[NO][2];
 #pragma unroll
     for (int o = 0; o < NO; ++o) s[o][0] = s[o][1] = 0.f;
-    for (long m = m0 + sub; m < m1; m += 4) {
-        const long r = m / (W - 1);
+    // four positions per trip, their operands fetched before the first FMA (the loop was one dependent fetch per position:
+    // 1 000 round trips per thread at eight waves per CU - 0.55 ms per launch); the sums keep their order
+    long m = m0 + sub;
+    for (; m + 12 < m1; m += 16) {
+        float x0[4], x1[4], d[4][NO];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long mu = m + 4 * u, r = tail_row(mu, W - 1);
+            x0[u] = in[(mu + r) * 64 + ci];
+            x1[u] = in[(mu + r + 1) * 64 + ci];
+#pragma unroll
+            for (int o = 0; o < NO; ++o) d[u][o] = dz[mu * NO + o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                s[o][0] = fmaf(d[u][o], x0[u], s[o][0]);
+                s[o][1] = fmaf(d[u][o], x1[u], s[o][1]);
+            }
+    }
+    for (; m < m1; m += 4) {
+        const long r = tail_row(m, W - 1);
         const float x0 = in[(m + r) * 64 + ci], x1 = in[(m + r + 1) * 64 + ci];
 #pragma unroll
         for (int o = 0; o < NO; ++o) {
