@@ -604,7 +604,7 @@ void ffn_x3_backward(LaunchCtx, const float* x, const float* dy, long M, const F
 void launch_wgrad_partial64_x3(LaunchCtx, const char* label, const float* P, const float* Q, long M, int R, int C,
                                float* partial, int nsplit, float* colp);
 void launch_db_conv_wgrad_x3(LaunchCtx, const float* dz, const float* a, int B, int T, int F, int dil, int nsplit,
-                             float* partial);
+                             float* partial, float* colp);
 void cm_x3_pack(LaunchCtx, const ConvModTrainParams& p, float* img_w1, float* img_w1t);
 void cm_x3_pw1glu(LaunchCtx, const float* x, long M, const float* img_w1, const ConvModTrainParams& p, float* u);
 void cm_x3_bwd2(LaunchCtx, const float* x, const float* du, long M, const float* img_w1, const float* img_w1t,
@@ -2929,11 +2929,14 @@ __global__ __launch_bounds__(256) void db_conv_fwd_kernel(DbSlots in, const floa
 // per-(clip, chunk, channel) sums over positions: MODE 0: (sum z, sum z^2) of z;  MODE 1 (backward): from z, the
 // incoming gradient ga and the layer's statistics / affine / slope: dn = ga * PReLU'(n) (written over ga) and
 // (sum dn, sum dn zhat, sum ga n [n < 0])
+// gin (MODE 1, optional): the incoming gradient is read from gin instead of ga (out of place: the dense block's last layer
+// reads the caller's dy directly - no copy of the plane into the workspace first)
 template <int MODE>
 __global__ __launch_bounds__(256) void db_sums_kernel(const float* __restrict__ z, float* __restrict__ ga, int P,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      const float* __restrict__ alpha, float* __restrict__ partial) {
+                                                      const float* __restrict__ alpha, float* __restrict__ partial,
+                                                      const float* __restrict__ gin = nullptr) {
     __shared__ float red[4][64][3];
     const int c = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const int b = blockIdx.x, chunk = blockIdx.y;
@@ -2948,7 +2951,7 @@ __global__ __launch_bounds__(256) void db_sums_kernel(const float* __restrict__ 
             s0 += zv;
             s1 = fmaf(zv, zv, s1);
         } else {
-            const float zh = (zv - mu) * rs, n = zh * gm + bt, gv = ga[i];
+            const float zh = (zv - mu) * rs, n = zh * gm + bt, gv = gin ? gin[i] : ga[i];
             const float dn = n < 0.f ? gv * al : gv;
             ga[i] = dn;
             s0 += dn;
@@ -3449,10 +3452,13 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
     const long M = (long)B * T * F;
     const int P = T * F;
     db_pack_images(ctx, p, ws, pl, F, false);
-    auto ga = [&](int s) { return ws + pl.ga + (size_t)s * M * 64; };
+    // gradient planes: ga_0 IS the caller's dx (accumulated in place - dx must not alias x or dy), ga_1 .. ga_4 in the
+    // workspace; ga_4 = dy is never materialised: layer 3 reads dy and writes its dn into ga_4 (db_sums_kernel gin).
+    // (Two plane copies per backward - 2 x 0.53 GB moved at the encoder's shape - are gone this way.)
+    auto ga = [&](int s) { return s == 0 ? dx : ws + pl.ga + (size_t)s * M * 64; };
     auto aslot = [&](int s) -> const float* { return s == 0 ? x : ws + pl.a + (size_t)(s - 1) * M * 64; };
-    hipMemsetAsync(ws + pl.ga, 0, (size_t)4 * M * 64 * sizeof(float), st);                       // ga_0 .. ga_3
-    hipMemcpyAsync(ga(4), dy, (size_t)M * 64 * sizeof(float), hipMemcpyDeviceToDevice, st);      // only layer 3's output is returned
+    hipMemsetAsync(dx, 0, (size_t)M * 64 * sizeof(float), st);                                   // ga_0
+    hipMemsetAsync(ga(1), 0, (size_t)3 * M * 64 * sizeof(float), st);                            // ga_1 .. ga_3
     float* cpart = ws + pl.cpart;
     for (int i = 3; i >= 0; --i) {
         const float* z = ws + pl.z + (size_t)i * M * 64;
@@ -3461,7 +3467,7 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
         const float* rstd = ws + pl.rstd + (size_t)i * B * 64;
         LAUNCH(ctx, "dense_train_bwd", (db_sums_kernel<1><<<dim3(B, DB_NCH), 256, 0, st>>>(z, g, P, mean, rstd, p.norm_w[i],
                                                                                          p.norm_b[i], p.prelu_w[i],
-                                                                                         ws + pl.part)));
+                                                                                         ws + pl.part, i == 3 ? dy : nullptr)));
         LAUNCH(ctx, "dense_train_bwd", (db_bwd_finalize_kernel<<<64, 256, 0, st>>>(ws + pl.part, B, (double)P, ws + pl.m1,
                                                                                 ws + pl.m2, grad.norm_w[i], grad.norm_b[i],
                                                                                 grad.prelu_w[i])));
@@ -3477,9 +3483,13 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
         for (int s = 0; s <= i; ++s) {
             // the split-f16 kernel addresses a plane with 32-bit byte offsets: planes of 4 GB and more (16.7 M positions,
             // 250 clips of the encoder's shape) take the fp32 kernel
-            if (TRAIN_X3 && (long)M * 256 < (1L << 32))
-                launch_db_conv_wgrad_x3(ctx, g, aslot(s), B, T, F, dil, DB_WG_SPLIT, ws + pl.wpart);
-            else
+            if (TRAIN_X3 && (long)M * 256 < (1L << 32)) {
+                // (the conv-bias gradient of layer i = colsum of its dz rides on the first of its weight-gradient launches)
+                launch_db_conv_wgrad_x3(ctx, g, aslot(s), B, T, F, dil, DB_WG_SPLIT, ws + pl.wpart, s == 0 ? cpart : nullptr);
+                if (s == 0)
+                    LAUNCH(ctx, "dense_train_reduce", (reduce_partials_kernel<<<4, 1024, 0, st>>>(cpart, DB_WG_SPLIT, 64,
+                                                                                                  grad.conv_b[i])));
+            } else
                 LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_kernel<<<dim3(6, DB_WG_SPLIT), 256, 0, st>>>(
                                                      g, aslot(s), B, T, F, dil, ws + pl.wpart)));
             LAUNCH(ctx, "dense_train_reduce", (db_wgrad_scatter_kernel<<<6 * 64, 256, 0, st>>>(ws + pl.wpart, Cin, 64 * (i - s),
@@ -3502,10 +3512,11 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
         }
     }
     // the four conv-bias gradients (column sums of the layers' dz planes, which stay untouched once written) in one batch
-    const ColsumJobs jobs{{ga(1), ga(2), ga(3), ga(4)}, {grad.conv_b[0], grad.conv_b[1], grad.conv_b[2], grad.conv_b[3]},
-                          {64, 64, 64, 64}};
-    colsum_batch(ctx, "dense_train_reduce", jobs, 4, M, cpart);
-    hipMemcpyAsync(dx, ga(0), (size_t)M * 64 * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (!(TRAIN_X3 && (long)M * 256 < (1L << 32))) {              // (split-f16 build: done inside the weight-gradient launches)
+        const ColsumJobs jobs{{ga(1), ga(2), ga(3), ga(4)}, {grad.conv_b[0], grad.conv_b[1], grad.conv_b[2], grad.conv_b[3]},
+                              {64, 64, 64, 64}};
+        colsum_batch(ctx, "dense_train_reduce", jobs, 4, M, cpart);
+    }
 }
 
 // =====================================================================================
@@ -3749,13 +3760,14 @@ static void in_prelu_forward(LaunchCtx ctx, const float* z, int B, int P, const 
     LAUNCH(ctx, "in_prelu_train", (db_norm_prelu_kernel<<<2048, 256, 0, st>>>(z, (long)B * P * 64, P, mean, rstd, gamma, beta,
                                                                               alpha, a)));
 }
-// ... and backward: g holds dL/da on entry and dL/dz on exit; the three parameter gradients are written
+// ... and backward: g holds dL/da on entry (or gin does: then g is output only) and dL/dz on exit; the three parameter
+// gradients are written
 static void in_prelu_backward(LaunchCtx ctx, const float* z, float* g, int B, int P, const float* gamma, const float* beta,
                               const float* alpha, const float* mean, const float* rstd, float* part, float* m1, float* m2,
-                              float* dgamma, float* dbeta, float* dalpha) {
+                              float* dgamma, float* dbeta, float* dalpha, const float* gin = nullptr) {
     hipStream_t st = ctx.stream;
     LAUNCH(ctx, "in_prelu_train", (db_sums_kernel<1><<<dim3(B, DB_NCH), 256, 0, st>>>(z, g, P, mean, rstd, gamma, beta, alpha,
-                                                                                    part)));
+                                                                                    part, gin)));
     LAUNCH(ctx, "in_prelu_train", (db_bwd_finalize_kernel<<<64, 256, 0, st>>>(part, B, (double)P, m1, m2, dgamma, dbeta, dalpha)));
     LAUNCH(ctx, "in_prelu_train", (db_in_bwd_kernel<<<2048, 256, 0, st>>>(g, z, (long)B * P * 64, P, mean, rstd, gamma, m1, m2)));
 }
@@ -3898,9 +3910,8 @@ void launch_encoder_train_backward(LaunchCtx ctx, const float* xin, const float*
     float* cpart = ws + pl.cpart;
     // conv_2 + IN + PReLU: dy -> dz2 (kept in the front of the [M,64] gradient plane)
     float* dz2 = ws + pl.g;
-    hipMemcpyAsync(dz2, dy, (size_t)M2 * 64 * sizeof(float), hipMemcpyDeviceToDevice, st);
     in_prelu_backward(ctx, ws + pl.z2, dz2, B, T * F2, p.n2_w, p.n2_b, p.p2_w, stt + 2 * B * 64, stt + 3 * B * 64, ws + pl.part,
-                      ws + pl.m, ws + pl.m + B * 64, grad.n2_w, grad.n2_b, grad.p2_w);
+                      ws + pl.m, ws + pl.m + B * 64, grad.n2_w, grad.n2_b, grad.p2_w, dy);      // (reads dy: no copy first)
     // the weight gradient reads conv_2's input d; only then is d overwritten by its own gradient dd.  (db_c2 = colsum dz2
     // comes out of the split-f16 weight-gradient kernel; otherwise the column-sum pass)
     if (!rc_backward<1>(ctx, dz2, ws + pl.d, ws + pl.img2T, g2, nullptr, grad.c2_w, ws + pl.wpart, grad.c2_b, cpart)) {

@@ -916,10 +916,13 @@ __global__ __launch_bounds__(256) void wgrad_partial64_x3_kernel(const float* __
 // (shifted, zero outside the plane) activation column per 16-wide block.  dz is a gradient: scaled by the running
 // exact power of two of wgrad_partial64_x3_kernel.  Same block shape, LDS combine and slab layout as the fp32 kernel.
 // ---------------------------------------------------------------------------------
+// colp (optional): the conv-bias gradient - column sums of dz - as [split][64] partials from the tap-0 blocks (the separate
+// pass re-read the four dz planes of a dense block: 1 - 2 GB).
 __global__ __launch_bounds__(256) void db_conv_wgrad_x3_kernel(const float* __restrict__ dz, const float* __restrict__ a,
                                                                int B, int T, int F, int dil, int nsplit,
-                                                               float* __restrict__ partial) {
+                                                               float* __restrict__ partial, float* __restrict__ colp) {
     __shared__ float red[2][64 * 64];
+    __shared__ float cs_l[4][64];
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wv = threadIdx.x >> 6;
     // 1-D grid of 6 nsplit blocks (nsplit a multiple of 8), dealt round-robin to the 8 XCDs: the six tap blocks of one
     // position range read the same dz / activation rows, so they are given to the SAME XCD (one L2 fill, five hits)
@@ -936,6 +939,8 @@ __global__ __launch_bounds__(256) void db_conv_wgrad_x3_kernel(const float* __re
         for (int jb = 0; jb < 4; ++jb) acc[ib][jb] = splat4(0.f);
     float sP = 1.f, iP = 1.f;
     bool fresh = true;
+    const bool want_cs = colp != nullptr && tap == 0;             // block-uniform
+    f32x4 csum = splat4(0.f);                                     // [ib]: this lane's positions of channel 16 ib + c
     for (unsigned st = st0 + wv; st < st1; st += 4) {
         const unsigned m0 = st * 32 + 8 * g;
         unsigned bb = m0 / tf;
@@ -967,6 +972,13 @@ __global__ __launch_bounds__(256) void db_conv_wgrad_x3_kernel(const float* __re
                 bv[jb][e >> 2][e & 3] = inb ? v : 0.f;
             }
             if (++f == F) { f = 0; if (++t == T) { t = 0; ++bb; } }
+        }
+        if (want_cs) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 tsum = av[k][0] + av[k][1];
+                csum[k] += (tsum[0] + tsum[1]) + (tsum[2] + tsum[3]);
+            }
         }
         mx = tx_wave_max(mx);
         const float ms_ = mx * sP;
@@ -1016,6 +1028,13 @@ __global__ __launch_bounds__(256) void db_conv_wgrad_x3_kernel(const float* __re
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[ib][jb][r] += src[(16 * ib + 4 * g + r) * 64 + 16 * jb + c];
     };
+    if (want_cs) {                                                // lane groups, then waves 0..3 in order: a fixed order
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            const float tsum = red_g_sum(csum[ib]);
+            if (g == 0) cs_l[wv][16 * ib + c] = tsum;
+        }
+    }
     if (wv >= 2) put(red[wv - 2]);
     __syncthreads();
     if (wv < 2) add(red[wv]);
@@ -1024,6 +1043,7 @@ __global__ __launch_bounds__(256) void db_conv_wgrad_x3_kernel(const float* __re
     __syncthreads();
     if (wv == 0) {
         add(red[0]);
+        if (want_cs) colp[(long)s * 64 + lane] = (cs_l[0][lane] + cs_l[1][lane]) + (cs_l[2][lane] + cs_l[3][lane]);
         float* out = partial + ((long)tap * nsplit + s) * 4096;
 #pragma unroll
         for (int ib = 0; ib < 4; ++ib)
@@ -1034,9 +1054,9 @@ __global__ __launch_bounds__(256) void db_conv_wgrad_x3_kernel(const float* __re
     }
 }
 void launch_db_conv_wgrad_x3(LaunchCtx ctx, const float* dz, const float* a, int B, int T, int F, int dil, int nsplit,
-                             float* partial) {
+                             float* partial, float* colp) {
     LAUNCH(ctx, "dense_train_wgrad", (db_conv_wgrad_x3_kernel<<<6 * nsplit, 256, 0, ctx.stream>>>(dz, a, B, T, F, dil,
-                                                                                                      nsplit, partial)));
+                                                                                                      nsplit, partial, colp)));
 }
 
 // ---------------------------------------------------------------------------------
