@@ -229,6 +229,8 @@ extern "C" int cmgan_dense_train_backward(cmgan_handle* h, const float* x, const
     if (!h) return CMGAN_E_BADARG;
     if (!x || !dy || !dx || B <= 0 || T <= 0 || F <= 0 || !dense_params_ok(params) || !dense_params_ok(grads))
         return fail(h, CMGAN_E_BADARG, "cmgan_dense_train_backward: bad argument");
+    if (dx == x || dx == dy)                              // dx is accumulated in place while x and dy are still being read
+        return fail(h, CMGAN_E_BADARG, "cmgan_dense_train_backward: dx must not alias x or dy");
     if (int rc = check_ws(h, ws, ws_bytes, dense_train_ws_floats(B, T, F) * sizeof(float))) return rc;
     launch_dense_train_backward(begin(h, stream), x, dy, B, T, F, dense_params(params), dx, dense_params(grads),
                                 (float*)ws);

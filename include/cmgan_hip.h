@@ -296,7 +296,8 @@ int cmgan_layernorm_train_backward(cmgan_handle* h, const float* x_dev, const fl
  * norm{i}.weight/bias, prelu{i}.weight for i = 1..4 (index i-1 below).  The forward keeps the layer outputs, the raw
  * conv outputs and the InstanceNorm statistics in the workspace; the backward needs the SAME workspace untouched and
  * writes dL/dx and the twenty parameter gradients (the conv biases sit in front of an InstanceNorm, so their
- * gradients are zero up to rounding).                                                                            */
+ * gradients are zero up to rounding).  dx_dev is accumulated in place while the backward runs: it must not alias
+ * x_dev or dy_dev (dy_dev is read, never written).                                                               */
 typedef struct cmgan_dense_params {
     float *conv_weight[4], *conv_bias[4], *norm_weight[4], *norm_bias[4], *prelu_weight[4];
 } cmgan_dense_params;
