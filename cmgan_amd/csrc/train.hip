@@ -612,6 +612,9 @@ void cm_x3_bwd2(LaunchCtx, const float* x, const float* du, long M, const float*
 void cm_x3_pack_pw2(LaunchCtx, const ConvModTrainParams& p, float* img_w2, float* img_w2t);
 void cm_x3_bn_swish_pw2(LaunchCtx, const float* d, long M, const float* scale, const float* shift, const float* img_w2,
                         const float* b2, const float* res, float* y);
+int cm_x3_bwd1_fused(LaunchCtx, const float* dy, const float* d, long M, const float* mean, const float* rstd,
+                     const float* scale, const float* shift, const float* w2raw, float* ddn, float* g2c, float* ddnc, float* dyc,
+                     float* part_w2);
 void cm_x3_bwd1(LaunchCtx, const float* dy, const float* d, long M, const float* mean, const float* rstd, const float* scale,
                 const float* shift, const float* img_w2t, float* ddn, float* s_out, float* g2c, float* ddnc, float* dyc);
 void at_x3_pack(LaunchCtx, const float* wraw, float* img_w, float* img_wt);
@@ -1312,17 +1315,28 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
         LAUNCH(ctx, "convmod_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(X, M, C, cpart)));
         LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, C, out)));
     };
-    const long trows = (M + 15) / 16;                             // per-tile partial sums inside the g2 region [M,128]
+    long trows = (M + 15) / 16;                                   // per-tile partial sums inside the g2 region [M,128]
     float *g2c = ws + pl.g2, *ddnc = g2c + trows * 128, *dyc = ddnc + trows * 128;
+    int ns_pw2 = 0;                                               // > 0: dW_pw2's slabs already written (fused part 1)
 #if TRAIN_X3
-    cm_x3_bwd1(ctx, dy, ws + pl.d, M, st.mean, st.rstd, st.scale, st.shift, im.w2t, ws + pl.ddn, ws + pl.s, g2c, ddnc, dyc);
+    // default: part 1 with the pointwise-2 weight gradient contracted on the chip (train_x3.hip; s never leaves it; its
+    // partial-sum rows are per 32-token tile); CMGAN_CM_BWD1_FUSED=0: A/B
+    static const bool k_fused1 = env_knob("CMGAN_CM_BWD1_FUSED", 1, 0, 1) != 0;
+    if (k_fused1)
+        ns_pw2 = cm_x3_bwd1_fused(ctx, dy, ws + pl.d, M, st.mean, st.rstd, st.scale, st.shift, p.pw2_w, ws + pl.ddn, g2c, ddnc,
+                                  dyc, ws + pl.wpart);
+    if (ns_pw2) trows = (M + 31) / 32;
+    else cm_x3_bwd1(ctx, dy, ws + pl.d, M, st.mean, st.rstd, st.scale, st.shift, im.w2t, ws + pl.ddn, ws + pl.s, g2c, ddnc, dyc);
 #else
     LAUNCH(ctx, "convmod_train_bwd", (cm_bwd1_kernel<<<grid, 256, 0, s>>>(dy, ws + pl.d, M, st, im.w2t, ws + pl.ddn,
                                                                           ws + pl.s, g2c, ddnc, dyc)));
 #endif
     // pointwise-2 gradients: dW_pw2 [64,128] = dy^T s, db_pw2 = colsum dy
-    wgrad_partial64(ctx, "convmod_train_wgrad", dy, ws + pl.s, M, 64, 128, ws + pl.wpart, wg_split(2));
-    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<128, 1024, 0, s>>>(ws + pl.wpart, wg_split(2), 8192,
+    if (!ns_pw2) {
+        wgrad_partial64(ctx, "convmod_train_wgrad", dy, ws + pl.s, M, 64, 128, ws + pl.wpart, wg_split(2));
+        ns_pw2 = wg_split(2);
+    }
+    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<128, 1024, 0, s>>>(ws + pl.wpart, ns_pw2, 8192,
                                                                                    grad.pw2_w)));
     // BatchNorm: dbeta = sum ddn, dgamma = sum ddn dhat; then dd in place   (+ db_pw2 = colsum dy in the same pair of launches)
     {

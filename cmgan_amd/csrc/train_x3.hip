@@ -1820,6 +1820,231 @@ void cm_x3_bn_swish_pw2(LaunchCtx ctx, const float* d, long M, const float* scal
     LAUNCH(ctx, "convmod_train_fwd", (cm_bn_swish_pw2_x3_kernel<<<x3_grid8(ntiles), 512, 0, ctx.stream>>>(
                                          d, M, scale, shift, reinterpret_cast<const _Float16*>(img_w2), b2, res, y, ntiles)));
 }
+// ---------------------------------------------------------------------------------
+// conv module backward, part 1 WITH the pointwise-2 weight gradient contracted on the chip (the default;
+// CMGAN_CM_BWD1_FUSED=0 selects cm_bwd1_x3_kernel + a token-contraction launch).  Part 1 wrote s = Swish(BN(d)) [M,128]
+// only so that dW_pw2 = dy^T s could read it back with dy: 1 KB per token of round trip + dy twice more.  Same design as
+// ffn_train_bwd_aw_x3_kernel: 8 waves, wave w owns hidden channels 16 w .. 16 w + 15 (its column block of pw2 as a
+// register-resident B operand, its [16 x 64] block of dW_pw2 as accumulators); per 32-token tile the block stages dy once
+// (row-major planes: A operands of ds^T = dy W2; transposed planes: B operands of dW_pw2 += s^T dy; at the running exact
+// power-of-two scale) and d transposed in fp32; ds^T lands as (hidden c) x (tokens 4 g + r of both token blocks), where s
+// is computed - already the A operand of the weight gradient.  The BatchNorm partial sums (ddn dhat, ddn) per tile are a
+// lane sum + one cross-group reduce instead of eight 16-lane reductions.  Out: ddn [M,128], slab blockIdx.x of dW_pw2
+// [64][128], per-TILE (32 tokens) partial rows g2c / ddnc [tiles][128] and dyc [tiles][64].
+// ---------------------------------------------------------------------------------
+#define CB_PD 37                      // floats per row of the [hidden][token slot] plane of d (odd: conflict-free dword reads)
+struct CbImg {
+    _Float16 yh[32 * FA_PR], yl[32 * FA_PR];          // dy [token][out]
+    _Float16 yth[64 * FA_PT], ytl[64 * FA_PT];        // dy [out][token slot]
+    float dT[128 * CB_PD];                            // d  [hidden][token slot]
+};
+__global__ __launch_bounds__(512) void cm_bwd1_w_x3_kernel(const float* __restrict__ dy, const float* __restrict__ d, long M,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ w2, float* __restrict__ ddn,
+                                                           float* __restrict__ g2c, float* __restrict__ ddnc,
+                                                           float* __restrict__ dyc, float* __restrict__ part_w2, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cb_sm[];
+    CbImg* const img = reinterpret_cast<CbImg*>(cb_sm);                                   // [2]
+    float* const zmax_l = reinterpret_cast<float*>(cb_sm + 2 * sizeof(CbImg));            // [2][8]
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = gridDim.x;
+    const int nloc = (ntiles - (int)blockIdx.x + G - 1) / G;
+    const int hu = 16 * wv + c;                                   // this lane's hidden channel
+    // resident B operand: pw2 [64 out][128 hidden], slot (g, e) of k-step ks <-> out 32 ks + 8 g + e
+    f16x8 w2h[2], w2l[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        f32x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            a[e] = w2[(long)(32 * ks + 8 * g + e) * 128 + hu];
+            b[e] = w2[(long)(32 * ks + 8 * g + 4 + e) * 128 + hu];
+        }
+        split8(a, b, w2h[ks], w2l[ks]);
+    }
+    const float mu = mean[hu], rs = rstd[hu], sc_bn = scale[hu], sh_bn = shift[hu];
+    // staging role: token tk = 4 wv + g of the tile; dy channels 4 c .. 4 c + 3, d channels 8 c .. 8 c + 7
+    const int tk = 4 * wv + g;
+    const int pos = 8 * ((tk & 15) >> 2) + 4 * (tk >> 4) + (tk & 3);          // split8 slot order of token tk
+    auto rsrc = [](const void* base, long bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (unsigned)bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t y_rs = rsrc(dy, M * 256), d_rs = rsrc(d, M * 512), n_rs = rsrc(ddn, M * 512);
+    struct Raw { f32x4 y, d0, d1; bool ok; };
+    auto load = [&](int i) __attribute__((always_inline)) {
+        long tile = (long)blockIdx.x + (long)i * G;
+        const bool have = i < nloc;
+        tile = have ? tile : ntiles - 1;                          // past the end: a readable dummy, contributes nothing
+        const int rem = (int)(M - tile * 32 < 32 ? M - tile * 32 : 32);
+        Raw r;
+        r.ok = have && tk < rem;
+        const unsigned trow = (unsigned)(tk < rem ? tk : rem - 1);
+        r.y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(y_rs, trow * 256 + 16 * c, (unsigned)tile * 8192u, 0));
+        r.d0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d_rs, trow * 512 + 32 * c, (unsigned)tile * 16384u, 0));
+        r.d1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(d_rs, trow * 512 + 32 * c + 16, (unsigned)tile * 16384u, 0));
+        if (!r.ok) r.y = splat4(0.f);
+        return r;
+    };
+    auto post_max = [&](const Raw& r, int buf) __attribute__((always_inline)) {
+        const float mx = tx_wave_max(tx_absmax4(r.y, 0.f));
+        if (lane == 0) zmax_l[buf * 8 + wv] = mx;
+    };
+    auto uni = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+    float s_run = 1.f, inv_run = 1.f;
+    bool fresh = true;
+    auto decide = [&](int buf) __attribute__((always_inline)) {
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m = fmaxf(m, zmax_l[buf * 8 + k]);
+        const float ms_ = m * s_run;
+        if (m > 0.f && (fresh || ms_ > 8192.f || ms_ < 0.25f)) {
+            tx_pow2(m, s_run, inv_run);
+            fresh = false;
+        }
+        s_run = uni(s_run);
+        inv_run = uni(inv_run);
+    };
+    auto write_images = [&](int buf, const Raw& r, float sc) __attribute__((always_inline)) {
+        CbImg& I = img[buf];
+        f16x4 h, l;
+        split4(r.y * splat4(sc), h, l);
+        *reinterpret_cast<f16x4*>(&I.yh[tk * FA_PR + 4 * c]) = h;
+        *reinterpret_cast<f16x4*>(&I.yl[tk * FA_PR + 4 * c]) = l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            I.yth[(4 * c + e) * FA_PT + pos] = h[e];
+            I.ytl[(4 * c + e) * FA_PT + pos] = l[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            I.dT[(8 * c + e) * CB_PD + pos] = r.d0[e];
+            I.dT[(8 * c + 4 + e) * CB_PD + pos] = r.d1[e];
+        }
+    };
+    f32x4 acc[4];                                                 // dW_pw2 [hidden 4 g + r][out 16 ob + c]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = splat4(0.f);
+    float sA = 1.f, invA = 1.f;
+    auto consume = [&](int i, int buf, float sc, float inv) __attribute__((always_inline)) {
+        const CbImg& I = img[buf];
+        const long tile = (long)blockIdx.x + (long)i * G;
+        const int rem = (int)(M - tile * 32 < 32 ? M - tile * 32 : 32);
+        f32x4 ds[2] = {splat4(0.f), splat4(0.f)};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const int o = (16 * tb + c) * FA_PR + 32 * ks + 8 * g;
+                const f16x8 zh = *reinterpret_cast<const f16x8*>(&I.yh[o]), zl = *reinterpret_cast<const f16x8*>(&I.yl[o]);
+                ds[tb] = mfma32h(zh, w2h[ks], ds[tb]);
+                ds[tb] = mfma32l(zh, w2l[ks], ds[tb]);
+                ds[tb] = mfma32l(zl, w2h[ks], ds[tb]);
+            }
+        f32x4 sv[2];
+        float ca = 0.f, cb = 0.f;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dv = I.dT[hu * CB_PD + 8 * g + 4 * tb + r];
+                const float dhat = (dv - mu) * rs, dn = fmaf(dv, sc_bn, sh_bn), sg = sigmoidf_fast(dn);
+                sv[tb][r] = dn * sg;
+                const float o_ddn = (ds[tb][r] * inv) * (sg * fmaf(dn, 1.f - sg, 1.f));   // tokens past M: dy = 0 -> 0
+                ca = fmaf(o_ddn, dhat, ca);
+                cb += o_ddn;
+                const int tok = 16 * tb + 4 * g + r;
+                // a token past M gets an offset beyond num_records: the hardware drops the store (the range check sees the
+                // per-lane offset only; the launcher keeps the tensor under 2 GB)
+                const unsigned vo = tok < rem ? (unsigned)((tok * 128 + hu) * 4) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o_ddn), n_rs, vo, (unsigned)tile * 16384u, 0);
+            }
+        ca = red_g_sum(ca);
+        cb = red_g_sum(cb);
+        if (g == 0) {
+            g2c[tile * 128 + hu] = ca;
+            ddnc[tile * 128 + hu] = cb;
+        }
+        if (sc != sA) {
+            const float ratio = sc * invA;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = acc[k] * splat4(ratio);
+            sA = sc; invA = inv;
+        }
+        f16x8 sh, sl;
+        split8(sv[0], sv[1], sh, sl);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+            const int o = (16 * ob + c) * FA_PT + 8 * g;
+            const f16x8 zh = fa_ld8(&I.yth[o]), zl = fa_ld8(&I.ytl[o]);
+            acc[ob] = mfma32h(sh, zh, acc[ob]);
+            acc[ob] = mfma32l(sh, zl, acc[ob]);
+            acc[ob] = mfma32l(sl, zh, acc[ob]);
+            if (wv == ob) {                                       // db_pw2 partial of the tile: column sums of dy (hi + lo: 2^-22)
+                float sm = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm += (float)zh[e] + (float)zl[e];
+                sm = red_g_sum(sm) * inv;
+                if (g == 0) dyc[tile * 64 + 16 * ob + c] = sm;
+            }
+        }
+    };
+    Raw pc = load(0);
+    post_max(pc, 0);
+    __syncthreads();
+    decide(0);
+    float s_cur = s_run, inv_cur = inv_run;
+    write_images(0, pc, s_cur);
+    pc = load(1);
+    post_max(pc, 1);
+    __syncthreads();
+#pragma unroll 1
+    for (int i = 0; i < nloc; ++i) {
+        const int buf = i & 1;
+        const Raw r2 = load(i + 2);
+        decide(buf ^ 1);
+        const float s_nxt = s_run, inv_nxt = inv_run;
+        write_images(buf ^ 1, pc, s_nxt);
+        consume(i, buf, s_cur, inv_cur);
+        post_max(r2, buf);
+        pc = r2;
+        __syncthreads();
+        s_cur = s_nxt; inv_cur = inv_nxt;
+    }
+    float* slab = part_w2 + (long)blockIdx.x * 8192;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        stg4(slab + (unsigned)((16 * k + c) * 128 + 16 * wv + 4 * g), acc[k] * splat4(invA));
+}
+// returns the number of slabs of dW_pw2 written (0: take cm_x3_bwd1 + the token contraction)
+int cm_x3_bwd1_fused(LaunchCtx ctx, const float* dy, const float* d, long M, const float* mean, const float* rstd,
+                     const float* scale, const float* shift, const float* w2raw, float* ddn, float* g2c, float* ddnc, float* dyc,
+                     float* part_w2) {
+    if (M * 512 >= (1l << 31)) return 0;                          // 32-bit offsets, 2^31 marks tokens past M
+    const void* fn = reinterpret_cast<const void*>(&cm_bwd1_w_x3_kernel);
+    const size_t lds = 2 * sizeof(CbImg) + 16 * sizeof(float);
+    static std::mutex mu;
+    static std::map<int, bool> optin;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = optin.find(dev);
+        if (it == optin.end()) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) (void)hipGetLastError();
+            it = optin.emplace(dev, e == hipSuccess).first;
+        }
+        if (!it->second) return 0;
+    }
+    const int ntiles = (int)((M + 31) / 32);
+    const int grid = ntiles < 512 ? ntiles : 512;                 // 114 VGPRs, 74 KB of LDS: two blocks per CU; the slab buffer
+                                                                  // (WG_SPLIT x 16384 floats) holds 512 slabs of 8192
+    LAUNCH(ctx, "convmod_train_bwd", (cm_bwd1_w_x3_kernel<<<grid, 512, lds, ctx.stream>>>(dy, d, M, mean, rstd, scale, shift, w2raw,
+                                                                                           ddn, g2c, ddnc, dyc, part_w2, ntiles)));
+    return grid;
+}
 void cm_x3_bwd1(LaunchCtx ctx, const float* dy, const float* d, long M, const float* mean, const float* rstd, const float* scale,
                 const float* shift, const float* img_w2t, float* ddn, float* s_out, float* g2c, float* ddnc, float* dyc) {
     const int ntiles = (int)((M + 15) / 16);
