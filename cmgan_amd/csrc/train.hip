@@ -612,6 +612,9 @@ void cm_x3_bwd2(LaunchCtx, const float* x, const float* du, long M, const float*
 void cm_x3_pack_pw2(LaunchCtx, const ConvModTrainParams& p, float* img_w2, float* img_w2t);
 void cm_x3_bn_swish_pw2(LaunchCtx, const float* d, long M, const float* scale, const float* shift, const float* img_w2,
                         const float* b2, const float* res, float* y);
+int cm_x3_bwd2_fused(LaunchCtx, const float* x, const float* du, long M, const float* img_w1t, const ConvModTrainParams& p,
+                     const float* dres, float* dx, float* dag, float* o_g1, float* o_dxn, float* o_dhc, float* dhmax,
+                     float* part_w1);
 int cm_x3_bwd1_fused(LaunchCtx, const float* dy, const float* d, long M, const float* mean, const float* rstd,
                      const float* scale, const float* shift, const float* w2raw, float* ddn, float* g2c, float* ddnc, float* dyc,
                      float* part_w2);
@@ -1360,6 +1363,20 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
                                                                                       ws + pl.du, nullptr)));
     }
 #if TRAIN_X3
+    // default: part 2 split like the FeedForward's backward - LN / GLU backward / [da ; dg] + dW_pw1 on the chip, then the
+    // FeedForward's own part B on pw1's image (train_x3.hip); CMGAN_CM_BWD2_FUSED=0: A/B
+    static const bool k_fused2 = env_knob("CMGAN_CM_BWD2_FUSED", 1, 0, 1) != 0;
+    const long t32 = (M + 31) / 32;
+    float* dhc = ws + pl.dxn + t32 * 64;                          // [tiles][256] partials of db_pw1 behind the [tiles][64] dxn rows
+    const int ns_pw1 = !k_fused2 ? 0
+        : cm_x3_bwd2_fused(ctx, x, ws + pl.du, M, im.w1t, p, dres, dx, ws + pl.dag, ws + pl.g1, ws + pl.dxn, dhc,
+                           cpart + (size_t)3 * FFN_COLSUM_BLOCKS * 256, ws + pl.wpart);
+    if (ns_pw1) {
+        LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(ws + pl.wpart, ns_pw1, 16384, grad.pw1_w)));
+        const ColsumJobs jobs{{dhc, ws + pl.g1, ws + pl.dxn}, {grad.pw1_b, grad.ln_w, grad.ln_b}, {256, 64, 64}, {t32, t32, t32}};
+        colsum_batch(ctx, "convmod_train_reduce", jobs, 3, M, cpart);
+        return;
+    }
     cm_x3_bwd2(ctx, x, ws + pl.du, M, im.w1, im.w1t, p, dres, dx, ws + pl.dag, ws + pl.xn, ws + pl.g1, ws + pl.dxn);
 #else
     LAUNCH(ctx, "convmod_train_bwd", (cm_bwd2_kernel<<<grid, 256, 0, s>>>(x, ws + pl.du, M, im.w1, im.w1t, p, dres, dx,

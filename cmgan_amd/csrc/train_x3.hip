@@ -2045,6 +2045,256 @@ int cm_x3_bwd1_fused(LaunchCtx ctx, const float* dy, const float* d, long M, con
                                                                                            ddn, g2c, ddnc, dyc, part_w2, ntiles)));
     return grid;
 }
+// ---------------------------------------------------------------------------------
+// conv module backward, part 2 split like the FeedForward's (the default; CMGAN_CM_BWD2_FUSED=0 selects cm_bwd2_x3_kernel
+// + a token-contraction launch):  part A'' (here) = LayerNorm, a / gate recomputed, GLU backward, [da ; dg] stored, the
+// pointwise-1 weight gradient contracted on the chip;  part B = ffn_train_bwd_b_x3_kernel AS IT IS (dxn = pw1^T [da ; dg],
+// LayerNorm backward, residual, per-tile partial sums - pw1 has the FeedForward's W1 shape).  cm_bwd2_x3_kernel wrote
+// [da ; dg] [M,256] and xn [M,64] for the token contraction to read back: 1.3 KB per token of the 4.9 KB the pair moved.
+// Wave w owns GLU channels 16 w .. 16 w + 15: rows 16 w + c (a) and 128 + 16 w + c (gate) of pw1 as register-resident B
+// operands, their two [16 x 64] blocks of dW_pw1 as accumulators.  du [M,128] is a gradient: staged (transposed, fp32) at the
+// running exact power-of-two scale; da, dg are then at that scale for the weight-gradient products and stored times its
+// inverse.  Staging / pipeline as ffn_train_bwd_aw_x3_kernel.
+// ---------------------------------------------------------------------------------
+struct CcImg {
+    _Float16 xnh[32 * FA_PR], xnl[32 * FA_PR];        // xn [token][channel]
+    _Float16 xth[64 * FA_PT], xtl[64 * FA_PT];        // xn [channel][token slot]
+    float duT[128 * CB_PD];                           // du (scaled) [GLU channel][token slot]
+};
+__global__ __launch_bounds__(512) void cm_bwd2_aw_x3_kernel(const float* __restrict__ x, const float* __restrict__ du, long M,
+                                                            ConvModTrainParams p, float* __restrict__ dag,
+                                                            float* __restrict__ o_dhmax, float* __restrict__ part_w1, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cc_sm[];
+    CcImg* const img = reinterpret_cast<CcImg*>(cc_sm);                                   // [2]
+    float* const zmax_l = reinterpret_cast<float*>(cc_sm + 2 * sizeof(CcImg));            // [2][8]
+    unsigned* const dhmax_l = reinterpret_cast<unsigned*>(zmax_l + 16);                   // [2]
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int G = gridDim.x;
+    const int nloc = (ntiles - (int)blockIdx.x + G - 1) / G;
+    if (threadIdx.x < 2) dhmax_l[threadIdx.x] = 0u;
+    // resident B operands: hb 0 = row 16 wv + c of pw1 (a), hb 1 = row 128 + 16 wv + c (gate); slot (g, e) of k-step ks <->
+    // input channel 32 ks + 8 g + e
+    f16x8 w1h[2][2], w1l[2][2];
+    float b1c[2];
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb) {
+        const int hu = 128 * hb + 16 * wv + c;
+        b1c[hb] = p.pw1_b[hu];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* wp = p.pw1_w + (long)hu * 64 + 32 * ks + 8 * g;
+            split8(ldg4(wp), ldg4(wp + 4), w1h[hb][ks], w1l[hb][ks]);
+        }
+    }
+    const int tk = 4 * wv + g;                                    // staging role: token tk, x channels 4 c .., du channels 8 c ..
+    const int pos = 8 * ((tk & 15) >> 2) + 4 * (tk >> 4) + (tk & 3);
+    const f32x4 gam = ldg4(p.ln_w + 4 * c), bet = ldg4(p.ln_b + 4 * c);
+    auto rsrc = [](const void* base, long bytes) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (unsigned)bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t x_rs = rsrc(x, M * 256), u_rs = rsrc(du, M * 512), o_rs = rsrc(dag, M * 1024);
+    struct Raw { f32x4 x, u0, u1; bool ok; };
+    struct Proc { f32x4 xn, u0, u1; };
+    auto load = [&](int i) __attribute__((always_inline)) {
+        long tile = (long)blockIdx.x + (long)i * G;
+        const bool have = i < nloc;
+        tile = have ? tile : ntiles - 1;
+        const int rem = (int)(M - tile * 32 < 32 ? M - tile * 32 : 32);
+        Raw r;
+        r.ok = have && tk < rem;
+        const unsigned trow = (unsigned)(tk < rem ? tk : rem - 1);
+        r.x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, trow * 256 + 16 * c, (unsigned)tile * 8192u, 0));
+        r.u0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rs, trow * 512 + 32 * c, (unsigned)tile * 16384u, 0));
+        r.u1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rs, trow * 512 + 32 * c + 16, (unsigned)tile * 16384u, 0));
+        return r;
+    };
+    auto process = [&](const Raw& r, Proc& q, int buf) __attribute__((always_inline)) {
+        const float mean = red_c_sum((r.x[0] + r.x[1]) + (r.x[2] + r.x[3])) * (1.0f / 64.0f);
+        const f32x4 d = r.x - splat4(mean);
+        const float rstd = rsqrtf(red_c_sum(fmaf(d[0], d[0], d[1] * d[1]) + fmaf(d[2], d[2], d[3] * d[3])) * (1.0f / 64.0f) + CMGAN_EPS);
+        q.xn = d * splat4(rstd) * gam + bet;
+        q.u0 = r.ok ? r.u0 : splat4(0.f);
+        q.u1 = r.ok ? r.u1 : splat4(0.f);
+        const float mx = tx_wave_max(tx_absmax4(q.u1, tx_absmax4(q.u0, 0.f)));
+        if (lane == 0) zmax_l[buf * 8 + wv] = mx;
+    };
+    auto uni = [](float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); };
+    float s_run = 1.f, inv_run = 1.f;
+    bool fresh = true;
+    auto decide = [&](int buf) __attribute__((always_inline)) {
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m = fmaxf(m, zmax_l[buf * 8 + k]);
+        const float ms_ = m * s_run;
+        if (m > 0.f && (fresh || ms_ > 8192.f || ms_ < 0.25f)) {
+            tx_pow2(m, s_run, inv_run);
+            fresh = false;
+        }
+        s_run = uni(s_run);
+        inv_run = uni(inv_run);
+    };
+    auto write_images = [&](int buf, const Proc& q, float sc) __attribute__((always_inline)) {
+        CcImg& I = img[buf];
+        f16x4 h, l;
+        split4(q.xn, h, l);
+        *reinterpret_cast<f16x4*>(&I.xnh[tk * FA_PR + 4 * c]) = h;
+        *reinterpret_cast<f16x4*>(&I.xnl[tk * FA_PR + 4 * c]) = l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            I.xth[(4 * c + e) * FA_PT + pos] = h[e];
+            I.xtl[(4 * c + e) * FA_PT + pos] = l[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            I.duT[(8 * c + e) * CB_PD + pos] = q.u0[e] * sc;
+            I.duT[(8 * c + 4 + e) * CB_PD + pos] = q.u1[e] * sc;
+        }
+    };
+    f32x4 acc[2][4];                                              // dW_pw1 [row 128 hb + 16 wv + 4 g + r][in 16 cb + c]
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[hb][k] = splat4(0.f);
+    float sA = 1.f, invA = 1.f;
+    auto consume = [&](int i, int buf, float sc, float inv) __attribute__((always_inline)) {
+        const CcImg& I = img[buf];
+        const long tile = (long)blockIdx.x + (long)i * G;
+        const int rem = (int)(M - tile * 32 < 32 ? M - tile * 32 : 32);
+        f32x4 ag[2][2];                                           // [hb: a | gate][tb]   (the biases are added below)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) ag[hb][tb] = splat4(0.f);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const int o = (16 * tb + c) * FA_PR + 32 * ks + 8 * g;
+                const f16x8 ah = *reinterpret_cast<const f16x8*>(&I.xnh[o]), al = *reinterpret_cast<const f16x8*>(&I.xnl[o]);
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) ag[hb][tb] = mfma32h(ah, w1h[hb][ks], ag[hb][tb]);
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) ag[hb][tb] = mfma32l(ah, w1l[hb][ks], ag[hb][tb]);
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) ag[hb][tb] = mfma32l(al, w1h[hb][ks], ag[hb][tb]);
+            }
+        f32x4 dav[2], dgv[2];
+        float dhm = 0.f;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float duv = I.duT[(16 * wv + c) * CB_PD + 8 * g + 4 * tb + r];          // at scale sc; 0 past M
+                const float av = ag[0][tb][r] + b1c[0], sg = sigmoidf_fast(ag[1][tb][r] + b1c[1]);
+                const float da = duv * sg, dg = duv * av * sg * (1.f - sg);
+                dav[tb][r] = da;
+                dgv[tb][r] = dg;
+                const float dat = da * inv, dgt = dg * inv;
+                dhm = fmaxf(dhm, fmaxf(fabsf(dat), fabsf(dgt)));
+                const int tok = 16 * tb + 4 * g + r;
+                // (a token past M gets an offset beyond num_records: the store is dropped; the launcher keeps dag under 2 GB)
+                const unsigned vo = tok < rem ? (unsigned)((tok * 256 + 16 * wv + c) * 4) : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dat), o_rs, vo, (unsigned)tile * 32768u, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dgt), o_rs, vo + 512u, (unsigned)tile * 32768u, 0);
+            }
+        dhm = tx_wave_max(dhm);
+        if (lane == 0) atomicMax(&dhmax_l[i & 1], __float_as_uint(dhm));
+        if (sc != sA) {
+            const float ratio = sc * invA;
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[hb][k] = acc[hb][k] * splat4(ratio);
+            sA = sc; invA = inv;
+        }
+        f16x8 dh_[2], dl_[2];
+        split8(dav[0], dav[1], dh_[0], dl_[0]);
+        split8(dgv[0], dgv[1], dh_[1], dl_[1]);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int o = (16 * cb + c) * FA_PT + 8 * g;
+            const f16x8 xh = fa_ld8(&I.xth[o]), xl = fa_ld8(&I.xtl[o]);
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) acc[hb][cb] = mfma32h(dh_[hb], xh, acc[hb][cb]);
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) acc[hb][cb] = mfma32l(dh_[hb], xl, acc[hb][cb]);
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) acc[hb][cb] = mfma32l(dl_[hb], xh, acc[hb][cb]);
+        }
+    };
+    Raw rw = load(0);
+    Proc pc;
+    process(rw, pc, 0);
+    __syncthreads();
+    decide(0);
+    float s_cur = s_run, inv_cur = inv_run;
+    write_images(0, pc, s_cur);
+    rw = load(1);
+    process(rw, pc, 1);
+    __syncthreads();
+#pragma unroll 1
+    for (int i = 0; i < nloc; ++i) {
+        const int buf = i & 1;
+        if (wv == 0 && lane == 0 && i > 0) {
+            o_dhmax[(long)blockIdx.x + (long)(i - 1) * G] = __uint_as_float(dhmax_l[buf ^ 1]);
+            dhmax_l[buf ^ 1] = 0u;
+        }
+        const Raw r2 = load(i + 2);
+        decide(buf ^ 1);
+        const float s_nxt = s_run, inv_nxt = inv_run;
+        write_images(buf ^ 1, pc, s_nxt);
+        consume(i, buf, s_cur, inv_cur);
+        process(r2, pc, buf);
+        __syncthreads();
+        s_cur = s_nxt; inv_cur = inv_nxt;
+    }
+    if (wv == 0 && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
+        o_dhmax[(long)blockIdx.x + (long)(nloc - 1) * G] = __uint_as_float(dhmax_l[(nloc - 1) & 1]);
+    float* slab = part_w1 + (long)blockIdx.x * 16384;
+    int ce = c, ge = g;
+    asm volatile("" : "+v"(ce), "+v"(ge));
+#pragma unroll
+    for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab[(unsigned)((128 * hb + 16 * wv + 4 * ge + r) * 64 + 16 * k + ce)] = acc[hb][k][r] * invA;
+}
+// part A'' then the FeedForward's part B on pw1's images.  Returns the number of slabs of dW_pw1 written (0: the caller takes
+// cm_x3_bwd2 + the token contraction).  o_g1 / o_dxn / o_dhc: per-32-token-tile partial rows ([tiles][64], [tiles][64],
+// [tiles][256] = the pw1 bias gradient's partials); dhmax: one float per tile.
+int cm_x3_bwd2_fused(LaunchCtx ctx, const float* x, const float* du, long M, const float* img_w1t, const ConvModTrainParams& p,
+                     const float* dres, float* dx, float* dag, float* o_g1, float* o_dxn, float* o_dhc, float* dhmax,
+                     float* part_w1) {
+    if (M * 1024 >= (1l << 31)) return 0;
+    const void* fn = reinterpret_cast<const void*>(&cm_bwd2_aw_x3_kernel);
+    const size_t lds = 2 * sizeof(CcImg) + 18 * sizeof(float);
+    static std::mutex mu;
+    static std::map<int, bool> optin;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = optin.find(dev);
+        if (it == optin.end()) {
+            const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) (void)hipGetLastError();
+            it = optin.emplace(dev, e == hipSuccess).first;
+        }
+        if (!it->second) return 0;
+    }
+    const int ntiles = (int)((M + 31) / 32);
+    const int grid = ntiles < 256 ? ntiles : 256;
+    LAUNCH(ctx, "convmod_train_bwd", (cm_bwd2_aw_x3_kernel<<<grid, 512, lds, ctx.stream>>>(x, du, M, p, dag, dhmax, part_w1, ntiles)));
+    const FfnTrainParams lnp{p.ln_w, p.ln_b, nullptr, nullptr, nullptr, nullptr};       // part B reads gamma / beta only
+    const int gridb = (ntiles + 7) / 8 < 512 ? ((ntiles + 7) / 8 > 0 ? (ntiles + 7) / 8 : 1) : 512;
+    LAUNCH(ctx, "convmod_train_bwd", (ffn_train_bwd_b_x3_kernel<<<gridb, 512, 0, ctx.stream>>>(
+                                         x, dag, dhmax, M, reinterpret_cast<const _Float16*>(img_w1t), lnp, dres, dx, o_g1, o_dxn,
+                                         o_dhc, ntiles)));
+    return grid;
+}
 void cm_x3_bwd1(LaunchCtx ctx, const float* dy, const float* d, long M, const float* mean, const float* rstd, const float* scale,
                 const float* shift, const float* img_w2t, float* ddn, float* s_out, float* g2c, float* ddnc, float* dyc) {
     const int ntiles = (int)((M + 15) / 16);

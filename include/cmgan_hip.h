@@ -533,8 +533,8 @@ int cmgan_profile_read(cmgan_handle* h, cmgan_kernel_time* out, int cap);
  *   CMGAN_ASP_TPB_LONG=1..64, CMGAN_ASP_GROUP_LONG=1..4096, CMGAN_ASP_GROUP_SHORT=1..4096, CMGAN_ASP_ALIGN_SHORT=0|1,
  *   CMGAN_ASP_SLOTS=8..65536, CMGAN_ASP_TAILK=0|1    tile order / block shape of the attention kernel
  *   CMGAN_STFT_FFT=0|1         front / back end as 16 x 25 real FFTs (1, default) or the folded DFT products (0)
- *   CMGAN_FFN_BWD_FUSED=0|1, CMGAN_CM_BWD1_FUSED=0|1
- *                              training: FeedForward backward / conv-module backward part 1 with their weight gradients
+ *   CMGAN_FFN_BWD_FUSED=0|1, CMGAN_CM_BWD1_FUSED=0|1, CMGAN_CM_BWD2_FUSED=0|1
+ *                              training: FeedForward backward / conv-module backward parts 1 and 2 with their weight gradients
  *                              contracted on the chip (1, default) or the un-fused kernels + token-contraction launches (0)
  *   CMGAN_RC_FWD_X3=0|1, CMGAN_RC_WGRAD_X3=0|1, CMGAN_RC_DGRAD_X3=0|1
  *                              training: forward (through the inference kernels), weight gradient and data gradient of the
