@@ -941,38 +941,73 @@ __global__ __launch_bounds__(256) void db_conv_wgrad_x3_kernel(const float* __re
     bool fresh = true;
     const bool want_cs = colp != nullptr && tap == 0;             // block-uniform
     f32x4 csum = splat4(0.f);                                     // [ib]: this lane's positions of channel 16 ib + c
-    for (unsigned st = st0 + wv; st < st1; st += 4) {
-        const unsigned m0 = st * 32 + 8 * g;
-        unsigned bb = m0 / tf;
+    // (t, f, clip) of this lane's first position, carried from step to step (a step advances every lane by 128 positions);
+    // PMC: 585 VALU instructions per wave and step against 48 MFMAs - the matrix pipe 21 % busy, the vector ALU 64 %:
+    // two divisions, 16 address computations, 64 selects.  INTERIOR steps (every lane's eight positions inside one row, the
+    // tap in range for all of them: ~70 % of the steps at F = 101) need none of the per-position work: both operand runs are
+    // contiguous rows, fetched as base + immediate.
+    unsigned m0 = (st0 + wv) * 32 + 8 * g;
+    unsigned bb = m0 / tf;
+    int t, f;
+    {
         const unsigned rem = m0 - bb * tf;
-        int t = (int)(rem / (unsigned)F), f = (int)(rem - (unsigned)t * F);
+        t = (int)(rem / (unsigned)F);
+        f = (int)(rem - (unsigned)t * F);
+    }
+    const int adv_t = 128 / F, adv_f = 128 - adv_t * F;           // 128 positions = adv_t rows + adv_f (uniform)
+    for (unsigned st = st0 + wv; st < st1; st += 4) {
         f32x4 av[4][2], bv[4][2];                     // [block][e >> 2][e & 3]
         float mx = 0.f;
-        // 32-bit BYTE offsets from the (uniform) plane bases: a plane is at most 2^32 bytes (checked by the launcher), so
-        // every load is "saddr + lane offset + immediate" with no 64-bit VALU arithmetic per element
+        const int ts0 = t + dt;
+        const bool interior = m0 + 7u < M && f + df >= 0 && f + 7 + df < F && f + 7 < F && ts0 >= 0 && ts0 < T;
+        if (__builtin_amdgcn_ballot_w64(!interior) == 0ull) {
+            // 32-bit BYTE offsets from the (uniform) plane bases (a plane is at most 2^32 bytes: checked by the launcher)
+            const unsigned oz0 = (m0 * 64u + (unsigned)c) * 4u;
+            const unsigned oa0 = ((unsigned)((int)m0 + dt * F + df) * 64u + (unsigned)c) * 4u;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const unsigned m = m0 + e;
-            const bool ok = m < M;
-            const int ts = t + dt, fs = f + df;
-            const bool inb = ok && ts >= 0 && ts < T && fs >= 0 && fs < F;
-            const unsigned src = inb ? ((bb * (unsigned)T + (unsigned)ts) * (unsigned)F + (unsigned)fs) : 0u;
-            const unsigned mm = ok ? m : M - 1u;
-            const unsigned oz = (mm * 64u + (unsigned)c) * 4u, oa = (src * 64u + (unsigned)c) * 4u;
+            for (int e = 0; e < 8; ++e) {
 #pragma unroll
-            for (int ib = 0; ib < 4; ++ib) {
-                const float v0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dz + 16 * ib) + oz);
-                const float v = ok ? v0 : 0.f;
-                av[ib][e >> 2][e & 3] = v;
-                mx = fmaxf(mx, fabsf(v));
+                for (int ib = 0; ib < 4; ++ib) {
+                    const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dz + 16 * ib) + oz0 + 256u * e);
+                    av[ib][e >> 2][e & 3] = v;
+                    mx = fmaxf(mx, fabsf(v));
+                }
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb)
+                    bv[jb][e >> 2][e & 3] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a + 16 * jb) + oa0 + 256u * e);
             }
+        } else {
+            unsigned bbe = bb;
+            int te = t, fe = f;
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb) {
-                const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a + 16 * jb) + oa);
-                bv[jb][e >> 2][e & 3] = inb ? v : 0.f;
+            for (int e = 0; e < 8; ++e) {
+                const unsigned m = m0 + e;
+                const bool ok = m < M;
+                const int ts = te + dt, fs = fe + df;
+                const bool inb = ok && ts >= 0 && ts < T && fs >= 0 && fs < F;
+                const unsigned src = inb ? ((bbe * (unsigned)T + (unsigned)ts) * (unsigned)F + (unsigned)fs) : 0u;
+                const unsigned mm = ok ? m : M - 1u;
+                const unsigned oz = (mm * 64u + (unsigned)c) * 4u, oa = (src * 64u + (unsigned)c) * 4u;
+#pragma unroll
+                for (int ib = 0; ib < 4; ++ib) {
+                    const float v0 = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(dz + 16 * ib) + oz);
+                    const float v = ok ? v0 : 0.f;
+                    av[ib][e >> 2][e & 3] = v;
+                    mx = fmaxf(mx, fabsf(v));
+                }
+#pragma unroll
+                for (int jb = 0; jb < 4; ++jb) {
+                    const float v = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a + 16 * jb) + oa);
+                    bv[jb][e >> 2][e & 3] = inb ? v : 0.f;
+                }
+                if (++fe == F) { fe = 0; if (++te == T) { te = 0; ++bbe; } }
             }
-            if (++f == F) { f = 0; if (++t == T) { t = 0; ++bb; } }
         }
+        // the same lane, four steps (128 positions) on
+        m0 += 128u;
+        f += adv_f; t += adv_t;
+        if (f >= F) { f -= F; ++t; }
+        while (t >= T) { t -= T; ++bb; }
         if (want_cs) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
