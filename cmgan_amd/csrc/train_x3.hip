@@ -432,7 +432,8 @@ __global__ __launch_bounds__(512) void ffn_train_bwd_b_x3_kernel(const float* __
 //     wave takes the same decision).  dd1 and dh are then AT SCALE s in registers: well inside fp16 range for the dW1
 //     product; dh is stored multiplied by 1 / s, the accumulators are rescaled by the exact ratio when s moves.
 // ---------------------------------------------------------------------------------
-#define FA_PR 72                      // halfs per row of the [token][channel] planes (144 B: conflict-free b128 reads)
+#define FA_PR 80                      // halfs per row of the [token][channel] planes (160 B: conflict-free ds_read_b128 under the
+                                      // instruction's lane grouping {0-3,12-15,20-27} ...; 144 B was 2-way)
 #define FA_PT 36                      // halfs per row of the [channel][token slot] planes (72 B: b64 reads, 2-way stores)
 struct FaImg {
     _Float16 xnh[32 * FA_PR], xnl[32 * FA_PR], dzh[32 * FA_PR], dzl[32 * FA_PR];
