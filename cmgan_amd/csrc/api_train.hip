@@ -55,8 +55,10 @@ extern "C" int cmgan_ffn_train_backward(cmgan_handle* h, const float* x, const f
     if (!x || !dy || !dx || M <= 0 || !ffn_params_ok(params) || !ffn_params_ok(grads))
         return fail(h, CMGAN_E_BADARG, "cmgan_ffn_train_backward: bad argument");
     if (int rc = check_ws(h, ws, ws_bytes, ffn_train_ws_floats((long)M) * sizeof(float))) return rc;
-    launch_ffn_train_backward(begin(h, stream), x, dy, (long)M, ffn_params(params), mask1, mask2, mask_scale,
-                              dresidual, dx, ffn_params(grads), (float*)ws);
+    if (!launch_ffn_train_backward(begin(h, stream), x, dy, (long)M, ffn_params(params), mask1, mask2, mask_scale,
+                                   dresidual, dx, ffn_params(grads), (float*)ws))
+        return fail(h, CMGAN_E_BADARG, "cmgan_ffn_train_backward: one keep-mask without the other (or a device that refuses the "
+                                       "fused kernel's LDS) needs the un-fused workspace: set CMGAN_FFN_BWD_FUSED=0");
     return check_launch(h, "ffn_train_backward");
 }
 
@@ -95,8 +97,10 @@ extern "C" int cmgan_convmod_train_backward(cmgan_handle* h, const float* x, con
     if (!x || !dy || !dx || N <= 0 || L <= 0 || !convmod_params_ok(params) || !convmod_params_ok(grads))
         return fail(h, CMGAN_E_BADARG, "cmgan_convmod_train_backward: bad argument");
     if (int rc = check_ws(h, ws, ws_bytes, convmod_train_ws_floats(N, L) * sizeof(float))) return rc;
-    launch_convmod_train_backward(begin(h, stream), x, dy, N, L, convmod_params(params), dresidual, dx,
-                                  convmod_params(grads), (float*)ws);
+    if (!launch_convmod_train_backward(begin(h, stream), x, dy, N, L, convmod_params(params), dresidual, dx,
+                                  convmod_params(grads), (float*)ws))
+        return fail(h, CMGAN_E_BADARG, "cmgan_convmod_train_backward: the device refused a fused backward kernel's LDS; set "
+                                       "CMGAN_CM_BWD1_FUSED=0 CMGAN_CM_BWD2_FUSED=0 (un-fused workspace)");
     return check_launch(h, "convmod_train_backward");
 }
 

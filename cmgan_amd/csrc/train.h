@@ -24,7 +24,8 @@ size_t ffn_train_ws_floats(long M);
 // connection of conformer.py:216-219 fused into the branch (y = res + f(x); dx = dres + f'(dy)); NULL = none.
 void launch_ffn_train_forward(LaunchCtx, const float* x, long M, const FfnTrainParams& p, const unsigned char* m1,
                               const unsigned char* m2, float mask_scale, const float* res, float* y, float* ws);
-void launch_ffn_train_backward(LaunchCtx, const float* x, const float* dy, long M, const FfnTrainParams& p,
+// false: the call cannot be served with the compact workspace (train.hip ffn_ws_compact)
+bool launch_ffn_train_backward(LaunchCtx, const float* x, const float* dy, long M, const FfnTrainParams& p,
                                const unsigned char* m1, const unsigned char* m2, float mask_scale, const float* dres,
                                float* dx, const FfnTrainParams& grad, float* ws);
 
@@ -39,7 +40,8 @@ struct ConvModTrainParams {
 size_t convmod_train_ws_floats(int N, int L);
 void launch_convmod_train_forward(LaunchCtx, const float* x, int N, int L, const ConvModTrainParams& p,
                                   float* running_mean, float* running_var, const float* res, float* y, float* ws);
-void launch_convmod_train_backward(LaunchCtx, const float* x, const float* dy, int N, int L,
+// false: the call cannot be served with the compact workspace (train.hip cm_ws_compact1 / 2)
+bool launch_convmod_train_backward(LaunchCtx, const float* x, const float* dy, int N, int L,
                                    const ConvModTrainParams& p, const float* dres, float* dx,
                                    const ConvModTrainParams& grad, float* ws);
 // training-mode PreNorm(Attention) forward + backward on raw parameters

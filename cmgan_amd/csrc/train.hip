@@ -651,9 +651,18 @@ static FfnTrainImg ffn_pack_images(LaunchCtx ctx, const FfnTrainParams& p, float
     return FfnTrainImg{w1, w2, w2t, w1t, p.gamma, p.beta, p.b1, p.b2};
 }
 
+// The fused backward (train_x3.hip, the default) keeps dh [M,256] and per-tile partial rows only: its workspace is COMPACT -
+// 270 floats per token instead of the 768 of dz | d1 | dh | xn | g1 | dxn (3.2 GB -> 1.1 GB per FeedForward at 32 clips,
+// sixteen of them in the generator).  Compact <=> this build, CMGAN_FFN_BWD_FUSED != 0 and a dh tensor under 2 GB; a call the
+// fused kernel cannot take then (one keep-mask without the other) is an ERROR, not a fallback into buffers that are not there.
+static bool ffn_ws_compact(long M) {
+    static const bool k_fused = env_knob("CMGAN_FFN_BWD_FUSED", 1, 0, 1) != 0;
+    return TRAIN_X3 && k_fused && M * 1024 < (1l << 31);
+}
 size_t ffn_train_ws_floats(long M) {
-    return (size_t)4 * 16384 + (size_t)M * 768 + (size_t)WG_SPLIT * 16384 * 2 +
-           (size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256;
+    const size_t tiles = (size_t)((M + 31) / 32);
+    const size_t act = ffn_ws_compact(M) ? (size_t)M * 256 + tiles * 448 : (size_t)M * 768;
+    return (size_t)4 * 16384 + act + (size_t)WG_SPLIT * 16384 * 2 + (size_t)COLSUM_MAX_JOBS * FFN_COLSUM_BLOCKS * 256;
 }
 
 void launch_ffn_train_forward(LaunchCtx ctx, const float* x, long M, const FfnTrainParams& p, const unsigned char* m1,
@@ -668,26 +677,30 @@ void launch_ffn_train_forward(LaunchCtx ctx, const float* x, long M, const FfnTr
 #endif
 }
 
-void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, long M, const FfnTrainParams& p,
+bool launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, long M, const FfnTrainParams& p,
                                const unsigned char* m1, const unsigned char* m2, float ms, const float* dres, float* dx,
                                const FfnTrainParams& grad, float* ws) {
     hipStream_t s = ctx.stream;
     const FfnTrainImg w = ffn_pack_images(ctx, p, ws, false);
     float* act = ws + 4 * 16384;
-    FfnBwdBufs o{act, act + M * 64, act + M * 320, act + M * 576, act + M * 640, act + M * 704};
-    float* part = act + M * 768;                                  // [SPLIT][16384] x 2, then colsum slabs
+    const bool compact = ffn_ws_compact(M);
+    const long xrows = (M + 31) / 32;
+    // compact: dh | g1 rows | dz sums | dxn rows | dh sums (ffn_train_ws_floats); else dz | d1 | dh | xn | g1 | dxn
+    FfnBwdBufs o = compact ? FfnBwdBufs{nullptr, nullptr, act, nullptr, act + M * 256, act + M * 256 + xrows * 128}
+                           : FfnBwdBufs{act, act + M * 64, act + M * 320, act + M * 576, act + M * 640, act + M * 704};
+    float* part = act + (compact ? M * 256 + xrows * 448 : M * 768);      // [SPLIT][16384] x 2, then colsum slabs
     float* cpart = part + (size_t)WG_SPLIT * 16384 * 2;
 #if TRAIN_X3
     (void)w;
     // per-tile partial sums for the four column sums: [tiles][64] dgamma | dz (db2) in the g1 region, [tiles][64] dbeta |
     // [tiles][256] dh (db1) in the dxn region (the full [M,64] g1 / dxn tensors of round 2 are no longer written)
-    const long xrows = (M + 31) / 32;
     float *dzc = o.g1 + xrows * 64, *dhc = o.dxn + xrows * 64;   // dzc: [2 tiles][64] (fused form: [tiles][64])
     // default: part A with both weight gradients contracted on the chip (train_x3.hip); CMGAN_FFN_BWD_FUSED=0: A/B
     static const bool k_fused = env_knob("CMGAN_FFN_BWD_FUSED", 1, 0, 1) != 0;
     const int fused_slabs = !k_fused ? 0
         : ffn_x3_backward_fused(ctx, x, dy, M, p, ws, m1, m2, ms, dres, dx, o.dh, o.g1, o.dxn, cpart, dzc, dhc, part,
                                 part + (size_t)WG_SPLIT * 16384);
+    if (!fused_slabs && compact) return false;                    // (one mask without the other / LDS refused: see ffn_ws_compact)
     if (!fused_slabs)
         ffn_x3_backward(ctx, x, dy, M, p, ws, m1, m2, ms, dres, dx, o.dz, o.d1, o.dh, o.xn, o.g1, o.dxn,
                         cpart,                                    // per-tile |dh| maxima: the column-sum slabs are free until colsum_batch
@@ -716,6 +729,7 @@ void launch_ffn_train_backward(LaunchCtx ctx, const float* x, const float* dy, l
                           {0, 0, trows, trows}};
 #endif
     colsum_batch(ctx, "ffn_train_reduce", jobs, 4, M, cpart);
+    return true;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1232,6 +1246,17 @@ __global__ __launch_bounds__(256) void cm_bwd2_kernel(const float* __restrict__ 
 #define CM_DW_BLOCKS 1536
 static int cm_dw_tpb(long ntile, int cap) { return (int)((ntile + cap - 1) / cap); }
 
+// The fused backward parts (train_x3.hip, the default) never write s = Swish(BN(d)) [M,128] (part 1) nor xn [M,64] (part 2): the
+// workspace leaves them out.  Compact <=> this build, the part's knob != 0 and a tensor size its 32-bit offsets cover; a call
+// the fused part cannot take then is an ERROR, not a fallback into buffers that are not there.
+static bool cm_ws_compact1(long M) {
+    static const bool k = env_knob("CMGAN_CM_BWD1_FUSED", 1, 0, 1) != 0;
+    return TRAIN_X3 && k && M * 512 < (1l << 31);
+}
+static bool cm_ws_compact2(long M) {
+    static const bool k = env_knob("CMGAN_CM_BWD2_FUSED", 1, 0, 1) != 0;
+    return TRAIN_X3 && k && M * 1024 < (1l << 31);
+}
 // workspace layout (floats): images | u | d | stats (4 x 128) | bwd buffers | partials
 struct CmPlan {
     size_t img, u, d, st, ddn, s, g2, du, dag, xn, g1, dxn, wpart, dwpart, bnpart, bnred, cpart, sums, total;
@@ -1243,8 +1268,11 @@ static CmPlan cm_plan(int N, int L) {
     auto take = [&](size_t n) { const size_t o = cur; cur += (n + 63) & ~(size_t)63; return o; };
     p.img = take(16384 * 2 + 8192 * 2);
     p.u = take(M * 128); p.d = take(M * 128); p.st = take(512);
-    p.ddn = take(M * 128); p.s = take(M * 128); p.g2 = take(M * 128); p.du = take(M * 128);
-    p.dag = take(M * 256); p.xn = take(M * 64); p.g1 = take(M * 64); p.dxn = take(M * 64);
+    // g2 / g1 / dxn hold per-TILE partial rows only ([tiles16][128] x 3; [tiles16][64]; [tiles16][64] + [tiles32][256]); s and xn
+    // exist only for the un-fused backward parts (cm_ws_compact1 / 2: the fused parts - the default - never write them)
+    const size_t t16 = (M + 15) / 16, t32 = (M + 31) / 32;
+    p.ddn = take(M * 128); p.s = take(cm_ws_compact1((long)M) ? 0 : M * 128); p.g2 = take(3 * t16 * 128); p.du = take(M * 128);
+    p.dag = take(M * 256); p.xn = take(cm_ws_compact2((long)M) ? 0 : M * 64); p.g1 = take(t16 * 64); p.dxn = take(t16 * 64 + t32 * 256);
     p.wpart = take((size_t)WG_SPLIT * 16384);
     p.dwpart = take((size_t)CM_DW_SLABS * 3968);
     p.bnpart = take(nblk * 256);
@@ -1300,7 +1328,7 @@ void launch_convmod_train_forward(LaunchCtx ctx, const float* x, int N, int L, c
 #endif
 }
 
-void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* dy, int N, int L,
+bool launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* dy, int N, int L,
                                    const ConvModTrainParams& p, const float* dres, float* dx,
                                    const ConvModTrainParams& grad, float* ws) {
     hipStream_t s = ctx.stream;
@@ -1329,6 +1357,7 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
         ns_pw2 = cm_x3_bwd1_fused(ctx, dy, ws + pl.d, M, st.mean, st.rstd, st.scale, st.shift, p.pw2_w, ws + pl.ddn, g2c, ddnc,
                                   dyc, ws + pl.wpart);
     if (ns_pw2) trows = (M + 31) / 32;
+    else if (cm_ws_compact1(M)) return false;                     // (the device refused the fused kernel's LDS)
     else cm_x3_bwd1(ctx, dy, ws + pl.d, M, st.mean, st.rstd, st.scale, st.shift, im.w2t, ws + pl.ddn, ws + pl.s, g2c, ddnc, dyc);
 #else
     LAUNCH(ctx, "convmod_train_bwd", (cm_bwd1_kernel<<<grid, 256, 0, s>>>(dy, ws + pl.d, M, st, im.w2t, ws + pl.ddn,
@@ -1375,8 +1404,9 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
         LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<256, 1024, 0, s>>>(ws + pl.wpart, ns_pw1, 16384, grad.pw1_w)));
         const ColsumJobs jobs{{dhc, ws + pl.g1, ws + pl.dxn}, {grad.pw1_b, grad.ln_w, grad.ln_b}, {256, 64, 64}, {t32, t32, t32}};
         colsum_batch(ctx, "convmod_train_reduce", jobs, 3, M, cpart);
-        return;
+        return true;
     }
+    if (cm_ws_compact2(M)) return false;
     cm_x3_bwd2(ctx, x, ws + pl.du, M, im.w1, im.w1t, p, dres, dx, ws + pl.dag, ws + pl.xn, ws + pl.g1, ws + pl.dxn);
 #else
     LAUNCH(ctx, "convmod_train_bwd", (cm_bwd2_kernel<<<grid, 256, 0, s>>>(x, ws + pl.du, M, im.w1, im.w1t, p, dres, dx,
@@ -1403,6 +1433,7 @@ void launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
                           {0, (M + 15) / 16, (M + 15) / 16}};                     // g1 / dxn: per-tile partial sums
     colsum_batch(ctx, "convmod_train_reduce", jobs, 3, M, cpart);
 #endif
+    return true;
 }
 
 // =====================================================================================
@@ -2555,7 +2586,7 @@ static AtPlan at_plan(int N, int L) {
     p.qkv = take(M * 192); p.o = take(M * 64); p.lse = take((size_t)N * 4 * L);
     p.dout = take(M * 64); p.dO = take(M * 64); p.D = take(M * 4); p.dqkv = take(M * 192);
     p.ewinp = p.ewin; p.qkvp = p.qkv; p.dOp = p.dO;             // one image per tensor (or the fp32 tensor itself)
-    p.xn = take(M * 64); p.g1 = take(M * 64); p.dxn = take(M * 64);
+    p.xn = take(M * 64); p.g1 = take((M + 15) / 16 * 64); p.dxn = take((M + 15) / 16 * 64);      // g1 / dxn: per-tile partial rows
     const size_t slabs = (size_t)(2 * at_blocks(L) - 1) * 512;       // dE band slabs [2 nb - 1][32][16]
     p.depart = take((size_t)N * 4 * slabs);
     p.dewin = take(slabs);
@@ -3278,7 +3309,7 @@ static DbPlan db_plan(int B, int T, int F) {
     p.img = take(60 * 4096); p.imgT = take(60 * 4096);
     p.a = take(4 * M * 64);            // a_1 .. a_4 (a_0 = x is the caller's)
     p.z = take(4 * M * 64);
-    p.ga = take(5 * M * 64);           // gradients w.r.t. a_0 .. a_4
+    p.ga = take(4 * M * 64);           // gradients w.r.t. a_1 .. a_4 (a_0's is the caller's dx)
     p.mean = take((size_t)4 * B * 64); p.rstd = take((size_t)4 * B * 64);
     {
         const size_t chunks = (size_t)B * DB_NCH * 64 * 3, tiles = (size_t)B * conv3x_ntiles(T, F, 64) * 128;
@@ -3486,7 +3517,7 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
     // gradient planes: ga_0 IS the caller's dx (accumulated in place - dx must not alias x or dy), ga_1 .. ga_4 in the
     // workspace; ga_4 = dy is never materialised: layer 3 reads dy and writes its dn into ga_4 (db_sums_kernel gin).
     // (Two plane copies per backward - 2 x 0.53 GB moved at the encoder's shape - are gone this way.)
-    auto ga = [&](int s) { return s == 0 ? dx : ws + pl.ga + (size_t)s * M * 64; };
+    auto ga = [&](int s) { return s == 0 ? dx : ws + pl.ga + (size_t)(s - 1) * M * 64; };
     auto aslot = [&](int s) -> const float* { return s == 0 ? x : ws + pl.a + (size_t)(s - 1) * M * 64; };
     hipMemsetAsync(dx, 0, (size_t)M * 64 * sizeof(float), st);                                   // ga_0
     hipMemsetAsync(ga(1), 0, (size_t)3 * M * 64 * sizeof(float), st);                            // ga_1 .. ga_3

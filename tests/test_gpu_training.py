@@ -72,26 +72,37 @@ def test_feed_forward_train_ragged_token_count_and_determinism(ff):
     assert torch.equal(dx, dx2) and all(torch.equal(first[k], grads2[k]) for k in KEYS)
 
 
-def test_feed_forward_backward_of_a_ragged_tile_stays_inside_the_dh_tensor(ff):
-    """The fused backward (train_x3.hip ffn_train_bwd_aw_x3_kernel, the default) stores dh [M,256] with buffer stores whose
-    rows past M must be DROPPED by the descriptor's range check - which sees the per-lane offset only, not the scalar tile
-    offset.  dh occupies floats [65536 + 320 M, 65536 + 576 M) of the module's workspace (train.hip
-    launch_ffn_train_backward: FfnBwdBufs); the region behind it is not written by this path: a sentinel there survives."""
+def test_feed_forward_backward_fits_its_compact_workspace_with_ragged_tiles(ff):
+    """The fused backward (train_x3.hip ffn_train_bwd_aw_x3_kernel, the default) keeps dh [M,256] and per-tile partial rows
+    only: `cmgan_ffn_train_workspace_bytes` is ~270 floats per token, not 768 (train.hip ffn_ws_compact).  Its dh stores of a
+    ragged last tile must be DROPPED by the buffer descriptor's range check (which sees the per-lane offset only, not the
+    scalar tile offset).  Run forward + backward inside a workspace of EXACTLY the advertised size with a guard band behind
+    it, at token counts whose last tile is ragged (M = 1000: 8 of 32 valid; M = 33: 1 of 32): the guard stays intact and the
+    gradients equal those computed in a roomy workspace bit for bit."""
     import os
-    if os.environ.get("CMGAN_FFN_BWD_FUSED", "1") == "0":
-        pytest.skip("the un-fused path writes xn behind dh")
-    M = 1000                                               # last tile: 8 valid tokens, 24 beyond M
-    rng = np.random.Generator(np.random.PCG64(11))
-    x = torch.from_numpy(rng.standard_normal((M, 64)).astype(np.float32)).to(DEV)
-    dy = torch.from_numpy(rng.standard_normal((M, 64)).astype(np.float32)).to(DEV)
-    m1, m2 = ff.masks(M, torch.Generator(device=DEV).manual_seed(4))
-    ff.forward(x, m1, m2)                                  # sizes the workspace
-    ws = ff._workspace(M).view(torch.float32)
-    behind = ws[65536 + 576 * M: 65536 + 576 * M + 32 * 256]
-    behind.fill_(-12345.0)
-    ff.backward(x, dy, m1, m2)
-    torch.cuda.synchronize()
-    assert bool((behind == -12345.0).all()), "rows past M of the last tile were stored"
+    for M in (1000, 33):
+        rng = np.random.Generator(np.random.PCG64(11 + M))
+        x = torch.from_numpy(rng.standard_normal((M, 64)).astype(np.float32)).to(DEV)
+        dy = torch.from_numpy(rng.standard_normal((M, 64)).astype(np.float32)).to(DEV)
+        m1, m2 = ff.masks(M, torch.Generator(device=DEV).manual_seed(4))
+        ff._ws = None
+        need = ff._workspace(M).numel()                    # bytes, as the library advertises them
+        if os.environ.get("CMGAN_FFN_BWD_FUSED", "1") != "0":
+            assert need < 4 * (65536 + 400 * M + 2 * 256 * 16384 + 4 * 512 * 256) + 4096, need      # compact: < 400 floats / token
+        roomy = torch.zeros(need + (1 << 22), dtype=torch.uint8, device=DEV)
+        ff._ws = roomy
+        ff.forward(x, m1, m2)
+        dx_ref, g_ref = ff.backward(x, dy, m1, m2)
+        g_ref = {k: v.clone() for k, v in g_ref.items()}
+        tight = torch.empty(need + 65536, dtype=torch.uint8, device=DEV)
+        tight[need:].fill_(0xA5)
+        ff._ws = tight
+        ff.forward(x, m1, m2)
+        dx, grads = ff.backward(x, dy, m1, m2)
+        torch.cuda.synchronize()
+        assert bool((tight[need:] == 0xA5).all()), f"M = {M}: the workspace was overrun"
+        assert torch.equal(dx, dx_ref) and all(torch.equal(grads[k], g_ref[k]) for k in KEYS), M
+    ff._ws = None
 
 
 def test_feed_forward_backward_is_exactly_scale_equivariant(ff):
