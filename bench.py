@@ -301,7 +301,7 @@ def train_leg(eng, sd, dev, rank, world, barrier, batch=32, cut_len=32000, steps
         return {"workload": f"configs[2]: adversarial train step, {batch} x {cut_len / 16000:g} s clips per GPU, dropout on, "
                             "TSCNet(64,201) + Discriminator(16) random-init, synthetic PESQ labels",
                 "batch_per_gpu": batch, "global_batch": batch * world, "steps": steps, "warmup": 2, "ms_per_step": round(ms, 2),
-                "clips_per_s": round(batch * world / (ms * 1e-3), 2), "dtype": "f32 storage / accumulate; every conformer kernel except to_out, the dense convs and all weight gradients as split-f16 MFMA products (fp32-class, exact power-of-two gradient scaling); encoder / decoder row convs and the discriminator fp32",
+                "clips_per_s": round(batch * world / (ms * 1e-3), 2), "dtype": "f32 storage / accumulate; every conformer kernel except to_out, the dense convs and all weight gradients as split-f16 MFMA products (fp32-class, exact power-of-two gradient scaling); the encoder's / decoders' 1 x 3 convs likewise since round 6; tail convs, conv_1 and the discriminator fp32",
                 "peak_device_GB": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
                 "collectives_per_step": "2 all-reduces over flat buckets (generator %.1f MB, discriminator %.1f MB)"
                                         % (gen.grad_bucket.numel * 4 / 2**20, disc.grad_bucket.numel * 4 / 2**20),

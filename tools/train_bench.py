@@ -58,4 +58,4 @@ for B in [int(b) for b in args.batches.split(",")]:
                         "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2),
                         "kernel_ms": {k: round(v, 2) for k, v in top}, "kernel_ms_total": round(sum(split.values()), 2)}
 print(json.dumps({"workload": f"{'adversarial' if args.adversarial else 'generator'} train step, {args.cut_len}-sample clips, TSCNet(64,201) random-init, dropout 0.2, "
-                              "split-f16 products in every conformer kernel except to_out, the dense convs and all weight gradients; fp32 MFMA row convs; 1 x MI355X", "results": res}))
+                              "split-f16 products in every conformer kernel except to_out, the dense and 1 x 3 convs and all weight gradients; fp32 tail convs / conv_1 / discriminator; 1 x MI355X", "results": res}))
