@@ -3742,14 +3742,28 @@ __global__ __launch_bounds__(256) void rc_wgrad_kernel(const float* __restrict__
 }
 
 // dW[co][ci][0][kw] = sum_s partial[kw][s][co][ci]                     (conv weight [Co, 64, 1, KW])
-__global__ void rc_wgrad_scatter_kernel(const float* __restrict__ partial, int nsplit, int Co, int KW,
-                                        float* __restrict__ dW) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= KW * Co * 64) return;
-    const int kw = idx / (Co * 64), e = idx - kw * Co * 64;               // e = co * 64 + ci
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[((long)kw * nsplit + k) * Co * 64 + e];
-    dW[(long)e * KW + kw] = s;
+// a block is 64 elements x 4 slab groups (group g adds slabs g, g + 4, ... two at a time; the groups are combined in group order:
+// a fixed order for a given launch shape) - one thread walking all the slabs of its element was a dependent fetch per slab
+__global__ __launch_bounds__(256) void rc_wgrad_scatter_kernel(const float* __restrict__ partial, int nsplit, int Co, int KW,
+                                                               float* __restrict__ dW) {
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + col, n = KW * Co * 64;
+    float s0 = 0.f, s1 = 0.f;
+    int kw = 0, e = 0;
+    if (idx < n) {
+        kw = idx / (Co * 64);
+        e = idx - kw * Co * 64;                                            // e = co * 64 + ci
+        int k = grp;
+        for (; k + 4 < nsplit; k += 8) {
+            s0 += partial[((long)kw * nsplit + k) * Co * 64 + e];
+            s1 += partial[((long)kw * nsplit + k + 4) * Co * 64 + e];
+        }
+        for (; k < nsplit; k += 4) s0 += partial[((long)kw * nsplit + k) * Co * 64 + e];
+    }
+    red[grp][col] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && idx < n) dW[(long)e * KW + kw] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
 // tap images of a row conv: plain [kw][Co/16][4] and transposed [kw][4][Co/16]
@@ -3903,7 +3917,7 @@ static bool rc_backward(LaunchCtx ctx, const float* dz, const float* in, const f
     if (k_wx3 && rows * 256 < (1l << 32)) {           // split products (train_x3.hip), RC_WG_SPLIT position ranges
         const int gm7[7] = {gm.B, gm.T, gm.Fi, gm.Fo, gm.KW, gm.SF, gm.PL};
         launch_rc_wgrad_x3(ctx, NG, dz, in, gm7, RC_WG_SPLIT, wpart, db ? cpart : nullptr);
-        LAUNCH(ctx, "rowconv_train", (rc_wgrad_scatter_kernel<<<(nw + 255) / 256, 256, 0, st>>>(wpart, RC_WG_SPLIT, 64 * NG,
+        LAUNCH(ctx, "rowconv_train", (rc_wgrad_scatter_kernel<<<(nw + 63) / 64, 256, 0, st>>>(wpart, RC_WG_SPLIT, 64 * NG,
                                                                                                 gm.KW, dW)));
         if (db) {
             LAUNCH(ctx, "rowconv_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(cpart, RC_WG_SPLIT, 64 * NG, db)));
@@ -3915,7 +3929,7 @@ static bool rc_backward(LaunchCtx ctx, const float* dz, const float* in, const f
         (void)rows;
         LAUNCH(ctx, "rowconv_train", (rc_wgrad_kernel<NG><<<dim3(4 * NG, gm.KW, FFN_WGRAD_SPLIT), 256, 0, st>>>(
                                          dz, in, gm, FFN_WGRAD_SPLIT, wpart)));
-        LAUNCH(ctx, "rowconv_train", (rc_wgrad_scatter_kernel<<<(nw + 255) / 256, 256, 0, st>>>(wpart, FFN_WGRAD_SPLIT, 64 * NG,
+        LAUNCH(ctx, "rowconv_train", (rc_wgrad_scatter_kernel<<<(nw + 63) / 64, 256, 0, st>>>(wpart, FFN_WGRAD_SPLIT, 64 * NG,
                                                                                                 gm.KW, dW)));
     }
     if (din)
