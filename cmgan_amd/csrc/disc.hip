@@ -395,14 +395,19 @@ __global__ __launch_bounds__(256) void gin_norm_prelu_kernel(const float* __rest
         a[i] = n >= 0.f ? n : alpha[c] * n;
     }
 }
-__global__ void gin_bwd_finalize_kernel(const float* __restrict__ partial, int B, int C, double count, float* __restrict__ m1,
-                                        float* __restrict__ m2, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                        float* __restrict__ dalpha) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
+// one block of 1024 threads = C channels x 1024 / C clip groups (C in {16, 32, 64, 128}): group g finalises clips g, g + G, ...
+// (means of (b, c) from the DC_NCH chunk partials in fp64), the parameter gradients add the groups' sums in group order - a
+// fixed order for a given launch shape.  (One thread per channel walking all clips and chunks: 40 us per launch, twelve per step.)
+__global__ __launch_bounds__(1024) void gin_bwd_finalize_kernel(const float* __restrict__ partial, int B, int C, double count,
+                                                                float* __restrict__ m1, float* __restrict__ m2,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                float* __restrict__ dalpha) {
+    __shared__ double red[3][1024];
+    const int tid = threadIdx.x, c = tid % C, grp = tid / C, G = 1024 / C;
     double g = 0.0, bsum = 0.0, a = 0.0;
-    for (int b = 0; b < B; ++b) {
+    for (int b = grp < G ? grp : B; b < B; b += G) {              // (threads past the last full group idle: any C <= 1024 works)
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
         for (int k = 0; k < DC_NCH; ++k) {
             const long o = (((long)b * DC_NCH + k) * C + c) * 3;
             s0 += (double)partial[o]; s1 += (double)partial[o + 1]; s2 += (double)partial[o + 2];
@@ -411,7 +416,12 @@ __global__ void gin_bwd_finalize_kernel(const float* __restrict__ partial, int B
         m2[b * C + c] = (float)(s1 / count);
         bsum += s0; g += s1; a += s2;
     }
-    dgamma[c] = (float)g; dbeta[c] = (float)bsum; dalpha[c] = (float)a;
+    red[0][tid] = g; red[1][tid] = bsum; red[2][tid] = a;
+    __syncthreads();
+    if (grp == 0) {
+        for (int gg = 1; gg < G; ++gg) { g += red[0][gg * C + c]; bsum += red[1][gg * C + c]; a += red[2][gg * C + c]; }
+        dgamma[c] = (float)g; dbeta[c] = (float)bsum; dalpha[c] = (float)a;
+    }
 }
 __global__ __launch_bounds__(256) void gin_in_bwd_kernel(float* __restrict__ dn, const float* __restrict__ z, long total, int P,
                                                          int C, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -701,7 +711,7 @@ void launch_disc_backward(LaunchCtx ctx, const float* xy, const float* dscore, i
         LAUNCH(ctx, "disc_norm", (gin_sums_kernel<1><<<dim3(B, DC_NCH), 256, 0, st>>>(ws + pl.z[i], g, P, L.Co, ws + pl.mean[i],
                                                                                      ws + pl.rstd[i], p.norm_w[i], p.norm_b[i],
                                                                                      p.prelu_w[i], ws + pl.part)));
-        LAUNCH(ctx, "disc_norm", (gin_bwd_finalize_kernel<<<1, 128, 0, st>>>(ws + pl.part, B, L.Co, (double)P, m1, m2, grad.norm_w[i],
+        LAUNCH(ctx, "disc_norm", (gin_bwd_finalize_kernel<<<1, 1024, 0, st>>>(ws + pl.part, B, L.Co, (double)P, m1, m2, grad.norm_w[i],
                                                                             grad.norm_b[i], grad.prelu_w[i])));
         LAUNCH(ctx, "disc_norm", (gin_in_bwd_kernel<<<grid, 256, 0, st>>>(g, ws + pl.z[i], total, P, L.Co, ws + pl.mean[i],
                                                                           ws + pl.rstd[i], p.norm_w[i], m1, m2)));

@@ -3099,38 +3099,46 @@ __global__ __launch_bounds__(256) void db_norm_prelu_kernel(const float* __restr
 
 // backward means per (b, c) and the per-channel parameter gradients (summed over clips in clip order): one block per
 // channel; the DB_NCH = 256 chunk partials of a clip are added in fp64 by a butterfly inside each wave and the four waves
-// in wave order - one barrier per clip (the shared fixed-shape tree of db_tree_sum took 27 barriers per clip: 99 us per
+// in wave order - one barrier per FOUR clips (the shared fixed-shape tree of db_tree_sum took 27 barriers per clip: 99 us per
 // launch at 32 clips, fifteen launches per step)
-__global__ __launch_bounds__(256) void db_bwd_finalize_kernel(const float* __restrict__ partial, int B, double count,
-                                                              float* __restrict__ m1, float* __restrict__ m2,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                              float* __restrict__ dalpha) {
+__global__ __launch_bounds__(1024) void db_bwd_finalize_kernel(const float* __restrict__ partial, int B, double count,
+                                                               float* __restrict__ m1, float* __restrict__ m2,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ dalpha) {
     static_assert(DB_NCH == 256, "one chunk per thread");
-    __shared__ double red[2][3][4];
-    const int c = blockIdx.x, k = threadIdx.x, lane = k & 63, wv = k >> 6;
+    // 1024 threads = FOUR clips per trip (clip lane q = wave >> 2, 256 chunk threads each): a barrier per four clips; the
+    // per-channel sums still add the clips in clip order (thread 0 walks the four results of a trip in order)
+    __shared__ double red[2][4][3][4];                            // [trip parity][clip lane][sum][wave of the lane]
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = (tid >> 6) & 3, q = tid >> 8, k = tid & 255;
     double g = 0.0, bsum = 0.0, a = 0.0;
-    for (int b = 0; b < B; ++b) {
-        const long o = (((long)b * DB_NCH + k) * 64 + c) * 3;
-        double v0 = (double)partial[o], v1 = (double)partial[o + 1], v2 = (double)partial[o + 2];
+    for (int b0 = 0; b0 < B; b0 += 4) {
+        const int b = b0 + q;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+        if (b < B) {
+            const long o = (((long)b * DB_NCH + k) * 64 + c) * 3;
+            v0 = (double)partial[o]; v1 = (double)partial[o + 1]; v2 = (double)partial[o + 2];
+        }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             v0 += __shfl_xor(v0, d);
             v1 += __shfl_xor(v1, d);
             v2 += __shfl_xor(v2, d);
         }
-        double (*r)[4] = red[b & 1];                              // (alternating buffers: the next clip's writes need no barrier)
-        if (lane == 0) { r[0][wv] = v0; r[1][wv] = v1; r[2][wv] = v2; }
+        double (*r)[3][4] = red[(b0 >> 2) & 1];                   // (alternating buffers: the next trip's writes need no barrier)
+        if (lane == 0) { r[q][0][wv] = v0; r[q][1][wv] = v1; r[q][2][wv] = v2; }
         __syncthreads();
-        const double s0 = (r[0][0] + r[0][1]) + (r[0][2] + r[0][3]);
-        const double s1 = (r[1][0] + r[1][1]) + (r[1][2] + r[1][3]);
-        const double s2 = (r[2][0] + r[2][1]) + (r[2][2] + r[2][3]);
-        if (k == 0) {
-            m1[b * 64 + c] = (float)(s0 / count);
-            m2[b * 64 + c] = (float)(s1 / count);
+        if (tid == 0) {
+            for (int qq = 0; qq < 4 && b0 + qq < B; ++qq) {
+                const double s0 = (r[qq][0][0] + r[qq][0][1]) + (r[qq][0][2] + r[qq][0][3]);
+                const double s1 = (r[qq][1][0] + r[qq][1][1]) + (r[qq][1][2] + r[qq][1][3]);
+                const double s2 = (r[qq][2][0] + r[qq][2][1]) + (r[qq][2][2] + r[qq][2][3]);
+                m1[(b0 + qq) * 64 + c] = (float)(s0 / count);
+                m2[(b0 + qq) * 64 + c] = (float)(s1 / count);
+                bsum += s0; g += s1; a += s2;
+            }
         }
-        bsum += s0; g += s1; a += s2;
     }
-    if (k == 0) { dgamma[c] = (float)g; dbeta[c] = (float)bsum; dalpha[c] = (float)a; }
+    if (tid == 0) { dgamma[c] = (float)g; dbeta[c] = (float)bsum; dalpha[c] = (float)a; }
 }
 
 // dz = gamma rstd (dn - mean(dn) - zhat mean(dn zhat)), in place on dn
@@ -3530,7 +3538,7 @@ void launch_dense_train_backward(LaunchCtx ctx, const float* x, const float* dy,
         LAUNCH(ctx, "dense_train_bwd", (db_sums_kernel<1><<<dim3(B, DB_NCH), 256, 0, st>>>(z, g, P, mean, rstd, p.norm_w[i],
                                                                                          p.norm_b[i], p.prelu_w[i],
                                                                                          ws + pl.part, i == 3 ? dy : nullptr)));
-        LAUNCH(ctx, "dense_train_bwd", (db_bwd_finalize_kernel<<<64, 256, 0, st>>>(ws + pl.part, B, (double)P, ws + pl.m1,
+        LAUNCH(ctx, "dense_train_bwd", (db_bwd_finalize_kernel<<<64, 1024, 0, st>>>(ws + pl.part, B, (double)P, ws + pl.m1,
                                                                                 ws + pl.m2, grad.norm_w[i], grad.norm_b[i],
                                                                                 grad.prelu_w[i])));
         const bool x3d = db_x3_forward(F);
@@ -3844,7 +3852,7 @@ static void in_prelu_backward(LaunchCtx ctx, const float* z, float* g, int B, in
     hipStream_t st = ctx.stream;
     LAUNCH(ctx, "in_prelu_train", (db_sums_kernel<1><<<dim3(B, DB_NCH), 256, 0, st>>>(z, g, P, mean, rstd, gamma, beta, alpha,
                                                                                     part, gin)));
-    LAUNCH(ctx, "in_prelu_train", (db_bwd_finalize_kernel<<<64, 256, 0, st>>>(part, B, (double)P, m1, m2, dgamma, dbeta, dalpha)));
+    LAUNCH(ctx, "in_prelu_train", (db_bwd_finalize_kernel<<<64, 1024, 0, st>>>(part, B, (double)P, m1, m2, dgamma, dbeta, dalpha)));
     LAUNCH(ctx, "in_prelu_train", (db_in_bwd_kernel<<<2048, 256, 0, st>>>(g, z, (long)B * P * 64, P, mean, rstd, gamma, m1, m2)));
 }
 
