@@ -1080,13 +1080,28 @@ __global__ __launch_bounds__(256) void cm_bwd1_kernel(const float* __restrict__ 
 }
 
 // BatchNorm backward (batch statistics): dd = gamma rstd (ddn - mean(ddn) - dhat mean(ddn dhat)), in place on ddn
+// bpart (optional): [gridDim.x][128] per-block sums of dd - the depthwise BIAS gradient's partials - for free in this HBM-bound
+// pass: a thread's channel is fixed (the stride is a multiple of 128), two threads per channel are combined through LDS.
+// (A separate column-sum pass re-read the [M,128] plane.)
 __global__ __launch_bounds__(256) void cm_bn_bwd_kernel(float* __restrict__ ddn, const float* __restrict__ d, long total,
                                                         CmStats st, const float* __restrict__ sum_ddn,
-                                                        const float* __restrict__ sum_g2, float inv_count) {
+                                                        const float* __restrict__ sum_g2, float inv_count,
+                                                        float* __restrict__ bpart) {
+    __shared__ float red[128];
+    const int ch = threadIdx.x & 127;                             // = i & 127 for every i of this thread
+    const float mu = st.mean[ch], rs = st.rstd[ch], sc = st.scale[ch];
+    const float c1 = sum_ddn[ch] * inv_count, c2 = sum_g2[ch] * inv_count;
+    float acc = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int ch = (int)(i & 127);
-        const float dhat = (d[i] - st.mean[ch]) * st.rstd[ch];
-        ddn[i] = st.scale[ch] * (ddn[i] - sum_ddn[ch] * inv_count - dhat * (sum_g2[ch] * inv_count));
+        const float dhat = (d[i] - mu) * rs;
+        const float v = sc * (ddn[i] - c1 - dhat * c2);
+        ddn[i] = v;
+        acc += v;
+    }
+    if (bpart) {
+        if (threadIdx.x >= 128) red[ch] = acc;
+        __syncthreads();
+        if (threadIdx.x < 128) bpart[(long)blockIdx.x * 128 + ch] = acc + red[ch];
     }
 }
 
@@ -1342,10 +1357,6 @@ bool launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     float* cpart = ws + pl.cpart;
     float* sum_ddn = ws + pl.sums;
     float* sum_g2 = ws + pl.sums + 128;
-    auto colsum = [&](const float* X, int C, float* out) {
-        LAUNCH(ctx, "convmod_train_reduce", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, s>>>(X, M, C, cpart)));
-        LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, FFN_COLSUM_BLOCKS, C, out)));
-    };
     long trows = (M + 15) / 16;                                   // per-tile partial sums inside the g2 region [M,128]
     float *g2c = ws + pl.g2, *ddnc = g2c + trows * 128, *dyc = ddnc + trows * 128;
     int ns_pw2 = 0;                                               // > 0: dW_pw2's slabs already written (fused part 1)
@@ -1378,10 +1389,11 @@ bool launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     hipMemcpyAsync(grad.bn_b, sum_ddn, 128 * sizeof(float), hipMemcpyDeviceToDevice, s);
     hipMemcpyAsync(grad.bn_w, sum_g2, 128 * sizeof(float), hipMemcpyDeviceToDevice, s);
     LAUNCH(ctx, "convmod_train_bwd", (cm_bn_bwd_kernel<<<2048, 256, 0, s>>>(ws + pl.ddn, ws + pl.d, M * 128, st, sum_ddn,
-                                                                            sum_g2, (float)(1.0 / (double)M))));
+                                                                            sum_g2, (float)(1.0 / (double)M), cpart)));
+    LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, 2048, 128, grad.dw_b)));
     float* dd = ws + pl.ddn;
-    // depthwise: bias / weight gradients, then the data gradient (same kernel, flipped taps)
-    colsum(dd, 128, grad.dw_b);
+    // depthwise: weight gradient (the bias gradient rode on the BatchNorm backward above), then the data gradient (same kernel,
+    // flipped taps)
     const int wtpb = cm_dw_tpb(nblk, CM_DW_SLABS), nslab = (int)((nblk + wtpb - 1) / wtpb);
     LAUNCH(ctx, "convmod_train_wgrad", (cm_dw_wgrad_kernel<<<nslab, 256, 0, s>>>(dd, ws + pl.u, L, (int)dgrid.y, nblk, wtpb,
                                                                                  ws + pl.dwpart)));
@@ -3803,12 +3815,13 @@ __global__ __launch_bounds__(256) void c1_fwd_kernel(const float* __restrict__ x
     }
 }
 // partial[blk][co][ci] = sum over the block's positions of dz[m][co] * xin[m][ci]
+// bpart: [blk][64] partial sums of dz itself (the conv_1 bias gradient) from the same pass
 __global__ __launch_bounds__(256) void c1_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ xin, long M,
-                                                       float* __restrict__ partial) {
-    __shared__ float red[4][64][3];
+                                                       float* __restrict__ partial, float* __restrict__ bpart) {
+    __shared__ float red[4][64][4];
     const int co = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const long per = (M + gridDim.x - 1) / gridDim.x, m0 = (long)blockIdx.x * per, m1 = m0 + per < M ? m0 + per : M;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, sb = 0.f;
     long m = m0 + sub;
     for (; m + 12 < m1; m += 16) {                                // four positions' operands in flight (same sum order)
         float d[4], x[4][3];
@@ -3819,18 +3832,20 @@ __global__ __launch_bounds__(256) void c1_wgrad_kernel(const float* __restrict__
             for (int k = 0; k < 3; ++k) x[u][k] = xin[(m + 4 * u) * 3 + k];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { s0 = fmaf(d[u], x[u][0], s0); s1 = fmaf(d[u], x[u][1], s1); s2 = fmaf(d[u], x[u][2], s2); }
+        for (int u = 0; u < 4; ++u) { s0 = fmaf(d[u], x[u][0], s0); s1 = fmaf(d[u], x[u][1], s1); s2 = fmaf(d[u], x[u][2], s2); sb += d[u]; }
     }
     for (; m < m1; m += 4) {
         const float d = dz[m * 64 + co];
         s0 = fmaf(d, xin[m * 3], s0); s1 = fmaf(d, xin[m * 3 + 1], s1); s2 = fmaf(d, xin[m * 3 + 2], s2);
+        sb += d;
     }
-    red[sub][co][0] = s0; red[sub][co][1] = s1; red[sub][co][2] = s2;
+    red[sub][co][0] = s0; red[sub][co][1] = s1; red[sub][co][2] = s2; red[sub][co][3] = sb;
     __syncthreads();
     if (sub == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             partial[((long)blockIdx.x * 64 + co) * 3 + k] = (red[0][co][k] + red[1][co][k]) + (red[2][co][k] + red[3][co][k]);
+        bpart[(long)blockIdx.x * 64 + co] = (red[0][co][3] + red[1][co][3]) + (red[2][co][3] + red[3][co][3]);
     }
 }
 
@@ -4011,9 +4026,8 @@ void launch_encoder_train_backward(LaunchCtx ctx, const float* xin, const float*
     float* dz1 = ws + pl.g;
     in_prelu_backward(ctx, ws + pl.z1, dz1, B, T * F, p.n1_w, p.n1_b, p.p1_w, stt, stt + B * 64, ws + pl.part, ws + pl.m,
                       ws + pl.m + B * 64, grad.n1_w, grad.n1_b, grad.p1_w);
-    LAUNCH(ctx, "encoder_train", (colsum_partial_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz1, M, 64, cpart)));
+    LAUNCH(ctx, "encoder_train", (c1_wgrad_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz1, xin, M, ws + pl.wpart, cpart)));
     LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(cpart, FFN_COLSUM_BLOCKS, 64, grad.c1_b)));
-    LAUNCH(ctx, "encoder_train", (c1_wgrad_kernel<<<FFN_COLSUM_BLOCKS, 256, 0, st>>>(dz1, xin, M, ws + pl.wpart)));
     LAUNCH(ctx, "encoder_train", (reduce_partials_kernel<<<4, 1024, 0, st>>>(ws + pl.wpart, FFN_COLSUM_BLOCKS, 192, grad.c1_w)));
 }
 
