@@ -1355,8 +1355,6 @@ bool launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
     const dim3 dgrid(N, (L + 31) / 32);
     const long nblk = (long)dgrid.x * dgrid.y;
     float* cpart = ws + pl.cpart;
-    float* sum_ddn = ws + pl.sums;
-    float* sum_g2 = ws + pl.sums + 128;
     long trows = (M + 15) / 16;                                   // per-tile partial sums inside the g2 region [M,128]
     float *g2c = ws + pl.g2, *ddnc = g2c + trows * 128, *dyc = ddnc + trows * 128;
     int ns_pw2 = 0;                                               // > 0: dW_pw2's slabs already written (fused part 1)
@@ -1383,13 +1381,12 @@ bool launch_convmod_train_backward(LaunchCtx ctx, const float* x, const float* d
                                                                                    grad.pw2_w)));
     // BatchNorm: dbeta = sum ddn, dgamma = sum ddn dhat; then dd in place   (+ db_pw2 = colsum dy in the same pair of launches)
     {
-        const ColsumJobs jobs{{dyc, ddnc, g2c}, {grad.pw2_b, sum_ddn, sum_g2}, {64, 128, 128}, {trows, trows, trows}};
+        // (sum ddn = dbeta and sum ddn dhat = dgamma land in the gradient tensors themselves; the BatchNorm backward reads them there)
+        const ColsumJobs jobs{{dyc, ddnc, g2c}, {grad.pw2_b, grad.bn_b, grad.bn_w}, {64, 128, 128}, {trows, trows, trows}};
         colsum_batch(ctx, "convmod_train_reduce", jobs, 3, M, cpart);
     }
-    hipMemcpyAsync(grad.bn_b, sum_ddn, 128 * sizeof(float), hipMemcpyDeviceToDevice, s);
-    hipMemcpyAsync(grad.bn_w, sum_g2, 128 * sizeof(float), hipMemcpyDeviceToDevice, s);
-    LAUNCH(ctx, "convmod_train_bwd", (cm_bn_bwd_kernel<<<2048, 256, 0, s>>>(ws + pl.ddn, ws + pl.d, M * 128, st, sum_ddn,
-                                                                            sum_g2, (float)(1.0 / (double)M), cpart)));
+    LAUNCH(ctx, "convmod_train_bwd", (cm_bn_bwd_kernel<<<2048, 256, 0, s>>>(ws + pl.ddn, ws + pl.d, M * 128, st, grad.bn_b,
+                                                                            grad.bn_w, (float)(1.0 / (double)M), cpart)));
     LAUNCH(ctx, "convmod_train_reduce", (reduce_partials_kernel<<<4, 1024, 0, s>>>(cpart, 2048, 128, grad.dw_b)));
     float* dd = ws + pl.ddn;
     // depthwise: weight gradient (the bias gradient rode on the BatchNorm backward above), then the data gradient (same kernel,
@@ -2613,15 +2610,20 @@ int attn_train_max_len() { return AT_MAX_L; }
 static void at_pack_images(LaunchCtx ctx, const AttnTrainParams& p, float* ws, const AtPlan& pl, bool pack = true) {
     if (!pack) return;
     hipStream_t s = ctx.stream;
-    hipMemcpyAsync(ws + pl.raw, p.wq, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);            // rows 0..63
-    hipMemcpyAsync(ws + pl.raw + 4096, p.wkv, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);    // rows 64..191
+    // [to_q ; to_kv] as one [192,64] matrix: in place when the two parameters are adjacent (views of one flat bucket), else a copy
+    const float* raw = p.wq;
+    if (p.wkv != p.wq + 4096) {
+        hipMemcpyAsync(ws + pl.raw, p.wq, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);            // rows 0..63
+        hipMemcpyAsync(ws + pl.raw + 4096, p.wkv, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);    // rows 64..191
+        raw = ws + pl.raw;
+    }
 #if TRAIN_X3
-    at_x3_pack(ctx, ws + pl.raw, ws + pl.wqkv, ws + pl.wqkvt);      // the projections run on split products
+    at_x3_pack(ctx, raw, ws + pl.wqkv, ws + pl.wqkvt);              // the projections run on split products
     launch_pack4(ctx, "attn_train_pack", PackJobs{{{p.wo, 64, 64, 64, 0, ws + pl.wo}, {p.wo, 64, 64, 64, 1, ws + pl.wot},
                                                    {}, {}}}, 2);
 #else
-    launch_pack4(ctx, "attn_train_pack", PackJobs{{{ws + pl.raw, 192, 64, 64, 0, ws + pl.wqkv},
-                                                   {ws + pl.raw, 64, 192, 64, 1, ws + pl.wqkvt},
+    launch_pack4(ctx, "attn_train_pack", PackJobs{{{raw, 192, 64, 64, 0, ws + pl.wqkv},
+                                                   {raw, 64, 192, 64, 1, ws + pl.wqkvt},
                                                    {p.wo, 64, 64, 64, 0, ws + pl.wo}, {p.wo, 64, 64, 64, 1, ws + pl.wot}}});
 #endif
 }
@@ -2721,10 +2723,14 @@ void launch_attn_train_backward(LaunchCtx ctx, const float* x, const float* dy, 
                                                                           dres, dx, ws + pl.xn, ws + pl.g1, ws + pl.dxn)));
 #endif
     wgrad_partial64(ctx, "attn_train_wgrad", ws + pl.dqkv, ws + pl.xn, M, 192, 64, ws + pl.wpart, wg_split(3));
+    // [192,64] = [dW_q ; dW_kv]: straight into the gradient tensors when they are adjacent (views of one flat bucket), else split
+    const bool adjacent = grad.wkv == grad.wq + 4096;
     LAUNCH(ctx, "attn_train_reduce", (reduce_partials_kernel<<<192, 1024, 0, s>>>(ws + pl.wpart, wg_split(3), 12288,
-                                                                                ws + pl.raw)));      // [192,64], then split
-    hipMemcpyAsync(grad.wq, ws + pl.raw, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);
-    hipMemcpyAsync(grad.wkv, ws + pl.raw + 4096, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);
+                                                                                adjacent ? grad.wq : ws + pl.raw)));
+    if (!adjacent) {
+        hipMemcpyAsync(grad.wq, ws + pl.raw, 4096 * sizeof(float), hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(grad.wkv, ws + pl.raw + 4096, 8192 * sizeof(float), hipMemcpyDeviceToDevice, s);
+    }
 #if TRAIN_X3
     const ColsumJobs jobs{{ws + pl.g1, ws + pl.dxn}, {grad.ln_w, grad.ln_b}, {64, 64},
                           {(M + 15) / 16, (M + 15) / 16}};                        // g1 / dxn: per-tile partial sums (dbo: above)
