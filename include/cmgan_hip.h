@@ -541,6 +541,8 @@ int cmgan_profile_read(cmgan_handle* h, cmgan_kernel_time* out, int cap);
  *                              encoder's stride-2 conv and the decoders' sub-pixel conv on split-f16 products (1, default)
  *                              or the fp32-MFMA row-conv kernels (0)
  *   CMGAN_ATTN_BWD=cores       training: the three attention backward cores instead of the fused kernel (read per launch)
+ *   CMGAN_ATF_SLOTS_SHORT=1|2  training: wrapped diagonals per wave of the fused attention backward at L <= 128 (2, default:
+ *                              4-wave blocks, three per CU; 1: 7-wave blocks, one per CU)
  * (The Python host adds CMGAN_BRANCHES=1|2 and CMGAN_BRANCH_OFFSET=n for Engine.enhance_graphed; CMGAN_HIP_LIB selects
  * the library file.)                                                                                                  */
 
